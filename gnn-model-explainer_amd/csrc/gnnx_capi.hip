@@ -1,0 +1,388 @@
+// gnnx_capi.hip — C ABI (include/gnnx.h) over the gfx950 kernels of gnnx_kernels.hpp.
+// Host side only: plan (tile tables, packed model block), workspace carving, the launch sequence of
+// one mask-optimisation job and its optional hipGraph capture.  No compute happens on the host.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gnnx.h"
+#include "gnnx_kernels.hpp"
+
+using namespace gnnx;
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) {
+    g_err = m;
+    return 1;
+}
+#define HIPCK(x)                                                                                   \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(std::string(#x) + ": " + hipGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
+    } while (0)
+
+static_assert(GNNX_FEAT_STRIDE == FS && GNNX_MAX_CLASSES == CMAX && GNNX_LOSS_TERMS == NLOSS, "header mismatch");
+
+struct GraphKey {
+    const void *A, *X, *yhat, *M, *Abar, *fm, *loss, *ws;
+    gnnx_hyper hy;
+    bool operator==(const GraphKey& o) const { return std::memcmp(this, &o, sizeof(GraphKey)) == 0; }
+};
+
+struct gnnx_plan_s {
+    gnnx_problem prob{};
+    std::vector<TargetMeta> meta;
+    int64_t Q = 0, R = 0;
+    int n_conv = 0, n_mask = 0;
+    TargetMeta* d_meta = nullptr;
+    ConvTile* d_conv = nullptr;
+    MaskTile* d_mask = nullptr;
+    float* d_wts = nullptr;
+    double sum_n2 = 0;
+    // workspace offsets in bytes
+    size_t o_mM, o_vM, o_XT, o_U[3], o_UT[3], o_rn[3], o_dZ[3], o_dZT[3], o_dE, o_arg, o_df, o_f[2], o_mf, o_vf,
+        o_probs, ws_bytes;
+    hipGraphExec_t gexec = nullptr;
+    GraphKey gkey{};
+};
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+extern "C" const char* gnnx_last_error(void) { return g_err.c_str(); }
+extern "C" const char* gnnx_version(void) { return "gnnx-hip 0.1 (gfx950, mfma_f32_32x32x2f32)"; }
+
+extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* model, gnnx_handle* out) {
+    if (!prob || !model || !out) return fail("null argument");
+    if (prob->num_targets <= 0) return fail("num_targets must be positive");
+    if (prob->D < 1 || prob->D > FS || prob->H < 1 || prob->H > FS || prob->O < 1 || prob->O > FS)
+        return fail("D, H, O must be in [1, 32] for the 32-wide MFMA feature tile");
+    if (prob->C < 1 || prob->C > CMAX) return fail("C must be in [1, 32]");
+    auto* h = new gnnx_plan_s();
+    h->prob = *prob;
+    const int T = prob->num_targets;
+    h->meta.resize(T);
+    std::vector<ConvTile> conv;
+    std::vector<MaskTile> mask;
+    for (int t = 0; t < T; ++t) {
+        const int n = prob->n[t];
+        if (n < 1) {
+            delete h;
+            return fail("empty sub-graph (n < 1) for target " + std::to_string(t));
+        }
+        TargetMeta& m = h->meta[t];
+        m.n = n;
+        m.ld = (n + TILE - 1) / TILE * TILE;
+        m.t = prob->graph_mode ? 0 : prob->target_row[t];
+        m.y_gt = prob->gt_label[t];
+        if (!prob->graph_mode && (m.t < 0 || m.t >= n)) {
+            delete h;
+            return fail("target_row out of range for target " + std::to_string(t));
+        }
+        if (m.y_gt < 0 || m.y_gt >= prob->C) {
+            delete h;
+            return fail("gt_label out of range for target " + std::to_string(t));
+        }
+        m.offQ = h->Q;
+        m.offR = h->R;
+        h->Q += (int64_t)m.ld * m.ld;
+        h->R += m.ld;
+        h->sum_n2 += (double)n * n;
+    }
+    // tile tables, largest targets first so the long poles start early
+    std::vector<int> order(T);
+    for (int t = 0; t < T; ++t) order[t] = t;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h->meta[a].ld > h->meta[b].ld; });
+    for (int t : order) {
+        const int nb = h->meta[t].ld / TILE;
+        for (int rb = 0; rb < nb; ++rb) conv.push_back({t, rb});
+        for (int I = 0; I < nb; ++I)
+            for (int J = I; J < nb; ++J) mask.push_back({t, I, J, 0});
+    }
+    h->n_conv = (int)conv.size();
+    h->n_mask = (int)mask.size();
+
+    // packed, zero padded model block
+    std::vector<float> w(WT_TOTAL, 0.0f);
+    const int din[3] = {prob->D, prob->H, prob->H}, dout[3] = {prob->H, prob->H, prob->O};
+    for (int l = 0; l < 3; ++l) {
+        for (int k = 0; k < din[l]; ++k)
+            for (int c = 0; c < dout[l]; ++c) w[WT_W + l * 1024 + k * 32 + c] = model->W[l][k * dout[l] + c];
+        for (int c = 0; c < dout[l]; ++c) w[WT_B + l * 32 + c] = model->b[l] ? model->b[l][c] : 0.0f;
+    }
+    const int E = prob->H + prob->H + prob->O;
+    const int eoff[3] = {0, prob->H, 2 * prob->H};
+    for (int c = 0; c < prob->C; ++c) {
+        for (int l = 0; l < 3; ++l)
+            for (int j = 0; j < dout[l]; ++j) w[WT_WP + c * 96 + l * 32 + j] = model->Wp[c * E + eoff[l] + j];
+        w[WT_BP + c] = model->bp[c];
+    }
+
+#define PLANCK(x)                                                                                      \
+    do {                                                                                               \
+        hipError_t e_ = (x);                                                                           \
+        if (e_ != hipSuccess) {                                                                        \
+            gnnx_destroy(h);                                                                           \
+            return fail(std::string(#x) + ": " + hipGetErrorString(e_));                               \
+        }                                                                                              \
+    } while (0)
+    PLANCK(hipMalloc(&h->d_meta, sizeof(TargetMeta) * T));
+    PLANCK(hipMalloc(&h->d_conv, sizeof(ConvTile) * conv.size()));
+    PLANCK(hipMalloc(&h->d_mask, sizeof(MaskTile) * mask.size()));
+    PLANCK(hipMalloc(&h->d_wts, sizeof(float) * WT_TOTAL));
+    PLANCK(hipMemcpy(h->d_meta, h->meta.data(), sizeof(TargetMeta) * T, hipMemcpyHostToDevice));
+    PLANCK(hipMemcpy(h->d_conv, conv.data(), sizeof(ConvTile) * conv.size(), hipMemcpyHostToDevice));
+    PLANCK(hipMemcpy(h->d_mask, mask.data(), sizeof(MaskTile) * mask.size(), hipMemcpyHostToDevice));
+    PLANCK(hipMemcpy(h->d_wts, w.data(), sizeof(float) * WT_TOTAL, hipMemcpyHostToDevice));
+#undef PLANCK
+
+    // workspace carving
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t r = o;
+        o = align_up(o + bytes, 256);
+        return r;
+    };
+    const size_t qb = sizeof(float) * (size_t)h->Q, rb32 = sizeof(float) * (size_t)h->R * FS, rb1 = sizeof(float) * (size_t)h->R;
+    h->o_mM = take(qb);
+    h->o_vM = take(qb);
+    h->o_XT = take(rb32);
+    for (int l = 0; l < 3; ++l) {
+        h->o_U[l] = take(rb32);
+        h->o_UT[l] = take(rb32);
+        h->o_rn[l] = take(rb1);
+        h->o_dZ[l] = take(rb32);
+        h->o_dZT[l] = take(rb32);
+    }
+    h->o_dE = take(sizeof(float) * T * 96);
+    h->o_arg = take(sizeof(int32_t) * T * 96);
+    h->o_df = take(sizeof(float) * T * FS);
+    h->o_f[0] = take(sizeof(float) * T * FS);
+    h->o_f[1] = take(sizeof(float) * T * FS);
+    h->o_mf = take(sizeof(float) * T * FS);
+    h->o_vf = take(sizeof(float) * T * FS);
+    h->o_probs = take(sizeof(float) * T * CMAX);
+    h->ws_bytes = o;
+    *out = h;
+    return 0;
+}
+
+extern "C" int gnnx_destroy(gnnx_handle h) {
+    if (!h) return 0;
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    if (h->d_meta) (void)hipFree(h->d_meta);
+    if (h->d_conv) (void)hipFree(h->d_conv);
+    if (h->d_mask) (void)hipFree(h->d_mask);
+    if (h->d_wts) (void)hipFree(h->d_wts);
+    delete h;
+    return 0;
+}
+
+extern "C" int64_t gnnx_total_q(gnnx_handle h) { return h ? h->Q : -1; }
+extern "C" int64_t gnnx_total_rows(gnnx_handle h) { return h ? h->R : -1; }
+extern "C" size_t gnnx_workspace_bytes(gnnx_handle h) { return h ? h->ws_bytes : 0; }
+
+extern "C" int gnnx_get_layout(gnnx_handle h, int32_t* ld, int64_t* offQ, int64_t* offR) {
+    if (!h) return fail("null plan");
+    for (size_t t = 0; t < h->meta.size(); ++t) {
+        if (ld) ld[t] = h->meta[t].ld;
+        if (offQ) offQ[t] = h->meta[t].offQ;
+        if (offR) offR[t] = h->meta[t].offR;
+    }
+    return 0;
+}
+
+static Params make_params(gnnx_handle h, const gnnx_hyper* hy, const float* A, const float* X, const float* yhat,
+                          float* M, float* Abar, float* loss, void* ws) {
+    Params p{};
+    char* w = static_cast<char*>(ws);
+    p.meta = h->d_meta;
+    p.A = A;
+    p.M = M;
+    p.mM = reinterpret_cast<float*>(w + h->o_mM);
+    p.vM = reinterpret_cast<float*>(w + h->o_vM);
+    p.Abar = Abar;
+    p.X = X;
+    p.XT = reinterpret_cast<float*>(w + h->o_XT);
+    p.yhat = yhat;
+    for (int l = 0; l < 3; ++l) {
+        p.U[l] = reinterpret_cast<float*>(w + h->o_U[l]);
+        p.UT[l] = reinterpret_cast<float*>(w + h->o_UT[l]);
+        p.rn[l] = reinterpret_cast<float*>(w + h->o_rn[l]);
+        p.dZ[l] = reinterpret_cast<float*>(w + h->o_dZ[l]);
+        p.dZT[l] = reinterpret_cast<float*>(w + h->o_dZT[l]);
+    }
+    p.dE = reinterpret_cast<float*>(w + h->o_dE);
+    p.argrow = reinterpret_cast<int32_t*>(w + h->o_arg);
+    p.df = reinterpret_cast<float*>(w + h->o_df);
+    p.f[0] = reinterpret_cast<float*>(w + h->o_f[0]);
+    p.f[1] = reinterpret_cast<float*>(w + h->o_f[1]);
+    p.mf = reinterpret_cast<float*>(w + h->o_mf);
+    p.vf = reinterpret_cast<float*>(w + h->o_vf);
+    p.probs = reinterpret_cast<float*>(w + h->o_probs);
+    p.loss = loss;
+    p.wts = h->d_wts;
+    p.D = h->prob.D;
+    p.H = h->prob.H;
+    p.O = h->prob.O;
+    p.C = h->prob.C;
+    p.graph_mode = h->prob.graph_mode;
+    if (hy) {
+        p.num_iters = hy->num_iters;
+        p.lr = hy->lr;
+        p.beta1 = hy->beta1;
+        p.beta2 = hy->beta2;
+        p.eps = hy->eps;
+        p.c_size = hy->c_size;
+        p.c_feat_size = hy->c_feat_size;
+        p.c_ent = hy->c_ent;
+        p.c_lap = hy->c_lap;
+    }
+    return p;
+}
+
+static void adam_scalars(const gnnx_hyper* hy, int it, float* step_size, float* bc2s) {
+    const double b1 = 1.0 - std::pow((double)hy->beta1, (double)(it + 1));
+    const double b2 = 1.0 - std::pow((double)hy->beta2, (double)(it + 1));
+    *step_size = (float)((double)hy->lr / b1);
+    *bc2s = (float)std::sqrt(b2);
+}
+
+template <int MODE>
+static void launch_conv(gnnx_handle h, const Params& p, int it, hipStream_t s) {
+    hipLaunchKernelGGL((k_conv<MODE>), dim3(h->n_conv), dim3(256), 0, s, p, h->d_conv, it);
+}
+
+static void launch_forward(gnnx_handle h, const Params& p, int it, hipStream_t s) {
+    launch_conv<FWD1>(h, p, it, s);
+    launch_conv<FWD2>(h, p, it, s);
+    launch_conv<FWD3>(h, p, it, s);
+    hipLaunchKernelGGL(k_head, dim3(h->prob.num_targets), dim3(256), 0, s, p, it);
+}
+
+// the whole job, stream-ordered: usable directly or under stream capture
+static int enqueue_job(gnnx_handle h, const gnnx_hyper* hy, const Params& p, float* feat_mask, hipStream_t s) {
+    const int T = h->prob.num_targets;
+    HIPCK(hipMemsetAsync(p.mM, 0, sizeof(float) * (size_t)h->Q, s));
+    HIPCK(hipMemsetAsync(p.vM, 0, sizeof(float) * (size_t)h->Q, s));
+    if (p.loss) HIPCK(hipMemsetAsync(p.loss, 0, sizeof(float) * (size_t)T * hy->num_iters * NLOSS, s));
+    hipLaunchKernelGGL(k_prep, dim3(T), dim3(256), 0, s, p, (const float*)nullptr);
+    hipLaunchKernelGGL((k_mask<false, true>), dim3(h->n_mask), dim3(64), 0, s, p, h->d_mask, 0, 0.0f, 1.0f);
+    for (int it = 0; it < hy->num_iters; ++it) {
+        launch_forward(h, p, it, s);
+        launch_conv<BWD3>(h, p, it, s);
+        launch_conv<BWD2>(h, p, it, s);
+        launch_conv<BWD1>(h, p, it, s);
+        launch_conv<BWD0>(h, p, it, s);
+        float ss, b2;
+        adam_scalars(hy, it, &ss, &b2);
+        if (it + 1 < hy->num_iters)
+            hipLaunchKernelGGL((k_mask<true, true>), dim3(h->n_mask), dim3(64), 0, s, p, h->d_mask, it, ss, b2);
+        else
+            hipLaunchKernelGGL((k_mask<true, false>), dim3(h->n_mask), dim3(64), 0, s, p, h->d_mask, it, ss, b2);
+    }
+    if (feat_mask)
+        HIPCK(hipMemcpyAsync(feat_mask, p.f[hy->num_iters & 1], sizeof(float) * T * FS, hipMemcpyDeviceToDevice, s));
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, const float* X, const float* yhat,
+                        float* M, float* Abar, float* feat_mask, float* loss, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+    if (!h || !hy || !A || !X || !M || !Abar || !workspace) return fail("null argument");
+    if (!h->prob.graph_mode && !yhat) return fail("yhat is required in node mode (Laplacian term)");
+    if (workspace_bytes < h->ws_bytes) return fail("workspace too small");
+    if (hy->num_iters < 1) return fail("num_iters must be >= 1");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* lossp = hy->record_loss ? loss : nullptr;
+    if (hy->record_loss && !loss) return fail("record_loss set but loss buffer is null");
+    Params p = make_params(h, hy, A, X, yhat, M, Abar, lossp, workspace);
+    if (!hy->use_graph) return enqueue_job(h, hy, p, feat_mask, s);
+
+    GraphKey key{A, X, yhat, M, Abar, feat_mask, lossp, workspace, *hy};
+    if (!h->gexec || !(key == h->gkey)) {
+        if (h->gexec) {
+            (void)hipGraphExecDestroy(h->gexec);
+            h->gexec = nullptr;
+        }
+        hipGraph_t g = nullptr;
+        HIPCK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+        int rc = enqueue_job(h, hy, p, feat_mask, s);
+        hipError_t e = hipStreamEndCapture(s, &g);
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        e = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) {
+            h->gexec = nullptr;
+            return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        }
+        h->gkey = key;
+    }
+    HIPCK(hipGraphLaunch(h->gexec, s));
+    return 0;
+}
+
+extern "C" int gnnx_forward(gnnx_handle h, const float* A, const float* X, const float* M, const float* feat_mask_in,
+                            float* Abar, float* probs, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !A || !X || !M || !Abar || !probs || !workspace) return fail("null argument");
+    if (workspace_bytes < h->ws_bytes) return fail("workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Params p = make_params(h, nullptr, A, X, nullptr, const_cast<float*>(M), Abar, nullptr, workspace);
+    p.num_iters = 1;
+    hipLaunchKernelGGL(k_prep, dim3(h->prob.num_targets), dim3(256), 0, s, p, feat_mask_in);
+    hipLaunchKernelGGL((k_mask<false, true>), dim3(h->n_mask), dim3(64), 0, s, p, h->d_mask, 0, 0.0f, 1.0f);
+    launch_forward(h, p, 0, s);
+    HIPCK(hipMemcpyAsync(probs, p.probs, sizeof(float) * h->prob.num_targets * CMAX, hipMemcpyDeviceToDevice, s));
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hy, int32_t kind, int32_t reps, const float* A,
+                                const float* X, const float* yhat, float* M, float* Abar, void* workspace,
+                                size_t workspace_bytes, void* stream, float* ms_avg, double* alg_bytes,
+                                double* alg_flops) {
+    if (!h || !hy || !ms_avg || reps < 1) return fail("bad argument");
+    if (workspace_bytes < h->ws_bytes) return fail("workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Params p = make_params(h, hy, A, X, yhat, M, Abar, nullptr, workspace);
+    hipEvent_t e0, e1;
+    HIPCK(hipEventCreate(&e0));
+    HIPCK(hipEventCreate(&e1));
+    float ss, b2;
+    adam_scalars(hy, 0, &ss, &b2);
+    auto once = [&]() {
+        switch (kind) {
+            case 0: hipLaunchKernelGGL((k_mask<true, true>), dim3(h->n_mask), dim3(64), 0, s, p, h->d_mask, 0, ss, b2); break;
+            case 1: launch_conv<FWD1>(h, p, 0, s); break;
+            case 2: launch_conv<FWD2>(h, p, 0, s); break;
+            case 3: launch_conv<FWD3>(h, p, 0, s); break;
+            case 4: launch_conv<BWD2>(h, p, 0, s); break;
+            case 5: launch_conv<BWD1>(h, p, 0, s); break;
+            default: launch_conv<BWD0>(h, p, 0, s); break;
+        }
+    };
+    once();  // warm
+    HIPCK(hipEventRecord(e0, s));
+    for (int r = 0; r < reps; ++r) once();
+    HIPCK(hipEventRecord(e1, s));
+    HIPCK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_avg = ms / reps;
+    const double kagg = h->prob.D + 2.0 * h->prob.H;
+    if (alg_bytes) *alg_bytes = (kind == 0) ? 28.0 * h->sum_n2 : 4.0 * h->sum_n2;
+    if (alg_flops) {
+        const double d = (kind == 1 || kind == 6) ? h->prob.D : h->prob.H;
+        *alg_flops = (kind == 0) ? 2.0 * h->sum_n2 * kagg : 2.0 * h->sum_n2 * d;
+    }
+    HIPCK(hipGetLastError());
+    return 0;
+}

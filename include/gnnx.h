@@ -1,0 +1,110 @@
+/* gnnx.h — C ABI of the MI355X-native GNNExplainer mask-optimisation engine (libgnnx_hip.so).
+ *
+ * The reference (RexYing/gnn-model-explainer) has no FFI: its boundary for this path is the
+ * Python class API of explainer/explain.py.  These entry points are what a ctypes binding
+ * behind that API calls; each cites the reference code it replaces.
+ * Paths are relative to the reference root.
+ *
+ * Conventions: plain C, no torch types.  Every device buffer is owned by the caller (PyTorch);
+ * the library allocates only its small per-plan tables at gnnx_plan_create and nothing in
+ * gnnx_run.  gnnx_run is asynchronous on the given hipStream_t.  Return 0 = ok, non-zero =
+ * error with text in gnnx_last_error().  One plan per device, not thread-safe.
+ *
+ * Packed layout ("segmented over targets"):
+ *   target t has n_t sub-graph nodes, ld_t = round_up(n_t, 32);
+ *   square arrays (A, M, Abar)  : ld_t x ld_t floats at float offset offQ[t], row-major, zero padded;
+ *   row arrays (X, feature-like): ld_t rows x 32 floats at row offset offR[t], zero padded;
+ *   yhat (predicted class id of every sub-graph node, as float): one float per row.
+ */
+#ifndef GNNX_H
+#define GNNX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNNX_FEAT_STRIDE 32 /* floats per row of row arrays; D, H, O <= 32 */
+#define GNNX_MAX_CLASSES 32
+#define GNNX_LOSS_TERMS 8   /* per (target, iteration): pred, size, lap, ent, feat_size, 3 spare */
+
+typedef struct gnnx_plan_s* gnnx_handle;
+
+/* Which sub-graphs are optimised in one batched job.  Replaces the per-target Python setup of
+ * Explainer.explain (explainer/explain.py:80-117) for a whole list of targets
+ * (explain_nodes :234-236, explain_nodes_gnn_stats :296-299, explain_graphs :362-363). */
+typedef struct {
+    int32_t num_targets;
+    const int32_t* n;          /* host [T] sub-graph sizes (extract_neighborhood, explain.py:492-501) */
+    const int32_t* target_row; /* host [T] node_idx_new (explain.py:496); ignored in graph mode */
+    const int32_t* gt_label;   /* host [T] label used by the prediction loss (explain.py:750-753) */
+    int32_t D, H, O, C;        /* input dim, hidden dim, embedding dim, classes (models.py:83-132) */
+    int32_t graph_mode;        /* 0: GcnEncoderNode head (models.py:363-376); 1: GcnEncoderGraph max-pool head (models.py:269-316) */
+} gnnx_problem;
+
+/* Frozen encoder parameters, HOST pointers in the reference state_dict layouts:
+ * conv_first/conv_block.0/conv_last .weight [d_in, d_out] and .bias [d_out] (models.py:31-52),
+ * pred_model.weight [C, H+H+O], pred_model.bias [C] (models.py:198). */
+typedef struct {
+    const float* W[3];
+    const float* b[3];
+    const float* Wp;
+    const float* bp;
+} gnnx_model;
+
+/* Optimiser + regulariser constants: Adam of utils/train_utils.py:9-10 (torch defaults) and
+ * ExplainModule.coeffs (explain.py:624-631). */
+typedef struct {
+    float lr, beta1, beta2, eps;
+    float c_size, c_feat_size, c_ent, c_lap;
+    int32_t num_iters;   /* args.num_epochs (explain.py:137) */
+    int32_t record_loss; /* 1: fill loss[T][num_iters][GNNX_LOSS_TERMS] (explain.py:808-819 scalars) */
+    int32_t use_graph;   /* 1: capture the launch sequence once into a hipGraph and replay it */
+} gnnx_hyper;
+
+int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* model, gnnx_handle* out);
+int gnnx_destroy(gnnx_handle h);
+
+/* Layout the caller packs into. ld/offQ/offR are host arrays of num_targets entries. */
+int64_t gnnx_total_q(gnnx_handle h);    /* floats in each square array */
+int64_t gnnx_total_rows(gnnx_handle h); /* rows in each row array */
+int gnnx_get_layout(gnnx_handle h, int32_t* ld, int64_t* offQ, int64_t* offR);
+size_t gnnx_workspace_bytes(gnnx_handle h);
+
+/* The hot loop: num_iters x {masked adjacency, 3-layer GCN forward, loss, analytic backward through the
+ * mask, Adam on edge mask + feature mask} for every target of the plan (explain.py:137-146 with
+ * ExplainModule.forward :685-715, .loss :740-820, loss.backward :142, optimizer.step :144).
+ *   A, X, yhat : device inputs in the packed layout (read-only)
+ *   M          : device in/out; in = initial edge mask M0 (construct_edge_mask, explain.py:645-663),
+ *                out = mask after num_iters Adam steps (ExplainModule.mask)
+ *   Abar       : device out; masked adjacency of the LAST forward, i.e. after num_iters-1 steps
+ *                (ExplainModule.masked_adj consumed at explain.py:209-211)
+ *   feat_mask  : device out [T][32]; feature-mask parameter after num_iters steps (ExplainModule.feat_mask)
+ *   loss       : device out [T][num_iters][GNNX_LOSS_TERMS] or NULL
+ *   workspace  : device scratch of gnnx_workspace_bytes(h) bytes
+ *   stream     : hipStream_t */
+int gnnx_run(gnnx_handle h, const gnnx_hyper* hyper, const float* A, const float* X, const float* yhat,
+             float* M, float* Abar, float* feat_mask, float* loss, void* workspace, size_t workspace_bytes,
+             void* stream);
+
+/* One forward only (no update): fills Abar from M and returns softmax probabilities of the head,
+ * probs device out [T][GNNX_MAX_CLASSES] (ExplainModule.forward, explain.py:685-715). */
+int gnnx_forward(gnnx_handle h, const float* A, const float* X, const float* M, const float* feat_mask_in,
+                 float* Abar, float* probs, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Measurement hook for bench.py: relaunch one kernel class `reps` times on the current workspace
+ * state between two hipEvents on `stream`; returns the average launch duration in milliseconds and
+ * the algorithmic bytes / flops of one launch.  kind: 0 = fused mask/regulariser/Adam kernel,
+ * 1..3 = forward contraction layer 1..3, 4..6 = backward contraction. */
+int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hyper, int32_t kind, int32_t reps, const float* A,
+                     const float* X, const float* yhat, float* M, float* Abar, void* workspace,
+                     size_t workspace_bytes, void* stream, float* ms_avg, double* alg_bytes, double* alg_flops);
+
+const char* gnnx_last_error(void);
+const char* gnnx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNX_H */

@@ -1,0 +1,216 @@
+"""ORACLE (test infrastructure, never shipped, never on the product path).
+
+Closed-form fp32 NumPy restatement of ONE mask-optimisation iteration: forward,
+analytic backward and Adam.  This is the stage-by-stage specification the HIP
+kernels implement; every intermediate the kernels write to
+HBM is exposed so each kernel can be unit-tested against its own stage.
+
+It is pinned against the reference through `oracle/reference_restatement.py`
+(torch autograd, bit-identical to /root/reference on the golden fixtures):
+tests/test_oracle_closed_form.py requires the two to agree to fp32 round-off.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import this module.
+
+Reference lines restated (relative to /root/reference):
+  explainer/explain.py:665-678 (masked adjacency), :685-715 (forward), :740-808 (loss),
+  models.py:58-80, 230-267, 269-316, 363-376 (encoder), torch.optim.Adam via
+  utils/train_utils.py:9-10 (lr, betas (0.9, 0.999), eps 1e-8, no weight decay).
+"""
+import numpy as np
+
+F32 = np.float32
+C_SIZE, C_FEAT_SIZE, C_ENT, C_LAP = F32(0.005), F32(1.0), F32(1.0), F32(1.0)
+BETA1, BETA2, EPS = 0.9, 0.999, 1e-8
+NORM_EPS = F32(1e-12)   # F.normalize eps
+
+
+def sigmoid(x):
+    x = x.astype(F32)
+    return (F32(1) / (F32(1) + np.exp(-x, dtype=F32))).astype(F32)
+
+
+class Weights:
+    """fp32 copies of the encoder parameters (state_dict names of models.py)."""
+
+    def __init__(self, sd):
+        g = lambda k: np.ascontiguousarray(np.asarray(sd[k], dtype=F32))
+        self.W = [g("conv_first.weight"), g("conv_block.0.weight"), g("conv_last.weight")]
+        self.b = [g("conv_first.bias"), g("conv_block.0.bias"), g("conv_last.bias")]
+        self.Wp = g("pred_model.weight")   # [C, H+H+O]
+        self.bp = g("pred_model.bias")
+
+
+def masked_adj(M, A):
+    """Abar = A * (sigma(M) + sigma(M)^T)/2 with zero diagonal; also returns S = sigma(M)."""
+    S = sigmoid(M)
+    T = (S + S.T) / F32(2)
+    Abar = (A * T).astype(F32)
+    np.fill_diagonal(Abar, 0)
+    return Abar, S
+
+
+def forward(Abar, X0, wts):
+    """3 GraphConv layers. Returns per-layer (U_l = normalised pre-activation, r_l = row norm)."""
+    U, R, Xin = [], [], [X0]
+    x = X0
+    for l in range(3):
+        z = (Abar @ x).astype(F32)
+        y = (z @ wts.W[l] + wts.b[l]).astype(F32)
+        r = np.maximum(np.sqrt((y * y).sum(1, dtype=F32)), NORM_EPS).astype(F32)
+        u = (y / r[:, None]).astype(F32)
+        U.append(u)
+        R.append(r)
+        x = np.maximum(u, 0) if l < 2 else u
+        if l < 2:
+            Xin.append(x)
+    return U, R, Xin   # Xin = [X0, X1, X2] (inputs of the three layers)
+
+
+def head_node(U, wts, t, y_gt):
+    """Logits/softmax of row t, -log p[y_gt], and the direct gradient dE[t] (length H+H+O)."""
+    e = np.concatenate([np.maximum(U[0][t], 0), np.maximum(U[1][t], 0), U[2][t]]).astype(F32)
+    z = (wts.Wp @ e + wts.bp).astype(F32)
+    z = z - z.max()
+    p = np.exp(z, dtype=F32)
+    p = (p / p.sum(dtype=F32)).astype(F32)
+    g = p.copy()
+    g[y_gt] -= F32(1)
+    dE = (wts.Wp.T @ g).astype(F32)
+    return p, F32(-np.log(p[y_gt])), dE
+
+
+def head_graph(U, wts, y_gt):
+    """Graph mode: per-layer column-wise max over ALL rows (padded rows included)."""
+    n = U[0].shape[0]
+    acts = [np.maximum(U[0], 0), np.maximum(U[1], 0), U[2]]
+    arg = [a.argmax(0) for a in acts]
+    e = np.concatenate([a.max(0) for a in acts]).astype(F32)
+    z = (wts.Wp @ e + wts.bp).astype(F32)
+    z = z - z.max()
+    p = np.exp(z, dtype=F32)
+    p = (p / p.sum(dtype=F32)).astype(F32)
+    g = p.copy()
+    g[y_gt] -= F32(1)
+    dE = (wts.Wp.T @ g).astype(F32)
+    return p, F32(-np.log(p[y_gt])), dE, arg
+
+
+def direct_grads(dE, n, dims, rows):
+    """Scatter dE (concat of 3 layer slices) to dense [n, d_l] 'direct' gradients.
+    rows: node mode -> int t (all columns go to row t); graph mode -> list of 3 argmax index arrays."""
+    out, off = [], 0
+    for l, d in enumerate(dims):
+        g = np.zeros((n, d), F32)
+        if np.isscalar(rows) or isinstance(rows, (int, np.integer)):
+            g[rows, :] = dE[off:off + d]
+        else:
+            g[rows[l], np.arange(d)] = dE[off:off + d]
+        out.append(g)
+        off += d
+    return out
+
+
+def backward(Abar, U, R, wts, dXd):
+    """dZ_l for l = 3, 2, 1 (as list index 2, 1, 0) and dX0 = Abar @ dZ_1."""
+    dZ = [None, None, None]
+    dX = dXd[2]
+    for l in (2, 1, 0):
+        dU = dX * (U[l] > 0) if l < 2 else dX
+        dY = ((dU - U[l] * (dU * U[l]).sum(1, dtype=F32)[:, None]) / R[l][:, None]).astype(F32)
+        dZ[l] = (dY @ wts.W[l].T).astype(F32)
+        dX = (Abar @ dZ[l]).astype(F32)      # Abar is symmetric
+        if l > 0:
+            dX = dX + dXd[l - 1]
+    return dZ, dX     # dX is dL/dX0
+
+
+def grad_Abar(dZ, Xin, yhat, n, node_mode):
+    """G = dL/dAbar = [dZ1|dZ2|dZ3] [X0|X1|X2]^T (+ Laplacian term in node mode)."""
+    G = (np.concatenate(dZ, 1) @ np.concatenate(Xin, 1).T).astype(F32)
+    if node_mode:
+        y = yhat.astype(F32)
+        G = G + ((y[None, :] ** 2 - y[:, None] * y[None, :]) / F32(n * n)).astype(F32)
+    return G
+
+
+def mask_grad(G, A, S, n):
+    off = F32(1) - np.eye(n, dtype=F32)
+    Gs = (G + G.T) / F32(2)
+    ent = (np.log(F32(1) - S) - np.log(S)) / F32(n * n)
+    return ((Gs * A * off + C_SIZE + C_ENT * ent) * S * (F32(1) - S)).astype(F32)
+
+
+def adam(theta, m, v, g, step, lr):
+    """torch.optim.Adam single-tensor update (fp32 state, scalars in double as torch does)."""
+    m = (m + (g - m) * F32(1 - BETA1)).astype(F32)
+    v = (v * F32(BETA2) + F32(1 - BETA2) * g * g).astype(F32)
+    bc1 = 1.0 - BETA1 ** step
+    bc2_sqrt = (1.0 - BETA2 ** step) ** 0.5
+    denom = (np.sqrt(v) / F32(bc2_sqrt) + F32(EPS)).astype(F32)
+    theta = (theta - F32(lr / bc1) * (m / denom)).astype(F32)
+    return theta, m, v
+
+
+class ClosedFormOracle:
+    """Whole loop for one target; `stages` keeps the last iteration's intermediates."""
+
+    def __init__(self, A, X, sd, gt_label, pred_label, node_idx, M0, graph_mode=False, lr=0.1):
+        self.A = np.asarray(A, F32)
+        self.X = np.asarray(X, F32)
+        self.w = sd if isinstance(sd, Weights) else Weights(sd)
+        self.n, self.D = self.X.shape
+        self.t = int(node_idx)
+        self.y_gt = int(gt_label)
+        self.graph_mode = graph_mode
+        self.yhat = None if graph_mode else np.asarray(pred_label, F32)
+        self.M = np.asarray(M0, F32).copy()
+        self.mM = np.zeros_like(self.M)
+        self.vM = np.zeros_like(self.M)
+        self.f = np.zeros(self.D, F32)
+        self.mf = np.zeros(self.D, F32)
+        self.vf = np.zeros(self.D, F32)
+        self.lr = lr
+        self.step = 0
+        self.stages = {}
+        self.trace = []
+
+    def iterate(self):
+        n, w = self.n, self.w
+        Abar, S = masked_adj(self.M, self.A)
+        phi = sigmoid(self.f)
+        X0 = (self.X * phi).astype(F32)
+        U, R, Xin = forward(Abar, X0, w)
+        dims = [w.W[0].shape[1], w.W[1].shape[1], w.W[2].shape[1]]
+        if self.graph_mode:
+            p, pred_loss, dE, arg = head_graph(U, w, self.y_gt)
+            dXd = direct_grads(dE, n, dims, arg)
+        else:
+            p, pred_loss, dE = head_node(U, w, self.t, self.y_gt)
+            dXd = direct_grads(dE, n, dims, self.t)
+        dZ, dX0 = backward(Abar, U, R, w, dXd)
+        G = grad_Abar(dZ, Xin, self.yhat, n, not self.graph_mode)
+        dM = mask_grad(G, self.A, S, n)
+        df = (((dX0 * self.X).sum(0, dtype=F32) + C_FEAT_SIZE / F32(self.D)) * phi * (F32(1) - phi)).astype(F32)
+        # loss terms (logging parity only)
+        size_l = C_SIZE * S.sum(dtype=F32)
+        ent_l = C_ENT * (-S * np.log(S) - (F32(1) - S) * np.log(F32(1) - S)).mean(dtype=F32)
+        fs_l = C_FEAT_SIZE * phi.mean(dtype=F32)
+        if self.graph_mode:
+            lap_l = F32(0)
+        else:
+            y = self.yhat
+            lap_l = C_LAP * F32((y * y * Abar.sum(0, dtype=F32)).sum(dtype=F32) - y @ Abar @ y) / F32(n * n)
+        loss = pred_loss + size_l + lap_l + ent_l + fs_l
+        self.trace.append((float(loss), float(pred_loss), float(size_l), float(lap_l), float(ent_l), float(fs_l)))
+        self.stages = dict(Abar=Abar, S=S, phi=phi, X0=X0, U=U, R=R, Xin=Xin, p=p, dE=dE, dXd=dXd,
+                           dZ=dZ, dX0=dX0, G=G, dM=dM, df=df)
+        self.step += 1
+        self.M, self.mM, self.vM = adam(self.M, self.mM, self.vM, dM, self.step, self.lr)
+        self.f, self.mf, self.vf = adam(self.f, self.mf, self.vf, df, self.step, self.lr)
+
+    def run(self, num_epochs):
+        for _ in range(num_epochs):
+            self.iterate()
+        # explain.py:209-211: mask of the LAST forward (before the last step) times adj, float64
+        return self.stages["Abar"].astype(np.float64) * self.A.astype(np.float64)
