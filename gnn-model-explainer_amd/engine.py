@@ -1,0 +1,354 @@
+"""ctypes binding of libgnnx_hip.so (include/gnnx.h) + the batched mask-optimisation job.
+
+This is the host side of the hot path: it packs many targets' sub-graphs into the segmented
+device layout, hands raw device pointers and the current HIP stream to the C ABI, and unpacks
+the masks.  PyTorch is used only for device memory and streams.  There is NO CPU fallback: if the
+HIP library is missing or no GPU is visible the constructor raises.
+
+Replaces, for a whole list of targets at once, the body of the reference's
+Explainer.explain (explainer/explain.py:94-146, 208-211) and everything it calls
+(ExplainModule, explain.py:582-820; models.GcnEncoderNode/Graph forward, models.py:230-376;
+torch autograd; torch.optim.Adam via utils/train_utils.py:9-10).
+"""
+import ctypes
+import math
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+FEAT_STRIDE = 32
+MAX_CLASSES = 32
+LOSS_TERMS = 8
+_DEVICE_TYPE = "cuda"          # PyTorch-ROCm exposes HIP devices as "cuda"
+_LIB_NAME = "libgnnx_hip.so"
+
+
+class _Problem(ctypes.Structure):
+    _fields_ = [("num_targets", ctypes.c_int32), ("n", ctypes.POINTER(ctypes.c_int32)),
+                ("target_row", ctypes.POINTER(ctypes.c_int32)), ("gt_label", ctypes.POINTER(ctypes.c_int32)),
+                ("D", ctypes.c_int32), ("H", ctypes.c_int32), ("O", ctypes.c_int32), ("C", ctypes.c_int32),
+                ("graph_mode", ctypes.c_int32)]
+
+
+class _Model(ctypes.Structure):
+    _fields_ = [("W", ctypes.POINTER(ctypes.c_float) * 3), ("b", ctypes.POINTER(ctypes.c_float) * 3),
+                ("Wp", ctypes.POINTER(ctypes.c_float)), ("bp", ctypes.POINTER(ctypes.c_float))]
+
+
+class _Hyper(ctypes.Structure):
+    _fields_ = [("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
+                ("c_size", ctypes.c_float), ("c_feat_size", ctypes.c_float), ("c_ent", ctypes.c_float),
+                ("c_lap", ctypes.c_float), ("num_iters", ctypes.c_int32), ("record_loss", ctypes.c_int32),
+                ("use_graph", ctypes.c_int32)]
+
+
+@dataclass
+class Hyper:
+    """Adam (utils/train_utils.py:9-10, torch defaults) + ExplainModule.coeffs (explain.py:624-631)."""
+    num_iters: int = 100
+    lr: float = 0.1
+    beta1: float = 0.9
+    beta2: float = 0.999
+    eps: float = 1e-8
+    c_size: float = 0.005
+    c_feat_size: float = 1.0
+    c_ent: float = 1.0
+    c_lap: float = 1.0
+    record_loss: bool = False
+    use_graph: bool = False
+
+    def c(self):
+        return _Hyper(self.lr, self.beta1, self.beta2, self.eps, self.c_size, self.c_feat_size, self.c_ent,
+                      self.c_lap, int(self.num_iters), int(self.record_loss), int(self.use_graph))
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", _LIB_NAME)
+
+
+def _load_hip_library():
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: the HIP extension is not built (run `python __graft_entry__.py` / "
+            "`hipcc --offload-arch=gfx950`). This engine has no CPU fallback.")
+    return ctypes.CDLL(path)
+
+
+_API = {
+    "gnnx_plan_create": (ctypes.c_int, [ctypes.POINTER(_Problem), ctypes.POINTER(_Model), ctypes.POINTER(ctypes.c_void_p)]),
+    "gnnx_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "gnnx_total_q": (ctypes.c_int64, [ctypes.c_void_p]),
+    "gnnx_total_rows": (ctypes.c_int64, [ctypes.c_void_p]),
+    "gnnx_get_layout": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64),
+                                       ctypes.POINTER(ctypes.c_int64)]),
+    "gnnx_workspace_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
+    "gnnx_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper)] + [ctypes.c_void_p] * 8 +
+                 [ctypes.c_size_t, ctypes.c_void_p]),
+    "gnnx_forward": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_void_p] * 7 + [ctypes.c_size_t, ctypes.c_void_p]),
+    "gnnx_time_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper), ctypes.c_int32, ctypes.c_int32] +
+                         [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
+                                                  ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "gnnx_last_error": (ctypes.c_char_p, []),
+    "gnnx_version": (ctypes.c_char_p, []),
+}
+
+
+def bind(lib):
+    for name, (res, args) in _API.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib_cache = None
+
+
+def get_library():
+    global _lib_cache
+    if _lib_cache is None:
+        _lib_cache = bind(_load_hip_library())
+    return _lib_cache
+
+
+class GnnxError(RuntimeError):
+    pass
+
+
+def _check(lib, rc):
+    if rc != 0:
+        raise GnnxError(lib.gnnx_last_error().decode())
+
+
+def _fptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+STATE_KEYS = ("conv_first.weight", "conv_first.bias", "conv_block.0.weight", "conv_block.0.bias",
+              "conv_last.weight", "conv_last.bias", "pred_model.weight", "pred_model.bias")
+
+
+def model_arrays(state_dict):
+    """fp32 host copies of the 3-layer GCN encoder (models.py:114-132 state_dict names)."""
+    extra = [k for k in state_dict if k.startswith("conv_block.") and not k.startswith("conv_block.0.")]
+    if extra:
+        raise NotImplementedError("the HIP path implements num_gc_layers == 3 (one conv_block), got " + str(extra))
+    out = {}
+    for k in STATE_KEYS:
+        if k not in state_dict:
+            raise NotImplementedError(f"state_dict lacks {k}: only bias=True, method='base' encoders are supported")
+        v = state_dict[k]
+        v = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+        out[k] = np.ascontiguousarray(v, dtype=np.float32)
+    return out
+
+
+@dataclass
+class Subgraph:
+    """One target's inputs (what Explainer.explain builds at explain.py:80-106)."""
+    adj: np.ndarray                 # [n, n] symmetric, zero diagonal irrelevant (masked), float
+    feat: np.ndarray                # [n, D]
+    gt_label: int                   # label used by the prediction loss (explain.py:751)
+    target_row: int = 0             # node_idx_new (node mode)
+    pred_label: Optional[np.ndarray] = None   # [n] predicted class ids (node mode, Laplacian term)
+    mask0: Optional[np.ndarray] = None        # [n, n] initial edge mask (explain.py:645-652)
+
+
+@dataclass
+class JobResult:
+    masked_adj: List[np.ndarray]    # per target [n, n] float32: sigma-symmetrised mask * adj of the last forward
+    mask: List[np.ndarray]          # per target [n, n] final mask parameter
+    feat_mask: np.ndarray           # [T, D] final feature-mask parameter (pre-sigmoid)
+    loss: Optional[np.ndarray] = None   # [T, iters, LOSS_TERMS]: pred, size, lap, ent, feat_size
+    stats: dict = field(default_factory=dict)
+
+
+class MaskOptimJob:
+    """A batch of targets resident on one GPU: plan + packed device buffers."""
+
+    def __init__(self, subgraphs: Sequence[Subgraph], state_dict, graph_mode=False, device=None, lib=None):
+        self.lib = lib if lib is not None else get_library()
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("no HIP device visible: the gnnx engine runs on MI355X only (no CPU fallback)")
+            device = torch.device(_DEVICE_TYPE, torch.cuda.current_device())
+        self.device = torch.device(device)
+        self.graph_mode = bool(graph_mode)
+        self.w = model_arrays(state_dict)
+        self.D, self.H = self.w["conv_first.weight"].shape
+        self.O = self.w["conv_last.weight"].shape[1]
+        self.C = self.w["pred_model.weight"].shape[0]
+        if self.w["conv_block.0.weight"].shape != (self.H, self.H) or self.w["conv_last.weight"].shape[0] != self.H:
+            raise NotImplementedError("unexpected encoder shapes")
+        if self.w["pred_model.weight"].shape[1] != 2 * self.H + self.O:
+            raise NotImplementedError("only concat=True prediction heads are supported")
+        self.T = len(subgraphs)
+        if self.T == 0:
+            raise ValueError("empty batch")
+        self.n = np.asarray([s.adj.shape[0] for s in subgraphs], np.int32)
+        for s in subgraphs:
+            a = np.asarray(s.adj)
+            if a.shape[0] != a.shape[1] or s.feat.shape != (a.shape[0], self.D):
+                raise ValueError("bad sub-graph shapes")
+            if not np.array_equal(a, a.T):
+                raise NotImplementedError("the HIP path requires a symmetric adjacency (all reference datasets are undirected)")
+        rows = np.asarray([0 if graph_mode else s.target_row for s in subgraphs], np.int32)
+        labels = np.asarray([s.gt_label for s in subgraphs], np.int32)
+        prob = _Problem(self.T, self.n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                        rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                        labels.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), self.D, self.H, self.O, self.C,
+                        int(self.graph_mode))
+        mdl = _Model()
+        for l, k in enumerate(("conv_first", "conv_block.0", "conv_last")):
+            mdl.W[l] = _fptr(self.w[k + ".weight"])
+            mdl.b[l] = _fptr(self.w[k + ".bias"])
+        mdl.Wp = _fptr(self.w["pred_model.weight"])
+        mdl.bp = _fptr(self.w["pred_model.bias"])
+        self.handle = ctypes.c_void_p()
+        _check(self.lib, self.lib.gnnx_plan_create(ctypes.byref(prob), ctypes.byref(mdl), ctypes.byref(self.handle)))
+        self.Q = int(self.lib.gnnx_total_q(self.handle))
+        self.R = int(self.lib.gnnx_total_rows(self.handle))
+        self.ld = np.zeros(self.T, np.int32)
+        self.offQ = np.zeros(self.T, np.int64)
+        self.offR = np.zeros(self.T, np.int64)
+        _check(self.lib, self.lib.gnnx_get_layout(self.handle, self.ld.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                                  self.offQ.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                                  self.offR.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
+        self.ws_bytes = int(self.lib.gnnx_workspace_bytes(self.handle))
+        self._pack(subgraphs)
+
+    # -- packing -------------------------------------------------------------------------------
+    def _square_views(self, flat):
+        return [flat[o:o + l * l].reshape(l, l) for o, l in zip(self.offQ, self.ld)]
+
+    def _pack(self, subgraphs):
+        A = np.zeros(self.Q, np.float32)
+        X = np.zeros((self.R, FEAT_STRIDE), np.float32)
+        yhat = np.zeros(self.R, np.float32)
+        for s, v, r, n in zip(subgraphs, self._square_views(A), self.offR, self.n):
+            v[:n, :n] = s.adj
+            X[r:r + n, :self.D] = s.feat
+            if not self.graph_mode:
+                if s.pred_label is None:
+                    raise ValueError("node mode needs pred_label for the Laplacian term (explain.py:780-793)")
+                yhat[r:r + n] = s.pred_label
+        dev = self.device
+        self.A = torch.from_numpy(A).to(dev)
+        self.X = torch.from_numpy(X).to(dev)
+        self.yhat = torch.from_numpy(yhat).to(dev)
+        self.M = torch.empty(self.Q, dtype=torch.float32, device=dev)
+        self.Abar = torch.empty(self.Q, dtype=torch.float32, device=dev)
+        self.fmask = torch.empty(self.T, FEAT_STRIDE, dtype=torch.float32, device=dev)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        self.loss = None
+        # the job owns a non-default stream: hipGraph capture is illegal on the legacy default stream
+        self.stream = torch.cuda.Stream(dev) if dev.type == _DEVICE_TYPE else None
+
+    def set_masks(self, masks: Sequence[np.ndarray]):
+        """Upload the initial edge masks (host-generated so the torch CPU RNG stream matches the reference)."""
+        M = np.zeros(self.Q, np.float32)
+        for m, v, n in zip(masks, self._square_views(M), self.n):
+            v[:n, :n] = m
+        self.M.copy_(torch.from_numpy(M), non_blocking=False)
+
+    def _stream(self):
+        return ctypes.c_void_p(self.stream.cuda_stream if self.stream is not None else 0)
+
+    def _enter(self):
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def _leave(self):
+        if self.stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    # -- the hot loop --------------------------------------------------------------------------
+    def launch(self, hyper: Hyper):
+        """Enqueue the whole optimisation on the current stream (asynchronous)."""
+        if hyper.record_loss and (self.loss is None or self.loss.shape[1] != hyper.num_iters):
+            self.loss = torch.empty(self.T, hyper.num_iters, LOSS_TERMS, dtype=torch.float32, device=self.device)
+        hy = hyper.c()
+        loss_ptr = self.loss.data_ptr() if hyper.record_loss else None
+        self._enter()
+        _check(self.lib, self.lib.gnnx_run(self.handle, ctypes.byref(hy), self.A.data_ptr(), self.X.data_ptr(),
+                                           self.yhat.data_ptr(), self.M.data_ptr(), self.Abar.data_ptr(),
+                                           self.fmask.data_ptr(), loss_ptr, self.ws.data_ptr(), self.ws_bytes,
+                                           self._stream()))
+        self._leave()
+
+    def fetch(self, hyper: Hyper) -> JobResult:
+        if self.device.type == _DEVICE_TYPE:
+            torch.cuda.synchronize(self.device)
+        Abar = self.Abar.cpu().numpy()
+        M = self.M.cpu().numpy()
+        ma = [v[:n, :n].copy() for v, n in zip(self._square_views(Abar), self.n)]
+        mk = [v[:n, :n].copy() for v, n in zip(self._square_views(M), self.n)]
+        loss = self.loss.cpu().numpy() if hyper.record_loss else None
+        return JobResult(ma, mk, self.fmask.cpu().numpy()[:, :self.D].copy(), loss)
+
+    def run(self, masks, hyper: Hyper) -> JobResult:
+        self.set_masks(masks)
+        self.launch(hyper)
+        return self.fetch(hyper)
+
+    def forward(self, masks, feat_mask=None):
+        """One forward under the given masks: (softmax probs [T, C], masked_adj list). ExplainModule.forward."""
+        self.set_masks(masks)
+        probs = torch.empty(self.T, MAX_CLASSES, dtype=torch.float32, device=self.device)
+        fm = None
+        if feat_mask is not None:
+            f = np.zeros((self.T, FEAT_STRIDE), np.float32)
+            f[:, :self.D] = feat_mask
+            fm = torch.from_numpy(f).to(self.device)
+        self._enter()
+        _check(self.lib, self.lib.gnnx_forward(self.handle, self.A.data_ptr(), self.X.data_ptr(), self.M.data_ptr(),
+                                               fm.data_ptr() if fm is not None else None, self.Abar.data_ptr(),
+                                               probs.data_ptr(), self.ws.data_ptr(), self.ws_bytes, self._stream()))
+        self._leave()
+        if self.device.type == _DEVICE_TYPE:
+            torch.cuda.synchronize(self.device)
+        Abar = self.Abar.cpu().numpy()
+        ma = [v[:n, :n].copy() for v, n in zip(self._square_views(Abar), self.n)]
+        return probs.cpu().numpy()[:, :self.C], ma
+
+    def time_kernel(self, hyper: Hyper, kind: int, reps: int):
+        """(avg ms per launch, algorithmic bytes, algorithmic flops) of one kernel class — bench.py's roofline."""
+        ms = ctypes.c_float()
+        by = ctypes.c_double()
+        fl = ctypes.c_double()
+        hy = hyper.c()
+        self._enter()
+        _check(self.lib, self.lib.gnnx_time_kernel(self.handle, ctypes.byref(hy), kind, reps, self.A.data_ptr(),
+                                                   self.X.data_ptr(), self.yhat.data_ptr(), self.M.data_ptr(),
+                                                   self.Abar.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
+                                                   self._stream(), ctypes.byref(ms), ctypes.byref(by), ctypes.byref(fl)))
+        self._leave()
+        return ms.value, by.value, fl.value
+
+    @property
+    def sum_n2(self):
+        return float((self.n.astype(np.float64) ** 2).sum())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gnnx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def init_edge_mask(n, generator=None):
+    """construct_edge_mask(init_strategy='normal') (explain.py:645-652): ONE normal_(1, std) draw of n*n
+    values from the torch CPU generator, std = gain('relu') * sqrt(2 / (n + n))."""
+    std = math.sqrt(2.0) * math.sqrt(2.0 / (n + n))
+    m = torch.empty(n, n, dtype=torch.float32)
+    m.normal_(1.0, std, generator=generator)
+    return m.numpy()

@@ -128,7 +128,8 @@ class MaskOptimOracle:
             lap = deg - self.masked_adj[-1]
             lap_loss = COEFF_LAP * (self.pred_label_t @ lap @ self.pred_label_t) / self.adj.numel()
         total = pred_loss + size_loss + lap_loss + ent_loss + feat_size_loss
-        terms = (float(pred_loss), float(size_loss), float(lap_loss), float(ent_loss), float(feat_size_loss))
+        terms = tuple(float(v.detach()) if torch.is_tensor(v) else float(v)
+                      for v in (pred_loss, size_loss, lap_loss, ent_loss, feat_size_loss))
         return total, terms
 
     def run(self, num_epochs, record=False):
@@ -141,7 +142,7 @@ class MaskOptimOracle:
             loss.backward()
             self.opt.step()
             if record:
-                trace.append((float(loss),) + terms)
+                trace.append((float(loss.detach()),) + terms)
         out = self.masked_adj[0].detach().numpy() * self.adj[0].numpy().astype(np.float64)
         self.trace = np.asarray(trace, dtype=np.float64)
         return out

@@ -1,0 +1,131 @@
+// TEST INFRASTRUCTURE ONLY — fiber scheduler behind tests/emu/include/hip/hip_runtime.h.
+#include <hip/hip_runtime.h>
+
+emu_uint3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace emu {
+namespace {
+constexpr size_t STACK = 256 * 1024;
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    bool done = false;
+};
+struct WaveSlot {
+    int gen = 0, arrived = 0;
+    float fa[2][64], fb[2][64];
+    int ia[2][64];
+};
+struct Block {
+    std::vector<Fiber> fibers;
+    ucontext_t main;
+    int cur = 0, nthreads = 0;
+    int bar_count = 0, bar_gen = 0;
+    std::vector<WaveSlot> waves;
+    const std::function<void()>* body = nullptr;
+};
+Block* g_blk = nullptr;
+
+void yield() { swapcontext(&g_blk->fibers[g_blk->cur].ctx, &g_blk->main); }
+
+void trampoline() {
+    Block* b = g_blk;
+    (*b->body)();
+    b->fibers[b->cur].done = true;
+    swapcontext(&b->fibers[b->cur].ctx, &b->main);
+}
+
+template <class F>
+void wave_collective(F publish) {
+    Block* b = g_blk;
+    const int tid = b->cur;
+    WaveSlot& w = b->waves[tid >> 6];
+    const int g = w.gen;
+    publish(w, g & 1, tid & 63);
+    const int wsize = std::min(64, b->nthreads - (tid >> 6) * 64);
+    if (++w.arrived == wsize) {
+        w.arrived = 0;
+        w.gen++;
+    } else {
+        while (w.gen == g) yield();
+    }
+}
+}  // namespace
+
+void syncthreads() {
+    Block* b = g_blk;
+    const int g = b->bar_gen;
+    if (++b->bar_count == b->nthreads) {
+        b->bar_count = 0;
+        b->bar_gen++;
+    } else {
+        while (b->bar_gen == g) yield();
+    }
+}
+
+float shfl_xor_f(float v, int mask) {
+    int buf = 0, lane = 0;
+    wave_collective([&](WaveSlot& w, int bf, int ln) { w.fa[bf][ln] = v; buf = bf; lane = ln; });
+    return g_blk->waves[g_blk->cur >> 6].fa[buf][(lane ^ mask) & 63];
+}
+
+int shfl_xor_i(int v, int mask) {
+    int buf = 0, lane = 0;
+    wave_collective([&](WaveSlot& w, int bf, int ln) { w.ia[bf][ln] = v; buf = bf; lane = ln; });
+    return g_blk->waves[g_blk->cur >> 6].ia[buf][(lane ^ mask) & 63];
+}
+
+// v_mfma_f32_32x32x2_f32: A[i][k] from lane i + 32k, B[k][j] from lane j + 32k,
+// D[i][j] in lane j + 32*((i>>2)&1), register (i&3) + 4*(i>>3); k-ordered fma chain.
+f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
+    int buf = 0, lane = 0;
+    wave_collective([&](WaveSlot& w, int bf, int ln) { w.fa[bf][ln] = a; w.fb[bf][ln] = b; buf = bf; lane = ln; });
+    const WaveSlot& w = g_blk->waves[g_blk->cur >> 6];
+    const int j = lane & 31, h = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) acc = std::fmaf(w.fa[buf][i + 32 * k], w.fb[buf][j + 32 * k], acc);
+        c[r] = acc;
+    }
+    return c;
+}
+
+void launch(unsigned grid, unsigned block, const std::function<void()>& body) {
+    static std::vector<char*> stacks;
+    while (stacks.size() < block) stacks.push_back(static_cast<char*>(malloc(STACK)));
+    Block blk;
+    blk.nthreads = (int)block;
+    blk.body = &body;
+    blk.fibers.resize(block);
+    blk.waves.resize((block + 63) / 64);
+    g_blk = &blk;
+    gridDim = {grid, 1, 1};
+    blockDim = {block, 1, 1};
+    for (unsigned bid = 0; bid < grid; ++bid) {
+        blk.bar_count = 0;
+        for (auto& w : blk.waves) w.arrived = 0;
+        for (unsigned t = 0; t < block; ++t) {
+            Fiber& f = blk.fibers[t];
+            f.done = false;
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = stacks[t];
+            f.ctx.uc_stack.ss_size = STACK;
+            f.ctx.uc_link = &blk.main;
+            makecontext(&f.ctx, trampoline, 0);
+        }
+        unsigned ndone = 0;
+        while (ndone < block) {
+            ndone = 0;
+            for (unsigned t = 0; t < block; ++t) {
+                if (blk.fibers[t].done) { ++ndone; continue; }
+                blk.cur = (int)t;
+                threadIdx = {t, 0, 0};
+                blockIdx = {bid, 0, 0};
+                swapcontext(&blk.main, &blk.fibers[t].ctx);
+            }
+        }
+    }
+    g_blk = nullptr;
+}
+}  // namespace emu

@@ -1,0 +1,80 @@
+// TEST INFRASTRUCTURE ONLY — a tiny single-threaded emulator of the HIP constructs used by
+// gnn-model-explainer_amd/csrc (64-lane waves as cooperative fibers, __syncthreads, __shfl_xor,
+// v_mfma_f32_32x32x2_f32 with the gfx950 lane layout, atomicAdd, and malloc-backed "device" memory).
+// It lets `pytest -m "not gpu"` run the REAL kernel and host source on the CPU of the build
+// container, where there is no GPU.  It is never built into, loaded by, or reachable from the
+// product library (libgnnx_hip.so); tests/emu/build_emu.py compiles it into tests/emu/_build/.
+#pragma once
+#include <ucontext.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct emu_uint3 { unsigned x, y, z; };
+extern emu_uint3 threadIdx, blockIdx, blockDim, gridDim;
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorNotSupported = 801 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+enum hipStreamCaptureMode { hipStreamCaptureModeRelaxed };
+typedef void* hipStream_t;
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
+typedef std::chrono::steady_clock::time_point* hipEvent_t;
+
+namespace emu {
+void launch(unsigned grid, unsigned block, const std::function<void()>& body);
+void syncthreads();
+float shfl_xor_f(float v, int mask);
+int shfl_xor_i(int v, int mask);
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+f32x16 mfma_32x32x2(float a, float b, f32x16 c);
+}  // namespace emu
+
+inline void __syncthreads() { emu::syncthreads(); }
+inline float __shfl_xor(float v, int m) { return emu::shfl_xor_f(v, m); }
+inline int __shfl_xor(int v, int m) { return emu::shfl_xor_i(v, m); }
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2((a), (b), (c))
+inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+
+inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "ok" : "emulator: unsupported"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+template <class T> hipError_t hipMalloc(T** p, size_t n) { *p = static_cast<T*>(malloc(n ? n : 1)); return hipSuccess; }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorNotSupported; }
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t*) { return hipErrorNotSupported; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return hipErrorNotSupported; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new std::chrono::steady_clock::time_point(); return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { *e = std::chrono::steady_clock::now(); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(*b - *a).count();
+    return hipSuccess;
+}
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    emu::launch((grid).x, (block).x, [=]() { kernel(__VA_ARGS__); })

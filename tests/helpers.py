@@ -1,0 +1,43 @@
+"""Shared test helpers: load the committed golden fixtures (tests/golden/*.npz)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_ckpt(name):
+    """-> dict(adj [N,N] f32 dense, feat [N,D], label [N], pred [N,C], sd {state_dict name: ndarray})."""
+    z = np.load(os.path.join(GOLDEN, name + "_ckpt.npz"))
+    n = int(z["num_nodes"])
+    adj = np.zeros((n, n), np.float32)
+    e = z["edges"]
+    adj[e[:, 0], e[:, 1]] = 1
+    adj[e[:, 1], e[:, 0]] = 1
+    sd = {k[2:]: z[k] for k in z.files if k.startswith("w:")}
+    return dict(adj=adj, feat=z["feat"], label=z["label"], pred=z["pred"], sd=sd, edges=e, num_nodes=n)
+
+
+def load_explain(name):
+    return np.load(os.path.join(GOLDEN, name + "_explain.npz"))
+
+
+def subgraph(ck, nb):
+    """Dense sub-adjacency / features / labels on the node id list nb (ascending)."""
+    nb = np.asarray(nb)
+    return ck["adj"][np.ix_(nb, nb)], ck["feat"][nb], ck["label"][nb], np.argmax(ck["pred"][nb], axis=1)
+
+
+def seeded_mask0(target, n):
+    """Seed protocol of the golden runs: torch.manual_seed(1000 + target) then one normal_ draw."""
+    import math
+    torch.manual_seed(1000 + int(target))
+    std = math.sqrt(2.0) * math.sqrt(2.0 / (n + n))
+    return torch.empty(n, n).normal_(1.0, std)
+
+
+def dense_from_edges(n, rc, vals):
+    out = np.zeros((n, n), np.float64)
+    out[rc[:, 0], rc[:, 1]] = vals
+    return out

@@ -1,0 +1,127 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (ctypes), against
+(a) the committed golden outputs of the REAL reference and (b) the oracle on seeded inputs.
+Tolerance: 1e-5 absolute on masked_adj and sigma(feat_mask) (fp32, exact-f32 MFMA)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from gnn_model_explainer_amd import engine
+from gnn_model_explainer_amd.engine import Hyper, MaskOptimJob, Subgraph
+from oracle import closed_form
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _sig(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def _node_subgraph(ck, gx, t):
+    nb = gx[f"{t}:neighbors"]
+    A, X, lab, yhat = helpers.subgraph(ck, nb)
+    new = int(gx[f"{t}:node_idx_new"])
+    return Subgraph(A, X, int(lab[new]), new, yhat, helpers.seeded_mask0(t, len(nb)).numpy())
+
+
+def test_library_is_the_hip_build():
+    lib = engine.get_library()
+    assert b"gfx950" in lib.gnnx_version()
+    assert os.path.basename(engine.library_path()) == "libgnnx_hip.so"
+
+
+@pytest.mark.parametrize("name", ["syn1", "syn4"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_golden_reference_outputs_node_mode(name, use_graph):
+    """All golden targets of a dataset as ONE batched job, 300 iterations, vs the reference's own outputs."""
+    ck, gx = helpers.load_ckpt(name), helpers.load_explain(name)
+    targets = [int(t) for t in gx["targets"]]
+    subs = [_node_subgraph(ck, gx, t) for t in targets]
+    job = MaskOptimJob(subs, ck["sd"])
+    hy = Hyper(num_iters=int(gx["epochs"]), record_loss=True, use_graph=use_graph)
+    res = job.run([s.mask0 for s in subs], hy)
+    for i, t in enumerate(targets):
+        rc = gx[f"{t}:edge_rc"]
+        got = res.masked_adj[i][rc[:, 0], rc[:, 1]]
+        err = np.abs(got - gx[f"{t}:masked_adj_edges"]).max()
+        assert err <= TOL, f"{name}/{t} n={len(subs[i].adj)}: masked_adj err {err}"
+        assert np.all(res.masked_adj[i][subs[i].adj == 0] == 0)
+        assert np.array_equal(res.masked_adj[i], res.masked_adj[i].T)
+        ferr = np.abs(_sig(res.feat_mask[i]) - gx[f"{t}:feat_mask_sigmoid"]).max()
+        assert ferr <= TOL, f"{name}/{t}: feat mask err {ferr}"
+        merr = np.abs(res.mask[i][rc[:, 0], rc[:, 1]] - gx[f"{t}:final_mask_edges"]).max()
+        assert merr <= 1e-3, f"{name}/{t}: final mask parameter err {merr}"
+        loss = res.loss[i][:, :5].sum(1)
+        assert np.allclose(loss, gx[f"{t}:loss"], rtol=1e-4, atol=1e-4), f"{name}/{t}: loss trace"
+
+
+def test_golden_reference_outputs_graph_mode():
+    z = np.load(os.path.join(helpers.GOLDEN, "graphmode_explain.npz"))
+    sd = {k[2:]: z[k] for k in z.files if k.startswith("w:")}
+    G = z["adj"].shape[0]
+    subs = [Subgraph(z["adj"][g], z["feat"][g], int(z["label"][g]), 0, None,
+                     helpers.seeded_mask0(g, z["adj"].shape[1]).numpy()) for g in range(G)]
+    job = MaskOptimJob(subs, sd, graph_mode=True)
+    res = job.run([s.mask0 for s in subs], Hyper(num_iters=int(z["epochs"]), record_loss=True))
+    for g in range(G):
+        assert np.abs(res.masked_adj[g] - z[f"{g}:masked_adj"]).max() <= TOL
+        assert np.abs(_sig(res.feat_mask[g]) - z[f"{g}:feat_mask_sigmoid"]).max() <= TOL
+        assert np.allclose(res.loss[g][:, :5].sum(1), z[f"{g}:loss"], rtol=1e-4, atol=1e-4)
+
+
+def test_single_iteration_stages_vs_oracle():
+    """One forward (probabilities + masked adjacency) and one full step on a mid-size target."""
+    ck, gx = helpers.load_ckpt("syn1"), helpers.load_explain("syn1")
+    s = _node_subgraph(ck, gx, 555)
+    job = MaskOptimJob([s], ck["sd"])
+    probs, ma = job.forward([s.mask0])
+    o = closed_form.ClosedFormOracle(s.adj, s.feat, ck["sd"], s.gt_label, s.pred_label, s.target_row, s.mask0)
+    o.iterate()
+    assert np.abs(ma[0] - o.stages["Abar"]).max() < 1e-6
+    assert np.abs(probs[0] - o.stages["p"]).max() < 1e-5
+    res = job.run([s.mask0], Hyper(num_iters=1))
+    assert np.abs(res.mask[0] - o.M).max() < 1e-5
+    assert np.abs(res.feat_mask[0] - o.f).max() < 1e-5
+
+
+def test_ragged_batch_equals_individual_jobs_and_is_deterministic():
+    ck, gx = helpers.load_ckpt("syn1"), helpers.load_explain("syn1")
+    subs = [_node_subgraph(ck, gx, t) for t in (302, 555, 309, 302)]
+    hy = Hyper(num_iters=30)
+    res = MaskOptimJob(subs, ck["sd"]).run([s.mask0 for s in subs], hy)
+    again = MaskOptimJob(subs, ck["sd"]).run([s.mask0 for s in subs], hy)
+    for i, s in enumerate(subs):
+        solo = MaskOptimJob([s], ck["sd"]).run([s.mask0], hy)
+        assert np.array_equal(solo.masked_adj[0], res.masked_adj[i])      # batching must not change any bit
+        assert np.array_equal(again.masked_adj[i], res.masked_adj[i])
+    assert np.array_equal(res.masked_adj[0], res.masked_adj[3])
+
+
+def test_edge_cases_single_node_and_unsupported():
+    ck, _ = helpers.load_ckpt("syn1"), None
+    one = Subgraph(np.zeros((1, 1), np.float32), np.ones((1, 10), np.float32), 0, 0, np.zeros(1), np.ones((1, 1), np.float32))
+    res = MaskOptimJob([one], ck["sd"]).run([one.mask0], Hyper(num_iters=5))
+    assert res.masked_adj[0].shape == (1, 1) and res.masked_adj[0][0, 0] == 0 and np.isfinite(res.mask[0]).all()
+    asym = Subgraph(np.triu(np.ones((4, 4), np.float32), 1), np.ones((4, 10), np.float32), 0, 0, np.zeros(4), None)
+    with pytest.raises(NotImplementedError):
+        MaskOptimJob([asym], ck["sd"])
+
+
+def test_full_size_properties_syn1_all_motif_nodes():
+    """BASELINE config 2 at full size (400 targets): size-independent properties of the output."""
+    from gnn_model_explainer_amd.utils.graph_utils import KHopIndex
+    ck = helpers.load_ckpt("syn1")
+    idx = KHopIndex((ck["num_nodes"], ck["edges"]), 3)
+    subs = []
+    for t in range(300, 700):
+        new, A, nb = idx.extract(t)
+        subs.append(Subgraph(A, ck["feat"][nb], int(ck["label"][t]), new, np.argmax(ck["pred"][nb], 1),
+                             helpers.seeded_mask0(t, len(nb)).numpy()))
+    res = MaskOptimJob(subs, ck["sd"]).run([s.mask0 for s in subs], Hyper(num_iters=300, use_graph=True))
+    for s, ma, fm in zip(subs, res.masked_adj, res.feat_mask):
+        assert np.isfinite(ma).all() and np.isfinite(fm).all()
+        assert ma.min() >= 0 and ma.max() <= 1
+        assert np.array_equal(ma, ma.T) and np.all(ma[s.adj == 0] == 0) and np.all(np.diag(ma) == 0)
