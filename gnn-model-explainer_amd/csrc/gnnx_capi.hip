@@ -160,7 +160,7 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
     }
     h->o_dE = take(sizeof(float) * T * 96);
     h->o_arg = take(sizeof(int32_t) * T * 96);
-    h->o_df = take(sizeof(float) * T * FS);
+    h->o_df = take(rb1);  // (R / 32) row blocks x 32 floats
     h->o_f[0] = take(sizeof(float) * T * FS);
     h->o_f[1] = take(sizeof(float) * T * FS);
     h->o_mf = take(sizeof(float) * T * FS);

@@ -65,7 +65,7 @@ struct Params {
     float* dZT[3];    // same, column-major
     float* dE;        // direct gradient of the concatenated embedding [T][3][32]
     int32_t* argrow;  // row that receives dE[l][c]  [T][3][32]
-    float* df;        // feature-mask gradient accumulator [T][32]
+    float* df;        // feature-mask gradient partials, one row of 32 per 32-row block [R/32][32]
     float* f[2];      // feature-mask parameter, ping-pong by iteration parity [T][32]
     float* mf;
     float* vf;
@@ -210,9 +210,9 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
             for (int j = 0; j < 4; ++j) red[wave * 32 + cg + j] = part[j];
         }
         __syncthreads();
-        if (tid < 32 && tid < p.D) {
+        if (tid < 32) {  // one partial per row block: summed in a fixed order by k_mask (deterministic)
             const float s = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
-            atomicAdd(&p.df[tl.t * FS + tid], s);
+            p.df[((size_t)(tm.offR >> 5) + tl.rb) * FS + tid] = s;
         }
     } else {
         // BWD3 / BWD2 / BWD1: dX (+ direct part) -> dZ_layer
@@ -342,7 +342,6 @@ __global__ __launch_bounds__(256) void k_head(Params p, int iter) {
         p.dE[t * 96 + tid] = s;
         p.argrow[t * 96 + tid] = erow[tid];
     }
-    if (tid < FS) p.df[t * FS + tid] = 0.0f;
     if (p.loss && tid == 128) {
         float s = 0.0f;
         for (int d = 0; d < p.D; ++d) s += sigmoidf_(p.f[iter & 1][t * FS + d]);
@@ -497,7 +496,9 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
         const int o = tl.t * FS + lane;
         const float fcur = p.f[iter & 1][o];
         const float ph = sigmoidf_(fcur);
-        const float gf = (p.df[o] + p.c_feat_size / (float)p.D) * ph * (1.0f - ph);
+        float dsum = 0.0f;
+        for (int rb = 0; rb < (ld >> 5); ++rb) dsum += p.df[((size_t)(tm.offR >> 5) + rb) * FS + lane];
+        const float gf = (dsum + p.c_feat_size / (float)p.D) * ph * (1.0f - ph);
         float m = p.mf[o], v = p.vf[o];
         m = m + (gf - m) * (1.0f - p.beta1);
         v = v * p.beta2 + (1.0f - p.beta2) * gf * gf;
@@ -524,7 +525,6 @@ __global__ __launch_bounds__(256) void k_prep(Params p, const float* f_init) {
         p.f[1][o] = f0;
         p.mf[o] = 0.0f;
         p.vf[o] = 0.0f;
-        p.df[o] = 0.0f;
     }
 }
 
