@@ -45,7 +45,7 @@ struct gnnx_plan_s {
     float* d_wts = nullptr;
     double sum_n2 = 0;
     // workspace offsets in bytes
-    size_t o_mM, o_vM, o_XT, o_U[3], o_UT[3], o_rn[3], o_dZ[3], o_dZT[3], o_dE, o_arg, o_df, o_f[2], o_mf, o_vf,
+    size_t o_mM, o_vM, o_XT, o_Zraw, o_g3, o_U[3], o_UT[3], o_rn[3], o_dZ[3], o_dZT[3], o_dE, o_arg, o_df, o_f[2], o_mf, o_vf,
         o_probs, ws_bytes;
     hipGraphExec_t gexec = nullptr;
     GraphKey gkey{};
@@ -151,6 +151,8 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
     h->o_mM = take(qb);
     h->o_vM = take(qb);
     h->o_XT = take(rb32);
+    h->o_Zraw = take(rb32);
+    h->o_g3 = take(rb1);
     for (int l = 0; l < 3; ++l) {
         h->o_U[l] = take(rb32);
         h->o_UT[l] = take(rb32);
@@ -209,6 +211,8 @@ static Params make_params(gnnx_handle h, const gnnx_hyper* hy, const float* A, c
     p.X = X;
     p.XT = reinterpret_cast<float*>(w + h->o_XT);
     p.yhat = yhat;
+    p.Zraw = reinterpret_cast<float*>(w + h->o_Zraw);
+    p.g3 = reinterpret_cast<float*>(w + h->o_g3);
     for (int l = 0; l < 3; ++l) {
         p.U[l] = reinterpret_cast<float*>(w + h->o_U[l]);
         p.UT[l] = reinterpret_cast<float*>(w + h->o_UT[l]);
@@ -257,11 +261,33 @@ static void launch_conv(gnnx_handle h, const Params& p, int it, hipStream_t s) {
     hipLaunchKernelGGL((k_conv<MODE>), dim3(h->n_conv), dim3(256), 0, s, p, h->d_conv, it);
 }
 
+template <bool UPDATE, bool WRITE_ABAR>
+static void launch_mask(gnnx_handle h, const Params& p, int it, float ss, float b2, hipStream_t s) {
+    if (h->prob.graph_mode)
+        hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, false>), dim3(h->n_mask), dim3(64), 0, s, p, h->d_mask, it, ss, b2);
+    else
+        hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, true>), dim3(h->n_mask), dim3(64), 0, s, p, h->d_mask, it, ss, b2);
+}
+
+// forward up to the head (+ in node mode the fused start of the backward pass)
 static void launch_forward(gnnx_handle h, const Params& p, int it, hipStream_t s) {
+    const int T = h->prob.num_targets;
     launch_conv<FWD1>(h, p, it, s);
     launch_conv<FWD2>(h, p, it, s);
-    launch_conv<FWD3>(h, p, it, s);
-    hipLaunchKernelGGL(k_head, dim3(h->prob.num_targets), dim3(256), 0, s, p, it);
+    if (h->prob.graph_mode) {
+        launch_conv<FWD3>(h, p, it, s);
+        hipLaunchKernelGGL(k_head, dim3(T), dim3(256), 0, s, p, it);
+    } else {
+        hipLaunchKernelGGL(k_node_head, dim3(T), dim3(256), 0, s, p, it);
+    }
+}
+
+static void launch_backward(gnnx_handle h, const Params& p, int it, hipStream_t s) {
+    if (h->prob.graph_mode) {
+        launch_conv<BWD3>(h, p, it, s);
+        launch_conv<BWD2>(h, p, it, s);
+    }
+    launch_conv<BWD1>(h, p, it, s);
 }
 
 // the whole job, stream-ordered: usable directly or under stream capture
@@ -271,19 +297,16 @@ static int enqueue_job(gnnx_handle h, const gnnx_hyper* hy, const Params& p, flo
     HIPCK(hipMemsetAsync(p.vM, 0, sizeof(float) * (size_t)h->Q, s));
     if (p.loss) HIPCK(hipMemsetAsync(p.loss, 0, sizeof(float) * (size_t)T * hy->num_iters * NLOSS, s));
     hipLaunchKernelGGL(k_prep, dim3(T), dim3(256), 0, s, p, (const float*)nullptr);
-    hipLaunchKernelGGL((k_mask<false, true>), dim3(h->n_mask), dim3(64), 0, s, p, h->d_mask, 0, 0.0f, 1.0f);
+    launch_mask<false, true>(h, p, 0, 0.0f, 1.0f, s);
     for (int it = 0; it < hy->num_iters; ++it) {
         launch_forward(h, p, it, s);
-        launch_conv<BWD3>(h, p, it, s);
-        launch_conv<BWD2>(h, p, it, s);
-        launch_conv<BWD1>(h, p, it, s);
-        launch_conv<BWD0>(h, p, it, s);
+        launch_backward(h, p, it, s);
         float ss, b2;
         adam_scalars(hy, it, &ss, &b2);
         if (it + 1 < hy->num_iters)
-            hipLaunchKernelGGL((k_mask<true, true>), dim3(h->n_mask), dim3(64), 0, s, p, h->d_mask, it, ss, b2);
+            launch_mask<true, true>(h, p, it, ss, b2, s);
         else
-            hipLaunchKernelGGL((k_mask<true, false>), dim3(h->n_mask), dim3(64), 0, s, p, h->d_mask, it, ss, b2);
+            launch_mask<true, false>(h, p, it, ss, b2, s);  // keep Abar of the LAST forward (explain.py:209-211)
     }
     if (feat_mask)
         HIPCK(hipMemcpyAsync(feat_mask, p.f[hy->num_iters & 1], sizeof(float) * T * FS, hipMemcpyDeviceToDevice, s));
@@ -336,7 +359,7 @@ extern "C" int gnnx_forward(gnnx_handle h, const float* A, const float* X, const
     Params p = make_params(h, nullptr, A, X, nullptr, const_cast<float*>(M), Abar, nullptr, workspace);
     p.num_iters = 1;
     hipLaunchKernelGGL(k_prep, dim3(h->prob.num_targets), dim3(256), 0, s, p, feat_mask_in);
-    hipLaunchKernelGGL((k_mask<false, true>), dim3(h->n_mask), dim3(64), 0, s, p, h->d_mask, 0, 0.0f, 1.0f);
+    launch_mask<false, true>(h, p, 0, 0.0f, 1.0f, s);
     launch_forward(h, p, 0, s);
     HIPCK(hipMemcpyAsync(probs, p.probs, sizeof(float) * h->prob.num_targets * CMAX, hipMemcpyDeviceToDevice, s));
     HIPCK(hipGetLastError());
@@ -356,15 +379,20 @@ extern "C" int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hy, int32_t kin
     HIPCK(hipEventCreate(&e1));
     float ss, b2;
     adam_scalars(hy, 0, &ss, &b2);
+    const bool gm = h->prob.graph_mode != 0;
     auto once = [&]() {
         switch (kind) {
-            case 0: hipLaunchKernelGGL((k_mask<true, true>), dim3(h->n_mask), dim3(64), 0, s, p, h->d_mask, 0, ss, b2); break;
+            case 0: launch_mask<true, true>(h, p, 0, ss, b2, s); break;
             case 1: launch_conv<FWD1>(h, p, 0, s); break;
             case 2: launch_conv<FWD2>(h, p, 0, s); break;
-            case 3: launch_conv<FWD3>(h, p, 0, s); break;
-            case 4: launch_conv<BWD2>(h, p, 0, s); break;
-            case 5: launch_conv<BWD1>(h, p, 0, s); break;
-            default: launch_conv<BWD0>(h, p, 0, s); break;
+            case 3:
+                if (gm) hipLaunchKernelGGL(k_head, dim3(h->prob.num_targets), dim3(256), 0, s, p, 0);
+                else hipLaunchKernelGGL(k_node_head, dim3(h->prob.num_targets), dim3(256), 0, s, p, 0);
+                break;
+            case 4: launch_conv<BWD1>(h, p, 0, s); break;
+            case 5: launch_conv<FWD3>(h, p, 0, s); break;
+            case 6: launch_conv<BWD3>(h, p, 0, s); break;
+            default: launch_conv<BWD2>(h, p, 0, s); break;
         }
     };
     once();  // warm
@@ -377,11 +405,14 @@ extern "C" int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hy, int32_t kin
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *ms_avg = ms / reps;
+    // algorithmic work of one launch: fused mask kernel = read+write M, m, v + read A = 28 B and
+    // the K = D+2H product = 2 (D+2H) flop per mask entry; a contraction = one 4-B read of Abar and 2 d flop per entry
     const double kagg = h->prob.D + 2.0 * h->prob.H;
-    if (alg_bytes) *alg_bytes = (kind == 0) ? 28.0 * h->sum_n2 : 4.0 * h->sum_n2;
+    const bool contraction = (kind == 1 || kind == 2 || kind == 4 || kind == 5 || kind == 7);
+    if (alg_bytes) *alg_bytes = (kind == 0) ? 28.0 * h->sum_n2 : contraction ? 4.0 * h->sum_n2 : 0.0;
     if (alg_flops) {
-        const double d = (kind == 1 || kind == 6) ? h->prob.D : h->prob.H;
-        *alg_flops = (kind == 0) ? 2.0 * h->sum_n2 * kagg : 2.0 * h->sum_n2 * d;
+        const double d = (kind == 1) ? h->prob.D : h->prob.H;
+        *alg_flops = (kind == 0) ? 2.0 * h->sum_n2 * kagg : contraction ? 2.0 * h->sum_n2 * d : 0.0;
     }
     HIPCK(hipGetLastError());
     return 0;

@@ -1,24 +1,28 @@
 // gnnx_kernels.hpp — CDNA4 (gfx950) device code of the GNNExplainer mask-optimisation loop.
 //
-// One iteration of the reference loop (explainer/explain.py:137-146) for ALL targets of a batch is
-//   k_conv<FWD1..3>   masked-adjacency contraction  Z = Abar . X_{l-1}  on MFMA (exact f32,
-//                     v_mfma_f32_32x32x2_f32), split-K over the 4 waves of a workgroup, LDS reduction,
-//                     fused epilogue  (.W + b, row L2-normalise)            models.py:58-80, 230-267
-//   k_head            logits of the target row / max-pooled rows, softmax, -log p, dE    models.py:375,
-//                     269-316; explain.py:709-714, 750-753
-//   k_conv<BWD3>      row-local backward through the last layer's normalise -> dZ3
-//   k_conv<BWD2,1>    dX = Abar . dZ_{l+1} (same MFMA contraction, Abar symmetric) + fused row-local
-//                     backward (ReLU mask, normalise Jacobian, .W^T) -> dZ_l
-//   k_conv<BWD0>      dX0 = Abar . dZ_1, reduced to the feature-mask gradient
-//   k_mask<true>      fused, memory-bound: G = dL/dAbar tile on MFMA (K = D+2H, never materialised),
-//                     + Laplacian, size and entropy regulariser gradients, sigmoid', Adam on (M, m, v),
-//                     new sigma(M) symmetrised into the next Abar, loss partial sums wave-reduced.
-//                     explain.py:665-678, 755-770, 780-793; utils/train_utils.py:9-10
-// Math: SURVEY.md Appendix A; CPU spec: oracle/closed_form.py (tests only).
+// One iteration of the reference loop (explainer/explain.py:137-146) for ALL targets of a batch:
 //
-// Layout: see include/gnnx.h.  Every leading dimension is a multiple of 32 so a 32x32 MFMA tile never
-// straddles a target; the symmetric Abar is read as Abar[k][i] (128-B coalesced segments) for the A
-// operand, feature rows are the B operand.
+//  node mode (GcnEncoderNode, 5 launches)            graph mode (GcnEncoderGraph, 8 launches)
+//   k_conv<FWD1>   Zraw = Abar.X ; U1                 k_conv<FWD1>, k_conv<FWD2>, k_conv<FWD3>
+//   k_conv<FWD2>   U2                                 k_head          max-pool head, dE, argmax rows
+//   k_node_head    row t of layer 3, head, dE,        k_conv<BWD3>    row-local -> dZ3
+//                  dZ3[t], dZ2 (rank-1), g3           k_conv<BWD2>    Abar.dZ3 -> dZ2
+//   k_conv<BWD1>   Abar.dZ2 -> dZ1, df partials       k_conv<BWD1>    Abar.dZ2 -> dZ1, df partials
+//   k_mask<..>     fused G-tile + regularisers + Adam k_mask<..>
+//
+//   k_conv   masked-adjacency contraction on MFMA (exact f32, v_mfma_f32_32x32x2_f32): one workgroup per
+//            32-row block, K split over its 4 waves, operand loads issued 16 k-steps deep, LDS split-K
+//            reduction, fused row-local epilogue (.W + b, L2-normalise / its Jacobian, ReLU mask, .W^T).
+//            models.py:58-80, 230-267
+//   k_mask   one wave per tile pair {(I,J),(J,I)}: G = dL/dAbar tile on MFMA (never materialised), Laplacian
+//            + size + entropy gradients, sigmoid', Adam on (M, m, v), the next symmetrised masked adjacency,
+//            loss partial sums wave-reduced.  explain.py:665-678, 755-770, 780-793; utils/train_utils.py:9-10
+//
+// Exact algebraic shortcuts used in node mode: only row t of the last layer is ever read
+// (explain.py:713), so dZ3 has one non-zero row, Abar.dZ3 is rank-1 and the layer-3 part of G is rank-2;
+// and colsum((Abar.dZ1) * X) == colsum(dZ1 * (Abar.X)) because Abar is symmetric, so the feature-mask
+// gradient needs no fourth contraction.
+// Math: SURVEY.md Appendix A; CPU spec: oracle/closed_form.py (tests only).
 #pragma once
 #include <stdint.h>
 
@@ -30,10 +34,10 @@ constexpr int CMAX = 32;  // max classes
 constexpr int NLOSS = 8;
 
 // offsets (floats) inside the packed, zero-padded model block
-constexpr int WT_W = 0;                  // W_l   [32][32]  at WT_W + l*1024   (row = input k, col = output c)
-constexpr int WT_B = 3 * 1024;           // b_l   [32]      at WT_B + l*32
-constexpr int WT_WP = WT_B + 3 * 32;     // Wp    [32][96]  (class c, l*32 + j)
-constexpr int WT_BP = WT_WP + CMAX * 96; // bp    [32]
+constexpr int WT_W = 0;                   // W_l   [32][32]  at WT_W + l*1024   (row = input k, col = output c)
+constexpr int WT_B = 3 * 1024;            // b_l   [32]      at WT_B + l*32
+constexpr int WT_WP = WT_B + 3 * 32;      // Wp    [32][96]  (class c, l*32 + j)
+constexpr int WT_BP = WT_WP + CMAX * 96;  // bp    [32]
 constexpr int WT_TOTAL = WT_BP + CMAX;
 
 struct TargetMeta {
@@ -45,33 +49,35 @@ struct TargetMeta {
     int64_t offR;  // row offset in row arrays
 };
 
-struct ConvTile { int32_t t, rb; };       // target, 32-row block
+struct ConvTile { int32_t t, rb; };                 // target, 32-row block
 struct MaskTile { int32_t t, I, J; int32_t pad; };  // target, tile pair I <= J
 
 struct Params {
     const TargetMeta* meta;
-    const float* A;   // adjacency (symmetric, zero padded)
-    float* M;         // edge-mask parameter
-    float* mM;        // Adam first moment
-    float* vM;        // Adam second moment
-    float* Abar;      // masked adjacency of the current iterate
-    const float* X;   // input features [R][32]
-    const float* XT;  // per target column-major copy [32][ld]
+    const float* A;     // adjacency (symmetric, zero padded)
+    float* M;           // edge-mask parameter
+    float* mM;          // Adam first moment
+    float* vM;          // Adam second moment
+    float* Abar;        // masked adjacency of the current iterate
+    const float* X;     // input features [R][32]
+    const float* XT;    // per target column-major copy [32][ld]
     const float* yhat;  // predicted class ids as float [R]
-    float* U[3];      // normalised pre-activations, row-major [R][32]
-    float* UT[3];     // same, per target column-major [32][ld]
-    float* rn[3];     // row norms [R]
-    float* dZ[3];     // gradients w.r.t. the aggregated inputs, row-major [R][32]
-    float* dZT[3];    // same, column-major
-    float* dE;        // direct gradient of the concatenated embedding [T][3][32]
-    int32_t* argrow;  // row that receives dE[l][c]  [T][3][32]
-    float* df;        // feature-mask gradient partials, one row of 32 per 32-row block [R/32][32]
-    float* f[2];      // feature-mask parameter, ping-pong by iteration parity [T][32]
+    float* Zraw;        // Abar . X (before the feature mask) [R][32]
+    float* U[3];        // normalised pre-activations, row-major [R][32]
+    float* UT[3];       // same, per target column-major [32][ld]
+    float* rn[3];       // row norms [R]
+    float* dZ[3];       // gradients w.r.t. the aggregated inputs, row-major [R][32]
+    float* dZT[3];      // same, column-major
+    float* g3;          // node mode: layer-3 part of row t of G, one float per row [R]
+    float* dE;          // direct gradient of the concatenated embedding [T][3][32]
+    int32_t* argrow;    // row that receives dE[l][c]  [T][3][32]
+    float* df;          // feature-mask gradient partials, one row of 32 per 32-row block [R/32][32]
+    float* f[2];        // feature-mask parameter, ping-pong by iteration parity [T][32]
     float* mf;
     float* vf;
-    float* probs;     // softmax of the head [T][CMAX]
-    float* loss;      // [T][num_iters][NLOSS] or null
-    const float* wts; // packed model block
+    float* probs;       // softmax of the head [T][CMAX]
+    float* loss;        // [T][num_iters][NLOSS] or null
+    const float* wts;   // packed model block
     int32_t D, H, O, C;
     int32_t graph_mode;
     int32_t num_iters;
@@ -86,7 +92,38 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // row of the 32x32 MFMA accumulator held in register r of a lane in half h (lane>>5); column = lane&31
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-enum ConvMode { FWD1 = 0, FWD2 = 1, FWD3 = 2, BWD3 = 3, BWD2 = 4, BWD1 = 5, BWD0 = 6 };
+// torch.optim.Adam, single-tensor form; step_size = lr/(1-beta1^k), bc2s = sqrt(1-beta2^k) from the host
+__device__ __forceinline__ void adam_update(float& theta, float& m, float& v, float g, float beta1, float beta2,
+                                            float eps, float step_size, float bc2s) {
+    m = m + (g - m) * (1.0f - beta1);
+    v = v * beta2 + (1.0f - beta2) * g * g;
+    theta = theta - step_size * (m / (sqrtf(v) / bc2s + eps));
+}
+
+enum ConvMode { FWD1 = 0, FWD2 = 1, FWD3 = 2, BWD3 = 3, BWD2 = 4, BWD1 = 5 };
+
+// row-local backward of one GraphConv layer for the 8 lanes that share a row:
+// du -> dY = (dU - U (dU.U)) / r, staged in zs, then dZ[k] = sum_c dY[c] W[k][c]
+__device__ __forceinline__ void rowlocal_backward(const float (&du)[4], const float (&u)[4], float rnorm, int dout,
+                                                  int row, int cg, float* zs, const float* wl, float (&dz)[4]) {
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s = fmaf(du[j], u[j], s);
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    __syncthreads();  // previous readers of zs are done
+#pragma unroll
+    for (int j = 0; j < 4; ++j) zs[row * 33 + cg + j] = (du[j] - u[j] * s) / rnorm;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dz[j] = 0.0f;
+    for (int c = 0; c < dout; ++c) {
+        const float dy = zs[row * 33 + c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dz[j] = fmaf(dy, wl[(cg + j) * 33 + c], dz[j]);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Masked-adjacency contraction + fused row-local epilogue.  One workgroup (4 waves) per 32-row
@@ -94,9 +131,10 @@ enum ConvMode { FWD1 = 0, FWD2 = 1, FWD3 = 2, BWD3 = 3, BWD2 = 4, BWD1 = 5, BWD0
 // ---------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, int iter) {
-    __shared__ float red[4 * TILE * 33];  // split-K partial tiles, then reused as Z / dY staging
+    __shared__ float red[4 * TILE * 33];  // split-K partial tiles
     __shared__ float wl[32 * 33];         // layer weight, padded rows
-    __shared__ float zs[TILE * 33];
+    __shared__ float zs[TILE * 33];       // reduced Z rows, then dY staging
+    __shared__ float phis[32];
 
     const ConvTile tl = tiles[blockIdx.x];
     const TargetMeta tm = p.meta[tl.t];
@@ -106,10 +144,10 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
     const int wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
 
     constexpr int layer = (MODE == FWD1 || MODE == BWD1) ? 0 : (MODE == FWD2 || MODE == BWD2) ? 1 : 2;
-    // stage the layer weight (BWD0 has no row-local part)
-    if (MODE != BWD0) {
+    {
         const float* W = p.wts + WT_W + layer * 1024;
         for (int e = tid; e < 1024; e += 256) wl[(e >> 5) * 33 + (e & 31)] = W[e];
+        if (MODE == FWD1 && tid < 32) phis[tid] = (tid < p.D) ? sigmoidf_(p.f[iter & 1][tl.t * FS + tid]) : 0.0f;
     }
 
     f32x16 acc;
@@ -117,34 +155,38 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
     if (MODE != BWD3) {
-        const float* Ab = p.Abar + tm.offQ;
+        const float* Ab = p.Abar + tm.offQ + row0 + li;  // Abar[k][i] == Abar[i][k]: 128-B coalesced segments
         const float* Bsrc = (MODE == FWD1)   ? p.X
                             : (MODE == FWD2) ? p.U[0]
                             : (MODE == FWD3) ? p.U[1]
                             : (MODE == BWD2) ? p.dZ[2]
-                            : (MODE == BWD1) ? p.dZ[1]
-                                             : p.dZ[0];
-        Bsrc += tm.offR * FS;
-        float phi = 1.0f;
-        if (MODE == FWD1) phi = (li < p.D) ? sigmoidf_(p.f[iter & 1][tl.t * FS + li]) : 0.0f;
-        const int kchunk = ld >> 2;
-        const int k0 = wave * kchunk;
-
-        for (int s = 0; s < kchunk; s += 2) {
-            const int k = k0 + s + h;
-            float a = Ab[(size_t)k * ld + row0 + li];  // Abar[k][i] == Abar[i][k]
-            float b = Bsrc[(size_t)k * FS + li];
-            if (MODE == FWD1) b *= phi;
-            if (MODE == FWD2 || MODE == FWD3) b = fmaxf(b, 0.0f);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                                             : p.dZ[1];
+        Bsrc += tm.offR * FS + li;
+        const int kchunk = ld >> 2;  // multiple of 8
+        const int k0 = wave * kchunk + h;
+        for (int s0 = 0; s0 < kchunk; s0 += 32) {
+            float a[16], b[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {  // issue all loads of 16 k-steps before the first MFMA
+                const bool on = (s0 + 2 * u) < kchunk;
+                const int k = k0 + s0 + 2 * u;
+                a[u] = on ? Ab[(size_t)k * ld] : 0.0f;
+                b[u] = on ? Bsrc[(size_t)k * FS] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                float bb = b[u];
+                if (MODE == FWD2 || MODE == FWD3) bb = fmaxf(bb, 0.0f);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bb, acc, 0, 0, 0);
+            }
         }
     }
     // split-K reduction through LDS
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wave * TILE + acc_row(r, h)) * 33 + li] = acc[r];
     __syncthreads();
-    const int row = tid >> 3;        // 0..31
-    const int cg = (tid & 7) * 4;    // column group
+    const int row = tid >> 3;      // 0..31
+    const int cg = (tid & 7) * 4;  // column group
     float z4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -153,14 +195,20 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
         for (int w = 0; w < 4; ++w) s += red[(w * TILE + row) * 33 + cg + j];
         z4[j] = s;
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) zs[row * 33 + cg + j] = z4[j];
-    __syncthreads();
-
     const size_t grow = (size_t)tm.offR + row0 + row;  // global row in row arrays
     const int irow = row0 + row;                       // row inside the target
 
     if (MODE == FWD1 || MODE == FWD2 || MODE == FWD3) {
+        if (MODE == FWD1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                p.Zraw[grow * FS + cg + j] = z4[j];
+                z4[j] *= phis[cg + j];  // Abar.(X * phi) == (Abar.X) * phi, phi is a per-column scale
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) zs[row * 33 + cg + j] = z4[j];
+        __syncthreads();
         const int din = (MODE == FWD1) ? p.D : p.H;
         const int dout = (MODE == FWD3) ? p.O : p.H;
         const float* bias = p.wts + WT_B + layer * 32;
@@ -191,29 +239,6 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
             UT[(size_t)(cg + j) * ld + irow] = u;
         }
         if ((tid & 7) == 0) p.rn[layer][grow] = rnorm;
-    } else if (MODE == BWD0) {
-        // dX0 rows -> feature-mask gradient: df[d] += sum_rows dX0[row][d] * X[row][d]
-        const float* Xr = p.X + grow * FS;
-        float part[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) part[j] = zs[row * 33 + cg + j] * Xr[cg + j];
-        // reduce over the 32 rows: rows differ in tid>>3 -> lanes 8 apart inside a wave, waves via LDS
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            part[j] += __shfl_xor(part[j], 8);
-            part[j] += __shfl_xor(part[j], 16);
-            part[j] += __shfl_xor(part[j], 32);
-        }
-        __syncthreads();
-        if (lane < 8) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) red[wave * 32 + cg + j] = part[j];
-        }
-        __syncthreads();
-        if (tid < 32) {  // one partial per row block: summed in a fixed order by k_mask (deterministic)
-            const float s = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
-            p.df[((size_t)(tm.offR >> 5) + tl.rb) * FS + tid] = s;
-        }
     } else {
         // BWD3 / BWD2 / BWD1: dX (+ direct part) -> dZ_layer
         const int dout = (layer == 2) ? p.O : p.H;  // width of U[layer] / dX
@@ -221,98 +246,52 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
         const float* U = p.U[layer] + grow * FS;
         const float* dE = p.dE + (tl.t * 3 + layer) * FS;
         const int32_t* ar = p.argrow + (tl.t * 3 + layer) * FS;
-        float du[4], u[4];
-        float s = 0.0f;
+        float du[4], u[4], dz[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = cg + j;
-            float dx = (MODE == BWD3) ? 0.0f : zs[row * 33 + c];
+            float dx = (MODE == BWD3) ? 0.0f : z4[j];
             u[j] = U[c];
             if (c < dout && ar[c] == irow) dx += dE[c];
             if (layer < 2) dx = (u[j] > 0.0f) ? dx : 0.0f;
             du[j] = (c < dout) ? dx : 0.0f;
-            s = fmaf(du[j], u[j], s);
         }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        const float rnorm = p.rn[layer][grow];
-        __syncthreads();  // everyone is done reading zs
-#pragma unroll
-        for (int j = 0; j < 4; ++j) zs[row * 33 + cg + j] = (du[j] - u[j] * s) / rnorm;  // dY
-        __syncthreads();
-        float dz[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dz[j] = 0.0f;
-        for (int c = 0; c < dout; ++c) {
-            const float dy = zs[row * 33 + c];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dz[j] = fmaf(dy, wl[(cg + j) * 33 + c], dz[j]);
-        }
+        rowlocal_backward(du, u, p.rn[layer][grow], dout, row, cg, zs, wl, dz);
         float* dZ = p.dZ[layer] + grow * FS;
         float* dZT = p.dZT[layer] + tm.offR * FS;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float v = (cg + j < din) ? dz[j] : 0.0f;
-            dZ[cg + j] = v;
-            dZT[(size_t)(cg + j) * ld + irow] = v;
+            dz[j] = (cg + j < din) ? dz[j] : 0.0f;
+            dZ[cg + j] = dz[j];
+            dZT[(size_t)(cg + j) * ld + irow] = dz[j];
+        }
+        if (MODE == BWD1) {
+            // feature-mask gradient: colsum((Abar.dZ1) * X) == colsum(dZ1 * (Abar.X)), Abar symmetric
+            float part[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                part[j] = dz[j] * p.Zraw[grow * FS + cg + j];
+                part[j] += __shfl_xor(part[j], 8);  // the 8 rows of this wave
+                part[j] += __shfl_xor(part[j], 16);
+                part[j] += __shfl_xor(part[j], 32);
+            }
+            __syncthreads();
+            if (lane < 8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) red[wave * 32 + cg + j] = part[j];
+            }
+            __syncthreads();
+            if (tid < 32)  // one partial per row block, summed in a fixed order by k_mask (deterministic)
+                p.df[((size_t)(tm.offR >> 5) + tl.rb) * FS + tid] = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
         }
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Head: one workgroup (256 threads) per target.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_head(Params p, int iter) {
-    __shared__ float e[96];
-    __shared__ int erow[96];
-    __shared__ float g[CMAX];
-    __shared__ float wmax[4 * 96];
-    __shared__ int warg[4 * 96];
-    const int t = blockIdx.x;
-    const TargetMeta tm = p.meta[t];
+// softmax head shared by both modes: e[96] (concatenated embedding) -> probs, g = p - onehot, dE = Wp^T g.
+// Must be called by all 256 threads of the workgroup.
+__device__ __forceinline__ void head_softmax(const Params& p, const TargetMeta& tm, int t, int iter, const float* e,
+                                             float* g, float* dEs) {
     const int tid = threadIdx.x;
-    const int dims[3] = {p.H, p.H, p.O};
-
-    if (!p.graph_mode) {
-        if (tid < 96) {
-            const int l = tid >> 5, c = tid & 31;
-            float v = 0.0f;
-            if (c < dims[l]) {
-                v = p.U[l][(tm.offR + tm.t) * FS + c];
-                if (l < 2) v = fmaxf(v, 0.0f);
-            }
-            e[tid] = v;
-            erow[tid] = tm.t;
-        }
-    } else {
-        // column-wise max over the n rows of every layer (padded rows of the reference included:
-        // they are rows < n here; the engine's own padding rows n..ld-1 are excluded)
-        const int wave = tid >> 6, lane = tid & 63;
-        for (int col = wave; col < 96; col += 4) {
-            const int l = col >> 5, c = col & 31;
-            float best = -3.0e38f;
-            int barg = 0;
-            if (c < dims[l]) {
-                const float* UT = p.UT[l] + tm.offR * FS + (size_t)c * tm.ld;
-                for (int i = lane; i < tm.n; i += 64) {
-                    float v = UT[i];
-                    if (l < 2) v = fmaxf(v, 0.0f);
-                    if (v > best) { best = v; barg = i; }
-                }
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) {
-                    const float ob = __shfl_xor(best, o);
-                    const int oa = __shfl_xor(barg, o);
-                    if (ob > best || (ob == best && oa < barg)) { best = ob; barg = oa; }
-                }
-            } else {
-                best = 0.0f;
-            }
-            if (lane == 0) { e[col] = best; erow[col] = barg; }
-        }
-    }
-    __syncthreads();
     const float* Wp = p.wts + WT_WP;
     if (tid < 64) {  // wave 0: logits, softmax
         float z = -3.0e38f;
@@ -324,7 +303,7 @@ __global__ __launch_bounds__(256) void k_head(Params p, int iter) {
         float mx = z;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        float ex = (tid < p.C) ? expf(z - mx) : 0.0f;
+        const float ex = (tid < p.C) ? expf(z - mx) : 0.0f;
         float sum = ex;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
@@ -339,24 +318,185 @@ __global__ __launch_bounds__(256) void k_head(Params p, int iter) {
     if (tid < 96) {
         float s = 0.0f;
         for (int c = 0; c < p.C; ++c) s = fmaf(Wp[c * 96 + tid], g[c], s);
-        p.dE[t * 96 + tid] = s;
-        p.argrow[t * 96 + tid] = erow[tid];
+        dEs[tid] = s;
     }
     if (p.loss && tid == 128) {
         float s = 0.0f;
         for (int d = 0; d < p.D; ++d) s += sigmoidf_(p.f[iter & 1][t * FS + d]);
         p.loss[((size_t)t * p.num_iters + iter) * NLOSS + 4] = p.c_feat_size * s / (float)p.D;
     }
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused mask kernel: one wave per tile pair {(I,J),(J,I)}, I <= J.
-//   UPDATE=false : only Abar = A * sym(sigma(M)) (initial forward)
-//   UPDATE=true  : gradient + Adam step on both tiles, then (WRITE_ABAR) the next Abar
+// Graph-mode head: one workgroup per graph.  Column-wise max over the n rows of every layer.
 // ---------------------------------------------------------------------------------------------
-template <bool UPDATE, bool WRITE_ABAR>
+__global__ __launch_bounds__(256) void k_head(Params p, int iter) {
+    __shared__ float e[96];
+    __shared__ int erow[96];
+    __shared__ float g[CMAX];
+    __shared__ float dEs[96];
+    const int t = blockIdx.x;
+    const TargetMeta tm = p.meta[t];
+    const int tid = threadIdx.x;
+    const int dims[3] = {p.H, p.H, p.O};
+    // padded rows of the reference are rows < n here; the engine's own padding rows n..ld-1 are excluded
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int col = wave; col < 96; col += 4) {
+        const int l = col >> 5, c = col & 31;
+        float best = -3.0e38f;
+        int barg = 0;
+        if (c < dims[l]) {
+            const float* UT = p.UT[l] + tm.offR * FS + (size_t)c * tm.ld;
+            for (int i = lane; i < tm.n; i += 64) {
+                float v = UT[i];
+                if (l < 2) v = fmaxf(v, 0.0f);
+                if (v > best) { best = v; barg = i; }
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const float ob = __shfl_xor(best, o);
+                const int oa = __shfl_xor(barg, o);
+                if (ob > best || (ob == best && oa < barg)) { best = ob; barg = oa; }
+            }
+        } else {
+            best = 0.0f;
+        }
+        if (lane == 0) { e[col] = best; erow[col] = barg; }
+    }
+    __syncthreads();
+    head_softmax(p, tm, t, iter, e, g, dEs);
+    if (tid < 96) {
+        p.dE[t * 96 + tid] = dEs[tid];
+        p.argrow[t * 96 + tid] = erow[tid];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Node-mode head: one workgroup per target.  Only row t of the last layer is consumed by the
+// reference (explain.py:713), so this kernel computes that row (mat-vec with Abar[t,:]), the head,
+// dE, dZ3[t] and - because Abar.dZ3 is rank-1 - the whole of dZ2 and the layer-3 row g3 of G.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_node_head(Params p, int iter) {
+    __shared__ float part[8 * 32];
+    __shared__ float e[96], g[CMAX], dEs[96];
+    __shared__ float y3[32], dz3[32];
+    __shared__ float wl[32 * 33], zs[TILE * 33];
+    __shared__ float sr3;
+    const int t = blockIdx.x;
+    const TargetMeta tm = p.meta[t];
+    const int tid = threadIdx.x, ld = tm.ld, n = tm.n, tr = tm.t;
+    const float* Ab = p.Abar + tm.offQ;
+    const float* U1 = p.U[0] + tm.offR * FS;
+    const float* U2 = p.U[1] + tm.offR * FS;
+    const float* W3 = p.wts + WT_W + 2 * 1024;
+    const float* W2 = p.wts + WT_W + 1 * 1024;
+
+    // Z3[t][c] = sum_k Abar[t][k] relu(U2[k][c]) : 8 k-slices x 32 columns
+    {
+        const int c = tid & 31, sl = tid >> 5;
+        float s = 0.0f;
+        for (int k = sl; k < n; k += 8) s = fmaf(Ab[(size_t)tr * ld + k], fmaxf(U2[(size_t)k * FS + c], 0.0f), s);
+        part[sl * 32 + c] = s;
+        for (int e2 = tid; e2 < 1024; e2 += 256) wl[(e2 >> 5) * 33 + (e2 & 31)] = W3[e2];
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float z = 0.0f;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) z += part[sl * 32 + tid];
+        zs[tid] = z;
+    }
+    __syncthreads();
+    if (tid < 64) {  // Y3 = Z3 W3 + b3, normalise (wave 0, columns in lanes 0..31)
+        const int c = tid & 31;
+        float y = 0.0f;
+        if (c < p.O) {
+            for (int k = 0; k < p.H; ++k) y = fmaf(zs[k], wl[k * 33 + c], y);
+            y += p.wts[WT_B + 2 * 32 + c];
+        }
+        float ss = (tid < 32) ? y * y : 0.0f;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+        const float rnorm = fmaxf(sqrtf(ss), 1e-12f);
+        if (tid < 32) {
+            const float u = y / rnorm;
+            y3[tid] = u;
+            e[64 + tid] = u;
+            e[tid] = (tid < p.H) ? fmaxf(U1[(size_t)tr * FS + tid], 0.0f) : 0.0f;
+            e[32 + tid] = (tid < p.H) ? fmaxf(U2[(size_t)tr * FS + tid], 0.0f) : 0.0f;
+        }
+        if (tid == 0) sr3 = rnorm;
+    }
+    __syncthreads();
+    head_softmax(p, tm, t, iter, e, g, dEs);
+    // dZ3[t] : backward through the last layer's normalisation and W3 (row t only)
+    if (tid < 64) {
+        const int c = tid & 31;
+        const float du = (tid < 32 && c < p.O) ? dEs[64 + c] : 0.0f;
+        const float u = (tid < 32) ? y3[c] : 0.0f;
+        float s = du * u;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        if (tid < 32) zs[c] = (du - u * s) / sr3;  // dY3[t]
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float v = 0.0f;
+        if (tid < p.H)
+            for (int c = 0; c < p.O; ++c) v = fmaf(zs[c], wl[tid * 33 + c], v);
+        dz3[tid] = v;
+    }
+    __syncthreads();
+    for (int e2 = tid; e2 < 1024; e2 += 256) wl[(e2 >> 5) * 33 + (e2 & 31)] = W2[e2];
+    // g3[j] = dZ3[t] . relu(U2[j]) : layer-3 part of row t of dL/dAbar
+    for (int j = tid; j < ld; j += 256) {
+        float s = 0.0f;
+        if (j < n)
+            for (int k = 0; k < p.H; ++k) s = fmaf(dz3[k], fmaxf(U2[(size_t)j * FS + k], 0.0f), s);
+        p.g3[tm.offR + j] = s;
+    }
+    // dZ2 for every row: dX2[i] = Abar[i][t] dZ3[t] (+ dE2 on row t), then the row-local backward of layer 2
+    const int row = tid >> 3, cg = (tid & 7) * 4;
+    float* dZ = p.dZ[1] + tm.offR * FS;
+    float* dZT = p.dZT[1] + tm.offR * FS;
+    for (int r0 = 0; r0 < ld; r0 += TILE) {
+        const int i = r0 + row;
+        const float ait = Ab[(size_t)tr * ld + i];  // Abar[t][i] == Abar[i][t]
+        float du[4], u[4], dz[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = cg + j;
+            u[j] = U2[(size_t)i * FS + c];
+            float dx = ait * dz3[c];
+            if (i == tr) dx += dEs[32 + c];
+            dx = (u[j] > 0.0f) ? dx : 0.0f;
+            du[j] = (c < p.H) ? dx : 0.0f;
+        }
+        rowlocal_backward(du, u, p.rn[1][tm.offR + i], p.H, row, cg, zs, wl, dz);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = (cg + j < p.H) ? dz[j] : 0.0f;
+            dZ[(size_t)i * FS + cg + j] = v;
+            dZT[(size_t)(cg + j) * ld + i] = v;
+        }
+    }
+    if (tid < 96) {
+        p.dE[t * 96 + tid] = dEs[tid];
+        p.argrow[t * 96 + tid] = tr;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused mask kernel: one wave per tile pair {(I,J),(J,I)}, I <= J.  Every mask entry is updated by
+// exactly one lane (diagonal tiles exchange through LDS) so the result is bitwise symmetric.
+//   UPDATE=false : only Abar = A * sym(sigma(M)) (initial forward)
+//   UPDATE=true  : gradient + Adam step, then (WRITE_ABAR) the next Abar
+//   NODE         : layer-3 part of G is the rank-2 term built from g3 (node mode)
+// ---------------------------------------------------------------------------------------------
+template <bool UPDATE, bool WRITE_ABAR, bool NODE>
 __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, int iter, float step_size, float bc2s) {
-    __shared__ float tM[TILE * 33], tm1[TILE * 33], tv[TILE * 33], tA[TILE * 33];
+    __shared__ float sM[TILE * 33], sm[TILE * 33], sv[TILE * 33], sS[TILE * 33];
     const MaskTile tl = tiles[blockIdx.x];
     const TargetMeta tm = p.meta[tl.t];
     const int ld = tm.ld, n = tm.n;
@@ -365,46 +505,70 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
     const int lane = threadIdx.x, li = lane & 31, h = lane >> 5;
     const size_t q = tm.offQ;
 
+    // ---- issue every global load first (they overlap with the MFMA chain) ----
+    float Mo[16], Ao[16], mo[16], vo[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const size_t own = q + (size_t)(I0 + acc_row(r, h)) * ld + J0 + li;
+        Mo[r] = p.M[own];
+        Ao[r] = p.A[own];
+        if (UPDATE) { mo[r] = p.mM[own]; vo[r] = p.vM[own]; }
+    }
+    // partner tile (J,I), row-wise (coalesced) into LDS so it can be read transposed
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        const int row = 2 * rr + h;
+        const size_t gidx = q + (size_t)(J0 + row) * ld + I0 + li;
+        sM[row * 33 + li] = p.M[gidx];
+        if (UPDATE && !diag) { sm[row * 33 + li] = p.mM[gidx]; sv[row * 33 + li] = p.vM[gidx]; }
+    }
+
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-
     if (UPDATE) {
         const size_t ro = (size_t)tm.offR * FS;
+        constexpr int NL = NODE ? 2 : 3;
 #pragma unroll
-        for (int l = 0; l < 3; ++l) {
+        for (int l = 0; l < NL; ++l) {
             const int d = (l == 0) ? p.D : p.H;
             const float* zT = p.dZT[l] + ro;
             const float* xT = (l == 0) ? p.XT + ro : p.UT[l - 1] + ro;
-            for (int s = 0; s < d; s += 2) {
-                const int k = s + h;  // k < 32 always; columns >= d hold zeros
-                float phi = 1.0f;
-                if (l == 0) phi = (k < p.D) ? sigmoidf_(p.f[iter & 1][tl.t * FS + k]) : 0.0f;
-                const float zi = zT[(size_t)k * ld + I0 + li];
-                const float zj = zT[(size_t)k * ld + J0 + li];
-                float xi = xT[(size_t)k * ld + I0 + li];
-                float xj = xT[(size_t)k * ld + J0 + li];
-                if (l == 0) { xi *= phi; xj *= phi; } else { xi = fmaxf(xi, 0.0f); xj = fmaxf(xj, 0.0f); }
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zi, xj, acc, 0, 0, 0);  // G[i][j]
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xi, zj, acc, 0, 0, 0);  // G[j][i]
+            for (int s0 = 0; s0 < d; s0 += 8) {
+                float zi[4], zj[4], xi[4], xj[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {  // 4 k-steps of loads in flight; columns >= d hold zeros (k < 32)
+                    const int k = s0 + 2 * u + h;
+                    zi[u] = zT[(size_t)k * ld + I0 + li];
+                    zj[u] = zT[(size_t)k * ld + J0 + li];
+                    xi[u] = xT[(size_t)k * ld + I0 + li];
+                    xj[u] = xT[(size_t)k * ld + J0 + li];
+                    if (l == 0) {
+                        const float phi = (k < p.D) ? sigmoidf_(p.f[iter & 1][tl.t * FS + k]) : 0.0f;
+                        xi[u] *= phi;
+                        xj[u] *= phi;
+                    } else {
+                        xi[u] = fmaxf(xi[u], 0.0f);
+                        xj[u] = fmaxf(xj[u], 0.0f);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zi[u], xj[u], acc, 0, 0, 0);  // G[i][j]
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xi[u], zj[u], acc, 0, 0, 0);  // G[j][i]
+                }
             }
         }
-    }
-
-    // stage the partner tile (J,I) row-wise (coalesced) so it can be read transposed
-    for (int rr = h; rr < TILE; rr += 2) {
-        const size_t g = q + (size_t)(J0 + rr) * ld + I0 + li;
-        tM[rr * 33 + li] = p.M[g];
-        if (UPDATE) { tm1[rr * 33 + li] = p.mM[g]; tv[rr * 33 + li] = p.vM[g]; }
     }
     __syncthreads();
 
     const float inv_n2 = 1.0f / ((float)n * (float)n);
-    float yj = 0.0f;
     const bool lapl = UPDATE && !p.graph_mode;
+    float yj = 0.0f, g3j = 0.0f;
     if (lapl) yj = p.yhat[tm.offR + J0 + li];
-    // step_size = lr / (1 - beta1^k), bc2s = sqrt(1 - beta2^k): evaluated in double on the host, as torch does
+    if (UPDATE && NODE) g3j = p.g3[tm.offR + J0 + li];
     float s_size = 0.0f, s_ent = 0.0f, s_lap = 0.0f;
+    float Sown[16];
 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -412,69 +576,90 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
         const int gi = I0 + i, gj = J0 + j;
         const bool valid = (gi < n) && (gj < n);
         const size_t own = q + (size_t)gi * ld + gj;
-        const float Aij = p.A[own];
-        const float offd = (gi != gj) ? 1.0f : 0.0f;
-        float Mij = p.M[own];
-        float Mji = tM[j * 33 + i];
+        const float Aij = Ao[r];
+        float Mij = Mo[r];
         if (UPDATE) {
-            float mij = p.mM[own], vij = p.vM[own];
-            float mji = tm1[j * 33 + i], vji = tv[j * 33 + i];
-            const float Sij = sigmoidf_(Mij), Sji = sigmoidf_(Mji);
-            float Gs = 0.5f * acc[r];
+            const float offd = (gi != gj) ? 1.0f : 0.0f;
+            float Gsum = acc[r];
+            if (NODE) {
+                if (gi == tm.t) Gsum += g3j;
+                if (gj == tm.t) Gsum += p.g3[tm.offR + gi];
+            }
+            float Gs = 0.5f * Gsum;
+            float yi = 0.0f;
             if (lapl) {
-                const float yi = p.yhat[tm.offR + gi];
+                yi = p.yhat[tm.offR + gi];
                 const float dy = yi - yj;
                 Gs += p.c_lap * 0.5f * dy * dy * inv_n2;
+            }
+            const float gc = Gs * Aij * offd;
+            const float Sij = sigmoidf_(Mij);
+            float Sji_old = 0.0f;
+            if (!diag) {  // this lane also owns the partner entry (j,i)
+                float Mji = sM[j * 33 + i], mji = sm[j * 33 + i], vji = sv[j * 33 + i];
+                const float Sji = sigmoidf_(Mji);
+                Sji_old = Sji;
+                const float gji = (gc + p.c_size + p.c_ent * (logf(1.0f - Sji) - logf(Sji)) * inv_n2) * Sji * (1.0f - Sji);
+                adam_update(Mji, mji, vji, gji, p.beta1, p.beta2, p.eps, step_size, bc2s);
+                sM[j * 33 + i] = Mji;
+                sm[j * 33 + i] = mji;
+                sv[j * 33 + i] = vji;
+                sS[j * 33 + i] = sigmoidf_(Mji);
                 if (p.loss && valid) {
-                    const float ab = Aij * 0.5f * (Sij + Sji) * offd;
-                    s_lap += ab * (yj * yj - yi * yj);
-                    if (!diag) s_lap += ab * (yi * yi - yi * yj);
+                    s_size += Sji;
+                    s_ent += -Sji * logf(Sji) - (1.0f - Sji) * logf(1.0f - Sji);
                 }
             }
             if (p.loss && valid) {
                 s_size += Sij;
                 s_ent += -Sij * logf(Sij) - (1.0f - Sij) * logf(1.0f - Sij);
-                if (!diag) {
-                    s_size += Sji;
-                    s_ent += -Sji * logf(Sji) - (1.0f - Sji) * logf(1.0f - Sji);
+                if (lapl) {
+                    if (diag) Sji_old = sigmoidf_(sM[j * 33 + i]);  // old value, logging only
+                    const float ab = Aij * 0.5f * (Sij + Sji_old) * offd;
+                    s_lap += ab * (yj * yj - yi * yj);
+                    if (!diag) s_lap += ab * (yi * yi - yi * yj);
                 }
             }
-            const float gc = Gs * Aij * offd;
             const float gij = (gc + p.c_size + p.c_ent * (logf(1.0f - Sij) - logf(Sij)) * inv_n2) * Sij * (1.0f - Sij);
-            const float gji = (gc + p.c_size + p.c_ent * (logf(1.0f - Sji) - logf(Sji)) * inv_n2) * Sji * (1.0f - Sji);
-            // torch.optim.Adam, single-tensor form
-            mij = mij + (gij - mij) * (1.0f - p.beta1);
-            mji = mji + (gji - mji) * (1.0f - p.beta1);
-            vij = vij * p.beta2 + (1.0f - p.beta2) * gij * gij;
-            vji = vji * p.beta2 + (1.0f - p.beta2) * gji * gji;
-            Mij = Mij - step_size * (mij / (sqrtf(vij) / bc2s + p.eps));
-            Mji = Mji - step_size * (mji / (sqrtf(vji) / bc2s + p.eps));
+            float mij = mo[r], vij = vo[r];
+            adam_update(Mij, mij, vij, gij, p.beta1, p.beta2, p.eps, step_size, bc2s);
             if (valid) {
                 p.M[own] = Mij;
                 p.mM[own] = mij;
                 p.vM[own] = vij;
             }
-            tM[j * 33 + i] = Mji;
-            tm1[j * 33 + i] = mji;
-            tv[j * 33 + i] = vji;
+        } else if (!diag) {
+            sS[j * 33 + i] = sigmoidf_(sM[j * 33 + i]);
         }
-        if (WRITE_ABAR) {
-            const float ab = Aij * (0.5f * (sigmoidf_(Mij) + sigmoidf_(Mji))) * offd;
-            p.Abar[own] = valid ? ab : 0.0f;
-            tA[j * 33 + i] = valid ? ab : 0.0f;
-        }
+        Sown[r] = sigmoidf_(Mij);
+        if (diag) sS[i * 33 + j] = Sown[r];  // diagonal tile: publish, the partner lane reads it transposed
     }
     __syncthreads();
+    if (WRITE_ABAR) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = acc_row(r, h), j = li;
+            const int gi = I0 + i, gj = J0 + j;
+            const bool valid = (gi < n) && (gj < n) && (gi != gj);
+            const float Sother = sS[j * 33 + i];
+            const float ab = valid ? Ao[r] * (0.5f * (Sown[r] + Sother)) : 0.0f;
+            p.Abar[q + (size_t)gi * ld + gj] = ab;
+            if (!diag) sS[j * 33 + i] = ab;  // same value for (j,i): stage for the coalesced row-wise store
+        }
+        __syncthreads();
+    }
     if (!diag) {
-        for (int rr = h; rr < TILE; rr += 2) {
-            const size_t g = q + (size_t)(J0 + rr) * ld + I0 + li;
-            const bool valid = (J0 + rr < n) && (I0 + li < n);
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = 2 * rr + h;
+            const size_t gidx = q + (size_t)(J0 + row) * ld + I0 + li;
+            const bool valid = (J0 + row < n) && (I0 + li < n);
             if (UPDATE && valid) {
-                p.M[g] = tM[rr * 33 + li];
-                p.mM[g] = tm1[rr * 33 + li];
-                p.vM[g] = tv[rr * 33 + li];
+                p.M[gidx] = sM[row * 33 + li];
+                p.mM[gidx] = sm[row * 33 + li];
+                p.vM[gidx] = sv[row * 33 + li];
             }
-            if (WRITE_ABAR) p.Abar[g] = tA[rr * 33 + li];
+            if (WRITE_ABAR) p.Abar[gidx] = sS[row * 33 + li];
         }
     }
     if (UPDATE && p.loss) {
@@ -484,7 +669,7 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
             s_ent += __shfl_xor(s_ent, o);
             s_lap += __shfl_xor(s_lap, o);
         }
-        if (lane == 0) {
+        if (lane == 0) {  // logging only: float atomics, summation order not fixed
             float* L = p.loss + ((size_t)tl.t * p.num_iters + iter) * NLOSS;
             atomicAdd(&L[1], p.c_size * s_size);
             atomicAdd(&L[2], p.c_lap * s_lap * inv_n2);
@@ -499,12 +684,11 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
         float dsum = 0.0f;
         for (int rb = 0; rb < (ld >> 5); ++rb) dsum += p.df[((size_t)(tm.offR >> 5) + rb) * FS + lane];
         const float gf = (dsum + p.c_feat_size / (float)p.D) * ph * (1.0f - ph);
-        float m = p.mf[o], v = p.vf[o];
-        m = m + (gf - m) * (1.0f - p.beta1);
-        v = v * p.beta2 + (1.0f - p.beta2) * gf * gf;
+        float fnew = fcur, m = p.mf[o], v = p.vf[o];
+        adam_update(fnew, m, v, gf, p.beta1, p.beta2, p.eps, step_size, bc2s);
         p.mf[o] = m;
         p.vf[o] = v;
-        p.f[(iter + 1) & 1][o] = fcur - step_size * (m / (sqrtf(v) / bc2s + p.eps));
+        p.f[(iter + 1) & 1][o] = fnew;
     }
 }
 

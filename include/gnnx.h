@@ -95,8 +95,9 @@ int gnnx_forward(gnnx_handle h, const float* A, const float* X, const float* M, 
 
 /* Measurement hook for bench.py: relaunch one kernel class `reps` times on the current workspace
  * state between two hipEvents on `stream`; returns the average launch duration in milliseconds and
- * the algorithmic bytes / flops of one launch.  kind: 0 = fused mask/regulariser/Adam kernel,
- * 1..3 = forward contraction layer 1..3, 4..6 = backward contraction. */
+ * the algorithmic bytes / flops of one launch.  kind: 0 = fused mask/regulariser/Adam kernel, 1/2 = forward
+ * contraction of layer 1/2, 3 = head kernel, 4 = backward contraction into layer 1; graph mode only:
+ * 5 = forward contraction of layer 3, 6 = row-local backward of layer 3, 7 = backward contraction into layer 2. */
 int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hyper, int32_t kind, int32_t reps, const float* A,
                      const float* X, const float* yhat, float* M, float* Abar, void* workspace,
                      size_t workspace_bytes, void* stream, float* ms_avg, double* alg_bytes, double* alg_flops);

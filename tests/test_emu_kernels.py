@@ -61,3 +61,25 @@ def test_batch_of_ragged_targets_matches_individual_runs():
         o = closed_form.ClosedFormOracle(s.adj, s.feat, ck["sd"], s.gt_label, s.pred_label, s.target_row, s.mask0)
         assert np.abs(res.masked_adj[i] - o.run(4)).max() < 2e-6
     assert np.array_equal(res.masked_adj[0], res.masked_adj[2])
+
+
+def test_graph_mode_short_run_matches_closed_form():
+    z = np.load(helpers.GOLDEN + "/graphmode_explain.npz")
+    sd = {k[2:]: z[k] for k in z.files if k.startswith("w:")}
+    g = 4
+    A, X, lab = z["adj"][g], z["feat"][g], int(z["label"][g])
+    m0 = helpers.seeded_mask0(g, A.shape[0]).numpy()
+    job = emu_job([Subgraph(A, X, lab, 0, None, m0)], sd, graph_mode=True)
+    res = job.run([m0], Hyper(num_iters=5, record_loss=True))
+    o = closed_form.ClosedFormOracle(A, X, sd, lab, None, 0, m0, graph_mode=True)
+    want = o.run(5)
+    assert np.abs(res.masked_adj[0] - want).max() < 2e-6
+    assert np.abs(res.feat_mask[0] - o.f).max() < 2e-5
+    assert np.allclose(res.loss[0][:, :5].sum(1), np.asarray(o.trace)[:, 0], rtol=1e-5)
+
+
+def test_outputs_are_bitwise_symmetric_and_zero_off_edges():
+    ck, gx, sg = _node_case("syn1", 309)       # n = 48 -> 2x2 tiles: diagonal and off-diagonal tile pairs
+    res = emu_job([sg], ck["sd"]).run([sg.mask0], Hyper(num_iters=5))
+    ma = res.masked_adj[0]
+    assert np.array_equal(ma, ma.T) and np.all(ma[sg.adj == 0] == 0) and np.all(np.diag(ma) == 0)
