@@ -263,10 +263,12 @@ static void launch_conv(gnnx_handle h, const Params& p, int it, hipStream_t s) {
 
 template <bool UPDATE, bool WRITE_ABAR>
 static void launch_mask(gnnx_handle h, const Params& p, int it, float ss, float b2, hipStream_t s) {
-    if (h->prob.graph_mode)
-        hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, false>), dim3(h->n_mask), dim3(64), 0, s, p, h->d_mask, it, ss, b2);
-    else
-        hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, true>), dim3(h->n_mask), dim3(64), 0, s, p, h->d_mask, it, ss, b2);
+    const dim3 g(h->n_mask), b(64);
+    const bool node = !h->prob.graph_mode, loss = UPDATE && p.loss != nullptr;
+    if (node && loss) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, true, UPDATE>), g, b, 0, s, p, h->d_mask, it, ss, b2);
+    else if (node) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, true, false>), g, b, 0, s, p, h->d_mask, it, ss, b2);
+    else if (loss) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, false, UPDATE>), g, b, 0, s, p, h->d_mask, it, ss, b2);
+    else hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, false, false>), g, b, 0, s, p, h->d_mask, it, ss, b2);
 }
 
 // forward up to the head (+ in node mode the fused start of the backward pass)
@@ -278,7 +280,7 @@ static void launch_forward(gnnx_handle h, const Params& p, int it, hipStream_t s
         launch_conv<FWD3>(h, p, it, s);
         hipLaunchKernelGGL(k_head, dim3(T), dim3(256), 0, s, p, it);
     } else {
-        hipLaunchKernelGGL(k_node_head, dim3(T), dim3(256), 0, s, p, it);
+        hipLaunchKernelGGL(k_node_head, dim3(h->n_conv), dim3(256), 0, s, p, h->d_conv, it);
     }
 }
 
@@ -387,7 +389,7 @@ extern "C" int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hy, int32_t kin
             case 2: launch_conv<FWD2>(h, p, 0, s); break;
             case 3:
                 if (gm) hipLaunchKernelGGL(k_head, dim3(h->prob.num_targets), dim3(256), 0, s, p, 0);
-                else hipLaunchKernelGGL(k_node_head, dim3(h->prob.num_targets), dim3(256), 0, s, p, 0);
+                else hipLaunchKernelGGL(k_node_head, dim3(h->n_conv), dim3(256), 0, s, p, h->d_conv, 0);
                 break;
             case 4: launch_conv<BWD1>(h, p, 0, s); break;
             case 5: launch_conv<FWD3>(h, p, 0, s); break;

@@ -87,17 +87,22 @@ struct Params {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Hardware forms (v_exp_f32 / v_rcp_f32 / v_sqrt_f32, ~1 ulp): the fused mask kernel is VALU-bound, and an
+// IEEE divide or an accurate expf costs 10-20 instructions each.  Their error (~1e-7 relative) is the same
+// class as the reference's own SLEEF/MKL round-off; parity is checked at 1e-5 against the golden outputs.
+__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return rcp_(1.0f + __expf(-x)); }
 
 // row of the 32x32 MFMA accumulator held in register r of a lane in half h (lane>>5); column = lane&31
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // torch.optim.Adam, single-tensor form; step_size = lr/(1-beta1^k), bc2s = sqrt(1-beta2^k) from the host
+// inv_bc2s = 1 / sqrt(1 - beta2^k)
 __device__ __forceinline__ void adam_update(float& theta, float& m, float& v, float g, float beta1, float beta2,
-                                            float eps, float step_size, float bc2s) {
+                                            float eps, float step_size, float inv_bc2s) {
     m = m + (g - m) * (1.0f - beta1);
     v = v * beta2 + (1.0f - beta2) * g * g;
-    theta = theta - step_size * (m / (sqrtf(v) / bc2s + eps));
+    theta = theta - step_size * (m * rcp_(__builtin_amdgcn_sqrtf(v) * inv_bc2s + eps));
 }
 
 enum ConvMode { FWD1 = 0, FWD2 = 1, FWD3 = 2, BWD3 = 3, BWD2 = 4, BWD1 = 5 };
@@ -164,21 +169,33 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
         Bsrc += tm.offR * FS + li;
         const int kchunk = ld >> 2;  // multiple of 8
         const int k0 = wave * kchunk + h;
-        for (int s0 = 0; s0 < kchunk; s0 += 32) {
-            float a[16], b[16];
+        // 8 k-steps per batch, two batches of loads in flight (register double buffer)
+        float a0[8], b0[8], a1[8], b1[8];
+        auto load8 = [&](float (&a)[8], float (&b)[8], int s0) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {  // issue all loads of 16 k-steps before the first MFMA
-                const bool on = (s0 + 2 * u) < kchunk;
+            for (int u = 0; u < 8; ++u) {
+                const bool on = (s0 + 2 * u) < kchunk;  // kchunk is a multiple of 8, a batch spans 16 k values
                 const int k = k0 + s0 + 2 * u;
                 a[u] = on ? Ab[(size_t)k * ld] : 0.0f;
                 b[u] = on ? Bsrc[(size_t)k * FS] : 0.0f;
             }
+        };
+        auto mma8 = [&](const float (&a)[8], const float (&b)[8]) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 float bb = b[u];
                 if (MODE == FWD2 || MODE == FWD3) bb = fmaxf(bb, 0.0f);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bb, acc, 0, 0, 0);
             }
+        };
+        load8(a0, b0, 0);
+        for (int s0 = 0; s0 < kchunk; s0 += 32) {
+            const bool more1 = s0 + 16 < kchunk;
+            if (more1) load8(a1, b1, s0 + 16);
+            mma8(a0, b0);
+            const bool more0 = s0 + 32 < kchunk;
+            if (more0) load8(a0, b0, s0 + 32);
+            if (more1) mma8(a1, b1);
         }
     }
     // split-K reduction through LDS
@@ -289,8 +306,8 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
 
 // softmax head shared by both modes: e[96] (concatenated embedding) -> probs, g = p - onehot, dE = Wp^T g.
 // Must be called by all 256 threads of the workgroup.
-__device__ __forceinline__ void head_softmax(const Params& p, const TargetMeta& tm, int t, int iter, const float* e,
-                                             float* g, float* dEs) {
+__device__ __forceinline__ void head_softmax(const Params& p, const TargetMeta& tm, int t, int iter, bool write,
+                                             const float* e, float* g, float* dEs) {
     const int tid = threadIdx.x;
     const float* Wp = p.wts + WT_WP;
     if (tid < 64) {  // wave 0: logits, softmax
@@ -310,9 +327,9 @@ __device__ __forceinline__ void head_softmax(const Params& p, const TargetMeta& 
         const float pr = ex / sum;
         if (tid < CMAX) {
             g[tid] = (tid < p.C) ? pr - ((tid == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
-            p.probs[t * CMAX + tid] = (tid < p.C) ? pr : 0.0f;
+            if (write) p.probs[t * CMAX + tid] = (tid < p.C) ? pr : 0.0f;
         }
-        if (p.loss && tid == tm.y_gt) p.loss[((size_t)t * p.num_iters + iter) * NLOSS + 0] = -logf(pr);
+        if (write && p.loss && tid == tm.y_gt) p.loss[((size_t)t * p.num_iters + iter) * NLOSS + 0] = -logf(pr);
     }
     __syncthreads();
     if (tid < 96) {
@@ -320,7 +337,7 @@ __device__ __forceinline__ void head_softmax(const Params& p, const TargetMeta& 
         for (int c = 0; c < p.C; ++c) s = fmaf(Wp[c * 96 + tid], g[c], s);
         dEs[tid] = s;
     }
-    if (p.loss && tid == 128) {
+    if (write && p.loss && tid == 128) {
         float s = 0.0f;
         for (int d = 0; d < p.D; ++d) s += sigmoidf_(p.f[iter & 1][t * FS + d]);
         p.loss[((size_t)t * p.num_iters + iter) * NLOSS + 4] = p.c_feat_size * s / (float)p.D;
@@ -365,7 +382,7 @@ __global__ __launch_bounds__(256) void k_head(Params p, int iter) {
         if (lane == 0) { e[col] = best; erow[col] = barg; }
     }
     __syncthreads();
-    head_softmax(p, tm, t, iter, e, g, dEs);
+    head_softmax(p, tm, t, iter, true, e, g, dEs);
     if (tid < 96) {
         p.dE[t * 96 + tid] = dEs[tid];
         p.argrow[t * 96 + tid] = erow[tid];
@@ -373,17 +390,19 @@ __global__ __launch_bounds__(256) void k_head(Params p, int iter) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Node-mode head: one workgroup per target.  Only row t of the last layer is consumed by the
-// reference (explain.py:713), so this kernel computes that row (mat-vec with Abar[t,:]), the head,
-// dE, dZ3[t] and - because Abar.dZ3 is rank-1 - the whole of dZ2 and the layer-3 row g3 of G.
+// Node-mode head: one workgroup per 32-row block of a target.  Only row t of the last layer is consumed
+// by the reference (explain.py:713), so every workgroup (redundantly, it is a length-n mat-vec) computes
+// that row with Abar[t,:], the head, dE and dZ3[t]; then - because Abar.dZ3 is rank-1 - its own 32 rows
+// of dZ2 and of g3, the layer-3 row of G.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_node_head(Params p, int iter) {
+__global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* tiles, int iter) {
     __shared__ float part[8 * 32];
     __shared__ float e[96], g[CMAX], dEs[96];
     __shared__ float y3[32], dz3[32];
     __shared__ float wl[32 * 33], zs[TILE * 33];
     __shared__ float sr3;
-    const int t = blockIdx.x;
+    const ConvTile tl = tiles[blockIdx.x];
+    const int t = tl.t;
     const TargetMeta tm = p.meta[t];
     const int tid = threadIdx.x, ld = tm.ld, n = tm.n, tr = tm.t;
     const float* Ab = p.Abar + tm.offQ;
@@ -392,11 +411,20 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, int iter) {
     const float* W3 = p.wts + WT_W + 2 * 1024;
     const float* W2 = p.wts + WT_W + 1 * 1024;
 
-    // Z3[t][c] = sum_k Abar[t][k] relu(U2[k][c]) : 8 k-slices x 32 columns
+    // Z3[t][c] = sum_k Abar[t][k] relu(U2[k][c]) : 8 k-slices x 32 columns, 4 loads in flight per thread
     {
         const int c = tid & 31, sl = tid >> 5;
         float s = 0.0f;
-        for (int k = sl; k < n; k += 8) s = fmaf(Ab[(size_t)tr * ld + k], fmaxf(U2[(size_t)k * FS + c], 0.0f), s);
+        for (int k = sl; k < ld; k += 32) {  // rows >= n of Abar[t,:] are zero, U2 is finite there
+            float a[4], u[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a[q] = Ab[(size_t)tr * ld + k + 8 * q];
+                u[q] = U2[(size_t)(k + 8 * q) * FS + c];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s = fmaf(a[q], fmaxf(u[q], 0.0f), s);
+        }
         part[sl * 32 + c] = s;
         for (int e2 = tid; e2 < 1024; e2 += 256) wl[(e2 >> 5) * 33 + (e2 & 31)] = W3[e2];
     }
@@ -429,7 +457,7 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, int iter) {
         if (tid == 0) sr3 = rnorm;
     }
     __syncthreads();
-    head_softmax(p, tm, t, iter, e, g, dEs);
+    head_softmax(p, tm, t, iter, tl.rb == 0, e, g, dEs);
     // dZ3[t] : backward through the last layer's normalisation and W3 (row t only)
     if (tid < 64) {
         const int c = tid & 31;
@@ -449,39 +477,37 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, int iter) {
     }
     __syncthreads();
     for (int e2 = tid; e2 < 1024; e2 += 256) wl[(e2 >> 5) * 33 + (e2 & 31)] = W2[e2];
-    // g3[j] = dZ3[t] . relu(U2[j]) : layer-3 part of row t of dL/dAbar
-    for (int j = tid; j < ld; j += 256) {
-        float s = 0.0f;
-        if (j < n)
-            for (int k = 0; k < p.H; ++k) s = fmaf(dz3[k], fmaxf(U2[(size_t)j * FS + k], 0.0f), s);
-        p.g3[tm.offR + j] = s;
-    }
-    // dZ2 for every row: dX2[i] = Abar[i][t] dZ3[t] (+ dE2 on row t), then the row-local backward of layer 2
+    // this block's 32 rows: dX2[i] = Abar[i][t] dZ3[t] (+ dE2 on row t), row-local backward of layer 2 -> dZ2;
+    // g3[i] = dZ3[t] . relu(U2[i]) (layer-3 part of row t of dL/dAbar)
     const int row = tid >> 3, cg = (tid & 7) * 4;
+    const int i = tl.rb * TILE + row;
+    const float ait = Ab[(size_t)tr * ld + i];  // Abar[t][i] == Abar[i][t]
+    float du[4], u[4], dz[4];
+    float gpart = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = cg + j;
+        u[j] = U2[(size_t)i * FS + c];
+        gpart = fmaf(dz3[c], fmaxf(u[j], 0.0f), gpart);  // dz3[c] == 0 for c >= H
+        float dx = ait * dz3[c];
+        if (i == tr) dx += dEs[32 + c];
+        dx = (u[j] > 0.0f) ? dx : 0.0f;
+        du[j] = (c < p.H) ? dx : 0.0f;
+    }
+    gpart += __shfl_xor(gpart, 1);
+    gpart += __shfl_xor(gpart, 2);
+    gpart += __shfl_xor(gpart, 4);
+    if ((tid & 7) == 0) p.g3[tm.offR + i] = (i < n) ? gpart : 0.0f;
+    rowlocal_backward(du, u, p.rn[1][tm.offR + i], p.H, row, cg, zs, wl, dz);
     float* dZ = p.dZ[1] + tm.offR * FS;
     float* dZT = p.dZT[1] + tm.offR * FS;
-    for (int r0 = 0; r0 < ld; r0 += TILE) {
-        const int i = r0 + row;
-        const float ait = Ab[(size_t)tr * ld + i];  // Abar[t][i] == Abar[i][t]
-        float du[4], u[4], dz[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = cg + j;
-            u[j] = U2[(size_t)i * FS + c];
-            float dx = ait * dz3[c];
-            if (i == tr) dx += dEs[32 + c];
-            dx = (u[j] > 0.0f) ? dx : 0.0f;
-            du[j] = (c < p.H) ? dx : 0.0f;
-        }
-        rowlocal_backward(du, u, p.rn[1][tm.offR + i], p.H, row, cg, zs, wl, dz);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float v = (cg + j < p.H) ? dz[j] : 0.0f;
-            dZ[(size_t)i * FS + cg + j] = v;
-            dZT[(size_t)(cg + j) * ld + i] = v;
-        }
+    for (int j = 0; j < 4; ++j) {
+        const float v = (cg + j < p.H) ? dz[j] : 0.0f;
+        dZ[(size_t)i * FS + cg + j] = v;
+        dZT[(size_t)(cg + j) * ld + i] = v;
     }
-    if (tid < 96) {
+    if (tl.rb == 0 && tid < 96) {
         p.dE[t * 96 + tid] = dEs[tid];
         p.argrow[t * 96 + tid] = tr;
     }
@@ -494,7 +520,7 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, int iter) {
 //   UPDATE=true  : gradient + Adam step, then (WRITE_ABAR) the next Abar
 //   NODE         : layer-3 part of G is the rank-2 term built from g3 (node mode)
 // ---------------------------------------------------------------------------------------------
-template <bool UPDATE, bool WRITE_ABAR, bool NODE>
+template <bool UPDATE, bool WRITE_ABAR, bool NODE, bool LOSS>
 __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, int iter, float step_size, float bc2s) {
     __shared__ float sM[TILE * 33], sm[TILE * 33], sv[TILE * 33], sS[TILE * 33];
     const MaskTile tl = tiles[blockIdx.x];
@@ -563,6 +589,7 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
     __syncthreads();
 
     const float inv_n2 = 1.0f / ((float)n * (float)n);
+    const float inv_bc2s = 1.0f / bc2s;
     const bool lapl = UPDATE && !p.graph_mode;
     float yj = 0.0f, g3j = 0.0f;
     if (lapl) yj = p.yhat[tm.offR + J0 + li];
@@ -599,18 +626,19 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
                 float Mji = sM[j * 33 + i], mji = sm[j * 33 + i], vji = sv[j * 33 + i];
                 const float Sji = sigmoidf_(Mji);
                 Sji_old = Sji;
-                const float gji = (gc + p.c_size + p.c_ent * (logf(1.0f - Sji) - logf(Sji)) * inv_n2) * Sji * (1.0f - Sji);
-                adam_update(Mji, mji, vji, gji, p.beta1, p.beta2, p.eps, step_size, bc2s);
+                // d(entropy)/dS = log(1-S) - log(S) = -M exactly (S = sigma(M)): no logs on the update path
+                const float gji = (gc + p.c_size - p.c_ent * Mji * inv_n2) * Sji * (1.0f - Sji);
+                adam_update(Mji, mji, vji, gji, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
                 sM[j * 33 + i] = Mji;
                 sm[j * 33 + i] = mji;
                 sv[j * 33 + i] = vji;
                 sS[j * 33 + i] = sigmoidf_(Mji);
-                if (p.loss && valid) {
+                if (LOSS && valid) {
                     s_size += Sji;
                     s_ent += -Sji * logf(Sji) - (1.0f - Sji) * logf(1.0f - Sji);
                 }
             }
-            if (p.loss && valid) {
+            if (LOSS && valid) {
                 s_size += Sij;
                 s_ent += -Sij * logf(Sij) - (1.0f - Sij) * logf(1.0f - Sij);
                 if (lapl) {
@@ -620,9 +648,9 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
                     if (!diag) s_lap += ab * (yi * yi - yi * yj);
                 }
             }
-            const float gij = (gc + p.c_size + p.c_ent * (logf(1.0f - Sij) - logf(Sij)) * inv_n2) * Sij * (1.0f - Sij);
+            const float gij = (gc + p.c_size - p.c_ent * Mij * inv_n2) * Sij * (1.0f - Sij);
             float mij = mo[r], vij = vo[r];
-            adam_update(Mij, mij, vij, gij, p.beta1, p.beta2, p.eps, step_size, bc2s);
+            adam_update(Mij, mij, vij, gij, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
             if (valid) {
                 p.M[own] = Mij;
                 p.mM[own] = mij;
@@ -662,7 +690,7 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
             if (WRITE_ABAR) p.Abar[gidx] = sS[row * 33 + li];
         }
     }
-    if (UPDATE && p.loss) {
+    if (UPDATE && LOSS) {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
             s_size += __shfl_xor(s_size, o);
@@ -685,7 +713,7 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
         for (int rb = 0; rb < (ld >> 5); ++rb) dsum += p.df[((size_t)(tm.offR >> 5) + rb) * FS + lane];
         const float gf = (dsum + p.c_feat_size / (float)p.D) * ph * (1.0f - ph);
         float fnew = fcur, m = p.mf[o], v = p.vf[o];
-        adam_update(fnew, m, v, gf, p.beta1, p.beta2, p.eps, step_size, bc2s);
+        adam_update(fnew, m, v, gf, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
         p.mf[o] = m;
         p.vf[o] = v;
         p.f[(iter + 1) & 1][o] = fnew;

@@ -22,7 +22,7 @@ def build(force=False):
     cxx = "/opt/rocm/lib/llvm/bin/clang++"
     if not os.path.exists(cxx):
         cxx = "clang++"
-    cmd = [cxx, "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=on", "-I", os.path.join(HERE, "include"),
+    cmd = [cxx, "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=on", "-Wno-psabi", "-I", os.path.join(HERE, "include"),
            "-x", "c++", srcs[0], srcs[2], "-o", OUT]
     subprocess.check_call(cmd)
     return OUT

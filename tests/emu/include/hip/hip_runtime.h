@@ -52,6 +52,9 @@ inline void __syncthreads() { emu::syncthreads(); }
 inline float __shfl_xor(float v, int m) { return emu::shfl_xor_f(v, m); }
 inline int __shfl_xor(int v, int m) { return emu::shfl_xor_i(v, m); }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2((a), (b), (c))
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_sqrtf(x) std::sqrt(x)
+#define __expf(x) std::exp(x)
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "ok" : "emulator: unsupported"; }
