@@ -1,0 +1,304 @@
+"""Drop-in `Explainer` / `ExplainModule` behind which the mask optimisation runs on the MI355X engine.
+
+Same constructor and method signatures, argument meaning, return types, output files and error behaviour
+as the reference's explainer/explain.py (Explainer :42-579, ExplainModule :582-820), for the
+mask-optimisation path (`model="exp"`, `unconstrained=False`, sigmoid mask, Adam):
+
+  * `explain()` returns the float64 [n, n] `masked_adj * sub_adj` of the LAST forward and writes
+    `<logdir>/masked_adj_<prefix>node_idx_<i>graph_idx_<g>.npy` (explain.py:208-221);
+  * `explain_nodes`, `explain_nodes_gnn_stats`, `explain_graphs` return `list[np.ndarray]` — but the list
+    comprehension over targets (explain.py:234-236, 296-299, 362-363) is ONE batched GPU job;
+  * the initial edge masks are drawn from the caller's global torch CPU generator, one `normal_` per target
+    in list order, exactly like `construct_edge_mask` (explain.py:645-652), so seeded runs reproduce the
+    reference's masks.
+
+Options the HIP path does not implement raise NotImplementedError (never a silent difference):
+`mask_act="ReLU"`, `--mask-bias`, `--bn`, `method="att"`, non-Adam optimisers / LR schedulers,
+`unconstrained=True`, `model="grad"/"att"`, num_gc_layers != 3.
+Plotting / TensorBoard / alignment post-processing of the reference is out of scope.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..engine import FEAT_STRIDE, Hyper, MaskOptimJob, Subgraph, init_edge_mask
+from ..utils import io_utils
+from ..utils.graph_utils import KHopIndex
+
+COEFFS = {"size": 0.005, "feat_size": 1.0, "ent": 1.0, "feat_ent": 0.1, "grad": 0, "lap": 1.0}  # explain.py:624-631
+
+
+def _check_supported(args):
+    if getattr(args, "mask_act", "sigmoid") != "sigmoid":
+        raise NotImplementedError("mask_act=%r: the HIP path implements the sigmoid mask" % args.mask_act)
+    if getattr(args, "mask_bias", False):
+        raise NotImplementedError("--mask-bias is not implemented on the HIP path")
+    if getattr(args, "bn", False):
+        raise NotImplementedError("--bn is not implemented on the HIP path")
+    if getattr(args, "method", "base") != "base":
+        raise NotImplementedError("method=%r: only 'base' is implemented on the HIP path" % args.method)
+    if getattr(args, "opt", "adam") != "adam" or getattr(args, "opt_scheduler", "none") != "none":
+        raise NotImplementedError("only Adam without LR scheduler (utils/train_utils.py:9-10, 17-18) is implemented")
+    if getattr(args, "num_gc_layers", 3) != 3:
+        raise NotImplementedError("num_gc_layers=%r: the HIP path implements 3 layers" % args.num_gc_layers)
+
+
+def _hyper(args, **kw):
+    return Hyper(num_iters=int(args.num_epochs), lr=float(args.lr), c_size=COEFFS["size"], c_feat_size=COEFFS["feat_size"],
+                 c_ent=COEFFS["ent"], c_lap=COEFFS["lap"], **kw)
+
+
+def _np(a):
+    return a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+
+
+class Explainer:
+    def __init__(self, model, adj, feat, label, pred, train_idx, args, writer=None, print_training=True,
+                 graph_mode=False, graph_idx=False):
+        self.model = model
+        self.model.eval()
+        self.adj = adj
+        self.feat = feat
+        self.label = label
+        self.pred = pred
+        self.train_idx = train_idx
+        self.n_hops = args.num_gc_layers
+        self.graph_mode = graph_mode
+        self.graph_idx = graph_idx
+        self.args = args
+        self.writer = writer
+        self.print_training = print_training
+        _check_supported(args)
+        self._khop = {}             # graph index -> KHopIndex (sparse; replaces the dense utils/graph_utils.py:147-158)
+        self.last_result = None     # JobResult of the most recent batch (feature masks, loss traces)
+        self.last_time = None
+
+    # -- neighbourhoods ------------------------------------------------------------------------
+    def _index(self, graph_idx):
+        if graph_idx not in self._khop:
+            self._khop[graph_idx] = KHopIndex(_np(self.adj[graph_idx]), self.n_hops)
+        return self._khop[graph_idx]
+
+    @property
+    def neighborhoods(self):
+        """Dense [G, N, N] int matrix like the reference attribute — built on demand, small graphs only."""
+        if self.graph_mode:
+            return None
+        out = []
+        for g in range(len(self.adj)):
+            idx = self._index(g)
+            m = np.zeros((idx.num_nodes, idx.num_nodes), dtype=int)
+            for v in range(idx.num_nodes):
+                m[v, idx.neighbors(v)] = 1
+            out.append(m)
+        return np.stack(out)
+
+    def extract_neighborhood(self, node_idx, graph_idx=0):
+        """Returns (node_idx_new, sub_adj, sub_feat, sub_label, neighbors) — explain.py:492-501."""
+        node_idx_new, sub_adj, neighbors = self._index(graph_idx).extract(node_idx)
+        sub_adj = sub_adj.astype(_np(self.adj).dtype)
+        sub_feat = _np(self.feat)[graph_idx, neighbors]
+        sub_label = _np(self.label)[graph_idx][neighbors]
+        return node_idx_new, sub_adj, sub_feat, sub_label, neighbors
+
+    # -- batched core --------------------------------------------------------------------------
+    def _node_subgraph(self, node_idx, graph_idx):
+        node_idx_new, sub_adj, sub_feat, sub_label, neighbors = self.extract_neighborhood(node_idx, graph_idx)
+        if len(neighbors) == 0:
+            raise IndexError("node %d has an empty %d-hop neighbourhood" % (node_idx, self.n_hops))
+        pred_label = np.argmax(_np(self.pred)[graph_idx][neighbors], axis=1)          # explain.py:105
+        gt = int(sub_label[node_idx_new])                                              # explain.py:751
+        return Subgraph(np.asarray(sub_adj, np.float32), np.asarray(sub_feat, np.float32), gt, int(node_idx_new),
+                        pred_label, None), sub_adj
+
+    def _graph_subgraph(self, graph_idx):
+        sub_adj = _np(self.adj[graph_idx])                                             # explain.py:82-85
+        sub_feat = _np(self.feat[graph_idx])
+        gt = int(_np(self.label[graph_idx]))
+        return Subgraph(np.asarray(sub_adj, np.float32), np.asarray(sub_feat, np.float32), gt, 0, None, None), sub_adj
+
+    def explain_batch(self, node_indices=None, graph_indices=None, graph_idx=0, record_loss=False, use_graph=True):
+        """All targets as ONE job on the GPU. Returns list of float64 masked adjacencies (reference layout)."""
+        if self.graph_mode or graph_indices is not None:
+            targets = list(graph_indices)
+            built = [self._graph_subgraph(g) for g in targets]
+            mode = True
+        else:
+            targets = list(node_indices)
+            built = [self._node_subgraph(v, graph_idx) for v in targets]
+            mode = False
+        subs = [b[0] for b in built]
+        for s in subs:                                   # same RNG stream as ExplainModule.__init__ per target
+            s.mask0 = init_edge_mask(s.adj.shape[0])
+        begin = time.time()
+        job = MaskOptimJob(subs, self.model.state_dict(), graph_mode=mode)
+        hy = _hyper(self.args, record_loss=record_loss, use_graph=use_graph and len(subs) > 1)
+        res = job.run([s.mask0 for s in subs], hy)
+        job.close()
+        self.last_time = time.time() - begin
+        self.last_result = res
+        # explain.py:209-211: float32 mask * float64 sub_adj -> float64
+        return [ma.astype(np.float64) * np.asarray(sa, np.float64) for ma, (_, sa) in zip(res.masked_adj, built)]
+
+    def _save(self, masked_adj, node_idx):
+        fname = "masked_adj_" + io_utils.gen_explainer_prefix(self.args) + (
+            "node_idx_" + str(node_idx) + "graph_idx_" + str(self.graph_idx) + ".npy")
+        with open(os.path.join(self.args.logdir, fname), "wb") as outfile:
+            np.save(outfile, np.asarray(masked_adj.copy()))
+        return fname
+
+    # -- reference API ---------------------------------------------------------------------------
+    def explain(self, node_idx, graph_idx=0, graph_mode=False, unconstrained=False, model="exp"):
+        """Explain a single node (or graph) prediction — explain.py:74-221."""
+        if unconstrained:
+            raise NotImplementedError("unconstrained=True is not implemented on the HIP path")
+        if model != "exp":
+            raise NotImplementedError("model=%r: only the mask optimisation ('exp') is implemented" % model)
+        if graph_mode:
+            masked_adj = self.explain_batch(graph_indices=[graph_idx], record_loss=self.print_training)[0]
+        else:
+            masked_adj = self.explain_batch(node_indices=[node_idx], graph_idx=graph_idx,
+                                            record_loss=self.print_training)[0]
+        if self.print_training and self.last_result.loss is not None:
+            tr = self.last_result.loss[0]
+            for epoch in (0, len(tr) - 1):
+                print("epoch: ", epoch, "; loss: ", float(tr[epoch, :5].sum()))
+        print("finished training in ", self.last_time)
+        fname = self._save(masked_adj, node_idx)
+        print("Saved adjacency matrix to ", fname)
+        return masked_adj
+
+    def explain_nodes(self, node_indices, args, graph_idx=0):
+        """explain.py:225-292 without the alignment / plotting post-processing."""
+        masked_adjs = self.explain_batch(node_indices=node_indices, graph_idx=graph_idx)
+        for v, ma in zip(node_indices, masked_adjs):
+            self._save(ma, v)
+        return masked_adjs
+
+    def explain_nodes_gnn_stats(self, node_indices, args, graph_idx=0, model="exp"):
+        """explain.py:295-353: batch explanation + the ROC-AUC text file (no plots)."""
+        if model != "exp":
+            raise NotImplementedError("model=%r: only 'exp' is implemented" % model)
+        node_indices = list(node_indices)
+        masked_adjs = self.explain_batch(node_indices=node_indices, graph_idx=graph_idx)
+        pred_all, real_all = [], []
+        for v, ma in zip(node_indices, masked_adjs):
+            self._save(ma, v)
+            new_idx = self._index(graph_idx).extract(v)[0]
+            pr = self.make_pred_real(ma, new_idx)
+            if pr is not None:
+                pred_all.append(pr[0])
+                real_all.append(pr[1])
+        if pred_all:
+            from sklearn.metrics import roc_auc_score
+            pred_all, real_all = np.concatenate(pred_all), np.concatenate(real_all)
+            if 0 < real_all.sum() < len(real_all):
+                self.last_auc = float(roc_auc_score(real_all, pred_all))
+                os.makedirs("log/pr", exist_ok=True)
+                with open("log/pr/auc_" + self.args.dataset + "_" + model + ".txt", "w") as f:
+                    f.write("dataset: {}, model: {}, auc: {}\n".format(self.args.dataset, "exp", str(self.last_auc)))
+        return masked_adjs
+
+    def explain_graphs(self, graph_indices):
+        """explain.py:356-402 without denoise/plot logging."""
+        graph_indices = list(graph_indices)
+        masked_adjs = self.explain_batch(graph_indices=graph_indices)
+        for g, ma in zip(graph_indices, masked_adjs):
+            self._save(ma, 0)
+        return masked_adjs
+
+    def make_pred_real(self, adj, start):
+        """Motif ground truth for syn1/syn2 (house) and syn4 (cycle) — explain.py:535-579."""
+        ds = getattr(self.args, "dataset", None)
+        if ds in ("syn1", "syn2"):
+            motif = [(0, 1), (1, 2), (2, 3), (0, 3), (0, 4), (1, 4)]
+        elif ds == "syn4":
+            motif = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (0, 5)]
+        else:
+            return None
+        if start + max(max(m) for m in motif) >= adj.shape[0]:
+            return None
+        pred = adj[np.triu(adj) > 0]
+        real = adj.copy()
+        for a, b in motif:
+            if real[start + a][start + b] > 0:
+                real[start + a][start + b] = 10
+        real = real[np.triu(real) > 0]
+        real[real != 10] = 0
+        real[real == 10] = 1
+        return pred, real
+
+
+class ExplainModule(nn.Module):
+    """One target's mask parameters with the reference's attribute surface (explain.py:582-715).
+
+    `mask`, `feat_mask`, `masked_adj`, `forward`, `loss`, `mask_density` behave like the reference; the
+    `num_epochs` loop itself is `optimize()` — one fused call into the HIP engine instead of
+    zero_grad / forward / loss / backward / optimizer.step per epoch (explain.py:137-146)."""
+
+    def __init__(self, adj, x, model, label, args, graph_idx=0, writer=None, use_sigmoid=True, graph_mode=False,
+                 node_idx=0, pred_label=None):
+        super().__init__()
+        _check_supported(args)
+        if not use_sigmoid:
+            raise NotImplementedError("use_sigmoid=False is not implemented on the HIP path")
+        self.adj, self.x, self.model, self.label = adj, x, model, label
+        self.graph_idx, self.args, self.writer, self.graph_mode = graph_idx, args, writer, graph_mode
+        self.mask_act = args.mask_act
+        n = adj.size()[1]
+        self.mask = nn.Parameter(torch.from_numpy(init_edge_mask(n)))          # explain.py:645-652
+        self.feat_mask = nn.Parameter(torch.zeros(x.size(-1)))                  # explain.py:639-641
+        self.mask_bias = None
+        self.diag_mask = torch.ones(n, n) - torch.eye(n)
+        self.coeffs = dict(COEFFS)
+        self.scheduler = None
+        self.masked_adj = None
+        self._node_idx = int(node_idx)
+        lab = _np(label)
+        gt = int(lab) if graph_mode else int(lab.reshape(-1)[self._node_idx])
+        self._sub = Subgraph(_np(adj)[0].astype(np.float32), _np(x)[0].astype(np.float32), gt, self._node_idx,
+                             None if graph_mode else np.asarray(pred_label), None)
+        self._job = MaskOptimJob([self._sub], model.state_dict(), graph_mode=graph_mode)
+
+    def forward(self, node_idx, unconstrained=False, mask_features=True, marginalize=False):
+        if unconstrained or marginalize or not mask_features:
+            raise NotImplementedError("only the default forward (explain.py:693-707) is implemented")
+        if not self.graph_mode and int(node_idx) != self._node_idx:
+            raise ValueError("ExplainModule was built for node_idx=%d" % self._node_idx)
+        probs, ma = self._job.forward([self.mask.detach().numpy()], self.feat_mask.detach().numpy()[None])
+        self.masked_adj = torch.from_numpy(ma[0])[None]
+        return torch.from_numpy(probs[0].copy()), None
+
+    def mask_density(self):
+        if self.masked_adj is None:
+            self.forward(self._node_idx)
+        return self.masked_adj.sum() / torch.as_tensor(_np(self.adj)).sum()      # explain.py:680-683
+
+    def loss(self, pred, pred_label, node_idx, epoch):
+        """Scalar loss of the current parameters (explain.py:740-808), evaluated on the host from the engine's
+        forward; logging only — the optimisation itself is `optimize()`."""
+        m = torch.sigmoid(self.mask.detach())
+        fm = torch.sigmoid(self.feat_mask.detach())
+        gt = self._sub.gt_label
+        out = -torch.log(pred[gt]) + self.coeffs["size"] * m.sum() + self.coeffs["feat_size"] * fm.mean()
+        out = out + self.coeffs["ent"] * (-m * torch.log(m) - (1 - m) * torch.log(1 - m)).mean()
+        if not self.graph_mode:
+            y = torch.tensor(np.asarray(pred_label), dtype=torch.float)
+            ma = self.masked_adj[0]
+            out = out + self.coeffs["lap"] * (y @ (torch.diag(ma.sum(0)) - ma) @ y) / ma.numel()
+        return out
+
+    def optimize(self, num_epochs=None, record_loss=False):
+        """The hot loop (explain.py:137-146) on the GPU; updates mask / feat_mask / masked_adj in place."""
+        hy = _hyper(self.args, record_loss=record_loss)
+        if num_epochs is not None:
+            hy.num_iters = int(num_epochs)
+        res = self._job.run([self.mask.detach().numpy()], hy)
+        with torch.no_grad():
+            self.mask.copy_(torch.from_numpy(res.mask[0]))
+            self.feat_mask.copy_(torch.from_numpy(res.feat_mask[0]))
+        self.masked_adj = torch.from_numpy(res.masked_adj[0])[None]
+        return res

@@ -1,0 +1,139 @@
+"""Drop-in API tests: the Explainer/ExplainModule mirror of explainer/explain.py, seeded like the reference's
+golden runs.  On CPU the engine is swapped for the emulator build of the same sources (tests/emu); on a GPU
+box the same assertions run against libgnnx_hip.so (marked gpu)."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from gnn_model_explainer_amd import models
+from gnn_model_explainer_amd.explainer import explain
+
+TOL = 1e-5
+
+
+def _args(tmp, epochs, dataset="syn1", **kw):
+    a = argparse.Namespace(logdir=str(tmp), ckptdir=str(tmp), dataset=dataset, bmname=None, opt="adam",
+                           opt_scheduler="none", lr=0.1, num_epochs=epochs, hidden_dim=20, output_dim=20,
+                           num_gc_layers=3, method="base", name_suffix="", explainer_suffix="", graph_idx=-1,
+                           mask_act="sigmoid", mask_bias=False, bn=False, bias=True, gpu=True)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def _explainer(tmp, epochs, name="syn1", **kw):
+    ck = helpers.load_ckpt(name)
+    args = _args(tmp, epochs, name, **kw)
+    model = models.GcnEncoderNode(ck["feat"].shape[1], 20, 20, ck["pred"].shape[1], 3, bn=False, args=args)
+    model.load_state_dict({k: torch.tensor(v) for k, v in ck["sd"].items()})
+    ex = explain.Explainer(model, ck["adj"][None].astype(np.float64), ck["feat"][None].astype(np.float64),
+                           ck["label"][None], ck["pred"][None], None, args, writer=None, print_training=False,
+                           graph_mode=False, graph_idx=-1)
+    return ck, args, ex
+
+
+@pytest.fixture
+def emu_engine(monkeypatch):
+    from emu.emu_engine import emu_job
+    monkeypatch.setattr(explain, "MaskOptimJob", lambda subs, sd, graph_mode=False: emu_job(subs, sd, graph_mode))
+    real_hyper = explain._hyper
+
+    def no_graph_hyper(args, **kw):          # the emulator has no hipGraph: plain launches, same kernels
+        kw["use_graph"] = False
+        return real_hyper(args, **kw)
+    monkeypatch.setattr(explain, "_hyper", no_graph_hyper)
+
+
+def _check_against_golden(ex, args, gx, t, tmp, epochs_full):
+    torch.manual_seed(1000 + t)                                  # the golden seed protocol
+    ma = ex.explain(t)
+    assert ma.dtype == np.float64
+    nb = gx[f"{t}:neighbors"]
+    assert ma.shape == (len(nb), len(nb))
+    f = os.path.join(str(tmp), "masked_adj_syn1_base_h20_o20_explainnode_idx_%dgraph_idx_-1.npy" % t)
+    assert np.array_equal(np.load(f), ma)                        # same file name and content as the reference writes
+    if epochs_full:
+        rc = gx[f"{t}:edge_rc"]
+        assert np.abs(ma[rc[:, 0], rc[:, 1]] - gx[f"{t}:masked_adj_edges"]).max() <= TOL
+        fm = 1 / (1 + np.exp(-ex.last_result.feat_mask[0]))
+        assert np.abs(fm - gx[f"{t}:feat_mask_sigmoid"]).max() <= TOL
+
+
+def test_explain_single_node_matches_reference_emulated(tmp_path, emu_engine):
+    gx = helpers.load_explain("syn1")
+    ck, args, ex = _explainer(tmp_path, int(gx["epochs"]))
+    _check_against_golden(ex, args, gx, 302, tmp_path, True)
+
+
+def test_extract_neighborhood_contract(tmp_path, emu_engine):
+    gx = helpers.load_explain("syn1")
+    ck, args, ex = _explainer(tmp_path, 3)
+    new, sub_adj, sub_feat, sub_label, nb = ex.extract_neighborhood(309)
+    assert new == int(gx["309:node_idx_new"]) and np.array_equal(nb, gx["309:neighbors"])
+    assert sub_adj.dtype == np.float64 and sub_adj.shape == (len(nb), len(nb))
+    assert sub_feat.shape == (len(nb), 10) and np.array_equal(sub_label, ck["label"][nb])
+    assert np.array_equal(ex.neighborhoods[0][309].nonzero()[0], nb)
+
+
+def test_batched_list_api_equals_sequential_explains(tmp_path, emu_engine):
+    """explain_nodes([...]) (one batched job) == [explain(i) ...] with the same RNG stream."""
+    ck, args, ex = _explainer(tmp_path, 4)
+    torch.manual_seed(7)
+    seq = [ex.explain(v) for v in (302, 309)]
+    torch.manual_seed(7)
+    bat = ex.explain_nodes([302, 309], args)
+    for a, b in zip(seq, bat):
+        assert np.array_equal(a, b)
+
+
+def test_unsupported_options_raise(tmp_path):
+    for kw in ({"mask_act": "ReLU"}, {"mask_bias": True}, {"bn": True}, {"opt": "sgd"}, {"num_gc_layers": 4}):
+        with pytest.raises(NotImplementedError):
+            _explainer(tmp_path, 3, **kw)
+    ck, args, ex = _explainer(tmp_path, 3)
+    with pytest.raises(NotImplementedError):
+        ex.explain(302, unconstrained=True)
+    with pytest.raises(NotImplementedError):
+        ex.explain(302, model="grad")
+
+
+def test_explain_module_surface_emulated(tmp_path, emu_engine):
+    gx = helpers.load_explain("syn1")
+    ck, args, ex = _explainer(tmp_path, 5)
+    t = 302
+    new, sub_adj, sub_feat, sub_label, nb = ex.extract_neighborhood(t)
+    pl = np.argmax(ck["pred"][nb], 1)
+    torch.manual_seed(1000 + t)
+    mod = explain.ExplainModule(torch.tensor(sub_adj[None], dtype=torch.float), torch.tensor(sub_feat[None], dtype=torch.float),
+                                ex.model, torch.tensor(sub_label[None]), args, graph_idx=-1, node_idx=new, pred_label=pl)
+    assert np.array_equal(mod.mask.detach().numpy(), gx[f"{t}:mask0"])       # same init stream as the reference
+    pred, _ = mod.forward(new)
+    assert abs(float(pred.sum()) - 1) < 1e-5 and mod.masked_adj.shape == (1, len(nb), len(nb))
+    loss0 = float(mod.loss(pred, pl, new, 0))
+    assert abs(loss0 - float(gx[f"{t}:loss"][0])) < 1e-4                     # reference's epoch-0 loss
+    assert 0 < float(mod.mask_density()) < 1
+    mod.optimize(5)
+    assert not np.array_equal(mod.mask.detach().numpy(), gx[f"{t}:mask0"])
+
+
+@pytest.mark.gpu
+def test_explain_matches_reference_on_gpu(tmp_path):
+    gx = helpers.load_explain("syn1")
+    ck, args, ex = _explainer(tmp_path, int(gx["epochs"]))
+    for t in (302, 555):
+        _check_against_golden(ex, args, gx, t, tmp_path, True)
+
+
+@pytest.mark.gpu
+def test_explain_nodes_gnn_stats_auc_on_gpu(tmp_path, monkeypatch):
+    """The reference's only quantitative check (ROC-AUC vs motif ground truth, explain.py:328-351)."""
+    monkeypatch.chdir(tmp_path)
+    ck, args, ex = _explainer(tmp_path, 100)
+    torch.manual_seed(0)
+    out = ex.explain_nodes_gnn_stats(range(400, 700, 5), args)
+    assert len(out) == 60 and ex.last_auc > 0.8
+    assert os.path.exists("log/pr/auc_syn1_exp.txt")
