@@ -520,7 +520,9 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
 //   UPDATE=true  : gradient + Adam step, then (WRITE_ABAR) the next Abar
 //   NODE         : layer-3 part of G is the rank-2 term built from g3 (node mode)
 // ---------------------------------------------------------------------------------------------
-template <bool UPDATE, bool WRITE_ABAR, bool NODE, bool LOSS>
+//   DS, HS       : k-steps (pairs of columns) of layers 1 / 2 held in registers: (5, 10) for the default
+//                  D <= 10, H <= 20 encoder, (8, 16) for anything up to 16 / 32 (keeps the VGPR count < 256)
+template <bool UPDATE, bool WRITE_ABAR, bool NODE, bool LOSS, int DS, int HS>
 __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, int iter, float step_size, float bc2s) {
     __shared__ float sM[TILE * 33], sm[TILE * 33], sv[TILE * 33], sS[TILE * 33];
     const MaskTile tl = tiles[blockIdx.x];
@@ -549,21 +551,67 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
         if (UPDATE && !diag) { sm[row * 33 + li] = p.mM[gidx]; sv[row * 33 + li] = p.vM[gidx]; }
     }
 
+    // operands of the G-tile product: ALL loads are issued here, together with the state loads above, so the
+    // wave pays one DRAM round trip instead of one per k-batch (this kernel is latency-bound otherwise)
+    const size_t ro = (size_t)tm.offR * FS;
+    float zi0[DS], zj0[DS], xi0[DS], xj0[DS];  // layer 1, k = 2u+h < 2 DS
+    float zi1[HS], zj1[HS], xi1[HS], xj1[HS];  // layer 2, k = 2u+h < 2 HS
+    if (UPDATE) {
+        const float* zT0 = p.dZT[0] + ro;
+        const float* xT0 = p.XT + ro;
+        const float* zT1 = p.dZT[1] + ro;
+        const float* xT1 = p.UT[0] + ro;
+        const float* fcur = p.f[iter & 1] + tl.t * FS;
+#pragma unroll
+        for (int u = 0; u < DS; ++u) {
+            const int k = 2 * u + h;  // columns >= D hold zeros in dZT; phi = 0 there
+            const bool on = 2 * u < p.D;
+            const float phi = (on && k < p.D) ? sigmoidf_(fcur[k]) : 0.0f;
+            zi0[u] = on ? zT0[(size_t)k * ld + I0 + li] : 0.0f;
+            zj0[u] = on ? zT0[(size_t)k * ld + J0 + li] : 0.0f;
+            xi0[u] = on ? xT0[(size_t)k * ld + I0 + li] * phi : 0.0f;
+            xj0[u] = on ? xT0[(size_t)k * ld + J0 + li] * phi : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < HS; ++u) {
+            const int k = 2 * u + h;
+            const bool on = 2 * u < p.H;
+            zi1[u] = on ? zT1[(size_t)k * ld + I0 + li] : 0.0f;
+            zj1[u] = on ? zT1[(size_t)k * ld + J0 + li] : 0.0f;
+            xi1[u] = on ? fmaxf(xT1[(size_t)k * ld + I0 + li], 0.0f) : 0.0f;
+            xj1[u] = on ? fmaxf(xT1[(size_t)k * ld + J0 + li], 0.0f) : 0.0f;
+        }
+    }
+
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     if (UPDATE) {
-        const size_t ro = (size_t)tm.offR * FS;
-        constexpr int NL = NODE ? 2 : 3;
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {
+        for (int u = 0; u < DS; ++u) {
+            if (2 * u < p.D) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zi0[u], xj0[u], acc, 0, 0, 0);  // G[i][j]
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xi0[u], zj0[u], acc, 0, 0, 0);  // G[j][i]
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < HS; ++u) {
+            if (2 * u < p.H) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zi1[u], xj1[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xi1[u], zj1[u], acc, 0, 0, 0);
+            }
+        }
+        // rare shapes: input dim > 16 (rest of layer 1) and, in graph mode, layer 3 (dense dZ3)
+        for (int l = 0; l < 3; l += 2) {
+            if (l == 0 && p.D <= 2 * DS) continue;
+            if (l == 2 && NODE) continue;
             const int d = (l == 0) ? p.D : p.H;
             const float* zT = p.dZT[l] + ro;
-            const float* xT = (l == 0) ? p.XT + ro : p.UT[l - 1] + ro;
-            for (int s0 = 0; s0 < d; s0 += 8) {
+            const float* xT = (l == 0) ? p.XT + ro : p.UT[1] + ro;
+            for (int s0 = (l == 0) ? 2 * DS : 0; s0 < d; s0 += 8) {
                 float zi[4], zj[4], xi[4], xj[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {  // 4 k-steps of loads in flight; columns >= d hold zeros (k < 32)
+                for (int u = 0; u < 4; ++u) {
                     const int k = s0 + 2 * u + h;
                     zi[u] = zT[(size_t)k * ld + I0 + li];
                     zj[u] = zT[(size_t)k * ld + J0 + li];
@@ -580,8 +628,8 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zi[u], xj[u], acc, 0, 0, 0);  // G[i][j]
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xi[u], zj[u], acc, 0, 0, 0);  // G[j][i]
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zi[u], xj[u], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xi[u], zj[u], acc, 0, 0, 0);
                 }
             }
         }
