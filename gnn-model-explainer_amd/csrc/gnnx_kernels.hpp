@@ -514,45 +514,56 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused mask kernel: one wave per tile pair {(I,J),(J,I)}, I <= J.  Every mask entry is updated by
-// exactly one lane (diagonal tiles exchange through LDS) so the result is bitwise symmetric.
+// Fused mask kernel: one wave per tile pair {(I,J),(J,I)}, I <= J.
+//   * every global access to the n x n state (M, m, v, A, Abar) is 16 B per lane (dwordx4): the
+//     elementwise work runs in a row-major layout (lane -> row 8q + lane/8, columns 4 (lane%8) .. +3) and the
+//     MFMA accumulator (G tile) and the partner tile (J,I) are transposed into it through LDS.  Narrow
+//     (4 B / lane) access caps this kernel at ~2.3 TB/s on MI355X (measured, profiles/r01_v3_pmc_*).
+//   * every mask entry is updated by exactly one lane (diagonal tiles exchange sigma through LDS) so the
+//     output is bitwise symmetric, batch-invariant and deterministic.
 //   UPDATE=false : only Abar = A * sym(sigma(M)) (initial forward)
 //   UPDATE=true  : gradient + Adam step, then (WRITE_ABAR) the next Abar
 //   NODE         : layer-3 part of G is the rank-2 term built from g3 (node mode)
-// ---------------------------------------------------------------------------------------------
+//   LOSS         : also accumulate the size / entropy / Laplacian loss terms (logging)
 //   DS, HS       : k-steps (pairs of columns) of layers 1 / 2 held in registers: (5, 10) for the default
 //                  D <= 10, H <= 20 encoder, (8, 16) for anything up to 16 / 32 (keeps the VGPR count < 256)
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 template <bool UPDATE, bool WRITE_ABAR, bool NODE, bool LOSS, int DS, int HS>
 __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, int iter, float step_size, float bc2s) {
-    __shared__ float sM[TILE * 33], sm[TILE * 33], sv[TILE * 33], sS[TILE * 33];
+    constexpr int LS = 33;  // LDS row stride
+    __shared__ float sG[TILE * LS];                                // G tile, [i][j]
+    __shared__ float sPM[TILE * LS], sPm[TILE * LS], sPv[TILE * LS];  // partner tile (J,I), natural orientation [j][i]
+    __shared__ float sS[TILE * LS];                                // sigma exchange, then Abar of the partner tile
     const MaskTile tl = tiles[blockIdx.x];
     const TargetMeta tm = p.meta[tl.t];
     const int ld = tm.ld, n = tm.n;
     const int I0 = tl.I * TILE, J0 = tl.J * TILE;
     const bool diag = (tl.I == tl.J);
     const int lane = threadIdx.x, li = lane & 31, h = lane >> 5;
-    const size_t q = tm.offQ;
+    const int rl = lane >> 3, c4 = (lane & 7) * 4;  // row-major layout: row 8q + rl, columns c4 .. c4+3
+    const size_t q0 = tm.offQ;
 
-    // ---- issue every global load first (they overlap with the MFMA chain) ----
-    float Mo[16], Ao[16], mo[16], vo[16];
+    // ---- issue every global load first: one DRAM round trip for the whole wave ----
+    f32x4 Mo[4], Ao[4], mo[4], vo[4], Mp[4], mp[4], vp[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const size_t own = q + (size_t)(I0 + acc_row(r, h)) * ld + J0 + li;
-        Mo[r] = p.M[own];
-        Ao[r] = p.A[own];
-        if (UPDATE) { mo[r] = p.mM[own]; vo[r] = p.vM[own]; }
+    for (int q = 0; q < 4; ++q) {
+        const size_t own = q0 + (size_t)(I0 + 8 * q + rl) * ld + J0 + c4;
+        const size_t par = q0 + (size_t)(J0 + 8 * q + rl) * ld + I0 + c4;
+        Mo[q] = *reinterpret_cast<const f32x4*>(p.M + own);
+        Ao[q] = *reinterpret_cast<const f32x4*>(p.A + own);
+        Mp[q] = *reinterpret_cast<const f32x4*>(p.M + par);
+        if (UPDATE) {
+            mo[q] = *reinterpret_cast<const f32x4*>(p.mM + own);
+            vo[q] = *reinterpret_cast<const f32x4*>(p.vM + own);
+            if (!diag) {
+                mp[q] = *reinterpret_cast<const f32x4*>(p.mM + par);
+                vp[q] = *reinterpret_cast<const f32x4*>(p.vM + par);
+            }
+        }
     }
-    // partner tile (J,I), row-wise (coalesced) into LDS so it can be read transposed
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-        const int row = 2 * rr + h;
-        const size_t gidx = q + (size_t)(J0 + row) * ld + I0 + li;
-        sM[row * 33 + li] = p.M[gidx];
-        if (UPDATE && !diag) { sm[row * 33 + li] = p.mM[gidx]; sv[row * 33 + li] = p.vM[gidx]; }
-    }
-
-    // operands of the G-tile product: ALL loads are issued here, together with the state loads above, so the
-    // wave pays one DRAM round trip instead of one per k-batch (this kernel is latency-bound otherwise)
+    // operands of the G-tile product (K-major copies: coalesced 128-B segments)
     const size_t ro = (size_t)tm.offR * FS;
     float zi0[DS], zj0[DS], xi0[DS], xj0[DS];  // layer 1, k = 2u+h < 2 DS
     float zi1[HS], zj1[HS], xi1[HS], xj1[HS];  // layer 2, k = 2u+h < 2 HS
@@ -582,11 +593,21 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
             xj1[u] = on ? fmaxf(xT1[(size_t)k * ld + J0 + li], 0.0f) : 0.0f;
         }
     }
-
-    f32x16 acc;
+    // partner tile -> LDS in its natural orientation [j][i]; read back transposed below
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int a = (8 * q + rl) * LS + c4 + e;
+            sPM[a] = Mp[q][e];
+            if (UPDATE && !diag) { sPm[a] = mp[q][e]; sPv[a] = vp[q][e]; }
+        }
+    }
+
     if (UPDATE) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
         for (int u = 0; u < DS; ++u) {
             if (2 * u < p.D) {
@@ -601,7 +622,7 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xi1[u], zj1[u], acc, 0, 0, 0);
             }
         }
-        // rare shapes: input dim > 16 (rest of layer 1) and, in graph mode, layer 3 (dense dZ3)
+        // rare shapes: input dim > 2 DS (rest of layer 1) and, in graph mode, layer 3 (dense dZ3)
         for (int l = 0; l < 3; l += 2) {
             if (l == 0 && p.D <= 2 * DS) continue;
             if (l == 2 && NODE) continue;
@@ -633,109 +654,138 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
                 }
             }
         }
+        // accumulator (C layout: row acc_row(r,h), column li) -> LDS [i][j]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sG[acc_row(r, h) * LS + li] = acc[r];
     }
     __syncthreads();
 
     const float inv_n2 = 1.0f / ((float)n * (float)n);
     const float inv_bc2s = 1.0f / bc2s;
     const bool lapl = UPDATE && !p.graph_mode;
-    float yj = 0.0f, g3j = 0.0f;
-    if (lapl) yj = p.yhat[tm.offR + J0 + li];
-    if (UPDATE && NODE) g3j = p.g3[tm.offR + J0 + li];
     float s_size = 0.0f, s_ent = 0.0f, s_lap = 0.0f;
-    float Sown[16];
+    f32x4 Sown[4];
 
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = acc_row(r, h), j = li;
-        const int gi = I0 + i, gj = J0 + j;
-        const bool valid = (gi < n) && (gj < n);
-        const size_t own = q + (size_t)gi * ld + gj;
-        const float Aij = Ao[r];
-        float Mij = Mo[r];
-        if (UPDATE) {
-            const float offd = (gi != gj) ? 1.0f : 0.0f;
-            float Gsum = acc[r];
-            if (NODE) {
-                if (gi == tm.t) Gsum += g3j;
-                if (gj == tm.t) Gsum += p.g3[tm.offR + gi];
-            }
-            float Gs = 0.5f * Gsum;
-            float yi = 0.0f;
-            if (lapl) {
-                yi = p.yhat[tm.offR + gi];
-                const float dy = yi - yj;
-                Gs += p.c_lap * 0.5f * dy * dy * inv_n2;
-            }
-            const float gc = Gs * Aij * offd;
-            const float Sij = sigmoidf_(Mij);
-            float Sji_old = 0.0f;
-            if (!diag) {  // this lane also owns the partner entry (j,i)
-                float Mji = sM[j * 33 + i], mji = sm[j * 33 + i], vji = sv[j * 33 + i];
-                const float Sji = sigmoidf_(Mji);
-                Sji_old = Sji;
-                // d(entropy)/dS = log(1-S) - log(S) = -M exactly (S = sigma(M)): no logs on the update path
-                const float gji = (gc + p.c_size - p.c_ent * Mji * inv_n2) * Sji * (1.0f - Sji);
-                adam_update(Mji, mji, vji, gji, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
-                sM[j * 33 + i] = Mji;
-                sm[j * 33 + i] = mji;
-                sv[j * 33 + i] = vji;
-                sS[j * 33 + i] = sigmoidf_(Mji);
-                if (LOSS && valid) {
-                    s_size += Sji;
-                    s_ent += -Sji * logf(Sji) - (1.0f - Sji) * logf(1.0f - Sji);
+    for (int q = 0; q < 4; ++q) {
+        const int i = 8 * q + rl, gi = I0 + i;
+        float yi = 0.0f, g3i = 0.0f;
+        if (lapl) yi = p.yhat[tm.offR + gi];
+        if (UPDATE && NODE) g3i = p.g3[tm.offR + gi];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = c4 + e, gj = J0 + j;
+            const bool valid = (gi < n) && (gj < n);
+            float Mij = Mo[q][e];
+            if (UPDATE) {
+                const float Aij = Ao[q][e];
+                const float offd = (gi != gj) ? 1.0f : 0.0f;
+                float Gsum = sG[i * LS + j];
+                float yj = 0.0f;
+                if (NODE) {
+                    if (gi == tm.t) Gsum += p.g3[tm.offR + gj];
+                    if (gj == tm.t) Gsum += g3i;
                 }
-            }
-            if (LOSS && valid) {
-                s_size += Sij;
-                s_ent += -Sij * logf(Sij) - (1.0f - Sij) * logf(1.0f - Sij);
+                float Gs = 0.5f * Gsum;
                 if (lapl) {
-                    if (diag) Sji_old = sigmoidf_(sM[j * 33 + i]);  // old value, logging only
-                    const float ab = Aij * 0.5f * (Sij + Sji_old) * offd;
-                    s_lap += ab * (yj * yj - yi * yj);
-                    if (!diag) s_lap += ab * (yi * yi - yi * yj);
+                    yj = p.yhat[tm.offR + gj];
+                    const float dy = yi - yj;
+                    Gs += p.c_lap * 0.5f * dy * dy * inv_n2;
                 }
+                const float gc = Gs * Aij * offd;
+                const float Sij = sigmoidf_(Mij);
+                const float Mji_old = sPM[j * LS + i];
+                float Sji_old = 0.0f;
+                if (LOSS) Sji_old = sigmoidf_(Mji_old);
+                if (!diag) {  // this lane also owns the partner entry (j,i)
+                    float Mji = Mji_old, mji = sPm[j * LS + i], vji = sPv[j * LS + i];
+                    const float Sji = sigmoidf_(Mji);
+                    // d(entropy)/dS = log(1-S) - log(S) = -M exactly (S = sigma(M)): no logs on the update path
+                    const float gji = (gc + p.c_size - p.c_ent * Mji * inv_n2) * Sji * (1.0f - Sji);
+                    adam_update(Mji, mji, vji, gji, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+                    if (valid) {
+                        sPM[j * LS + i] = Mji;
+                        sPm[j * LS + i] = mji;
+                        sPv[j * LS + i] = vji;
+                    }
+                    sS[j * LS + i] = sigmoidf_(valid ? Mji : Mji_old);
+                    if (LOSS && valid) {
+                        s_size += Sji;
+                        s_ent += -Sji * logf(Sji) - (1.0f - Sji) * logf(1.0f - Sji);
+                    }
+                }
+                if (LOSS && valid) {
+                    s_size += Sij;
+                    s_ent += -Sij * logf(Sij) - (1.0f - Sij) * logf(1.0f - Sij);
+                    if (lapl) {
+                        const float ab = Aij * 0.5f * (Sij + Sji_old) * offd;
+                        s_lap += ab * (yj * yj - yi * yj);
+                        if (!diag) s_lap += ab * (yi * yi - yi * yj);
+                    }
+                }
+                const float gij = (gc + p.c_size - p.c_ent * Mij * inv_n2) * Sij * (1.0f - Sij);
+                float mij = mo[q][e], vij = vo[q][e];
+                float Mnew = Mij;
+                adam_update(Mnew, mij, vij, gij, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+                if (valid) {  // padding entries keep their (zero) state
+                    Mij = Mnew;
+                    mo[q][e] = mij;
+                    vo[q][e] = vij;
+                }
+                Mo[q][e] = Mij;
+            } else if (!diag) {
+                sS[j * LS + i] = sigmoidf_(sPM[j * LS + i]);
             }
-            const float gij = (gc + p.c_size - p.c_ent * Mij * inv_n2) * Sij * (1.0f - Sij);
-            float mij = mo[r], vij = vo[r];
-            adam_update(Mij, mij, vij, gij, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
-            if (valid) {
-                p.M[own] = Mij;
-                p.mM[own] = mij;
-                p.vM[own] = vij;
-            }
-        } else if (!diag) {
-            sS[j * 33 + i] = sigmoidf_(sM[j * 33 + i]);
+            Sown[q][e] = sigmoidf_(Mij);
+            if (diag) sS[i * LS + j] = Sown[q][e];  // diagonal tile: publish, the partner lane reads it transposed
         }
-        Sown[r] = sigmoidf_(Mij);
-        if (diag) sS[i * 33 + j] = Sown[r];  // diagonal tile: publish, the partner lane reads it transposed
+        if (UPDATE) {
+            const size_t own = q0 + (size_t)gi * ld + J0 + c4;
+            *reinterpret_cast<f32x4*>(p.M + own) = Mo[q];
+            *reinterpret_cast<f32x4*>(p.mM + own) = mo[q];
+            *reinterpret_cast<f32x4*>(p.vM + own) = vo[q];
+        }
     }
     __syncthreads();
     if (WRITE_ABAR) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = acc_row(r, h), j = li;
-            const int gi = I0 + i, gj = J0 + j;
-            const bool valid = (gi < n) && (gj < n) && (gi != gj);
-            const float Sother = sS[j * 33 + i];
-            const float ab = valid ? Ao[r] * (0.5f * (Sown[r] + Sother)) : 0.0f;
-            p.Abar[q + (size_t)gi * ld + gj] = ab;
-            if (!diag) sS[j * 33 + i] = ab;  // same value for (j,i): stage for the coalesced row-wise store
+        for (int q = 0; q < 4; ++q) {
+            const int i = 8 * q + rl, gi = I0 + i;
+            f32x4 ab4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = c4 + e, gj = J0 + j;
+                const bool valid = (gi < n) && (gj < n) && (gi != gj);
+                const float Sother = sS[j * LS + i];
+                ab4[e] = valid ? Ao[q][e] * (0.5f * (Sown[q][e] + Sother)) : 0.0f;
+            }
+            *reinterpret_cast<f32x4*>(p.Abar + q0 + (size_t)gi * ld + J0 + c4) = ab4;
+            if (!diag) {  // same values for (j,i): stage for the row-wise store of the partner tile
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sS[(c4 + e) * LS + i] = ab4[e];
+            }
         }
         __syncthreads();
     }
     if (!diag) {
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-            const int row = 2 * rr + h;
-            const size_t gidx = q + (size_t)(J0 + row) * ld + I0 + li;
-            const bool valid = (J0 + row < n) && (I0 + li < n);
-            if (UPDATE && valid) {
-                p.M[gidx] = sM[row * 33 + li];
-                p.mM[gidx] = sm[row * 33 + li];
-                p.vM[gidx] = sv[row * 33 + li];
+        for (int q = 0; q < 4; ++q) {
+            const size_t par = q0 + (size_t)(J0 + 8 * q + rl) * ld + I0 + c4;
+            const int a = (8 * q + rl) * LS + c4;
+            if (UPDATE) {
+                f32x4 x, y, z;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x[e] = sPM[a + e]; y[e] = sPm[a + e]; z[e] = sPv[a + e]; }
+                *reinterpret_cast<f32x4*>(p.M + par) = x;
+                *reinterpret_cast<f32x4*>(p.mM + par) = y;
+                *reinterpret_cast<f32x4*>(p.vM + par) = z;
             }
-            if (WRITE_ABAR) p.Abar[gidx] = sS[row * 33 + li];
+            if (WRITE_ABAR) {
+                f32x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = sS[a + e];
+                *reinterpret_cast<f32x4*>(p.Abar + par) = w;
+            }
         }
     }
     if (UPDATE && LOSS) {
