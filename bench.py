@@ -31,20 +31,35 @@ HBM_PEAK = 8.0e12       # B/s, MI355X spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK = 157.3e12
 
 
-def build_workload(name, iters):
+def build_workload(name, iters, rank=0, num_targets=4096):
     import helpers
     from gnn_model_explainer_amd.engine import Subgraph
     from gnn_model_explainer_amd.utils.graph_utils import KHopIndex
-    if name != "syn1":
-        raise SystemExit("unknown workload " + name)
     ck = helpers.load_ckpt("syn1")
-    idx = KHopIndex((ck["num_nodes"], ck["edges"]), 3)
+    if name == "syn1":
+        idx = KHopIndex((ck["num_nodes"], ck["edges"]), 3)
+        feat, label, pred, targets = ck["feat"], ck["label"], ck["pred"], range(300, 700)
+        desc = "syn1: all 400 house-motif nodes (300..699) as one batch per GPU"
+    elif name == "ba100k":
+        # BASELINE.json configs[4]: BA-House scaled to 100k nodes (42857 BA + 11428 houses, 1 % random edges),
+        # encoder = the syn1 checkpoint (same D/H/C), targets = a fixed random sample of motif nodes per rank
+        from gnn_model_explainer_amd.utils import synthetic
+        n, edges, label = synthetic.ba_house(42857, 11428, seed=0)
+        csr = synthetic.csr_from_edges(n, edges)
+        feat = np.ones((n, 10), np.float32)
+        pred = synthetic.sparse_gcn_predict(csr, feat, ck["sd"])
+        idx = KHopIndex(csr, 3)
+        rng = np.random.default_rng(1234 + rank)
+        targets = np.sort(rng.choice(np.arange(42857, n), num_targets, replace=False))
+        desc = f"BA-House x100k (99997 nodes): {num_targets} sampled motif nodes per GPU (seed 1234+rank)"
+    else:
+        raise SystemExit("unknown workload " + name)
     subs = []
-    for t in range(300, 700):
-        new, A, nb = idx.extract(t)
-        subs.append(Subgraph(A, ck["feat"][nb], int(ck["label"][t]), new, np.argmax(ck["pred"][nb], 1),
-                             helpers.seeded_mask0(t, len(nb)).numpy()))
-    return ck, subs
+    for t in targets:
+        new, A, nb = idx.extract(int(t))
+        subs.append(Subgraph(A, feat[nb], int(label[t]), new, np.argmax(pred[nb], 1),
+                             helpers.seeded_mask0(int(t), len(nb)).numpy()))
+    return ck, subs, desc
 
 
 def cpu_baseline(ck, subs, iters, budget_s=20.0):
@@ -84,7 +99,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--iters", type=int, default=300)
-    ap.add_argument("--workload", default="syn1")
+    ap.add_argument("--workload", default="syn1", choices=["syn1", "ba100k"])
+    ap.add_argument("--targets", type=int, default=4096, help="ba100k: sampled motif targets per GPU")
     ap.add_argument("--no-graph", action="store_true", help="plain launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -107,7 +123,7 @@ def main():
         if rank == 0:
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
-    ck, subs = build_workload(args.workload, args.iters)
+    ck, subs, desc = build_workload(args.workload, args.iters, rank, args.targets)
     log(f"workload built: {len(subs)} targets")
     job = MaskOptimJob(subs, ck["sd"])
     hy = Hyper(num_iters=args.iters, use_graph=not args.no_graph)
@@ -146,8 +162,9 @@ def main():
         # roofline of the dominant kernels, measured live with HIP events on the launch stream
         sum_n2 = job.sum_n2
         kagg = job.D + 2 * job.H
-        ms_mask, by_mask, fl_mask = job.time_kernel(hy, 0, 50)
-        conv = [job.time_kernel(hy, k, 50) for k in (1, 2, 3, 4, 5, 6)]
+        reps = 50 if sum_n2 < 1e8 else 5
+        ms_mask, by_mask, fl_mask = job.time_kernel(hy, 0, reps)
+        conv = [job.time_kernel(hy, k, reps) for k in (1, 2, 3, 4)]
         ms_conv = sum(c[0] for c in conv)
         per_iter_ms = ms_mask + ms_conv
         if ms_mask >= max(c[0] for c in conv):
@@ -156,10 +173,11 @@ def main():
                     "frac": by_mask / (ms_mask * 1e-3) / HBM_PEAK, "traffic": None}
         else:
             k = int(np.argmax([c[0] for c in conv]))
-            roof = {"kernel": f"k_conv mode {k} (masked-adjacency contraction)", "bound": "hbm",
+            roof = {"kernel": ["k_conv<FWD1>", "k_conv<FWD2>", "k_node_head", "k_conv<BWD1>"][k] + " (masked-adjacency contraction)", "bound": "hbm",
                     "achieved": conv[k][1] / (conv[k][0] * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": conv[k][1] / (conv[k][0] * 1e-3) / HBM_PEAK, "traffic": None}
-        roof["avg_launch_us"] = {"k_mask": ms_mask * 1e3, "k_conv_fwd1..3,bwd2..0": [c[0] * 1e3 for c in conv]}
+        roof["avg_launch_us"] = {"k_mask": ms_mask * 1e3, "k_conv<FWD1>": conv[0][0] * 1e3, "k_conv<FWD2>": conv[1][0] * 1e3,
+                                 "k_node_head": conv[2][0] * 1e3, "k_conv<BWD1>": conv[3][0] * 1e3}
         roof["whole_job"] = {
             "alg_flops_per_step": 6.0 * sum_n2 * kagg * args.iters,
             "mfma_f32_frac": 6.0 * sum_n2 * kagg * args.iters * args.steps / dt / MFMA_F32_PEAK,
@@ -169,9 +187,9 @@ def main():
         out = {"metric": "explained nodes/sec (300 mask-opt iters, k-hop subgraph)", "value": value,
                "unit": "explained nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic (syn1 BA-House from the reference generator, GCN trained by the reference train.py; fixture tests/golden/syn1_ckpt.npz)",
-               "config": {"workload": "syn1: all 400 house-motif nodes (300..699) as one batch per GPU, 3-hop sub-graphs, "
-                                      f"{args.iters} iters, Adam lr 0.1", "targets_per_gpu": len(subs), "sum_n2": sum_n2,
+               "dtype": "f32", "data": "synthetic (BA-House graphs; GCN trained by the reference train.py on syn1, fixture tests/golden/syn1_ckpt.npz)",
+               "config": {"workload": desc + f", 3-hop sub-graphs, {args.iters} iters, Adam lr 0.1",
+                          "targets_per_gpu": len(subs), "sum_n2": sum_n2,
                           "launch": "plain" if args.no_graph else "hipGraph", "parallelism": f"target-sharded x{world}"},
                "roofline": roof}
         log("kernel timings done")
