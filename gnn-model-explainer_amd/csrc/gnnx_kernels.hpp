@@ -86,6 +86,7 @@ struct Params {
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Hardware forms (v_exp_f32 / v_rcp_f32 / v_sqrt_f32, ~1 ulp): the fused mask kernel is VALU-bound, and an
 // IEEE divide or an accurate expf costs 10-20 instructions each.  Their error (~1e-7 relative) is the same
@@ -155,6 +156,26 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
         if (MODE == FWD1 && tid < 32) phis[tid] = (tid < p.D) ? sigmoidf_(p.f[iter & 1][tl.t * FS + tid]) : 0.0f;
     }
 
+    // epilogue operands, loaded BEFORE the contraction so their latency hides under it
+    const int row = tid >> 3;      // 0..31
+    const int cg = (tid & 7) * 4;  // column group
+    const size_t grow = (size_t)tm.offR + row0 + row;  // global row in row arrays
+    const int irow = row0 + row;                       // row inside the target
+    constexpr bool IS_FWD = (MODE == FWD1 || MODE == FWD2 || MODE == FWD3);
+    f32x4 pre_a = {0.0f, 0.0f, 0.0f, 0.0f}, pre_b = pre_a, pre_c = pre_a;
+    int pre_ar[4] = {-1, -1, -1, -1};
+    float pre_rn = 1.0f;
+    if (IS_FWD) {
+        pre_a = *reinterpret_cast<const f32x4*>(p.wts + WT_B + layer * 32 + cg);  // bias
+    } else {
+        pre_a = *reinterpret_cast<const f32x4*>(p.U[layer] + grow * FS + cg);                // U
+        pre_b = *reinterpret_cast<const f32x4*>(p.dE + (tl.t * 3 + layer) * FS + cg);        // direct gradient
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pre_ar[j] = p.argrow[(tl.t * 3 + layer) * FS + cg + j];
+        pre_rn = p.rn[layer][grow];
+        if (MODE == BWD1) pre_c = *reinterpret_cast<const f32x4*>(p.Zraw + grow * FS + cg);
+    }
+
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -202,8 +223,6 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wave * TILE + acc_row(r, h)) * 33 + li] = acc[r];
     __syncthreads();
-    const int row = tid >> 3;      // 0..31
-    const int cg = (tid & 7) * 4;  // column group
     float z4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -212,10 +231,7 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
         for (int w = 0; w < 4; ++w) s += red[(w * TILE + row) * 33 + cg + j];
         z4[j] = s;
     }
-    const size_t grow = (size_t)tm.offR + row0 + row;  // global row in row arrays
-    const int irow = row0 + row;                       // row inside the target
-
-    if (MODE == FWD1 || MODE == FWD2 || MODE == FWD3) {
+    if (IS_FWD) {
         if (MODE == FWD1) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -228,7 +244,6 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
         __syncthreads();
         const int din = (MODE == FWD1) ? p.D : p.H;
         const int dout = (MODE == FWD3) ? p.O : p.H;
-        const float* bias = p.wts + WT_B + layer * 32;
         float y[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) y[j] = 0.0f;
@@ -240,7 +255,7 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
         float ss = 0.0f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            y[j] = (cg + j < dout) ? y[j] + bias[cg + j] : 0.0f;
+            y[j] = (cg + j < dout) ? y[j] + pre_a[j] : 0.0f;
             ss = fmaf(y[j], y[j], ss);
         }
         ss += __shfl_xor(ss, 1);
@@ -260,20 +275,17 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
         // BWD3 / BWD2 / BWD1: dX (+ direct part) -> dZ_layer
         const int dout = (layer == 2) ? p.O : p.H;  // width of U[layer] / dX
         const int din = (layer == 0) ? p.D : p.H;   // width of dZ[layer]
-        const float* U = p.U[layer] + grow * FS;
-        const float* dE = p.dE + (tl.t * 3 + layer) * FS;
-        const int32_t* ar = p.argrow + (tl.t * 3 + layer) * FS;
         float du[4], u[4], dz[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = cg + j;
             float dx = (MODE == BWD3) ? 0.0f : z4[j];
-            u[j] = U[c];
-            if (c < dout && ar[c] == irow) dx += dE[c];
+            u[j] = pre_a[j];
+            if (c < dout && pre_ar[j] == irow) dx += pre_b[j];
             if (layer < 2) dx = (u[j] > 0.0f) ? dx : 0.0f;
             du[j] = (c < dout) ? dx : 0.0f;
         }
-        rowlocal_backward(du, u, p.rn[layer][grow], dout, row, cg, zs, wl, dz);
+        rowlocal_backward(du, u, pre_rn, dout, row, cg, zs, wl, dz);
         float* dZ = p.dZ[layer] + grow * FS;
         float* dZT = p.dZT[layer] + tm.offR * FS;
 #pragma unroll
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
             float part[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                part[j] = dz[j] * p.Zraw[grow * FS + cg + j];
+                part[j] = dz[j] * pre_c[j];
                 part[j] += __shfl_xor(part[j], 8);  // the 8 rows of this wave
                 part[j] += __shfl_xor(part[j], 16);
                 part[j] += __shfl_xor(part[j], 32);
@@ -306,16 +318,22 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
 
 // softmax head shared by both modes: e[96] (concatenated embedding) -> probs, g = p - onehot, dE = Wp^T g.
 // Must be called by all 256 threads of the workgroup.
+// sWp: the prediction head (C rows of 96 + bias) staged in LDS by stage_head_weights().
+__device__ __forceinline__ void stage_head_weights(const Params& p, float* sWp) {
+    for (int e = threadIdx.x; e < p.C * 96; e += blockDim.x) sWp[e] = p.wts[WT_WP + e];
+    if (threadIdx.x < CMAX) sWp[CMAX * 96 + threadIdx.x] = p.wts[WT_BP + threadIdx.x];
+}
+
 __device__ __forceinline__ void head_softmax(const Params& p, const TargetMeta& tm, int t, int iter, bool write,
-                                             const float* e, float* g, float* dEs) {
+                                             const float* sWp, const float* e, float* g, float* dEs) {
     const int tid = threadIdx.x;
-    const float* Wp = p.wts + WT_WP;
+    const float* Wp = sWp;
     if (tid < 64) {  // wave 0: logits, softmax
         float z = -3.0e38f;
         if (tid < p.C) {
             float s = 0.0f;
             for (int q = 0; q < 96; ++q) s = fmaf(Wp[tid * 96 + q], e[q], s);
-            z = s + p.wts[WT_BP + tid];
+            z = s + sWp[CMAX * 96 + tid];
         }
         float mx = z;
 #pragma unroll
@@ -353,10 +371,12 @@ __global__ __launch_bounds__(256) void k_head(Params p, int iter) {
     __shared__ int erow[96];
     __shared__ float g[CMAX];
     __shared__ float dEs[96];
+    __shared__ float sWp[CMAX * 96 + CMAX];
     const int t = blockIdx.x;
     const TargetMeta tm = p.meta[t];
     const int tid = threadIdx.x;
     const int dims[3] = {p.H, p.H, p.O};
+    stage_head_weights(p, sWp);
     // padded rows of the reference are rows < n here; the engine's own padding rows n..ld-1 are excluded
     const int wave = tid >> 6, lane = tid & 63;
     for (int col = wave; col < 96; col += 4) {
@@ -382,7 +402,7 @@ __global__ __launch_bounds__(256) void k_head(Params p, int iter) {
         if (lane == 0) { e[col] = best; erow[col] = barg; }
     }
     __syncthreads();
-    head_softmax(p, tm, t, iter, true, e, g, dEs);
+    head_softmax(p, tm, t, iter, true, sWp, e, g, dEs);
     if (tid < 96) {
         p.dE[t * 96 + tid] = dEs[tid];
         p.argrow[t * 96 + tid] = erow[tid];
@@ -400,6 +420,7 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
     __shared__ float e[96], g[CMAX], dEs[96];
     __shared__ float y3[32], dz3[32];
     __shared__ float wl[32 * 33], zs[TILE * 33];
+    __shared__ float sWp[CMAX * 96 + CMAX];
     __shared__ float sr3;
     const ConvTile tl = tiles[blockIdx.x];
     const int t = tl.t;
@@ -410,6 +431,16 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
     const float* U2 = p.U[1] + tm.offR * FS;
     const float* W3 = p.wts + WT_W + 2 * 1024;
     const float* W2 = p.wts + WT_W + 1 * 1024;
+    stage_head_weights(p, sWp);
+    // operands of the later phases, loaded up-front (their latency hides under the mat-vec below)
+    const int row = tid >> 3, cg = (tid & 7) * 4;
+    const int i = tl.rb * TILE + row;
+    const float u1t = (tid < 32) ? U1[(size_t)tr * FS + tid] : 0.0f;
+    const float u2t = (tid < 32) ? U2[(size_t)tr * FS + tid] : 0.0f;
+    const float b3 = (tid < 32) ? p.wts[WT_B + 2 * 32 + tid] : 0.0f;
+    const float ait = Ab[(size_t)tr * ld + i];  // Abar[t][i] == Abar[i][t]
+    const f32x4 u2i = *reinterpret_cast<const f32x4*>(U2 + (size_t)i * FS + cg);
+    const float rn2i = p.rn[1][tm.offR + i];
 
     // Z3[t][c] = sum_k Abar[t][k] relu(U2[k][c]) : 8 k-slices x 32 columns, 4 loads in flight per thread
     {
@@ -438,10 +469,11 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
     __syncthreads();
     if (tid < 64) {  // Y3 = Z3 W3 + b3, normalise (wave 0, columns in lanes 0..31)
         const int c = tid & 31;
+        const float b3c = __shfl(b3, c);  // all 64 lanes take part in the shuffle
         float y = 0.0f;
         if (c < p.O) {
             for (int k = 0; k < p.H; ++k) y = fmaf(zs[k], wl[k * 33 + c], y);
-            y += p.wts[WT_B + 2 * 32 + c];
+            y += b3c;
         }
         float ss = (tid < 32) ? y * y : 0.0f;
 #pragma unroll
@@ -451,13 +483,13 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
             const float u = y / rnorm;
             y3[tid] = u;
             e[64 + tid] = u;
-            e[tid] = (tid < p.H) ? fmaxf(U1[(size_t)tr * FS + tid], 0.0f) : 0.0f;
-            e[32 + tid] = (tid < p.H) ? fmaxf(U2[(size_t)tr * FS + tid], 0.0f) : 0.0f;
+            e[tid] = (tid < p.H) ? fmaxf(u1t, 0.0f) : 0.0f;
+            e[32 + tid] = (tid < p.H) ? fmaxf(u2t, 0.0f) : 0.0f;
         }
         if (tid == 0) sr3 = rnorm;
     }
     __syncthreads();
-    head_softmax(p, tm, t, iter, tl.rb == 0, e, g, dEs);
+    head_softmax(p, tm, t, iter, tl.rb == 0, sWp, e, g, dEs);
     // dZ3[t] : backward through the last layer's normalisation and W3 (row t only)
     if (tid < 64) {
         const int c = tid & 31;
@@ -479,15 +511,12 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
     for (int e2 = tid; e2 < 1024; e2 += 256) wl[(e2 >> 5) * 33 + (e2 & 31)] = W2[e2];
     // this block's 32 rows: dX2[i] = Abar[i][t] dZ3[t] (+ dE2 on row t), row-local backward of layer 2 -> dZ2;
     // g3[i] = dZ3[t] . relu(U2[i]) (layer-3 part of row t of dL/dAbar)
-    const int row = tid >> 3, cg = (tid & 7) * 4;
-    const int i = tl.rb * TILE + row;
-    const float ait = Ab[(size_t)tr * ld + i];  // Abar[t][i] == Abar[i][t]
     float du[4], u[4], dz[4];
     float gpart = 0.0f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int c = cg + j;
-        u[j] = U2[(size_t)i * FS + c];
+        u[j] = u2i[j];
         gpart = fmaf(dz3[c], fmaxf(u[j], 0.0f), gpart);  // dz3[c] == 0 for c >= H
         float dx = ait * dz3[c];
         if (i == tr) dx += dEs[32 + c];
@@ -498,7 +527,7 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
     gpart += __shfl_xor(gpart, 2);
     gpart += __shfl_xor(gpart, 4);
     if ((tid & 7) == 0) p.g3[tm.offR + i] = (i < n) ? gpart : 0.0f;
-    rowlocal_backward(du, u, p.rn[1][tm.offR + i], p.H, row, cg, zs, wl, dz);
+    rowlocal_backward(du, u, rn2i, p.H, row, cg, zs, wl, dz);
     float* dZ = p.dZ[1] + tm.offR * FS;
     float* dZT = p.dZT[1] + tm.offR * FS;
 #pragma unroll
@@ -528,8 +557,6 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
 //   DS, HS       : k-steps (pairs of columns) of layers 1 / 2 held in registers: (5, 10) for the default
 //                  D <= 10, H <= 20 encoder, (8, 16) for anything up to 16 / 32 (keeps the VGPR count < 256)
 // ---------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 template <bool UPDATE, bool WRITE_ABAR, bool NODE, bool LOSS, int DS, int HS>
 __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, int iter, float step_size, float bc2s) {
     constexpr int LS = 33;  // LDS row stride
@@ -562,6 +589,20 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
                 vp[q] = *reinterpret_cast<const f32x4*>(p.vM + par);
             }
         }
+    }
+    // per-row / per-column vectors used by the elementwise phase (no global load may sit inside that phase:
+    // each would add a serial DRAM round trip)
+    f32x4 yj4 = {0.0f, 0.0f, 0.0f, 0.0f}, g3j4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    float yiv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, g3iv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (UPDATE && !p.graph_mode) {
+        yj4 = *reinterpret_cast<const f32x4*>(p.yhat + tm.offR + J0 + c4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) yiv[q] = p.yhat[tm.offR + I0 + 8 * q + rl];
+    }
+    if (UPDATE && NODE) {
+        g3j4 = *reinterpret_cast<const f32x4*>(p.g3 + tm.offR + J0 + c4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g3iv[q] = p.g3[tm.offR + I0 + 8 * q + rl];
     }
     // operands of the G-tile product (K-major copies: coalesced 128-B segments)
     const size_t ro = (size_t)tm.offR * FS;
@@ -669,9 +710,7 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int i = 8 * q + rl, gi = I0 + i;
-        float yi = 0.0f, g3i = 0.0f;
-        if (lapl) yi = p.yhat[tm.offR + gi];
-        if (UPDATE && NODE) g3i = p.g3[tm.offR + gi];
+        const float yi = yiv[q], g3i = g3iv[q];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int j = c4 + e, gj = J0 + j;
@@ -681,14 +720,13 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
                 const float Aij = Ao[q][e];
                 const float offd = (gi != gj) ? 1.0f : 0.0f;
                 float Gsum = sG[i * LS + j];
-                float yj = 0.0f;
+                const float yj = yj4[e];
                 if (NODE) {
-                    if (gi == tm.t) Gsum += p.g3[tm.offR + gj];
-                    if (gj == tm.t) Gsum += g3i;
+                    Gsum += (gi == tm.t) ? g3j4[e] : 0.0f;
+                    Gsum += (gj == tm.t) ? g3i : 0.0f;
                 }
                 float Gs = 0.5f * Gsum;
                 if (lapl) {
-                    yj = p.yhat[tm.offR + gj];
                     const float dy = yi - yj;
                     Gs += p.c_lap * 0.5f * dy * dy * inv_n2;
                 }

@@ -25,6 +25,7 @@ struct Block {
     const std::function<void()>* body = nullptr;
 };
 Block* g_blk = nullptr;
+unsigned long g_progress = 0;  // bumped whenever a collective / barrier completes or a fiber ends
 
 void yield() { swapcontext(&g_blk->fibers[g_blk->cur].ctx, &g_blk->main); }
 
@@ -32,6 +33,7 @@ void trampoline() {
     Block* b = g_blk;
     (*b->body)();
     b->fibers[b->cur].done = true;
+    ++g_progress;
     swapcontext(&b->fibers[b->cur].ctx, &b->main);
 }
 
@@ -46,6 +48,7 @@ void wave_collective(F publish) {
     if (++w.arrived == wsize) {
         w.arrived = 0;
         w.gen++;
+        ++g_progress;
     } else {
         while (w.gen == g) yield();
     }
@@ -58,6 +61,7 @@ void syncthreads() {
     if (++b->bar_count == b->nthreads) {
         b->bar_count = 0;
         b->bar_gen++;
+        ++g_progress;
     } else {
         while (b->bar_gen == g) yield();
     }
@@ -67,6 +71,13 @@ float shfl_xor_f(float v, int mask) {
     int buf = 0, lane = 0;
     wave_collective([&](WaveSlot& w, int bf, int ln) { w.fa[bf][ln] = v; buf = bf; lane = ln; });
     return g_blk->waves[g_blk->cur >> 6].fa[buf][(lane ^ mask) & 63];
+}
+
+float shfl_f(float v, int src) {
+    int buf = 0, lane = 0;
+    wave_collective([&](WaveSlot& w, int bf, int ln) { w.fa[bf][ln] = v; buf = bf; lane = ln; });
+    (void)lane;
+    return g_blk->waves[g_blk->cur >> 6].fa[buf][src & 63];
 }
 
 int shfl_xor_i(int v, int mask) {
@@ -116,6 +127,7 @@ void launch(unsigned grid, unsigned block, const std::function<void()>& body) {
         }
         unsigned ndone = 0;
         while (ndone < block) {
+            const unsigned long before = g_progress;
             ndone = 0;
             for (unsigned t = 0; t < block; ++t) {
                 if (blk.fibers[t].done) { ++ndone; continue; }
@@ -123,6 +135,11 @@ void launch(unsigned grid, unsigned block, const std::function<void()>& body) {
                 threadIdx = {t, 0, 0};
                 blockIdx = {bid, 0, 0};
                 swapcontext(&blk.main, &blk.fibers[t].ctx);
+            }
+            if (ndone < block && g_progress == before) {
+                fprintf(stderr, "hip emulator: deadlock in block %u (a wave collective or __syncthreads is not reached by every "
+                                "lane: divergent shuffle / barrier)\n", bid);
+                abort();
             }
         }
     }

@@ -44,6 +44,7 @@ void launch(unsigned grid, unsigned block, const std::function<void()>& body);
 void syncthreads();
 float shfl_xor_f(float v, int mask);
 int shfl_xor_i(int v, int mask);
+float shfl_f(float v, int src);
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 f32x16 mfma_32x32x2(float a, float b, f32x16 c);
 }  // namespace emu
@@ -51,6 +52,7 @@ f32x16 mfma_32x32x2(float a, float b, f32x16 c);
 inline void __syncthreads() { emu::syncthreads(); }
 inline float __shfl_xor(float v, int m) { return emu::shfl_xor_f(v, m); }
 inline int __shfl_xor(int v, int m) { return emu::shfl_xor_i(v, m); }
+inline float __shfl(float v, int src) { return emu::shfl_f(v, src); }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_sqrtf(x) std::sqrt(x)
