@@ -263,24 +263,12 @@ static void launch_conv(gnnx_handle h, const Params& p, int it, hipStream_t s) {
 
 template <bool UPDATE, bool WRITE_ABAR>
 static void launch_mask(gnnx_handle h, const Params& p, int it, float ss, float b2, hipStream_t s) {
-    const dim3 g(h->n_mask), b(64);
+    const dim3 g(h->n_mask), b(256);
     const bool node = !h->prob.graph_mode, loss = UPDATE && p.loss != nullptr;
-    const bool small = UPDATE && h->prob.D <= 10 && h->prob.H <= 20;  // default encoder: fewer operand registers
-#define GNNX_MASK(NODE, LOSS, DS, HS) \
-    hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, NODE, LOSS, DS, HS>), g, b, 0, s, p, h->d_mask, it, ss, b2)
-    if (small) {
-        if (node && loss) GNNX_MASK(true, UPDATE, 5, 10);
-        else if (node) GNNX_MASK(true, false, 5, 10);
-        else if (loss) GNNX_MASK(false, UPDATE, 5, 10);
-        else GNNX_MASK(false, false, 5, 10);
-    } else {
-        if (h->prob.H > 32 || h->prob.D > 32) return;  // rejected at plan creation
-        if (node && loss) GNNX_MASK(true, UPDATE, 8, 16);
-        else if (node) GNNX_MASK(true, false, 8, 16);
-        else if (loss) GNNX_MASK(false, UPDATE, 8, 16);
-        else GNNX_MASK(false, false, 8, 16);
-    }
-#undef GNNX_MASK
+    if (node && loss) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, true, UPDATE>), g, b, 0, s, p, h->d_mask, it, ss, b2);
+    else if (node) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, true, false>), g, b, 0, s, p, h->d_mask, it, ss, b2);
+    else if (loss) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, false, UPDATE>), g, b, 0, s, p, h->d_mask, it, ss, b2);
+    else hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, false, false>), g, b, 0, s, p, h->d_mask, it, ss, b2);
 }
 
 // forward up to the head (+ in node mode the fused start of the backward pass)

@@ -543,161 +543,118 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused mask kernel: one wave per tile pair {(I,J),(J,I)}, I <= J.
-//   * every global access to the n x n state (M, m, v, A, Abar) is 16 B per lane (dwordx4): the
-//     elementwise work runs in a row-major layout (lane -> row 8q + lane/8, columns 4 (lane%8) .. +3) and the
-//     MFMA accumulator (G tile) and the partner tile (J,I) are transposed into it through LDS.  Narrow
-//     (4 B / lane) access caps this kernel at ~2.3 TB/s on MI355X (measured, profiles/r01_v3_pmc_*).
-//   * every mask entry is updated by exactly one lane (diagonal tiles exchange sigma through LDS) so the
-//     output is bitwise symmetric, batch-invariant and deterministic.
+// Fused mask kernel: one workgroup (4 waves) per tile pair {(I,J),(J,I)}, I <= J.
+//   * thread (i = tid/8, c4 = 4 (tid%8)) owns the 4 entries (i, c4..c4+3) of tile (I,J) AND their mirror
+//     entries (c4.., i) of tile (J,I); every mask entry is updated by exactly one thread (diagonal tiles
+//     exchange sigma through LDS) => bitwise symmetric, batch-invariant, deterministic output;
+//   * every global access to the n x n state (M, m, v, A, Abar) is 16 B per lane; the mirror tile is loaded
+//     row-wise and transposed through LDS;
+//   * the K = D + 2H product of the G tile (dL/dAbar, never materialised) is split over the 4 waves on
+//     v_mfma_f32_32x32x2_f32, the 4 partial tiles are summed through LDS in a fixed order;
+//   * all global loads are issued before any dependent work (one DRAM round trip per workgroup);
+//   * padding entries (>= n) are ordinary non-edges (A = 0 there): they are updated like any other entry,
+//     which keeps the inner loop free of predication; they never influence a real entry and are not returned.
 //   UPDATE=false : only Abar = A * sym(sigma(M)) (initial forward)
 //   UPDATE=true  : gradient + Adam step, then (WRITE_ABAR) the next Abar
 //   NODE         : layer-3 part of G is the rank-2 term built from g3 (node mode)
 //   LOSS         : also accumulate the size / entropy / Laplacian loss terms (logging)
-//   DS, HS       : k-steps (pairs of columns) of layers 1 / 2 held in registers: (5, 10) for the default
-//                  D <= 10, H <= 20 encoder, (8, 16) for anything up to 16 / 32 (keeps the VGPR count < 256)
 // ---------------------------------------------------------------------------------------------
-template <bool UPDATE, bool WRITE_ABAR, bool NODE, bool LOSS, int DS, int HS>
-__global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, int iter, float step_size, float bc2s) {
+template <bool UPDATE, bool WRITE_ABAR, bool NODE, bool LOSS>
+__global__ __launch_bounds__(256) void k_mask(Params p, const MaskTile* tiles, int iter, float step_size, float bc2s) {
     constexpr int LS = 33;  // LDS row stride
-    __shared__ float sG[TILE * LS];                                // G tile, [i][j]
-    __shared__ float sPM[TILE * LS], sPm[TILE * LS], sPv[TILE * LS];  // partner tile (J,I), natural orientation [j][i]
-    __shared__ float sS[TILE * LS];                                // sigma exchange, then Abar of the partner tile
+    __shared__ float sGp[4 * TILE * LS];                             // per-wave partial G tiles, [w][i][j]
+    __shared__ float sPM[TILE * LS], sPm[TILE * LS], sPv[TILE * LS];  // mirror tile (J,I), natural orientation [j][i]
+    __shared__ float sS[TILE * LS];                                  // sigma exchange, then Abar of the mirror tile
     const MaskTile tl = tiles[blockIdx.x];
     const TargetMeta tm = p.meta[tl.t];
     const int ld = tm.ld, n = tm.n;
     const int I0 = tl.I * TILE, J0 = tl.J * TILE;
     const bool diag = (tl.I == tl.J);
-    const int lane = threadIdx.x, li = lane & 31, h = lane >> 5;
-    const int rl = lane >> 3, c4 = (lane & 7) * 4;  // row-major layout: row 8q + rl, columns c4 .. c4+3
-    const size_t q0 = tm.offQ;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int i = tid >> 3, c4 = (tid & 7) * 4;  // row-major layout: row i, columns c4 .. c4+3
+    const int gi = I0 + i;
+    const size_t own = tm.offQ + (size_t)gi * ld + J0 + c4;        // my 4 entries of tile (I,J)
+    const size_t par = tm.offQ + (size_t)(J0 + i) * ld + I0 + c4;  // my row segment of tile (J,I) (staging only)
 
-    // ---- issue every global load first: one DRAM round trip for the whole wave ----
-    f32x4 Mo[4], Ao[4], mo[4], vo[4], Mp[4], mp[4], vp[4];
+    // ---- every global load is issued here ----
+    f32x4 Mo = *reinterpret_cast<const f32x4*>(p.M + own);
+    const f32x4 Ao = *reinterpret_cast<const f32x4*>(p.A + own);
+    const f32x4 Mp = *reinterpret_cast<const f32x4*>(p.M + par);
+    f32x4 mo, vo, mp, vp;
+    f32x4 yj4 = {0.0f, 0.0f, 0.0f, 0.0f}, g3j4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    float yi = 0.0f, g3i = 0.0f;
+    // G operands: k-step s (columns 2s, 2s+1) of a layer goes to wave s % 4 -> at most 4 steps per wave per layer
+    float zi[3][4], zj[3][4], xi[3][4], xj[3][4];
+    constexpr int NL = NODE ? 2 : 3;
+    if (UPDATE) {
+        mo = *reinterpret_cast<const f32x4*>(p.mM + own);
+        vo = *reinterpret_cast<const f32x4*>(p.vM + own);
+        if (!diag) {
+            mp = *reinterpret_cast<const f32x4*>(p.mM + par);
+            vp = *reinterpret_cast<const f32x4*>(p.vM + par);
+        }
+        if (!p.graph_mode) {
+            yj4 = *reinterpret_cast<const f32x4*>(p.yhat + tm.offR + J0 + c4);
+            yi = p.yhat[tm.offR + gi];
+        }
+        if (NODE) {
+            g3j4 = *reinterpret_cast<const f32x4*>(p.g3 + tm.offR + J0 + c4);
+            g3i = p.g3[tm.offR + gi];
+        }
+        const size_t ro = (size_t)tm.offR * FS;
+        const float* fcur = p.f[iter & 1] + tl.t * FS;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const size_t own = q0 + (size_t)(I0 + 8 * q + rl) * ld + J0 + c4;
-        const size_t par = q0 + (size_t)(J0 + 8 * q + rl) * ld + I0 + c4;
-        Mo[q] = *reinterpret_cast<const f32x4*>(p.M + own);
-        Ao[q] = *reinterpret_cast<const f32x4*>(p.A + own);
-        Mp[q] = *reinterpret_cast<const f32x4*>(p.M + par);
-        if (UPDATE) {
-            mo[q] = *reinterpret_cast<const f32x4*>(p.mM + own);
-            vo[q] = *reinterpret_cast<const f32x4*>(p.vM + own);
-            if (!diag) {
-                mp[q] = *reinterpret_cast<const f32x4*>(p.mM + par);
-                vp[q] = *reinterpret_cast<const f32x4*>(p.vM + par);
+        for (int l = 0; l < NL; ++l) {
+            const int d = (l == 0) ? p.D : p.H;
+            const float* zT = p.dZT[l] + ro;
+            const float* xT = (l == 0) ? p.XT + ro : p.UT[l - 1] + ro;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = 2 * (wave + 4 * u) + h;  // < 32; columns >= d hold zeros
+                const bool on = 2 * (wave + 4 * u) < d;
+                float a = 0.0f, b = 0.0f, c = 0.0f, e = 0.0f;
+                if (on) {
+                    a = zT[(size_t)k * ld + I0 + li];
+                    b = zT[(size_t)k * ld + J0 + li];
+                    c = xT[(size_t)k * ld + I0 + li];
+                    e = xT[(size_t)k * ld + J0 + li];
+                    if (l == 0) {
+                        const float phi = (k < p.D) ? sigmoidf_(fcur[k]) : 0.0f;
+                        c *= phi;
+                        e *= phi;
+                    } else {
+                        c = fmaxf(c, 0.0f);
+                        e = fmaxf(e, 0.0f);
+                    }
+                }
+                zi[l][u] = a; zj[l][u] = b; xi[l][u] = c; xj[l][u] = e;
             }
         }
     }
-    // per-row / per-column vectors used by the elementwise phase (no global load may sit inside that phase:
-    // each would add a serial DRAM round trip)
-    f32x4 yj4 = {0.0f, 0.0f, 0.0f, 0.0f}, g3j4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    float yiv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, g3iv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (UPDATE && !p.graph_mode) {
-        yj4 = *reinterpret_cast<const f32x4*>(p.yhat + tm.offR + J0 + c4);
+    // mirror tile -> LDS in its natural orientation [j][i]; read back transposed below
 #pragma unroll
-        for (int q = 0; q < 4; ++q) yiv[q] = p.yhat[tm.offR + I0 + 8 * q + rl];
+    for (int e = 0; e < 4; ++e) {
+        sPM[i * LS + c4 + e] = Mp[e];
+        if (UPDATE && !diag) { sPm[i * LS + c4 + e] = mp[e]; sPv[i * LS + c4 + e] = vp[e]; }
     }
-    if (UPDATE && NODE) {
-        g3j4 = *reinterpret_cast<const f32x4*>(p.g3 + tm.offR + J0 + c4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) g3iv[q] = p.g3[tm.offR + I0 + 8 * q + rl];
-    }
-    // operands of the G-tile product (K-major copies: coalesced 128-B segments)
-    const size_t ro = (size_t)tm.offR * FS;
-    float zi0[DS], zj0[DS], xi0[DS], xj0[DS];  // layer 1, k = 2u+h < 2 DS
-    float zi1[HS], zj1[HS], xi1[HS], xj1[HS];  // layer 2, k = 2u+h < 2 HS
-    if (UPDATE) {
-        const float* zT0 = p.dZT[0] + ro;
-        const float* xT0 = p.XT + ro;
-        const float* zT1 = p.dZT[1] + ro;
-        const float* xT1 = p.UT[0] + ro;
-        const float* fcur = p.f[iter & 1] + tl.t * FS;
-#pragma unroll
-        for (int u = 0; u < DS; ++u) {
-            const int k = 2 * u + h;  // columns >= D hold zeros in dZT; phi = 0 there
-            const bool on = 2 * u < p.D;
-            const float phi = (on && k < p.D) ? sigmoidf_(fcur[k]) : 0.0f;
-            zi0[u] = on ? zT0[(size_t)k * ld + I0 + li] : 0.0f;
-            zj0[u] = on ? zT0[(size_t)k * ld + J0 + li] : 0.0f;
-            xi0[u] = on ? xT0[(size_t)k * ld + I0 + li] * phi : 0.0f;
-            xj0[u] = on ? xT0[(size_t)k * ld + J0 + li] * phi : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < HS; ++u) {
-            const int k = 2 * u + h;
-            const bool on = 2 * u < p.H;
-            zi1[u] = on ? zT1[(size_t)k * ld + I0 + li] : 0.0f;
-            zj1[u] = on ? zT1[(size_t)k * ld + J0 + li] : 0.0f;
-            xi1[u] = on ? fmaxf(xT1[(size_t)k * ld + I0 + li], 0.0f) : 0.0f;
-            xj1[u] = on ? fmaxf(xT1[(size_t)k * ld + J0 + li], 0.0f) : 0.0f;
-        }
-    }
-    // partner tile -> LDS in its natural orientation [j][i]; read back transposed below
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int a = (8 * q + rl) * LS + c4 + e;
-            sPM[a] = Mp[q][e];
-            if (UPDATE && !diag) { sPm[a] = mp[q][e]; sPv[a] = vp[q][e]; }
-        }
-    }
-
     if (UPDATE) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-        for (int u = 0; u < DS; ++u) {
-            if (2 * u < p.D) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zi0[u], xj0[u], acc, 0, 0, 0);  // G[i][j]
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xi0[u], zj0[u], acc, 0, 0, 0);  // G[j][i]
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < HS; ++u) {
-            if (2 * u < p.H) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zi1[u], xj1[u], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xi1[u], zj1[u], acc, 0, 0, 0);
-            }
-        }
-        // rare shapes: input dim > 2 DS (rest of layer 1) and, in graph mode, layer 3 (dense dZ3)
-        for (int l = 0; l < 3; l += 2) {
-            if (l == 0 && p.D <= 2 * DS) continue;
-            if (l == 2 && NODE) continue;
+        for (int l = 0; l < NL; ++l) {
             const int d = (l == 0) ? p.D : p.H;
-            const float* zT = p.dZT[l] + ro;
-            const float* xT = (l == 0) ? p.XT + ro : p.UT[1] + ro;
-            for (int s0 = (l == 0) ? 2 * DS : 0; s0 < d; s0 += 8) {
-                float zi[4], zj[4], xi[4], xj[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = s0 + 2 * u + h;
-                    zi[u] = zT[(size_t)k * ld + I0 + li];
-                    zj[u] = zT[(size_t)k * ld + J0 + li];
-                    xi[u] = xT[(size_t)k * ld + I0 + li];
-                    xj[u] = xT[(size_t)k * ld + J0 + li];
-                    if (l == 0) {
-                        const float phi = (k < p.D) ? sigmoidf_(p.f[iter & 1][tl.t * FS + k]) : 0.0f;
-                        xi[u] *= phi;
-                        xj[u] *= phi;
-                    } else {
-                        xi[u] = fmaxf(xi[u], 0.0f);
-                        xj[u] = fmaxf(xj[u], 0.0f);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zi[u], xj[u], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xi[u], zj[u], acc, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+                if (2 * (wave + 4 * u) < d) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zi[l][u], xj[l][u], acc, 0, 0, 0);  // G[i][j]
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xi[l][u], zj[l][u], acc, 0, 0, 0);  // G[j][i]
                 }
             }
         }
-        // accumulator (C layout: row acc_row(r,h), column li) -> LDS [i][j]
+        // accumulator (C layout: row acc_row(r,h), column li) -> this wave's partial tile in LDS
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sG[acc_row(r, h) * LS + li] = acc[r];
+        for (int r = 0; r < 16; ++r) sGp[(wave * TILE + acc_row(r, h)) * LS + li] = acc[r];
     }
     __syncthreads();
 
@@ -705,125 +662,104 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
     const float inv_bc2s = 1.0f / bc2s;
     const bool lapl = UPDATE && !p.graph_mode;
     float s_size = 0.0f, s_ent = 0.0f, s_lap = 0.0f;
-    f32x4 Sown[4];
-
+    f32x4 Sown;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = 8 * q + rl, gi = I0 + i;
-        const float yi = yiv[q], g3i = g3iv[q];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int j = c4 + e, gj = J0 + j;
-            const bool valid = (gi < n) && (gj < n);
-            float Mij = Mo[q][e];
-            if (UPDATE) {
-                const float Aij = Ao[q][e];
-                const float offd = (gi != gj) ? 1.0f : 0.0f;
-                float Gsum = sG[i * LS + j];
-                const float yj = yj4[e];
-                if (NODE) {
-                    Gsum += (gi == tm.t) ? g3j4[e] : 0.0f;
-                    Gsum += (gj == tm.t) ? g3i : 0.0f;
-                }
-                float Gs = 0.5f * Gsum;
-                if (lapl) {
-                    const float dy = yi - yj;
-                    Gs += p.c_lap * 0.5f * dy * dy * inv_n2;
-                }
-                const float gc = Gs * Aij * offd;
-                const float Sij = sigmoidf_(Mij);
-                const float Mji_old = sPM[j * LS + i];
-                float Sji_old = 0.0f;
-                if (LOSS) Sji_old = sigmoidf_(Mji_old);
-                if (!diag) {  // this lane also owns the partner entry (j,i)
-                    float Mji = Mji_old, mji = sPm[j * LS + i], vji = sPv[j * LS + i];
-                    const float Sji = sigmoidf_(Mji);
-                    // d(entropy)/dS = log(1-S) - log(S) = -M exactly (S = sigma(M)): no logs on the update path
-                    const float gji = (gc + p.c_size - p.c_ent * Mji * inv_n2) * Sji * (1.0f - Sji);
-                    adam_update(Mji, mji, vji, gji, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
-                    if (valid) {
-                        sPM[j * LS + i] = Mji;
-                        sPm[j * LS + i] = mji;
-                        sPv[j * LS + i] = vji;
-                    }
-                    sS[j * LS + i] = sigmoidf_(valid ? Mji : Mji_old);
-                    if (LOSS && valid) {
-                        s_size += Sji;
-                        s_ent += -Sji * logf(Sji) - (1.0f - Sji) * logf(1.0f - Sji);
-                    }
-                }
-                if (LOSS && valid) {
-                    s_size += Sij;
-                    s_ent += -Sij * logf(Sij) - (1.0f - Sij) * logf(1.0f - Sij);
-                    if (lapl) {
-                        const float ab = Aij * 0.5f * (Sij + Sji_old) * offd;
-                        s_lap += ab * (yj * yj - yi * yj);
-                        if (!diag) s_lap += ab * (yi * yi - yi * yj);
-                    }
-                }
-                const float gij = (gc + p.c_size - p.c_ent * Mij * inv_n2) * Sij * (1.0f - Sij);
-                float mij = mo[q][e], vij = vo[q][e];
-                float Mnew = Mij;
-                adam_update(Mnew, mij, vij, gij, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
-                if (valid) {  // padding entries keep their (zero) state
-                    Mij = Mnew;
-                    mo[q][e] = mij;
-                    vo[q][e] = vij;
-                }
-                Mo[q][e] = Mij;
-            } else if (!diag) {
-                sS[j * LS + i] = sigmoidf_(sPM[j * LS + i]);
-            }
-            Sown[q][e] = sigmoidf_(Mij);
-            if (diag) sS[i * LS + j] = Sown[q][e];  // diagonal tile: publish, the partner lane reads it transposed
-        }
+    for (int e = 0; e < 4; ++e) {
+        const int j = c4 + e, gj = J0 + j;
+        float Mij = Mo[e];
         if (UPDATE) {
-            const size_t own = q0 + (size_t)gi * ld + J0 + c4;
-            *reinterpret_cast<f32x4*>(p.M + own) = Mo[q];
-            *reinterpret_cast<f32x4*>(p.mM + own) = mo[q];
-            *reinterpret_cast<f32x4*>(p.vM + own) = vo[q];
+            const float Aij = Ao[e];
+            const float offd = (gi != gj) ? 1.0f : 0.0f;
+            float Gsum = (sGp[(0 * TILE + i) * LS + j] + sGp[(1 * TILE + i) * LS + j]) +
+                         (sGp[(2 * TILE + i) * LS + j] + sGp[(3 * TILE + i) * LS + j]);
+            const float yj = yj4[e];
+            if (NODE) {
+                Gsum += (gi == tm.t) ? g3j4[e] : 0.0f;
+                Gsum += (gj == tm.t) ? g3i : 0.0f;
+            }
+            float Gs = 0.5f * Gsum;
+            if (lapl) {
+                const float dy = yi - yj;
+                Gs += p.c_lap * 0.5f * dy * dy * inv_n2;
+            }
+            const float gc = Gs * Aij * offd;
+            const float Sij = sigmoidf_(Mij);
+            const float Mji_old = sPM[j * LS + i];
+            const bool valid = LOSS && (gi < n) && (gj < n);
+            float Sji_old = 0.0f;
+            if (LOSS) Sji_old = sigmoidf_(Mji_old);
+            if (!diag) {  // this thread also owns the mirror entry (j,i)
+                float Mji = Mji_old, mji = sPm[j * LS + i], vji = sPv[j * LS + i];
+                const float Sji = sigmoidf_(Mji);
+                // d(entropy)/dS = log(1-S) - log(S) = -M exactly (S = sigma(M)): no logs on the update path
+                const float gji = (gc + p.c_size - p.c_ent * Mji * inv_n2) * Sji * (1.0f - Sji);
+                adam_update(Mji, mji, vji, gji, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+                sPM[j * LS + i] = Mji;
+                sPm[j * LS + i] = mji;
+                sPv[j * LS + i] = vji;
+                sS[j * LS + i] = sigmoidf_(Mji);
+                if (valid) {
+                    s_size += Sji;
+                    s_ent += -Sji * logf(Sji) - (1.0f - Sji) * logf(1.0f - Sji);
+                }
+            }
+            if (valid) {
+                s_size += Sij;
+                s_ent += -Sij * logf(Sij) - (1.0f - Sij) * logf(1.0f - Sij);
+                if (lapl) {
+                    const float ab = Aij * 0.5f * (Sij + Sji_old) * offd;
+                    s_lap += ab * (yj * yj - yi * yj);
+                    if (!diag) s_lap += ab * (yi * yi - yi * yj);
+                }
+            }
+            const float gij = (gc + p.c_size - p.c_ent * Mij * inv_n2) * Sij * (1.0f - Sij);
+            float mij = mo[e], vij = vo[e];
+            adam_update(Mij, mij, vij, gij, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+            Mo[e] = Mij;
+            mo[e] = mij;
+            vo[e] = vij;
+        } else if (!diag) {
+            sS[j * LS + i] = sigmoidf_(sPM[j * LS + i]);
         }
+        Sown[e] = sigmoidf_(Mij);
+        if (diag) sS[i * LS + j] = Sown[e];  // diagonal tile: publish, the mirror thread reads it transposed
+    }
+    if (UPDATE) {
+        *reinterpret_cast<f32x4*>(p.M + own) = Mo;
+        *reinterpret_cast<f32x4*>(p.mM + own) = mo;
+        *reinterpret_cast<f32x4*>(p.vM + own) = vo;
     }
     __syncthreads();
     if (WRITE_ABAR) {
+        f32x4 ab4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = 8 * q + rl, gi = I0 + i;
-            f32x4 ab4;
+        for (int e = 0; e < 4; ++e) {
+            const int j = c4 + e;
+            const float Sother = sS[j * LS + i];
+            ab4[e] = (gi != J0 + j) ? Ao[e] * (0.5f * (Sown[e] + Sother)) : 0.0f;  // A = 0 on padding
+        }
+        *reinterpret_cast<f32x4*>(p.Abar + own) = ab4;
+        if (!diag) {  // same values for (j,i): stage for the row-wise store of the mirror tile
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int j = c4 + e, gj = J0 + j;
-                const bool valid = (gi < n) && (gj < n) && (gi != gj);
-                const float Sother = sS[j * LS + i];
-                ab4[e] = valid ? Ao[q][e] * (0.5f * (Sown[q][e] + Sother)) : 0.0f;
-            }
-            *reinterpret_cast<f32x4*>(p.Abar + q0 + (size_t)gi * ld + J0 + c4) = ab4;
-            if (!diag) {  // same values for (j,i): stage for the row-wise store of the partner tile
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sS[(c4 + e) * LS + i] = ab4[e];
-            }
+            for (int e = 0; e < 4; ++e) sS[(c4 + e) * LS + i] = ab4[e];
         }
         __syncthreads();
     }
     if (!diag) {
+        const int a = i * LS + c4;
+        if (UPDATE) {
+            f32x4 x, y, z;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const size_t par = q0 + (size_t)(J0 + 8 * q + rl) * ld + I0 + c4;
-            const int a = (8 * q + rl) * LS + c4;
-            if (UPDATE) {
-                f32x4 x, y, z;
+            for (int e = 0; e < 4; ++e) { x[e] = sPM[a + e]; y[e] = sPm[a + e]; z[e] = sPv[a + e]; }
+            *reinterpret_cast<f32x4*>(p.M + par) = x;
+            *reinterpret_cast<f32x4*>(p.mM + par) = y;
+            *reinterpret_cast<f32x4*>(p.vM + par) = z;
+        }
+        if (WRITE_ABAR) {
+            f32x4 w;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { x[e] = sPM[a + e]; y[e] = sPm[a + e]; z[e] = sPv[a + e]; }
-                *reinterpret_cast<f32x4*>(p.M + par) = x;
-                *reinterpret_cast<f32x4*>(p.mM + par) = y;
-                *reinterpret_cast<f32x4*>(p.vM + par) = z;
-            }
-            if (WRITE_ABAR) {
-                f32x4 w;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) w[e] = sS[a + e];
-                *reinterpret_cast<f32x4*>(p.Abar + par) = w;
-            }
+            for (int e = 0; e < 4; ++e) w[e] = sS[a + e];
+            *reinterpret_cast<f32x4*>(p.Abar + par) = w;
         }
     }
     if (UPDATE && LOSS) {
@@ -840,13 +776,13 @@ __global__ __launch_bounds__(64) void k_mask(Params p, const MaskTile* tiles, in
             atomicAdd(&L[3], p.c_ent * s_ent * inv_n2);
         }
     }
-    // feature-mask Adam step: once per target, by the wave that owns tile (0,0)
-    if (UPDATE && tl.I == 0 && tl.J == 0 && lane < p.D) {
-        const int o = tl.t * FS + lane;
+    // feature-mask Adam step: once per target, by the workgroup that owns tile (0,0)
+    if (UPDATE && tl.I == 0 && tl.J == 0 && tid < p.D) {
+        const int o = tl.t * FS + tid;
         const float fcur = p.f[iter & 1][o];
         const float ph = sigmoidf_(fcur);
         float dsum = 0.0f;
-        for (int rb = 0; rb < (ld >> 5); ++rb) dsum += p.df[((size_t)(tm.offR >> 5) + rb) * FS + lane];
+        for (int rb = 0; rb < (ld >> 5); ++rb) dsum += p.df[((size_t)(tm.offR >> 5) + rb) * FS + tid];
         const float gf = (dsum + p.c_feat_size / (float)p.D) * ph * (1.0f - ph);
         float fnew = fcur, m = p.mf[o], v = p.vf[o];
         adam_update(fnew, m, v, gf, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
