@@ -49,8 +49,9 @@ struct TargetMeta {
     int64_t offR;  // row offset in row arrays
 };
 
-struct ConvTile { int32_t t, rb; };                 // target, 32-row block
-struct MaskTile { int32_t t, I, J; int32_t pad; };  // target, tile pair I <= J
+// tile-table entries carry a copy of the target's meta: one dependent load per workgroup instead of two
+struct ConvTile { int32_t t, rb; TargetMeta tm; };               // target, 32-row block
+struct MaskTile { int32_t t, I, J; int32_t pad; TargetMeta tm; };  // target, tile pair I <= J
 
 struct Params {
     const TargetMeta* meta;
@@ -69,6 +70,7 @@ struct Params {
     float* dZ[3];       // gradients w.r.t. the aggregated inputs, row-major [R][32]
     float* dZT[3];      // same, column-major
     float* g3;          // node mode: layer-3 part of row t of G, one float per row [R]
+    float* z3p;         // node mode: per row block partial of row t of Abar . relu(U2)  [R/32][32]
     float* dE;          // direct gradient of the concatenated embedding [T][3][32]
     int32_t* argrow;    // row that receives dE[l][c]  [T][3][32]
     float* df;          // feature-mask gradient partials, one row of 32 per 32-row block [R/32][32]
@@ -132,62 +134,200 @@ __device__ __forceinline__ void rowlocal_backward(const float (&du)[4], const fl
 }
 
 // ---------------------------------------------------------------------------------------------
-// Masked-adjacency contraction + fused row-local epilogue.  One workgroup (4 waves) per 32-row
-// block of one target; the K range (all ld columns of Abar) is split over the 4 waves.
+// Masked-adjacency contraction + fused row-local epilogue.
+//   k_conv      : one workgroup (4 waves) per 32-row block; 4 B / lane operand loads (a 32-row block is only
+//                 128 B wide).  Used for every target with ld < 256 and for the tail blocks of larger ones.
+//   k_conv_wide : one workgroup per 128-row group of a large target (ld >= 256): the symmetric Abar is read as
+//                 16 B / lane segments Abar[k][row0 + 4 li .. +3], register g of the float4 feeds the MFMA whose
+//                 32 output rows are row0 + 4 rho + g; the B operand is shared by the 4 MFMAs.
+// In both, the K range (all ld columns of Abar) is split over the 4 waves and reduced through LDS.
 // ---------------------------------------------------------------------------------------------
+struct ConvShared {
+    float red[4 * TILE * 33];  // split-K partial tiles
+    float wl[32 * 33];         // layer weight, padded rows
+    float zs[TILE * 33];       // reduced Z rows, then dY staging
+    float phis[32];
+};
+
+// Fused row-local epilogue for 32 rows: thread (row = tid/8, cg = 4 (tid%8)) holds z4 = the reduced contraction of
+// target row `irow`.  `slot` = index of this 32-row set among the target's row sets (for the per-set partials).
 template <int MODE>
-__global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, int iter) {
-    __shared__ float red[4 * TILE * 33];  // split-K partial tiles
-    __shared__ float wl[32 * 33];         // layer weight, padded rows
-    __shared__ float zs[TILE * 33];       // reduced Z rows, then dY staging
-    __shared__ float phis[32];
-
-    const ConvTile tl = tiles[blockIdx.x];
-    const TargetMeta tm = p.meta[tl.t];
-    const int ld = tm.ld;
-    const int row0 = tl.rb * TILE;
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
-
+__device__ __forceinline__ void conv_epilogue(const Params& p, const ConvTile& tl, const TargetMeta& tm, ConvShared& sh,
+                                              float (&z4)[4], int irow, int slot, const f32x4& pre_a, const f32x4& pre_b,
+                                              const f32x4& pre_c, const int (&pre_ar)[4], float pre_rn) {
     constexpr int layer = (MODE == FWD1 || MODE == BWD1) ? 0 : (MODE == FWD2 || MODE == BWD2) ? 1 : 2;
-    {
-        const float* W = p.wts + WT_W + layer * 1024;
-        for (int e = tid; e < 1024; e += 256) wl[(e >> 5) * 33 + (e & 31)] = W[e];
-        if (MODE == FWD1 && tid < 32) phis[tid] = (tid < p.D) ? sigmoidf_(p.f[iter & 1][tl.t * FS + tid]) : 0.0f;
-    }
-
-    // epilogue operands, loaded BEFORE the contraction so their latency hides under it
-    const int row = tid >> 3;      // 0..31
-    const int cg = (tid & 7) * 4;  // column group
-    const size_t grow = (size_t)tm.offR + row0 + row;  // global row in row arrays
-    const int irow = row0 + row;                       // row inside the target
     constexpr bool IS_FWD = (MODE == FWD1 || MODE == FWD2 || MODE == FWD3);
-    f32x4 pre_a = {0.0f, 0.0f, 0.0f, 0.0f}, pre_b = pre_a, pre_c = pre_a;
-    int pre_ar[4] = {-1, -1, -1, -1};
-    float pre_rn = 1.0f;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row = tid >> 3, cg = (tid & 7) * 4;
+    const int ld = tm.ld;
+    const size_t grow = (size_t)tm.offR + irow;
+    if (IS_FWD) {
+        if (MODE == FWD1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                p.Zraw[grow * FS + cg + j] = z4[j];
+                z4[j] *= sh.phis[cg + j];  // Abar.(X * phi) == (Abar.X) * phi, phi is a per-column scale
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sh.zs[row * 33 + cg + j] = z4[j];
+        __syncthreads();
+        const int din = (MODE == FWD1) ? p.D : p.H;
+        const int dout = (MODE == FWD3) ? p.O : p.H;
+        float y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = 0.0f;
+        for (int k = 0; k < din; ++k) {
+            const float z = sh.zs[row * 33 + k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = fmaf(z, sh.wl[k * 33 + cg + j], y[j]);
+        }
+        float ss = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            y[j] = (cg + j < dout) ? y[j] + pre_a[j] : 0.0f;
+            ss = fmaf(y[j], y[j], ss);
+        }
+        ss += __shfl_xor(ss, 1);
+        ss += __shfl_xor(ss, 2);
+        ss += __shfl_xor(ss, 4);
+        const float rnorm = fmaxf(sqrtf(ss), 1e-12f);
+        float* U = p.U[layer] + grow * FS;
+        float* UT = p.UT[layer] + tm.offR * FS;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float u = y[j] / rnorm;
+            U[cg + j] = u;
+            UT[(size_t)(cg + j) * ld + irow] = u;
+        }
+        if ((tid & 7) == 0) p.rn[layer][grow] = rnorm;
+        if (MODE == FWD2 && !p.graph_mode) {
+            // node mode reads only row t of layer 3 (explain.py:713): this row set's share of
+            // Z3[t] = sum_k Abar[t][k] relu(U2[k]) is reduced here so the head never walks all n rows
+            float part[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                part[j] = pre_rn * fmaxf(y[j] / rnorm, 0.0f);
+                part[j] += __shfl_xor(part[j], 8);
+                part[j] += __shfl_xor(part[j], 16);
+                part[j] += __shfl_xor(part[j], 32);
+            }
+            __syncthreads();
+            if (lane < 8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sh.red[wave * 32 + cg + j] = part[j];
+            }
+            __syncthreads();
+            if (tid < 32)
+                p.z3p[((size_t)(tm.offR >> 5) + slot) * FS + tid] =
+                    sh.red[tid] + sh.red[32 + tid] + sh.red[64 + tid] + sh.red[96 + tid];
+        }
+    } else {
+        // BWD3 / BWD2 / BWD1: dX (+ direct part) -> dZ_layer
+        const int dout = (layer == 2) ? p.O : p.H;  // width of U[layer] / dX
+        const int din = (layer == 0) ? p.D : p.H;   // width of dZ[layer]
+        float du[4], u[4], dz[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = cg + j;
+            float dx = (MODE == BWD3) ? 0.0f : z4[j];
+            u[j] = pre_a[j];
+            if (c < dout && pre_ar[j] == irow) dx += pre_b[j];
+            if (layer < 2) dx = (u[j] > 0.0f) ? dx : 0.0f;
+            du[j] = (c < dout) ? dx : 0.0f;
+        }
+        rowlocal_backward(du, u, pre_rn, dout, row, cg, sh.zs, sh.wl, dz);
+        float* dZ = p.dZ[layer] + grow * FS;
+        float* dZT = p.dZT[layer] + tm.offR * FS;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dz[j] = (cg + j < din) ? dz[j] : 0.0f;
+            dZ[cg + j] = dz[j];
+            dZT[(size_t)(cg + j) * ld + irow] = dz[j];
+        }
+        if (MODE == BWD1) {
+            // feature-mask gradient: colsum((Abar.dZ1) * X) == colsum(dZ1 * (Abar.X)), Abar symmetric
+            float part[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                part[j] = dz[j] * pre_c[j];
+                part[j] += __shfl_xor(part[j], 8);  // the 8 rows of this wave
+                part[j] += __shfl_xor(part[j], 16);
+                part[j] += __shfl_xor(part[j], 32);
+            }
+            __syncthreads();
+            if (lane < 8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sh.red[wave * 32 + cg + j] = part[j];
+            }
+            __syncthreads();
+            if (tid < 32)  // one partial per row set, summed in a fixed order by k_mask (deterministic)
+                p.df[((size_t)(tm.offR >> 5) + slot) * FS + tid] =
+                    sh.red[tid] + sh.red[32 + tid] + sh.red[64 + tid] + sh.red[96 + tid];
+        }
+    }
+}
+
+// operands of the epilogue for target row irow, columns cg..cg+3
+template <int MODE>
+__device__ __forceinline__ void conv_epilogue_operands(const Params& p, const ConvTile& tl, const TargetMeta& tm, int irow,
+                                                       int cg, f32x4& pre_a, f32x4& pre_b, f32x4& pre_c, int (&pre_ar)[4],
+                                                       float& pre_rn) {
+    constexpr int layer = (MODE == FWD1 || MODE == BWD1) ? 0 : (MODE == FWD2 || MODE == BWD2) ? 1 : 2;
+    constexpr bool IS_FWD = (MODE == FWD1 || MODE == FWD2 || MODE == FWD3);
+    const size_t grow = (size_t)tm.offR + irow;
     if (IS_FWD) {
         pre_a = *reinterpret_cast<const f32x4*>(p.wts + WT_B + layer * 32 + cg);  // bias
+        if (MODE == FWD2 && !p.graph_mode) pre_rn = p.Abar[tm.offQ + (size_t)tm.t * tm.ld + irow];  // Abar[t][row]
     } else {
-        pre_a = *reinterpret_cast<const f32x4*>(p.U[layer] + grow * FS + cg);                // U
-        pre_b = *reinterpret_cast<const f32x4*>(p.dE + (tl.t * 3 + layer) * FS + cg);        // direct gradient
+        pre_a = *reinterpret_cast<const f32x4*>(p.U[layer] + grow * FS + cg);          // U
+        pre_b = *reinterpret_cast<const f32x4*>(p.dE + (tl.t * 3 + layer) * FS + cg);  // direct gradient
 #pragma unroll
         for (int j = 0; j < 4; ++j) pre_ar[j] = p.argrow[(tl.t * 3 + layer) * FS + cg + j];
         pre_rn = p.rn[layer][grow];
         if (MODE == BWD1) pre_c = *reinterpret_cast<const f32x4*>(p.Zraw + grow * FS + cg);
     }
+}
+
+template <int MODE>
+__device__ __forceinline__ void conv_stage_weights(const Params& p, const ConvTile& tl, ConvShared& sh, int iter) {
+    constexpr int layer = (MODE == FWD1 || MODE == BWD1) ? 0 : (MODE == FWD2 || MODE == BWD2) ? 1 : 2;
+    const int tid = threadIdx.x;
+    const float* W = p.wts + WT_W + layer * 1024;
+    for (int e = tid; e < 1024; e += 256) sh.wl[(e >> 5) * 33 + (e & 31)] = W[e];
+    if (MODE == FWD1 && tid < 32) sh.phis[tid] = (tid < p.D) ? sigmoidf_(p.f[iter & 1][tl.t * FS + tid]) : 0.0f;
+}
+
+template <int MODE>
+__device__ __forceinline__ const float* conv_b_source(const Params& p) {
+    return (MODE == FWD1) ? p.X : (MODE == FWD2) ? p.U[0] : (MODE == FWD3) ? p.U[1] : (MODE == BWD2) ? p.dZ[2] : p.dZ[1];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, int iter) {
+    __shared__ ConvShared sh;
+    const ConvTile tl = tiles[blockIdx.x];
+    const TargetMeta tm = tl.tm;
+    const int ld = tm.ld;
+    const int row0 = tl.rb * TILE;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    conv_stage_weights<MODE>(p, tl, sh, iter);
+
+    // epilogue operands, loaded BEFORE the contraction so their latency hides under it
+    const int row = tid >> 3, cg = (tid & 7) * 4;
+    const int irow = row0 + row;
+    f32x4 pre_a = {0.0f, 0.0f, 0.0f, 0.0f}, pre_b = pre_a, pre_c = pre_a;
+    int pre_ar[4] = {-1, -1, -1, -1};
+    float pre_rn = 1.0f;
+    conv_epilogue_operands<MODE>(p, tl, tm, irow, cg, pre_a, pre_b, pre_c, pre_ar, pre_rn);
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-
     if (MODE != BWD3) {
         const float* Ab = p.Abar + tm.offQ + row0 + li;  // Abar[k][i] == Abar[i][k]: 128-B coalesced segments
-        const float* Bsrc = (MODE == FWD1)   ? p.X
-                            : (MODE == FWD2) ? p.U[0]
-                            : (MODE == FWD3) ? p.U[1]
-                            : (MODE == BWD2) ? p.dZ[2]
-                                             : p.dZ[1];
-        Bsrc += tm.offR * FS + li;
+        const float* Bsrc = conv_b_source<MODE>(p) + tm.offR * FS + li;
         const int kchunk = ld >> 2;  // multiple of 8
         const int k0 = wave * kchunk + h;
         // 8 k-steps per batch, two batches of loads in flight (register double buffer)
@@ -221,98 +361,92 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
     }
     // split-K reduction through LDS
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wave * TILE + acc_row(r, h)) * 33 + li] = acc[r];
+    for (int r = 0; r < 16; ++r) sh.red[(wave * TILE + acc_row(r, h)) * 33 + li] = acc[r];
     __syncthreads();
     float z4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float s = 0.0f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) s += red[(w * TILE + row) * 33 + cg + j];
+        for (int w = 0; w < 4; ++w) s += sh.red[(w * TILE + row) * 33 + cg + j];
         z4[j] = s;
     }
-    if (IS_FWD) {
-        if (MODE == FWD1) {
+    conv_epilogue<MODE>(p, tl, tm, sh, z4, irow, tl.rb, pre_a, pre_b, pre_c, pre_ar, pre_rn);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_conv_wide(Params p, const ConvTile* tiles, int iter) {
+    static_assert(MODE != BWD3, "the row-local BWD3 has no contraction");
+    __shared__ ConvShared sh;
+    const ConvTile tl = tiles[blockIdx.x];  // rb = index of the 128-row group
+    const TargetMeta tm = tl.tm;
+    const int ld = tm.ld;
+    const int row0 = tl.rb * (4 * TILE);
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    conv_stage_weights<MODE>(p, tl, sh, iter);
+
+    f32x16 acc[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                p.Zraw[grow * FS + cg + j] = z4[j];
-                z4[j] *= phis[cg + j];  // Abar.(X * phi) == (Abar.X) * phi, phi is a per-column scale
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
+    {
+        const float* Ab = p.Abar + tm.offQ + row0 + 4 * li;  // 512-B coalesced segments of row k
+        const float* Bsrc = conv_b_source<MODE>(p) + tm.offR * FS + li;
+        const int kchunk = ld >> 2;  // multiple of 8
+        const int k0 = wave * kchunk + h;
+        f32x4 a0[4], a1[4];
+        float b0[4], b1[4];
+        auto load4 = [&](f32x4 (&a)[4], float (&b)[4], int s0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // kchunk is a multiple of 8: a batch of 4 k-steps (8 k values) is never partial
+                const int k = k0 + s0 + 2 * u;
+                a[u] = *reinterpret_cast<const f32x4*>(Ab + (size_t)k * ld);
+                b[u] = Bsrc[(size_t)k * FS];
             }
-        }
+        };
+        auto mma4 = [&](const f32x4 (&a)[4], const float (&b)[4]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) zs[row * 33 + cg + j] = z4[j];
+            for (int u = 0; u < 4; ++u) {
+                float bb = b[u];
+                if (MODE == FWD2 || MODE == FWD3) bb = fmaxf(bb, 0.0f);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][g], bb, acc[g], 0, 0, 0);
+            }
+        };
+        load4(a0, b0, 0);
+        for (int s0 = 0; s0 < kchunk; s0 += 16) {
+            const bool more1 = s0 + 8 < kchunk;
+            if (more1) load4(a1, b1, s0 + 8);
+            mma4(a0, b0);
+            const bool more0 = s0 + 16 < kchunk;
+            if (more0) load4(a0, b0, s0 + 16);
+            if (more1) mma4(a1, b1);
+        }
+    }
+    const int row = tid >> 3, cg = (tid & 7) * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        // MFMA g produced the rows row0 + 4 rho + g (rho = accumulator row)
+        const int irow = row0 + 4 * row + g;
+        f32x4 pre_a = {0.0f, 0.0f, 0.0f, 0.0f}, pre_b = pre_a, pre_c = pre_a;
+        int pre_ar[4] = {-1, -1, -1, -1};
+        float pre_rn = 1.0f;
+        conv_epilogue_operands<MODE>(p, tl, tm, irow, cg, pre_a, pre_b, pre_c, pre_ar, pre_rn);
+        __syncthreads();  // previous pass is done with red / zs
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sh.red[(wave * TILE + acc_row(r, h)) * 33 + li] = acc[g][r];
         __syncthreads();
-        const int din = (MODE == FWD1) ? p.D : p.H;
-        const int dout = (MODE == FWD3) ? p.O : p.H;
-        float y[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = 0.0f;
-        for (int k = 0; k < din; ++k) {
-            const float z = zs[row * 33 + k];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) y[j] = fmaf(z, wl[k * 33 + cg + j], y[j]);
-        }
-        float ss = 0.0f;
+        float z4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            y[j] = (cg + j < dout) ? y[j] + pre_a[j] : 0.0f;
-            ss = fmaf(y[j], y[j], ss);
-        }
-        ss += __shfl_xor(ss, 1);
-        ss += __shfl_xor(ss, 2);
-        ss += __shfl_xor(ss, 4);
-        const float rnorm = fmaxf(sqrtf(ss), 1e-12f);
-        float* U = p.U[layer] + grow * FS;
-        float* UT = p.UT[layer] + tm.offR * FS;
+            float s = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float u = y[j] / rnorm;
-            U[cg + j] = u;
-            UT[(size_t)(cg + j) * ld + irow] = u;
+            for (int w = 0; w < 4; ++w) s += sh.red[(w * TILE + row) * 33 + cg + j];
+            z4[j] = s;
         }
-        if ((tid & 7) == 0) p.rn[layer][grow] = rnorm;
-    } else {
-        // BWD3 / BWD2 / BWD1: dX (+ direct part) -> dZ_layer
-        const int dout = (layer == 2) ? p.O : p.H;  // width of U[layer] / dX
-        const int din = (layer == 0) ? p.D : p.H;   // width of dZ[layer]
-        float du[4], u[4], dz[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = cg + j;
-            float dx = (MODE == BWD3) ? 0.0f : z4[j];
-            u[j] = pre_a[j];
-            if (c < dout && pre_ar[j] == irow) dx += pre_b[j];
-            if (layer < 2) dx = (u[j] > 0.0f) ? dx : 0.0f;
-            du[j] = (c < dout) ? dx : 0.0f;
-        }
-        rowlocal_backward(du, u, pre_rn, dout, row, cg, zs, wl, dz);
-        float* dZ = p.dZ[layer] + grow * FS;
-        float* dZT = p.dZT[layer] + tm.offR * FS;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            dz[j] = (cg + j < din) ? dz[j] : 0.0f;
-            dZ[cg + j] = dz[j];
-            dZT[(size_t)(cg + j) * ld + irow] = dz[j];
-        }
-        if (MODE == BWD1) {
-            // feature-mask gradient: colsum((Abar.dZ1) * X) == colsum(dZ1 * (Abar.X)), Abar symmetric
-            float part[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                part[j] = dz[j] * pre_c[j];
-                part[j] += __shfl_xor(part[j], 8);  // the 8 rows of this wave
-                part[j] += __shfl_xor(part[j], 16);
-                part[j] += __shfl_xor(part[j], 32);
-            }
-            __syncthreads();
-            if (lane < 8) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) red[wave * 32 + cg + j] = part[j];
-            }
-            __syncthreads();
-            if (tid < 32)  // one partial per row block, summed in a fixed order by k_mask (deterministic)
-                p.df[((size_t)(tm.offR >> 5) + tl.rb) * FS + tid] = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
-        }
+        conv_epilogue<MODE>(p, tl, tm, sh, z4, irow, tl.rb * 4 + g, pre_a, pre_b, pre_c, pre_ar, pre_rn);
     }
 }
 
@@ -424,7 +558,7 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
     __shared__ float sr3;
     const ConvTile tl = tiles[blockIdx.x];
     const int t = tl.t;
-    const TargetMeta tm = p.meta[t];
+    const TargetMeta tm = tl.tm;
     const int tid = threadIdx.x, ld = tm.ld, n = tm.n, tr = tm.t;
     const float* Ab = p.Abar + tm.offQ;
     const float* U1 = p.U[0] + tm.offR * FS;
@@ -442,20 +576,12 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
     const f32x4 u2i = *reinterpret_cast<const f32x4*>(U2 + (size_t)i * FS + cg);
     const float rn2i = p.rn[1][tm.offR + i];
 
-    // Z3[t][c] = sum_k Abar[t][k] relu(U2[k][c]) : 8 k-slices x 32 columns, 4 loads in flight per thread
+    // Z3[t][c] = sum_k Abar[t][k] relu(U2[k][c]): the per-row-block partials were reduced by k_conv<FWD2>;
+    // sum them in a fixed order (8 slices x 32 columns)
     {
         const int c = tid & 31, sl = tid >> 5;
         float s = 0.0f;
-        for (int k = sl; k < ld; k += 32) {  // rows >= n of Abar[t,:] are zero, U2 is finite there
-            float a[4], u[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                a[q] = Ab[(size_t)tr * ld + k + 8 * q];
-                u[q] = U2[(size_t)(k + 8 * q) * FS + c];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) s = fmaf(a[q], fmaxf(u[q], 0.0f), s);
-        }
+        for (int rb = sl; rb < (ld >> 5); rb += 8) s += p.z3p[((size_t)(tm.offR >> 5) + rb) * FS + c];
         part[sl * 32 + c] = s;
         for (int e2 = tid; e2 < 1024; e2 += 256) wl[(e2 >> 5) * 33 + (e2 & 31)] = W3[e2];
     }
@@ -566,7 +692,7 @@ __global__ __launch_bounds__(256) void k_mask(Params p, const MaskTile* tiles, i
     __shared__ float sPM[TILE * LS], sPm[TILE * LS], sPv[TILE * LS];  // mirror tile (J,I), natural orientation [j][i]
     __shared__ float sS[TILE * LS];                                  // sigma exchange, then Abar of the mirror tile
     const MaskTile tl = tiles[blockIdx.x];
-    const TargetMeta tm = p.meta[tl.t];
+    const TargetMeta tm = tl.tm;
     const int ld = tm.ld, n = tm.n;
     const int I0 = tl.I * TILE, J0 = tl.J * TILE;
     const bool diag = (tl.I == tl.J);

@@ -83,3 +83,15 @@ def test_outputs_are_bitwise_symmetric_and_zero_off_edges():
     res = emu_job([sg], ck["sd"]).run([sg.mask0], Hyper(num_iters=5))
     ma = res.masked_adj[0]
     assert np.array_equal(ma, ma.T) and np.all(ma[sg.adj == 0] == 0) and np.all(np.diag(ma) == 0)
+
+
+def test_wide_contraction_path_large_target():
+    """n = 310 -> ld = 320: two 128-row groups go through k_conv_wide, the 64-row tail through k_conv."""
+    ck, gx, sg = _node_case("syn1", 300)
+    assert sg.adj.shape[0] == 310
+    res = emu_job([sg], ck["sd"]).run([sg.mask0], Hyper(num_iters=2))
+    o = closed_form.ClosedFormOracle(sg.adj, sg.feat, ck["sd"], sg.gt_label, sg.pred_label, sg.target_row, sg.mask0)
+    want = o.run(2)
+    assert np.abs(res.masked_adj[0] - want).max() < 2e-6
+    assert np.abs(res.mask[0] - o.M).max() < 2e-5
+    assert np.abs(res.feat_mask[0] - o.f).max() < 2e-5
