@@ -38,11 +38,9 @@ struct gnnx_plan_s {
     gnnx_problem prob{};
     std::vector<TargetMeta> meta;
     int64_t Q = 0, R = 0;
-    int n_conv = 0, n_convw = 0, n_rows = 0, n_mask = 0;
+    int n_conv = 0, n_mask = 0;
     TargetMeta* d_meta = nullptr;
-    ConvTile* d_conv = nullptr;   // 32-row blocks handled by k_conv (small targets + tails of large ones)
-    ConvTile* d_convw = nullptr;  // 128-row groups of large targets (ld >= 256), handled by k_conv_wide
-    ConvTile* d_rows = nullptr;   // every 32-row block (row-local kernels)
+    ConvTile* d_conv = nullptr;   // every 32-row block of every target
     MaskTile* d_mask = nullptr;
     float* d_wts = nullptr;
     double sum_n2 = 0;
@@ -68,7 +66,7 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
     h->prob = *prob;
     const int T = prob->num_targets;
     h->meta.resize(T);
-    std::vector<ConvTile> conv, convw, rows;
+    std::vector<ConvTile> conv;
     std::vector<MaskTile> mask;
     for (int t = 0; t < T; ++t) {
         const int n = prob->n[t];
@@ -101,16 +99,11 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h->meta[a].ld > h->meta[b].ld; });
     for (int t : order) {
         const int nb = h->meta[t].ld / TILE;
-        const int n128 = (h->meta[t].ld >= 256) ? h->meta[t].ld / 128 : 0;
-        for (int g = 0; g < n128; ++g) convw.push_back({t, g, h->meta[t]});
-        for (int rb = n128 * 4; rb < nb; ++rb) conv.push_back({t, rb, h->meta[t]});
-        for (int rb = 0; rb < nb; ++rb) rows.push_back({t, rb, h->meta[t]});
+        for (int rb = 0; rb < nb; ++rb) conv.push_back({t, rb, h->meta[t]});
         for (int I = 0; I < nb; ++I)
             for (int J = I; J < nb; ++J) mask.push_back({t, I, J, 0, h->meta[t]});
     }
     h->n_conv = (int)conv.size();
-    h->n_convw = (int)convw.size();
-    h->n_rows = (int)rows.size();
     h->n_mask = (int)mask.size();
 
     // packed, zero padded model block
@@ -138,15 +131,11 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
         }                                                                                              \
     } while (0)
     PLANCK(hipMalloc(&h->d_meta, sizeof(TargetMeta) * T));
-    PLANCK(hipMalloc(&h->d_conv, sizeof(ConvTile) * (conv.size() + 1)));
-    PLANCK(hipMalloc(&h->d_convw, sizeof(ConvTile) * (convw.size() + 1)));
-    PLANCK(hipMalloc(&h->d_rows, sizeof(ConvTile) * rows.size()));
+    PLANCK(hipMalloc(&h->d_conv, sizeof(ConvTile) * conv.size()));
     PLANCK(hipMalloc(&h->d_mask, sizeof(MaskTile) * mask.size()));
     PLANCK(hipMalloc(&h->d_wts, sizeof(float) * WT_TOTAL));
     PLANCK(hipMemcpy(h->d_meta, h->meta.data(), sizeof(TargetMeta) * T, hipMemcpyHostToDevice));
     PLANCK(hipMemcpy(h->d_conv, conv.data(), sizeof(ConvTile) * conv.size(), hipMemcpyHostToDevice));
-    PLANCK(hipMemcpy(h->d_convw, convw.data(), sizeof(ConvTile) * convw.size(), hipMemcpyHostToDevice));
-    PLANCK(hipMemcpy(h->d_rows, rows.data(), sizeof(ConvTile) * rows.size(), hipMemcpyHostToDevice));
     PLANCK(hipMemcpy(h->d_mask, mask.data(), sizeof(MaskTile) * mask.size(), hipMemcpyHostToDevice));
     PLANCK(hipMemcpy(h->d_wts, w.data(), sizeof(float) * WT_TOTAL, hipMemcpyHostToDevice));
 #undef PLANCK
@@ -190,8 +179,6 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->d_meta) (void)hipFree(h->d_meta);
     if (h->d_conv) (void)hipFree(h->d_conv);
-    if (h->d_convw) (void)hipFree(h->d_convw);
-    if (h->d_rows) (void)hipFree(h->d_rows);
     if (h->d_mask) (void)hipFree(h->d_mask);
     if (h->d_wts) (void)hipFree(h->d_wts);
     delete h;
@@ -273,13 +260,7 @@ static void adam_scalars(const gnnx_hyper* hy, int it, float* step_size, float* 
 
 template <int MODE>
 static void launch_conv(gnnx_handle h, const Params& p, int it, hipStream_t s) {
-    if (MODE == BWD3) {  // row-local: every 32-row block
-        hipLaunchKernelGGL((k_conv<MODE>), dim3(h->n_rows), dim3(256), 0, s, p, h->d_rows, it);
-        return;
-    }
-    // large targets first (longest workgroups), then the 32-row blocks; independent outputs, same stream
-    if (h->n_convw) hipLaunchKernelGGL((k_conv_wide<(MODE == BWD3 ? BWD2 : MODE)>), dim3(h->n_convw), dim3(256), 0, s, p, h->d_convw, it);
-    if (h->n_conv) hipLaunchKernelGGL((k_conv<MODE>), dim3(h->n_conv), dim3(256), 0, s, p, h->d_conv, it);
+    hipLaunchKernelGGL((k_conv<MODE>), dim3(h->n_conv), dim3(256), 0, s, p, h->d_conv, it);
 }
 
 template <bool UPDATE, bool WRITE_ABAR>
@@ -301,7 +282,7 @@ static void launch_forward(gnnx_handle h, const Params& p, int it, hipStream_t s
         launch_conv<FWD3>(h, p, it, s);
         hipLaunchKernelGGL(k_head, dim3(T), dim3(256), 0, s, p, it);
     } else {
-        hipLaunchKernelGGL(k_node_head, dim3(h->n_rows), dim3(256), 0, s, p, h->d_rows, it);
+        hipLaunchKernelGGL(k_node_head, dim3(h->n_conv), dim3(256), 0, s, p, h->d_conv, it);
     }
 }
 
@@ -410,7 +391,7 @@ extern "C" int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hy, int32_t kin
             case 2: launch_conv<FWD2>(h, p, 0, s); break;
             case 3:
                 if (gm) hipLaunchKernelGGL(k_head, dim3(h->prob.num_targets), dim3(256), 0, s, p, 0);
-                else hipLaunchKernelGGL(k_node_head, dim3(h->n_rows), dim3(256), 0, s, p, h->d_rows, 0);
+                else hipLaunchKernelGGL(k_node_head, dim3(h->n_conv), dim3(256), 0, s, p, h->d_conv, 0);
                 break;
             case 4: launch_conv<BWD1>(h, p, 0, s); break;
             case 5: launch_conv<FWD3>(h, p, 0, s); break;

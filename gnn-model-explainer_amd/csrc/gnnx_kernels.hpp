@@ -134,13 +134,10 @@ __device__ __forceinline__ void rowlocal_backward(const float (&du)[4], const fl
 }
 
 // ---------------------------------------------------------------------------------------------
-// Masked-adjacency contraction + fused row-local epilogue.
-//   k_conv      : one workgroup (4 waves) per 32-row block; 4 B / lane operand loads (a 32-row block is only
-//                 128 B wide).  Used for every target with ld < 256 and for the tail blocks of larger ones.
-//   k_conv_wide : one workgroup per 128-row group of a large target (ld >= 256): the symmetric Abar is read as
-//                 16 B / lane segments Abar[k][row0 + 4 li .. +3], register g of the float4 feeds the MFMA whose
-//                 32 output rows are row0 + 4 rho + g; the B operand is shared by the 4 MFMAs.
-// In both, the K range (all ld columns of Abar) is split over the 4 waves and reduced through LDS.
+// Masked-adjacency contraction + fused row-local epilogue: one workgroup (4 waves) per 32-row block; the K
+// range (all ld columns of Abar) is split over the 4 waves and reduced through LDS.  (A 128-row / 16-B-per-lane
+// variant was measured in round 1 and was slower - 175 vs 152 us per launch on the BA-House x100k sample - because
+// its per-wave MFMA chains are 4x longer while the prefetch depth stays the same; see DESIGN.md.)
 // ---------------------------------------------------------------------------------------------
 struct ConvShared {
     float red[4 * TILE * 33];  // split-K partial tiles
@@ -326,37 +323,37 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     if (MODE != BWD3) {
-        const float* Ab = p.Abar + tm.offQ + row0 + li;  // Abar[k][i] == Abar[i][k]: 128-B coalesced segments
+        // A operand: lane (i = li, half h) reads 16 B of row row0+i: Abar[row0+i][k0 + 8u + 4h .. +3].  The MFMA
+        // k index is a free permutation as long as A and B agree, so step e of batch u uses k = k0 + 8u + 4h + e:
+        // one 16-B load feeds 4 MFMAs (4-B loads cap at ~2.3-2.9 TB/s on this chip).
+        const float* Ab = p.Abar + tm.offQ + (size_t)(row0 + li) * ld + 4 * h;
         const float* Bsrc = conv_b_source<MODE>(p) + tm.offR * FS + li;
         const int kchunk = ld >> 2;  // multiple of 8
-        const int k0 = wave * kchunk + h;
-        // 8 k-steps per batch, two batches of loads in flight (register double buffer)
-        float a0[8], b0[8], a1[8], b1[8];
-        auto load8 = [&](float (&a)[8], float (&b)[8], int s0) {
+        const int k0 = wave * kchunk;
+        constexpr int NB = 4;  // batches of 8 k values in flight per wave
+        f32x4 a[NB];
+        float b[NB][4];
+        auto load = [&](int slot, int kk) {
+            a[slot] = *reinterpret_cast<const f32x4*>(Ab + k0 + kk);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool on = (s0 + 2 * u) < kchunk;  // kchunk is a multiple of 8, a batch spans 16 k values
-                const int k = k0 + s0 + 2 * u;
-                a[u] = on ? Ab[(size_t)k * ld] : 0.0f;
-                b[u] = on ? Bsrc[(size_t)k * FS] : 0.0f;
-            }
+            for (int e = 0; e < 4; ++e) b[slot][e] = Bsrc[(size_t)(k0 + kk + 4 * h + e) * FS];
         };
-        auto mma8 = [&](const float (&a)[8], const float (&b)[8]) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                float bb = b[u];
-                if (MODE == FWD2 || MODE == FWD3) bb = fmaxf(bb, 0.0f);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bb, acc, 0, 0, 0);
+        for (int sl = 0; sl < NB; ++sl)
+            if (8 * sl < kchunk) load(sl, 8 * sl);
+        for (int kk = 0; kk < kchunk; kk += 8 * NB) {
+#pragma unroll
+            for (int sl = 0; sl < NB; ++sl) {
+                if (kk + 8 * sl < kchunk) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float bb = b[sl][e];
+                        if (MODE == FWD2 || MODE == FWD3) bb = fmaxf(bb, 0.0f);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sl][e], bb, acc, 0, 0, 0);
+                    }
+                    if (kk + 8 * (sl + NB) < kchunk) load(sl, kk + 8 * (sl + NB));
+                }
             }
-        };
-        load8(a0, b0, 0);
-        for (int s0 = 0; s0 < kchunk; s0 += 32) {
-            const bool more1 = s0 + 16 < kchunk;
-            if (more1) load8(a1, b1, s0 + 16);
-            mma8(a0, b0);
-            const bool more0 = s0 + 32 < kchunk;
-            if (more0) load8(a0, b0, s0 + 32);
-            if (more1) mma8(a1, b1);
         }
     }
     // split-K reduction through LDS
@@ -372,82 +369,6 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
         z4[j] = s;
     }
     conv_epilogue<MODE>(p, tl, tm, sh, z4, irow, tl.rb, pre_a, pre_b, pre_c, pre_ar, pre_rn);
-}
-
-template <int MODE>
-__global__ __launch_bounds__(256) void k_conv_wide(Params p, const ConvTile* tiles, int iter) {
-    static_assert(MODE != BWD3, "the row-local BWD3 has no contraction");
-    __shared__ ConvShared sh;
-    const ConvTile tl = tiles[blockIdx.x];  // rb = index of the 128-row group
-    const TargetMeta tm = tl.tm;
-    const int ld = tm.ld;
-    const int row0 = tl.rb * (4 * TILE);
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
-    conv_stage_weights<MODE>(p, tl, sh, iter);
-
-    f32x16 acc[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
-    {
-        const float* Ab = p.Abar + tm.offQ + row0 + 4 * li;  // 512-B coalesced segments of row k
-        const float* Bsrc = conv_b_source<MODE>(p) + tm.offR * FS + li;
-        const int kchunk = ld >> 2;  // multiple of 8
-        const int k0 = wave * kchunk + h;
-        f32x4 a0[4], a1[4];
-        float b0[4], b1[4];
-        auto load4 = [&](f32x4 (&a)[4], float (&b)[4], int s0) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {  // kchunk is a multiple of 8: a batch of 4 k-steps (8 k values) is never partial
-                const int k = k0 + s0 + 2 * u;
-                a[u] = *reinterpret_cast<const f32x4*>(Ab + (size_t)k * ld);
-                b[u] = Bsrc[(size_t)k * FS];
-            }
-        };
-        auto mma4 = [&](const f32x4 (&a)[4], const float (&b)[4]) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                float bb = b[u];
-                if (MODE == FWD2 || MODE == FWD3) bb = fmaxf(bb, 0.0f);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][g], bb, acc[g], 0, 0, 0);
-            }
-        };
-        load4(a0, b0, 0);
-        for (int s0 = 0; s0 < kchunk; s0 += 16) {
-            const bool more1 = s0 + 8 < kchunk;
-            if (more1) load4(a1, b1, s0 + 8);
-            mma4(a0, b0);
-            const bool more0 = s0 + 16 < kchunk;
-            if (more0) load4(a0, b0, s0 + 16);
-            if (more1) mma4(a1, b1);
-        }
-    }
-    const int row = tid >> 3, cg = (tid & 7) * 4;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        // MFMA g produced the rows row0 + 4 rho + g (rho = accumulator row)
-        const int irow = row0 + 4 * row + g;
-        f32x4 pre_a = {0.0f, 0.0f, 0.0f, 0.0f}, pre_b = pre_a, pre_c = pre_a;
-        int pre_ar[4] = {-1, -1, -1, -1};
-        float pre_rn = 1.0f;
-        conv_epilogue_operands<MODE>(p, tl, tm, irow, cg, pre_a, pre_b, pre_c, pre_ar, pre_rn);
-        __syncthreads();  // previous pass is done with red / zs
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sh.red[(wave * TILE + acc_row(r, h)) * 33 + li] = acc[g][r];
-        __syncthreads();
-        float z4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float s = 0.0f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) s += sh.red[(w * TILE + row) * 33 + cg + j];
-            z4[j] = s;
-        }
-        conv_epilogue<MODE>(p, tl, tm, sh, z4, irow, tl.rb * 4 + g, pre_a, pre_b, pre_c, pre_ar, pre_rn);
-    }
 }
 
 // softmax head shared by both modes: e[96] (concatenated embedding) -> probs, g = p - onehot, dE = Wp^T g.

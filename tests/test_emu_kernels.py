@@ -85,8 +85,8 @@ def test_outputs_are_bitwise_symmetric_and_zero_off_edges():
     assert np.array_equal(ma, ma.T) and np.all(ma[sg.adj == 0] == 0) and np.all(np.diag(ma) == 0)
 
 
-def test_wide_contraction_path_large_target():
-    """n = 310 -> ld = 320: two 128-row groups go through k_conv_wide, the 64-row tail through k_conv."""
+def test_large_target_many_row_blocks():
+    """n = 310 -> ld = 320: 10 row blocks, 55 tile pairs, per-block partials (df, z3p) summed over 10 slots."""
     ck, gx, sg = _node_case("syn1", 300)
     assert sg.adj.shape[0] == 310
     res = emu_job([sg], ck["sd"]).run([sg.mask0], Hyper(num_iters=2))
