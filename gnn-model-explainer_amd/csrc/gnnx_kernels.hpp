@@ -323,36 +323,72 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     if (MODE != BWD3) {
-        // A operand: lane (i = li, half h) reads 16 B of row row0+i: Abar[row0+i][k0 + 8u + 4h .. +3].  The MFMA
-        // k index is a free permutation as long as A and B agree, so step e of batch u uses k = k0 + 8u + 4h + e:
-        // one 16-B load feeds 4 MFMAs (4-B loads cap at ~2.3-2.9 TB/s on this chip).
-        const float* Ab = p.Abar + tm.offQ + (size_t)(row0 + li) * ld + 4 * h;
         const float* Bsrc = conv_b_source<MODE>(p) + tm.offR * FS + li;
         const int kchunk = ld >> 2;  // multiple of 8
-        const int k0 = wave * kchunk;
-        constexpr int NB = 4;  // batches of 8 k values in flight per wave
-        f32x4 a[NB];
-        float b[NB][4];
-        auto load = [&](int slot, int kk) {
-            a[slot] = *reinterpret_cast<const f32x4*>(Ab + k0 + kk);
+        if (ld < 256) {
+            // small targets (latency-bound): lane (i = li, half h) reads 16 B of row row0+i,
+            // Abar[row0+i][k0 + 8u + 4h .. +3].  The MFMA k index is a free permutation as long as A and B agree,
+            // so step e of a batch uses k = k0 + 8u + 4h + e: one 16-B load feeds 4 MFMAs.  Measured on syn1:
+            // 9.5-10.8 us per launch vs 11.0-11.5 us for the 4-B form below.
+            const float* Ab = p.Abar + tm.offQ + (size_t)(row0 + li) * ld + 4 * h;
+            const int k0 = wave * kchunk;
+            constexpr int NB = 4;  // batches of 8 k values in flight per wave
+            f32x4 a[NB];
+            float b[NB][4];
+            auto load = [&](int slot, int kk) {
+                a[slot] = *reinterpret_cast<const f32x4*>(Ab + k0 + kk);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) b[slot][e] = Bsrc[(size_t)(k0 + kk + 4 * h + e) * FS];
-        };
+                for (int e = 0; e < 4; ++e) b[slot][e] = Bsrc[(size_t)(k0 + kk + 4 * h + e) * FS];
+            };
 #pragma unroll
-        for (int sl = 0; sl < NB; ++sl)
-            if (8 * sl < kchunk) load(sl, 8 * sl);
-        for (int kk = 0; kk < kchunk; kk += 8 * NB) {
+            for (int sl = 0; sl < NB; ++sl)
+                if (8 * sl < kchunk) load(sl, 8 * sl);
+            for (int kk = 0; kk < kchunk; kk += 8 * NB) {
 #pragma unroll
-            for (int sl = 0; sl < NB; ++sl) {
-                if (kk + 8 * sl < kchunk) {
+                for (int sl = 0; sl < NB; ++sl) {
+                    if (kk + 8 * sl < kchunk) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float bb = b[sl][e];
-                        if (MODE == FWD2 || MODE == FWD3) bb = fmaxf(bb, 0.0f);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sl][e], bb, acc, 0, 0, 0);
+                        for (int e = 0; e < 4; ++e) {
+                            float bb = b[sl][e];
+                            if (MODE == FWD2 || MODE == FWD3) bb = fmaxf(bb, 0.0f);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sl][e], bb, acc, 0, 0, 0);
+                        }
+                        if (kk + 8 * (sl + NB) < kchunk) load(sl, kk + 8 * (sl + NB));
                     }
-                    if (kk + 8 * (sl + NB) < kchunk) load(sl, kk + 8 * (sl + NB));
                 }
+            }
+        } else {
+            // large targets (bandwidth-bound): Abar is symmetric, so the A operand is read as Abar[k][row0 + li]:
+            // 128-B fully coalesced segments straight into the MFMA A layout.  The row form above touches 32
+            // cache lines per wave instruction and was 12 % slower here (BA-House x100k: 152-162 vs 171-181 us).
+            const float* Ab = p.Abar + tm.offQ + row0 + li;
+            const int k0 = wave * kchunk + h;
+            float a0[8], b0[8], a1[8], b1[8];
+            auto load8 = [&](float (&a)[8], float (&b)[8], int s0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool on = (s0 + 2 * u) < kchunk;  // a batch spans 16 k values, kchunk is a multiple of 8
+                    const int k = k0 + s0 + 2 * u;
+                    a[u] = on ? Ab[(size_t)k * ld] : 0.0f;
+                    b[u] = on ? Bsrc[(size_t)k * FS] : 0.0f;
+                }
+            };
+            auto mma8 = [&](const float (&a)[8], const float (&b)[8]) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    float bb = b[u];
+                    if (MODE == FWD2 || MODE == FWD3) bb = fmaxf(bb, 0.0f);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bb, acc, 0, 0, 0);
+                }
+            };
+            load8(a0, b0, 0);
+            for (int s0 = 0; s0 < kchunk; s0 += 32) {
+                const bool more1 = s0 + 16 < kchunk;
+                if (more1) load8(a1, b1, s0 + 16);
+                mma8(a0, b0);
+                const bool more0 = s0 + 32 < kchunk;
+                if (more0) load8(a0, b0, s0 + 32);
+                if (more1) mma8(a1, b1);
             }
         }
     }
