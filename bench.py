@@ -55,10 +55,10 @@ def build_workload(name, iters, rank=0, num_targets=4096):
     else:
         raise SystemExit("unknown workload " + name)
     subs = []
-    for t in targets:
-        new, A, nb = idx.extract(int(t))
+    targets = [int(t) for t in targets]
+    for t, (new, A, nb) in zip(targets, idx.extract_batch(targets)):
         subs.append(Subgraph(A, feat[nb], int(label[t]), new, np.argmax(pred[nb], 1),
-                             helpers.seeded_mask0(int(t), len(nb)).numpy()))
+                             helpers.seeded_mask0(t, len(nb)).numpy()))
     return ck, subs, desc
 
 

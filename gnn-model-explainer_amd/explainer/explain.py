@@ -114,6 +114,19 @@ class Explainer:
         return Subgraph(np.asarray(sub_adj, np.float32), np.asarray(sub_feat, np.float32), gt, int(node_idx_new),
                         pred_label, None), sub_adj
 
+    def _node_subgraphs(self, nodes, graph_idx):
+        """Batched form of _node_subgraph: one vectorised k-hop pass for all targets."""
+        feat, label, pred = _np(self.feat), _np(self.label), _np(self.pred)
+        adj_dtype = _np(self.adj).dtype
+        out = []
+        for v, (new, sub, nb) in zip(nodes, self._index(graph_idx).extract_batch(nodes)):
+            if len(nb) == 0:
+                raise IndexError("node %d has an empty %d-hop neighbourhood" % (v, self.n_hops))
+            pl = np.argmax(pred[graph_idx][nb], axis=1)
+            out.append((Subgraph(sub, np.asarray(feat[graph_idx, nb], np.float32), int(label[graph_idx][nb][new]), new,
+                                 pl, None), sub.astype(adj_dtype)))
+        return out
+
     def _graph_subgraph(self, graph_idx):
         sub_adj = _np(self.adj[graph_idx])                                             # explain.py:82-85
         sub_feat = _np(self.feat[graph_idx])
@@ -128,7 +141,7 @@ class Explainer:
             mode = True
         else:
             targets = list(node_indices)
-            built = [self._node_subgraph(v, graph_idx) for v in targets]
+            built = self._node_subgraphs(targets, graph_idx)
             mode = False
         subs = [b[0] for b in built]
         for s in subs:                                   # same RNG stream as ExplainModule.__init__ per target

@@ -46,8 +46,30 @@ class KHopIndex:
             frontier = nxt          # walks, not shortest paths: revisiting is what puts `node` itself in the set
         return seen.astype(np.int64)
 
+    def neighbors_batch(self, nodes):
+        """k-hop walk sets of many targets at once: rows of S + S.A + ... + S.A^(k-1), S = A[nodes] (sparse
+        products in C, no Python loop per hop).  -> list of ascending id arrays, same sets as `neighbors`."""
+        nodes = np.asarray(nodes, np.int64)
+        pattern = self.csr.astype(bool).astype(np.float32)
+        walk = pattern[nodes]
+        reach = walk.copy()
+        for _ in range(self.n_hops - 1):
+            walk = (walk @ pattern)
+            walk.data[:] = 1.0          # keep counts from overflowing / growing
+            reach = reach + walk
+        reach = reach.tocsr()
+        reach.sort_indices()
+        return [reach.indices[reach.indptr[r]:reach.indptr[r + 1]].astype(np.int64) for r in range(len(nodes))]
+
     def sizes(self, nodes):
-        return np.asarray([self.neighbors(v).size for v in nodes], np.int64)
+        return np.asarray([len(nb) for nb in self.neighbors_batch(nodes)], np.int64)
+
+    def extract_batch(self, nodes):
+        """-> list of (node_idx_new, sub_adj [n,n] float32, neighbors) for many targets (vectorised k-hop)."""
+        out = []
+        for v, nb in zip(nodes, self.neighbors_batch(nodes)):
+            out.append((int(np.searchsorted(nb, v)), self.sub_adjacency(nb), nb))
+        return out
 
     def sub_adjacency(self, nb):
         return np.asarray(self.csr[nb][:, nb].todense(), dtype=np.float32)

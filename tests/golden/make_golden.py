@@ -12,9 +12,9 @@ Seed protocol:
   * torch.manual_seed(1000 + target_id) immediately before each Explainer.explain call.
 
 Fixtures written:
-  syn1_ckpt.npz / syn4_ckpt.npz   graph (edge list), features, labels, model predictions, encoder weights
+  syn1_ckpt.npz / syn4_ckpt.npz / syn5_ckpt.npz   graph (edge list), features, labels, model predictions, encoder weights
                                    as minted by the reference's own train.py (syn_task1 / syn_task4)
-  syn1_explain.npz / syn4_explain.npz
+  syn1_explain.npz / syn4_explain.npz / syn5_explain.npz
                                    per target: sub-graph node ids, edge-entry values of the returned
                                    masked_adj (300 epochs), final sigma(feat_mask), final mask at edge
                                    entries, per-epoch loss, and for two small targets the initial mask
@@ -247,6 +247,9 @@ def main():
         print("syn4: training with the reference train.py ...")
         mint_checkpoint("syn4", work)
         node_fixture("syn4", [511, 520, 700, 870], work, keep_mask0=(511,))
+        print("syn5: training with the reference train.py ...")
+        mint_checkpoint("syn5", work)
+        node_fixture("syn5", [511, 515, 1000, 1230], work)
         print("graph mode ...")
         graph_fixture(work)
     finally:

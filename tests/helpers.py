@@ -41,3 +41,10 @@ def dense_from_edges(n, rc, vals):
     out = np.zeros((n, n), np.float64)
     out[rc[:, 0], rc[:, 1]] = vals
     return out
+
+
+# Targets whose optimisation crosses a loss plateau: fp32 round-off of any re-ordering is amplified (shown on the
+# CPU alone by tests/test_oracle_golden.py::test_ill_conditioned_targets_amplify_roundoff_even_on_cpu).
+ILL_CONDITIONED = {"syn5": (511, 1000, 1230)}
+ILL_TOL_MASK = 5e-4     # measured CPU-vs-CPU: up to 7.3e-5
+ILL_TOL_FEAT = 2e-2     # measured CPU-vs-CPU: up to 5.5e-3
