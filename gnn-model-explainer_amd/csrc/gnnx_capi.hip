@@ -3,9 +3,7 @@
 // one mask-optimisation job and its optional hipGraph capture.  No compute happens on the host.
 #include <hip/hip_runtime.h>
 
-#include <algorithm>
 #include <cmath>
-#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -41,12 +39,6 @@ struct gnnx_plan_s {
     std::vector<TargetMeta> meta;
     int64_t Q = 0, R = 0;
     int n_conv = 0, n_mask = 0;
-    // independent launch chains: targets are split into groups whose tile ranges are contiguous in the tables
-    struct Span { int conv_off, conv_n, mask_off, mask_n; };
-    std::vector<Span> chains;
-    std::vector<hipStream_t> side;   // chains.size() - 1 extra streams (chain 0 runs on the caller's stream)
-    std::vector<hipEvent_t> joined;
-    hipEvent_t forked = nullptr;
     TargetMeta* d_meta = nullptr;
     ConvTile* d_conv = nullptr;   // every 32-row block of every target
     MaskTile* d_mask = nullptr;
@@ -101,43 +93,15 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
         h->R += m.ld;
         h->sum_n2 += (double)n * n;
     }
-    // tile tables.  A batch is a chain of ~5 dependent launches per iteration; when it is small, every launch is
-    // latency-bound, so the targets are split into G groups whose chains run as parallel branches (own stream /
-    // hipGraph branch): each launch has fewer workgroups and the branches overlap on the chip.  Targets are
-    // independent, so the grouping changes no result bit.
+    // tile tables, largest targets first so the long poles start early
     std::vector<int> order(T);
     for (int t = 0; t < T; ++t) order[t] = t;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h->meta[a].ld > h->meta[b].ld; });
-    long total_pairs = 0;
-    for (int t = 0; t < T; ++t) {
-        const long nb = h->meta[t].ld / TILE;
-        total_pairs += nb * (nb + 1) / 2;
-    }
-    int G = (int)std::min<long>(8, std::max<long>(1, total_pairs / 400));
-    if (total_pairs > 16384) G = 1;  // large batches are throughput-bound: one chain fills the chip
-    if (const char* env = std::getenv("GNNX_CHAINS")) G = std::max(1, std::min(16, std::atoi(env)));
-    G = std::min(G, T);
-    std::vector<std::vector<int>> groups(G);
-    std::vector<long> load(G, 0);
-    for (int t : order) {  // longest-processing-time first on the tile-pair count
-        int g = 0;
-        for (int k = 1; k < G; ++k)
-            if (load[k] < load[g]) g = k;
-        const long nb = h->meta[t].ld / TILE;
-        groups[g].push_back(t);
-        load[g] += nb * (nb + 1) / 2;
-    }
-    for (int g = 0; g < G; ++g) {
-        gnnx_plan_s::Span sp{(int)conv.size(), 0, (int)mask.size(), 0};
-        for (int t : groups[g]) {  // largest targets first inside a chain so the long poles start early
-            const int nb = h->meta[t].ld / TILE;
-            for (int rb = 0; rb < nb; ++rb) conv.push_back({t, rb, h->meta[t]});
-            for (int I = 0; I < nb; ++I)
-                for (int J = I; J < nb; ++J) mask.push_back({t, I, J, 0, h->meta[t]});
-        }
-        sp.conv_n = (int)conv.size() - sp.conv_off;
-        sp.mask_n = (int)mask.size() - sp.mask_off;
-        h->chains.push_back(sp);
+    for (int t : order) {
+        const int nb = h->meta[t].ld / TILE;
+        for (int rb = 0; rb < nb; ++rb) conv.push_back({t, rb, h->meta[t]});
+        for (int I = 0; I < nb; ++I)
+            for (int J = I; J < nb; ++J) mask.push_back({t, I, J, 0, h->meta[t]});
     }
     h->n_conv = (int)conv.size();
     h->n_mask = (int)mask.size();
@@ -174,15 +138,6 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
     PLANCK(hipMemcpy(h->d_conv, conv.data(), sizeof(ConvTile) * conv.size(), hipMemcpyHostToDevice));
     PLANCK(hipMemcpy(h->d_mask, mask.data(), sizeof(MaskTile) * mask.size(), hipMemcpyHostToDevice));
     PLANCK(hipMemcpy(h->d_wts, w.data(), sizeof(float) * WT_TOTAL, hipMemcpyHostToDevice));
-    for (int g = 1; g < G; ++g) {
-        hipStream_t st;
-        hipEvent_t ev;
-        PLANCK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        PLANCK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        h->side.push_back(st);
-        h->joined.push_back(ev);
-    }
-    PLANCK(hipEventCreateWithFlags(&h->forked, hipEventDisableTiming));
 #undef PLANCK
 
     // workspace carving
@@ -223,9 +178,6 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
     if (!h) return 0;
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->d_meta) (void)hipFree(h->d_meta);
-    for (auto st : h->side) (void)hipStreamDestroy(st);
-    for (auto ev : h->joined) (void)hipEventDestroy(ev);
-    if (h->forked) (void)hipEventDestroy(h->forked);
     if (h->d_conv) (void)hipFree(h->d_conv);
     if (h->d_mask) (void)hipFree(h->d_mask);
     if (h->d_wts) (void)hipFree(h->d_wts);
@@ -306,79 +258,59 @@ static void adam_scalars(const gnnx_hyper* hy, int it, float* step_size, float* 
     *bc2s = (float)std::sqrt(b2);
 }
 
-using Span = gnnx_plan_s::Span;
-static Span whole(gnnx_handle h) { return Span{0, h->n_conv, 0, h->n_mask}; }
-
 template <int MODE>
-static void launch_conv(gnnx_handle h, const Params& p, const Span& sp, int it, hipStream_t s) {
-    hipLaunchKernelGGL((k_conv<MODE>), dim3(sp.conv_n), dim3(256), 0, s, p, h->d_conv + sp.conv_off, it);
+static void launch_conv(gnnx_handle h, const Params& p, int it, hipStream_t s) {
+    hipLaunchKernelGGL((k_conv<MODE>), dim3(h->n_conv), dim3(256), 0, s, p, h->d_conv, it);
 }
 
 template <bool UPDATE, bool WRITE_ABAR>
-static void launch_mask(gnnx_handle h, const Params& p, const Span& sp, int it, float ss, float b2, hipStream_t s) {
-    const dim3 g(sp.mask_n), b(256);
-    const MaskTile* tiles = h->d_mask + sp.mask_off;
+static void launch_mask(gnnx_handle h, const Params& p, int it, float ss, float b2, hipStream_t s) {
+    const dim3 g(h->n_mask), b(256);
     const bool node = !h->prob.graph_mode, loss = UPDATE && p.loss != nullptr;
-    if (node && loss) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, true, UPDATE>), g, b, 0, s, p, tiles, it, ss, b2);
-    else if (node) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, true, false>), g, b, 0, s, p, tiles, it, ss, b2);
-    else if (loss) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, false, UPDATE>), g, b, 0, s, p, tiles, it, ss, b2);
-    else hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, false, false>), g, b, 0, s, p, tiles, it, ss, b2);
-}
-
-static void launch_head(gnnx_handle h, const Params& p, const Span& sp, int it, hipStream_t s) {
-    if (h->prob.graph_mode)  // one workgroup per graph; the head kernel indexes targets directly
-        hipLaunchKernelGGL(k_head, dim3(sp.conv_n), dim3(256), 0, s, p, h->d_conv + sp.conv_off, it);
-    else
-        hipLaunchKernelGGL(k_node_head, dim3(sp.conv_n), dim3(256), 0, s, p, h->d_conv + sp.conv_off, it);
+    if (node && loss) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, true, UPDATE>), g, b, 0, s, p, h->d_mask, it, ss, b2);
+    else if (node) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, true, false>), g, b, 0, s, p, h->d_mask, it, ss, b2);
+    else if (loss) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, false, UPDATE>), g, b, 0, s, p, h->d_mask, it, ss, b2);
+    else hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, false, false>), g, b, 0, s, p, h->d_mask, it, ss, b2);
 }
 
 // forward up to the head (+ in node mode the fused start of the backward pass)
-static void launch_forward(gnnx_handle h, const Params& p, const Span& sp, int it, hipStream_t s) {
-    launch_conv<FWD1>(h, p, sp, it, s);
-    launch_conv<FWD2>(h, p, sp, it, s);
-    if (h->prob.graph_mode) launch_conv<FWD3>(h, p, sp, it, s);
-    launch_head(h, p, sp, it, s);
-}
-
-static void launch_backward(gnnx_handle h, const Params& p, const Span& sp, int it, hipStream_t s) {
+static void launch_forward(gnnx_handle h, const Params& p, int it, hipStream_t s) {
+    const int T = h->prob.num_targets;
+    launch_conv<FWD1>(h, p, it, s);
+    launch_conv<FWD2>(h, p, it, s);
     if (h->prob.graph_mode) {
-        launch_conv<BWD3>(h, p, sp, it, s);
-        launch_conv<BWD2>(h, p, sp, it, s);
+        launch_conv<FWD3>(h, p, it, s);
+        hipLaunchKernelGGL(k_head, dim3(T), dim3(256), 0, s, p, it);
+    } else {
+        hipLaunchKernelGGL(k_node_head, dim3(h->n_conv), dim3(256), 0, s, p, h->d_conv, it);
     }
-    launch_conv<BWD1>(h, p, sp, it, s);
 }
 
-// the whole job, stream-ordered: usable directly or under stream capture (the chains become graph branches)
+static void launch_backward(gnnx_handle h, const Params& p, int it, hipStream_t s) {
+    if (h->prob.graph_mode) {
+        launch_conv<BWD3>(h, p, it, s);
+        launch_conv<BWD2>(h, p, it, s);
+    }
+    launch_conv<BWD1>(h, p, it, s);
+}
+
+// the whole job, stream-ordered: usable directly or under stream capture
 static int enqueue_job(gnnx_handle h, const gnnx_hyper* hy, const Params& p, float* feat_mask, hipStream_t s) {
     const int T = h->prob.num_targets;
-    const int G = (int)h->chains.size();
     HIPCK(hipMemsetAsync(p.mM, 0, sizeof(float) * (size_t)h->Q, s));
     HIPCK(hipMemsetAsync(p.vM, 0, sizeof(float) * (size_t)h->Q, s));
     if (p.loss) HIPCK(hipMemsetAsync(p.loss, 0, sizeof(float) * (size_t)T * hy->num_iters * NLOSS, s));
     hipLaunchKernelGGL(k_prep, dim3(T), dim3(256), 0, s, p, (const float*)nullptr);
-    if (G > 1) {
-        HIPCK(hipEventRecord(h->forked, s));
-        for (int g = 1; g < G; ++g) HIPCK(hipStreamWaitEvent(h->side[g - 1], h->forked, 0));
-    }
-    auto stream_of = [&](int g) { return g == 0 ? s : h->side[g - 1]; };
-    for (int g = 0; g < G; ++g) launch_mask<false, true>(h, p, h->chains[g], 0, 0.0f, 1.0f, stream_of(g));
+    launch_mask<false, true>(h, p, 0, 0.0f, 1.0f, s);
     for (int it = 0; it < hy->num_iters; ++it) {
+        launch_forward(h, p, it, s);
+        launch_backward(h, p, it, s);
         float ss, b2;
         adam_scalars(hy, it, &ss, &b2);
-        for (int g = 0; g < G; ++g) {
-            const Span& sp = h->chains[g];
-            hipStream_t sg = stream_of(g);
-            launch_forward(h, p, sp, it, sg);
-            launch_backward(h, p, sp, it, sg);
-            if (it + 1 < hy->num_iters)
-                launch_mask<true, true>(h, p, sp, it, ss, b2, sg);
-            else
-                launch_mask<true, false>(h, p, sp, it, ss, b2, sg);  // keep Abar of the LAST forward (explain.py:209-211)
-        }
-    }
-    for (int g = 1; g < G; ++g) {
-        HIPCK(hipEventRecord(h->joined[g - 1], h->side[g - 1]));
-        HIPCK(hipStreamWaitEvent(s, h->joined[g - 1], 0));
+        if (it + 1 < hy->num_iters)
+            launch_mask<true, true>(h, p, it, ss, b2, s);
+        else
+            launch_mask<true, false>(h, p, it, ss, b2, s);  // keep Abar of the LAST forward (explain.py:209-211)
     }
     if (feat_mask)
         HIPCK(hipMemcpyAsync(feat_mask, p.f[hy->num_iters & 1], sizeof(float) * T * FS, hipMemcpyDeviceToDevice, s));
@@ -431,8 +363,8 @@ extern "C" int gnnx_forward(gnnx_handle h, const float* A, const float* X, const
     Params p = make_params(h, nullptr, A, X, nullptr, const_cast<float*>(M), Abar, nullptr, workspace);
     p.num_iters = 1;
     hipLaunchKernelGGL(k_prep, dim3(h->prob.num_targets), dim3(256), 0, s, p, feat_mask_in);
-    launch_mask<false, true>(h, p, whole(h), 0, 0.0f, 1.0f, s);
-    launch_forward(h, p, whole(h), 0, s);
+    launch_mask<false, true>(h, p, 0, 0.0f, 1.0f, s);
+    launch_forward(h, p, 0, s);
     HIPCK(hipMemcpyAsync(probs, p.probs, sizeof(float) * h->prob.num_targets * CMAX, hipMemcpyDeviceToDevice, s));
     HIPCK(hipGetLastError());
     return 0;
@@ -451,17 +383,20 @@ extern "C" int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hy, int32_t kin
     HIPCK(hipEventCreate(&e1));
     float ss, b2;
     adam_scalars(hy, 0, &ss, &b2);
-    const Span all = whole(h);
+    const bool gm = h->prob.graph_mode != 0;
     auto once = [&]() {
         switch (kind) {
-            case 0: launch_mask<true, true>(h, p, all, 0, ss, b2, s); break;
-            case 1: launch_conv<FWD1>(h, p, all, 0, s); break;
-            case 2: launch_conv<FWD2>(h, p, all, 0, s); break;
-            case 3: launch_head(h, p, all, 0, s); break;
-            case 4: launch_conv<BWD1>(h, p, all, 0, s); break;
-            case 5: launch_conv<FWD3>(h, p, all, 0, s); break;
-            case 6: launch_conv<BWD3>(h, p, all, 0, s); break;
-            default: launch_conv<BWD2>(h, p, all, 0, s); break;
+            case 0: launch_mask<true, true>(h, p, 0, ss, b2, s); break;
+            case 1: launch_conv<FWD1>(h, p, 0, s); break;
+            case 2: launch_conv<FWD2>(h, p, 0, s); break;
+            case 3:
+                if (gm) hipLaunchKernelGGL(k_head, dim3(h->prob.num_targets), dim3(256), 0, s, p, 0);
+                else hipLaunchKernelGGL(k_node_head, dim3(h->n_conv), dim3(256), 0, s, p, h->d_conv, 0);
+                break;
+            case 4: launch_conv<BWD1>(h, p, 0, s); break;
+            case 5: launch_conv<FWD3>(h, p, 0, s); break;
+            case 6: launch_conv<BWD3>(h, p, 0, s); break;
+            default: launch_conv<BWD2>(h, p, 0, s); break;
         }
     };
     once();  // warm

@@ -457,16 +457,14 @@ __device__ __forceinline__ void head_softmax(const Params& p, const TargetMeta& 
 // ---------------------------------------------------------------------------------------------
 // Graph-mode head: one workgroup per graph.  Column-wise max over the n rows of every layer.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_head(Params p, const ConvTile* tiles, int iter) {
+__global__ __launch_bounds__(256) void k_head(Params p, int iter) {
     __shared__ float e[96];
     __shared__ int erow[96];
     __shared__ float g[CMAX];
     __shared__ float dEs[96];
     __shared__ float sWp[CMAX * 96 + CMAX];
-    const ConvTile tl = tiles[blockIdx.x];  // launched over the row-block table: only block 0 of a graph works
-    if (tl.rb != 0) return;
-    const int t = tl.t;
-    const TargetMeta tm = tl.tm;
+    const int t = blockIdx.x;
+    const TargetMeta tm = p.meta[t];
     const int tid = threadIdx.x;
     const int dims[3] = {p.H, p.H, p.O};
     stage_head_weights(p, sWp);
