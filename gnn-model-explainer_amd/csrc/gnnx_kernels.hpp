@@ -363,37 +363,32 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
             // cache lines per wave instruction and was 12 % slower here (BA-House x100k: 152-162 vs 171-181 us).
             const float* Ab = p.Abar + tm.offQ + row0 + li;
             const int k0 = wave * kchunk + h;
-            // ring of NQ batches x 8 k-steps (16 k values): up to 48 k-steps = 96 loads per lane in flight.  Each
-            // DRAM round trip is ~2 us here (Abar was just written by another XCD), so a mid-size target
-            // (ld = 320: 40 k-steps per wave) pays ONE round trip instead of three (device timeline:
-            // K loop 6.7 us -> see profiles/r01_timeline_*).
-            constexpr int NQ = 6;
-            float a[NQ][8], b[NQ][8];
-            auto load8 = [&](int q, int s0) {
+            float a0[8], b0[8], a1[8], b1[8];
+            auto load8 = [&](float (&a)[8], float (&b)[8], int s0) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const bool on = (s0 + 2 * u) < kchunk;  // a batch spans 16 k values, kchunk is a multiple of 8
                     const int k = k0 + s0 + 2 * u;
-                    a[q][u] = on ? Ab[(size_t)k * ld] : 0.0f;
-                    b[q][u] = on ? Bsrc[(size_t)k * FS] : 0.0f;
+                    a[u] = on ? Ab[(size_t)k * ld] : 0.0f;
+                    b[u] = on ? Bsrc[(size_t)k * FS] : 0.0f;
                 }
             };
+            auto mma8 = [&](const float (&a)[8], const float (&b)[8]) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                if (16 * q < kchunk) load8(q, 16 * q);
-            for (int s0 = 0; s0 < kchunk; s0 += 16 * NQ) {
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    if (s0 + 16 * q < kchunk) {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            float bb = b[q][u];
-                            if (MODE == FWD2 || MODE == FWD3) bb = fmaxf(bb, 0.0f);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][u], bb, acc, 0, 0, 0);
-                        }
-                        if (s0 + 16 * (q + NQ) < kchunk) load8(q, s0 + 16 * (q + NQ));
-                    }
+                for (int u = 0; u < 8; ++u) {
+                    float bb = b[u];
+                    if (MODE == FWD2 || MODE == FWD3) bb = fmaxf(bb, 0.0f);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bb, acc, 0, 0, 0);
                 }
+            };
+            load8(a0, b0, 0);
+            for (int s0 = 0; s0 < kchunk; s0 += 32) {
+                const bool more1 = s0 + 16 < kchunk;
+                if (more1) load8(a1, b1, s0 + 16);
+                mma8(a0, b0);
+                const bool more0 = s0 + 32 < kchunk;
+                if (more0) load8(a0, b0, s0 + 32);
+                if (more1) mma8(a1, b1);
             }
         }
     }
