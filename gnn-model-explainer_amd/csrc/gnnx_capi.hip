@@ -11,6 +11,7 @@
 
 #include "../../include/gnnx.h"
 #include "gnnx_kernels.hpp"
+#include "gnnx_resident.hpp"
 
 using namespace gnnx;
 
@@ -38,7 +39,15 @@ struct gnnx_plan_s {
     gnnx_problem prob{};
     std::vector<TargetMeta> meta;
     int64_t Q = 0, R = 0;
-    int n_conv = 0, n_mask = 0;
+    int n_conv = 0, n_mask = 0;      // tile tables over ALL targets (streaming path for everything)
+    // hybrid split: single-tile node-mode targets run in the on-chip-resident kernel, the rest stream
+    int n_res = 0, n_big = 0, n_conv_big = 0, n_mask_big = 0;
+    int32_t* d_res = nullptr;        // target ids of the resident set
+    int32_t* d_big = nullptr;        // target ids of the streaming set
+    ConvTile* d_conv_big = nullptr;
+    MaskTile* d_mask_big = nullptr;
+    hipStream_t side = nullptr;      // the resident kernel runs beside the streaming launches
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
     TargetMeta* d_meta = nullptr;
     ConvTile* d_conv = nullptr;   // every 32-row block of every target
     MaskTile* d_mask = nullptr;
@@ -66,8 +75,9 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
     h->prob = *prob;
     const int T = prob->num_targets;
     h->meta.resize(T);
-    std::vector<ConvTile> conv;
-    std::vector<MaskTile> mask;
+    std::vector<ConvTile> conv, conv_big;
+    std::vector<MaskTile> mask, mask_big;
+    std::vector<int32_t> res_ids, big_ids;
     for (int t = 0; t < T; ++t) {
         const int n = prob->n[t];
         if (n < 1) {
@@ -97,12 +107,25 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
     std::vector<int> order(T);
     for (int t = 0; t < T; ++t) order[t] = t;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h->meta[a].ld > h->meta[b].ld; });
+    const bool resident_ok = !prob->graph_mode && prob->C <= RES_CMAX;
     for (int t : order) {
         const int nb = h->meta[t].ld / TILE;
-        for (int rb = 0; rb < nb; ++rb) conv.push_back({t, rb, h->meta[t]});
+        const bool res = resident_ok && nb == 1;
+        (res ? res_ids : big_ids).push_back(t);
+        for (int rb = 0; rb < nb; ++rb) {
+            conv.push_back({t, rb, h->meta[t]});
+            if (!res) conv_big.push_back({t, rb, h->meta[t]});
+        }
         for (int I = 0; I < nb; ++I)
-            for (int J = I; J < nb; ++J) mask.push_back({t, I, J, 0, h->meta[t]});
+            for (int J = I; J < nb; ++J) {
+                mask.push_back({t, I, J, 0, h->meta[t]});
+                if (!res) mask_big.push_back({t, I, J, 0, h->meta[t]});
+            }
     }
+    h->n_res = (int)res_ids.size();
+    h->n_big = (int)big_ids.size();
+    h->n_conv_big = (int)conv_big.size();
+    h->n_mask_big = (int)mask_big.size();
     h->n_conv = (int)conv.size();
     h->n_mask = (int)mask.size();
 
@@ -134,6 +157,21 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
     PLANCK(hipMalloc(&h->d_conv, sizeof(ConvTile) * conv.size()));
     PLANCK(hipMalloc(&h->d_mask, sizeof(MaskTile) * mask.size()));
     PLANCK(hipMalloc(&h->d_wts, sizeof(float) * WT_TOTAL));
+    if (h->n_res) {
+        PLANCK(hipMalloc(&h->d_res, sizeof(int32_t) * res_ids.size()));
+        PLANCK(hipMemcpy(h->d_res, res_ids.data(), sizeof(int32_t) * res_ids.size(), hipMemcpyHostToDevice));
+        PLANCK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        PLANCK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+        PLANCK(hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+    }
+    if (h->n_res && h->n_big) {
+        PLANCK(hipMalloc(&h->d_big, sizeof(int32_t) * big_ids.size()));
+        PLANCK(hipMalloc(&h->d_conv_big, sizeof(ConvTile) * conv_big.size()));
+        PLANCK(hipMalloc(&h->d_mask_big, sizeof(MaskTile) * mask_big.size()));
+        PLANCK(hipMemcpy(h->d_big, big_ids.data(), sizeof(int32_t) * big_ids.size(), hipMemcpyHostToDevice));
+        PLANCK(hipMemcpy(h->d_conv_big, conv_big.data(), sizeof(ConvTile) * conv_big.size(), hipMemcpyHostToDevice));
+        PLANCK(hipMemcpy(h->d_mask_big, mask_big.data(), sizeof(MaskTile) * mask_big.size(), hipMemcpyHostToDevice));
+    }
     PLANCK(hipMemcpy(h->d_meta, h->meta.data(), sizeof(TargetMeta) * T, hipMemcpyHostToDevice));
     PLANCK(hipMemcpy(h->d_conv, conv.data(), sizeof(ConvTile) * conv.size(), hipMemcpyHostToDevice));
     PLANCK(hipMemcpy(h->d_mask, mask.data(), sizeof(MaskTile) * mask.size(), hipMemcpyHostToDevice));
@@ -178,6 +216,13 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
     if (!h) return 0;
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->d_meta) (void)hipFree(h->d_meta);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
+    if (h->ev_out) (void)hipEventDestroy(h->ev_out);
+    if (h->d_res) (void)hipFree(h->d_res);
+    if (h->d_big) (void)hipFree(h->d_big);
+    if (h->d_conv_big) (void)hipFree(h->d_conv_big);
+    if (h->d_mask_big) (void)hipFree(h->d_mask_big);
     if (h->d_conv) (void)hipFree(h->d_conv);
     if (h->d_mask) (void)hipFree(h->d_mask);
     if (h->d_wts) (void)hipFree(h->d_wts);
@@ -258,62 +303,71 @@ static void adam_scalars(const gnnx_hyper* hy, int it, float* step_size, float* 
     *bc2s = (float)std::sqrt(b2);
 }
 
+// which tile tables a launch sequence walks: all targets, or only the streaming ("big") set of a hybrid run
+struct Tables {
+    const ConvTile* conv;
+    int n_conv;
+    const MaskTile* mask;
+    int n_mask;
+    const int32_t* ids;  // target ids for per-target kernels (null = 0..T-1)
+    int n_targets;
+};
+static Tables tables_all(gnnx_handle h) { return {h->d_conv, h->n_conv, h->d_mask, h->n_mask, nullptr, h->prob.num_targets}; }
+static Tables tables_big(gnnx_handle h) { return {h->d_conv_big, h->n_conv_big, h->d_mask_big, h->n_mask_big, h->d_big, h->n_big}; }
+
 template <int MODE>
-static void launch_conv(gnnx_handle h, const Params& p, int it, hipStream_t s) {
-    hipLaunchKernelGGL((k_conv<MODE>), dim3(h->n_conv), dim3(256), 0, s, p, h->d_conv, it);
+static void launch_conv(const Tables& tb, const Params& p, int it, hipStream_t s) {
+    hipLaunchKernelGGL((k_conv<MODE>), dim3(tb.n_conv), dim3(256), 0, s, p, tb.conv, it);
 }
 
 template <bool UPDATE, bool WRITE_ABAR>
-static void launch_mask(gnnx_handle h, const Params& p, int it, float ss, float b2, hipStream_t s) {
-    const dim3 g(h->n_mask), b(256);
+static void launch_mask(gnnx_handle h, const Tables& tb, const Params& p, int it, float ss, float b2, hipStream_t s) {
+    const dim3 g(tb.n_mask), b(256);
     const bool node = !h->prob.graph_mode, loss = UPDATE && p.loss != nullptr;
-    if (node && loss) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, true, UPDATE>), g, b, 0, s, p, h->d_mask, it, ss, b2);
-    else if (node) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, true, false>), g, b, 0, s, p, h->d_mask, it, ss, b2);
-    else if (loss) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, false, UPDATE>), g, b, 0, s, p, h->d_mask, it, ss, b2);
-    else hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, false, false>), g, b, 0, s, p, h->d_mask, it, ss, b2);
+    if (node && loss) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, true, UPDATE>), g, b, 0, s, p, tb.mask, it, ss, b2);
+    else if (node) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, true, false>), g, b, 0, s, p, tb.mask, it, ss, b2);
+    else if (loss) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, false, UPDATE>), g, b, 0, s, p, tb.mask, it, ss, b2);
+    else hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, false, false>), g, b, 0, s, p, tb.mask, it, ss, b2);
 }
 
 // forward up to the head (+ in node mode the fused start of the backward pass)
-static void launch_forward(gnnx_handle h, const Params& p, int it, hipStream_t s) {
-    const int T = h->prob.num_targets;
-    launch_conv<FWD1>(h, p, it, s);
-    launch_conv<FWD2>(h, p, it, s);
+static void launch_forward(gnnx_handle h, const Tables& tb, const Params& p, int it, hipStream_t s) {
+    launch_conv<FWD1>(tb, p, it, s);
+    launch_conv<FWD2>(tb, p, it, s);
     if (h->prob.graph_mode) {
-        launch_conv<FWD3>(h, p, it, s);
-        hipLaunchKernelGGL(k_head, dim3(T), dim3(256), 0, s, p, it);
+        launch_conv<FWD3>(tb, p, it, s);
+        hipLaunchKernelGGL(k_head, dim3(h->prob.num_targets), dim3(256), 0, s, p, it);
     } else {
-        hipLaunchKernelGGL(k_node_head, dim3(h->n_conv), dim3(256), 0, s, p, h->d_conv, it);
+        hipLaunchKernelGGL(k_node_head, dim3(tb.n_conv), dim3(256), 0, s, p, tb.conv, it);
     }
 }
 
-static void launch_backward(gnnx_handle h, const Params& p, int it, hipStream_t s) {
+static void launch_backward(gnnx_handle h, const Tables& tb, const Params& p, int it, hipStream_t s) {
     if (h->prob.graph_mode) {
-        launch_conv<BWD3>(h, p, it, s);
-        launch_conv<BWD2>(h, p, it, s);
+        launch_conv<BWD3>(tb, p, it, s);
+        launch_conv<BWD2>(tb, p, it, s);
     }
-    launch_conv<BWD1>(h, p, it, s);
+    launch_conv<BWD1>(tb, p, it, s);
 }
 
-// the whole job, stream-ordered: usable directly or under stream capture
-static int enqueue_job(gnnx_handle h, const gnnx_hyper* hy, const Params& p, float* feat_mask, hipStream_t s) {
+// the streaming job over the given tables, stream-ordered: usable directly or under stream capture
+static int enqueue_job(gnnx_handle h, const Tables& tb, const gnnx_hyper* hy, const Params& p, hipStream_t s) {
     const int T = h->prob.num_targets;
     HIPCK(hipMemsetAsync(p.mM, 0, sizeof(float) * (size_t)h->Q, s));
     HIPCK(hipMemsetAsync(p.vM, 0, sizeof(float) * (size_t)h->Q, s));
     if (p.loss) HIPCK(hipMemsetAsync(p.loss, 0, sizeof(float) * (size_t)T * hy->num_iters * NLOSS, s));
-    hipLaunchKernelGGL(k_prep, dim3(T), dim3(256), 0, s, p, (const float*)nullptr);
-    launch_mask<false, true>(h, p, 0, 0.0f, 1.0f, s);
+    hipLaunchKernelGGL(k_prep, dim3(tb.n_targets), dim3(256), 0, s, p, (const float*)nullptr, tb.ids);
+    launch_mask<false, true>(h, tb, p, 0, 0.0f, 1.0f, s);
     for (int it = 0; it < hy->num_iters; ++it) {
-        launch_forward(h, p, it, s);
-        launch_backward(h, p, it, s);
+        launch_forward(h, tb, p, it, s);
+        launch_backward(h, tb, p, it, s);
         float ss, b2;
         adam_scalars(hy, it, &ss, &b2);
         if (it + 1 < hy->num_iters)
-            launch_mask<true, true>(h, p, it, ss, b2, s);
+            launch_mask<true, true>(h, tb, p, it, ss, b2, s);
         else
-            launch_mask<true, false>(h, p, it, ss, b2, s);  // keep Abar of the LAST forward (explain.py:209-211)
+            launch_mask<true, false>(h, tb, p, it, ss, b2, s);  // keep Abar of the LAST forward (explain.py:209-211)
     }
-    if (feat_mask)
-        HIPCK(hipMemcpyAsync(feat_mask, p.f[hy->num_iters & 1], sizeof(float) * T * FS, hipMemcpyDeviceToDevice, s));
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -329,29 +383,50 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
     float* lossp = hy->record_loss ? loss : nullptr;
     if (hy->record_loss && !loss) return fail("record_loss set but loss buffer is null");
     Params p = make_params(h, hy, A, X, yhat, M, Abar, lossp, workspace);
-    if (!hy->use_graph) return enqueue_job(h, hy, p, feat_mask, s);
-
-    GraphKey key{A, X, yhat, M, Abar, feat_mask, lossp, workspace, *hy};
-    if (!h->gexec || !(key == h->gkey)) {
-        if (h->gexec) {
-            (void)hipGraphExecDestroy(h->gexec);
-            h->gexec = nullptr;
-        }
-        hipGraph_t g = nullptr;
-        HIPCK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-        int rc = enqueue_job(h, hy, p, feat_mask, s);
-        hipError_t e = hipStreamEndCapture(s, &g);
-        if (rc) return rc;
-        if (e != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-        e = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        if (e != hipSuccess) {
-            h->gexec = nullptr;
-            return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-        }
-        h->gkey = key;
+    // hybrid split: single-tile targets -> on-chip-resident kernel on the side stream (overlaps with the
+    // streaming launches of the other targets); loss logging is a streaming-path feature
+    const bool resident = hy->use_resident && h->n_res > 0 && !lossp;
+    const Tables tb = (resident && h->n_big > 0) ? tables_big(h) : tables_all(h);
+    const bool streaming = !resident || h->n_big > 0;
+    if (resident) {
+        HIPCK(hipEventRecord(h->ev_in, s));
+        HIPCK(hipStreamWaitEvent(h->side, h->ev_in, 0));
+        hipLaunchKernelGGL(k_resident32, dim3(h->n_res), dim3(256), 0, h->side, p, h->d_res);
+        HIPCK(hipEventRecord(h->ev_out, h->side));
     }
-    HIPCK(hipGraphLaunch(h->gexec, s));
+    if (streaming) {
+        if (!hy->use_graph) {
+            int rc = enqueue_job(h, tb, hy, p, s);
+            if (rc) return rc;
+        } else {
+            GraphKey key{A, X, yhat, M, Abar, (const void*)(size_t)(resident ? 1 : 0), lossp, workspace, *hy};
+            if (!h->gexec || !(key == h->gkey)) {
+                if (h->gexec) {
+                    (void)hipGraphExecDestroy(h->gexec);
+                    h->gexec = nullptr;
+                }
+                hipGraph_t g = nullptr;
+                HIPCK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+                int rc = enqueue_job(h, tb, hy, p, s);
+                hipError_t e = hipStreamEndCapture(s, &g);
+                if (rc) return rc;
+                if (e != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+                e = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(g);
+                if (e != hipSuccess) {
+                    h->gexec = nullptr;
+                    return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+                }
+                h->gkey = key;
+            }
+            HIPCK(hipGraphLaunch(h->gexec, s));
+        }
+    }
+    if (resident) HIPCK(hipStreamWaitEvent(s, h->ev_out, 0));
+    if (feat_mask)
+        HIPCK(hipMemcpyAsync(feat_mask, p.f[hy->num_iters & 1], sizeof(float) * h->prob.num_targets * FS,
+                             hipMemcpyDeviceToDevice, s));
+    HIPCK(hipGetLastError());
     return 0;
 }
 
@@ -362,9 +437,10 @@ extern "C" int gnnx_forward(gnnx_handle h, const float* A, const float* X, const
     hipStream_t s = static_cast<hipStream_t>(stream);
     Params p = make_params(h, nullptr, A, X, nullptr, const_cast<float*>(M), Abar, nullptr, workspace);
     p.num_iters = 1;
-    hipLaunchKernelGGL(k_prep, dim3(h->prob.num_targets), dim3(256), 0, s, p, feat_mask_in);
-    launch_mask<false, true>(h, p, 0, 0.0f, 1.0f, s);
-    launch_forward(h, p, 0, s);
+    const Tables tb = tables_all(h);
+    hipLaunchKernelGGL(k_prep, dim3(h->prob.num_targets), dim3(256), 0, s, p, feat_mask_in, (const int32_t*)nullptr);
+    launch_mask<false, true>(h, tb, p, 0, 0.0f, 1.0f, s);
+    launch_forward(h, tb, p, 0, s);
     HIPCK(hipMemcpyAsync(probs, p.probs, sizeof(float) * h->prob.num_targets * CMAX, hipMemcpyDeviceToDevice, s));
     HIPCK(hipGetLastError());
     return 0;
@@ -383,20 +459,20 @@ extern "C" int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hy, int32_t kin
     HIPCK(hipEventCreate(&e1));
     float ss, b2;
     adam_scalars(hy, 0, &ss, &b2);
-    const bool gm = h->prob.graph_mode != 0;
+    const Tables tb = tables_all(h);
     auto once = [&]() {
         switch (kind) {
-            case 0: launch_mask<true, true>(h, p, 0, ss, b2, s); break;
-            case 1: launch_conv<FWD1>(h, p, 0, s); break;
-            case 2: launch_conv<FWD2>(h, p, 0, s); break;
+            case 0: launch_mask<true, true>(h, tb, p, 0, ss, b2, s); break;
+            case 1: launch_conv<FWD1>(tb, p, 0, s); break;
+            case 2: launch_conv<FWD2>(tb, p, 0, s); break;
             case 3:
-                if (gm) hipLaunchKernelGGL(k_head, dim3(h->prob.num_targets), dim3(256), 0, s, p, 0);
-                else hipLaunchKernelGGL(k_node_head, dim3(h->n_conv), dim3(256), 0, s, p, h->d_conv, 0);
+                if (h->prob.graph_mode) hipLaunchKernelGGL(k_head, dim3(h->prob.num_targets), dim3(256), 0, s, p, 0);
+                else hipLaunchKernelGGL(k_node_head, dim3(tb.n_conv), dim3(256), 0, s, p, tb.conv, 0);
                 break;
-            case 4: launch_conv<BWD1>(h, p, 0, s); break;
-            case 5: launch_conv<FWD3>(h, p, 0, s); break;
-            case 6: launch_conv<BWD3>(h, p, 0, s); break;
-            default: launch_conv<BWD2>(h, p, 0, s); break;
+            case 4: launch_conv<BWD1>(tb, p, 0, s); break;
+            case 5: launch_conv<FWD3>(tb, p, 0, s); break;
+            case 6: launch_conv<BWD3>(tb, p, 0, s); break;
+            default: launch_conv<BWD2>(tb, p, 0, s); break;
         }
     };
     once();  // warm

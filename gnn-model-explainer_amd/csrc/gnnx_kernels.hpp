@@ -876,8 +876,8 @@ __global__ __launch_bounds__(256) void k_mask(Params p, const MaskTile* tiles, i
 }
 
 // per target: column-major copy of X, zero the Adam state of the feature mask, initial feature mask
-__global__ __launch_bounds__(256) void k_prep(Params p, const float* f_init) {
-    const int t = blockIdx.x;
+__global__ __launch_bounds__(256) void k_prep(Params p, const float* f_init, const int32_t* ids) {
+    const int t = ids ? ids[blockIdx.x] : (int)blockIdx.x;
     const TargetMeta tm = p.meta[t];
     const float* X = p.X + tm.offR * FS;
     float* XT = const_cast<float*>(p.XT) + tm.offR * FS;

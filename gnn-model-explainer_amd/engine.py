@@ -42,7 +42,7 @@ class _Hyper(ctypes.Structure):
     _fields_ = [("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
                 ("c_size", ctypes.c_float), ("c_feat_size", ctypes.c_float), ("c_ent", ctypes.c_float),
                 ("c_lap", ctypes.c_float), ("num_iters", ctypes.c_int32), ("record_loss", ctypes.c_int32),
-                ("use_graph", ctypes.c_int32)]
+                ("use_graph", ctypes.c_int32), ("use_resident", ctypes.c_int32)]
 
 
 @dataclass
@@ -59,10 +59,11 @@ class Hyper:
     c_lap: float = 1.0
     record_loss: bool = False
     use_graph: bool = False
+    use_resident: bool = True     # on-chip-resident kernel for single-tile (n <= 32) node-mode targets
 
     def c(self):
         return _Hyper(self.lr, self.beta1, self.beta2, self.eps, self.c_size, self.c_feat_size, self.c_ent,
-                      self.c_lap, int(self.num_iters), int(self.record_loss), int(self.use_graph))
+                      self.c_lap, int(self.num_iters), int(self.record_loss), int(self.use_graph), int(self.use_resident))
 
 
 def library_path():

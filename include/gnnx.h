@@ -61,6 +61,8 @@ typedef struct {
     int32_t num_iters;   /* args.num_epochs (explain.py:137) */
     int32_t record_loss; /* 1: fill loss[T][num_iters][GNNX_LOSS_TERMS] (explain.py:808-819 scalars) */
     int32_t use_graph;   /* 1: capture the launch sequence once into a hipGraph and replay it */
+    int32_t use_resident; /* 1: node-mode targets with n <= 32 run in the on-chip-resident kernel (one workgroup per
+                           * target, all iterations in one launch) beside the streaming kernels; ignored with record_loss */
 } gnnx_hyper;
 
 int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* model, gnnx_handle* out);

@@ -95,3 +95,28 @@ def test_large_target_many_row_blocks():
     assert np.abs(res.masked_adj[0] - want).max() < 2e-6
     assert np.abs(res.mask[0] - o.M).max() < 2e-5
     assert np.abs(res.feat_mask[0] - o.f).max() < 2e-5
+
+
+def test_resident_kernel_matches_streaming_and_reference():
+    """Single-tile targets (n <= 32) take the on-chip-resident kernel; an all-resident batch launches no streaming
+    kernel at all.  Both paths must agree with each other and with the reference's golden output."""
+    ck, gx = helpers.load_ckpt("syn4"), helpers.load_explain("syn4")
+    subs = [_node_case("syn4", t)[2] for t in (511, 870)]
+    iters = 40
+    res = emu_job(subs, ck["sd"]).run([s.mask0 for s in subs], Hyper(num_iters=iters, use_resident=True))
+    stream = emu_job(subs, ck["sd"]).run([s.mask0 for s in subs], Hyper(num_iters=iters, use_resident=False))
+    for a, b, fa, fb in zip(res.masked_adj, stream.masked_adj, res.feat_mask, stream.feat_mask):
+        assert np.abs(a - b).max() < 1e-6 and np.abs(fa - fb).max() < 1e-5
+        assert np.array_equal(a, a.T)
+    s = subs[0]
+    o = closed_form.ClosedFormOracle(s.adj, s.feat, ck["sd"], s.gt_label, s.pred_label, s.target_row, s.mask0)
+    assert np.abs(res.masked_adj[0] - o.run(iters)).max() < 2e-6
+    assert np.abs(res.mask[0] - o.M).max() < 2e-5 and np.abs(res.feat_mask[0] - o.f).max() < 2e-5
+
+
+def test_resident_kernel_full_run_vs_golden():
+    ck, gx, sg = _node_case("syn1", 302)
+    res = emu_job([sg], ck["sd"]).run([sg.mask0], Hyper(num_iters=300))
+    rc = gx["302:edge_rc"]
+    assert np.abs(res.masked_adj[0][rc[:, 0], rc[:, 1]] - gx["302:masked_adj_edges"]).max() <= 1e-5
+    assert np.abs(1 / (1 + np.exp(-res.feat_mask[0])) - gx["302:feat_mask_sigmoid"]).max() <= 1e-5
