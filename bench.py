@@ -35,8 +35,13 @@ def build_workload(name, iters, rank=0, num_targets=4096):
     import helpers
     from gnn_model_explainer_amd.engine import Subgraph
     from gnn_model_explainer_amd.utils.graph_utils import KHopIndex
-    ck = helpers.load_ckpt("syn1")
-    if name == "syn1":
+    ck = helpers.load_ckpt("syn4" if name == "syn4" else "syn5" if name == "syn5" else "syn1")
+    if name in ("syn4", "syn5"):
+        # BASELINE.json configs[2] for the record: Tree-Cycle / Tree-Grid, all motif nodes (ids >= 511), every target n <= 48
+        idx = KHopIndex((ck["num_nodes"], ck["edges"]), 3)
+        feat, label, pred, targets = ck["feat"], ck["label"], ck["pred"], range(511, ck["num_nodes"])
+        desc = f"{name}: all {ck['num_nodes'] - 511} motif nodes (511..{ck['num_nodes'] - 1}) as one batch per GPU"
+    elif name == "syn1":
         idx = KHopIndex((ck["num_nodes"], ck["edges"]), 3)
         feat, label, pred, targets = ck["feat"], ck["label"], ck["pred"], range(300, 700)
         desc = "syn1: all 400 house-motif nodes (300..699) as one batch per GPU"
@@ -99,10 +104,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--iters", type=int, default=300)
-    ap.add_argument("--workload", default="syn1", choices=["syn1", "ba100k"])
+    ap.add_argument("--workload", default="syn1", choices=["syn1", "ba100k", "syn4", "syn5"])
     ap.add_argument("--targets", type=int, default=4096, help="ba100k: sampled motif targets per GPU")
     ap.add_argument("--no-graph", action="store_true", help="plain launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-resident", action="store_true", help="streaming kernels for every target (no on-chip-resident path)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,7 +133,7 @@ def main():
     log(f"workload built: {len(subs)} targets")
     t_pack = time.perf_counter()
     job = MaskOptimJob(subs, ck["sd"])
-    hy = Hyper(num_iters=args.iters, use_graph=not args.no_graph)
+    hy = Hyper(num_iters=args.iters, use_graph=not args.no_graph, use_resident=not args.no_resident)
     job.set_masks([s.mask0 for s in subs])
     torch.cuda.synchronize()
     t_pack = time.perf_counter() - t_pack          # host packing + H2D of A, X, yhat, M0 (pageable memory)
@@ -196,7 +202,7 @@ def main():
                "dtype": "f32", "data": "synthetic (BA-House graphs; GCN trained by the reference train.py on syn1, fixture tests/golden/syn1_ckpt.npz)",
                "config": {"workload": desc + f", 3-hop sub-graphs, {args.iters} iters, Adam lr 0.1",
                           "targets_per_gpu": len(subs), "sum_n2": sum_n2,
-                          "launch": "plain" if args.no_graph else "hipGraph", "parallelism": f"target-sharded x{world}"},
+                          "launch": "plain" if args.no_graph else "hipGraph", "resident_path": not args.no_resident, "parallelism": f"target-sharded x{world}"},
                "roofline": roof}
         log("kernel timings done")
         step_s = dt / args.steps
