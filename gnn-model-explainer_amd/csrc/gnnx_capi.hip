@@ -48,6 +48,9 @@ struct gnnx_plan_s {
     MaskTile* d_mask_big = nullptr;
     hipStream_t side = nullptr;      // the resident kernel runs beside the streaming launches
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    float* d_adam = nullptr;         // per-iteration Adam scalars for the resident kernel
+    std::vector<float> adam_host;
+    gnnx_hyper adam_for{};
     TargetMeta* d_meta = nullptr;
     ConvTile* d_conv = nullptr;   // every 32-row block of every target
     MaskTile* d_mask = nullptr;
@@ -220,6 +223,7 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_out) (void)hipEventDestroy(h->ev_out);
     if (h->d_res) (void)hipFree(h->d_res);
+    if (h->d_adam) (void)hipFree(h->d_adam);
     if (h->d_big) (void)hipFree(h->d_big);
     if (h->d_conv_big) (void)hipFree(h->d_conv_big);
     if (h->d_mask_big) (void)hipFree(h->d_mask_big);
@@ -391,7 +395,15 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
     if (resident) {
         HIPCK(hipEventRecord(h->ev_in, s));
         HIPCK(hipStreamWaitEvent(h->side, h->ev_in, 0));
-        hipLaunchKernelGGL(k_resident32, dim3(h->n_res), dim3(256), 0, h->side, p, h->d_res);
+        if (!h->d_adam || std::memcmp(&h->adam_for, hy, sizeof(gnnx_hyper)) != 0) {
+            if (h->d_adam) (void)hipFree(h->d_adam);
+            h->adam_host.resize(2 * (size_t)hy->num_iters);
+            for (int it = 0; it < hy->num_iters; ++it) adam_scalars(hy, it, &h->adam_host[2 * it], &h->adam_host[2 * it + 1]);
+            HIPCK(hipMalloc(&h->d_adam, sizeof(float) * h->adam_host.size()));
+            HIPCK(hipMemcpy(h->d_adam, h->adam_host.data(), sizeof(float) * h->adam_host.size(), hipMemcpyHostToDevice));
+            h->adam_for = *hy;
+        }
+        hipLaunchKernelGGL(k_resident32, dim3(h->n_res), dim3(256), 0, h->side, p, h->d_res, h->d_adam);
         HIPCK(hipEventRecord(h->ev_out, h->side));
     }
     if (streaming) {

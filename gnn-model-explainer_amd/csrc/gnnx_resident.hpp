@@ -32,7 +32,7 @@ struct ResidentShared {
     float rn1[TILE], rn2[TILE], yhat[TILE], g3[TILE], arow[TILE];
     float phi[32], fcur[32], mf[32], vf[32], bias[3][32];
     float z3[32], y3[32], dz3[32], e[96], g[CMAX], dEs[96], dfp[32];
-    float sr3, step_size, inv_bc2s;
+    float sr3;
 };
 
 // split-K contraction of the resident tile: Z = Abar . B for the 32 rows, B given by a functor of (k, column).
@@ -107,7 +107,7 @@ __device__ __forceinline__ void resident_colsum(ResidentShared& sh, float (&part
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_resident32(Params p, const int32_t* targets) {
+__global__ __launch_bounds__(256) void k_resident32(Params p, const int32_t* targets, const float* adam_tab) {
     __shared__ ResidentShared sh;
     const int t = targets[blockIdx.x];
     const TargetMeta tm = p.meta[t];
@@ -159,17 +159,11 @@ __global__ __launch_bounds__(256) void k_resident32(Params p, const int32_t* tar
     publish_abar();
 
     for (int iter = 0; iter < p.num_iters; ++iter) {
-        // Adam scalars exactly as the host computes them for the streaming kernels (double, then float):
-        // step_size = lr / (1 - beta1^k), bc2s = sqrt(1 - beta2^k)
-        if (tid == 0) {
-            const double b1 = 1.0 - pow((double)p.beta1, (double)(iter + 1));
-            const double b2 = 1.0 - pow((double)p.beta2, (double)(iter + 1));
-            sh.step_size = (float)((double)p.lr / b1);
-            sh.inv_bc2s = 1.0f / (float)sqrt(b2);
-        }
+        // Adam scalars: the same host-computed values (double, then float) the streaming kernels receive as
+        // arguments: adam_tab[2k] = lr / (1 - beta1^(k+1)), adam_tab[2k+1] = sqrt(1 - beta2^(k+1))
         if (tid < 32) sh.phi[tid] = (tid < p.D) ? sigmoidf_(sh.fcur[tid]) : 0.0f;
         __syncthreads();
-        const float step_size = sh.step_size, inv_bc2s = sh.inv_bc2s;
+        const float step_size = adam_tab[2 * iter], inv_bc2s = 1.0f / adam_tab[2 * iter + 1];
 
         // ---- layer 1: Zraw = Abar . X ; U1 ----
         float z4[4], u4[4];
@@ -214,12 +208,16 @@ __global__ __launch_bounds__(256) void k_resident32(Params p, const int32_t* tar
         __syncthreads();
         {   // softmax head (explain.py:713-714, 750-753): g = p - onehot(y_gt), dE = Wp^T g
             if (tid < 64) {
-                float z = -3.0e38f;
-                if (tid < p.C) {
-                    float s = 0.0f;
-                    for (int q = 0; q < 96; ++q) s = fmaf(sh.sWp[tid * 96 + q], sh.e[q], s);
-                    z = s + sh.sbp[tid];
-                }
+                // logits: class c = lane / 8 (C <= 8), the 96-term dot split over 8 lanes, then moved to lane c
+                const int c = tid >> 3, part = tid & 7;
+                float s = 0.0f;
+                if (c < p.C)
+                    for (int q = part * 12; q < part * 12 + 12; ++q) s = fmaf(sh.sWp[c * 96 + q], sh.e[q], s);
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                s += __shfl_xor(s, 4);
+                const float zc = __shfl(s, (tid & 7) * 8);  // lane l < 8 receives the sum of class l
+                float z = (tid < p.C) ? zc + sh.sbp[tid] : -3.0e38f;
                 float mx = z;
 #pragma unroll
                 for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
