@@ -6,8 +6,8 @@
  * Paths are relative to the reference root.
  *
  * Conventions: plain C, no torch types.  Every device buffer is owned by the caller (PyTorch);
- * the library allocates only its small per-plan tables at gnnx_plan_create and nothing in
- * gnnx_run.  gnnx_run is asynchronous on the given hipStream_t.  Return 0 = ok, non-zero =
+ * the library allocates only its small per-plan tables at gnnx_plan_create (and one per-iteration Adam
+ * scalar table the first time a given gnnx_hyper is run), never per-target or per-iteration buffers.  gnnx_run is asynchronous on the given hipStream_t.  Return 0 = ok, non-zero =
  * error with text in gnnx_last_error().  One plan per device, not thread-safe.
  *
  * Packed layout ("segmented over targets"):
