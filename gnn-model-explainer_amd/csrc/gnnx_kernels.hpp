@@ -126,6 +126,7 @@ __device__ __forceinline__ void rowlocal_backward(const float (&du)[4], const fl
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) dz[j] = 0.0f;
+#pragma unroll 4
     for (int c = 0; c < dout; ++c) {
         const float dy = zs[row * 33 + c];
 #pragma unroll
@@ -174,6 +175,7 @@ __device__ __forceinline__ void conv_epilogue(const Params& p, const ConvTile& t
         float y[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) y[j] = 0.0f;
+#pragma unroll 4
         for (int k = 0; k < din; ++k) {
             const float z = sh.zs[row * 33 + k];
 #pragma unroll
@@ -555,6 +557,7 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
         const float b3c = __shfl(b3, c);  // all 64 lanes take part in the shuffle
         float y = 0.0f;
         if (c < p.O) {
+#pragma unroll 4
             for (int k = 0; k < p.H; ++k) y = fmaf(zs[k], wl[k * 33 + c], y);
             y += b3c;
         }
@@ -587,6 +590,7 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
     if (tid < 32) {
         float v = 0.0f;
         if (tid < p.H)
+#pragma unroll 4
             for (int c = 0; c < p.O; ++c) v = fmaf(zs[c], wl[tid * 33 + c], v);
         dz3[tid] = v;
     }

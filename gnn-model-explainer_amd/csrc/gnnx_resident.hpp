@@ -65,6 +65,7 @@ __device__ __forceinline__ void resident_fwd_epilogue(ResidentShared& sh, const 
     for (int j = 0; j < 4; ++j) sh.zs[row * 33 + cg + j] = z4[j];
     __syncthreads();
     float y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
     for (int k = 0; k < din; ++k) {
         const float z = sh.zs[row * 33 + k];
 #pragma unroll
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(256) void k_resident32(Params p, const int32_t* tar
             const int c = tid & 31;
             float y = 0.0f;
             if (c < p.O) {
+#pragma unroll 4
                 for (int k = 0; k < p.H; ++k) y = fmaf(sh.z3[k], sh.wl[2][k * 33 + c], y);
                 y += sh.bias[2][c];
             }
@@ -230,6 +232,7 @@ __global__ __launch_bounds__(256) void k_resident32(Params p, const int32_t* tar
             __syncthreads();
             if (tid < 96) {
                 float s = 0.0f;
+#pragma unroll 4
                 for (int c = 0; c < p.C; ++c) s = fmaf(sh.sWp[c * 96 + tid], sh.g[c], s);
                 sh.dEs[tid] = s;
             }
@@ -248,6 +251,7 @@ __global__ __launch_bounds__(256) void k_resident32(Params p, const int32_t* tar
         if (tid < 32) {
             float v = 0.0f;
             if (tid < p.H)
+#pragma unroll 4
                 for (int c = 0; c < p.O; ++c) v = fmaf(sh.zs[c], sh.wl[2][tid * 33 + c], v);
             sh.dz3[tid] = v;
         }
