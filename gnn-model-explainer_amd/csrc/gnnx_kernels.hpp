@@ -647,7 +647,7 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
 //   LOSS         : also accumulate the size / entropy / Laplacian loss terms (logging)
 // ---------------------------------------------------------------------------------------------
 template <bool UPDATE, bool WRITE_ABAR, bool NODE, bool LOSS>
-__global__ __launch_bounds__(256) void k_mask(Params p, const MaskTile* tiles, int iter, float step_size, float bc2s) {
+__global__ __launch_bounds__(256, 4) void k_mask(Params p, const MaskTile* tiles, int iter, float step_size, float bc2s) {
     constexpr int LS = 33;  // LDS row stride
     __shared__ float sGp[4 * TILE * LS];                             // per-wave partial G tiles, [w][i][j]
     __shared__ float sPM[TILE * LS], sPm[TILE * LS], sPv[TILE * LS];  // mirror tile (J,I), natural orientation [j][i]
