@@ -226,17 +226,10 @@ class MaskOptimJob:
     def _square_views(self, flat):
         return [flat[o:o + l * l].reshape(l, l) for o, l in zip(self.offQ, self.ld)]
 
-    def _host_buffer(self, shape):
-        """Zero-filled host staging buffer: pinned when the job lives on a GPU (async H2D, no page-fault storm)."""
-        t = torch.zeros(shape, dtype=torch.float32, pin_memory=(self.device.type == _DEVICE_TYPE))
-        return t, t.numpy()
-
     def _pack(self, subgraphs):
-        dev = self.device
-        tA, A = self._host_buffer(self.Q)
-        tX, X = self._host_buffer((self.R, FEAT_STRIDE))
-        ty, yhat = self._host_buffer(self.R)
-        self._hM, self._hM_np = self._host_buffer(self.Q)        # reused by every set_masks call
+        A = np.zeros(self.Q, np.float32)
+        X = np.zeros((self.R, FEAT_STRIDE), np.float32)
+        yhat = np.zeros(self.R, np.float32)
         for s, v, r, n in zip(subgraphs, self._square_views(A), self.offR, self.n):
             v[:n, :n] = s.adj
             X[r:r + n, :self.D] = s.feat
@@ -244,9 +237,10 @@ class MaskOptimJob:
                 if s.pred_label is None:
                     raise ValueError("node mode needs pred_label for the Laplacian term (explain.py:780-793)")
                 yhat[r:r + n] = s.pred_label
-        self.A = tA.to(dev, non_blocking=True)
-        self.X = tX.to(dev, non_blocking=True)
-        self.yhat = ty.to(dev, non_blocking=True)
+        dev = self.device
+        self.A = torch.from_numpy(A).to(dev)
+        self.X = torch.from_numpy(X).to(dev)
+        self.yhat = torch.from_numpy(yhat).to(dev)
         self.M = torch.empty(self.Q, dtype=torch.float32, device=dev)
         self.Abar = torch.empty(self.Q, dtype=torch.float32, device=dev)
         self.fmask = torch.empty(self.T, FEAT_STRIDE, dtype=torch.float32, device=dev)
@@ -254,16 +248,13 @@ class MaskOptimJob:
         self.loss = None
         # the job owns a non-default stream: hipGraph capture is illegal on the legacy default stream
         self.stream = torch.cuda.Stream(dev) if dev.type == _DEVICE_TYPE else None
-        if dev.type == _DEVICE_TYPE:
-            torch.cuda.current_stream(dev).synchronize()      # staging buffers may be released after this point
 
     def set_masks(self, masks: Sequence[np.ndarray]):
         """Upload the initial edge masks (host-generated so the torch CPU RNG stream matches the reference)."""
-        for m, v, n in zip(masks, self._square_views(self._hM_np), self.n):
-            v[:n, :n] = m          # padding stays zero
-        self.M.copy_(self._hM, non_blocking=True)
-        if self.device.type == _DEVICE_TYPE:
-            torch.cuda.current_stream(self.device).synchronize()   # the staging buffer is reused by the next call
+        M = np.zeros(self.Q, np.float32)
+        for m, v, n in zip(masks, self._square_views(M), self.n):
+            v[:n, :n] = m
+        self.M.copy_(torch.from_numpy(M), non_blocking=False)
 
     def _stream(self):
         return ctypes.c_void_p(self.stream.cuda_stream if self.stream is not None else 0)
