@@ -442,6 +442,21 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
     return 0;
 }
 
+extern "C" int gnnx_pack_csr(gnnx_handle h, const int64_t* indptr, const int32_t* indices, const float* weights,
+                             const float* feat, int32_t feat_stride, const float* pred_label, const int32_t* nb,
+                             const int64_t* nb_off, float* A, float* X, float* yhat, void* stream) {
+    if (!h || !indptr || !indices || !feat || !nb || !nb_off || !A || !X) return fail("null argument");
+    if (!h->prob.graph_mode && (!pred_label || !yhat)) return fail("pred_label / yhat are required in node mode");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIPCK(hipMemsetAsync(A, 0, sizeof(float) * (size_t)h->Q, s));
+    HIPCK(hipMemsetAsync(X, 0, sizeof(float) * (size_t)h->R * FS, s));
+    if (yhat) HIPCK(hipMemsetAsync(yhat, 0, sizeof(float) * (size_t)h->R, s));
+    PackArgs a{indptr, indices, weights, feat, feat_stride, pred_label, nb, nb_off, A, X, yhat, h->prob.D};
+    hipLaunchKernelGGL(k_pack, dim3(h->n_conv), dim3(256), 0, s, a, h->d_conv);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int gnnx_forward(gnnx_handle h, const float* A, const float* X, const float* M, const float* feat_mask_in,
                             float* Abar, float* probs, void* workspace, size_t workspace_bytes, void* stream) {
     if (!h || !A || !X || !M || !Abar || !probs || !workspace) return fail("null argument");

@@ -899,4 +899,48 @@ __global__ __launch_bounds__(256) void k_prep(Params p, const float* f_init, con
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Device-side sub-graph packing (replaces the host's dense slicing adj[nb][:, nb], feat[nb] of
+// explainer/explain.py:492-501 for a whole batch): one workgroup per 32-row block.  Row i of target t is node
+// u = nb[i]; each CSR neighbour v of u is located in the (ascending) neighbour list by binary search and its
+// weight written to A[i][j].  A, X, yhat must be zero-filled by the caller (padding stays zero).
+// ---------------------------------------------------------------------------------------------
+struct PackArgs {
+    const int64_t* indptr;   // CSR of the full graph [N+1]
+    const int32_t* indices;  // [nnz]
+    const float* weights;    // [nnz] or null (all ones)
+    const float* feat;       // [N][feat_stride]
+    int32_t feat_stride;
+    const float* pred_label; // [N] predicted class id as float, or null (graph-free use)
+    const int32_t* nb;       // concatenated neighbour lists
+    const int64_t* nb_off;   // [T+1]
+    float* A;
+    float* X;
+    float* yhat;
+    int32_t D;
+};
+
+__global__ __launch_bounds__(256) void k_pack(PackArgs a, const ConvTile* tiles) {
+    const ConvTile tl = tiles[blockIdx.x];
+    const TargetMeta tm = tl.tm;
+    const int row = threadIdx.x >> 3, part = threadIdx.x & 7;
+    const int i = tl.rb * TILE + row;
+    if (i >= tm.n) return;
+    const int32_t* nb = a.nb + a.nb_off[tl.t];
+    const int u = nb[i];
+    float* Arow = a.A + tm.offQ + (size_t)i * tm.ld;
+    for (int64_t e = a.indptr[u] + part; e < a.indptr[u + 1]; e += 8) {
+        const int v = a.indices[e];
+        int lo = 0, hi = tm.n - 1;
+        while (lo < hi) {  // lower bound of v in the ascending neighbour list
+            const int mid = (lo + hi) >> 1;
+            if (nb[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        if (nb[lo] == v) Arow[lo] = a.weights ? a.weights[e] : 1.0f;
+    }
+    float* Xrow = a.X + ((size_t)tm.offR + i) * FS;
+    for (int c = part; c < a.D; c += 8) Xrow[c] = a.feat[(size_t)u * a.feat_stride + c];
+    if (part == 0 && a.pred_label) a.yhat[tm.offR + i] = a.pred_label[u];
+}
+
 }  // namespace gnnx

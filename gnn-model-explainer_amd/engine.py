@@ -89,6 +89,7 @@ _API = {
     "gnnx_workspace_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
     "gnnx_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper)] + [ctypes.c_void_p] * 8 +
                  [ctypes.c_size_t, ctypes.c_void_p]),
+    "gnnx_pack_csr": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int32] + [ctypes.c_void_p] * 7),
     "gnnx_forward": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_void_p] * 7 + [ctypes.c_size_t, ctypes.c_void_p]),
     "gnnx_time_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper), ctypes.c_int32, ctypes.c_int32] +
                          [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
@@ -168,8 +169,76 @@ class JobResult:
     stats: dict = field(default_factory=dict)
 
 
+@dataclass
+class DeviceGraph:
+    """The full graph resident on the device in CSR form (uploaded once, reused by every batch)."""
+    indptr: torch.Tensor       # int64 [N+1]
+    indices: torch.Tensor      # int32 [nnz]
+    weights: Optional[torch.Tensor]   # float32 [nnz] or None (binary adjacency)
+    feat: torch.Tensor         # float32 [N, D]
+    pred_label: Optional[torch.Tensor]   # float32 [N] predicted class ids (node mode)
+    num_nodes: int
+    binary: bool
+
+
+def device_graph(csr, feat, pred=None, device=None):
+    """Upload a scipy CSR adjacency + features (+ argmax of the model's predictions) for device-side packing."""
+    import scipy.sparse as sp
+    csr = sp.csr_matrix(csr)
+    csr.sum_duplicates()
+    csr.sort_indices()
+    if abs(csr - csr.T).nnz != 0:
+        raise NotImplementedError("the HIP path requires a symmetric adjacency (all reference datasets are undirected)")
+    if device is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: the gnnx engine runs on MI355X only (no CPU fallback)")
+        device = torch.device(_DEVICE_TYPE, torch.cuda.current_device())
+    device = torch.device(device)
+    binary = bool(np.all(csr.data == 1))
+    to = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(device)
+    return DeviceGraph(to(csr.indptr, np.int64), to(csr.indices, np.int32), None if binary else to(csr.data, np.float32),
+                       to(feat, np.float32), None if pred is None else to(np.argmax(pred, axis=1), np.float32),
+                       csr.shape[0], binary)
+
+
 class MaskOptimJob:
     """A batch of targets resident on one GPU: plan + packed device buffers."""
+
+    @classmethod
+    def from_csr(cls, graph: DeviceGraph, neighbors: Sequence[np.ndarray], target_rows, gt_labels, state_dict, lib=None):
+        """Node-mode batch whose sub-graphs are sliced ON THE DEVICE from the CSR graph (gnnx_pack_csr): the host
+        only supplies the ascending k-hop neighbour list of every target (explain.py:492-501)."""
+        self = cls.__new__(cls)
+        self.lib = lib if lib is not None else get_library()
+        self.device = graph.feat.device
+        self.graph_mode = False
+        self._init_model(state_dict)
+        if graph.feat.shape[1] != self.D:
+            raise ValueError("feature width does not match the encoder")
+        self.T = len(neighbors)
+        if self.T == 0:
+            raise ValueError("empty batch")
+        self.n = np.asarray([len(nb) for nb in neighbors], np.int32)
+        self._create_plan(np.asarray(target_rows, np.int32), np.asarray(gt_labels, np.int32))
+        self._alloc_device()
+        nb_off = np.zeros(self.T + 1, np.int64)
+        np.cumsum(self.n, out=nb_off[1:])
+        nb_flat = torch.from_numpy(np.concatenate(neighbors).astype(np.int32)).to(self.device)
+        nb_off_d = torch.from_numpy(nb_off).to(self.device)
+        self._enter()
+        _check(self.lib, self.lib.gnnx_pack_csr(
+            self.handle, graph.indptr.data_ptr(), graph.indices.data_ptr(),
+            graph.weights.data_ptr() if graph.weights is not None else None, graph.feat.data_ptr(), graph.feat.shape[1],
+            graph.pred_label.data_ptr(), nb_flat.data_ptr(), nb_off_d.data_ptr(), self.A.data_ptr(), self.X.data_ptr(),
+            self.yhat.data_ptr(), self._stream()))
+        self._leave()
+        self._keepalive = (nb_flat, nb_off_d, graph)
+        return self
+
+    def adjacency(self):
+        """Per-target dense sub-adjacencies as packed on the device (host copies)."""
+        A = self.A.cpu().numpy()
+        return [v[:n, :n].copy() for v, n in zip(self._square_views(A), self.n)]
 
     def __init__(self, subgraphs: Sequence[Subgraph], state_dict, graph_mode=False, device=None, lib=None):
         self.lib = lib if lib is not None else get_library()
@@ -179,14 +248,7 @@ class MaskOptimJob:
             device = torch.device(_DEVICE_TYPE, torch.cuda.current_device())
         self.device = torch.device(device)
         self.graph_mode = bool(graph_mode)
-        self.w = model_arrays(state_dict)
-        self.D, self.H = self.w["conv_first.weight"].shape
-        self.O = self.w["conv_last.weight"].shape[1]
-        self.C = self.w["pred_model.weight"].shape[0]
-        if self.w["conv_block.0.weight"].shape != (self.H, self.H) or self.w["conv_last.weight"].shape[0] != self.H:
-            raise NotImplementedError("unexpected encoder shapes")
-        if self.w["pred_model.weight"].shape[1] != 2 * self.H + self.O:
-            raise NotImplementedError("only concat=True prediction heads are supported")
+        self._init_model(state_dict)
         self.T = len(subgraphs)
         if self.T == 0:
             raise ValueError("empty batch")
@@ -199,6 +261,21 @@ class MaskOptimJob:
                 raise NotImplementedError("the HIP path requires a symmetric adjacency (all reference datasets are undirected)")
         rows = np.asarray([0 if graph_mode else s.target_row for s in subgraphs], np.int32)
         labels = np.asarray([s.gt_label for s in subgraphs], np.int32)
+        self._create_plan(rows, labels)
+        self._alloc_device()
+        self._pack(subgraphs)
+
+    def _init_model(self, state_dict):
+        self.w = model_arrays(state_dict)
+        self.D, self.H = self.w["conv_first.weight"].shape
+        self.O = self.w["conv_last.weight"].shape[1]
+        self.C = self.w["pred_model.weight"].shape[0]
+        if self.w["conv_block.0.weight"].shape != (self.H, self.H) or self.w["conv_last.weight"].shape[0] != self.H:
+            raise NotImplementedError("unexpected encoder shapes")
+        if self.w["pred_model.weight"].shape[1] != 2 * self.H + self.O:
+            raise NotImplementedError("only concat=True prediction heads are supported")
+
+    def _create_plan(self, rows, labels):
         prob = _Problem(self.T, self.n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                         rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                         labels.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), self.D, self.H, self.O, self.C,
@@ -220,7 +297,20 @@ class MaskOptimJob:
                                                   self.offQ.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
                                                   self.offR.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
         self.ws_bytes = int(self.lib.gnnx_workspace_bytes(self.handle))
-        self._pack(subgraphs)
+
+    def _alloc_device(self):
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.A = torch.empty(self.Q, **f32)
+        self.X = torch.empty(self.R, FEAT_STRIDE, **f32)
+        self.yhat = torch.empty(self.R, **f32)
+        self.M = torch.empty(self.Q, **f32)
+        self.Abar = torch.empty(self.Q, **f32)
+        self.fmask = torch.empty(self.T, FEAT_STRIDE, **f32)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        self.loss = None
+        # the job owns a non-default stream: hipGraph capture is illegal on the legacy default stream
+        self.stream = torch.cuda.Stream(dev) if dev.type == _DEVICE_TYPE else None
 
     # -- packing -------------------------------------------------------------------------------
     def _square_views(self, flat):
@@ -237,17 +327,9 @@ class MaskOptimJob:
                 if s.pred_label is None:
                     raise ValueError("node mode needs pred_label for the Laplacian term (explain.py:780-793)")
                 yhat[r:r + n] = s.pred_label
-        dev = self.device
-        self.A = torch.from_numpy(A).to(dev)
-        self.X = torch.from_numpy(X).to(dev)
-        self.yhat = torch.from_numpy(yhat).to(dev)
-        self.M = torch.empty(self.Q, dtype=torch.float32, device=dev)
-        self.Abar = torch.empty(self.Q, dtype=torch.float32, device=dev)
-        self.fmask = torch.empty(self.T, FEAT_STRIDE, dtype=torch.float32, device=dev)
-        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
-        self.loss = None
-        # the job owns a non-default stream: hipGraph capture is illegal on the legacy default stream
-        self.stream = torch.cuda.Stream(dev) if dev.type == _DEVICE_TYPE else None
+        self.A.copy_(torch.from_numpy(A))
+        self.X.copy_(torch.from_numpy(X))
+        self.yhat.copy_(torch.from_numpy(yhat))
 
     def set_masks(self, masks: Sequence[np.ndarray]):
         """Upload the initial edge masks (host-generated so the torch CPU RNG stream matches the reference)."""

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ..engine import FEAT_STRIDE, Hyper, MaskOptimJob, Subgraph, init_edge_mask
+from ..engine import FEAT_STRIDE, Hyper, MaskOptimJob, Subgraph, device_graph, init_edge_mask
 from ..utils import io_utils
 from ..utils.graph_utils import KHopIndex
 
@@ -73,6 +73,7 @@ class Explainer:
         self.print_training = print_training
         _check_supported(args)
         self._khop = {}             # graph index -> KHopIndex (sparse; replaces the dense utils/graph_utils.py:147-158)
+        self._dev_graph = {}        # graph index -> engine.DeviceGraph (CSR + features on the GPU, uploaded once)
         self.last_result = None     # JobResult of the most recent batch (feature masks, loss traces)
         self.last_time = None
 
@@ -133,28 +134,52 @@ class Explainer:
         gt = int(_np(self.label[graph_idx]))
         return Subgraph(np.asarray(sub_adj, np.float32), np.asarray(sub_feat, np.float32), gt, 0, None, None), sub_adj
 
+    def _device_graph(self, graph_idx):
+        if graph_idx not in self._dev_graph:
+            self._dev_graph[graph_idx] = device_graph(self._index(graph_idx).csr, _np(self.feat)[graph_idx],
+                                                      _np(self.pred)[graph_idx])
+        return self._dev_graph[graph_idx]
+
     def explain_batch(self, node_indices=None, graph_indices=None, graph_idx=0, record_loss=False, use_graph=True):
-        """All targets as ONE job on the GPU. Returns list of float64 masked adjacencies (reference layout)."""
+        """All targets as ONE job on the GPU. Returns list of float64 masked adjacencies (reference layout).
+
+        Node mode: only the k-hop neighbour lists are computed on the host; the dense sub-adjacencies, feature
+        rows and predicted labels are sliced on the device from the CSR graph (gnnx_pack_csr)."""
+        begin = time.time()
         if self.graph_mode or graph_indices is not None:
             targets = list(graph_indices)
             built = [self._graph_subgraph(g) for g in targets]
-            mode = True
+            subs = [b[0] for b in built]
+            sizes = [s.adj.shape[0] for s in subs]
+            make_job = lambda: MaskOptimJob(subs, self.model.state_dict(), graph_mode=True)
+            sub_adjs = lambda job: [np.asarray(b[1], np.float64) for b in built]
         else:
-            targets = list(node_indices)
-            built = self._node_subgraphs(targets, graph_idx)
-            mode = False
-        subs = [b[0] for b in built]
-        for s in subs:                                   # same RNG stream as ExplainModule.__init__ per target
-            s.mask0 = init_edge_mask(s.adj.shape[0])
-        begin = time.time()
-        job = MaskOptimJob(subs, self.model.state_dict(), graph_mode=mode)
-        hy = _hyper(self.args, record_loss=record_loss, use_graph=use_graph and len(subs) > 1)
-        res = job.run([s.mask0 for s in subs], hy)
+            targets = [int(v) for v in node_indices]
+            idx = self._index(graph_idx)
+            nbs = idx.neighbors_batch(targets)
+            for v, nb in zip(targets, nbs):
+                if len(nb) == 0:
+                    raise IndexError("node %d has an empty %d-hop neighbourhood" % (v, self.n_hops))
+            rows = [int(np.searchsorted(nb, v)) for v, nb in zip(targets, nbs)]          # explain.py:496
+            labels = _np(self.label)[graph_idx][np.asarray(targets)]                      # explain.py:751
+            sizes = [len(nb) for nb in nbs]
+            graph = self._device_graph(graph_idx)
+            make_job = lambda: self._job_from_csr(graph, nbs, rows, labels)
+            # explain.py:209-211 multiplies by sub_adj: a no-op for a 0/1 adjacency, otherwise fetched back once
+            sub_adjs = lambda job: [None] * len(targets) if graph.binary else [a.astype(np.float64) for a in job.adjacency()]
+        masks = [init_edge_mask(n) for n in sizes]          # same RNG stream as ExplainModule.__init__ per target
+        job = make_job()
+        hy = _hyper(self.args, record_loss=record_loss, use_graph=use_graph and len(targets) > 1)
+        res = job.run(masks, hy)
+        adjs = sub_adjs(job)
         job.close()
         self.last_time = time.time() - begin
         self.last_result = res
         # explain.py:209-211: float32 mask * float64 sub_adj -> float64
-        return [ma.astype(np.float64) * np.asarray(sa, np.float64) for ma, (_, sa) in zip(res.masked_adj, built)]
+        return [ma.astype(np.float64) if sa is None else ma.astype(np.float64) * sa for ma, sa in zip(res.masked_adj, adjs)]
+
+    def _job_from_csr(self, graph, nbs, rows, labels):
+        return MaskOptimJob.from_csr(graph, nbs, rows, labels, self.model.state_dict())
 
     def _save(self, masked_adj, node_idx):
         fname = "masked_adj_" + io_utils.gen_explainer_prefix(self.args) + (

@@ -90,6 +90,17 @@ int gnnx_run(gnnx_handle h, const gnnx_hyper* hyper, const float* A, const float
              float* M, float* Abar, float* feat_mask, float* loss, void* workspace, size_t workspace_bytes,
              void* stream);
 
+/* Device-side packing of the plan's sub-graphs from the full graph in CSR form (all pointers are DEVICE
+ * pointers): replaces the host's dense slicing `adj[nb][:, nb]`, `feat[nb]`, `argmax(pred[nb])` of
+ * Explainer.extract_neighborhood / explain (explain.py:492-501, 94-106) for the whole batch.
+ *   indptr [N+1] int64, indices [nnz] int32, weights [nnz] or NULL (all ones): symmetric adjacency
+ *   feat [N][feat_stride], pred_label [N] (predicted class id as float) or NULL (graph mode)
+ *   nb: concatenated ascending neighbour lists, nb_off [T+1] offsets (nb_off[t+1]-nb_off[t] == n[t] of the plan)
+ *   A, X, yhat: outputs in the packed layout; zero-filled by this call before packing */
+int gnnx_pack_csr(gnnx_handle h, const int64_t* indptr, const int32_t* indices, const float* weights, const float* feat,
+                  int32_t feat_stride, const float* pred_label, const int32_t* nb, const int64_t* nb_off, float* A,
+                  float* X, float* yhat, void* stream);
+
 /* One forward only (no update): fills Abar from M and returns softmax probabilities of the head,
  * probs device out [T][GNNX_MAX_CLASSES] (ExplainModule.forward, explain.py:685-715). */
 int gnnx_forward(gnnx_handle h, const float* A, const float* X, const float* M, const float* feat_mask_in,

@@ -120,3 +120,25 @@ def test_resident_kernel_full_run_vs_golden():
     rc = gx["302:edge_rc"]
     assert np.abs(res.masked_adj[0][rc[:, 0], rc[:, 1]] - gx["302:masked_adj_edges"]).max() <= 1e-5
     assert np.abs(1 / (1 + np.exp(-res.feat_mask[0])) - gx["302:feat_mask_sigmoid"]).max() <= 1e-5
+
+
+def test_device_side_packing_equals_host_packing():
+    """gnnx_pack_csr (sub-graphs sliced from CSR on the device) must build exactly the buffers the host packer builds."""
+    import torch
+    from emu.emu_engine import emu_library
+    from gnn_model_explainer_amd import engine
+    from gnn_model_explainer_amd.utils.graph_utils import KHopIndex
+    ck = helpers.load_ckpt("syn1")
+    idx = KHopIndex((ck["num_nodes"], ck["edges"]), 3)
+    targets = [302, 309, 555, 300]
+    nbs = idx.neighbors_batch(targets)
+    rows = [int(np.searchsorted(nb, v)) for v, nb in zip(targets, nbs)]
+    graph = engine.device_graph(idx.csr, ck["feat"], ck["pred"], device="cpu")
+    assert graph.binary
+    dev = engine.MaskOptimJob.from_csr(graph, nbs, rows, ck["label"][targets], ck["sd"], lib=emu_library())
+    subs = [Subgraph(ck["adj"][np.ix_(nb, nb)], ck["feat"][nb], int(ck["label"][t]), r, np.argmax(ck["pred"][nb], 1), None)
+            for t, nb, r in zip(targets, nbs, rows)]
+    host = emu_job(subs, ck["sd"])
+    assert torch.equal(dev.A, host.A) and torch.equal(dev.X, host.X) and torch.equal(dev.yhat, host.yhat)
+    for a, s in zip(dev.adjacency(), subs):
+        assert np.array_equal(a, s.adj)

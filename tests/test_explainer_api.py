@@ -39,7 +39,13 @@ def _explainer(tmp, epochs, name="syn1", **kw):
 @pytest.fixture
 def emu_engine(monkeypatch):
     from emu.emu_engine import emu_job
+    from emu.emu_engine import emu_library
+    from gnn_model_explainer_amd import engine
     monkeypatch.setattr(explain, "MaskOptimJob", lambda subs, sd, graph_mode=False: emu_job(subs, sd, graph_mode))
+    monkeypatch.setattr(explain, "device_graph", lambda csr, feat, pred=None: engine.device_graph(csr, feat, pred, device="cpu"))
+    monkeypatch.setattr(explain.Explainer, "_job_from_csr",
+                        lambda self, graph, nbs, rows, labels: engine.MaskOptimJob.from_csr(
+                            graph, nbs, rows, labels, self.model.state_dict(), lib=emu_library()))
     real_hyper = explain._hyper
 
     def no_graph_hyper(args, **kw):          # the emulator has no hipGraph: plain launches, same kernels

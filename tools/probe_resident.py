@@ -39,7 +39,8 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-
 import bench
 from gnn_model_explainer_amd import engine
 lib = engine.bind(ctypes.CDLL(so))
-ck, subs, _ = bench.build_workload("syn4", 300)
+wl = bench.Workload("syn4"); wl.prepare()
+ck, subs = wl.ck, [wl.dense_subgraph(k) for k in range(len(wl.targets))]
 job = engine.MaskOptimJob(subs, ck["sd"], lib=lib)
 job.run([s.mask0 for s in subs], engine.Hyper(num_iters=20))
 buf = (ctypes.c_ulonglong * NP)()

@@ -36,7 +36,8 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-
 import bench
 from gnn_model_explainer_amd import engine
 lib = engine.bind(ctypes.CDLL(so))
-ck, subs, _ = bench.build_workload("syn1", 300)
+wl = bench.Workload("syn1"); wl.prepare()
+ck, subs = wl.ck, [wl.dense_subgraph(k) for k in range(len(wl.targets))]
 job = engine.MaskOptimJob(subs, ck["sd"], lib=lib)
 hy = engine.Hyper(num_iters=3)
 job.run([s.mask0 for s in subs], hy)
