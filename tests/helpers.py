@@ -48,3 +48,19 @@ def dense_from_edges(n, rc, vals):
 ILL_CONDITIONED = {"syn5": (511, 1000, 1230)}
 ILL_TOL_MASK = 5e-4     # measured CPU-vs-CPU: up to 7.3e-5
 ILL_TOL_FEAT = 5e-2     # measured CPU-vs-CPU: up to 5.5e-3, GPU-vs-reference: up to 2.0e-2 (one entry of target 1230)
+
+
+def random_model(rng, D, H, O, C):
+    g = lambda *s: rng.standard_normal(s).astype(np.float32) * 0.5
+    return {"conv_first.weight": g(D, H), "conv_first.bias": g(H) * 0.2, "conv_block.0.weight": g(H, H),
+            "conv_block.0.bias": g(H) * 0.2, "conv_last.weight": g(H, O), "conv_last.bias": g(O) * 0.2,
+            "pred_model.weight": g(C, 2 * H + O), "pred_model.bias": g(C) * 0.2}
+
+
+def random_graph(rng, n, D, density=0.15):
+    A = (rng.random((n, n)) < density).astype(np.float32)
+    A = np.triu(A, 1)
+    A = A + A.T
+    for i in range(n - 1):          # keep it connected-ish
+        A[i, i + 1] = A[i + 1, i] = 1
+    return A, rng.standard_normal((n, D)).astype(np.float32)

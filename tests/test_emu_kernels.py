@@ -142,3 +142,28 @@ def test_device_side_packing_equals_host_packing():
     assert torch.equal(dev.A, host.A) and torch.equal(dev.X, host.X) and torch.equal(dev.yhat, host.yhat)
     for a, s in zip(dev.adjacency(), subs):
         assert np.array_equal(a, s.adj)
+
+
+@pytest.mark.parametrize("D,H,O,C,n,graph_mode,resident", [
+    (7, 13, 9, 3, 21, False, True),      # odd widths, resident kernel
+    (7, 13, 9, 3, 21, False, False),     # same through the streaming kernels
+    (5, 32, 32, 6, 45, False, False),    # full-width hidden layers, two row blocks
+    (31, 8, 3, 2, 70, False, False),     # wide input (beyond the 16 columns of the common case), three row blocks
+    (14, 20, 20, 2, 40, True, False),    # graph mode
+    (3, 9, 17, 9, 33, True, False),      # graph mode, odd widths, more classes than the resident path takes
+])
+def test_generic_shapes_match_closed_form(D, H, O, C, n, graph_mode, resident):
+    rng = np.random.default_rng(D * 1000 + H * 10 + n)
+    sd = helpers.random_model(rng, D, H, O, C)
+    A, X = helpers.random_graph(rng, n, D)
+    m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
+    t, gt = int(rng.integers(0, n)), int(rng.integers(0, C))
+    yhat = None if graph_mode else rng.integers(0, C, n)
+    sg = Subgraph(A, X, gt, 0 if graph_mode else t, yhat, m0)
+    iters = 4
+    res = emu_job([sg], sd, graph_mode=graph_mode).run([m0], Hyper(num_iters=iters, use_resident=resident))
+    o = closed_form.ClosedFormOracle(A, X, sd, gt, yhat, 0 if graph_mode else t, m0, graph_mode=graph_mode)
+    want = o.run(iters)
+    assert np.abs(res.masked_adj[0] - want).max() < 5e-6
+    assert np.abs(res.mask[0] - o.M).max() < 5e-5
+    assert np.abs(res.feat_mask[0] - o.f).max() < 5e-5

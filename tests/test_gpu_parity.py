@@ -163,3 +163,26 @@ def test_resident_only_batch_is_deterministic():
     for x, y in zip(a.masked_adj, b.masked_adj):
         assert np.array_equal(x, y)
     assert np.array_equal(a.masked_adj[0], a.masked_adj[4])
+
+
+@pytest.mark.parametrize("D,H,O,C,n,graph_mode,resident", [
+    (7, 13, 9, 3, 21, False, True), (7, 13, 9, 3, 21, False, False), (5, 32, 32, 6, 45, False, False),
+    (31, 8, 3, 2, 70, False, False), (14, 20, 20, 2, 40, True, False), (3, 9, 17, 9, 33, True, False),
+    (10, 20, 20, 4, 300, False, False),
+])
+def test_generic_shapes_match_closed_form(D, H, O, C, n, graph_mode, resident):
+    """Encoder shapes other than the fixtures': odd widths, full 32-wide layers, wide input, many classes."""
+    rng = np.random.default_rng(D * 1000 + H * 10 + n)
+    sd = helpers.random_model(rng, D, H, O, C)
+    A, X = helpers.random_graph(rng, n, D, density=0.15 if n < 100 else 0.03)
+    m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
+    t, gt = int(rng.integers(0, n)), int(rng.integers(0, C))
+    yhat = None if graph_mode else rng.integers(0, C, n)
+    sg = Subgraph(A, X, gt, 0 if graph_mode else t, yhat, m0)
+    iters = 6
+    res = MaskOptimJob([sg], sd, graph_mode=graph_mode).run([m0], Hyper(num_iters=iters, use_resident=resident))
+    o = closed_form.ClosedFormOracle(A, X, sd, gt, yhat, 0 if graph_mode else t, m0, graph_mode=graph_mode)
+    want = o.run(iters)
+    assert np.abs(res.masked_adj[0] - want).max() < 5e-6
+    assert np.abs(res.mask[0] - o.M).max() < 5e-5
+    assert np.abs(res.feat_mask[0] - o.f).max() < 5e-5
