@@ -171,6 +171,10 @@ def node_fixture(dataset, targets, work, epochs=300, keep_mask0=()):
         out[f"{t}:feat_mask_sigmoid"] = torch.sigmoid(mod.feat_mask).detach().numpy()
         out[f"{t}:final_mask_edges"] = mod.mask.detach().numpy()[r, c]
         out[f"{t}:loss"] = np.asarray(mod.loss_trace, np.float32)
+        with quiet():   # reference post-processing of explain_nodes_gnn_stats (explain.py:306-308)
+            G = io_utils.denoise_graph(ma, new_idx, ex.feat[0][nb], threshold_num=20)
+        out[f"{t}:denoised_nodes"] = np.asarray(sorted(G.nodes()), np.int32)
+        out[f"{t}:denoised_edges"] = np.asarray(sorted((min(u, v), max(u, v)) for u, v in G.edges()), np.int32).reshape(-1, 2)
         if t in keep_mask0:
             out[f"{t}:mask0"] = mod.mask0.numpy()
         print(f"  {dataset} target {t}: n={len(nb)} edges={len(r)//2} loss[0]={mod.loss_trace[0]:.4f} "

@@ -79,3 +79,17 @@ def test_engine_fails_loudly_without_gpu():
     sg = engine.Subgraph(np.zeros((2, 2), np.float32), np.ones((2, 10), np.float32), 0, 0, np.zeros(2), None)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         engine.MaskOptimJob([sg], ck["sd"])
+
+
+def test_denoise_graph_matches_reference_postprocessing():
+    """Same node / edge sets as the reference's io_utils.denoise_graph on the golden explanations."""
+    from gnn_model_explainer_amd.utils import io_utils
+    for name in ("syn1", "syn4"):
+        gx = helpers.load_explain(name)
+        for t in gx["targets"]:
+            nb = gx[f"{t}:neighbors"]
+            ma = helpers.dense_from_edges(len(nb), gx[f"{t}:edge_rc"], gx[f"{t}:masked_adj_edges"])
+            G = io_utils.denoise_graph(ma, int(gx[f"{t}:node_idx_new"]), threshold_num=20)
+            assert sorted(G.nodes()) == list(gx[f"{t}:denoised_nodes"])
+            edges = sorted((min(u, v), max(u, v)) for u, v in G.edges())
+            assert edges == [tuple(e) for e in gx[f"{t}:denoised_edges"]]
