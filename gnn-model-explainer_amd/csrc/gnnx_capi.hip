@@ -3,8 +3,10 @@
 // one mask-optimisation job and its optional hipGraph capture.  No compute happens on the host.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -40,14 +42,17 @@ struct gnnx_plan_s {
     std::vector<TargetMeta> meta;
     int64_t Q = 0, R = 0;
     int n_conv = 0, n_mask = 0;      // tile tables over ALL targets (streaming path for everything)
-    // hybrid split: single-tile node-mode targets run in the on-chip-resident kernel, the rest stream
+    // hybrid split: node-mode targets of up to res_nbmax row blocks run in the on-chip-resident kernels, the rest stream
     int n_res = 0, n_big = 0, n_conv_big = 0, n_mask_big = 0;
-    int32_t* d_res = nullptr;        // target ids of the resident set
+    int res_nbmax = RES_NBMAX;
+    int res_count[RES_NBMAX + 1] = {};  // resident targets with nb row blocks
+    int res_first[RES_NBMAX + 1] = {};  // their first index in d_res
+    int32_t* d_res = nullptr;        // target ids of the resident set (grouped by nb, largest first)
     int32_t* d_big = nullptr;        // target ids of the streaming set
     ConvTile* d_conv_big = nullptr;
     MaskTile* d_mask_big = nullptr;
-    hipStream_t side = nullptr;      // the resident kernel runs beside the streaming launches
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipStream_t side[RES_NBMAX] = {};   // the resident kernels (one per nb) run beside the streaming launches
+    hipEvent_t ev_in = nullptr, ev_out[RES_NBMAX] = {};
     float* d_adam = nullptr;         // per-iteration Adam scalars for the resident kernel
     std::vector<float> adam_host;
     gnnx_hyper adam_for{};
@@ -111,9 +116,26 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
     for (int t = 0; t < T; ++t) order[t] = t;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h->meta[a].ld > h->meta[b].ld; });
     const bool resident_ok = !prob->graph_mode && prob->C <= RES_CMAX;
+    if (const char* env = std::getenv("GNNX_RESIDENT_MAX_BLOCKS")) {  // tuning knob, see include/gnnx.h
+        const int v = std::atoi(env);
+        h->res_nbmax = v < 0 ? 0 : (v > RES_NBMAX ? RES_NBMAX : v);
+    }
+    // A batch whose targets ALL fit runs entirely on chip (no streaming launch at all).  Otherwise only the
+    // single-tile targets ride beside the streaming chain of the larger ones: measured on syn1 (400 targets, 72 of
+    // them with >= 4 row blocks), moving the 2- and 3-block targets beside the chain as well made the batch slower
+    // (22.2 -> 24-38 ms: their workgroups hold whole CUs for the full run and add hardware queues), while the
+    // streaming chain of the large targets stays the long pole either way.
+    {
+        int max_nb = 0;
+        for (int t = 0; t < T; ++t) max_nb = std::max(max_nb, h->meta[t].ld / TILE);
+        if (max_nb > h->res_nbmax) h->res_nbmax = std::min(h->res_nbmax, 1);
+    }
     for (int t : order) {
         const int nb = h->meta[t].ld / TILE;
-        const bool res = resident_ok && nb == 1;
+        const bool res = resident_ok && nb <= h->res_nbmax;
+        if (res) {
+            if (h->res_count[nb]++ == 0) h->res_first[nb] = (int)res_ids.size();  // `order` is sorted by ld: groups are contiguous
+        }
         (res ? res_ids : big_ids).push_back(t);
         for (int rb = 0; rb < nb; ++rb) {
             conv.push_back({t, rb, h->meta[t]});
@@ -163,9 +185,17 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
     if (h->n_res) {
         PLANCK(hipMalloc(&h->d_res, sizeof(int32_t) * res_ids.size()));
         PLANCK(hipMemcpy(h->d_res, res_ids.data(), sizeof(int32_t) * res_ids.size(), hipMemcpyHostToDevice));
-        PLANCK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
         PLANCK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
-        PLANCK(hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+        // side streams at the LOWEST priority: the streaming chain is the long pole of a hybrid batch and must not queue
+        // behind a resident kernel (streams of one priority share a small pool of hardware queues, and packets of
+        // one hardware queue run in order - measured: 22 -> 38 ms on syn1 when the main stream shared a queue)
+        int prio_least = 0, prio_greatest = 0;
+        PLANCK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        for (int k = 0; k < RES_NBMAX; ++k) {
+            if (!h->res_count[k + 1]) continue;
+            PLANCK(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
+            PLANCK(hipEventCreateWithFlags(&h->ev_out[k], hipEventDisableTiming));
+        }
     }
     if (h->n_res && h->n_big) {
         PLANCK(hipMalloc(&h->d_big, sizeof(int32_t) * big_ids.size()));
@@ -219,9 +249,11 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
     if (!h) return 0;
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->d_meta) (void)hipFree(h->d_meta);
-    if (h->side) (void)hipStreamDestroy(h->side);
+    for (int k = 0; k < RES_NBMAX; ++k) {
+        if (h->side[k]) (void)hipStreamDestroy(h->side[k]);
+        if (h->ev_out[k]) (void)hipEventDestroy(h->ev_out[k]);
+    }
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
-    if (h->ev_out) (void)hipEventDestroy(h->ev_out);
     if (h->d_res) (void)hipFree(h->d_res);
     if (h->d_adam) (void)hipFree(h->d_adam);
     if (h->d_big) (void)hipFree(h->d_big);
@@ -387,14 +419,13 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
     float* lossp = hy->record_loss ? loss : nullptr;
     if (hy->record_loss && !loss) return fail("record_loss set but loss buffer is null");
     Params p = make_params(h, hy, A, X, yhat, M, Abar, lossp, workspace);
-    // hybrid split: single-tile targets -> on-chip-resident kernel on the side stream (overlaps with the
+    // hybrid split: small targets (<= res_nbmax row blocks) -> on-chip-resident kernels on side streams (overlap with the
     // streaming launches of the other targets); loss logging is a streaming-path feature
     const bool resident = hy->use_resident && h->n_res > 0 && !lossp;
     const Tables tb = (resident && h->n_big > 0) ? tables_big(h) : tables_all(h);
     const bool streaming = !resident || h->n_big > 0;
     if (resident) {
         HIPCK(hipEventRecord(h->ev_in, s));
-        HIPCK(hipStreamWaitEvent(h->side, h->ev_in, 0));
         if (!h->d_adam || std::memcmp(&h->adam_for, hy, sizeof(gnnx_hyper)) != 0) {
             if (h->d_adam) (void)hipFree(h->d_adam);
             h->adam_host.resize(2 * (size_t)hy->num_iters);
@@ -403,8 +434,17 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
             HIPCK(hipMemcpy(h->d_adam, h->adam_host.data(), sizeof(float) * h->adam_host.size(), hipMemcpyHostToDevice));
             h->adam_for = *hy;
         }
-        hipLaunchKernelGGL(k_resident32, dim3(h->n_res), dim3(256), 0, h->side, p, h->d_res, h->d_adam);
-        HIPCK(hipEventRecord(h->ev_out, h->side));
+        for (int nb = RES_NBMAX; nb >= 1; --nb) {  // largest targets first; each group on its own stream
+            if (!h->res_count[nb]) continue;
+            hipStream_t ss = h->side[nb - 1];
+            HIPCK(hipStreamWaitEvent(ss, h->ev_in, 0));
+            const dim3 grid(h->res_count[nb]), block(256);
+            const int32_t* ids = h->d_res + h->res_first[nb];
+            if (nb == 1) hipLaunchKernelGGL(k_resident<1>, grid, block, 0, ss, p, ids, h->d_adam);
+            else if (nb == 2) hipLaunchKernelGGL(k_resident<2>, grid, block, 0, ss, p, ids, h->d_adam);
+            else hipLaunchKernelGGL(k_resident<3>, grid, block, 0, ss, p, ids, h->d_adam);
+            HIPCK(hipEventRecord(h->ev_out[nb - 1], ss));
+        }
     }
     if (streaming) {
         if (!hy->use_graph) {
@@ -434,7 +474,9 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
             HIPCK(hipGraphLaunch(h->gexec, s));
         }
     }
-    if (resident) HIPCK(hipStreamWaitEvent(s, h->ev_out, 0));
+    if (resident)
+        for (int k = 0; k < RES_NBMAX; ++k)
+            if (h->res_count[k + 1]) HIPCK(hipStreamWaitEvent(s, h->ev_out[k], 0));
     if (feat_mask)
         HIPCK(hipMemcpyAsync(feat_mask, p.f[hy->num_iters & 1], sizeof(float) * h->prob.num_targets * FS,
                              hipMemcpyDeviceToDevice, s));

@@ -1,52 +1,77 @@
-// gnnx_resident.hpp — on-chip-resident mask optimisation for single-tile targets (n <= 32), node mode.
+// gnnx_resident.hpp — on-chip-resident mask optimisation for small targets (NB = ld/32 <= 3 row blocks, i.e.
+// n <= 96), node mode.
 //
 // One workgroup (4 waves) per target runs ALL iterations of explainer/explain.py:137-146 in one launch:
-//   * the edge mask M and its Adam moments live in registers (thread (i, c4) owns entries (i, c4..c4+3)),
-//   * the masked adjacency, the input features and every intermediate of the 3-layer GCN forward/backward
-//     (Zraw, U1, U2, dZ2, dZ1, row norms, head vectors) live in LDS,
-//   * the contractions Abar.X run on v_mfma_f32_32x32x2_f32 with both operands read from LDS
-//     (K = 32 split over the 4 waves, partial tiles reduced through LDS),
+//   * the edge mask M and its Adam moments live in registers: for every tile pair {(I,J),(J,I)}, I <= J, thread
+//     (i, c4) owns the entries (I0+i, J0+c4..+3) and, off the diagonal, their mirror entries (J0+c4.., I0+i) - the
+//     ownership rule of the streaming k_mask, so the output is bitwise symmetric and deterministic;
+//   * the masked adjacency (upper tiles), the input features and every intermediate of the 3-layer GCN
+//     forward/backward (Zraw, U1, U2, dZ2, dZ1, row norms, head vectors) live in LDS;
+//   * the contractions Abar.X run on v_mfma_f32_32x32x2_f32 with BOTH operands read from LDS (per 32-row block:
+//     K = 32 NB split over the 4 waves, partial tiles reduced through LDS);
 //   * phases are separated by __syncthreads() instead of kernel boundaries; HBM is touched only to load the
 //     target at the start and to store M, Abar and the feature mask at the end.
-// Same mathematics, same algebraic shortcuts and same per-entry ownership rules as the streaming kernels of
+// Same mathematics, same algebraic shortcuts and same per-entry ownership as the streaming kernels of
 // gnnx_kernels.hpp; the streaming path remains the general one (any n, graph mode, loss logging).
 #pragma once
 #include "gnnx_kernels.hpp"
 
 namespace gnnx {
 
-constexpr int RES_CMAX = 8;
+constexpr int RES_CMAX = 8;   // classes the resident path takes
+constexpr int RES_NBMAX = 3;  // row blocks the resident path takes (LDS: ~145 KB of the CU's 160 KB at NB = 3)
 
+__host__ __device__ constexpr int res_pairs(int nb) { return nb * (nb + 1) / 2; }
+// index of the upper tile (I <= J) in the order (0,0) (0,1) .. (0,NB-1) (1,1) ..
+__host__ __device__ constexpr int res_pair_index(int nb, int I, int J) { return I * nb - I * (I - 1) / 2 + (J - I); }
+
+template <int NB>
 struct ResidentShared {
-    float sA[TILE * 33];     // masked adjacency (symmetric), [i][j]
-    float sX[TILE * 33];     // input features
-    float sZraw[TILE * 33];  // Abar . X
-    float sU1[TILE * 33], sU2[TILE * 33];
-    float sdZ2[TILE * 33], sdZ1[TILE * 33];
-    float wl[3][32 * 33];    // layer weights W1, W2, W3
+    static constexpr int LD = NB * TILE;
+    float sA[res_pairs(NB)][TILE * 33];  // masked adjacency, upper tiles [I<=J][i][j] (the matrix is symmetric)
+    float sX[LD * 33];                   // input features
+    float sZraw[LD * 33];                // Abar . X
+    float sU1[LD * 33], sU2[LD * 33];
+    float sdZ2[LD * 33], sdZ1[LD * 33];
+    float wl[3][32 * 33];      // layer weights W1, W2, W3
     float red[4 * TILE * 33];  // split-K partial tiles / partial G tiles
     float zs[TILE * 33];
-    float sS[TILE * 33];     // sigma exchange
-    float sWp[RES_CMAX * 96];  // prediction head rows (the resident path takes C <= RES_CMAX)
+    float sS[TILE * 33];       // sigma exchange on diagonal tiles
+    float sWp[RES_CMAX * 96];  // prediction head rows
     float sbp[CMAX];
-    float rn1[TILE], rn2[TILE], yhat[TILE], g3[TILE], arow[TILE];
+    float rn1[LD], rn2[LD], yhat[LD], g3[LD];
     float phi[32], fcur[32], mf[32], vf[32], bias[3][32];
-    float z3[32], y3[32], dz3[32], e[96], g[CMAX], dEs[96], dfp[32];
+    float z3[32], y3[32], dz3[32], e[96], g[CMAX], dEs[96], dfp[32], col32[32];
     float sr3;
 };
 
-// split-K contraction of the resident tile: Z = Abar . B for the 32 rows, B given by a functor of (k, column).
-template <class BFn>
-__device__ __forceinline__ void resident_contract(ResidentShared& sh, BFn bval, float (&z4)[4]) {
+// element (r, c) of the symmetric masked adjacency from its upper tiles
+template <int NB>
+__device__ __forceinline__ float res_abar(const ResidentShared<NB>& sh, int r, int c) {
+    const int rb = r >> 5, cb = c >> 5;
+    return (rb <= cb) ? sh.sA[res_pair_index(NB, rb, cb)][(r & 31) * 33 + (c & 31)]
+                      : sh.sA[res_pair_index(NB, cb, rb)][(c & 31) * 33 + (r & 31)];
+}
+
+// split-K contraction for the 32 rows of block I: Z = Abar[I-block, :] . B, B given by a functor of (row k, column).
+template <int NB, class BFn>
+__device__ __forceinline__ void resident_contract(ResidentShared<NB>& sh, int I, BFn bval, float (&z4)[4]) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int row = tid >> 3, cg = (tid & 7) * 4;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {  // wave w owns k in [8w, 8w+8): 4 MFMA steps of 2 k values
-        const int k = 8 * wave + 2 * u + h;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sh.sA[li * 33 + k], bval(k, li), acc, 0, 0, 0);
+    for (int J = 0; J < NB; ++J) {
+        // A operand A[rho = li][kappa = k] = Abar[I0+li][J0+k]: the stored tile if I <= J, its transpose otherwise
+        const bool upper = I <= J;
+        const float* T = sh.sA[upper ? res_pair_index(NB, I, J) : res_pair_index(NB, J, I)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // wave w owns k in [8w, 8w+8) of every tile: 4 MFMA steps of 2 k values
+            const int k = 8 * wave + 2 * u + h;
+            const float a = upper ? T[li * 33 + k] : T[k * 33 + li];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bval(J * TILE + k, li), acc, 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) sh.red[(wave * TILE + acc_row(r, h)) * 33 + li] = acc[r];
@@ -57,10 +82,12 @@ __device__ __forceinline__ void resident_contract(ResidentShared& sh, BFn bval, 
                 (sh.red[(2 * TILE + row) * 33 + cg + j] + sh.red[(3 * TILE + row) * 33 + cg + j]);
 }
 
-// forward row-local epilogue: Y = Z W + b, U = Y / max(|Y|, 1e-12); returns this thread's 4 outputs
-__device__ __forceinline__ void resident_fwd_epilogue(ResidentShared& sh, const float (&z4)[4], int layer, int din, int dout,
-                                                      float* sU, float* srn, float (&u4)[4]) {
+// forward row-local epilogue for the rows of block I: Y = Z W + b, U = Y / max(|Y|, 1e-12)
+template <int NB>
+__device__ __forceinline__ void resident_fwd_epilogue(ResidentShared<NB>& sh, const float (&z4)[4], int I, int layer, int din,
+                                                      int dout, float* sU, float* srn) {
     const int tid = threadIdx.x, row = tid >> 3, cg = (tid & 7) * 4;
+    const int gr = I * TILE + row;
 #pragma unroll
     for (int j = 0; j < 4; ++j) sh.zs[row * 33 + cg + j] = z4[j];
     __syncthreads();
@@ -82,15 +109,13 @@ __device__ __forceinline__ void resident_fwd_epilogue(ResidentShared& sh, const 
     ss += __shfl_xor(ss, 4);
     const float rnorm = fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        u4[j] = y[j] / rnorm;
-        sU[row * 33 + cg + j] = u4[j];
-    }
-    if ((tid & 7) == 0) srn[row] = rnorm;
+    for (int j = 0; j < 4; ++j) sU[gr * 33 + cg + j] = y[j] / rnorm;
+    if ((tid & 7) == 0) srn[gr] = rnorm;
 }
 
-// sum over the 32 rows of a per-thread 4-vector (thread (row, cg)): result in sh.red[0..31] after the call
-__device__ __forceinline__ void resident_colsum(ResidentShared& sh, float (&part)[4], float* out32) {
+// sum over the 32 rows the workgroup is working on of a per-thread 4-vector (thread (row, cg)) -> sh.col32[0..31]
+template <int NB>
+__device__ __forceinline__ void resident_colsum(ResidentShared<NB>& sh, float (&part)[4]) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cg = (tid & 7) * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -104,57 +129,85 @@ __device__ __forceinline__ void resident_colsum(ResidentShared& sh, float (&part
         for (int j = 0; j < 4; ++j) sh.red[wave * 32 + cg + j] = part[j];
     }
     __syncthreads();
-    if (tid < 32) out32[tid] = sh.red[tid] + sh.red[32 + tid] + sh.red[64 + tid] + sh.red[96 + tid];
+    if (tid < 32) sh.col32[tid] = sh.red[tid] + sh.red[32 + tid] + sh.red[64 + tid] + sh.red[96 + tid];
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_resident32(Params p, const int32_t* targets, const float* adam_tab) {
-    __shared__ ResidentShared sh;
+template <int NB>
+__global__ __launch_bounds__(256) void k_resident(Params p, const int32_t* targets, const float* adam_tab) {
+    constexpr int P = res_pairs(NB);
+    constexpr int LD = NB * TILE;
+    __shared__ ResidentShared<NB> sh;
     const int t = targets[blockIdx.x];
     const TargetMeta tm = p.meta[t];
-    const int n = tm.n, tr = tm.t;  // ld == 32
+    const int n = tm.n, tr = tm.t;  // tm.ld == LD
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int i = tid >> 3, c4 = (tid & 7) * 4;
-    const size_t own = tm.offQ + (size_t)i * TILE + c4;
 
-    // ---- load the target once ----
-    f32x4 M4 = *reinterpret_cast<const f32x4*>(p.M + own);
-    const f32x4 A4 = *reinterpret_cast<const f32x4*>(p.A + own);
-    f32x4 m4 = {0.0f, 0.0f, 0.0f, 0.0f}, v4 = m4;
-    {
-        const f32x4 x4 = *reinterpret_cast<const f32x4*>(p.X + (tm.offR + i) * FS + c4);
+    // ---- load the target once: own entries (I0+i, J0+c4..) and mirror entries (J0+c4.., I0+i) of every tile pair ----
+    f32x4 Mo[P], mo[P], vo[P], Ao[P], Mp[P], mp[P], vp[P];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sh.sX[i * 33 + c4 + e] = x4[e];
-        for (int l = 0; l < 3; ++l)
-            for (int e = tid; e < 1024; e += 256) sh.wl[l][(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + l * 1024 + e];
-        if (tid < 96) sh.bias[tid >> 5][tid & 31] = p.wts[WT_B + tid];
-        for (int e = tid; e < p.C * 96; e += 256) sh.sWp[e] = p.wts[WT_WP + e];
-        if (tid < CMAX) sh.sbp[tid] = p.wts[WT_BP + tid];
-        if (tid < 32) {
-            sh.yhat[tid] = p.yhat[tm.offR + tid];
-            sh.fcur[tid] = 0.0f;  // construct_feat_mask: constant 0 (explain.py:639-641)
-            sh.mf[tid] = 0.0f;
-            sh.vf[tid] = 0.0f;
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = I; J < NB; ++J) {
+            const int pi = res_pair_index(NB, I, J);
+            const size_t own = tm.offQ + (size_t)(I * TILE + i) * LD + J * TILE + c4;
+            Mo[pi] = *reinterpret_cast<const f32x4*>(p.M + own);
+            Ao[pi] = *reinterpret_cast<const f32x4*>(p.A + own);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mo[pi][e] = 0.0f;
+                vo[pi][e] = 0.0f;
+                mp[pi][e] = 0.0f;
+                vp[pi][e] = 0.0f;
+                Mp[pi][e] = (I != J) ? p.M[tm.offQ + (size_t)(J * TILE + c4 + e) * LD + I * TILE + i] : 0.0f;
+            }
         }
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(p.X + (tm.offR + I * TILE + i) * FS + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sh.sX[(I * TILE + i) * 33 + c4 + e] = x4[e];
+    }
+    for (int l = 0; l < 3; ++l)
+        for (int e = tid; e < 1024; e += 256) sh.wl[l][(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + l * 1024 + e];
+    if (tid < 96) sh.bias[tid >> 5][tid & 31] = p.wts[WT_B + tid];
+    for (int e = tid; e < p.C * 96; e += 256) sh.sWp[e] = p.wts[WT_WP + e];
+    if (tid < CMAX) sh.sbp[tid] = p.wts[WT_BP + tid];
+    if (tid < LD) sh.yhat[tid] = p.yhat[tm.offR + tid];
+    if (tid < 32) {
+        sh.fcur[tid] = 0.0f;  // construct_feat_mask: constant 0 (explain.py:639-641)
+        sh.mf[tid] = 0.0f;
+        sh.vf[tid] = 0.0f;
     }
     const float inv_n2 = 1.0f / ((float)n * (float)n);
-    const float yi = p.yhat[tm.offR + i];
-    const f32x4 yj4 = *reinterpret_cast<const f32x4*>(p.yhat + tm.offR + c4);
 
-    // sigma(M) -> symmetrised masked adjacency in LDS (also used after every update)
+    // sigma(M) -> symmetrised masked adjacency tiles in LDS (at the start and after every update)
     auto publish_abar = [&]() {
-        f32x4 S;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            S[e] = sigmoidf_(M4[e]);
-            sh.sS[i * 33 + c4 + e] = S[e];
-        }
-        __syncthreads();
+        for (int I = 0; I < NB; ++I)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int j = c4 + e;
-            sh.sA[i * 33 + j] = (i != j) ? A4[e] * (0.5f * (S[e] + sh.sS[j * 33 + i])) : 0.0f;
-        }
+            for (int J = I; J < NB; ++J) {
+                const int pi = res_pair_index(NB, I, J);
+                f32x4 S;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S[e] = sigmoidf_(Mo[pi][e]);
+                if (I == J) {  // diagonal tile: the mirror entry belongs to another thread -> exchange sigma through LDS
+                    if (I > 0) __syncthreads();  // the previous diagonal tile's sigmas have been consumed
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sh.sS[i * 33 + c4 + e] = S[e];
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int j = c4 + e;
+                        sh.sA[pi][i * 33 + j] = (i != j) ? Ao[pi][e] * (0.5f * (S[e] + sh.sS[j * 33 + i])) : 0.0f;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        sh.sA[pi][i * 33 + c4 + e] = Ao[pi][e] * (0.5f * (S[e] + sigmoidf_(Mp[pi][e])));
+                }
+            }
         __syncthreads();
     };
     publish_abar();
@@ -162,29 +215,46 @@ __global__ __launch_bounds__(256) void k_resident32(Params p, const int32_t* tar
     for (int iter = 0; iter < p.num_iters; ++iter) {
         // Adam scalars: the same host-computed values (double, then float) the streaming kernels receive as
         // arguments: adam_tab[2k] = lr / (1 - beta1^(k+1)), adam_tab[2k+1] = sqrt(1 - beta2^(k+1))
-        if (tid < 32) sh.phi[tid] = (tid < p.D) ? sigmoidf_(sh.fcur[tid]) : 0.0f;
+        if (tid < 32) {
+            sh.phi[tid] = (tid < p.D) ? sigmoidf_(sh.fcur[tid]) : 0.0f;
+            sh.z3[tid] = 0.0f;
+            sh.dfp[tid] = 0.0f;
+        }
         __syncthreads();
         const float step_size = adam_tab[2 * iter], inv_bc2s = 1.0f / adam_tab[2 * iter + 1];
 
+        float z4[4];
         // ---- layer 1: Zraw = Abar . X ; U1 ----
-        float z4[4], u4[4];
-        resident_contract(sh, [&](int k, int c) { return sh.sX[k * 33 + c]; }, z4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            sh.sZraw[i * 33 + c4 + j] = z4[j];
-            z4[j] *= sh.phi[c4 + j];
+        for (int I = 0; I < NB; ++I) {
+            resident_contract<NB>(sh, I, [&](int k, int c) { return sh.sX[k * 33 + c]; }, z4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sh.sZraw[(I * TILE + i) * 33 + c4 + j] = z4[j];
+                z4[j] *= sh.phi[c4 + j];
+            }
+            resident_fwd_epilogue<NB>(sh, z4, I, 0, p.D, p.H, sh.sU1, sh.rn1);
+            __syncthreads();
         }
-        resident_fwd_epilogue(sh, z4, 0, p.D, p.H, sh.sU1, sh.rn1, u4);
-        __syncthreads();
-        // ---- layer 2: U2, and row t of Abar . relu(U2) ----
-        resident_contract(sh, [&](int k, int c) { return fmaxf(sh.sU1[k * 33 + c], 0.0f); }, z4);
-        resident_fwd_epilogue(sh, z4, 1, p.H, p.H, sh.sU2, sh.rn2, u4);
-        {
+        // ---- layer 2: U2 ----
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            resident_contract<NB>(sh, I, [&](int k, int c) { return fmaxf(sh.sU1[k * 33 + c], 0.0f); }, z4);
+            resident_fwd_epilogue<NB>(sh, z4, I, 1, p.H, p.H, sh.sU2, sh.rn2);
+            __syncthreads();
+        }
+        // ---- row t of Abar . relu(U2) (the only row of layer 3 the reference reads, explain.py:713) ----
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            const int gr = I * TILE + i;
+            const float atr = res_abar<NB>(sh, tr, gr);
             float part[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) part[j] = sh.sA[tr * 33 + i] * fmaxf(u4[j], 0.0f);
-            resident_colsum(sh, part, sh.z3);
+            for (int j = 0; j < 4; ++j) part[j] = atr * fmaxf(sh.sU2[gr * 33 + c4 + j], 0.0f);
+            resident_colsum<NB>(sh, part);
+            if (tid < 32) sh.z3[tid] += sh.col32[tid];
         }
+        __syncthreads();
         // ---- layer 3 (row t only), head, dE, dZ3[t] ----
         if (tid < 64) {
             const int c = tid & 31;
@@ -250,104 +320,130 @@ __global__ __launch_bounds__(256) void k_resident32(Params p, const int32_t* tar
         __syncthreads();
         if (tid < 32) {
             float v = 0.0f;
-            if (tid < p.H)
+            if (tid < p.H) {
 #pragma unroll 4
                 for (int c = 0; c < p.O; ++c) v = fmaf(sh.zs[c], sh.wl[2][tid * 33 + c], v);
+            }
             sh.dz3[tid] = v;
         }
         __syncthreads();
-        // ---- dZ2 (rank-1: dX2[i] = Abar[i][t] dZ3[t] + dE2 on row t) and g3 ----
-        {
-            const float ait = sh.sA[tr * 33 + i];
+        // ---- dZ2 (rank-1: dX2[r] = Abar[r][t] dZ3[t] + dE2 on row t) and g3 ----
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            const int gr = I * TILE + i;
+            const float ait = res_abar<NB>(sh, tr, gr);
             float du[4], u[4], dz[4];
             float gpart = 0.0f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = c4 + j;
-                u[j] = sh.sU2[i * 33 + c];
+                u[j] = sh.sU2[gr * 33 + c];
                 gpart = fmaf(sh.dz3[c], fmaxf(u[j], 0.0f), gpart);
                 float dx = ait * sh.dz3[c];
-                if (i == tr) dx += sh.dEs[32 + c];
+                if (gr == tr) dx += sh.dEs[32 + c];
                 dx = (u[j] > 0.0f) ? dx : 0.0f;
                 du[j] = (c < p.H) ? dx : 0.0f;
             }
             gpart += __shfl_xor(gpart, 1);
             gpart += __shfl_xor(gpart, 2);
             gpart += __shfl_xor(gpart, 4);
-            if ((tid & 7) == 0) sh.g3[i] = (i < n) ? gpart : 0.0f;
-            rowlocal_backward(du, u, sh.rn2[i], p.H, i, c4, sh.zs, sh.wl[1], dz);
+            if ((tid & 7) == 0) sh.g3[gr] = (gr < n) ? gpart : 0.0f;
+            rowlocal_backward(du, u, sh.rn2[gr], p.H, i, c4, sh.zs, sh.wl[1], dz);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sh.sdZ2[i * 33 + c4 + j] = (c4 + j < p.H) ? dz[j] : 0.0f;
+            for (int j = 0; j < 4; ++j) sh.sdZ2[gr * 33 + c4 + j] = (c4 + j < p.H) ? dz[j] : 0.0f;
         }
         __syncthreads();
         // ---- dX1 = Abar . dZ2 (+ dE1 on row t) -> dZ1 ; feature-mask gradient ----
-        resident_contract(sh, [&](int k, int c) { return sh.sdZ2[k * 33 + c]; }, z4);
-        {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            const int gr = I * TILE + i;
+            resident_contract<NB>(sh, I, [&](int k, int c) { return sh.sdZ2[k * 33 + c]; }, z4);
             float du[4], u[4], dz[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = c4 + j;
-                u[j] = sh.sU1[i * 33 + c];
+                u[j] = sh.sU1[gr * 33 + c];
                 float dx = z4[j];
-                if (i == tr && c < p.H) dx += sh.dEs[c];
+                if (gr == tr && c < p.H) dx += sh.dEs[c];
                 dx = (u[j] > 0.0f) ? dx : 0.0f;
                 du[j] = (c < p.H) ? dx : 0.0f;
             }
-            rowlocal_backward(du, u, sh.rn1[i], p.H, i, c4, sh.zs, sh.wl[0], dz);
+            rowlocal_backward(du, u, sh.rn1[gr], p.H, i, c4, sh.zs, sh.wl[0], dz);
             float part[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 dz[j] = (c4 + j < p.D) ? dz[j] : 0.0f;
-                sh.sdZ1[i * 33 + c4 + j] = dz[j];
-                part[j] = dz[j] * sh.sZraw[i * 33 + c4 + j];
+                sh.sdZ1[gr * 33 + c4 + j] = dz[j];
+                part[j] = dz[j] * sh.sZraw[gr * 33 + c4 + j];
             }
-            resident_colsum(sh, part, sh.dfp);
-        }
-        // ---- G tile = dL/dAbar (+ transpose) on MFMA, K = D + H split over the waves; layer 3 is the rank-2 g3 term
-        {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int s = wave + 4 * u;  // k-step (columns 2s, 2s+1)
-                const int k = 2 * s + h;
-                if (2 * s < p.D) {
-                    const float z = sh.sdZ1[li * 33 + k];
-                    const float x = sh.sX[li * 33 + k] * sh.phi[k];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z, x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, z, acc, 0, 0, 0);
-                }
-                if (2 * s < p.H) {
-                    const float z = sh.sdZ2[li * 33 + k];
-                    const float x = fmaxf(sh.sU1[li * 33 + k], 0.0f);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z, x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, z, acc, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sh.red[(wave * TILE + acc_row(r, h)) * 33 + li] = acc[r];
+            resident_colsum<NB>(sh, part);
+            if (tid < 32) sh.dfp[tid] += sh.col32[tid];
         }
         __syncthreads();
-        // ---- gradient + Adam on the register-resident mask ----
+        // ---- per tile pair: G = dL/dAbar (+ transpose) on MFMA (K = D + H split over the waves; layer 3 is the
+        //      rank-2 g3 term), then the gradient and Adam on the register-resident entries ----
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int j = c4 + e;
-            float Gsum = (sh.red[(0 * TILE + i) * 33 + j] + sh.red[(1 * TILE + i) * 33 + j]) +
-                         (sh.red[(2 * TILE + i) * 33 + j] + sh.red[(3 * TILE + i) * 33 + j]);
-            Gsum += (i == tr) ? sh.g3[j] : 0.0f;
-            Gsum += (j == tr) ? sh.g3[i] : 0.0f;
-            const float dy = yi - yj4[e];
-            const float Gs = 0.5f * Gsum + p.c_lap * 0.5f * dy * dy * inv_n2;
-            const float gc = (i != j) ? Gs * A4[e] : 0.0f;
-            const float S = sigmoidf_(M4[e]);
-            const float gij = (gc + p.c_size - p.c_ent * M4[e] * inv_n2) * S * (1.0f - S);
-            float Mn = M4[e], mn = m4[e], vn = v4[e];
-            adam_update(Mn, mn, vn, gij, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
-            M4[e] = Mn;
-            m4[e] = mn;
-            v4[e] = vn;
-        }
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int J = I; J < NB; ++J) {
+                const int pi = res_pair_index(NB, I, J);
+                const int I0 = I * TILE, J0 = J * TILE;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int s = wave + 4 * u;  // k-step (columns 2s, 2s+1)
+                    const int k = 2 * s + h;
+                    if (2 * s < p.D) {
+                        const float zi = sh.sdZ1[(I0 + li) * 33 + k], zj = sh.sdZ1[(J0 + li) * 33 + k];
+                        const float xi = sh.sX[(I0 + li) * 33 + k] * sh.phi[k], xj = sh.sX[(J0 + li) * 33 + k] * sh.phi[k];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zi, xj, acc, 0, 0, 0);  // G[i][j]
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xi, zj, acc, 0, 0, 0);  // G[j][i]
+                    }
+                    if (2 * s < p.H) {
+                        const float zi = sh.sdZ2[(I0 + li) * 33 + k], zj = sh.sdZ2[(J0 + li) * 33 + k];
+                        const float xi = fmaxf(sh.sU1[(I0 + li) * 33 + k], 0.0f), xj = fmaxf(sh.sU1[(J0 + li) * 33 + k], 0.0f);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zi, xj, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xi, zj, acc, 0, 0, 0);
+                    }
+                }
+                if (pi > 0) __syncthreads();  // the previous pair's partial sums have been read
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sh.red[(wave * TILE + acc_row(r, h)) * 33 + li] = acc[r];
+                __syncthreads();
+                const int gi = I0 + i;
+                const float yi = sh.yhat[gi], g3i = sh.g3[gi];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = c4 + e, gj = J0 + j;
+                    float Gsum = (sh.red[(0 * TILE + i) * 33 + j] + sh.red[(1 * TILE + i) * 33 + j]) +
+                                 (sh.red[(2 * TILE + i) * 33 + j] + sh.red[(3 * TILE + i) * 33 + j]);
+                    Gsum += (gi == tr) ? sh.g3[gj] : 0.0f;
+                    Gsum += (gj == tr) ? g3i : 0.0f;
+                    const float dy = yi - sh.yhat[gj];
+                    const float Gs = 0.5f * Gsum + p.c_lap * 0.5f * dy * dy * inv_n2;
+                    const float gc = (gi != gj) ? Gs * Ao[pi][e] : 0.0f;
+                    {
+                        const float S = sigmoidf_(Mo[pi][e]);
+                        const float gij = (gc + p.c_size - p.c_ent * Mo[pi][e] * inv_n2) * S * (1.0f - S);
+                        float Mn = Mo[pi][e], mn = mo[pi][e], vn = vo[pi][e];
+                        adam_update(Mn, mn, vn, gij, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+                        Mo[pi][e] = Mn;
+                        mo[pi][e] = mn;
+                        vo[pi][e] = vn;
+                    }
+                    if (I != J) {  // the mirror entry (gj, gi) belongs to this thread too
+                        const float S = sigmoidf_(Mp[pi][e]);
+                        const float gji = (gc + p.c_size - p.c_ent * Mp[pi][e] * inv_n2) * S * (1.0f - S);
+                        float Mn = Mp[pi][e], mn = mp[pi][e], vn = vp[pi][e];
+                        adam_update(Mn, mn, vn, gji, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+                        Mp[pi][e] = Mn;
+                        mp[pi][e] = mn;
+                        vp[pi][e] = vn;
+                    }
+                }
+            }
         if (tid < p.D) {  // feature mask
             const float ph = sh.phi[tid];
             const float gf = (sh.dfp[tid] + p.c_feat_size / (float)p.D) * ph * (1.0f - ph);
@@ -360,12 +456,29 @@ __global__ __launch_bounds__(256) void k_resident32(Params p, const int32_t* tar
         __syncthreads();
         if (iter + 1 < p.num_iters) publish_abar();  // the returned mask is the one of the LAST forward (explain.py:209-211)
     }
-    // ---- store the results ----
-    *reinterpret_cast<f32x4*>(p.M + own) = M4;
-    f32x4 ab;
+    // ---- store the results: M (own + mirror entries), Abar of the last forward (both orientations), feature mask ----
 #pragma unroll
-    for (int e = 0; e < 4; ++e) ab[e] = sh.sA[i * 33 + c4 + e];
-    *reinterpret_cast<f32x4*>(p.Abar + own) = ab;
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = I; J < NB; ++J) {
+            const int pi = res_pair_index(NB, I, J);
+            const size_t own = tm.offQ + (size_t)(I * TILE + i) * LD + J * TILE + c4;
+            *reinterpret_cast<f32x4*>(p.M + own) = Mo[pi];
+            f32x4 ab;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ab[e] = sh.sA[pi][i * 33 + c4 + e];
+            *reinterpret_cast<f32x4*>(p.Abar + own) = ab;
+            if (I != J) {
+                const size_t mirror_row = tm.offQ + (size_t)(J * TILE + i) * LD + I * TILE + c4;  // row i of tile (J, I)
+                f32x4 abT;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    abT[e] = sh.sA[pi][(c4 + e) * 33 + i];
+                    p.M[tm.offQ + (size_t)(J * TILE + c4 + e) * LD + I * TILE + i] = Mp[pi][e];
+                }
+                *reinterpret_cast<f32x4*>(p.Abar + mirror_row) = abT;
+            }
+        }
     // final feature mask into the slot the streaming path would have used (copied out by the host afterwards)
     if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = (tid < p.D) ? sh.fcur[tid] : 0.0f;
 }

@@ -59,7 +59,7 @@ class Hyper:
     c_lap: float = 1.0
     record_loss: bool = False
     use_graph: bool = False
-    use_resident: bool = True     # on-chip-resident kernel for single-tile (n <= 32) node-mode targets
+    use_resident: bool = True     # on-chip-resident kernels for small (n <= 96) node-mode targets
 
     def c(self):
         return _Hyper(self.lr, self.beta1, self.beta2, self.eps, self.c_size, self.c_feat_size, self.c_ent,

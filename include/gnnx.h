@@ -61,8 +61,11 @@ typedef struct {
     int32_t num_iters;   /* args.num_epochs (explain.py:137) */
     int32_t record_loss; /* 1: fill loss[T][num_iters][GNNX_LOSS_TERMS] (explain.py:808-819 scalars) */
     int32_t use_graph;   /* 1: capture the launch sequence once into a hipGraph and replay it */
-    int32_t use_resident; /* 1: node-mode targets with n <= 32 run in the on-chip-resident kernel (one workgroup per
-                           * target, all iterations in one launch) beside the streaming kernels; ignored with record_loss */
+    int32_t use_resident; /* 1: use the on-chip-resident kernels (one workgroup per target, all iterations in one launch,
+                           * node mode): a batch whose targets all have n <= 96 (3 blocks of 32 rows) runs entirely
+                           * in them; otherwise its n <= 32 targets do, beside the streaming kernels of the others.
+                           * The environment variable GNNX_RESIDENT_MAX_BLOCKS=0..3, read by gnnx_plan_create, lowers
+                           * the block limit.  Ignored with record_loss. */
 } gnnx_hyper;
 
 int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* model, gnnx_handle* out);

@@ -98,7 +98,7 @@ def test_large_target_many_row_blocks():
 
 
 def test_resident_kernel_matches_streaming_and_reference():
-    """Single-tile targets (n <= 32) take the on-chip-resident kernel; an all-resident batch launches no streaming
+    """Small targets (n <= 96; here single-tile ones) take the on-chip-resident kernel; an all-resident batch launches no streaming
     kernel at all.  Both paths must agree with each other and with the reference's golden output."""
     ck, gx = helpers.load_ckpt("syn4"), helpers.load_explain("syn4")
     subs = [_node_case("syn4", t)[2] for t in (511, 870)]
@@ -120,6 +120,21 @@ def test_resident_kernel_full_run_vs_golden():
     rc = gx["302:edge_rc"]
     assert np.abs(res.masked_adj[0][rc[:, 0], rc[:, 1]] - gx["302:masked_adj_edges"]).max() <= 1e-5
     assert np.abs(1 / (1 + np.exp(-res.feat_mask[0])) - gx["302:feat_mask_sigmoid"]).max() <= 1e-5
+
+
+def test_two_block_resident_kernel_vs_streaming_and_golden():
+    """syn1 target 309 (n = 48 -> 2 row blocks: diagonal and off-diagonal tile pairs, mirror entries in registers)
+    through the resident kernel: 300 iterations against the reference's golden mask, and against the streaming path."""
+    ck, gx, sg = _node_case("syn1", 309)
+    res = emu_job([sg], ck["sd"]).run([sg.mask0], Hyper(num_iters=300, use_resident=True))
+    rc = gx["309:edge_rc"]
+    assert np.abs(res.masked_adj[0][rc[:, 0], rc[:, 1]] - gx["309:masked_adj_edges"]).max() <= 1e-5
+    assert np.abs(1 / (1 + np.exp(-res.feat_mask[0])) - gx["309:feat_mask_sigmoid"]).max() <= 1e-5
+    short = emu_job([sg], ck["sd"]).run([sg.mask0], Hyper(num_iters=20, use_resident=True))
+    stream = emu_job([sg], ck["sd"]).run([sg.mask0], Hyper(num_iters=20, use_resident=False))
+    assert np.abs(short.masked_adj[0] - stream.masked_adj[0]).max() < 1e-6
+    assert np.abs(short.mask[0] - stream.mask[0]).max() < 1e-5
+    assert np.array_equal(short.masked_adj[0], short.masked_adj[0].T)
 
 
 def test_device_side_packing_equals_host_packing():
@@ -148,7 +163,10 @@ def test_device_side_packing_equals_host_packing():
     (7, 13, 9, 3, 21, False, True),      # odd widths, resident kernel
     (7, 13, 9, 3, 21, False, False),     # same through the streaming kernels
     (5, 32, 32, 6, 45, False, False),    # full-width hidden layers, two row blocks
+    (5, 32, 32, 6, 45, False, True),     # ... in the two-block resident kernel
     (31, 8, 3, 2, 70, False, False),     # wide input (beyond the 16 columns of the common case), three row blocks
+    (31, 8, 3, 2, 70, False, True),      # ... in the three-block resident kernel
+    (10, 20, 20, 4, 96, False, True),    # largest resident target (no padding rows)
     (14, 20, 20, 2, 40, True, False),    # graph mode
     (3, 9, 17, 9, 33, True, False),      # graph mode, odd widths, more classes than the resident path takes
 ])
