@@ -9,11 +9,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/gnnx.h"
 #include "gnnx_kernels.hpp"
 #include "gnnx_resident.hpp"
+#include "gnnx_sparse.hpp"
 
 using namespace gnnx;
 
@@ -51,8 +53,14 @@ struct gnnx_plan_s {
     int32_t* d_big = nullptr;        // target ids of the streaming set
     ConvTile* d_conv_big = nullptr;
     MaskTile* d_mask_big = nullptr;
-    hipStream_t side[RES_NBMAX] = {};   // the resident kernels (one per nb) run beside the streaming launches
-    hipEvent_t ev_in = nullptr, ev_out[RES_NBMAX] = {};
+    hipStream_t side[RES_NBMAX + 1] = {};   // the resident kernels (dense: one per nb; [RES_NBMAX]: sparse) run beside the streaming launches
+    hipEvent_t ev_in = nullptr, ev_out[RES_NBMAX + 1] = {};
+    std::vector<int> order;          // targets, largest first
+    std::vector<int> cat;            // per target: 0 streaming, 1..RES_NBMAX dense resident kernel of that many row blocks, CAT_SPARSE
+    std::vector<int32_t> nnz;        // per target (directed edge entries, row slots) from gnnx_plan_analyze, empty before
+    int n_sp = 0;                    // targets of the sparse resident kernel
+    int32_t* d_sp = nullptr;
+    int32_t* d_nnz = nullptr;
     float* d_adam = nullptr;         // per-iteration Adam scalars for the resident kernel
     std::vector<float> adam_host;
     gnnx_hyper adam_for{};
@@ -69,6 +77,73 @@ struct gnnx_plan_s {
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+constexpr int CAT_SPARSE = RES_NBMAX + 1;
+
+// (Re)build the hybrid split from h->cat: id lists of the resident kernels, tile tables of the streaming remainder,
+// side streams.  Invalidates a captured graph.
+static int build_split(gnnx_handle h) {
+#define SPLITCK(x)                                                                 \
+    do {                                                                           \
+        hipError_t e_ = (x);                                                       \
+        if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+    if (h->gexec) {
+        (void)hipGraphExecDestroy(h->gexec);
+        h->gexec = nullptr;
+    }
+    for (void* ptr : {(void*)h->d_res, (void*)h->d_sp, (void*)h->d_big, (void*)h->d_conv_big, (void*)h->d_mask_big})
+        if (ptr) (void)hipFree(ptr);
+    h->d_res = h->d_sp = h->d_big = nullptr;
+    h->d_conv_big = nullptr;
+    h->d_mask_big = nullptr;
+    std::vector<ConvTile> conv_big;
+    std::vector<MaskTile> mask_big;
+    std::vector<int32_t> res_ids, sp_ids, big_ids;
+    for (int k = 0; k <= RES_NBMAX; ++k) h->res_count[k] = h->res_first[k] = 0;
+    for (int t : h->order) {  // sorted by ld: the dense resident groups are contiguous
+        const int nb = h->meta[t].ld / TILE, c = h->cat[t];
+        if (c == CAT_SPARSE) {
+            sp_ids.push_back(t);
+        } else if (c >= 1) {
+            if (h->res_count[nb]++ == 0) h->res_first[nb] = (int)res_ids.size();
+            res_ids.push_back(t);
+        } else {
+            big_ids.push_back(t);
+            for (int rb = 0; rb < nb; ++rb) conv_big.push_back({t, rb, h->meta[t]});
+            for (int I = 0; I < nb; ++I)
+                for (int J = I; J < nb; ++J) mask_big.push_back({t, I, J, 0, h->meta[t]});
+        }
+    }
+    h->n_res = (int)res_ids.size();
+    h->n_sp = (int)sp_ids.size();
+    h->n_big = (int)big_ids.size();
+    h->n_conv_big = (int)conv_big.size();
+    h->n_mask_big = (int)mask_big.size();
+    auto upload = [&](auto*& dst, const auto& v) -> hipError_t {
+        using E = typename std::remove_reference<decltype(v)>::type::value_type;
+        if (v.empty()) return hipSuccess;
+        hipError_t e = hipMalloc(&dst, sizeof(E) * v.size());
+        if (e != hipSuccess) return e;
+        return hipMemcpy(dst, v.data(), sizeof(E) * v.size(), hipMemcpyHostToDevice);
+    };
+    SPLITCK(upload(h->d_res, res_ids));
+    SPLITCK(upload(h->d_sp, sp_ids));
+    if ((h->n_res || h->n_sp) && h->n_big) {
+        SPLITCK(upload(h->d_big, big_ids));
+        SPLITCK(upload(h->d_conv_big, conv_big));
+        SPLITCK(upload(h->d_mask_big, mask_big));
+    }
+    if ((h->n_res || h->n_sp) && !h->ev_in) SPLITCK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+    for (int k = 0; k <= RES_NBMAX; ++k) {
+        const bool need = k < RES_NBMAX ? h->res_count[k + 1] > 0 : h->n_sp > 0;
+        if (need && !h->side[k]) {
+            SPLITCK(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
+            SPLITCK(hipEventCreateWithFlags(&h->ev_out[k], hipEventDisableTiming));
+        }
+    }
+#undef SPLITCK
+    return 0;
+}
 
 extern "C" const char* gnnx_last_error(void) { return g_err.c_str(); }
 extern "C" const char* gnnx_version(void) { return "gnnx-hip 0.1 (gfx950, mfma_f32_32x32x2f32)"; }
@@ -83,9 +158,8 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
     h->prob = *prob;
     const int T = prob->num_targets;
     h->meta.resize(T);
-    std::vector<ConvTile> conv, conv_big;
-    std::vector<MaskTile> mask, mask_big;
-    std::vector<int32_t> res_ids, big_ids;
+    std::vector<ConvTile> conv;
+    std::vector<MaskTile> mask;
     for (int t = 0; t < T; ++t) {
         const int n = prob->n[t];
         if (n < 1) {
@@ -112,45 +186,33 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
         h->sum_n2 += (double)n * n;
     }
     // tile tables, largest targets first so the long poles start early
-    std::vector<int> order(T);
-    for (int t = 0; t < T; ++t) order[t] = t;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h->meta[a].ld > h->meta[b].ld; });
+    h->order.resize(T);
+    for (int t = 0; t < T; ++t) h->order[t] = t;
+    std::stable_sort(h->order.begin(), h->order.end(), [&](int a, int b) { return h->meta[a].ld > h->meta[b].ld; });
     const bool resident_ok = !prob->graph_mode && prob->C <= RES_CMAX;
     if (const char* env = std::getenv("GNNX_RESIDENT_MAX_BLOCKS")) {  // tuning knob, see include/gnnx.h
         const int v = std::atoi(env);
         h->res_nbmax = v < 0 ? 0 : (v > RES_NBMAX ? RES_NBMAX : v);
     }
-    // A batch whose targets ALL fit runs entirely on chip (no streaming launch at all).  Otherwise only the
-    // single-tile targets ride beside the streaming chain of the larger ones: measured on syn1 (400 targets, 72 of
-    // them with >= 4 row blocks), moving the 2- and 3-block targets beside the chain as well made the batch slower
-    // (22.2 -> 24-38 ms: their workgroups hold whole CUs for the full run and add hardware queues), while the
-    // streaming chain of the large targets stays the long pole either way.
+    // Default split (before gnnx_plan_analyze has seen the adjacency): a batch whose targets ALL fit the dense
+    // resident kernels runs entirely on chip (no streaming launch at all).  Otherwise only the single-tile targets ride
+    // beside the streaming chain of the larger ones: measured on syn1 (400 targets, 72 of them with >= 4 row blocks),
+    // moving the 2- and 3-block targets beside the chain as well made the batch slower (22.2 -> 24-38 ms: their
+    // workgroups hold whole CUs for the full run and add hardware queues), while the streaming chain of the large
+    // targets stays the long pole either way.
     {
         int max_nb = 0;
         for (int t = 0; t < T; ++t) max_nb = std::max(max_nb, h->meta[t].ld / TILE);
         if (max_nb > h->res_nbmax) h->res_nbmax = std::min(h->res_nbmax, 1);
     }
-    for (int t : order) {
+    h->cat.assign(T, 0);
+    for (int t : h->order) {
         const int nb = h->meta[t].ld / TILE;
-        const bool res = resident_ok && nb <= h->res_nbmax;
-        if (res) {
-            if (h->res_count[nb]++ == 0) h->res_first[nb] = (int)res_ids.size();  // `order` is sorted by ld: groups are contiguous
-        }
-        (res ? res_ids : big_ids).push_back(t);
-        for (int rb = 0; rb < nb; ++rb) {
-            conv.push_back({t, rb, h->meta[t]});
-            if (!res) conv_big.push_back({t, rb, h->meta[t]});
-        }
+        if (resident_ok && nb <= h->res_nbmax) h->cat[t] = nb;
+        for (int rb = 0; rb < nb; ++rb) conv.push_back({t, rb, h->meta[t]});
         for (int I = 0; I < nb; ++I)
-            for (int J = I; J < nb; ++J) {
-                mask.push_back({t, I, J, 0, h->meta[t]});
-                if (!res) mask_big.push_back({t, I, J, 0, h->meta[t]});
-            }
+            for (int J = I; J < nb; ++J) mask.push_back({t, I, J, 0, h->meta[t]});
     }
-    h->n_res = (int)res_ids.size();
-    h->n_big = (int)big_ids.size();
-    h->n_conv_big = (int)conv_big.size();
-    h->n_mask_big = (int)mask_big.size();
     h->n_conv = (int)conv.size();
     h->n_mask = (int)mask.size();
 
@@ -182,34 +244,15 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
     PLANCK(hipMalloc(&h->d_conv, sizeof(ConvTile) * conv.size()));
     PLANCK(hipMalloc(&h->d_mask, sizeof(MaskTile) * mask.size()));
     PLANCK(hipMalloc(&h->d_wts, sizeof(float) * WT_TOTAL));
-    if (h->n_res) {
-        PLANCK(hipMalloc(&h->d_res, sizeof(int32_t) * res_ids.size()));
-        PLANCK(hipMemcpy(h->d_res, res_ids.data(), sizeof(int32_t) * res_ids.size(), hipMemcpyHostToDevice));
-        PLANCK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
-        // side streams at the LOWEST priority: the streaming chain is the long pole of a hybrid batch and must not queue
-        // behind a resident kernel (streams of one priority share a small pool of hardware queues, and packets of
-        // one hardware queue run in order - measured: 22 -> 38 ms on syn1 when the main stream shared a queue)
-        int prio_least = 0, prio_greatest = 0;
-        PLANCK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        for (int k = 0; k < RES_NBMAX; ++k) {
-            if (!h->res_count[k + 1]) continue;
-            PLANCK(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
-            PLANCK(hipEventCreateWithFlags(&h->ev_out[k], hipEventDisableTiming));
-        }
-    }
-    if (h->n_res && h->n_big) {
-        PLANCK(hipMalloc(&h->d_big, sizeof(int32_t) * big_ids.size()));
-        PLANCK(hipMalloc(&h->d_conv_big, sizeof(ConvTile) * conv_big.size()));
-        PLANCK(hipMalloc(&h->d_mask_big, sizeof(MaskTile) * mask_big.size()));
-        PLANCK(hipMemcpy(h->d_big, big_ids.data(), sizeof(int32_t) * big_ids.size(), hipMemcpyHostToDevice));
-        PLANCK(hipMemcpy(h->d_conv_big, conv_big.data(), sizeof(ConvTile) * conv_big.size(), hipMemcpyHostToDevice));
-        PLANCK(hipMemcpy(h->d_mask_big, mask_big.data(), sizeof(MaskTile) * mask_big.size(), hipMemcpyHostToDevice));
-    }
     PLANCK(hipMemcpy(h->d_meta, h->meta.data(), sizeof(TargetMeta) * T, hipMemcpyHostToDevice));
     PLANCK(hipMemcpy(h->d_conv, conv.data(), sizeof(ConvTile) * conv.size(), hipMemcpyHostToDevice));
     PLANCK(hipMemcpy(h->d_mask, mask.data(), sizeof(MaskTile) * mask.size(), hipMemcpyHostToDevice));
     PLANCK(hipMemcpy(h->d_wts, w.data(), sizeof(float) * WT_TOTAL, hipMemcpyHostToDevice));
 #undef PLANCK
+    if (int rc = build_split(h)) {
+        gnnx_destroy(h);
+        return rc;
+    }
 
     // workspace carving
     size_t o = 0;
@@ -249,12 +292,14 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
     if (!h) return 0;
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->d_meta) (void)hipFree(h->d_meta);
-    for (int k = 0; k < RES_NBMAX; ++k) {
+    for (int k = 0; k <= RES_NBMAX; ++k) {
         if (h->side[k]) (void)hipStreamDestroy(h->side[k]);
         if (h->ev_out[k]) (void)hipEventDestroy(h->ev_out[k]);
     }
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->d_res) (void)hipFree(h->d_res);
+    if (h->d_sp) (void)hipFree(h->d_sp);
+    if (h->d_nnz) (void)hipFree(h->d_nnz);
     if (h->d_adam) (void)hipFree(h->d_adam);
     if (h->d_big) (void)hipFree(h->d_big);
     if (h->d_conv_big) (void)hipFree(h->d_conv_big);
@@ -421,7 +466,7 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
     Params p = make_params(h, hy, A, X, yhat, M, Abar, lossp, workspace);
     // hybrid split: small targets (<= res_nbmax row blocks) -> on-chip-resident kernels on side streams (overlap with the
     // streaming launches of the other targets); loss logging is a streaming-path feature
-    const bool resident = hy->use_resident && h->n_res > 0 && !lossp;
+    const bool resident = hy->use_resident && (h->n_res > 0 || h->n_sp > 0) && !lossp;
     const Tables tb = (resident && h->n_big > 0) ? tables_big(h) : tables_all(h);
     const bool streaming = !resident || h->n_big > 0;
     if (resident) {
@@ -433,6 +478,17 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
             HIPCK(hipMalloc(&h->d_adam, sizeof(float) * h->adam_host.size()));
             HIPCK(hipMemcpy(h->d_adam, h->adam_host.data(), sizeof(float) * h->adam_host.size(), hipMemcpyHostToDevice));
             h->adam_for = *hy;
+        }
+        if (h->n_sp) {  // targets whose edge state fits one CU: sparse resident kernel (gnnx_plan_analyze).  Submitted FIRST:
+            // its workgroups need a whole CU's LDS, so they must be placed before the small dense-resident workgroups
+            // spread over every CU (measured on syn1: 21.5 -> see DESIGN.md)
+            hipStream_t ss = h->side[RES_NBMAX];
+            HIPCK(hipStreamWaitEvent(ss, h->ev_in, 0));
+            if (h->prob.D <= 10 && h->prob.H <= 20)  // the reference's encoder (hidden 20, 10 input features)
+                hipLaunchKernelGGL((k_sparse_resident<5, 10>), dim3(h->n_sp), dim3(SP_THREADS), 0, ss, p, h->d_sp, h->d_adam);
+            else
+                hipLaunchKernelGGL((k_sparse_resident<16, 16>), dim3(h->n_sp), dim3(SP_THREADS), 0, ss, p, h->d_sp, h->d_adam);
+            HIPCK(hipEventRecord(h->ev_out[RES_NBMAX], ss));
         }
         for (int nb = RES_NBMAX; nb >= 1; --nb) {  // largest targets first; each group on its own stream
             if (!h->res_count[nb]) continue;
@@ -474,14 +530,46 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
             HIPCK(hipGraphLaunch(h->gexec, s));
         }
     }
-    if (resident)
+    if (resident) {
         for (int k = 0; k < RES_NBMAX; ++k)
             if (h->res_count[k + 1]) HIPCK(hipStreamWaitEvent(s, h->ev_out[k], 0));
+        if (h->n_sp) HIPCK(hipStreamWaitEvent(s, h->ev_out[RES_NBMAX], 0));
+    }
     if (feat_mask)
         HIPCK(hipMemcpyAsync(feat_mask, p.f[hy->num_iters & 1], sizeof(float) * h->prob.num_targets * FS,
                              hipMemcpyDeviceToDevice, s));
     HIPCK(hipGetLastError());
     return 0;
+}
+
+extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
+    if (!h || !A) return fail("null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int T = h->prob.num_targets;
+    if (!h->d_nnz) HIPCK(hipMalloc(&h->d_nnz, sizeof(int32_t) * 2 * T));
+    hipLaunchKernelGGL(k_count_edges, dim3(T), dim3(256), 0, s, h->d_meta, A, h->d_nnz);
+    HIPCK(hipGetLastError());
+    h->nnz.resize(2 * (size_t)T);  // (directed entries, row slots) per target
+    HIPCK(hipMemcpyAsync(h->nnz.data(), h->d_nnz, sizeof(int32_t) * 2 * T, hipMemcpyDeviceToHost, s));
+    HIPCK(hipStreamSynchronize(s));
+    const bool resident_ok = !h->prob.graph_mode && h->prob.C <= RES_CMAX;
+    if (!resident_ok) return 0;
+    int sparse_on = 1;
+    if (const char* env = std::getenv("GNNX_SPARSE_RESIDENT")) sparse_on = std::atoi(env);
+    if (!sparse_on) return 0;
+    // single-tile targets keep the dense resident kernel (two workgroups per CU); every larger target whose edge
+    // state fits one CU's LDS / registers takes the sparse resident kernel; the rest streams
+    bool changed = false;
+    for (int t = 0; t < T; ++t) {
+        const TargetMeta& m = h->meta[t];
+        const int nb = m.ld / TILE;
+        int c = 0;
+        if (nb == 1 && h->res_nbmax >= 1) c = 1;
+        else if (sparse_fits(m.ld, h->nnz[2 * t], h->nnz[2 * t + 1], h->prob.D, h->prob.H, h->prob.C)) c = CAT_SPARSE;
+        changed |= (c != h->cat[t]);
+        h->cat[t] = c;
+    }
+    return changed ? build_split(h) : 0;
 }
 
 extern "C" int gnnx_pack_csr(gnnx_handle h, const int64_t* indptr, const int32_t* indices, const float* weights,

@@ -89,6 +89,7 @@ _API = {
     "gnnx_workspace_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
     "gnnx_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper)] + [ctypes.c_void_p] * 8 +
                  [ctypes.c_size_t, ctypes.c_void_p]),
+    "gnnx_plan_analyze": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "gnnx_pack_csr": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int32] + [ctypes.c_void_p] * 7),
     "gnnx_forward": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_void_p] * 7 + [ctypes.c_size_t, ctypes.c_void_p]),
     "gnnx_time_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper), ctypes.c_int32, ctypes.c_int32] +
@@ -205,7 +206,8 @@ class MaskOptimJob:
     """A batch of targets resident on one GPU: plan + packed device buffers."""
 
     @classmethod
-    def from_csr(cls, graph: DeviceGraph, neighbors: Sequence[np.ndarray], target_rows, gt_labels, state_dict, lib=None):
+    def from_csr(cls, graph: DeviceGraph, neighbors: Sequence[np.ndarray], target_rows, gt_labels, state_dict, lib=None,
+                 analyze=True):
         """Node-mode batch whose sub-graphs are sliced ON THE DEVICE from the CSR graph (gnnx_pack_csr): the host
         only supplies the ascending k-hop neighbour list of every target (explain.py:492-501)."""
         self = cls.__new__(cls)
@@ -233,14 +235,23 @@ class MaskOptimJob:
             self.yhat.data_ptr(), self._stream()))
         self._leave()
         self._keepalive = (nb_flat, nb_off_d, graph)
+        if analyze:
+            self.analyze()
         return self
+
+    def analyze(self):
+        """Let the plan look at the packed adjacency and route every target to the best kernel (gnnx_plan_analyze):
+        the sparse on-chip-resident kernel for targets whose edge state fits one compute unit."""
+        self._enter()
+        _check(self.lib, self.lib.gnnx_plan_analyze(self.handle, self.A.data_ptr(), self._stream()))
+        self._leave()
 
     def adjacency(self):
         """Per-target dense sub-adjacencies as packed on the device (host copies)."""
         A = self.A.cpu().numpy()
         return [v[:n, :n].copy() for v, n in zip(self._square_views(A), self.n)]
 
-    def __init__(self, subgraphs: Sequence[Subgraph], state_dict, graph_mode=False, device=None, lib=None):
+    def __init__(self, subgraphs: Sequence[Subgraph], state_dict, graph_mode=False, device=None, lib=None, analyze=True):
         self.lib = lib if lib is not None else get_library()
         if device is None:
             if not torch.cuda.is_available():
@@ -264,6 +275,8 @@ class MaskOptimJob:
         self._create_plan(rows, labels)
         self._alloc_device()
         self._pack(subgraphs)
+        if analyze and not self.graph_mode:
+            self.analyze()
 
     def _init_model(self, state_dict):
         self.w = model_arrays(state_dict)

@@ -93,6 +93,15 @@ int gnnx_run(gnnx_handle h, const gnnx_hyper* hyper, const float* A, const float
              float* M, float* Abar, float* feat_mask, float* loss, void* workspace, size_t workspace_bytes,
              void* stream);
 
+/* Inspect the packed adjacency A (DEVICE pointer, the layout of gnnx_get_layout) and choose the kernel of every target:
+ * node-mode targets with n <= 32 keep the dense on-chip-resident kernel; larger ones whose EDGE state fits one
+ * compute unit (n <= 384, <= 2048 undirected edges, LDS budget) take the sparse on-chip-resident kernel, which
+ * optimises only the mask entries on edges - the only ones that reach an output of the reference
+ * (explain.py:665-678, 209-211; non-edge entries of M then keep their initial values); the rest streams.
+ * Optional: without this call the plan uses the split described at gnnx_hyper.use_resident.  Synchronises `stream`.
+ * GNNX_SPARSE_RESIDENT=0 in the environment disables the sparse kernel. */
+int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream);
+
 /* Device-side packing of the plan's sub-graphs from the full graph in CSR form (all pointers are DEVICE
  * pointers): replaces the host's dense slicing `adj[nb][:, nb]`, `feat[nb]`, `argmax(pred[nb])` of
  * Explainer.extract_neighborhood / explain (explain.py:492-501, 94-106) for the whole batch.

@@ -20,5 +20,5 @@ def emu_library():
     return _lib
 
 
-def emu_job(subgraphs, state_dict, graph_mode=False):
-    return engine.MaskOptimJob(subgraphs, state_dict, graph_mode=graph_mode, device="cpu", lib=emu_library())
+def emu_job(subgraphs, state_dict, graph_mode=False, analyze=True):
+    return engine.MaskOptimJob(subgraphs, state_dict, graph_mode=graph_mode, device="cpu", lib=emu_library(), analyze=analyze)

@@ -80,6 +80,30 @@ float shfl_f(float v, int src) {
     return g_blk->waves[g_blk->cur >> 6].fa[buf][src & 63];
 }
 
+int shfl_i(int v, int src) {
+    int buf = 0, lane = 0;
+    wave_collective([&](WaveSlot& w, int bf, int ln) { w.ia[bf][ln] = v; buf = bf; lane = ln; });
+    (void)lane;
+    return g_blk->waves[g_blk->cur >> 6].ia[buf][src & 63];
+}
+
+unsigned long long ballot(bool pred) {
+    int buf = 0, lane = 0;
+    wave_collective([&](WaveSlot& w, int bf, int ln) { w.ia[bf][ln] = pred ? 1 : 0; buf = bf; lane = ln; });
+    (void)lane;
+    const WaveSlot& w = g_blk->waves[g_blk->cur >> 6];
+    const int wsize = std::min(64, g_blk->nthreads - (g_blk->cur >> 6) * 64);
+    unsigned long long m = 0;
+    for (int l = 0; l < wsize; ++l)
+        if (w.ia[buf][l]) m |= 1ull << l;
+    return m;
+}
+
+// rendezvous of the lanes of one wave (fibers between collectives are NOT in lockstep, unlike hardware lanes)
+void wave_sync() {
+    wave_collective([&](WaveSlot&, int, int) {});
+}
+
 int shfl_xor_i(int v, int mask) {
     int buf = 0, lane = 0;
     wave_collective([&](WaveSlot& w, int bf, int ln) { w.ia[bf][ln] = v; buf = bf; lane = ln; });

@@ -45,6 +45,9 @@ void syncthreads();
 float shfl_xor_f(float v, int mask);
 int shfl_xor_i(int v, int mask);
 float shfl_f(float v, int src);
+int shfl_i(int v, int src);
+unsigned long long ballot(bool pred);
+void wave_sync();
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 f32x16 mfma_32x32x2(float a, float b, f32x16 c);
 }  // namespace emu
@@ -53,6 +56,12 @@ inline void __syncthreads() { emu::syncthreads(); }
 inline float __shfl_xor(float v, int m) { return emu::shfl_xor_f(v, m); }
 inline int __shfl_xor(int v, int m) { return emu::shfl_xor_i(v, m); }
 inline float __shfl(float v, int src) { return emu::shfl_f(v, src); }
+inline int __shfl(int v, int src) { return emu::shfl_i(v, src); }
+inline unsigned long long __ballot(bool pred) { return emu::ballot(pred); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline void __threadfence_block() {}
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_wave_barrier() emu::wave_sync()
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_sqrtf(x) std::sqrt(x)
@@ -85,6 +94,7 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = null
 inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 1; *greatest = -1; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 

@@ -85,16 +85,23 @@ def test_outputs_are_bitwise_symmetric_and_zero_off_edges():
     assert np.array_equal(ma, ma.T) and np.all(ma[sg.adj == 0] == 0) and np.all(np.diag(ma) == 0)
 
 
-def test_large_target_many_row_blocks():
-    """n = 310 -> ld = 320: 10 row blocks, 55 tile pairs, per-block partials (df, z3p) summed over 10 slots."""
+@pytest.mark.parametrize("sparse", [False, True])
+def test_large_target_many_row_blocks(sparse):
+    """n = 310 -> ld = 320: 10 row blocks.  Dense streaming kernels (55 tile pairs, per-block partials summed over 10
+    slots) and the sparse on-chip-resident kernel (1432 undirected edges, 3 row blocks per wave)."""
     ck, gx, sg = _node_case("syn1", 300)
     assert sg.adj.shape[0] == 310
-    res = emu_job([sg], ck["sd"]).run([sg.mask0], Hyper(num_iters=2))
+    res = emu_job([sg], ck["sd"], analyze=sparse).run([sg.mask0], Hyper(num_iters=2))
     o = closed_form.ClosedFormOracle(sg.adj, sg.feat, ck["sd"], sg.gt_label, sg.pred_label, sg.target_row, sg.mask0)
     want = o.run(2)
+    edges = sg.adj != 0
     assert np.abs(res.masked_adj[0] - want).max() < 2e-6
-    assert np.abs(res.mask[0] - o.M).max() < 2e-5
     assert np.abs(res.feat_mask[0] - o.f).max() < 2e-5
+    if sparse:   # only the entries on edges are live state; the others keep their initial values
+        assert np.abs(res.mask[0] - o.M)[edges].max() < 2e-5
+        assert np.array_equal(res.mask[0][~edges], sg.mask0[~edges])
+    else:
+        assert np.abs(res.mask[0] - o.M).max() < 2e-5
 
 
 def test_resident_kernel_matches_streaming_and_reference():
@@ -126,11 +133,11 @@ def test_two_block_resident_kernel_vs_streaming_and_golden():
     """syn1 target 309 (n = 48 -> 2 row blocks: diagonal and off-diagonal tile pairs, mirror entries in registers)
     through the resident kernel: 300 iterations against the reference's golden mask, and against the streaming path."""
     ck, gx, sg = _node_case("syn1", 309)
-    res = emu_job([sg], ck["sd"]).run([sg.mask0], Hyper(num_iters=300, use_resident=True))
+    res = emu_job([sg], ck["sd"], analyze=False).run([sg.mask0], Hyper(num_iters=300, use_resident=True))
     rc = gx["309:edge_rc"]
     assert np.abs(res.masked_adj[0][rc[:, 0], rc[:, 1]] - gx["309:masked_adj_edges"]).max() <= 1e-5
     assert np.abs(1 / (1 + np.exp(-res.feat_mask[0])) - gx["309:feat_mask_sigmoid"]).max() <= 1e-5
-    short = emu_job([sg], ck["sd"]).run([sg.mask0], Hyper(num_iters=20, use_resident=True))
+    short = emu_job([sg], ck["sd"], analyze=False).run([sg.mask0], Hyper(num_iters=20, use_resident=True))
     stream = emu_job([sg], ck["sd"]).run([sg.mask0], Hyper(num_iters=20, use_resident=False))
     assert np.abs(short.masked_adj[0] - stream.masked_adj[0]).max() < 1e-6
     assert np.abs(short.mask[0] - stream.mask[0]).max() < 1e-5
@@ -159,18 +166,21 @@ def test_device_side_packing_equals_host_packing():
         assert np.array_equal(a, s.adj)
 
 
-@pytest.mark.parametrize("D,H,O,C,n,graph_mode,resident", [
-    (7, 13, 9, 3, 21, False, True),      # odd widths, resident kernel
-    (7, 13, 9, 3, 21, False, False),     # same through the streaming kernels
-    (5, 32, 32, 6, 45, False, False),    # full-width hidden layers, two row blocks
-    (5, 32, 32, 6, 45, False, True),     # ... in the two-block resident kernel
-    (31, 8, 3, 2, 70, False, False),     # wide input (beyond the 16 columns of the common case), three row blocks
-    (31, 8, 3, 2, 70, False, True),      # ... in the three-block resident kernel
-    (10, 20, 20, 4, 96, False, True),    # largest resident target (no padding rows)
-    (14, 20, 20, 2, 40, True, False),    # graph mode
-    (3, 9, 17, 9, 33, True, False),      # graph mode, odd widths, more classes than the resident path takes
+@pytest.mark.parametrize("D,H,O,C,n,graph_mode,path", [
+    (7, 13, 9, 3, 21, False, "resident"),     # odd widths, single-tile resident kernel
+    (7, 13, 9, 3, 21, False, "stream"),       # same through the streaming kernels
+    (5, 32, 32, 6, 45, False, "stream"),      # full-width hidden layers, two row blocks
+    (5, 32, 32, 6, 45, False, "resident"),    # ... in the two-block dense resident kernel
+    (5, 32, 32, 6, 45, False, "sparse"),      # ... in the sparse resident kernel
+    (31, 8, 3, 2, 70, False, "stream"),       # wide input (beyond the 16 columns of the common case), three row blocks
+    (31, 8, 3, 2, 70, False, "resident"),     # ... in the three-block dense resident kernel
+    (31, 8, 3, 2, 70, False, "sparse"),
+    (10, 20, 20, 4, 96, False, "resident"),   # largest dense-resident target (no padding rows)
+    (7, 13, 9, 3, 130, False, "sparse"),      # odd widths, 5 row blocks (two per wave for wave 0)
+    (14, 20, 20, 2, 40, True, "stream"),      # graph mode
+    (3, 9, 17, 9, 33, True, "stream"),        # graph mode, odd widths, more classes than the resident paths take
 ])
-def test_generic_shapes_match_closed_form(D, H, O, C, n, graph_mode, resident):
+def test_generic_shapes_match_closed_form(D, H, O, C, n, graph_mode, path):
     rng = np.random.default_rng(D * 1000 + H * 10 + n)
     sd = helpers.random_model(rng, D, H, O, C)
     A, X = helpers.random_graph(rng, n, D)
@@ -179,9 +189,28 @@ def test_generic_shapes_match_closed_form(D, H, O, C, n, graph_mode, resident):
     yhat = None if graph_mode else rng.integers(0, C, n)
     sg = Subgraph(A, X, gt, 0 if graph_mode else t, yhat, m0)
     iters = 4
-    res = emu_job([sg], sd, graph_mode=graph_mode).run([m0], Hyper(num_iters=iters, use_resident=resident))
+    job = emu_job([sg], sd, graph_mode=graph_mode, analyze=(path == "sparse"))
+    res = job.run([m0], Hyper(num_iters=iters, use_resident=(path != "stream")))
     o = closed_form.ClosedFormOracle(A, X, sd, gt, yhat, 0 if graph_mode else t, m0, graph_mode=graph_mode)
     want = o.run(iters)
+    live = (A != 0) if path == "sparse" else np.ones_like(A, bool)
     assert np.abs(res.masked_adj[0] - want).max() < 5e-6
-    assert np.abs(res.mask[0] - o.M).max() < 5e-5
+    assert np.abs(res.mask[0] - o.M)[live].max() < 5e-5
     assert np.abs(res.feat_mask[0] - o.f).max() < 5e-5
+    if path == "sparse":
+        assert np.array_equal(res.mask[0][~live], m0[~live])
+
+
+def test_sparse_resident_kernel_full_run_vs_golden():
+    """syn1 targets 555 (n = 104) and 309 (n = 48) as one batch with 302 (n = 6, dense single-tile kernel): 300
+    iterations in the sparse on-chip-resident kernel against the reference's golden masks."""
+    ck, gx = helpers.load_ckpt("syn1"), helpers.load_explain("syn1")
+    targets = (555, 309, 302)
+    subs = [_node_case("syn1", t)[2] for t in targets]
+    res = emu_job(subs, ck["sd"]).run([s.mask0 for s in subs], Hyper(num_iters=300))
+    for i, t in enumerate(targets):
+        rc = gx[f"{t}:edge_rc"]
+        assert np.abs(res.masked_adj[i][rc[:, 0], rc[:, 1]] - gx[f"{t}:masked_adj_edges"]).max() <= 1e-5
+        assert np.abs(1 / (1 + np.exp(-res.feat_mask[i])) - gx[f"{t}:feat_mask_sigmoid"]).max() <= 1e-5
+        assert np.array_equal(res.masked_adj[i], res.masked_adj[i].T)
+        assert np.all(res.masked_adj[i][subs[i].adj == 0] == 0)

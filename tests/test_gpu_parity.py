@@ -88,15 +88,19 @@ def test_single_iteration_stages_vs_oracle():
     o.iterate()
     assert np.abs(ma[0] - o.stages["Abar"]).max() < 1e-6
     assert np.abs(probs[0] - o.stages["p"]).max() < 1e-5
-    res = job.run([s.mask0], Hyper(num_iters=1))
+    edges = s.adj != 0
+    res = job.run([s.mask0], Hyper(num_iters=1))                 # n = 104: sparse on-chip-resident kernel
+    assert np.abs(res.mask[0] - o.M)[edges].max() < 1e-5
+    assert np.array_equal(res.mask[0][~edges], s.mask0[~edges])  # non-edge entries are dead state there
+    assert np.abs(res.feat_mask[0] - o.f).max() < 1e-5
+    res = MaskOptimJob([s], ck["sd"], analyze=False).run([s.mask0], Hyper(num_iters=1))   # dense streaming kernels
     assert np.abs(res.mask[0] - o.M).max() < 1e-5
     assert np.abs(res.feat_mask[0] - o.f).max() < 1e-5
 
 
 def test_ragged_batch_equals_individual_jobs_and_is_deterministic():
-    """Batching must not change any bit as long as a target takes the same path (streaming, or the resident kernel of its
-    size).  The path of a 33 <= n <= 96 target depends on the batch (resident only when the whole batch is), so for
-    it solo-vs-batch is held to round-off instead."""
+    """Batching must not change any bit: every target takes the kernel its own size and edge count select (streaming,
+    dense single-tile resident, sparse resident), whatever else is in the batch."""
     ck, gx = helpers.load_ckpt("syn1"), helpers.load_explain("syn1")
     subs = [_node_subgraph(ck, gx, t) for t in (302, 555, 309, 302)]
     for use_resident in (False, True):
@@ -105,11 +109,7 @@ def test_ragged_batch_equals_individual_jobs_and_is_deterministic():
         again = MaskOptimJob(subs, ck["sd"]).run([s.mask0 for s in subs], hy)
         for i, s in enumerate(subs):
             solo = MaskOptimJob([s], ck["sd"]).run([s.mask0], hy)
-            same_path = (not use_resident) or len(s.adj) <= 32 or len(s.adj) > 96
-            if same_path:
-                assert np.array_equal(solo.masked_adj[0], res.masked_adj[i])
-            else:
-                assert np.abs(solo.masked_adj[0] - res.masked_adj[i]).max() < 2e-6
+            assert np.array_equal(solo.masked_adj[0], res.masked_adj[i])
             assert np.array_equal(again.masked_adj[i], res.masked_adj[i])
         assert np.array_equal(res.masked_adj[0], res.masked_adj[3])
 
@@ -163,12 +163,13 @@ def test_hybrid_resident_plus_streaming_vs_reference(name):
 
 
 def test_multi_block_resident_kernel_vs_golden_and_streaming():
-    """A batch whose targets all have n <= 96 runs entirely in the resident kernels: syn1 target 309 (n = 48, two row
-    blocks) + 302 (one block), 300 iterations against the reference's golden masks and against the streaming path."""
+    """Without gnnx_plan_analyze, a batch whose targets all have n <= 96 runs entirely in the DENSE resident kernels:
+    syn1 target 309 (n = 48, two row blocks) + 302 (one block), 300 iterations against the reference's golden masks
+    and against the streaming path."""
     ck, gx = helpers.load_ckpt("syn1"), helpers.load_explain("syn1")
     subs = [_node_subgraph(ck, gx, t) for t in (309, 302)]
     m0 = [s.mask0 for s in subs]
-    res = MaskOptimJob(subs, ck["sd"]).run(m0, Hyper(num_iters=300, use_graph=True, use_resident=True))
+    res = MaskOptimJob(subs, ck["sd"], analyze=False).run(m0, Hyper(num_iters=300, use_graph=True, use_resident=True))
     stream = MaskOptimJob(subs, ck["sd"]).run(m0, Hyper(num_iters=300, use_graph=True, use_resident=False))
     for i, t in enumerate((309, 302)):
         rc = gx[f"{t}:edge_rc"]
@@ -189,25 +190,31 @@ def test_resident_only_batch_is_deterministic():
     assert np.array_equal(a.masked_adj[0], a.masked_adj[4])
 
 
-@pytest.mark.parametrize("D,H,O,C,n,graph_mode,resident", [
-    (7, 13, 9, 3, 21, False, True), (7, 13, 9, 3, 21, False, False), (5, 32, 32, 6, 45, False, False),
-    (5, 32, 32, 6, 45, False, True), (31, 8, 3, 2, 70, False, False), (31, 8, 3, 2, 70, False, True),
-    (10, 20, 20, 4, 96, False, True), (14, 20, 20, 2, 40, True, False), (3, 9, 17, 9, 33, True, False),
-    (10, 20, 20, 4, 300, False, False),
+@pytest.mark.parametrize("D,H,O,C,n,graph_mode,path", [
+    (7, 13, 9, 3, 21, False, "resident"), (7, 13, 9, 3, 21, False, "stream"), (5, 32, 32, 6, 45, False, "stream"),
+    (5, 32, 32, 6, 45, False, "resident"), (5, 32, 32, 6, 45, False, "sparse"), (31, 8, 3, 2, 70, False, "stream"),
+    (31, 8, 3, 2, 70, False, "resident"), (31, 8, 3, 2, 70, False, "sparse"), (10, 20, 20, 4, 96, False, "resident"),
+    (7, 13, 9, 3, 130, False, "sparse"), (14, 20, 20, 2, 40, True, "stream"), (3, 9, 17, 9, 33, True, "stream"),
+    (10, 20, 20, 4, 300, False, "stream"), (10, 20, 20, 4, 300, False, "sparse"), (10, 20, 20, 4, 400, False, "sparse"),
 ])
-def test_generic_shapes_match_closed_form(D, H, O, C, n, graph_mode, resident):
-    """Encoder shapes other than the fixtures': odd widths, full 32-wide layers, wide input, many classes."""
+def test_generic_shapes_match_closed_form(D, H, O, C, n, graph_mode, path):
+    """Encoder shapes other than the fixtures': odd widths, full 32-wide layers, wide input, many classes; through the
+    streaming kernels, the dense resident kernels (no analysis) and the sparse resident kernel."""
     rng = np.random.default_rng(D * 1000 + H * 10 + n)
     sd = helpers.random_model(rng, D, H, O, C)
-    A, X = helpers.random_graph(rng, n, D, density=0.15 if n < 100 else 0.03)
+    A, X = helpers.random_graph(rng, n, D, density=0.15 if n < 100 else 0.03 if n < 400 else 0.01)
     m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
     t, gt = int(rng.integers(0, n)), int(rng.integers(0, C))
     yhat = None if graph_mode else rng.integers(0, C, n)
     sg = Subgraph(A, X, gt, 0 if graph_mode else t, yhat, m0)
     iters = 6
-    res = MaskOptimJob([sg], sd, graph_mode=graph_mode).run([m0], Hyper(num_iters=iters, use_resident=resident))
+    job = MaskOptimJob([sg], sd, graph_mode=graph_mode, analyze=(path == "sparse"))
+    res = job.run([m0], Hyper(num_iters=iters, use_resident=(path != "stream")))
     o = closed_form.ClosedFormOracle(A, X, sd, gt, yhat, 0 if graph_mode else t, m0, graph_mode=graph_mode)
     want = o.run(iters)
+    live = (A != 0) if path == "sparse" else np.ones_like(A, bool)
     assert np.abs(res.masked_adj[0] - want).max() < 5e-6
-    assert np.abs(res.mask[0] - o.M).max() < 5e-5
+    assert np.abs(res.mask[0] - o.M)[live].max() < 5e-5
     assert np.abs(res.feat_mask[0] - o.f).max() < 5e-5
+    if path == "sparse":
+        assert np.array_equal(res.mask[0][~live], m0[~live])      # proves the sparse kernel ran (dead state untouched)
