@@ -542,6 +542,12 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
     return 0;
 }
 
+extern "C" int gnnx_get_route(gnnx_handle h, int32_t* route) {
+    if (!h || !route) return fail("null argument");
+    for (int t = 0; t < h->prob.num_targets; ++t) route[t] = h->cat[t];
+    return 0;
+}
+
 extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
     if (!h || !A) return fail("null argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -614,9 +620,60 @@ extern "C" int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hy, int32_t kin
     hipEvent_t e0, e1;
     HIPCK(hipEventCreate(&e0));
     HIPCK(hipEventCreate(&e1));
+    if (kind == 8 || kind == 9) {
+        // one whole launch (all num_iters iterations) of the sparse (8) / single-tile dense (9) resident kernel on
+        // `stream`, alone on the device.  Algorithmic work per SURVEY.md §8d for the targets of that launch:
+        // 28 n^2 bytes and 6 n^2 (D + 2H) flop per iteration (the dense formulation the reference executes).
+        const int cnt = (kind == 8) ? h->n_sp : h->res_count[1];
+        if (cnt == 0) {
+            *ms_avg = 0.0f;
+            if (alg_bytes) *alg_bytes = 0.0;
+            if (alg_flops) *alg_flops = 0.0;
+            return 0;
+        }
+        std::vector<float> tab(2 * (size_t)hy->num_iters);
+        for (int it = 0; it < hy->num_iters; ++it) adam_scalars(hy, it, &tab[2 * it], &tab[2 * it + 1]);
+        float* d_tab = nullptr;
+        HIPCK(hipMalloc(&d_tab, sizeof(float) * tab.size()));
+        HIPCK(hipMemcpy(d_tab, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice));
+        auto launch = [&]() {
+            if (kind == 9)
+                hipLaunchKernelGGL(k_resident<1>, dim3(cnt), dim3(256), 0, s, p, h->d_res + h->res_first[1], d_tab);
+            else if (h->prob.D <= 10 && h->prob.H <= 20)
+                hipLaunchKernelGGL((k_sparse_resident<5, 10>), dim3(cnt), dim3(SP_THREADS), 0, s, p, h->d_sp, d_tab);
+            else
+                hipLaunchKernelGGL((k_sparse_resident<16, 16>), dim3(cnt), dim3(SP_THREADS), 0, s, p, h->d_sp, d_tab);
+        };
+        launch();  // warm
+        HIPCK(hipEventRecord(e0, s));
+        for (int r = 0; r < reps; ++r) launch();
+        HIPCK(hipEventRecord(e1, s));
+        HIPCK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipFree(d_tab);
+        *ms_avg = ms / reps;
+        double sn2 = 0;
+        for (int t = 0; t < h->prob.num_targets; ++t)
+            if (h->cat[t] == (kind == 8 ? CAT_SPARSE : 1)) sn2 += (double)h->meta[t].n * h->meta[t].n;
+        if (alg_bytes) *alg_bytes = 28.0 * sn2 * hy->num_iters;
+        if (alg_flops) *alg_flops = 6.0 * sn2 * (h->prob.D + 2.0 * h->prob.H) * hy->num_iters;
+        HIPCK(hipGetLastError());
+        return 0;
+    }
     float ss, b2;
     adam_scalars(hy, 0, &ss, &b2);
-    const Tables tb = tables_all(h);
+    // the tables gnnx_run would walk: only the streaming remainder when resident kernels take part of the batch
+    const bool hybrid = hy->use_resident && (h->n_res > 0 || h->n_sp > 0) && h->n_big > 0;
+    const Tables tb = hybrid ? tables_big(h) : tables_all(h);
+    double sum_n2 = h->sum_n2;
+    if (hybrid) {
+        sum_n2 = 0;
+        for (int t = 0; t < h->prob.num_targets; ++t)
+            if (h->cat[t] == 0) sum_n2 += (double)h->meta[t].n * h->meta[t].n;
+    }
     auto once = [&]() {
         switch (kind) {
             case 0: launch_mask<true, true>(h, tb, p, 0, ss, b2, s); break;
@@ -646,10 +703,10 @@ extern "C" int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hy, int32_t kin
     // the K = D+2H product = 2 (D+2H) flop per mask entry; a contraction = one 4-B read of Abar and 2 d flop per entry
     const double kagg = h->prob.D + 2.0 * h->prob.H;
     const bool contraction = (kind == 1 || kind == 2 || kind == 4 || kind == 5 || kind == 7);
-    if (alg_bytes) *alg_bytes = (kind == 0) ? 28.0 * h->sum_n2 : contraction ? 4.0 * h->sum_n2 : 0.0;
+    if (alg_bytes) *alg_bytes = (kind == 0) ? 28.0 * sum_n2 : contraction ? 4.0 * sum_n2 : 0.0;
     if (alg_flops) {
         const double d = (kind == 1) ? h->prob.D : h->prob.H;
-        *alg_flops = (kind == 0) ? 2.0 * h->sum_n2 * kagg : contraction ? 2.0 * h->sum_n2 * d : 0.0;
+        *alg_flops = (kind == 0) ? 2.0 * sum_n2 * kagg : contraction ? 2.0 * sum_n2 * d : 0.0;
     }
     HIPCK(hipGetLastError());
     return 0;

@@ -37,7 +37,7 @@ constexpr int SP_CHUNK = 16;                 // entries per row slot: longer row
 constexpr int SP_SLOTS = SP_THREADS / 2;     // row slots (two lanes = column halves per slot)
 
 // Row slots: row r takes ns(r) = max(1, ceil(deg(r) / SP_CHUNK)) consecutive slots that must not straddle a wave (32
-// slots); first slot of every row by greedy packing in row order.  Shared by k_count_edges (fit test) and the kernel.
+// slots).  Shared by k_count_edges (fit test) and the kernel (placement order: see "slot order" there).
 __host__ __device__ inline int sparse_slots_of(int deg) { return deg <= SP_CHUNK ? 1 : (deg + SP_CHUNK - 1) / SP_CHUNK; }
 __host__ __device__ inline int sparse_place(int pos, int ns) { return ((pos & 31) + ns > 32) ? ((pos + 31) & ~31) : pos; }
 constexpr int SP_POOL_FLOATS = 39168;        // 153 KB of the CU's 160 KB; the rest holds SparseFixed
@@ -112,9 +112,9 @@ __device__ __forceinline__ int lower_bound_u16(const unsigned short* a, int lo, 
 // sparse row gather for the lane's row: acc[q] += sum_e Abar_e * f(B[col_e][2q + half]), columns < W <= 2 NQ.
 // Loads are unconditional (out-of-range columns are read from the padding / the next row and discarded by a select),
 // so the compiler can issue all of an entry group's loads before the first use.
-template <bool RELU, int NQ>
-__device__ __forceinline__ void sparse_gather(const float* sAb, const unsigned short* scol, const float* B, int stride, int W,
-                                              int e0, int e1, int half, float (&acc)[NQ]) {
+template <bool RELU, int NQ, bool EXACT>
+__device__ __forceinline__ void sparse_gather_impl(const float* sAb, const unsigned short* scol, const float* B, int stride,
+                                                   int W, int e0, int e1, int half, float (&acc)[NQ]) {
     constexpr int UN = SP_GATHER_UNROLL;
     int e = e0;
 #pragma unroll 1
@@ -133,7 +133,7 @@ __device__ __forceinline__ void sparse_gather(const float* sAb, const unsigned s
             for (int q = 0; q < NQ; ++q) b[j][q] = br[j][2 * q];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const bool ok = 2 * q + half < W;
+            const bool ok = EXACT || 2 * q + half < W;
 #pragma unroll
             for (int j = 0; j < UN; ++j) {
                 float v = ok ? b[j][q] : 0.0f;
@@ -151,11 +151,21 @@ __device__ __forceinline__ void sparse_gather(const float* sAb, const unsigned s
         for (int q = 0; q < NQ; ++q) b[q] = br[2 * q];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            float v = (2 * q + half < W) ? b[q] : 0.0f;
+            float v = (EXACT || 2 * q + half < W) ? b[q] : 0.0f;
             if (RELU) v = fmaxf(v, 0.0f);
             acc[q] = fmaf(a, v, acc[q]);
         }
     }
+}
+
+// W == 2 NQ (every column of the trip count is real: the reference's D = 10, H = 20) needs no column selects
+template <bool RELU, int NQ>
+__device__ __forceinline__ void sparse_gather(const float* sAb, const unsigned short* scol, const float* B, int stride, int W,
+                                              int e0, int e1, int half, float (&acc)[NQ]) {
+    if (W == 2 * NQ)
+        sparse_gather_impl<RELU, NQ, true>(sAb, scol, B, stride, W, e0, e1, half, acc);
+    else
+        sparse_gather_impl<RELU, NQ, false>(sAb, scol, B, stride, W, e0, e1, half, acc);
 }
 
 // forward row-local part for the lane's row: Y^T[c][r] = sum_k W[k][c] Z[r][k] on MFMA (the lane's registers zq[u] =
@@ -352,18 +362,41 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
             sh.eup = incl;
         }
     }
-    int* slot_start = upptr + ld + 1;  // [ld + 1] first slot of every real row (greedy packing, see sparse_place)
+    // Row slots in "slot order": rows longer than SP_CHUNK first (row order, never straddling a wave), then the other
+    // rows by decreasing degree, so that the 32 slots of a wave have (nearly) equal trip counts in the gathers.
+    int* slot_start = upptr + ld + 1;     // [n + 1] first slot of the p-th row in slot order
+    int* order = slot_start + ld + 1;     // [n]     the p-th row in slot order
+    int* bucket = order + ld;             // [SP_CHUNK + 1] counting-sort cursors
     if (tid == 0) {
-        int pos = 0;
+        int pos = 0, p = 0;
+        for (int d = 0; d <= SP_CHUNK; ++d) bucket[d] = 0;
         for (int rr = 0; rr < n; ++rr) {
-            const int ns = sparse_slots_of(rowptr[rr + 1] - rowptr[rr]);
-            pos = sparse_place(pos, ns);
-            slot_start[rr] = pos;
-            pos += ns;
+            const int d = rowptr[rr + 1] - rowptr[rr];
+            if (d > SP_CHUNK) {
+                const int ns = sparse_slots_of(d);
+                pos = sparse_place(pos, ns);
+                order[p] = rr;
+                slot_start[p] = pos;
+                pos += ns;
+                ++p;
+            } else {
+                bucket[d]++;
+            }
         }
-        slot_start[n] = pos;
-        sh.slots = pos;
-        if (pos > SP_SLOTS) sh.bad = 1;
+        int run = p;
+        for (int d = SP_CHUNK; d >= 0; --d) {
+            const int c = bucket[d];
+            bucket[d] = run;
+            run += c;
+        }
+        for (int rr = 0; rr < n; ++rr) {
+            const int d = rowptr[rr + 1] - rowptr[rr];
+            if (d <= SP_CHUNK) order[bucket[d]++] = rr;
+        }
+        for (int q = p; q < n; ++q) slot_start[q] = pos + (q - p);
+        slot_start[n] = pos + (n - p);
+        sh.slots = pos + (n - p);
+        if (sh.slots > SP_SLOTS) sh.bad = 1;
     }
     __syncthreads();
     const int eup = sh.eup;
@@ -373,15 +406,16 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
     {
         const int sl = wave * TILE + li;
         if (sl < sh.slots && !sh.bad) {
-            int lo = 0, hi = n;  // largest row with slot_start[row] <= sl
+            int lo = 0, hi = n;  // largest position in slot order with slot_start[.] <= sl
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
                 if (slot_start[mid] <= sl) lo = mid; else hi = mid;
             }
-            const int a = rowptr[lo], b = rowptr[lo + 1];
+            const int row = order[lo];
+            const int a = rowptr[row], b = rowptr[row + 1];
             const int ns = sparse_slots_of(b - a), k = sl - slot_start[lo];
             if (k < ns) {  // otherwise: padding slot at the end of a wave
-                srow = lo;
+                srow = row;
                 re0 = a + k * SP_CHUNK;
                 re1 = (re0 + SP_CHUNK < b) ? re0 + SP_CHUNK : b;
                 nsplit = ns;
@@ -398,6 +432,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
     // owned undirected edges: k = tid + SP_THREADS q; mask entries and Adam moments stay in registers
     float Mij[SP_QMAX], Mji[SP_QMAX], mij[SP_QMAX], mji[SP_QMAX], vij[SP_QMAX], vji[SP_QMAX], wgt[SP_QMAX];
     int eij[SP_QMAX], eji[SP_QMAX], ni[SP_QMAX], nj[SP_QMAX];
+    bool near[SP_QMAX];  // an endpoint is t or a neighbour of t: only then dZ2 has a non-zero row on this edge
     {
         bool asym = (2 * eup != nnz);
 #pragma unroll
@@ -405,6 +440,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
             const int k = tid + SP_THREADS * q;
             Mij[q] = Mji[q] = mij[q] = mji[q] = vij[q] = vji[q] = wgt[q] = 0.0f;
             eij[q] = eji[q] = ni[q] = nj[q] = 0;
+            near[q] = false;
             if (k < eup) {
                 int lo = 0, hi = ld;  // largest row i with upptr[i] <= k
                 while (hi - lo > 1) {
@@ -424,6 +460,9 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
                 if (Ag[(size_t)j * ld + i] != wgt[q]) asym = true;
                 Mij[q] = Mg[(size_t)i * ld + j];
                 Mji[q] = Mg[(size_t)j * ld + i];
+                const int t0 = rowptr[tr], t1 = rowptr[tr + 1];
+                const int pi = lower_bound_u16(scol, t0, t1, i), pj = lower_bound_u16(scol, t0, t1, j);
+                near[q] = i == tr || j == tr || (pi < t1 && (int)scol[pi] == i) || (pj < t1 && (int)scol[pj] == j);
             }
         }
         if (asym) sh.bad = 1;  // benign race: every writer stores 1
@@ -509,73 +548,95 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
         }
         __syncthreads();
         // ======== row t of layer 3 (the only row the reference reads, explain.py:713), head, dE, dZ3[t] ========
-        if (tid < 64) {
-            const int c = tid & 31;
+        {   // row t of Abar . relu(U2): its entries dealt over the 16 waves, lane = column; partials summed in wave order
             float z = 0.0f;
-            if (c < H)
-                for (int e = rt0 + h; e < rt1; e += 2) z = fmaf(sAb[e], fmaxf(sU2[(int)scol[e] * sH + c], 0.0f), z);
+            if (li < H)
+                for (int e = rt0 + 2 * wave + h; e < rt1; e += 2 * NW)
+                    z = fmaf(sAb[e], fmaxf(sU2[(int)scol[e] * sH + li], 0.0f), z);
             z += __shfl_xor(z, 32);
-            // layer 3 for row t: y = z W3 + b3, normalised (z exchanged through shuffles: lane k holds z[k])
+            if (h == 0) sh.dfw[wave][li] = z;  // dfw is free until the layer-1 backward
+        }
+        __syncthreads();
+        if (wave == 0) {  // the head is a chain of tiny dependent steps: one wave, wave-level syncs only
+            const int c = li;
+            float z = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) z += sh.dfw[w][c];
+            // layer 3 for row t: y = z W3 + b3, normalised (z staged in LDS so the H products' loads are independent)
+            if (h == 0) sh.z3[c] = z;
+            wave_sync();
             float y = 0.0f;
-            for (int k = 0; k < H; ++k) {
-                const float zk = __shfl(z, k);
-                if (c < O) y = fmaf(zk, sW3[k * 33 + c], y);
+            if (c < O) {
+                float y0 = 0.0f, y1 = 0.0f;
+#pragma unroll 4
+                for (int k = 0; k + 1 < H; k += 2) {
+                    y0 = fmaf(sh.z3[k], sW3[k * 33 + c], y0);
+                    y1 = fmaf(sh.z3[k + 1], sW3[(k + 1) * 33 + c], y1);
+                }
+                if (H & 1) y0 = fmaf(sh.z3[H - 1], sW3[(H - 1) * 33 + c], y0);
+                y = y0 + y1 + sh.bias[2][c];
             }
-            if (c < O) y += sh.bias[2][c];
-            float ss = (tid < 32) ? y * y : 0.0f;
+            float ss = (h == 0) ? y * y : 0.0f;
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
             const float rnorm = fmaxf(sqrtf(ss), 1e-12f);
-            if (tid < 32) {
-                const float u = y / rnorm;
-                sh.y3[tid] = u;
-                sh.e[64 + tid] = u;
-                sh.e[tid] = (tid < H) ? fmaxf(sU1[tr * sH + tid], 0.0f) : 0.0f;
-                sh.e[32 + tid] = (tid < H) ? fmaxf(sU2[tr * sH + tid], 0.0f) : 0.0f;
+            const float u3 = y / rnorm;  // U3[t][c] (both halves)
+            if (h == 0) {
+                sh.e[64 + c] = u3;
+                sh.e[c] = (c < H) ? fmaxf(sU1[tr * sH + c], 0.0f) : 0.0f;
+                sh.e[32 + c] = (c < H) ? fmaxf(sU2[tr * sH + c], 0.0f) : 0.0f;
             }
-            if (tid == 0) sh.sr3 = rnorm;
-        }
-        __syncthreads();
-        if (tid < 64) {  // softmax head (explain.py:713-714, 750-753): g = p - onehot(y_gt)
-            const int c = tid >> 3, part = tid & 7;
-            float s = 0.0f;
-            if (c < C)
-                for (int q = part * 12; q < part * 12 + 12; ++q) s = fmaf(sWp[c * 96 + q], sh.e[q], s);
-            s += __shfl_xor(s, 1);
-            s += __shfl_xor(s, 2);
-            s += __shfl_xor(s, 4);
-            const float zc = __shfl(s, (tid & 7) * 8);
-            const float z = (tid < C) ? zc + sh.sbp[tid] : -3.0e38f;
-            float mx = z;
+            wave_sync();
+            {   // softmax head (explain.py:713-714, 750-753): g = p - onehot(y_gt); class = lane / 8, 12 terms per lane
+                const int cls = lane >> 3, part = lane & 7;
+                float s = 0.0f;
+                if (cls < C)
+                    for (int q = part * 12; q < part * 12 + 12; ++q) s = fmaf(sWp[cls * 96 + q], sh.e[q], s);
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                s += __shfl_xor(s, 4);
+                const float zc = __shfl(s, (lane & 7) * 8);
+                const float zl = (lane < C) ? zc + sh.sbp[lane] : -3.0e38f;
+                float mx = zl;
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-            const float ex = (tid < C) ? expf(z - mx) : 0.0f;
-            float sum = ex;
+                for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                const float ex = (lane < C) ? expf(zl - mx) : 0.0f;
+                float sum = ex;
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
-            if (tid < CMAX) sh.g[tid] = (tid < C) ? ex / sum - ((tid == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
-        }
-        __syncthreads();
-        if (tid < 96) {  // dE = Wp^T g
-            float s = 0.0f;
-            for (int c = 0; c < C; ++c) s = fmaf(sWp[c * 96 + tid], sh.g[c], s);
-            sh.dEs[tid] = s;
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const int c = tid & 31;
-            const float du = (tid < 32 && c < O) ? sh.dEs[64 + c] : 0.0f;
-            const float u = (tid < 32) ? sh.y3[c] : 0.0f;
-            float s = du * u;
+                for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+                if (lane < CMAX) sh.g[lane] = (lane < C) ? ex / sum - ((lane == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
+            }
+            wave_sync();
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {  // dE = Wp^T g (96 entries over 64 lanes)
+                const int idx = lane + 64 * part;
+                if (idx < 96) {
+                    float s = 0.0f;
+                    for (int cc = 0; cc < C; ++cc) s = fmaf(sWp[cc * 96 + idx], sh.g[cc], s);
+                    sh.dEs[idx] = s;
+                }
+            }
+            wave_sync();
+            const float du3 = (h == 0 && c < O) ? sh.dEs[64 + c] : 0.0f;
+            const float uq = (h == 0) ? u3 : 0.0f;
+            float s = du3 * uq;
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-            const float dy3 = (du - u * s) / sh.sr3;  // dY3[t][c] in lanes c < 32 (both halves hold the same s)
+            const float dy3 = (du3 - uq * s) / rnorm;  // dY3[t][c] in lanes c < 32
+            if (h == 0) sh.y3[c] = dy3;
+            wave_sync();
             float v = 0.0f;
-            for (int c2 = 0; c2 < O; ++c2) {
-                const float d = __shfl(dy3, c2);
-                if (c < H) v = fmaf(d, sW3[c * 33 + c2], v);
+            if (c < H) {
+                float v0 = 0.0f, v1 = 0.0f;
+#pragma unroll 4
+                for (int c2 = 0; c2 + 1 < O; c2 += 2) {
+                    v0 = fmaf(sh.y3[c2], sW3[c * 33 + c2], v0);
+                    v1 = fmaf(sh.y3[c2 + 1], sW3[c * 33 + c2 + 1], v1);
+                }
+                if (O & 1) v0 = fmaf(sh.y3[O - 1], sW3[c * 33 + O - 1], v0);
+                v = v0 + v1;
             }
-            if (tid < 32) sh.dz3[tid] = (tid < H) ? v : 0.0f;
+            if (h == 0) sh.dz3[c] = (c < H) ? v : 0.0f;
         }
         __syncthreads();
         // ======== dZ2 (rank-1: dX2[r] = Abar[r][t] dZ3[t] + dE2 on row t) and g3; dZ2 overwrites U2 row by row ========
@@ -668,8 +729,9 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
                         G0 += (c < D) ? t1 : 0.0f;
                     }
                 }
+                // dZ2 is exactly zero outside row t and its neighbours (rank-1 layer-3 backward): skip the products
 #pragma unroll 1
-                for (int c0 = 0; c0 < 2 * HQ; c0 += 2 * HQ / 4) {
+                for (int c0 = 0; near[q] && c0 < 2 * HQ; c0 += 2 * HQ / 4) {
 #pragma unroll
                     for (int cc = 0; cc < 2 * HQ / 4; ++cc) {
                         const int c = c0 + cc;
@@ -752,10 +814,16 @@ __global__ __launch_bounds__(256) void k_count_edges(const TargetMeta* meta, con
         int pos = -1;
         if (small) {
             pos = 0;
+            int singles = 0;  // same placement as k_sparse_resident: split rows first, the others one slot each
             for (int r = 0; r < tm.n; ++r) {
-                const int ns = sparse_slots_of(deg[r]);
-                pos = sparse_place(pos, ns) + ns;
+                if (deg[r] > SP_CHUNK) {
+                    const int ns = sparse_slots_of(deg[r]);
+                    pos = sparse_place(pos, ns) + ns;
+                } else {
+                    ++singles;
+                }
             }
+            pos += singles;
         }
         out[2 * blockIdx.x] = part[0] + part[1] + part[2] + part[3];
         out[2 * blockIdx.x + 1] = pos;

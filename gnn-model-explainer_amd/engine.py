@@ -90,6 +90,7 @@ _API = {
     "gnnx_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper)] + [ctypes.c_void_p] * 8 +
                  [ctypes.c_size_t, ctypes.c_void_p]),
     "gnnx_plan_analyze": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "gnnx_get_route": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
     "gnnx_pack_csr": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int32] + [ctypes.c_void_p] * 7),
     "gnnx_forward": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_void_p] * 7 + [ctypes.c_size_t, ctypes.c_void_p]),
     "gnnx_time_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper), ctypes.c_int32, ctypes.c_int32] +
@@ -424,6 +425,12 @@ class MaskOptimJob:
                                                    self._stream(), ctypes.byref(ms), ctypes.byref(by), ctypes.byref(fl)))
         self._leave()
         return ms.value, by.value, fl.value
+
+    def route(self):
+        """Kernel of every target: 0 dense streaming, 1..3 dense resident (row blocks), 4 sparse resident."""
+        r = np.zeros(self.T, np.int32)
+        _check(self.lib, self.lib.gnnx_get_route(self.handle, r.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
+        return r
 
     @property
     def sum_n2(self):

@@ -102,6 +102,10 @@ int gnnx_run(gnnx_handle h, const gnnx_hyper* hyper, const float* A, const float
  * GNNX_SPARSE_RESIDENT=0 in the environment disables the sparse kernel. */
 int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream);
 
+/* The kernel every target is routed to (host array of num_targets entries): 0 = dense streaming kernels,
+ * 1..3 = dense on-chip-resident kernel of that many 32-row blocks, 4 = sparse on-chip-resident kernel. */
+int gnnx_get_route(gnnx_handle h, int32_t* route);
+
 /* Device-side packing of the plan's sub-graphs from the full graph in CSR form (all pointers are DEVICE
  * pointers): replaces the host's dense slicing `adj[nb][:, nb]`, `feat[nb]`, `argmax(pred[nb])` of
  * Explainer.extract_neighborhood / explain (explain.py:492-501, 94-106) for the whole batch.
@@ -122,7 +126,10 @@ int gnnx_forward(gnnx_handle h, const float* A, const float* X, const float* M, 
  * state between two hipEvents on `stream`; returns the average launch duration in milliseconds and
  * the algorithmic bytes / flops of one launch.  kind: 0 = fused mask/regulariser/Adam kernel, 1/2 = forward
  * contraction of layer 1/2, 3 = head kernel, 4 = backward contraction into layer 1; graph mode only:
- * 5 = forward contraction of layer 3, 6 = row-local backward of layer 3, 7 = backward contraction into layer 2. */
+ * 5 = forward contraction of layer 3, 6 = row-local backward of layer 3, 7 = backward contraction into layer 2;
+ * 8 / 9 = one WHOLE launch (all num_iters iterations; overwrites M / Abar) of the sparse / single-tile dense
+ * on-chip-resident kernel, with the algorithmic work of its targets (28 n^2 B and 6 n^2 (D + 2H) flop per iteration).
+ * Kinds 0-7 walk the tile tables gnnx_run would walk (the streaming remainder of a hybrid batch). */
 int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hyper, int32_t kind, int32_t reps, const float* A,
                      const float* X, const float* yhat, float* M, float* Abar, void* workspace,
                      size_t workspace_bytes, void* stream, float* ms_avg, double* alg_bytes, double* alg_flops);

@@ -17,6 +17,14 @@ for k, a in enumerate(anchors):
     src = src.replace(a + "\n", "        PROBE(%d);\n" % k + a + "\n", 1)
     names.append(a.strip(" /="))
 k = len(anchors)
+# finer stamps inside layer 2 (wave 0 = the hub rows): after the gather, after the split-row combine, after MFMA + epilogue
+SUB = 12
+l2 = "            sparse_gather<true, HQ>(sAb, scol, sU1, sH, H, re0, re1, h, acc);\n            sparse_combine<HQ>(acc, lane, first, nsplit, wsplit);\n"
+assert l2 in src
+src = src.replace(l2, l2.replace(";\n            sparse_combine", ";\n            PROBE(%d);\n            sparse_combine" % SUB) + "            PROBE(%d);\n" % (SUB + 1), 1)
+l2b = "            sparse_forward_rowlocal<HQ>(acc, sW2, sh.bias[1], H, H, li, h, first, sU2 + r * sH, sRn2 + r);\n"
+assert l2b in src
+src = src.replace(l2b, l2b + "            PROBE(%d);\n" % (SUB + 2), 1)
 src = src.replace("        if (iter + 1 < p.num_iters) publish_abar();  // the returned mask", "        PROBE(%d);\n        if (iter + 1 < p.num_iters) publish_abar();\n        PROBE(%d);  // the returned mask" % (k, k + 1), 1)
 names += ["publish Abar"]
 for f in ("gnnx_kernels.hpp", "gnnx_resident.hpp"):
@@ -48,3 +56,6 @@ d = np.diff(a) * 10.0 / 1e3
 for nme, v in zip(names, d):
     print("%-100s %7.2f us" % (nme[:100], v))
 print("iteration total %7.2f us" % ((a[len(names)] - a[0]) * 10.0 / 1e3))
+b = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
+print("layer 2, wave 0: gather %.2f us, combine %.2f us, MFMA + epilogue %.2f us, wait at barrier %.2f us" % (
+    (b[12] - b[1]) / 100.0, (b[13] - b[12]) / 100.0, (b[14] - b[13]) / 100.0, (b[2] - b[14]) / 100.0))
