@@ -87,7 +87,7 @@ def cpu_baseline(wl, iters, budget_s=20.0):
     from oracle import reference_restatement as rr
     ck = wl.ck
     order = np.argsort([len(nb) for nb in wl.nbs])
-    sample = [wl.dense_subgraph(int(k)) for k in order[np.linspace(0, len(order) - 1, 8).astype(int)]]
+    sample = [wl.dense_subgraph(int(k)) for k in order[np.linspace(0, len(order) - 1, 24).astype(int)]]
     subs = wl.targets
     sd = {k: torch.tensor(v) for k, v in ck["sd"].items()}
     # the reference is dispatch-bound (~700 tiny aten ops / epoch): more than a few threads only adds OpenMP
@@ -212,8 +212,15 @@ def main():
                                      "avg_launch_us": {nm: x[0] * 1e3 for nm, x in zip(names, per)}}
         else:
             per = []
-        ms_sp, by_sp, fl_sp = job.time_kernel(hy, 8, 3) if (route == 4).any() else (0.0, 0.0, 0.0)
-        ms_r1, by_r1, fl_r1 = job.time_kernel(hy, 9, 3) if (route == 1).any() else (0.0, 0.0, 0.0)
+        # resident launches: timed IN SITU (HIP events on the side streams they run on) during one more full step, so
+        # the durations are those of the timed region's launches (the rocprofv3 kernel trace of this command shows the same)
+        step()
+        torch.cuda.synchronize()
+        rt = job.resident_times()
+        sel = lambda m: float(n2[m].sum())
+        ms_sp, ms_r1 = rt[3], rt[0]
+        by_sp, fl_sp = 28.0 * sel(route == 4) * args.iters, 6.0 * sel(route == 4) * kagg * args.iters
+        by_r1, fl_r1 = 28.0 * sel(route == 1) * args.iters, 6.0 * sel(route == 1) * kagg * args.iters
         if ms_sp:
             launches["k_sparse_resident"] = {"targets": int((route == 4).sum()), "ms_total": ms_sp}
         if ms_r1:

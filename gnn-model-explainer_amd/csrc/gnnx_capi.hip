@@ -55,6 +55,8 @@ struct gnnx_plan_s {
     MaskTile* d_mask_big = nullptr;
     hipStream_t side[RES_NBMAX + 1] = {};   // the resident kernels (dense: one per nb; [RES_NBMAX]: sparse) run beside the streaming launches
     hipEvent_t ev_in = nullptr, ev_out[RES_NBMAX + 1] = {};
+    hipEvent_t ev_t0[RES_NBMAX + 1] = {};   // start of the resident launch on its side stream (timed, for gnnx_resident_times)
+    bool launched[RES_NBMAX + 1] = {};
     std::vector<int> order;          // targets, largest first
     std::vector<int> cat;            // per target: 0 streaming, 1..RES_NBMAX dense resident kernel of that many row blocks, CAT_SPARSE
     std::vector<int32_t> nnz;        // per target (directed edge entries, row slots) from gnnx_plan_analyze, empty before
@@ -138,7 +140,8 @@ static int build_split(gnnx_handle h) {
         const bool need = k < RES_NBMAX ? h->res_count[k + 1] > 0 : h->n_sp > 0;
         if (need && !h->side[k]) {
             SPLITCK(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
-            SPLITCK(hipEventCreateWithFlags(&h->ev_out[k], hipEventDisableTiming));
+            SPLITCK(hipEventCreate(&h->ev_out[k]));
+            SPLITCK(hipEventCreate(&h->ev_t0[k]));
         }
     }
 #undef SPLITCK
@@ -295,6 +298,7 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
     for (int k = 0; k <= RES_NBMAX; ++k) {
         if (h->side[k]) (void)hipStreamDestroy(h->side[k]);
         if (h->ev_out[k]) (void)hipEventDestroy(h->ev_out[k]);
+        if (h->ev_t0[k]) (void)hipEventDestroy(h->ev_t0[k]);
     }
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->d_res) (void)hipFree(h->d_res);
@@ -484,6 +488,8 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
             // spread over every CU (measured on syn1: 21.5 -> see DESIGN.md)
             hipStream_t ss = h->side[RES_NBMAX];
             HIPCK(hipStreamWaitEvent(ss, h->ev_in, 0));
+            HIPCK(hipEventRecord(h->ev_t0[RES_NBMAX], ss));
+            h->launched[RES_NBMAX] = true;
             if (h->prob.D <= 10 && h->prob.H <= 20)  // the reference's encoder (hidden 20, 10 input features)
                 hipLaunchKernelGGL((k_sparse_resident<5, 10>), dim3(h->n_sp), dim3(SP_THREADS), 0, ss, p, h->d_sp, h->d_adam);
             else
@@ -494,6 +500,8 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
             if (!h->res_count[nb]) continue;
             hipStream_t ss = h->side[nb - 1];
             HIPCK(hipStreamWaitEvent(ss, h->ev_in, 0));
+            HIPCK(hipEventRecord(h->ev_t0[nb - 1], ss));
+            h->launched[nb - 1] = true;
             const dim3 grid(h->res_count[nb]), block(256);
             const int32_t* ids = h->d_res + h->res_first[nb];
             if (nb == 1) hipLaunchKernelGGL(k_resident<1>, grid, block, 0, ss, p, ids, h->d_adam);
@@ -542,6 +550,17 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
     return 0;
 }
 
+extern "C" int gnnx_resident_times(gnnx_handle h, float* ms) {
+    if (!h || !ms) return fail("null argument");
+    for (int k = 0; k <= RES_NBMAX; ++k) {
+        ms[k] = 0.0f;
+        if (!h->launched[k]) continue;
+        HIPCK(hipEventSynchronize(h->ev_out[k]));
+        HIPCK(hipEventElapsedTime(&ms[k], h->ev_t0[k], h->ev_out[k]));
+    }
+    return 0;
+}
+
 extern "C" int gnnx_get_route(gnnx_handle h, int32_t* route) {
     if (!h || !route) return fail("null argument");
     for (int t = 0; t < h->prob.num_targets; ++t) route[t] = h->cat[t];
@@ -571,7 +590,7 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
         const int nb = m.ld / TILE;
         int c = 0;
         if (nb == 1 && h->res_nbmax >= 1) c = 1;
-        else if (sparse_fits(m.ld, h->nnz[2 * t], h->nnz[2 * t + 1], h->prob.D, h->prob.H, h->prob.C)) c = CAT_SPARSE;
+        else if (h->nnz[2 * t] >= 0 && sparse_fits(m.ld, h->nnz[2 * t], h->nnz[2 * t + 1], h->prob.D, h->prob.H, h->prob.C)) c = CAT_SPARSE;
         changed |= (c != h->cat[t]);
         h->cat[t] = c;
     }

@@ -36,10 +36,12 @@ constexpr int SP_GATHER_UNROLL = 2;          // entries in flight per lane in th
 constexpr int SP_CHUNK = 16;                 // entries per row slot: longer rows are split over adjacent lanes of one wave
 constexpr int SP_SLOTS = SP_THREADS / 2;     // row slots (two lanes = column halves per slot)
 
-// Row slots: row r takes ns(r) = max(1, ceil(deg(r) / SP_CHUNK)) consecutive slots that must not straddle a wave (32
-// slots).  Shared by k_count_edges (fit test) and the kernel (placement order: see "slot order" there).
+// Row slots: row r takes ns(r) = max(1, ceil(deg(r) / SP_CHUNK)) consecutive slots that must not straddle a 16-lane
+// DPP row (so ns <= 16, i.e. degree <= 256; the partial sums are combined with row shifts).  Shared by k_count_edges
+// (fit test) and the kernel (placement order: see "slot order" there).
 __host__ __device__ inline int sparse_slots_of(int deg) { return deg <= SP_CHUNK ? 1 : (deg + SP_CHUNK - 1) / SP_CHUNK; }
-__host__ __device__ inline int sparse_place(int pos, int ns) { return ((pos & 31) + ns > 32) ? ((pos + 31) & ~31) : pos; }
+constexpr int SP_MAX_SPLIT = 16;
+__host__ __device__ inline int sparse_place(int pos, int ns) { return ((pos & 15) + ns > 16) ? ((pos + 15) & ~15) : pos; }
 constexpr int SP_POOL_FLOATS = 39168;        // 153 KB of the CU's 160 KB; the rest holds SparseFixed
 
 // carve-out of the LDS pool (float offsets) for a target of ld rows and nnz directed entries
@@ -112,48 +114,57 @@ __device__ __forceinline__ int lower_bound_u16(const unsigned short* a, int lo, 
 // sparse row gather for the lane's row: acc[q] += sum_e Abar_e * f(B[col_e][2q + half]), columns < W <= 2 NQ.
 // Loads are unconditional (out-of-range columns are read from the padding / the next row and discarded by a select),
 // so the compiler can issue all of an entry group's loads before the first use.
+// max(x, 0) in one instruction (fmaxf costs two: it canonicalises its operands first)
+__device__ __forceinline__ float relu_(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+
 template <bool RELU, int NQ, bool EXACT>
 __device__ __forceinline__ void sparse_gather_impl(const float* sAb, const unsigned short* scol, const float* B, int stride,
                                                    int W, int e0, int e1, int half, float (&acc)[NQ]) {
     constexpr int UN = SP_GATHER_UNROLL;
-    int e = e0;
+    // Software pipeline over groups of UN entries: the (Abar, column) pairs of the NEXT group are loaded while the
+    // rows of the current one are in flight, so a group costs one LDS round trip, not two.  A short last group is
+    // padded with zero-weight copies of the row's first entry (no tail loop).
+    float a[UN];
+    int cl[UN];
+#pragma unroll
+    for (int j = 0; j < UN; ++j) {
+        const bool in = e0 + j < e1;
+        a[j] = in ? sAb[in ? e0 + j : e0] : 0.0f;
+        cl[j] = scol[in ? e0 + j : e0];
+    }
 #pragma unroll 1
-    for (; e + UN <= e1; e += UN) {  // UN entries in flight: their column -> row load chains are independent
-        float a[UN];
+    for (int e = e0; e < e1; e += UN) {
         const float* br[UN];
+        float ac[UN];
 #pragma unroll
         for (int j = 0; j < UN; ++j) {
-            a[j] = sAb[e + j];
-            br[j] = B + (int)scol[e + j] * stride + half;
+            br[j] = B + cl[j] * stride + half;
+            ac[j] = a[j];
         }
         float b[UN][NQ];
 #pragma unroll
         for (int j = 0; j < UN; ++j)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) b[j][q] = br[j][2 * q];
+        const int en = e + UN;
+        if (en < e1) {
+#pragma unroll
+            for (int j = 0; j < UN; ++j) {
+                const bool in = en + j < e1;
+                const int idx = in ? en + j : en;
+                a[j] = in ? sAb[idx] : 0.0f;
+                cl[j] = scol[idx];
+            }
+        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const bool ok = EXACT || 2 * q + half < W;
 #pragma unroll
             for (int j = 0; j < UN; ++j) {
                 float v = ok ? b[j][q] : 0.0f;
-                if (RELU) v = fmaxf(v, 0.0f);
-                acc[q] = fmaf(a[j], v, acc[q]);
+                if (RELU) v = relu_(v);
+                acc[q] = fmaf(ac[j], v, acc[q]);
             }
-        }
-    }
-#pragma unroll 1
-    for (; e < e1; ++e) {
-        const float a = sAb[e];
-        const float* br = B + (int)scol[e] * stride + half;
-        float b[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) b[q] = br[2 * q];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            float v = (EXACT || 2 * q + half < W) ? b[q] : 0.0f;
-            if (RELU) v = fmaxf(v, 0.0f);
-            acc[q] = fmaf(a, v, acc[q]);
         }
     }
 }
@@ -192,10 +203,11 @@ __device__ __forceinline__ void sparse_forward_rowlocal(const float (&zq)[NQ], c
     }
     ss += __shfl_xor(ss, 32);
     const float rnorm = fmaxf(sqrtf(ss), 1e-12f);
+    const float rinv = 1.0f / rnorm;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
         const int c = acc_row(g, h);
-        if (store && c < dout) sUrow[c] = c16[g] / rnorm;
+        if (store && c < dout) sUrow[c] = c16[g] * rinv;
     }
     if (store && h == 0) *srn_r = rnorm;
 }
@@ -225,15 +237,32 @@ __device__ __forceinline__ f32x16 sparse_backward_rowlocal(const float (&du)[NQ]
 
 // rows split over several slots: the first slot's lanes add the partial sums of the following lanes (same column half)
 // in slot order; wsplit = the wave's longest split (uniform), nsplit = this row's
-template <int NQ>
-__device__ __forceinline__ void sparse_combine(float (&acc)[NQ], int lane, bool first, int nsplit, int wsplit) {
-    for (int s = 1; s < wsplit; ++s) {
+// lane l <- value of lane l + S of the same 16-lane row (0 beyond the row): DPP row_shl, no LDS traffic
+template <int S>
+__device__ __forceinline__ float row_shl(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + S, 0xf, 0xf, true));
+}
+
+template <int NQ, int S>
+__device__ __forceinline__ void sparse_combine_step(float (&acc)[NQ], bool first, int nsplit, int wsplit) {
+    if constexpr (S < SP_MAX_SPLIT) {
+        if (S < wsplit) {  // uniform per wave
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const float v = __shfl(acc[q], lane + s);
-            if (first && s < nsplit) acc[q] += v;
+            for (int q = 0; q < NQ; ++q) {
+                const float v = row_shl<S>(acc[q]);
+                if (first && S < nsplit) acc[q] += v;
+            }
+            sparse_combine_step<NQ, S + 1>(acc, first, nsplit, wsplit);
         }
     }
+}
+
+// rows split over several slots: the first slot's lanes add the partial sums of the following lanes (same column half,
+// same 16-lane row) in slot order; wsplit = the wave's longest split (uniform), nsplit = this row's
+template <int NQ>
+__device__ __forceinline__ void sparse_combine(float (&acc)[NQ], int lane, bool first, int nsplit, int wsplit) {
+    (void)lane;
+    sparse_combine_step<NQ, 1>(acc, first, nsplit, wsplit);
 }
 
 // DQ >= ceil(D / 2), HQ >= ceil(H / 2): compile-time trip counts of the column loops (instantiated for the
@@ -374,6 +403,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
             const int d = rowptr[rr + 1] - rowptr[rr];
             if (d > SP_CHUNK) {
                 const int ns = sparse_slots_of(d);
+                if (ns > SP_MAX_SPLIT) sh.bad = 1;
                 pos = sparse_place(pos, ns);
                 order[p] = rr;
                 slot_start[p] = pos;
@@ -552,7 +582,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
             float z = 0.0f;
             if (li < H)
                 for (int e = rt0 + 2 * wave + h; e < rt1; e += 2 * NW)
-                    z = fmaf(sAb[e], fmaxf(sU2[(int)scol[e] * sH + li], 0.0f), z);
+                    z = fmaf(sAb[e], relu_(sU2[(int)scol[e] * sH + li]), z);
             z += __shfl_xor(z, 32);
             if (h == 0) sh.dfw[wave][li] = z;  // dfw is free until the layer-1 backward
         }
@@ -583,8 +613,8 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
             const float u3 = y / rnorm;  // U3[t][c] (both halves)
             if (h == 0) {
                 sh.e[64 + c] = u3;
-                sh.e[c] = (c < H) ? fmaxf(sU1[tr * sH + c], 0.0f) : 0.0f;
-                sh.e[32 + c] = (c < H) ? fmaxf(sU2[tr * sH + c], 0.0f) : 0.0f;
+                sh.e[c] = (c < H) ? relu_(sU1[tr * sH + c]) : 0.0f;
+                sh.e[32 + c] = (c < H) ? relu_(sU2[tr * sH + c]) : 0.0f;
             }
             wave_sync();
             {   // softmax head (explain.py:713-714, 750-753): g = p - onehot(y_gt); class = lane / 8, 12 terms per lane
@@ -649,7 +679,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
                 const int c = 2 * q + h;
                 const float u = (first && c < H) ? sU2[r * sH + c] : 0.0f;
                 const float dz = (c < H) ? sh.dz3[c] : 0.0f;
-                gpart = fmaf(dz, fmaxf(u, 0.0f), gpart);
+                gpart = fmaf(dz, relu_(u), gpart);
                 float dx = art * dz;
                 if (first && r == tr && c < H) dx += sh.dEs[32 + c];
                 du[q] = (u > 0.0f) ? dx : 0.0f;
@@ -697,12 +727,17 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
                 for (int q = 0; q < DQ; ++q)
                     if (first && 2 * q + h < D) dfq[q] = sdZ1[r * sD + 2 * q + h] * zraw[q];
             }
-            // colsum(dZ1 * Zraw): over the 32 rows of the wave, then over the waves in fixed order
+            // colsum(dZ1 * Zraw): over the 16 lanes of a DPP row (row shifts), the two rows of a half (one shuffle), then
+            // over the waves in fixed order
 #pragma unroll
             for (int q = 0; q < DQ; ++q) {
-#pragma unroll
-                for (int o = 1; o <= 16; o <<= 1) dfq[q] += __shfl_xor(dfq[q], o);
-                if (li == 0) sh.dfw[wave][2 * q + h] = dfq[q];
+                float v = dfq[q];
+                v += row_shl<8>(v);
+                v += row_shl<4>(v);
+                v += row_shl<2>(v);
+                v += row_shl<1>(v);
+                v += __shfl_xor(v, 16);
+                if (li == 0) sh.dfw[wave][2 * q + h] = v;
             }
         }
         __syncthreads();
@@ -735,8 +770,8 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
 #pragma unroll
                     for (int cc = 0; cc < 2 * HQ / 4; ++cc) {
                         const int c = c0 + cc;
-                        const float t2 = fmaf(sdZ2[i * sH + c], fmaxf(sU1[j * sH + c], 0.0f),
-                                              sdZ2[j * sH + c] * fmaxf(sU1[i * sH + c], 0.0f));
+                        const float t2 = fmaf(sdZ2[i * sH + c], relu_(sU1[j * sH + c]),
+                                              sdZ2[j * sH + c] * relu_(sU1[i * sH + c]));
                         G1 += (c < H) ? t2 : 0.0f;
                     }
                 }
@@ -797,6 +832,13 @@ __global__ __launch_bounds__(256) void k_count_edges(const TargetMeta* meta, con
     const TargetMeta tm = meta[blockIdx.x];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool small = tm.ld <= SP_LD_MAX;
+    if (!small) {  // cannot take the sparse kernel whatever its edge count: skip the scan
+        if (tid == 0) {
+            out[2 * blockIdx.x] = -1;
+            out[2 * blockIdx.x + 1] = -1;
+        }
+        return;
+    }
     int cnt = 0;
     for (int r = wave; r < tm.n; r += 4) {
         int d = 0;
@@ -815,15 +857,17 @@ __global__ __launch_bounds__(256) void k_count_edges(const TargetMeta* meta, con
         if (small) {
             pos = 0;
             int singles = 0;  // same placement as k_sparse_resident: split rows first, the others one slot each
+            bool placeable = true;
             for (int r = 0; r < tm.n; ++r) {
                 if (deg[r] > SP_CHUNK) {
                     const int ns = sparse_slots_of(deg[r]);
+                    placeable &= ns <= SP_MAX_SPLIT;
                     pos = sparse_place(pos, ns) + ns;
                 } else {
                     ++singles;
                 }
             }
-            pos += singles;
+            pos = placeable ? pos + singles : -1;
         }
         out[2 * blockIdx.x] = part[0] + part[1] + part[2] + part[3];
         out[2 * blockIdx.x + 1] = pos;

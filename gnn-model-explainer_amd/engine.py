@@ -91,6 +91,7 @@ _API = {
                  [ctypes.c_size_t, ctypes.c_void_p]),
     "gnnx_plan_analyze": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "gnnx_get_route": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
+    "gnnx_resident_times": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
     "gnnx_pack_csr": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int32] + [ctypes.c_void_p] * 7),
     "gnnx_forward": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_void_p] * 7 + [ctypes.c_size_t, ctypes.c_void_p]),
     "gnnx_time_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper), ctypes.c_int32, ctypes.c_int32] +
@@ -425,6 +426,12 @@ class MaskOptimJob:
                                                    self._stream(), ctypes.byref(ms), ctypes.byref(by), ctypes.byref(fl)))
         self._leave()
         return ms.value, by.value, fl.value
+
+    def resident_times(self):
+        """In-situ device time (ms) of the resident launches of the last launch(): [dense nb=1, nb=2, nb=3, sparse]."""
+        ms = (ctypes.c_float * 4)()
+        _check(self.lib, self.lib.gnnx_resident_times(self.handle, ms))
+        return [float(x) for x in ms]
 
     def route(self):
         """Kernel of every target: 0 dense streaming, 1..3 dense resident (row blocks), 4 sparse resident."""

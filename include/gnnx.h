@@ -106,6 +106,12 @@ int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream);
  * 1..3 = dense on-chip-resident kernel of that many 32-row blocks, 4 = sparse on-chip-resident kernel. */
 int gnnx_get_route(gnnx_handle h, int32_t* route);
 
+/* Measurement hook: device time (ms, HIP events on the side streams the kernels run on) of the on-chip-resident
+ * launches of the LAST gnnx_run, in situ (i.e. while the other kernels of that run were executing):
+ * ms[0..2] = dense resident kernels of 1..3 row blocks, ms[3] = sparse resident kernel; 0 where nothing was launched.
+ * Waits for those launches to finish. */
+int gnnx_resident_times(gnnx_handle h, float* ms);
+
 /* Device-side packing of the plan's sub-graphs from the full graph in CSR form (all pointers are DEVICE
  * pointers): replaces the host's dense slicing `adj[nb][:, nb]`, `feat[nb]`, `argmax(pred[nb])` of
  * Explainer.extract_neighborhood / explain (explain.py:492-501, 94-106) for the whole batch.

@@ -104,6 +104,14 @@ void wave_sync() {
     wave_collective([&](WaveSlot&, int, int) {});
 }
 
+int dpp_row_shl(int v, int shift) {
+    int buf = 0, lane = 0;
+    wave_collective([&](WaveSlot& w, int bf, int ln) { w.ia[bf][ln] = v; buf = bf; lane = ln; });
+    const int src = lane + shift;
+    if ((src >> 4) != (lane >> 4)) return 0;  // beyond the 16-lane row: bound_ctrl -> 0
+    return g_blk->waves[g_blk->cur >> 6].ia[buf][src];
+}
+
 int shfl_xor_i(int v, int mask) {
     int buf = 0, lane = 0;
     wave_collective([&](WaveSlot& w, int bf, int ln) { w.ia[bf][ln] = v; buf = bf; lane = ln; });

@@ -48,6 +48,7 @@ float shfl_f(float v, int src);
 int shfl_i(int v, int src);
 unsigned long long ballot(bool pred);
 void wave_sync();
+int dpp_row_shl(int v, int shift);
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 f32x16 mfma_32x32x2(float a, float b, f32x16 c);
 }  // namespace emu
@@ -62,8 +63,16 @@ inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline void __threadfence_block() {}
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() emu::wave_sync()
+// DPP row_shl:S (dpp_ctrl 0x100 + S, all rows / banks, bound_ctrl): lane l <- lane l + S of its 16-lane row, else 0
+inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    (void)old; (void)row_mask; (void)bank_mask; (void)bound_ctrl;
+    return emu::dpp_row_shl(src, ctrl - 0x100);
+}
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+inline float emu_fmed3f(float a, float b, float c) { return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c)); }
+#define __builtin_amdgcn_fmed3f(a, b, c) emu_fmed3f((a), (b), (c))
 #define __builtin_amdgcn_sqrtf(x) std::sqrt(x)
 #define __expf(x) std::exp(x)
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
