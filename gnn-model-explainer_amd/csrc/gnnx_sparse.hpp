@@ -180,10 +180,15 @@ __device__ __forceinline__ void sparse_gather(const float* sAb, const unsigned s
 }
 
 // forward row-local part for the lane's row: Y^T[c][r] = sum_k W[k][c] Z[r][k] on MFMA (the lane's registers zq[u] =
-// Z[r][2u + half] are the B operand of step u), + bias, L2 normalisation; U -> sU[r][c], norm -> srn[r]
-template <int NQ>
-__device__ __forceinline__ void sparse_forward_rowlocal(const float (&zq)[NQ], const float* sW, const float* bias, int din,
-                                                        int dout, int li, int h, bool store, float* sUrow, float* srn_r) {
+// Z[r][2u + half] are the B operand of step u), + bias, L2 normalisation; U -> sU[r][c], norm -> srn[r].
+// DOUT_C = dout when it is known at compile time (the column predicates of the epilogue fold away), else 0.
+template <int NQ, int DOUT_C>
+__device__ __forceinline__ void sparse_forward_rowlocal_impl(const float (&zq)[NQ], const float* sW, const float* bias, int din,
+                                                             int dout_rt, int li, int h, bool store, float* sUrow, float* srn_r) {
+    const int dout = DOUT_C ? DOUT_C : dout_rt;
+    float bv[16];  // bias of this lane's 16 columns: loaded before the MFMA chain, consumed after it
+#pragma unroll
+    for (int g = 0; g < 16; ++g) bv[g] = (DOUT_C && (g & 3) + 8 * (g >> 2) >= DOUT_C) ? 0.0f : bias[acc_row(g, h)];
     f32x16 c16;
 #pragma unroll
     for (int g = 0; g < 16; ++g) c16[g] = 0.0f;
@@ -198,18 +203,46 @@ __device__ __forceinline__ void sparse_forward_rowlocal(const float (&zq)[NQ], c
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
         const int c = acc_row(g, h);
-        c16[g] = (c < dout) ? c16[g] + bias[c] : 0.0f;
+        c16[g] = (c < dout) ? c16[g] + bv[g] : 0.0f;
         ss = fmaf(c16[g], c16[g], ss);
     }
     ss += __shfl_xor(ss, 32);
-    const float rnorm = fmaxf(sqrtf(ss), 1e-12f);
-    const float rinv = 1.0f / rnorm;
+    const float rnorm = fmaxf(__builtin_amdgcn_sqrtf(ss), 1e-12f);  // hardware forms, ~1 ulp (as in k_mask)
+    const float rinv = rcp_(rnorm);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
         const int c = acc_row(g, h);
+        if (DOUT_C && (g & 3) + 8 * (g >> 2) >= DOUT_C) continue;  // no lane of this register holds a real column
         if (store && c < dout) sUrow[c] = c16[g] * rinv;
     }
     if (store && h == 0) *srn_r = rnorm;
+}
+
+template <int NQ>
+__device__ __forceinline__ void sparse_forward_rowlocal(const float (&zq)[NQ], const float* sW, const float* bias, int din,
+                                                        int dout, int li, int h, bool store, float* sUrow, float* srn_r) {
+    if (dout == 20)  // the reference's hidden / output width
+        sparse_forward_rowlocal_impl<NQ, 20>(zq, sW, bias, din, dout, li, h, store, sUrow, srn_r);
+    else
+        sparse_forward_rowlocal_impl<NQ, 0>(zq, sW, bias, din, dout, li, h, store, sUrow, srn_r);
+}
+
+// row[k] = c16[g] for the columns k = acc_row(g, half) < kmax this lane holds; KC = kmax when known at compile time (the
+// registers that hold no real column for either half are skipped without a test), else 0
+template <int KC>
+__device__ __forceinline__ void sparse_store_cols_impl(const f32x16& c16, float* row, int kmax_rt, bool pred, int h) {
+    const int kmax = KC ? KC : kmax_rt;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        if (KC && (g & 3) + 8 * (g >> 2) >= KC) continue;
+        const int k = acc_row(g, h);
+        if (pred && k < kmax) row[k] = c16[g];
+    }
+}
+__device__ __forceinline__ void sparse_store_cols(const f32x16& c16, float* row, int kmax, bool pred, int h) {
+    if (kmax == 20) sparse_store_cols_impl<20>(c16, row, kmax, pred, h);       // hidden width of the reference
+    else if (kmax == 10) sparse_store_cols_impl<10>(c16, row, kmax, pred, h);  // input width of the reference
+    else sparse_store_cols_impl<0>(c16, row, kmax, pred, h);
 }
 
 // backward row-local part for the lane's row: dY = (dU - U (dU.U)) / r (dU, U in registers, columns 2q + half), then
@@ -221,7 +254,7 @@ __device__ __forceinline__ f32x16 sparse_backward_rowlocal(const float (&du)[NQ]
 #pragma unroll
     for (int q = 0; q < NQ; ++q) sdot = fmaf(du[q], uu[q], sdot);
     sdot += __shfl_xor(sdot, 32);
-    const float rinv = 1.0f / rnorm;
+    const float rinv = rcp_(rnorm);
     f32x16 c16;
 #pragma unroll
     for (int g = 0; g < 16; ++g) c16[g] = 0.0f;
@@ -241,6 +274,24 @@ __device__ __forceinline__ f32x16 sparse_backward_rowlocal(const float (&du)[NQ]
 template <int S>
 __device__ __forceinline__ float row_shl(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + S, 0xf, 0xf, true));
+}
+
+// lane 0 of every 16-lane row <- sum of the row (the other lanes hold partial sums)
+__device__ __forceinline__ float row_sum16(float v) {
+    v += row_shl<8>(v);
+    v += row_shl<4>(v);
+    v += row_shl<2>(v);
+    v += row_shl<1>(v);
+    return v;
+}
+// every lane <- the value of the first lane (through an SGPR)
+__device__ __forceinline__ float bcast_first(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+// every lane <- sum over lanes 0..31 (4 DPP shifts + one cross-row shuffle + SGPR broadcast instead of 5-6 ds_bpermute)
+__device__ __forceinline__ float sum_lanes_0_31(float v) {
+    const float r = row_sum16(v);
+    return bcast_first(r + __shfl_xor(r, 16));
 }
 
 template <int NQ, int S>
@@ -606,9 +657,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
                 if (H & 1) y0 = fmaf(sh.z3[H - 1], sW3[(H - 1) * 33 + c], y0);
                 y = y0 + y1 + sh.bias[2][c];
             }
-            float ss = (h == 0) ? y * y : 0.0f;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+            const float ss = sum_lanes_0_31(y * y);  // lanes 0..31 and 32..63 hold the same y
             const float rnorm = fmaxf(sqrtf(ss), 1e-12f);
             const float u3 = y / rnorm;  // U3[t][c] (both halves)
             if (h == 0) {
@@ -622,18 +671,22 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
                 float s = 0.0f;
                 if (cls < C)
                     for (int q = part * 12; q < part * 12 + 12; ++q) s = fmaf(sWp[cls * 96 + q], sh.e[q], s);
-                s += __shfl_xor(s, 1);
-                s += __shfl_xor(s, 2);
-                s += __shfl_xor(s, 4);
+                s += row_shl<4>(s);  // class sums in lanes 0, 8, .., 56
+                s += row_shl<2>(s);
+                s += row_shl<1>(s);
                 const float zc = __shfl(s, (lane & 7) * 8);
                 const float zl = (lane < C) ? zc + sh.sbp[lane] : -3.0e38f;
-                float mx = zl;
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                float mx = zl;  // max / sum over lanes 0..7 (C <= 8) end up in lane 0
+                mx = fmaxf(mx, row_shl<4>(mx));
+                mx = fmaxf(mx, row_shl<2>(mx));
+                mx = fmaxf(mx, row_shl<1>(mx));
+                mx = bcast_first(mx);
                 const float ex = (lane < C) ? expf(zl - mx) : 0.0f;
                 float sum = ex;
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+                sum += row_shl<4>(sum);
+                sum += row_shl<2>(sum);
+                sum += row_shl<1>(sum);
+                sum = bcast_first(sum);
                 if (lane < CMAX) sh.g[lane] = (lane < C) ? ex / sum - ((lane == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
             }
             wave_sync();
@@ -649,9 +702,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
             wave_sync();
             const float du3 = (h == 0 && c < O) ? sh.dEs[64 + c] : 0.0f;
             const float uq = (h == 0) ? u3 : 0.0f;
-            float s = du3 * uq;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+            const float s = sum_lanes_0_31(du3 * uq);
             const float dy3 = (du3 - uq * s) / rnorm;  // dY3[t][c] in lanes c < 32
             if (h == 0) sh.y3[c] = dy3;
             wave_sync();
@@ -688,11 +739,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
             gpart += __shfl_xor(gpart, 32);
             if (first && h == 0) sG3[r] = gpart;
             const f32x16 c16 = sparse_backward_rowlocal<HQ>(du, uu, first ? sRn2[r] : 1.0f, sW2, H, H, li, h);
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int k = acc_row(g, h);
-                if (first && k < H) sU2[r * sH + k] = c16[g];  // dZ2[r][k]: every U2 value of this row is already in registers
-            }
+            sparse_store_cols(c16, sU2 + r * sH, H, first, h);  // dZ2[r][.]: every U2 value of this row is already in registers
         }
         __syncthreads();
         const float* sdZ2 = sU2;
@@ -717,11 +764,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
                     uu[q] = u;
                 }
                 const f32x16 c16 = sparse_backward_rowlocal<HQ>(acc, uu, first ? sRn1[r] : 1.0f, sW1, D, H, li, h);
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int k = acc_row(g, h);
-                    if (first && k < D) sdZ1[r * sD + k] = c16[g];
-                }
+                sparse_store_cols(c16, sdZ1 + r * sD, D, first, h);
                 wave_sync();  // the other half-lane of this row wrote the columns this lane reads next
 #pragma unroll
                 for (int q = 0; q < DQ; ++q)

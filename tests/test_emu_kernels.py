@@ -214,3 +214,26 @@ def test_sparse_resident_kernel_full_run_vs_golden():
         assert np.abs(1 / (1 + np.exp(-res.feat_mask[i])) - gx[f"{t}:feat_mask_sigmoid"]).max() <= 1e-5
         assert np.array_equal(res.masked_adj[i], res.masked_adj[i].T)
         assert np.all(res.masked_adj[i][subs[i].adj == 0] == 0)
+
+
+def test_plan_routing_by_size_and_edge_count():
+    """gnnx_plan_analyze routes every target by what it finds in the packed adjacency (gnnx_get_route): n <= 32 -> dense
+    single-tile resident kernel (1), larger targets whose edge state fits one CU -> sparse resident kernel (4), dense
+    graphs with more than 2048 undirected edges -> streaming (0).  Without the analysis nothing is routed to 4."""
+    rng = np.random.default_rng(5)
+    sd = helpers.random_model(rng, 10, 20, 20, 4)
+
+    def sub(n, density):
+        A, X = helpers.random_graph(rng, n, 10, density=density)
+        return Subgraph(A, X, 1, 0, rng.integers(0, 4, n), np.ones((n, n), np.float32))
+
+    subs = [sub(20, 0.2), sub(60, 0.1), sub(200, 0.02), sub(120, 0.5)]
+    assert (subs[3].adj != 0).sum() // 2 > 2048
+    assert list(emu_job(subs, sd).route()) == [1, 4, 4, 0]
+    assert list(emu_job(subs, sd, analyze=False).route()) == [1, 0, 0, 0]
+    small = [sub(20, 0.2), sub(60, 0.1)]
+    assert list(emu_job(small, sd, analyze=False).route()) == [1, 2]      # all-small batch: dense resident kernels
+    res = emu_job(subs, sd).run([s.mask0 for s in subs], Hyper(num_iters=2))
+    for s_, ma in zip(subs, res.masked_adj):
+        o = closed_form.ClosedFormOracle(s_.adj, s_.feat, sd, s_.gt_label, s_.pred_label, s_.target_row, s_.mask0)
+        assert np.abs(ma - o.run(2)).max() < 5e-6

@@ -17,6 +17,17 @@ for k, a in enumerate(anchors):
     src = src.replace(a + "\n", "        PROBE(%d);\n" % k + a + "\n", 1)
     names.append(a.strip(" /="))
 k = len(anchors)
+# stamps inside sparse_forward_rowlocal (last call = layer 2 of the last iteration): entry, after the MFMA chain, after the
+# norm (shuffle + sqrt + rcp), after the stores
+src = src.replace("#define PROBE(k)", "#define PROBE2(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_probe[(k)] = wall_clock64(); } while (0)\n#define PROBE(k)", 1)
+fr = src.index("__device__ __forceinline__ void sparse_forward_rowlocal")
+seg_end = src.index("// backward row-local part", fr)
+seg = src[fr:seg_end]
+seg = seg.replace("    f32x16 c16;\n", "    PROBE2(8);\n    f32x16 c16;\n", 1)
+seg = seg.replace("    float ss = 0.0f;\n", "    PROBE2(9);\n    float ss = 0.0f;\n", 1)
+seg = seg.replace("    const float rinv = 1.0f / rnorm;\n", "    const float rinv = 1.0f / rnorm;\n    PROBE2(10);\n", 1)
+seg = seg.replace("    if (store && h == 0) *srn_r = rnorm;\n", "    if (store && h == 0) *srn_r = rnorm;\n    PROBE2(11);\n", 1)
+src = src[:fr] + seg + src[seg_end:]
 # finer stamps inside layer 2 (wave 0 = the hub rows): after the gather, after the split-row combine, after MFMA + epilogue
 SUB = 12
 l2 = "            sparse_gather<true, HQ>(sAb, scol, sU1, sH, H, re0, re1, h, acc);\n            sparse_combine<HQ>(acc, lane, first, nsplit, wsplit);\n"
@@ -57,5 +68,7 @@ for nme, v in zip(names, d):
     print("%-100s %7.2f us" % (nme[:100], v))
 print("iteration total %7.2f us" % ((a[len(names)] - a[0]) * 10.0 / 1e3))
 b = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
+print("forward row-local (layer 2, wave 0): MFMA chain %.2f us, bias + norm %.2f us, stores %.2f us" % (
+    (b[9] - b[8]) / 100.0, (b[10] - b[9]) / 100.0, (b[11] - b[10]) / 100.0))
 print("layer 2, wave 0: gather %.2f us, combine %.2f us, MFMA + epilogue %.2f us, wait at barrier %.2f us" % (
     (b[12] - b[1]) / 100.0, (b[13] - b[12]) / 100.0, (b[14] - b[13]) / 100.0, (b[2] - b[14]) / 100.0))
