@@ -212,11 +212,14 @@ def main():
                                      "avg_launch_us": {nm: x[0] * 1e3 for nm, x in zip(names, per)}}
         else:
             per = []
-        # resident launches: timed IN SITU (HIP events on the side streams they run on) during one more full step, so
+        # resident launches: timed IN SITU (HIP events on the side streams they run on) during five more full steps, so
         # the durations are those of the timed region's launches (the rocprofv3 kernel trace of this command shows the same)
-        step()
-        torch.cuda.synchronize()
-        rt = job.resident_times()
+        rts = []
+        for _ in range(5):
+            step()
+            torch.cuda.synchronize()
+            rts.append(job.resident_times())
+        rt = [float(np.mean(x)) for x in zip(*rts)]
         sel = lambda m: float(n2[m].sum())
         ms_sp, ms_r1 = rt[3], rt[0]
         by_sp, fl_sp = 28.0 * sel(route == 4) * args.iters, 6.0 * sel(route == 4) * kagg * args.iters
