@@ -130,12 +130,13 @@ static int build_split(gnnx_handle h) {
     };
     SPLITCK(upload(h->d_res, res_ids));
     SPLITCK(upload(h->d_sp, sp_ids));
-    if ((h->n_res || h->n_sp) && h->n_big) {
+    const bool any_resident = h->n_res || h->n_sp;
+    if (any_resident && h->n_big) {
         SPLITCK(upload(h->d_big, big_ids));
         SPLITCK(upload(h->d_conv_big, conv_big));
         SPLITCK(upload(h->d_mask_big, mask_big));
     }
-    if ((h->n_res || h->n_sp) && !h->ev_in) SPLITCK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+    if (any_resident && !h->ev_in) SPLITCK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     for (int k = 0; k <= RES_NBMAX; ++k) {
         const bool need = k < RES_NBMAX ? h->res_count[k + 1] > 0 : h->n_sp > 0;
         if (need && !h->side[k]) {
@@ -457,6 +458,21 @@ static int enqueue_job(gnnx_handle h, const Tables& tb, const gnnx_hyper* hy, co
     return 0;
 }
 
+// the sparse resident kernel, instantiated for the reference's encoders (node: D = 10, graph: D = 14; hidden 20) and
+// for the general 32-wide case
+static void launch_sparse(gnnx_handle h, const Params& p, const int32_t* ids, int cnt, const float* adam_tab, hipStream_t s) {
+    const dim3 grid(cnt), block(SP_THREADS);
+    const int D = h->prob.D, HO = std::max(h->prob.H, h->prob.O);
+    if (h->prob.graph_mode) {
+        if (D <= 14 && HO <= 20) hipLaunchKernelGGL((k_sparse_resident<7, 10, true>), grid, block, 0, s, p, ids, adam_tab);
+        else hipLaunchKernelGGL((k_sparse_resident<16, 16, true>), grid, block, 0, s, p, ids, adam_tab);
+    } else {
+        if (D <= 10 && HO <= 20) hipLaunchKernelGGL((k_sparse_resident<5, 10, false>), grid, block, 0, s, p, ids, adam_tab);
+        else hipLaunchKernelGGL((k_sparse_resident<16, 16, false>), grid, block, 0, s, p, ids, adam_tab);
+    }
+}
+
+
 extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, const float* X, const float* yhat,
                         float* M, float* Abar, float* feat_mask, float* loss, void* workspace,
                         size_t workspace_bytes, void* stream) {
@@ -484,16 +500,13 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
             h->adam_for = *hy;
         }
         if (h->n_sp) {  // targets whose edge state fits one CU: sparse resident kernel (gnnx_plan_analyze).  Submitted FIRST:
-            // its workgroups need a whole CU's LDS, so they must be placed before the small dense-resident workgroups
-            // spread over every CU (measured on syn1: 21.5 -> see DESIGN.md)
+            // its workgroups need a whole CU (LDS and registers), so they must be placed before the small dense-resident
+            // workgroups spread over every CU (measured on syn1: 21.5 -> 13.4 ms)
             hipStream_t ss = h->side[RES_NBMAX];
             HIPCK(hipStreamWaitEvent(ss, h->ev_in, 0));
             HIPCK(hipEventRecord(h->ev_t0[RES_NBMAX], ss));
             h->launched[RES_NBMAX] = true;
-            if (h->prob.D <= 10 && h->prob.H <= 20)  // the reference's encoder (hidden 20, 10 input features)
-                hipLaunchKernelGGL((k_sparse_resident<5, 10>), dim3(h->n_sp), dim3(SP_THREADS), 0, ss, p, h->d_sp, h->d_adam);
-            else
-                hipLaunchKernelGGL((k_sparse_resident<16, 16>), dim3(h->n_sp), dim3(SP_THREADS), 0, ss, p, h->d_sp, h->d_adam);
+            launch_sparse(h, p, h->d_sp, h->n_sp, h->d_adam, ss);
             HIPCK(hipEventRecord(h->ev_out[RES_NBMAX], ss));
         }
         for (int nb = RES_NBMAX; nb >= 1; --nb) {  // largest targets first; each group on its own stream
@@ -577,8 +590,8 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
     h->nnz.resize(2 * (size_t)T);  // (directed entries, row slots) per target
     HIPCK(hipMemcpyAsync(h->nnz.data(), h->d_nnz, sizeof(int32_t) * 2 * T, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
-    const bool resident_ok = !h->prob.graph_mode && h->prob.C <= RES_CMAX;
-    if (!resident_ok) return 0;
+    const bool graph = h->prob.graph_mode != 0;
+    if (h->prob.C > RES_CMAX) return 0;
     int sparse_on = 1;
     if (const char* env = std::getenv("GNNX_SPARSE_RESIDENT")) sparse_on = std::atoi(env);
     if (!sparse_on) return 0;
@@ -589,8 +602,10 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
         const TargetMeta& m = h->meta[t];
         const int nb = m.ld / TILE;
         int c = 0;
-        if (nb == 1 && h->res_nbmax >= 1) c = 1;
-        else if (h->nnz[2 * t] >= 0 && sparse_fits(m.ld, h->nnz[2 * t], h->nnz[2 * t + 1], h->prob.D, h->prob.H, h->prob.C)) c = CAT_SPARSE;
+        if (!graph && nb == 1 && h->res_nbmax >= 1) c = 1;  // the dense resident kernels are node-mode kernels
+        else if (h->nnz[2 * t] >= 0 &&
+                 sparse_fits(m.ld, h->nnz[2 * t], h->nnz[2 * t + 1], h->prob.D, h->prob.H, h->prob.C, graph, h->prob.O))
+            c = CAT_SPARSE;
         changed |= (c != h->cat[t]);
         h->cat[t] = c;
     }
@@ -658,10 +673,8 @@ extern "C" int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hy, int32_t kin
         auto launch = [&]() {
             if (kind == 9)
                 hipLaunchKernelGGL(k_resident<1>, dim3(cnt), dim3(256), 0, s, p, h->d_res + h->res_first[1], d_tab);
-            else if (h->prob.D <= 10 && h->prob.H <= 20)
-                hipLaunchKernelGGL((k_sparse_resident<5, 10>), dim3(cnt), dim3(SP_THREADS), 0, s, p, h->d_sp, d_tab);
             else
-                hipLaunchKernelGGL((k_sparse_resident<16, 16>), dim3(cnt), dim3(SP_THREADS), 0, s, p, h->d_sp, d_tab);
+                launch_sparse(h, p, h->d_sp, cnt, d_tab, s);
         };
         launch();  // warm
         HIPCK(hipEventRecord(e0, s));

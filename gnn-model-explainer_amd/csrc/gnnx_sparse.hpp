@@ -42,21 +42,29 @@ constexpr int SP_SLOTS = SP_THREADS / 2;     // row slots (two lanes = column ha
 __host__ __device__ inline int sparse_slots_of(int deg) { return deg <= SP_CHUNK ? 1 : (deg + SP_CHUNK - 1) / SP_CHUNK; }
 constexpr int SP_MAX_SPLIT = 16;
 __host__ __device__ inline int sparse_place(int pos, int ns) { return ((pos & 15) + ns > 16) ? ((pos + 15) & ~15) : pos; }
-constexpr int SP_POOL_FLOATS = 39168;        // 153 KB of the CU's 160 KB; the rest holds SparseFixed
+constexpr int SP_POOL_FLOATS = 39168;        // 153 KB of the CU's 160 KB; the rest holds SparseFixed.  (A second, 73 KB
+                                             // instantiation for small targets was measured and dropped: 1024 threads x 128
+                                             // VGPRs fill the CU's register file, so two workgroups never share a CU anyway.)
 
 // carve-out of the LDS pool (float offsets) for a target of ld rows and nnz directed entries
 struct SparseLayout {
-    int sD, sH;  // row strides (odd: conflict-free row-strided access)
-    int oX, oU1, oU2, odZ1, oAb, oCol, oRowptr, oArt, oRn1, oRn2, oYhat, oG3, oW, oWp, total;
+    int sD, sH, sO;  // row strides (odd: conflict-free row-strided access)
+    int oX, oU1, oU2, oU3, odZ2, odZ1, oAb, oCol, oRowptr, oArt, oRn1, oRn2, oRn3, oYhat, oG3, oW, oWp, total;
 };
-__host__ __device__ inline SparseLayout sparse_layout(int ld, int nnz, int D, int H, int C) {
+// graph = 0: node mode (GcnEncoderNode: only row t of layer 3 is needed; dZ2 overwrites U2);
+// graph = 1: graph mode (GcnEncoderGraph: all three layers in full, U3 [ld][max(H, O)] overwritten by dZ3, dZ2 separate)
+__host__ __device__ inline SparseLayout sparse_layout(int ld, int nnz, int D, int H, int C, int graph = 0, int O = 0) {
     SparseLayout L;
     L.sD = D | 1;
     L.sH = H | 1;
+    L.sO = (O > H ? O : H) | 1;
     int o = 0;
     L.oX = o;      o += ld * L.sD;
     L.oU1 = o;     o += ld * L.sH;
-    L.oU2 = o;     o += ld * L.sH;   // U2, overwritten row by row with dZ2 once the row's U2 has been consumed
+    L.oU2 = o;     o += ld * L.sH;   // U2; node mode: overwritten row by row with dZ2 once the row's U2 has been consumed
+    L.oU3 = o;     o += graph ? ld * L.sO : 0;
+    L.odZ2 = graph ? o : L.oU2;
+    o += graph ? ld * L.sH : 0;
     L.odZ1 = o;    o += ld * L.sD;
     L.oAb = o;     o += nnz;
     L.oCol = o;    o += (nnz + 1) / 2;  // uint16 columns
@@ -64,6 +72,7 @@ __host__ __device__ inline SparseLayout sparse_layout(int ld, int nnz, int D, in
     L.oArt = o;    o += ld;
     L.oRn1 = o;    o += ld;
     L.oRn2 = o;    o += ld;
+    L.oRn3 = o;    o += graph ? ld : 0;
     L.oYhat = o;   o += ld;
     L.oG3 = o;     o += ld;
     L.oW = o;      o += (D + 2 * H) * 33;  // rows k < D of W1, k < H of W2, k < H of W3, 33-float rows
@@ -71,9 +80,9 @@ __host__ __device__ inline SparseLayout sparse_layout(int ld, int nnz, int D, in
     L.total = o;
     return L;
 }
-__host__ __device__ inline bool sparse_fits(int ld, int nnz, int slots, int D, int H, int C) {
+__host__ __device__ inline bool sparse_fits(int ld, int nnz, int slots, int D, int H, int C, int graph = 0, int O = 0) {
     return ld <= SP_LD_MAX && nnz / 2 <= SP_E_MAX && nnz < 65536 && slots >= 0 && slots <= SP_SLOTS && C <= RES_CMAX &&
-           H >= 2 && sparse_layout(ld, nnz, D, H, C).total <= SP_POOL_FLOATS;
+           H >= 2 && sparse_layout(ld, nnz, D, H, C, graph, O).total <= SP_POOL_FLOATS;
 }
 
 struct SparseFixed {
@@ -82,6 +91,7 @@ struct SparseFixed {
     float z3[32], y3[32], dz3[32], e[96], g[CMAX], dEs[96], dfp[32], dfw[SP_THREADS / 64][32];
     float sr3;
     int nnz, eup, bad, slots;
+    int erow[96];  // graph mode: arg-max row of every pooled column
 };
 
 // every lane of a wave has finished its LDS accesses before any lane continues (LDS operations of one wave
@@ -316,9 +326,10 @@ __device__ __forceinline__ void sparse_combine(float (&acc)[NQ], int lane, bool 
     sparse_combine_step<NQ, 1>(acc, first, nsplit, wsplit);
 }
 
-// DQ >= ceil(D / 2), HQ >= ceil(H / 2): compile-time trip counts of the column loops (instantiated for the
-// reference's D = 10, H = 20 and for the general 32-wide case)
-template <int DQ, int HQ>
+// DQ >= ceil(D / 2), HQ >= ceil(max(H, O) / 2): compile-time trip counts of the column loops (instantiated for the
+// reference's encoders and for the general 32-wide case).  GRAPH: GcnEncoderGraph (models.py:269-316: three full
+// layers, per-layer max-pool over all rows, no Laplacian term) instead of GcnEncoderNode (models.py:363-376).
+template <int DQ, int HQ, bool GRAPH>
 __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const int32_t* targets, const float* adam_tab) {
     __shared__ float pool[SP_POOL_FLOATS];
     __shared__ SparseFixed sh;
@@ -366,7 +377,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
     }
     __syncthreads();
     const int nnz = ld_ok ? sh.nnz : 0;
-    const bool fits = ld_ok && sparse_fits(ld, nnz, 0, D, H, C);  // the slot count is checked once the slots are placed
+    const bool fits = ld_ok && sparse_fits(ld, nnz, 0, D, H, C, GRAPH, O);  // the slot count is checked once the slots are placed
     if (!fits) {
         // the plan promised a target that fits (gnnx_plan_analyze); anything else must fail loudly, not silently
         const float qnan = __builtin_nanf("");
@@ -374,7 +385,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
         if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = qnan;
         return;
     }
-    const SparseLayout L = sparse_layout(ld, nnz, D, H, C);
+    const SparseLayout L = sparse_layout(ld, nnz, D, H, C, GRAPH, O);
     // rowptr currently sits at the start of the pool = inside the future sX region: move it through registers
     const int rp_keep = (tid < ld) ? tmp_deg[tid] : nnz;
     __syncthreads();
@@ -384,7 +395,10 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
     __syncthreads();
     float* sX = pool + L.oX;
     float* sU1 = pool + L.oU1;
-    float* sU2 = pool + L.oU2;   // == sdZ2 (see SparseLayout)
+    float* sU2 = pool + L.oU2;   // node mode: == sdZ2 (see SparseLayout)
+    float* sU3 = pool + L.oU3;   // graph mode only: U3, then dZ3
+    float* sdZ2w = pool + L.odZ2;
+    float* sRn3 = pool + L.oRn3;
     float* sdZ1 = pool + L.odZ1;
     float* sAb = pool + L.oAb;
     unsigned short* scol = reinterpret_cast<unsigned short*>(pool + L.oCol);
@@ -397,7 +411,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
     float* sW2 = sW1 + D * 33;
     float* sW3 = sW2 + H * 33;
     float* sWp = pool + L.oWp;
-    const int sD = L.sD, sH = L.sH;
+    const int sD = L.sD, sH = L.sH, sO = L.sO;
 
     // ---------------- setup 2: sorted column lists ----------------
     for (int r = wave; r < n; r += NW) {
@@ -543,7 +557,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
                 Mji[q] = Mg[(size_t)j * ld + i];
                 const int t0 = rowptr[tr], t1 = rowptr[tr + 1];
                 const int pi = lower_bound_u16(scol, t0, t1, i), pj = lower_bound_u16(scol, t0, t1, j);
-                near[q] = i == tr || j == tr || (pi < t1 && (int)scol[pi] == i) || (pj < t1 && (int)scol[pj] == j);
+                near[q] = GRAPH || i == tr || j == tr || (pi < t1 && (int)scol[pi] == i) || (pj < t1 && (int)scol[pj] == j);
             }
         }
         if (asym) sh.bad = 1;  // benign race: every writer stores 1
@@ -567,7 +581,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
     if (tid < 96) sh.bias[tid >> 5][tid & 31] = p.wts[WT_B + tid];
     for (int e = tid; e < C * 96; e += SP_THREADS) sWp[e] = p.wts[WT_WP + e];
     if (tid < CMAX) sh.sbp[tid] = p.wts[WT_BP + tid];
-    if (tid < ld) sYhat[tid] = p.yhat[tm.offR + tid];
+    if (tid < ld) sYhat[tid] = GRAPH ? 0.0f : p.yhat[tm.offR + tid];  // graph mode has no Laplacian term (explain.py:780)
     if (tid < 32) {
         sh.fcur[tid] = 0.0f;  // construct_feat_mask: constant 0 (explain.py:639-641)
         sh.mf[tid] = 0.0f;
@@ -597,7 +611,8 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
     for (int iter = 0; iter < p.num_iters; ++iter) {
         if (tid < 32) sh.phi[tid] = (tid < D) ? sigmoidf_(sh.fcur[tid]) : 0.0f;
         // Abar[t][.] as a dense row (rank-1 layer-3 backward): scatter row t's entries (sArt was zeroed by publish_abar)
-        for (int e = rt0 + tid; e < rt1; e += SP_THREADS) sArt[scol[e]] = sAb[e];
+        if (!GRAPH)
+            for (int e = rt0 + tid; e < rt1; e += SP_THREADS) sArt[scol[e]] = sAb[e];
         __syncthreads();
         const float step_size = adam_tab[2 * iter], inv_bc2s = 1.0f / adam_tab[2 * iter + 1];
 
@@ -628,6 +643,117 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
             sparse_forward_rowlocal<HQ>(acc, sW2, sh.bias[1], H, H, li, h, first, sU2 + r * sH, sRn2 + r);
         }
         __syncthreads();
+        if constexpr (GRAPH) {
+        // ======== graph mode: layer 3 in full (no ReLU), U3 ========
+        if (wave_active) {
+            float acc[HQ];
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
+            sparse_gather<true, HQ>(sAb, scol, sU2, sH, H, re0, re1, h, acc);
+            sparse_combine<HQ>(acc, lane, first, nsplit, wsplit);
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) acc[q] = first ? acc[q] : 0.0f;
+            sparse_forward_rowlocal<HQ>(acc, sW3, sh.bias[2], H, O, li, h, first, sU3 + r * sO, sRn3 + r);
+        }
+        __syncthreads();
+        // ======== graph mode: per-layer max-pool over ALL n rows (models.py:283, 291, 300; first maximal row wins), head, dE ========
+        if (wave < 2) {  // lane = pooled column (96 of them), rows scanned in order: no cross-lane reduction needed
+            const int col = wave * 64 + lane;
+            if (col < 96) {
+                const int l = col >> 5, c = col & 31;
+                const float* arr = (l == 0) ? sU1 : (l == 1) ? sU2 : sU3;
+                const int stride = (l == 2) ? sO : sH;
+                float best = -3.0e38f;
+                int barg = 0;
+                if (c < ((l == 2) ? O : H)) {
+                    for (int i = 0; i < n; ++i) {
+                        float v = arr[i * stride + c];
+                        if (l < 2) v = relu_(v);
+                        if (v > best) {
+                            best = v;
+                            barg = i;
+                        }
+                    }
+                } else {
+                    best = 0.0f;
+                }
+                sh.e[col] = best;
+                sh.erow[col] = barg;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {  // softmax head (explain.py:710-711, 750-753): g = p - onehot(label), dE = Wp^T g
+            {
+                const int cls = lane >> 3, part = lane & 7;
+                float s = 0.0f;
+                if (cls < C)
+                    for (int q = part * 12; q < part * 12 + 12; ++q) s = fmaf(sWp[cls * 96 + q], sh.e[q], s);
+                s += row_shl<4>(s);
+                s += row_shl<2>(s);
+                s += row_shl<1>(s);
+                const float zc = __shfl(s, (lane & 7) * 8);
+                const float zl = (lane < C) ? zc + sh.sbp[lane] : -3.0e38f;
+                float mx = zl;
+                mx = fmaxf(mx, row_shl<4>(mx));
+                mx = fmaxf(mx, row_shl<2>(mx));
+                mx = fmaxf(mx, row_shl<1>(mx));
+                mx = bcast_first(mx);
+                const float ex = (lane < C) ? expf(zl - mx) : 0.0f;
+                float sum = ex;
+                sum += row_shl<4>(sum);
+                sum += row_shl<2>(sum);
+                sum += row_shl<1>(sum);
+                sum = bcast_first(sum);
+                if (lane < CMAX) sh.g[lane] = (lane < C) ? ex / sum - ((lane == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
+            }
+            wave_sync();
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const int idx = lane + 64 * part;
+                if (idx < 96) {
+                    float s = 0.0f;
+                    for (int cc = 0; cc < C; ++cc) s = fmaf(sWp[cc * 96 + idx], sh.g[cc], s);
+                    sh.dEs[idx] = s;
+                }
+            }
+        }
+        __syncthreads();
+        // ======== graph mode: dZ3 (row-local backward of layer 3; dE3 lands on the arg-max rows), overwrites U3 ========
+        if (wave_active) {
+            float du[HQ], uu[HQ];
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) {
+                const int c = 2 * q + h;
+                const bool in = first && c < O;
+                uu[q] = in ? sU3[r * sO + c] : 0.0f;
+                du[q] = (in && sh.erow[64 + c] == r) ? sh.dEs[64 + c] : 0.0f;
+            }
+            const f32x16 c16 = sparse_backward_rowlocal<HQ>(du, uu, first ? sRn3[r] : 1.0f, sW3, H, O, li, h);
+            sparse_store_cols(c16, sU3 + r * sO, H, first, h);  // dZ3[r][.]
+        }
+        __syncthreads();
+        // ======== graph mode: dX2 = Abar . dZ3 (+ dE2 on the arg-max rows) -> dZ2 ========
+        if (wave_active) {
+            float acc[HQ], uu[HQ];
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
+            sparse_gather<false, HQ>(sAb, scol, sU3, sO, H, re0, re1, h, acc);
+            sparse_combine<HQ>(acc, lane, first, nsplit, wsplit);
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) {
+                const int c = 2 * q + h;
+                const bool in = first && c < H;
+                const float u = in ? sU2[r * sH + c] : 0.0f;
+                float dx = acc[q];
+                if (in && sh.erow[32 + c] == r) dx += sh.dEs[32 + c];
+                acc[q] = (u > 0.0f) ? dx : 0.0f;
+                uu[q] = u;
+            }
+            const f32x16 c16 = sparse_backward_rowlocal<HQ>(acc, uu, first ? sRn2[r] : 1.0f, sW2, H, H, li, h);
+            sparse_store_cols(c16, sdZ2w + r * sH, H, first, h);
+        }
+        __syncthreads();
+        } else {
         // ======== row t of layer 3 (the only row the reference reads, explain.py:713), head, dE, dZ3[t] ========
         {   // row t of Abar . relu(U2): its entries dealt over the 16 waves, lane = column; partials summed in wave order
             float z = 0.0f;
@@ -742,7 +868,8 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
             sparse_store_cols(c16, sU2 + r * sH, H, first, h);  // dZ2[r][.]: every U2 value of this row is already in registers
         }
         __syncthreads();
-        const float* sdZ2 = sU2;
+        }
+        const float* sdZ2 = sdZ2w;  // node mode: the U2 array (overwritten above); graph mode: its own array
         // ======== dX1 = Abar . dZ2 (+ dE1 on row t) -> dZ1 ; feature-mask gradient partials ========
         {
             float dfq[DQ];
@@ -759,7 +886,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
                     const int c = 2 * q + h;
                     const float u = (first && c < H) ? sU1[r * sH + c] : 0.0f;
                     float dx = acc[q];
-                    if (first && r == tr && c < H) dx += sh.dEs[c];
+                    if (GRAPH ? (first && c < H && sh.erow[c] == r) : (first && r == tr && c < H)) dx += sh.dEs[c];
                     acc[q] = (u > 0.0f) ? dx : 0.0f;
                     uu[q] = u;
                 }
@@ -819,8 +946,22 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
                     }
                 }
                 float G = G0 + G1;
-                G += (i == tr) ? sG3[j] : 0.0f;
-                G += (j == tr) ? sG3[i] : 0.0f;
+                if constexpr (GRAPH) {
+                    float G2 = 0.0f;  // layer 3: dZ3 . relu(U2)
+#pragma unroll 1
+                    for (int c0 = 0; c0 < 2 * HQ; c0 += 2 * HQ / 4) {
+#pragma unroll
+                        for (int cc = 0; cc < 2 * HQ / 4; ++cc) {
+                            const int c = c0 + cc;
+                            const float t3 = fmaf(sU3[i * sO + c], relu_(sU2[j * sH + c]), sU3[j * sO + c] * relu_(sU2[i * sH + c]));
+                            G2 += (c < H) ? t3 : 0.0f;
+                        }
+                    }
+                    G += G2;
+                } else {
+                    G += (i == tr) ? sG3[j] : 0.0f;
+                    G += (j == tr) ? sG3[i] : 0.0f;
+                }
                 const float dy = sYhat[i] - sYhat[j];
                 const float gc = (0.5f * G + p.c_lap * 0.5f * dy * dy * inv_n2) * wgt[q];
                 {

@@ -277,7 +277,7 @@ class MaskOptimJob:
         self._create_plan(rows, labels)
         self._alloc_device()
         self._pack(subgraphs)
-        if analyze and not self.graph_mode:
+        if analyze:
             self.analyze()
 
     def _init_model(self, state_dict):

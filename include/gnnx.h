@@ -95,7 +95,8 @@ int gnnx_run(gnnx_handle h, const gnnx_hyper* hyper, const float* A, const float
 
 /* Inspect the packed adjacency A (DEVICE pointer, the layout of gnnx_get_layout) and choose the kernel of every target:
  * node-mode targets with n <= 32 keep the dense on-chip-resident kernel; larger ones whose EDGE state fits one
- * compute unit (n <= 384, <= 2048 undirected edges, LDS budget) take the sparse on-chip-resident kernel, which
+ * compute unit (n <= 512, <= 2048 undirected edges, rows of <= 256 entries, LDS budget; graph mode too) take the
+ * sparse on-chip-resident kernel, which
  * optimises only the mask entries on edges - the only ones that reach an output of the reference
  * (explain.py:665-678, 209-211; non-edge entries of M then keep their initial values); the rest streams.
  * Optional: without this call the plan uses the split described at gnnx_hyper.use_resident.  Synchronises `stream`.

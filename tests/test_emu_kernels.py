@@ -179,6 +179,8 @@ def test_device_side_packing_equals_host_packing():
     (7, 13, 9, 3, 130, False, "sparse"),      # odd widths, 5 row blocks (two per wave for wave 0)
     (14, 20, 20, 2, 40, True, "stream"),      # graph mode
     (3, 9, 17, 9, 33, True, "stream"),        # graph mode, odd widths, more classes than the resident paths take
+    (14, 20, 20, 2, 40, True, "sparse"),      # graph mode in the sparse resident kernel (three full layers, max-pool head)
+    (3, 9, 17, 5, 70, True, "sparse"),        # ... odd widths, O > H
 ])
 def test_generic_shapes_match_closed_form(D, H, O, C, n, graph_mode, path):
     rng = np.random.default_rng(D * 1000 + H * 10 + n)

@@ -195,6 +195,7 @@ def test_resident_only_batch_is_deterministic():
     (5, 32, 32, 6, 45, False, "resident"), (5, 32, 32, 6, 45, False, "sparse"), (31, 8, 3, 2, 70, False, "stream"),
     (31, 8, 3, 2, 70, False, "resident"), (31, 8, 3, 2, 70, False, "sparse"), (10, 20, 20, 4, 96, False, "resident"),
     (7, 13, 9, 3, 130, False, "sparse"), (14, 20, 20, 2, 40, True, "stream"), (3, 9, 17, 9, 33, True, "stream"),
+    (14, 20, 20, 2, 40, True, "sparse"), (3, 9, 17, 5, 70, True, "sparse"),
     (10, 20, 20, 4, 300, False, "stream"), (10, 20, 20, 4, 300, False, "sparse"), (10, 20, 20, 4, 400, False, "sparse"),
 ])
 def test_generic_shapes_match_closed_form(D, H, O, C, n, graph_mode, path):
