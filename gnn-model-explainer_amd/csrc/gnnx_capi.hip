@@ -137,6 +137,8 @@ static int build_split(gnnx_handle h) {
         SPLITCK(upload(h->d_mask_big, mask_big));
     }
     if (any_resident && !h->ev_in) SPLITCK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+    // (Disjoint compute-unit masks for the sparse and the single-tile dense launch - hipExtStreamCreateWithCUMask - were
+    // measured on syn1 and made the sparse launch slower, 9.7 vs 6.4 ms in situ: not used.)
     for (int k = 0; k <= RES_NBMAX; ++k) {
         const bool need = k < RES_NBMAX ? h->res_count[k + 1] > 0 : h->n_sp > 0;
         if (need && !h->side[k]) {

@@ -85,12 +85,19 @@ __host__ __device__ inline bool sparse_fits(int ld, int nnz, int slots, int D, i
            H >= 2 && sparse_layout(ld, nnz, D, H, C, graph, O).total <= SP_POOL_FLOATS;
 }
 
+// a lane's row slot in one row set: the row (valid when first), its chunk of entries, the split bookkeeping
+struct RowSlot {
+    int row, e0, e1, nsplit, wsplit;
+    bool first, wave_active;
+};
+
 struct SparseFixed {
     float sbp[CMAX];
     float phi[32], fcur[32], mf[32], vf[32], bias[3][32];
     float z3[32], y3[32], dz3[32], e[96], g[CMAX], dEs[96], dfp[32], dfw[SP_THREADS / 64][32];
     float sr3;
-    int nnz, eup, bad, slots;
+    int nnz, eup, bad;
+    int set_rows[2], set_slots[2];
     int erow[96];  // graph mode: arg-max row of every pooled column
 };
 
@@ -456,15 +463,36 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
             sh.eup = incl;
         }
     }
-    // Row slots in "slot order": rows longer than SP_CHUNK first (row order, never straddling a wave), then the other
-    // rows by decreasing degree, so that the 32 slots of a wave have (nearly) equal trip counts in the gathers.
-    int* slot_start = upptr + ld + 1;     // [n + 1] first slot of the p-th row in slot order
-    int* order = slot_start + ld + 1;     // [n]     the p-th row in slot order
-    int* bucket = order + ld;             // [SP_CHUNK + 1] counting-sort cursors
-    if (tid == 0) {
-        int pos = 0, p = 0;
+    // Hop levels (node mode).  Row t of layer 3 is all the reference reads (explain.py:713), and every layer is
+    // row-local apart from the contraction with Abar, so layer 2 is needed only on t and its neighbours (level <= 1) and
+    // layer 1 only on rows within two hops (level <= 2); the same holds for their gradients (dZ2 / dZ1 are exactly zero
+    // elsewhere).  On syn1's largest target (n = 310) that is 5 and 69 rows.  The other rows - the third hop - still own
+    // mask entries, which keep receiving their regulariser gradients in the edge phase.  Graph mode pools over all rows.
+    int* level = upptr + ld + 1;  // [ld]
+    if (tid < ld) level[tid] = (GRAPH || tid == tr) ? 0 : 3;
+    __syncthreads();
+    if (!GRAPH)
+        for (int d = 1; d <= 2; ++d) {
+            if (tid < n && level[tid] == d - 1)
+                for (int e = rowptr[tid]; e < rowptr[tid + 1]; ++e)
+                    if (level[scol[e]] > d) level[scol[e]] = d;  // benign race: every writer stores d
+            __syncthreads();
+        }
+    // Row slots in "slot order", one table per row set (A: level <= 2, layer 1 and its backward; B: level <= 1, layer 2
+    // and its backward): rows longer than SP_CHUNK first (row order, never straddling a 16-lane DPP row), then the
+    // other rows by decreasing degree, so that the 32 slots of a wave have (nearly) equal trip counts in the gathers.
+    int* slot_tab = level + ld;  // per set: slot_start [ld + 1], order [ld], bucket [SP_CHUNK + 1]
+    constexpr int NSET = GRAPH ? 1 : 2;
+    if (lane == 0 && wave < NSET) {  // one thread per set, in different waves
+        const int lvlmax = GRAPH ? 9 : 2 - wave;
+        int* slot_start = slot_tab + wave * (2 * ld + SP_CHUNK + 2);
+        int* order = slot_start + ld + 1;
+        int* bucket = order + ld;
+        int pos = 0, p = 0, cnt = 0;
         for (int d = 0; d <= SP_CHUNK; ++d) bucket[d] = 0;
         for (int rr = 0; rr < n; ++rr) {
+            if (level[rr] > lvlmax) continue;
+            ++cnt;
             const int d = rowptr[rr + 1] - rowptr[rr];
             if (d > SP_CHUNK) {
                 const int ns = sparse_slots_of(d);
@@ -485,45 +513,59 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
             run += c;
         }
         for (int rr = 0; rr < n; ++rr) {
+            if (level[rr] > lvlmax) continue;
             const int d = rowptr[rr + 1] - rowptr[rr];
             if (d <= SP_CHUNK) order[bucket[d]++] = rr;
         }
-        for (int q = p; q < n; ++q) slot_start[q] = pos + (q - p);
-        slot_start[n] = pos + (n - p);
-        sh.slots = pos + (n - p);
-        if (sh.slots > SP_SLOTS) sh.bad = 1;
+        for (int q = p; q < cnt; ++q) slot_start[q] = pos + (q - p);
+        slot_start[cnt] = pos + (cnt - p);
+        sh.set_rows[wave] = cnt;
+        sh.set_slots[wave] = pos + (cnt - p);
+        if (pos + (cnt - p) > SP_SLOTS) sh.bad = 1;
     }
     __syncthreads();
     const int eup = sh.eup;
-    // this lane's row slot: lanes (li, half 0) and (li, half 1) of wave w share slot 32 w + li
-    int srow = -1, re0 = 0, re1 = 0, nsplit = 1;
-    bool first = false;
-    {
-        const int sl = wave * TILE + li;
-        if (sl < sh.slots && !sh.bad) {
-            int lo = 0, hi = n;  // largest position in slot order with slot_start[.] <= sl
+    // this lane's row slot in every set: lanes (li, half 0) and (li, half 1) of wave w share slot 32 w + li
+    RowSlot rs[NSET];
+#pragma unroll
+    for (int k = 0; k < NSET; ++k) {
+        const int* slot_start = slot_tab + k * (2 * ld + SP_CHUNK + 2);
+        const int* order = slot_start + ld + 1;
+        RowSlot z;
+        z.row = 0;
+        z.e0 = z.e1 = 0;
+        z.nsplit = 1;
+        z.first = false;
+        const int sl = wave * TILE + li, cnt = sh.set_rows[k];
+        if (sl < sh.set_slots[k] && !sh.bad) {
+            int lo = 0, hi = cnt;  // largest position in slot order with slot_start[.] <= sl
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
                 if (slot_start[mid] <= sl) lo = mid; else hi = mid;
             }
             const int row = order[lo];
-            const int a = rowptr[row], b = rowptr[row + 1];
-            const int ns = sparse_slots_of(b - a), k = sl - slot_start[lo];
-            if (k < ns) {  // otherwise: padding slot at the end of a wave
-                srow = row;
-                re0 = a + k * SP_CHUNK;
-                re1 = (re0 + SP_CHUNK < b) ? re0 + SP_CHUNK : b;
-                nsplit = ns;
-                first = (k == 0);
+            const int ra = rowptr[row], rb = rowptr[row + 1];
+            const int ns = sparse_slots_of(rb - ra), kk = sl - slot_start[lo];
+            if (kk < ns) {  // otherwise: padding slot in front of a split row
+                z.row = row;
+                z.e0 = ra + kk * SP_CHUNK;
+                z.e1 = (z.e0 + SP_CHUNK < rb) ? z.e0 + SP_CHUNK : rb;
+                z.nsplit = ns;
+                z.first = (kk == 0);
             }
         }
-    }
-    int wsplit = first ? nsplit : 1;  // longest split row of this wave (uniform)
+        int wsplit = z.first ? z.nsplit : 1;  // longest split row of this wave in this set (uniform)
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int other = __shfl_xor(wsplit, o);
-        wsplit = other > wsplit ? other : wsplit;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int other = __shfl_xor(wsplit, o);
+            wsplit = other > wsplit ? other : wsplit;
+        }
+        z.wsplit = wsplit;
+        z.wave_active = wave * TILE < sh.set_slots[k];
+        rs[k] = z;
     }
+    const RowSlot& SA = rs[0];         // rows of layer 1 / its backward (all rows in graph mode)
+    const RowSlot& SB = rs[NSET - 1];  // rows of layer 2 / its backward
     // owned undirected edges: k = tid + SP_THREADS q; mask entries and Adam moments stay in registers
     float Mij[SP_QMAX], Mji[SP_QMAX], mij[SP_QMAX], mji[SP_QMAX], vij[SP_QMAX], vji[SP_QMAX], wgt[SP_QMAX];
     int eij[SP_QMAX], eji[SP_QMAX], ni[SP_QMAX], nj[SP_QMAX];
@@ -570,6 +612,12 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
         return;
     }
 
+    // rows outside a phase's row set are never written: their U1 / U2 (= dZ2) / dZ1 must read as zero
+    for (int e = tid; e < ld * sH; e += SP_THREADS) {
+        sU1[e] = 0.0f;
+        sU2[e] = 0.0f;
+    }
+    for (int e = tid; e < ld * sD; e += SP_THREADS) sdZ1[e] = 0.0f;
     // ---------------- load features, model, labels ----------------
     for (int e = tid; e < ld * 32; e += SP_THREADS) {
         const int r = e >> 5, c = e & 31;
@@ -590,8 +638,6 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
     const float inv_n2 = 1.0f / ((float)n * (float)n);
     const int rt0 = rowptr[tr], rt1 = rowptr[tr + 1];
     // this lane's row (waves beyond the target's row blocks idle through the row phases)
-    const bool wave_active = wave * TILE < sh.slots;  // uniform per wave
-    const int r = first ? srow : 0;                    // rows are handled by the lanes of their FIRST slot
     float zraw[DQ];
 
     // sigma(M) -> symmetrised masked adjacency, one float per directed entry
@@ -617,7 +663,9 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
         const float step_size = adam_tab[2 * iter], inv_bc2s = 1.0f / adam_tab[2 * iter + 1];
 
         // ======== layer 1: Zraw = Abar . X (kept in registers for the feature-mask gradient), U1 ========
-        if (wave_active) {
+        if (SA.wave_active) {
+            const bool first = SA.first;
+            const int r = first ? SA.row : 0, re0 = SA.e0, re1 = SA.e1, nsplit = SA.nsplit, wsplit = SA.wsplit;
             float acc[DQ];
 #pragma unroll
             for (int q = 0; q < DQ; ++q) acc[q] = 0.0f;
@@ -632,7 +680,9 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
         }
         __syncthreads();
         // ======== layer 2: U2 ========
-        if (wave_active) {
+        if (SB.wave_active) {
+            const bool first = SB.first;
+            const int r = first ? SB.row : 0, re0 = SB.e0, re1 = SB.e1, nsplit = SB.nsplit, wsplit = SB.wsplit;
             float acc[HQ];
 #pragma unroll
             for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
@@ -645,7 +695,9 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
         __syncthreads();
         if constexpr (GRAPH) {
         // ======== graph mode: layer 3 in full (no ReLU), U3 ========
-        if (wave_active) {
+        if (SA.wave_active) {
+            const bool first = SA.first;
+            const int r = first ? SA.row : 0, re0 = SA.e0, re1 = SA.e1, nsplit = SA.nsplit, wsplit = SA.wsplit;
             float acc[HQ];
 #pragma unroll
             for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
@@ -719,7 +771,9 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
         }
         __syncthreads();
         // ======== graph mode: dZ3 (row-local backward of layer 3; dE3 lands on the arg-max rows), overwrites U3 ========
-        if (wave_active) {
+        if (SA.wave_active) {
+            const bool first = SA.first;
+            const int r = first ? SA.row : 0, re0 = SA.e0, re1 = SA.e1, nsplit = SA.nsplit, wsplit = SA.wsplit;
             float du[HQ], uu[HQ];
 #pragma unroll
             for (int q = 0; q < HQ; ++q) {
@@ -733,7 +787,9 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
         }
         __syncthreads();
         // ======== graph mode: dX2 = Abar . dZ3 (+ dE2 on the arg-max rows) -> dZ2 ========
-        if (wave_active) {
+        if (SA.wave_active) {
+            const bool first = SA.first;
+            const int r = first ? SA.row : 0, re0 = SA.e0, re1 = SA.e1, nsplit = SA.nsplit, wsplit = SA.wsplit;
             float acc[HQ], uu[HQ];
 #pragma unroll
             for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
@@ -847,7 +903,9 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
         }
         __syncthreads();
         // ======== dZ2 (rank-1: dX2[r] = Abar[r][t] dZ3[t] + dE2 on row t) and g3; dZ2 overwrites U2 row by row ========
-        if (wave_active) {
+        if (SB.wave_active) {
+            const bool first = SB.first;
+            const int r = first ? SB.row : 0, re0 = SB.e0, re1 = SB.e1, nsplit = SB.nsplit, wsplit = SB.wsplit;
             const float art = sArt[r];
             float du[HQ], uu[HQ];
             float gpart = 0.0f;
@@ -875,7 +933,9 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
             float dfq[DQ];
 #pragma unroll
             for (int q = 0; q < DQ; ++q) dfq[q] = 0.0f;
-            if (wave_active) {
+            if (SA.wave_active) {
+                const bool first = SA.first;
+                const int r = first ? SA.row : 0, re0 = SA.e0, re1 = SA.e1, nsplit = SA.nsplit, wsplit = SA.wsplit;
                 float acc[HQ], uu[HQ];
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;

@@ -8,28 +8,17 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 CSRC = os.path.join(ROOT, "gnn-model-explainer_amd", "csrc")
 src = open(os.path.join(CSRC, "gnnx_sparse.hpp")).read()
 capi = open(os.path.join(CSRC, "gnnx_capi.hip")).read()
-NP = 16
+NP = 32
 src = src.replace("namespace gnnx {\n", "namespace gnnx {\n__device__ unsigned long long g_probe[%d];\n"
                   "#define PROBE(k) do { if (iter == 5 && threadIdx.x == 0 && blockIdx.x == 0) g_probe[(k)] = wall_clock64(); } while (0)\n" % NP, 1)
-anchors = [l for l in src.split("\n") if l.strip().startswith("// ========")]
+anchors = [l for l in src.split("\n") if l.strip().startswith("// ========") and "graph mode" not in l]
 names = []
 for k, a in enumerate(anchors):
     src = src.replace(a + "\n", "        PROBE(%d);\n" % k + a + "\n", 1)
     names.append(a.strip(" /="))
 k = len(anchors)
-# stamps inside sparse_forward_rowlocal (last call = layer 2 of the last iteration): entry, after the MFMA chain, after the
-# norm (shuffle + sqrt + rcp), after the stores
-src = src.replace("#define PROBE(k)", "#define PROBE2(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_probe[(k)] = wall_clock64(); } while (0)\n#define PROBE(k)", 1)
-fr = src.index("__device__ __forceinline__ void sparse_forward_rowlocal")
-seg_end = src.index("// backward row-local part", fr)
-seg = src[fr:seg_end]
-seg = seg.replace("    f32x16 c16;\n", "    PROBE2(8);\n    f32x16 c16;\n", 1)
-seg = seg.replace("    float ss = 0.0f;\n", "    PROBE2(9);\n    float ss = 0.0f;\n", 1)
-seg = seg.replace("    const float rinv = 1.0f / rnorm;\n", "    const float rinv = 1.0f / rnorm;\n    PROBE2(10);\n", 1)
-seg = seg.replace("    if (store && h == 0) *srn_r = rnorm;\n", "    if (store && h == 0) *srn_r = rnorm;\n    PROBE2(11);\n", 1)
-src = src[:fr] + seg + src[seg_end:]
 # finer stamps inside layer 2 (wave 0 = the hub rows): after the gather, after the split-row combine, after MFMA + epilogue
-SUB = 12
+SUB = 20
 l2 = "            sparse_gather<true, HQ>(sAb, scol, sU1, sH, H, re0, re1, h, acc);\n            sparse_combine<HQ>(acc, lane, first, nsplit, wsplit);\n"
 assert l2 in src
 src = src.replace(l2, l2.replace(";\n            sparse_combine", ";\n            PROBE(%d);\n            sparse_combine" % SUB) + "            PROBE(%d);\n" % (SUB + 1), 1)
@@ -68,7 +57,5 @@ for nme, v in zip(names, d):
     print("%-100s %7.2f us" % (nme[:100], v))
 print("iteration total %7.2f us" % ((a[len(names)] - a[0]) * 10.0 / 1e3))
 b = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
-print("forward row-local (layer 2, wave 0): MFMA chain %.2f us, bias + norm %.2f us, stores %.2f us" % (
-    (b[9] - b[8]) / 100.0, (b[10] - b[9]) / 100.0, (b[11] - b[10]) / 100.0))
 print("layer 2, wave 0: gather %.2f us, combine %.2f us, MFMA + epilogue %.2f us, wait at barrier %.2f us" % (
-    (b[12] - b[1]) / 100.0, (b[13] - b[12]) / 100.0, (b[14] - b[13]) / 100.0, (b[2] - b[14]) / 100.0))
+    (b[20] - b[1]) / 100.0, (b[21] - b[20]) / 100.0, (b[22] - b[21]) / 100.0, (b[2] - b[22]) / 100.0))
