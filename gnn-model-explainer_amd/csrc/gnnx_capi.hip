@@ -39,6 +39,11 @@ struct GraphKey {
     bool operator==(const GraphKey& o) const { return std::memcmp(this, &o, sizeof(GraphKey)) == 0; }
 };
 
+constexpr int N_SPC = 3;                       // size classes of k_sparse_resident
+constexpr int SPC_THREADS[N_SPC] = {1024, 256, 64};
+constexpr int N_SIDE = RES_NBMAX + N_SPC;
+constexpr int CAT_SPARSE = RES_NBMAX + 1;      // CAT_SPARSE + k: sparse resident kernel of size class k
+
 struct gnnx_plan_s {
     gnnx_problem prob{};
     std::vector<TargetMeta> meta;
@@ -53,15 +58,18 @@ struct gnnx_plan_s {
     int32_t* d_big = nullptr;        // target ids of the streaming set
     ConvTile* d_conv_big = nullptr;
     MaskTile* d_mask_big = nullptr;
-    hipStream_t side[RES_NBMAX + 1] = {};   // the resident kernels (dense: one per nb; [RES_NBMAX]: sparse) run beside the streaming launches
-    hipEvent_t ev_in = nullptr, ev_out[RES_NBMAX + 1] = {};
-    hipEvent_t ev_t0[RES_NBMAX + 1] = {};   // start of the resident launch on its side stream (timed, for gnnx_resident_times)
-    bool launched[RES_NBMAX + 1] = {};
+    // the resident kernels run beside the streaming launches, each group on its own stream:
+    // [0..RES_NBMAX) dense resident kernels by row blocks, [RES_NBMAX + k] sparse resident kernel of size class k
+    hipStream_t side[N_SIDE] = {};
+    hipEvent_t ev_in = nullptr, ev_out[N_SIDE] = {};
+    hipEvent_t ev_t0[N_SIDE] = {};   // start of the resident launch on its side stream (timed, for gnnx_resident_times)
+    bool launched[N_SIDE] = {};
     std::vector<int> order;          // targets, largest first
     std::vector<int> cat;            // per target: 0 streaming, 1..RES_NBMAX dense resident kernel of that many row blocks, CAT_SPARSE
     std::vector<int32_t> nnz;        // per target (directed edge entries, row slots) from gnnx_plan_analyze, empty before
-    int n_sp = 0;                    // targets of the sparse resident kernel
-    int32_t* d_sp = nullptr;
+    int n_sp[N_SPC] = {};            // targets of the sparse resident kernel, per size class (1024 / 256 / 64 threads)
+    int32_t* d_sp[N_SPC] = {};
+    int n_sparse() const { return n_sp[0] + n_sp[1] + n_sp[2]; }
     int32_t* d_nnz = nullptr;
     float* d_adam = nullptr;         // per-iteration Adam scalars for the resident kernel
     std::vector<float> adam_host;
@@ -79,8 +87,6 @@ struct gnnx_plan_s {
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-constexpr int CAT_SPARSE = RES_NBMAX + 1;
-
 // (Re)build the hybrid split from h->cat: id lists of the resident kernels, tile tables of the streaming remainder,
 // side streams.  Invalidates a captured graph.
 static int build_split(gnnx_handle h) {
@@ -93,19 +99,21 @@ static int build_split(gnnx_handle h) {
         (void)hipGraphExecDestroy(h->gexec);
         h->gexec = nullptr;
     }
-    for (void* ptr : {(void*)h->d_res, (void*)h->d_sp, (void*)h->d_big, (void*)h->d_conv_big, (void*)h->d_mask_big})
+    for (void* ptr : {(void*)h->d_res, (void*)h->d_sp[0], (void*)h->d_sp[1], (void*)h->d_sp[2], (void*)h->d_big,
+                      (void*)h->d_conv_big, (void*)h->d_mask_big})
         if (ptr) (void)hipFree(ptr);
-    h->d_res = h->d_sp = h->d_big = nullptr;
+    h->d_res = h->d_big = nullptr;
+    for (int k = 0; k < N_SPC; ++k) h->d_sp[k] = nullptr;
     h->d_conv_big = nullptr;
     h->d_mask_big = nullptr;
     std::vector<ConvTile> conv_big;
     std::vector<MaskTile> mask_big;
-    std::vector<int32_t> res_ids, sp_ids, big_ids;
+    std::vector<int32_t> res_ids, sp_ids[N_SPC], big_ids;
     for (int k = 0; k <= RES_NBMAX; ++k) h->res_count[k] = h->res_first[k] = 0;
     for (int t : h->order) {  // sorted by ld: the dense resident groups are contiguous
         const int nb = h->meta[t].ld / TILE, c = h->cat[t];
-        if (c == CAT_SPARSE) {
-            sp_ids.push_back(t);
+        if (c >= CAT_SPARSE) {
+            sp_ids[c - CAT_SPARSE].push_back(t);
         } else if (c >= 1) {
             if (h->res_count[nb]++ == 0) h->res_first[nb] = (int)res_ids.size();
             res_ids.push_back(t);
@@ -117,7 +125,7 @@ static int build_split(gnnx_handle h) {
         }
     }
     h->n_res = (int)res_ids.size();
-    h->n_sp = (int)sp_ids.size();
+    for (int k = 0; k < N_SPC; ++k) h->n_sp[k] = (int)sp_ids[k].size();
     h->n_big = (int)big_ids.size();
     h->n_conv_big = (int)conv_big.size();
     h->n_mask_big = (int)mask_big.size();
@@ -129,8 +137,8 @@ static int build_split(gnnx_handle h) {
         return hipMemcpy(dst, v.data(), sizeof(E) * v.size(), hipMemcpyHostToDevice);
     };
     SPLITCK(upload(h->d_res, res_ids));
-    SPLITCK(upload(h->d_sp, sp_ids));
-    const bool any_resident = h->n_res || h->n_sp;
+    for (int k = 0; k < N_SPC; ++k) SPLITCK(upload(h->d_sp[k], sp_ids[k]));
+    const bool any_resident = h->n_res || h->n_sparse();
     if (any_resident && h->n_big) {
         SPLITCK(upload(h->d_big, big_ids));
         SPLITCK(upload(h->d_conv_big, conv_big));
@@ -139,8 +147,8 @@ static int build_split(gnnx_handle h) {
     if (any_resident && !h->ev_in) SPLITCK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     // (Disjoint compute-unit masks for the sparse and the single-tile dense launch - hipExtStreamCreateWithCUMask - were
     // measured on syn1 and made the sparse launch slower, 9.7 vs 6.4 ms in situ: not used.)
-    for (int k = 0; k <= RES_NBMAX; ++k) {
-        const bool need = k < RES_NBMAX ? h->res_count[k + 1] > 0 : h->n_sp > 0;
+    for (int k = 0; k < N_SIDE; ++k) {
+        const bool need = k < RES_NBMAX ? h->res_count[k + 1] > 0 : h->n_sp[k - RES_NBMAX] > 0;
         if (need && !h->side[k]) {
             SPLITCK(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
             SPLITCK(hipEventCreate(&h->ev_out[k]));
@@ -298,14 +306,15 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
     if (!h) return 0;
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->d_meta) (void)hipFree(h->d_meta);
-    for (int k = 0; k <= RES_NBMAX; ++k) {
+    for (int k = 0; k < N_SIDE; ++k) {
         if (h->side[k]) (void)hipStreamDestroy(h->side[k]);
         if (h->ev_out[k]) (void)hipEventDestroy(h->ev_out[k]);
         if (h->ev_t0[k]) (void)hipEventDestroy(h->ev_t0[k]);
     }
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->d_res) (void)hipFree(h->d_res);
-    if (h->d_sp) (void)hipFree(h->d_sp);
+    for (int k = 0; k < N_SPC; ++k)
+        if (h->d_sp[k]) (void)hipFree(h->d_sp[k]);
     if (h->d_nnz) (void)hipFree(h->d_nnz);
     if (h->d_adam) (void)hipFree(h->d_adam);
     if (h->d_big) (void)hipFree(h->d_big);
@@ -460,20 +469,25 @@ static int enqueue_job(gnnx_handle h, const Tables& tb, const gnnx_hyper* hy, co
     return 0;
 }
 
-// the sparse resident kernel, instantiated for the reference's encoders (node: D = 10, graph: D = 14; hidden 20) and
-// for the general 32-wide case
-static void launch_sparse(gnnx_handle h, const Params& p, const int32_t* ids, int cnt, const float* adam_tab, hipStream_t s) {
-    const dim3 grid(cnt), block(SP_THREADS);
+// the sparse resident kernel, instantiated per size class for the reference's encoders (node: D = 10, graph: D = 14;
+// hidden 20) and for the general 32-wide case
+template <int NT>
+static void launch_sparse_nt(gnnx_handle h, const Params& p, const int32_t* ids, int cnt, const float* adam_tab, hipStream_t s) {
+    const dim3 grid(cnt), block(NT);
     const int D = h->prob.D, HO = std::max(h->prob.H, h->prob.O);
     if (h->prob.graph_mode) {
-        if (D <= 14 && HO <= 20) hipLaunchKernelGGL((k_sparse_resident<7, 10, true>), grid, block, 0, s, p, ids, adam_tab);
-        else hipLaunchKernelGGL((k_sparse_resident<16, 16, true>), grid, block, 0, s, p, ids, adam_tab);
+        if (D <= 14 && HO <= 20) hipLaunchKernelGGL((k_sparse_resident<7, 10, true, NT>), grid, block, 0, s, p, ids, adam_tab);
+        else hipLaunchKernelGGL((k_sparse_resident<16, 16, true, NT>), grid, block, 0, s, p, ids, adam_tab);
     } else {
-        if (D <= 10 && HO <= 20) hipLaunchKernelGGL((k_sparse_resident<5, 10, false>), grid, block, 0, s, p, ids, adam_tab);
-        else hipLaunchKernelGGL((k_sparse_resident<16, 16, false>), grid, block, 0, s, p, ids, adam_tab);
+        if (D <= 10 && HO <= 20) hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT>), grid, block, 0, s, p, ids, adam_tab);
+        else hipLaunchKernelGGL((k_sparse_resident<16, 16, false, NT>), grid, block, 0, s, p, ids, adam_tab);
     }
 }
-
+static void launch_sparse(gnnx_handle h, const Params& p, int cls, const float* adam_tab, hipStream_t s) {
+    if (cls == 0) launch_sparse_nt<1024>(h, p, h->d_sp[0], h->n_sp[0], adam_tab, s);
+    else if (cls == 1) launch_sparse_nt<256>(h, p, h->d_sp[1], h->n_sp[1], adam_tab, s);
+    else launch_sparse_nt<64>(h, p, h->d_sp[2], h->n_sp[2], adam_tab, s);
+}
 
 extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, const float* X, const float* yhat,
                         float* M, float* Abar, float* feat_mask, float* loss, void* workspace,
@@ -488,7 +502,7 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
     Params p = make_params(h, hy, A, X, yhat, M, Abar, lossp, workspace);
     // hybrid split: small targets (<= res_nbmax row blocks) -> on-chip-resident kernels on side streams (overlap with the
     // streaming launches of the other targets); loss logging is a streaming-path feature
-    const bool resident = hy->use_resident && (h->n_res > 0 || h->n_sp > 0) && !lossp;
+    const bool resident = hy->use_resident && (h->n_res > 0 || h->n_sparse() > 0) && !lossp;
     const Tables tb = (resident && h->n_big > 0) ? tables_big(h) : tables_all(h);
     const bool streaming = !resident || h->n_big > 0;
     if (resident) {
@@ -501,20 +515,27 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
             HIPCK(hipMemcpy(h->d_adam, h->adam_host.data(), sizeof(float) * h->adam_host.size(), hipMemcpyHostToDevice));
             h->adam_for = *hy;
         }
-        if (h->n_sp) {  // targets whose edge state fits one CU: sparse resident kernel (gnnx_plan_analyze).  Submitted FIRST:
-            // its workgroups need a whole CU (LDS and registers), so they must be placed before the small dense-resident
-            // workgroups spread over every CU (measured on syn1: 21.5 -> 13.4 ms)
-            hipStream_t ss = h->side[RES_NBMAX];
-            HIPCK(hipStreamWaitEvent(ss, h->ev_in, 0));
-            HIPCK(hipEventRecord(h->ev_t0[RES_NBMAX], ss));
-            h->launched[RES_NBMAX] = true;
-            launch_sparse(h, p, h->d_sp, h->n_sp, h->d_adam, ss);
-            HIPCK(hipEventRecord(h->ev_out[RES_NBMAX], ss));
+        // Launch order: sparse resident kernel (gnnx_plan_analyze), largest size class FIRST - its workgroups need a whole
+        // CU (1024 threads x 128 VGPRs), so they must be placed before the small workgroups of the other launches spread
+        // over every CU (measured on syn1: 21.5 -> 13.4 ms) - then the dense resident kernels.  Every group has its own
+        // side stream.  (Running the last group on the caller's stream instead of a side stream serialised it behind
+        // another group, and a 40-200 us delay kernel in front of the small launches changed nothing - measured, not
+        // used; see gnnx_plan_analyze for which groups are allowed to meet.)
+        auto group_stream = [&](int k) -> hipStream_t { return h->side[k]; };
+        for (int k = 0; k < N_SPC; ++k) {
+            if (!h->n_sp[k]) continue;
+            const int g = RES_NBMAX + k;
+            hipStream_t ss = group_stream(g);
+            if (ss != s) HIPCK(hipStreamWaitEvent(ss, h->ev_in, 0));
+            HIPCK(hipEventRecord(h->ev_t0[g], ss));
+            h->launched[g] = true;
+            launch_sparse(h, p, k, h->d_adam, ss);
+            HIPCK(hipEventRecord(h->ev_out[g], ss));
         }
-        for (int nb = RES_NBMAX; nb >= 1; --nb) {  // largest targets first; each group on its own stream
+        for (int nb = RES_NBMAX; nb >= 1; --nb) {  // largest targets first
             if (!h->res_count[nb]) continue;
-            hipStream_t ss = h->side[nb - 1];
-            HIPCK(hipStreamWaitEvent(ss, h->ev_in, 0));
+            hipStream_t ss = group_stream(nb - 1);
+            if (ss != s) HIPCK(hipStreamWaitEvent(ss, h->ev_in, 0));
             HIPCK(hipEventRecord(h->ev_t0[nb - 1], ss));
             h->launched[nb - 1] = true;
             const dim3 grid(h->res_count[nb]), block(256);
@@ -556,7 +577,8 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
     if (resident) {
         for (int k = 0; k < RES_NBMAX; ++k)
             if (h->res_count[k + 1]) HIPCK(hipStreamWaitEvent(s, h->ev_out[k], 0));
-        if (h->n_sp) HIPCK(hipStreamWaitEvent(s, h->ev_out[RES_NBMAX], 0));
+        for (int k = 0; k < N_SPC; ++k)
+            if (h->n_sp[k]) HIPCK(hipStreamWaitEvent(s, h->ev_out[RES_NBMAX + k], 0));
     }
     if (feat_mask)
         HIPCK(hipMemcpyAsync(feat_mask, p.f[hy->num_iters & 1], sizeof(float) * h->prob.num_targets * FS,
@@ -567,7 +589,7 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
 
 extern "C" int gnnx_resident_times(gnnx_handle h, float* ms) {
     if (!h || !ms) return fail("null argument");
-    for (int k = 0; k <= RES_NBMAX; ++k) {
+    for (int k = 0; k < N_SIDE; ++k) {
         ms[k] = 0.0f;
         if (!h->launched[k]) continue;
         HIPCK(hipEventSynchronize(h->ev_out[k]));
@@ -597,19 +619,42 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
     int sparse_on = 1;
     if (const char* env = std::getenv("GNNX_SPARSE_RESIDENT")) sparse_on = std::atoi(env);
     if (!sparse_on) return 0;
-    // single-tile targets keep the dense resident kernel (two workgroups per CU); every larger target whose edge
-    // state fits one CU's LDS / registers takes the sparse resident kernel; the rest streams
+    // every target takes the smallest size class of the sparse resident kernel its rows / edges / LDS fit (64 threads:
+    // n <= 32; 256: n <= 128; 1024: n <= 512); single-tile node-mode targets that fit none keep the dense resident
+    // kernel; the rest streams.  GNNX_TINY_SPARSE=0 keeps every single-tile target on the dense resident kernel.
+    int tiny_on = 1;
+    if (const char* env = std::getenv("GNNX_TINY_SPARSE")) tiny_on = std::atoi(env);
     bool changed = false;
+    std::vector<int> new_cat(T, 0);
     for (int t = 0; t < T; ++t) {
         const TargetMeta& m = h->meta[t];
         const int nb = m.ld / TILE;
         int c = 0;
-        if (!graph && nb == 1 && h->res_nbmax >= 1) c = 1;  // the dense resident kernels are node-mode kernels
-        else if (h->nnz[2 * t] >= 0 &&
-                 sparse_fits(m.ld, h->nnz[2 * t], h->nnz[2 * t + 1], h->prob.D, h->prob.H, h->prob.C, graph, h->prob.O))
-            c = CAT_SPARSE;
-        changed |= (c != h->cat[t]);
-        h->cat[t] = c;
+        if (h->nnz[2 * t] >= 0)
+            for (int k = N_SPC - 1; k >= 0 && !c; --k)
+                if (sparse_fits(SPC_THREADS[k], m.n, m.ld, h->nnz[2 * t], h->nnz[2 * t + 1], h->prob.D, h->prob.H, h->prob.C,
+                                graph, h->prob.O) &&
+                    (k < 2 || tiny_on))
+                    c = CAT_SPARSE + k;
+        if (!graph && nb == 1 && h->res_nbmax >= 1 && (!c || !tiny_on)) c = 1;  // dense resident: node mode only
+        new_cat[t] = c;
+    }
+    // Batches that need the 1024-thread class keep to it and the dense single-tile kernel: measured on syn1, the 1024-thread
+    // launch runs back to back with a concurrent 64- or 256-thread sparse launch (10.2-11.3 ms per batch; its
+    // workgroups need empty CUs and its dispatch - 160 KB of LDS, scratch - does not interleave with theirs), while
+    // it overlaps with k_resident<1> (8.5 ms).  So there the middle class joins the large one (whatever fits 256
+    // threads fits 1024) and the single-tile node-mode targets stay on k_resident<1>.  Batches without such a target
+    // (syn4, syn5, graph mode) use the small classes: 1.2-2.7x faster than the alternatives.
+    bool has_large = false;
+    for (int t = 0; t < T; ++t) has_large |= (new_cat[t] == CAT_SPARSE);
+    if (has_large)
+        for (int t = 0; t < T; ++t) {
+            if (new_cat[t] == CAT_SPARSE + 1) new_cat[t] = CAT_SPARSE;
+            if (new_cat[t] == CAT_SPARSE + 2 && !graph && h->res_nbmax >= 1) new_cat[t] = 1;
+        }
+    for (int t = 0; t < T; ++t) {
+        changed |= (new_cat[t] != h->cat[t]);
+        h->cat[t] = new_cat[t];
     }
     return changed ? build_split(h) : 0;
 }
@@ -660,7 +705,7 @@ extern "C" int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hy, int32_t kin
         // one whole launch (all num_iters iterations) of the sparse (8) / single-tile dense (9) resident kernel on
         // `stream`, alone on the device.  Algorithmic work per SURVEY.md §8d for the targets of that launch:
         // 28 n^2 bytes and 6 n^2 (D + 2H) flop per iteration (the dense formulation the reference executes).
-        const int cnt = (kind == 8) ? h->n_sp : h->res_count[1];
+        const int cnt = (kind == 8) ? h->n_sp[0] : h->res_count[1];  // kind 8: the largest size class
         if (cnt == 0) {
             *ms_avg = 0.0f;
             if (alg_bytes) *alg_bytes = 0.0;
@@ -676,7 +721,7 @@ extern "C" int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hy, int32_t kin
             if (kind == 9)
                 hipLaunchKernelGGL(k_resident<1>, dim3(cnt), dim3(256), 0, s, p, h->d_res + h->res_first[1], d_tab);
             else
-                launch_sparse(h, p, h->d_sp, cnt, d_tab, s);
+                launch_sparse(h, p, 0, d_tab, s);
         };
         launch();  // warm
         HIPCK(hipEventRecord(e0, s));
@@ -700,7 +745,7 @@ extern "C" int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hy, int32_t kin
     float ss, b2;
     adam_scalars(hy, 0, &ss, &b2);
     // the tables gnnx_run would walk: only the streaming remainder when resident kernels take part of the batch
-    const bool hybrid = hy->use_resident && (h->n_res > 0 || h->n_sp > 0) && h->n_big > 0;
+    const bool hybrid = hy->use_resident && (h->n_res > 0 || h->n_sparse() > 0) && h->n_big > 0;
     const Tables tb = hybrid ? tables_big(h) : tables_all(h);
     double sum_n2 = h->sum_n2;
     if (hybrid) {

@@ -27,14 +27,18 @@
 
 namespace gnnx {
 
-constexpr int SP_THREADS = 1024;             // 16 waves: one 32-row block each -> ld <= 512
-constexpr int SP_QMAX = 2;                   // undirected edges per thread     -> E <= 2048
+// Three size classes of the kernel (template parameter NT = threads per workgroup): a 32-row block per wave and two
+// undirected edges per thread, so
+//   NT = 1024: n <= 512, E <= 2048, 153 KB of LDS  (one workgroup per CU: 16 waves x 128 VGPRs fill its register file)
+//   NT =  256: n <= 128, E <=  512,  72 KB         (two per CU)
+//   NT =   64: n <=  32, E <=  128,  20 KB         (one wave: every barrier is wave-local; six and more per CU)
+constexpr int SP_THREADS = 1024;             // the largest class (bounds shared tables)
+constexpr int SP_QMAX = 2;                   // undirected edges per thread
 constexpr int SP_LD_MAX = 32 * (SP_THREADS / 64);
-constexpr int SP_E_MAX = SP_QMAX * SP_THREADS;
-constexpr int SP_SCAN = SP_LD_MAX / 64;      // rows per lane in the setup prefix scans
+__host__ __device__ constexpr int sp_pool_floats(int nt) { return nt >= 1024 ? 39168 : nt >= 256 ? 18432 : 5120; }
 constexpr int SP_GATHER_UNROLL = 2;          // entries in flight per lane in the sparse gathers
 constexpr int SP_CHUNK = 16;                 // entries per row slot: longer rows are split over adjacent lanes of one wave
-constexpr int SP_SLOTS = SP_THREADS / 2;     // row slots (two lanes = column halves per slot)
+// row slots of a class: NT / 2 (two lanes = column halves per slot)
 
 // Row slots: row r takes ns(r) = max(1, ceil(deg(r) / SP_CHUNK)) consecutive slots that must not straddle a 16-lane
 // DPP row (so ns <= 16, i.e. degree <= 256; the partial sums are combined with row shifts).  Shared by k_count_edges
@@ -42,9 +46,6 @@ constexpr int SP_SLOTS = SP_THREADS / 2;     // row slots (two lanes = column ha
 __host__ __device__ inline int sparse_slots_of(int deg) { return deg <= SP_CHUNK ? 1 : (deg + SP_CHUNK - 1) / SP_CHUNK; }
 constexpr int SP_MAX_SPLIT = 16;
 __host__ __device__ inline int sparse_place(int pos, int ns) { return ((pos & 15) + ns > 16) ? ((pos + 15) & ~15) : pos; }
-constexpr int SP_POOL_FLOATS = 39168;        // 153 KB of the CU's 160 KB; the rest holds SparseFixed.  (A second, 73 KB
-                                             // instantiation for small targets was measured and dropped: 1024 threads x 128
-                                             // VGPRs fill the CU's register file, so two workgroups never share a CU anyway.)
 
 // carve-out of the LDS pool (float offsets) for a target of ld rows and nnz directed entries
 struct SparseLayout {
@@ -53,19 +54,20 @@ struct SparseLayout {
 };
 // graph = 0: node mode (GcnEncoderNode: only row t of layer 3 is needed; dZ2 overwrites U2);
 // graph = 1: graph mode (GcnEncoderGraph: all three layers in full, U3 [ld][max(H, O)] overwritten by dZ3, dZ2 separate)
-__host__ __device__ inline SparseLayout sparse_layout(int ld, int nnz, int D, int H, int C, int graph = 0, int O = 0) {
+// n rows of the big row arrays (rows >= n are never touched), ld = round_up(n, 32) entries of the per-row scalars
+__host__ __device__ inline SparseLayout sparse_layout(int n, int ld, int nnz, int D, int H, int C, int graph = 0, int O = 0) {
     SparseLayout L;
     L.sD = D | 1;
     L.sH = H | 1;
     L.sO = (O > H ? O : H) | 1;
     int o = 0;
-    L.oX = o;      o += ld * L.sD;
-    L.oU1 = o;     o += ld * L.sH;
-    L.oU2 = o;     o += ld * L.sH;   // U2; node mode: overwritten row by row with dZ2 once the row's U2 has been consumed
-    L.oU3 = o;     o += graph ? ld * L.sO : 0;
+    L.oX = o;      o += n * L.sD;
+    L.oU1 = o;     o += n * L.sH;
+    L.oU2 = o;     o += n * L.sH;   // U2; node mode: overwritten row by row with dZ2 once the row's U2 has been consumed
+    L.oU3 = o;     o += graph ? n * L.sO : 0;
     L.odZ2 = graph ? o : L.oU2;
-    o += graph ? ld * L.sH : 0;
-    L.odZ1 = o;    o += ld * L.sD;
+    o += graph ? n * L.sH : 0;
+    L.odZ1 = o;    o += n * L.sD;
     L.oAb = o;     o += nnz;
     L.oCol = o;    o += (nnz + 1) / 2;  // uint16 columns
     L.oRowptr = o; o += ld + 1;         // int
@@ -80,9 +82,13 @@ __host__ __device__ inline SparseLayout sparse_layout(int ld, int nnz, int D, in
     L.total = o;
     return L;
 }
-__host__ __device__ inline bool sparse_fits(int ld, int nnz, int slots, int D, int H, int C, int graph = 0, int O = 0) {
-    return ld <= SP_LD_MAX && nnz / 2 <= SP_E_MAX && nnz < 65536 && slots >= 0 && slots <= SP_SLOTS && C <= RES_CMAX &&
-           H >= 2 && sparse_layout(ld, nnz, D, H, C, graph, O).total <= SP_POOL_FLOATS;
+// does a target fit the class of nt threads?  (slots: row slots it needs with EVERY row placed, from k_count_edges)
+__host__ __device__ inline bool sparse_fits(int nt, int n, int ld, int nnz, int slots, int D, int H, int C, int graph = 0,
+                                            int O = 0) {
+    // the setup's temporaries (7 ld + 2 SP_CHUNK + 8 ints) live in the X / U1 / U2 / dZ1 arrays, which are contiguous
+    return ld <= 32 * (nt / 64) && nnz / 2 <= SP_QMAX * nt && nnz < 65536 && slots >= 0 && slots <= nt / 2 &&
+           C <= RES_CMAX && H >= 2 && 2 * n * ((H | 1) + (D | 1)) >= 7 * ld + 2 * SP_CHUNK + 8 &&
+           sparse_layout(n, ld, nnz, D, H, C, graph, O).total <= sp_pool_floats(nt);
 }
 
 // a lane's row slot in one row set: the row (valid when first), its chunk of entries, the split bookkeeping
@@ -336,22 +342,23 @@ __device__ __forceinline__ void sparse_combine(float (&acc)[NQ], int lane, bool 
 // DQ >= ceil(D / 2), HQ >= ceil(max(H, O) / 2): compile-time trip counts of the column loops (instantiated for the
 // reference's encoders and for the general 32-wide case).  GRAPH: GcnEncoderGraph (models.py:269-316: three full
 // layers, per-layer max-pool over all rows, no Laplacian term) instead of GcnEncoderNode (models.py:363-376).
-template <int DQ, int HQ, bool GRAPH>
-__global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const int32_t* targets, const float* adam_tab) {
-    __shared__ float pool[SP_POOL_FLOATS];
+template <int DQ, int HQ, bool GRAPH, int NT>
+__global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t* targets, const float* adam_tab) {
+    constexpr int SCAN = (32 * (NT / 64) + 63) / 64;  // rows per lane in the setup prefix scans
+    __shared__ float pool[sp_pool_floats(NT)];
     __shared__ SparseFixed sh;
     const int t = targets[blockIdx.x];
     const TargetMeta tm = p.meta[t];
     const int n = tm.n, ld = tm.ld, tr = tm.t;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
-    constexpr int NW = SP_THREADS / 64;
+    constexpr int NW = NT / 64;
     const int D = p.D, H = p.H, O = p.O, C = p.C;
     const float* Ag = p.A + tm.offQ;
     float* Mg = p.M + tm.offQ;
 
     // ---------------- setup 1: degrees (wave per row, ballot over 64-column chunks) ----------------
     int* tmp_deg = reinterpret_cast<int*>(pool);  // the pool is free until the layout is fixed
-    const bool ld_ok = ld <= SP_LD_MAX;
+    const bool ld_ok = ld <= 32 * NW;
     if (ld_ok)
         for (int r = wave; r < ld; r += NW) {
             int cnt = 0;
@@ -364,19 +371,19 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
             if (lane == 0) tmp_deg[r] = cnt;
         }
     __syncthreads();
-    if (wave == 0 && ld_ok) {  // exclusive prefix sum over the rows: SP_SCAN rows per lane
-        int loc[SP_SCAN], s = 0;
+    if (wave == 0 && ld_ok) {  // exclusive prefix sum over the rows: SCAN rows per lane
+        int loc[SCAN], s = 0;
 #pragma unroll
-        for (int k = 0; k < SP_SCAN; ++k) {
-            const int r = lane * SP_SCAN + k;
+        for (int k = 0; k < SCAN; ++k) {
+            const int r = lane * SCAN + k;
             loc[k] = (r < ld) ? tmp_deg[r] : 0;
             s += loc[k];
         }
         const int incl = wave_scan_inclusive(s, lane);
         int run = incl - s;
 #pragma unroll
-        for (int k = 0; k < SP_SCAN; ++k) {
-            const int r = lane * SP_SCAN + k;
+        for (int k = 0; k < SCAN; ++k) {
+            const int r = lane * SCAN + k;
             if (r < ld) tmp_deg[r] = run;  // becomes rowptr[r]
             run += loc[k];
         }
@@ -384,15 +391,15 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
     }
     __syncthreads();
     const int nnz = ld_ok ? sh.nnz : 0;
-    const bool fits = ld_ok && sparse_fits(ld, nnz, 0, D, H, C, GRAPH, O);  // the slot count is checked once the slots are placed
+    const bool fits = ld_ok && sparse_fits(NT, n, ld, nnz, 0, D, H, C, GRAPH, O);  // the slot count is checked once the slots are placed
     if (!fits) {
         // the plan promised a target that fits (gnnx_plan_analyze); anything else must fail loudly, not silently
         const float qnan = __builtin_nanf("");
-        for (int e = tid; e < ld * ld; e += SP_THREADS) p.Abar[tm.offQ + e] = qnan;
+        for (int e = tid; e < ld * ld; e += NT) p.Abar[tm.offQ + e] = qnan;
         if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = qnan;
         return;
     }
-    const SparseLayout L = sparse_layout(ld, nnz, D, H, C, GRAPH, O);
+    const SparseLayout L = sparse_layout(n, ld, nnz, D, H, C, GRAPH, O);
     // rowptr currently sits at the start of the pool = inside the future sX region: move it through registers
     const int rp_keep = (tid < ld) ? tmp_deg[tid] : nnz;
     __syncthreads();
@@ -433,7 +440,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
     }
     __syncthreads();
     // ---------------- setup 3: upper entries (col > row) are the tail of every row; prefix of their counts ----------------
-    int* u0 = reinterpret_cast<int*>(sU1);  // [ld] first upper entry of the row   (sU1 is free during setup)
+    int* u0 = reinterpret_cast<int*>(sX);  // [ld] first upper entry of the row   (X, U1, U2, dZ1 are free during setup)
     int* upptr = u0 + ld;                    // [ld + 1]
     if (tid < ld) {
         const int a = rowptr[tid], b = rowptr[tid + 1];
@@ -443,18 +450,18 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
     }
     __syncthreads();
     if (wave == 0) {
-        int loc[SP_SCAN], s = 0;
+        int loc[SCAN], s = 0;
 #pragma unroll
-        for (int k = 0; k < SP_SCAN; ++k) {
-            const int r = lane * SP_SCAN + k;
+        for (int k = 0; k < SCAN; ++k) {
+            const int r = lane * SCAN + k;
             loc[k] = (r < ld) ? upptr[r] : 0;
             s += loc[k];
         }
         const int incl = wave_scan_inclusive(s, lane);
         int run = incl - s;
 #pragma unroll
-        for (int k = 0; k < SP_SCAN; ++k) {
-            const int r = lane * SP_SCAN + k;
+        for (int k = 0; k < SCAN; ++k) {
+            const int r = lane * SCAN + k;
             if (r < ld) upptr[r] = run;
             run += loc[k];
         }
@@ -483,9 +490,10 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
     // other rows by decreasing degree, so that the 32 slots of a wave have (nearly) equal trip counts in the gathers.
     int* slot_tab = level + ld;  // per set: slot_start [ld + 1], order [ld], bucket [SP_CHUNK + 1]
     constexpr int NSET = GRAPH ? 1 : 2;
-    if (lane == 0 && wave < NSET) {  // one thread per set, in different waves
-        const int lvlmax = GRAPH ? 9 : 2 - wave;
-        int* slot_start = slot_tab + wave * (2 * ld + SP_CHUNK + 2);
+    if ((tid & 31) == 0 && (tid >> 5) < NSET) {  // one thread per set
+        const int set = tid >> 5;
+        const int lvlmax = GRAPH ? 9 : 2 - set;
+        int* slot_start = slot_tab + set * (2 * ld + SP_CHUNK + 2);
         int* order = slot_start + ld + 1;
         int* bucket = order + ld;
         int pos = 0, p = 0, cnt = 0;
@@ -519,9 +527,9 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
         }
         for (int q = p; q < cnt; ++q) slot_start[q] = pos + (q - p);
         slot_start[cnt] = pos + (cnt - p);
-        sh.set_rows[wave] = cnt;
-        sh.set_slots[wave] = pos + (cnt - p);
-        if (pos + (cnt - p) > SP_SLOTS) sh.bad = 1;
+        sh.set_rows[set] = cnt;
+        sh.set_slots[set] = pos + (cnt - p);
+        if (pos + (cnt - p) > NT / 2) sh.bad = 1;
     }
     __syncthreads();
     const int eup = sh.eup;
@@ -566,7 +574,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
     }
     const RowSlot& SA = rs[0];         // rows of layer 1 / its backward (all rows in graph mode)
     const RowSlot& SB = rs[NSET - 1];  // rows of layer 2 / its backward
-    // owned undirected edges: k = tid + SP_THREADS q; mask entries and Adam moments stay in registers
+    // owned undirected edges: k = tid + NT q; mask entries and Adam moments stay in registers
     float Mij[SP_QMAX], Mji[SP_QMAX], mij[SP_QMAX], mji[SP_QMAX], vij[SP_QMAX], vji[SP_QMAX], wgt[SP_QMAX];
     int eij[SP_QMAX], eji[SP_QMAX], ni[SP_QMAX], nj[SP_QMAX];
     bool near[SP_QMAX];  // an endpoint is t or a neighbour of t: only then dZ2 has a non-zero row on this edge
@@ -574,7 +582,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
         bool asym = (2 * eup != nnz);
 #pragma unroll
         for (int q = 0; q < SP_QMAX; ++q) {
-            const int k = tid + SP_THREADS * q;
+            const int k = tid + NT * q;
             Mij[q] = Mji[q] = mij[q] = mji[q] = vij[q] = vji[q] = wgt[q] = 0.0f;
             eij[q] = eji[q] = ni[q] = nj[q] = 0;
             near[q] = false;
@@ -604,30 +612,30 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
         }
         if (asym) sh.bad = 1;  // benign race: every writer stores 1
     }
-    __syncthreads();  // u0 / upptr (aliasing sU1) are dead from here on
+    __syncthreads();  // the setup temporaries (aliasing X .. dZ1) are dead from here on
     if (sh.bad) {     // asymmetric adjacency: not a graph the reference explains; fail loudly
         const float qnan = __builtin_nanf("");
-        for (int e = tid; e < ld * ld; e += SP_THREADS) p.Abar[tm.offQ + e] = qnan;
+        for (int e = tid; e < ld * ld; e += NT) p.Abar[tm.offQ + e] = qnan;
         if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = qnan;
         return;
     }
 
     // rows outside a phase's row set are never written: their U1 / U2 (= dZ2) / dZ1 must read as zero
-    for (int e = tid; e < ld * sH; e += SP_THREADS) {
+    for (int e = tid; e < n * sH; e += NT) {
         sU1[e] = 0.0f;
         sU2[e] = 0.0f;
     }
-    for (int e = tid; e < ld * sD; e += SP_THREADS) sdZ1[e] = 0.0f;
+    for (int e = tid; e < n * sD; e += NT) sdZ1[e] = 0.0f;
     // ---------------- load features, model, labels ----------------
-    for (int e = tid; e < ld * 32; e += SP_THREADS) {
+    for (int e = tid; e < n * 32; e += NT) {
         const int r = e >> 5, c = e & 31;
         if (c < D) sX[r * sD + c] = p.X[(tm.offR + r) * FS + c];
     }
-    for (int e = tid; e < D * 32; e += SP_THREADS) sW1[(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + e];
-    for (int e = tid; e < H * 32; e += SP_THREADS) sW2[(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + 1024 + e];
-    for (int e = tid; e < H * 32; e += SP_THREADS) sW3[(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + 2048 + e];
-    if (tid < 96) sh.bias[tid >> 5][tid & 31] = p.wts[WT_B + tid];
-    for (int e = tid; e < C * 96; e += SP_THREADS) sWp[e] = p.wts[WT_WP + e];
+    for (int e = tid; e < D * 32; e += NT) sW1[(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + e];
+    for (int e = tid; e < H * 32; e += NT) sW2[(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + 1024 + e];
+    for (int e = tid; e < H * 32; e += NT) sW3[(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + 2048 + e];
+    for (int e = tid; e < 96; e += NT) sh.bias[e >> 5][e & 31] = p.wts[WT_B + e];
+    for (int e = tid; e < C * 96; e += NT) sWp[e] = p.wts[WT_WP + e];
     if (tid < CMAX) sh.sbp[tid] = p.wts[WT_BP + tid];
     if (tid < ld) sYhat[tid] = GRAPH ? 0.0f : p.yhat[tm.offR + tid];  // graph mode has no Laplacian term (explain.py:780)
     if (tid < 32) {
@@ -644,7 +652,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
     auto publish_abar = [&]() {
 #pragma unroll
         for (int q = 0; q < SP_QMAX; ++q)
-            if (tid + SP_THREADS * q < eup) {
+            if (tid + NT * q < eup) {
                 const float a = wgt[q] * (0.5f * (sigmoidf_(Mij[q]) + sigmoidf_(Mji[q])));
                 sAb[eij[q]] = a;
                 sAb[eji[q]] = a;
@@ -658,7 +666,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
         if (tid < 32) sh.phi[tid] = (tid < D) ? sigmoidf_(sh.fcur[tid]) : 0.0f;
         // Abar[t][.] as a dense row (rank-1 layer-3 backward): scatter row t's entries (sArt was zeroed by publish_abar)
         if (!GRAPH)
-            for (int e = rt0 + tid; e < rt1; e += SP_THREADS) sArt[scol[e]] = sAb[e];
+            for (int e = rt0 + tid; e < rt1; e += NT) sArt[scol[e]] = sAb[e];
         __syncthreads();
         const float step_size = adam_tab[2 * iter], inv_bc2s = 1.0f / adam_tab[2 * iter + 1];
 
@@ -709,9 +717,8 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
         }
         __syncthreads();
         // ======== graph mode: per-layer max-pool over ALL n rows (models.py:283, 291, 300; first maximal row wins), head, dE ========
-        if (wave < 2) {  // lane = pooled column (96 of them), rows scanned in order: no cross-lane reduction needed
-            const int col = wave * 64 + lane;
-            if (col < 96) {
+        {   // thread = pooled column (96 of them), rows scanned in order: no cross-lane reduction needed
+            for (int col = tid; col < 96; col += NT) {
                 const int l = col >> 5, c = col & 31;
                 const float* arr = (l == 0) ? sU1 : (l == 1) ? sU2 : sU3;
                 const int stride = (l == 2) ? sO : sH;
@@ -980,7 +987,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
         // ======== per owned edge: G_ij + G_ji, regulariser gradients, Adam on both directed entries ========
 #pragma unroll
         for (int q = 0; q < SP_QMAX; ++q)
-            if (tid + SP_THREADS * q < eup) {
+            if (tid + NT * q < eup) {
                 const int i = ni[q], j = nj[q];
                 // compile-time trip counts: all loads of an edge are issued before the first use; columns beyond
                 // D / H are read from the row padding / the next row and dropped by the select
@@ -1051,13 +1058,13 @@ __global__ __launch_bounds__(SP_THREADS) void k_sparse_resident(Params p, const 
     // ---------------- results: dense Abar block (zero off the edges), M on the edges, feature mask ----------------
     {
         f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int e = tid * 4; e < ld * ld; e += 4 * SP_THREADS) *reinterpret_cast<f32x4*>(p.Abar + tm.offQ + e) = z4;
+        for (int e = tid * 4; e < ld * ld; e += 4 * NT) *reinterpret_cast<f32x4*>(p.Abar + tm.offQ + e) = z4;
     }
     __threadfence_block();
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < SP_QMAX; ++q)
-        if (tid + SP_THREADS * q < eup) {
+        if (tid + NT * q < eup) {
             const int i = ni[q], j = nj[q];
             const float a = sAb[eij[q]];
             p.Abar[tm.offQ + (size_t)i * ld + j] = a;

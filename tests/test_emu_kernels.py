@@ -104,13 +104,17 @@ def test_large_target_many_row_blocks(sparse):
         assert np.abs(res.mask[0] - o.M).max() < 2e-5
 
 
-def test_resident_kernel_matches_streaming_and_reference():
-    """Small targets (n <= 96; here single-tile ones) take the on-chip-resident kernel; an all-resident batch launches no streaming
-    kernel at all.  Both paths must agree with each other and with the reference's golden output."""
+@pytest.mark.parametrize("analyze", [False, True])
+def test_resident_kernel_matches_streaming_and_reference(analyze):
+    """Single-tile targets (n <= 32) run on chip: in the dense resident kernel k_resident<1> (plan not analysed) or in the
+    64-thread class of the sparse resident kernel; an all-resident batch launches no streaming kernel at all.  Both must
+    agree with the streaming path and with the closed form."""
     ck, gx = helpers.load_ckpt("syn4"), helpers.load_explain("syn4")
     subs = [_node_case("syn4", t)[2] for t in (511, 870)]
     iters = 40
-    res = emu_job(subs, ck["sd"]).run([s.mask0 for s in subs], Hyper(num_iters=iters, use_resident=True))
+    job = emu_job(subs, ck["sd"], analyze=analyze)
+    assert list(job.route()) == ([6, 6] if analyze else [1, 1])
+    res = job.run([s.mask0 for s in subs], Hyper(num_iters=iters, use_resident=True))
     stream = emu_job(subs, ck["sd"]).run([s.mask0 for s in subs], Hyper(num_iters=iters, use_resident=False))
     for a, b, fa, fb in zip(res.masked_adj, stream.masked_adj, res.feat_mask, stream.feat_mask):
         assert np.abs(a - b).max() < 1e-6 and np.abs(fa - fb).max() < 1e-5
@@ -118,12 +122,14 @@ def test_resident_kernel_matches_streaming_and_reference():
     s = subs[0]
     o = closed_form.ClosedFormOracle(s.adj, s.feat, ck["sd"], s.gt_label, s.pred_label, s.target_row, s.mask0)
     assert np.abs(res.masked_adj[0] - o.run(iters)).max() < 2e-6
-    assert np.abs(res.mask[0] - o.M).max() < 2e-5 and np.abs(res.feat_mask[0] - o.f).max() < 2e-5
+    live = (s.adj != 0) if analyze else np.ones_like(s.adj, bool)
+    assert np.abs(res.mask[0] - o.M)[live].max() < 2e-5 and np.abs(res.feat_mask[0] - o.f).max() < 2e-5
 
 
-def test_resident_kernel_full_run_vs_golden():
+@pytest.mark.parametrize("analyze", [False, True])
+def test_resident_kernel_full_run_vs_golden(analyze):
     ck, gx, sg = _node_case("syn1", 302)
-    res = emu_job([sg], ck["sd"]).run([sg.mask0], Hyper(num_iters=300))
+    res = emu_job([sg], ck["sd"], analyze=analyze).run([sg.mask0], Hyper(num_iters=300))
     rc = gx["302:edge_rc"]
     assert np.abs(res.masked_adj[0][rc[:, 0], rc[:, 1]] - gx["302:masked_adj_edges"]).max() <= 1e-5
     assert np.abs(1 / (1 + np.exp(-res.feat_mask[0])) - gx["302:feat_mask_sigmoid"]).max() <= 1e-5
@@ -219,9 +225,10 @@ def test_sparse_resident_kernel_full_run_vs_golden():
 
 
 def test_plan_routing_by_size_and_edge_count():
-    """gnnx_plan_analyze routes every target by what it finds in the packed adjacency (gnnx_get_route): n <= 32 -> dense
-    single-tile resident kernel (1), larger targets whose edge state fits one CU -> sparse resident kernel (4), dense
-    graphs with more than 2048 undirected edges -> streaming (0).  Without the analysis nothing is routed to 4."""
+    """gnnx_plan_analyze routes every target by what it finds in the packed adjacency (gnnx_get_route): targets whose edge
+    state fits a CU -> sparse resident kernel in the smallest size class that holds them (6: 64 threads, n <= 32;
+    5: 256 threads, n <= 128; 4: 1024 threads, n <= 512; a batch that needs class 4 uses only it and the dense single-tile
+    kernel), dense graphs with more than 2048 undirected edges -> streaming (0).  Without the analysis nothing is routed to the sparse kernel."""
     rng = np.random.default_rng(5)
     sd = helpers.random_model(rng, 10, 20, 20, 4)
 
@@ -231,7 +238,8 @@ def test_plan_routing_by_size_and_edge_count():
 
     subs = [sub(20, 0.2), sub(60, 0.1), sub(200, 0.02), sub(120, 0.5)]
     assert (subs[3].adj != 0).sum() // 2 > 2048
-    assert list(emu_job(subs, sd).route()) == [1, 4, 4, 0]
+    assert list(emu_job(subs, sd).route()) == [1, 4, 4, 0]     # a 1024-thread target in the batch: only that class + k_resident<1>
+    assert list(emu_job(subs[:2], sd).route()) == [6, 5]
     assert list(emu_job(subs, sd, analyze=False).route()) == [1, 0, 0, 0]
     small = [sub(20, 0.2), sub(60, 0.1)]
     assert list(emu_job(small, sd, analyze=False).route()) == [1, 2]      # all-small batch: dense resident kernels
