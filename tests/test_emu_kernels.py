@@ -247,3 +247,26 @@ def test_plan_routing_by_size_and_edge_count():
     for s_, ma in zip(subs, res.masked_adj):
         o = closed_form.ClosedFormOracle(s_.adj, s_.feat, sd, s_.gt_label, s_.pred_label, s_.target_row, s_.mask0)
         assert np.abs(ma - o.run(2)).max() < 5e-6
+
+
+@pytest.mark.parametrize("n", [24, 70, 200])
+def test_sparse_kernel_weighted_adjacency_and_self_loops(n):
+    """Non-binary symmetric edge weights and a non-zero diagonal (masked out by the reference, explain.py:618, 678)
+    through the three size classes of the sparse resident kernel."""
+    rng = np.random.default_rng(n)
+    sd = helpers.random_model(rng, 10, 20, 20, 4)
+    A, X = helpers.random_graph(rng, n, 10, density=0.08)
+    W = rng.uniform(0.25, 2.0, (n, n)).astype(np.float32)
+    A = A * np.triu(W, 1)
+    A = A + A.T + np.diag(rng.uniform(0.5, 1.5, n).astype(np.float32))
+    m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
+    sg = Subgraph(A, X, 2, 5, rng.integers(0, 4, n), m0)
+    job = emu_job([sg], sd)
+    assert job.route()[0] == {24: 6, 70: 5, 200: 4}[n]
+    res = job.run([m0], Hyper(num_iters=5))
+    o = closed_form.ClosedFormOracle(A, X, sd, 2, sg.pred_label, 5, m0)
+    want = o.run(5)                      # explain.py:209-211: masked adjacency of the last forward TIMES the adjacency
+    live = (A != 0) & ~np.eye(n, dtype=bool)
+    assert np.abs(res.masked_adj[0].astype(np.float64) * A - want).max() < 5e-6
+    assert np.abs(res.mask[0] - o.M)[live].max() < 5e-5
+    assert np.all(np.diag(res.masked_adj[0]) == 0)
