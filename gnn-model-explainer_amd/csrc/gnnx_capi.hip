@@ -16,6 +16,7 @@
 #include "gnnx_kernels.hpp"
 #include "gnnx_resident.hpp"
 #include "gnnx_sparse.hpp"
+#include "gnnx_sparse_large.hpp"
 
 using namespace gnnx;
 
@@ -39,8 +40,9 @@ struct GraphKey {
     bool operator==(const GraphKey& o) const { return std::memcmp(this, &o, sizeof(GraphKey)) == 0; }
 };
 
-constexpr int N_SPC = 3;                       // size classes of k_sparse_resident
-constexpr int SPC_THREADS[N_SPC] = {1024, 256, 64};
+constexpr int N_SPC = 4;                       // size classes of k_sparse_resident (0..2) + k_sparse_large (3)
+constexpr int SPC_THREADS[N_SPC] = {1024, 256, 64, 1024};
+constexpr int SPC_LARGE = 3;
 constexpr int N_SIDE = RES_NBMAX + N_SPC;
 constexpr int CAT_SPARSE = RES_NBMAX + 1;      // CAT_SPARSE + k: sparse resident kernel of size class k
 
@@ -69,7 +71,7 @@ struct gnnx_plan_s {
     std::vector<int32_t> nnz;        // per target (directed edge entries, row slots) from gnnx_plan_analyze, empty before
     int n_sp[N_SPC] = {};            // targets of the sparse resident kernel, per size class (1024 / 256 / 64 threads)
     int32_t* d_sp[N_SPC] = {};
-    int n_sparse() const { return n_sp[0] + n_sp[1] + n_sp[2]; }
+    int n_sparse() const { return n_sp[0] + n_sp[1] + n_sp[2] + n_sp[3]; }
     int32_t* d_nnz = nullptr;
     float* d_adam = nullptr;         // per-iteration Adam scalars for the resident kernel
     std::vector<float> adam_host;
@@ -99,8 +101,8 @@ static int build_split(gnnx_handle h) {
         (void)hipGraphExecDestroy(h->gexec);
         h->gexec = nullptr;
     }
-    for (void* ptr : {(void*)h->d_res, (void*)h->d_sp[0], (void*)h->d_sp[1], (void*)h->d_sp[2], (void*)h->d_big,
-                      (void*)h->d_conv_big, (void*)h->d_mask_big})
+    for (void* ptr : {(void*)h->d_res, (void*)h->d_sp[0], (void*)h->d_sp[1], (void*)h->d_sp[2], (void*)h->d_sp[3],
+                      (void*)h->d_big, (void*)h->d_conv_big, (void*)h->d_mask_big})
         if (ptr) (void)hipFree(ptr);
     h->d_res = h->d_big = nullptr;
     for (int k = 0; k < N_SPC; ++k) h->d_sp[k] = nullptr;
@@ -484,6 +486,14 @@ static void launch_sparse_nt(gnnx_handle h, const Params& p, const int32_t* ids,
     }
 }
 static void launch_sparse(gnnx_handle h, const Params& p, int cls, const float* adam_tab, hipStream_t s) {
+    if (cls == SPC_LARGE) {  // node-mode targets beyond the LDS-resident classes: row arrays in HBM / L2 (gnnx_sparse_large.hpp)
+        const dim3 grid(h->n_sp[cls]), block(SPL_THREADS);
+        if (h->prob.D <= 10 && std::max(h->prob.H, h->prob.O) <= 20)
+            hipLaunchKernelGGL((k_sparse_large<5, 10>), grid, block, 0, s, p, h->d_sp[cls], adam_tab);
+        else
+            hipLaunchKernelGGL((k_sparse_large<16, 16>), grid, block, 0, s, p, h->d_sp[cls], adam_tab);
+        return;
+    }
     if (cls == 0) launch_sparse_nt<1024>(h, p, h->d_sp[0], h->n_sp[0], adam_tab, s);
     else if (cls == 1) launch_sparse_nt<256>(h, p, h->d_sp[1], h->n_sp[1], adam_tab, s);
     else launch_sparse_nt<64>(h, p, h->d_sp[2], h->n_sp[2], adam_tab, s);
@@ -608,11 +618,12 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
     if (!h || !A) return fail("null argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int T = h->prob.num_targets;
-    if (!h->d_nnz) HIPCK(hipMalloc(&h->d_nnz, sizeof(int32_t) * 2 * T));
+    if (!h->d_nnz) HIPCK(hipMalloc(&h->d_nnz, sizeof(int32_t) * 4 * T));
     hipLaunchKernelGGL(k_count_edges, dim3(T), dim3(256), 0, s, h->d_meta, A, h->d_nnz);
+    if (!h->prob.graph_mode) hipLaunchKernelGGL(k_count_edges_large, dim3(T), dim3(256), 0, s, h->d_meta, A, h->d_nnz + 2 * T);
     HIPCK(hipGetLastError());
-    h->nnz.resize(2 * (size_t)T);  // (directed entries, row slots) per target
-    HIPCK(hipMemcpyAsync(h->nnz.data(), h->d_nnz, sizeof(int32_t) * 2 * T, hipMemcpyDeviceToHost, s));
+    h->nnz.assign(4 * (size_t)T, -1);  // per target: (directed entries, row slots); then the same for the large class
+    HIPCK(hipMemcpyAsync(h->nnz.data(), h->d_nnz, sizeof(int32_t) * (h->prob.graph_mode ? 2 : 4) * T, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
     const bool graph = h->prob.graph_mode != 0;
     if (h->prob.C > RES_CMAX) return 0;
@@ -622,8 +633,9 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
     // every target takes the smallest size class of the sparse resident kernel its rows / edges / LDS fit (64 threads:
     // n <= 32; 256: n <= 128; 1024: n <= 512); single-tile node-mode targets that fit none keep the dense resident
     // kernel; the rest streams.  GNNX_TINY_SPARSE=0 keeps every single-tile target on the dense resident kernel.
-    int tiny_on = 1;
+    int tiny_on = 1, large_on = 1;
     if (const char* env = std::getenv("GNNX_TINY_SPARSE")) tiny_on = std::atoi(env);
+    if (const char* env = std::getenv("GNNX_SPARSE_LARGE")) large_on = std::atoi(env);  // 0: those targets stream (dense)
     bool changed = false;
     std::vector<int> new_cat(T, 0);
     for (int t = 0; t < T; ++t) {
@@ -631,12 +643,15 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
         const int nb = m.ld / TILE;
         int c = 0;
         if (h->nnz[2 * t] >= 0)
-            for (int k = N_SPC - 1; k >= 0 && !c; --k)
+            for (int k = 2; k >= 0 && !c; --k)
                 if (sparse_fits(SPC_THREADS[k], m.n, m.ld, h->nnz[2 * t], h->nnz[2 * t + 1], h->prob.D, h->prob.H, h->prob.C,
                                 graph, h->prob.O) &&
                     (k < 2 || tiny_on))
                     c = CAT_SPARSE + k;
         if (!graph && nb == 1 && h->res_nbmax >= 1 && (!c || !tiny_on)) c = 1;  // dense resident: node mode only
+        if (!c && !graph && large_on && h->nnz[2 * T + 2 * t] >= 0 &&
+            sparse_large_fits(m.n, m.ld, h->nnz[2 * T + 2 * t], h->nnz[2 * T + 2 * t + 1], h->prob.D, h->prob.H, h->prob.C))
+            c = CAT_SPARSE + SPC_LARGE;
         new_cat[t] = c;
     }
     // Batches that need the 1024-thread class keep to it and the dense single-tile kernel: measured on syn1, the 1024-thread

@@ -1,0 +1,666 @@
+// gnnx_sparse_large.hpp — the edge-sparse, one-workgroup-per-target optimisation for targets that are too large for
+// k_sparse_resident's LDS (512 < n <= 4095 here; node mode).
+//
+// Same mathematics, row slots, hop pruning, lane mapping and helpers as k_sparse_resident (gnnx_sparse.hpp); what
+// changes is where things live:
+//   * LDS keeps what every gather chases through - the masked adjacency per directed entry, the sorted column lists,
+//     rowptr - and the per-row scalars (norms, labels, g3) and weights;
+//   * the row arrays X, U1, U2 (= dZ2), dZ1 are the caller's workspace arrays in HBM / L2 (stride 32 floats), written
+//     and re-read by the same workgroup, i.e. through one CU's L1/L2 path (__syncthreads makes them visible);
+//   * the mask entries on edges and their Adam moments are updated IN PLACE in the dense M / m / v arrays (two entries
+//     per undirected edge), the per-edge indices sit in the (otherwise unused) transposed workspace array;
+//   * rows of up to 1024 entries are split into slots of 64 (the BA-House x100k hubs), loops run over rows / edges
+//     instead of one item per thread.
+// Hop pruning is what makes this affordable: on the BA-House x100k sample a 2460-node sub-graph has a few hundred rows
+// within two hops of its target, so the row phases touch a small fraction of the sub-graph and the rest only costs
+// its edges' regulariser updates.
+#pragma once
+#include "gnnx_sparse.hpp"
+
+namespace gnnx {
+
+constexpr int SPL_THREADS = 1024;
+constexpr int SPL_CHUNK = 64;               // entries per row slot
+constexpr int SPL_N_MAX = 4095;             // node ids are packed in 12 bits
+constexpr int SPL_POOL_FLOATS = 39168;      // 153 KB of LDS
+constexpr int SPL_STAGE = 16 * TILE * 33;   // one staging tile per wave (dZ1 for the feature-mask gradient)
+
+__host__ __device__ inline int sparse_slots_of_c(int deg, int chunk) { return deg <= chunk ? 1 : (deg + chunk - 1) / chunk; }
+
+struct SparseLargeLayout {
+    int oRowptr, oArt, oRn1, oRn2, oYhat, oG3, oW, oWp, oStage, oAb, oCol, total;
+};
+__host__ __device__ inline SparseLargeLayout sparse_large_layout(int ld, int nnz, int D, int H, int C) {
+    SparseLargeLayout L;
+    int o = 0;
+    L.oRowptr = o; o += ld + 1;   // int; the degrees are counted straight into it
+    L.oArt = o;    o += ld;       // Art .. G3 (5 ld floats) double as the setup's uint16 temporaries
+    L.oRn1 = o;    o += ld;
+    L.oRn2 = o;    o += ld;
+    L.oYhat = o;   o += ld;
+    L.oG3 = o;     o += ld;
+    L.oW = o;      o += (D + 2 * H) * 33;
+    L.oWp = o;     o += C * 96;
+    L.oStage = o;  o += SPL_STAGE;
+    L.oAb = o;     o += nnz;
+    L.oCol = o;    o += (nnz + 1) / 2;
+    L.total = o;
+    return L;
+}
+// slots: row slots of 64 entries needed by the rows within two hops of the target (k_count_edges)
+__host__ __device__ inline bool sparse_large_fits(int n, int ld, int nnz, int slots, int D, int H, int C) {
+    return n <= SPL_N_MAX && nnz < 65536 && nnz <= 32 * ld && slots >= 0 && slots <= SPL_THREADS / 2 && C <= RES_CMAX &&
+           H >= 2 && 10 * ld >= 7 * ld + 2 * SPL_CHUNK + 16 && sparse_large_layout(ld, nnz, D, H, C).total <= SPL_POOL_FLOATS;
+}
+
+// exclusive prefix sum of a[0..len) in place by one wave (lane = tid & 63); returns the total
+template <class T>
+__device__ __forceinline__ int wave_exclusive_scan_array(T* a, int len, int lane) {
+    const int per = (len + 63) / 64;
+    const int lo = lane * per, hi = (lo + per < len) ? lo + per : len;
+    int s = 0;
+    for (int r = lo; r < hi; ++r) s += (int)a[r];
+    const int incl = wave_scan_inclusive(s, lane);
+    int run = incl - s;
+    for (int r = lo; r < hi; ++r) {
+        const int v = (int)a[r];
+        a[r] = (T)run;
+        run += v;
+    }
+    return __shfl(incl, 63);
+}
+
+template <int DQ, int HQ>
+__global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const int32_t* targets, const float* adam_tab) {
+    constexpr int NT = SPL_THREADS, NW = NT / 64;
+    __shared__ float pool[SPL_POOL_FLOATS];
+    __shared__ SparseFixed sh;
+    const int t = targets[blockIdx.x];
+    const TargetMeta tm = p.meta[t];
+    const int n = tm.n, ld = tm.ld, tr = tm.t;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int D = p.D, H = p.H, O = p.O, C = p.C;
+    const float* Ag = p.A + tm.offQ;
+    float* Mg = p.M + tm.offQ;
+    float* mg = p.mM + tm.offQ;
+    float* vg = p.vM + tm.offQ;
+    // row arrays in the caller's workspace (stride FS); dZ2 overwrites U2 row by row as in the resident kernel
+    const float* gX = p.X + tm.offR * FS;
+    float* gU1 = p.U[0] + tm.offR * FS;
+    float* gU2 = p.U[1] + tm.offR * FS;
+    float* gdZ1 = p.dZ[0] + tm.offR * FS;
+    unsigned* eidx = reinterpret_cast<unsigned*>(p.UT[0] + tm.offR * FS);  // [eup][2]: i | j << 12 | near << 24, e_ij | e_ji << 16
+
+    auto fail_nan = [&]() {
+        const float qnan = __builtin_nanf("");
+        for (int e = tid; e < ld * ld; e += NT) p.Abar[tm.offQ + e] = qnan;
+        if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = qnan;
+    };
+    if (n > SPL_N_MAX || 6 * ld + 1 + (D + 2 * H) * 33 + C * 96 + SPL_STAGE > SPL_POOL_FLOATS) {  // uniform
+        fail_nan();
+        return;
+    }
+    // ---------------- setup 1: degrees -> rowptr (the nnz-independent part of the layout comes first) ----------------
+    int* rowptr = reinterpret_cast<int*>(pool);
+    for (int r = wave; r < ld; r += NW) {
+        int cnt = 0;
+        if (r < n)
+            for (int c0 = 0; c0 < n; c0 += 64) {
+                const int c = c0 + lane;
+                const bool nz = (c < n && c != r) ? (Ag[(size_t)r * ld + c] != 0.0f) : false;
+                cnt += __popcll(__ballot(nz));
+            }
+        if (lane == 0) rowptr[r] = cnt;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int total = wave_exclusive_scan_array(rowptr, ld, lane);
+        if (lane == 0) {
+            rowptr[ld] = total;
+            sh.nnz = total;
+            sh.bad = 0;
+        }
+    }
+    __syncthreads();
+    const int nnz = sh.nnz;
+    if (!sparse_large_fits(n, ld, nnz, 0, D, H, C)) {
+        fail_nan();
+        return;
+    }
+    const SparseLargeLayout L = sparse_large_layout(ld, nnz, D, H, C);
+    float* sArt = pool + L.oArt;
+    float* sRn1 = pool + L.oRn1;
+    float* sRn2 = pool + L.oRn2;
+    float* sYhat = pool + L.oYhat;
+    float* sG3 = pool + L.oG3;
+    float* sW1 = pool + L.oW;
+    float* sW2 = sW1 + D * 33;
+    float* sW3 = sW2 + H * 33;
+    float* sWp = pool + L.oWp;
+    float* stage = pool + L.oStage + wave * (TILE * 33);
+    float* sAb = pool + L.oAb;
+    unsigned short* scol = reinterpret_cast<unsigned short*>(pool + L.oCol);
+
+    // ---------------- setup 2: sorted column lists ----------------
+    for (int r = wave; r < n; r += NW) {
+        int base = rowptr[r];
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int c = c0 + lane;
+            const bool nz = (c < n && c != r) ? (Ag[(size_t)r * ld + c] != 0.0f) : false;
+            const unsigned long long bal = __ballot(nz);
+            if (nz) scol[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)c;
+            base += __popcll(bal);
+        }
+    }
+    __syncthreads();
+    // ---------------- setup 3: uint16 temporaries in the Art .. G3 region ----------------
+    unsigned short* u0 = reinterpret_cast<unsigned short*>(sArt);  // [ld] first upper entry (col > row) of the row
+    unsigned short* upptr = u0 + ld;                                // [ld + 1] prefix of the upper counts
+    unsigned short* level = upptr + ld + 1;                         // [ld] hop level 0..3
+    unsigned short* slot_tab = level + ld;                          // per set: slot_start [ld + 1], order [ld], bucket [CHUNK + 1]
+    for (int r = tid; r < ld; r += NT) {
+        const int a = rowptr[r], b = rowptr[r + 1];
+        const int f = lower_bound_u16(scol, a, b, r + 1);
+        u0[r] = (unsigned short)f;
+        upptr[r] = (unsigned short)(b - f);
+        level[r] = (r == tr) ? 0 : 3;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int total = wave_exclusive_scan_array(upptr, ld, lane);
+        if (lane == 0) {
+            upptr[ld] = (unsigned short)total;
+            sh.eup = total;
+        }
+    }
+    __syncthreads();
+    for (int d = 1; d <= 2; ++d) {  // hop levels (see k_sparse_resident)
+        for (int r = tid; r < n; r += NT)
+            if (level[r] == d - 1)
+                for (int e = rowptr[r]; e < rowptr[r + 1]; ++e)
+                    if (level[scol[e]] > d) level[scol[e]] = (unsigned short)d;  // benign race
+        __syncthreads();
+    }
+    constexpr int SETSZ_EXTRA = SPL_CHUNK + 2;
+    if ((tid & 31) == 0 && (tid >> 5) < 2) {  // one thread per row set: A (level <= 2), B (level <= 1)
+        const int set = tid >> 5;
+        const int lvlmax = 2 - set;
+        unsigned short* slot_start = slot_tab + set * (2 * ld + SETSZ_EXTRA);
+        unsigned short* order = slot_start + ld + 1;
+        unsigned short* bucket = order + ld;
+        int pos = 0, pcount = 0, cnt = 0;
+        for (int d = 0; d <= SPL_CHUNK; ++d) bucket[d] = 0;
+        for (int rr = 0; rr < n; ++rr) {
+            if (level[rr] > lvlmax) continue;
+            ++cnt;
+            const int d = rowptr[rr + 1] - rowptr[rr];
+            if (d > SPL_CHUNK) {
+                const int ns = sparse_slots_of_c(d, SPL_CHUNK);
+                if (ns > SP_MAX_SPLIT) sh.bad = 1;
+                pos = sparse_place(pos, ns);
+                order[pcount] = (unsigned short)rr;
+                slot_start[pcount] = (unsigned short)pos;
+                pos += ns;
+                ++pcount;
+            } else {
+                bucket[d]++;
+            }
+        }
+        int run = pcount;
+        for (int d = SPL_CHUNK; d >= 0; --d) {
+            const int c = bucket[d];
+            bucket[d] = (unsigned short)run;
+            run += c;
+        }
+        for (int rr = 0; rr < n; ++rr) {
+            if (level[rr] > lvlmax) continue;
+            const int d = rowptr[rr + 1] - rowptr[rr];
+            if (d <= SPL_CHUNK) order[bucket[d]++] = (unsigned short)rr;
+        }
+        for (int q = pcount; q < cnt; ++q) slot_start[q] = (unsigned short)(pos + (q - pcount));
+        slot_start[cnt] = (unsigned short)(pos + (cnt - pcount));
+        sh.set_rows[set] = cnt;
+        sh.set_slots[set] = pos + (cnt - pcount);
+        if (pos + (cnt - pcount) > NT / 2) sh.bad = 1;
+    }
+    __syncthreads();
+    const int eup = sh.eup;
+    RowSlot rs[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const unsigned short* slot_start = slot_tab + k * (2 * ld + SETSZ_EXTRA);
+        const unsigned short* order = slot_start + ld + 1;
+        RowSlot z;
+        z.row = 0;
+        z.e0 = z.e1 = 0;
+        z.nsplit = 1;
+        z.first = false;
+        const int sl = wave * TILE + li, cnt = sh.set_rows[k];
+        if (sl < sh.set_slots[k] && !sh.bad) {
+            int lo = 0, hi = cnt;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if ((int)slot_start[mid] <= sl) lo = mid; else hi = mid;
+            }
+            const int row = order[lo];
+            const int ra = rowptr[row], rb = rowptr[row + 1];
+            const int ns = sparse_slots_of_c(rb - ra, SPL_CHUNK), kk = sl - (int)slot_start[lo];
+            if (kk < ns) {
+                z.row = row;
+                z.e0 = ra + kk * SPL_CHUNK;
+                z.e1 = (z.e0 + SPL_CHUNK < rb) ? z.e0 + SPL_CHUNK : rb;
+                z.nsplit = ns;
+                z.first = (kk == 0);
+            }
+        }
+        int wsplit = z.first ? z.nsplit : 1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int other = __shfl_xor(wsplit, o);
+            wsplit = other > wsplit ? other : wsplit;
+        }
+        z.wsplit = wsplit;
+        z.wave_active = wave * TILE < sh.set_slots[k];
+        rs[k] = z;
+    }
+    const RowSlot& SA = rs[0];
+    const RowSlot& SB = rs[1];
+    // per-edge indices -> global; Adam moments of the live entries start at zero; symmetry check
+    {
+        bool asym = (2 * eup != nnz);
+        const int t0 = rowptr[tr], t1 = rowptr[tr + 1];
+        for (int k = tid; k < eup; k += NT) {
+            int lo = 0, hi = ld;  // largest row i with upptr[i] <= k
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if ((int)upptr[mid] <= k) lo = mid; else hi = mid;
+            }
+            const int i = lo;
+            const int e = (int)u0[i] + (k - (int)upptr[i]);
+            const int j = scol[e];
+            const int em = lower_bound_u16(scol, rowptr[j], rowptr[j + 1], i);
+            if (em >= rowptr[j + 1] || (int)scol[em] != i) asym = true;
+            if (Ag[(size_t)j * ld + i] != Ag[(size_t)i * ld + j]) asym = true;
+            const int pi = lower_bound_u16(scol, t0, t1, i), pj = lower_bound_u16(scol, t0, t1, j);
+            const bool near = i == tr || j == tr || (pi < t1 && (int)scol[pi] == i) || (pj < t1 && (int)scol[pj] == j);
+            eidx[2 * k] = (unsigned)i | ((unsigned)j << 12) | ((unsigned)near << 24);
+            eidx[2 * k + 1] = (unsigned)e | ((unsigned)(asym ? e : em) << 16);
+            mg[(size_t)i * ld + j] = 0.0f;
+            mg[(size_t)j * ld + i] = 0.0f;
+            vg[(size_t)i * ld + j] = 0.0f;
+            vg[(size_t)j * ld + i] = 0.0f;
+        }
+        if (asym) sh.bad = 1;
+    }
+    __syncthreads();  // the uint16 temporaries are dead from here on
+    if (sh.bad) {
+        fail_nan();
+        return;
+    }
+    // ---------------- row arrays (never-written rows must read as zero), model, labels ----------------
+    for (int e = tid; e < n * FS; e += NT) {
+        gU1[e] = 0.0f;
+        gU2[e] = 0.0f;
+        gdZ1[e] = 0.0f;
+    }
+    for (int e = tid; e < D * 32; e += NT) sW1[(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + e];
+    for (int e = tid; e < H * 32; e += NT) sW2[(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + 1024 + e];
+    for (int e = tid; e < H * 32; e += NT) sW3[(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + 2048 + e];
+    if (tid < 96) sh.bias[tid >> 5][tid & 31] = p.wts[WT_B + tid];
+    for (int e = tid; e < C * 96; e += NT) sWp[e] = p.wts[WT_WP + e];
+    if (tid < CMAX) sh.sbp[tid] = p.wts[WT_BP + tid];
+    for (int r = tid; r < ld; r += NT) {
+        sYhat[r] = p.yhat[tm.offR + r];
+        sArt[r] = 0.0f;
+    }
+    if (tid < 32) {
+        sh.fcur[tid] = 0.0f;  // construct_feat_mask: constant 0 (explain.py:639-641)
+        sh.mf[tid] = 0.0f;
+        sh.vf[tid] = 0.0f;
+    }
+    const float inv_n2 = 1.0f / ((float)n * (float)n);
+    const int rt0 = rowptr[tr], rt1 = rowptr[tr + 1];
+    float zraw[DQ];
+    // sigma(M) -> symmetrised masked adjacency, one float per directed entry
+    for (int k = tid; k < eup; k += NT) {
+        const unsigned nd = eidx[2 * k], en = eidx[2 * k + 1];
+        const int i = nd & 4095u, j = (nd >> 12) & 4095u;
+        const float a = Ag[(size_t)i * ld + j] * (0.5f * (sigmoidf_(Mg[(size_t)i * ld + j]) + sigmoidf_(Mg[(size_t)j * ld + i])));
+        sAb[en & 0xffffu] = a;
+        sAb[en >> 16] = a;
+    }
+    __syncthreads();
+
+    for (int iter = 0; iter < p.num_iters; ++iter) {
+        if (tid < 32) sh.phi[tid] = (tid < D) ? sigmoidf_(sh.fcur[tid]) : 0.0f;
+        for (int e = rt0 + tid; e < rt1; e += NT) sArt[scol[e]] = sAb[e];  // Abar[t][.] as a dense row (zero elsewhere)
+        __syncthreads();
+        const float step_size = adam_tab[2 * iter], inv_bc2s = 1.0f / adam_tab[2 * iter + 1];
+
+        // ======== layer 1 on the rows within two hops: Zraw = Abar . X (kept in registers), U1 ========
+        if (SA.wave_active) {
+            const bool first = SA.first;
+            const int r = first ? SA.row : 0;
+            float acc[DQ];
+#pragma unroll
+            for (int q = 0; q < DQ; ++q) acc[q] = 0.0f;
+            sparse_gather<false, DQ>(sAb, scol, gX, FS, D, SA.e0, SA.e1, h, acc);
+            sparse_combine<DQ>(acc, lane, first, SA.nsplit, SA.wsplit);
+#pragma unroll
+            for (int q = 0; q < DQ; ++q) {
+                zraw[q] = acc[q];
+                acc[q] = (first && 2 * q + h < D) ? acc[q] * sh.phi[2 * q + h] : 0.0f;
+            }
+            sparse_forward_rowlocal<DQ>(acc, sW1, sh.bias[0], D, H, li, h, first, gU1 + r * FS, sRn1 + r);
+        }
+        __syncthreads();
+        // ======== layer 2 on the target and its neighbours: U2 ========
+        if (SB.wave_active) {
+            const bool first = SB.first;
+            const int r = first ? SB.row : 0;
+            float acc[HQ];
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
+            sparse_gather<true, HQ>(sAb, scol, gU1, FS, H, SB.e0, SB.e1, h, acc);
+            sparse_combine<HQ>(acc, lane, first, SB.nsplit, SB.wsplit);
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) acc[q] = first ? acc[q] : 0.0f;
+            sparse_forward_rowlocal<HQ>(acc, sW2, sh.bias[1], H, H, li, h, first, gU2 + r * FS, sRn2 + r);
+        }
+        __syncthreads();
+        // ======== row t of layer 3, head, dE, dZ3[t] ========
+        {
+            float z = 0.0f;
+            if (li < H)
+                for (int e = rt0 + 2 * wave + h; e < rt1; e += 2 * NW) z = fmaf(sAb[e], relu_(gU2[(int)scol[e] * FS + li]), z);
+            z += __shfl_xor(z, 32);
+            if (h == 0) sh.dfw[wave][li] = z;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int c = li;
+            float z = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) z += sh.dfw[w][c];
+            if (h == 0) sh.z3[c] = z;
+            wave_sync();
+            float y = 0.0f;
+            if (c < O) {
+                for (int k = 0; k < H; ++k) y = fmaf(sh.z3[k], sW3[k * 33 + c], y);
+                y += sh.bias[2][c];
+            }
+            const float ss = sum_lanes_0_31(y * y);
+            const float rnorm = fmaxf(sqrtf(ss), 1e-12f);
+            const float u3 = y / rnorm;
+            if (h == 0) {
+                sh.e[64 + c] = u3;
+                sh.e[c] = (c < H) ? relu_(gU1[tr * FS + c]) : 0.0f;
+                sh.e[32 + c] = (c < H) ? relu_(gU2[tr * FS + c]) : 0.0f;
+            }
+            wave_sync();
+            {
+                const int cls = lane >> 3, part = lane & 7;
+                float s = 0.0f;
+                if (cls < C)
+                    for (int q = part * 12; q < part * 12 + 12; ++q) s = fmaf(sWp[cls * 96 + q], sh.e[q], s);
+                s += row_shl<4>(s);
+                s += row_shl<2>(s);
+                s += row_shl<1>(s);
+                const float zc = __shfl(s, (lane & 7) * 8);
+                const float zl = (lane < C) ? zc + sh.sbp[lane] : -3.0e38f;
+                float mx = zl;
+                mx = fmaxf(mx, row_shl<4>(mx));
+                mx = fmaxf(mx, row_shl<2>(mx));
+                mx = fmaxf(mx, row_shl<1>(mx));
+                mx = bcast_first(mx);
+                const float ex = (lane < C) ? expf(zl - mx) : 0.0f;
+                float sum = ex;
+                sum += row_shl<4>(sum);
+                sum += row_shl<2>(sum);
+                sum += row_shl<1>(sum);
+                sum = bcast_first(sum);
+                if (lane < CMAX) sh.g[lane] = (lane < C) ? ex / sum - ((lane == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
+            }
+            wave_sync();
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const int idx = lane + 64 * part;
+                if (idx < 96) {
+                    float s = 0.0f;
+                    for (int cc = 0; cc < C; ++cc) s = fmaf(sWp[cc * 96 + idx], sh.g[cc], s);
+                    sh.dEs[idx] = s;
+                }
+            }
+            wave_sync();
+            const float du3 = (h == 0 && c < O) ? sh.dEs[64 + c] : 0.0f;
+            const float uq = (h == 0) ? u3 : 0.0f;
+            const float s = sum_lanes_0_31(du3 * uq);
+            const float dy3 = (du3 - uq * s) / rnorm;
+            if (h == 0) sh.y3[c] = dy3;
+            wave_sync();
+            float v = 0.0f;
+            if (c < H)
+                for (int c2 = 0; c2 < O; ++c2) v = fmaf(sh.y3[c2], sW3[c * 33 + c2], v);
+            if (h == 0) sh.dz3[c] = (c < H) ? v : 0.0f;
+        }
+        __syncthreads();
+        // ======== dZ2 (rank-1) on the target and its neighbours, g3; dZ2 overwrites U2 row by row ========
+        if (SB.wave_active) {
+            const bool first = SB.first;
+            const int r = first ? SB.row : 0;
+            const float art = sArt[r];
+            float du[HQ], uu[HQ];
+            float gpart = 0.0f;
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) {
+                const int c = 2 * q + h;
+                const float u = (first && c < H) ? gU2[r * FS + c] : 0.0f;
+                const float dz = (c < H) ? sh.dz3[c] : 0.0f;
+                gpart = fmaf(dz, relu_(u), gpart);
+                float dx = art * dz;
+                if (first && r == tr && c < H) dx += sh.dEs[32 + c];
+                du[q] = (u > 0.0f) ? dx : 0.0f;
+                uu[q] = u;
+            }
+            gpart += __shfl_xor(gpart, 32);
+            if (first && h == 0) sG3[r] = gpart;
+            const f32x16 c16 = sparse_backward_rowlocal<HQ>(du, uu, first ? sRn2[r] : 1.0f, sW2, H, H, li, h);
+            sparse_store_cols(c16, gU2 + r * FS, H, first, h);
+        }
+        __syncthreads();
+        const float* gdZ2 = gU2;
+        // ======== dX1 = Abar . dZ2 (+ dE1 on row t) -> dZ1 on the rows within two hops; feature-mask gradient partials ========
+        {
+            float dfq[DQ];
+#pragma unroll
+            for (int q = 0; q < DQ; ++q) dfq[q] = 0.0f;
+            if (SA.wave_active) {
+                const bool first = SA.first;
+                const int r = first ? SA.row : 0;
+                float acc[HQ], uu[HQ];
+#pragma unroll
+                for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
+                sparse_gather<false, HQ>(sAb, scol, gdZ2, FS, H, SA.e0, SA.e1, h, acc);
+                sparse_combine<HQ>(acc, lane, first, SA.nsplit, SA.wsplit);
+#pragma unroll
+                for (int q = 0; q < HQ; ++q) {
+                    const int c = 2 * q + h;
+                    const float u = (first && c < H) ? gU1[r * FS + c] : 0.0f;
+                    float dx = acc[q];
+                    if (first && r == tr && c < H) dx += sh.dEs[c];
+                    acc[q] = (u > 0.0f) ? dx : 0.0f;
+                    uu[q] = u;
+                }
+                const f32x16 c16 = sparse_backward_rowlocal<HQ>(acc, uu, first ? sRn1[r] : 1.0f, sW1, D, H, li, h);
+                sparse_store_cols(c16, gdZ1 + r * FS, D, first, h);
+                sparse_store_cols(c16, stage + li * 33, D, true, h);  // same values through LDS for the other half-lane
+                wave_sync();
+#pragma unroll
+                for (int q = 0; q < DQ; ++q)
+                    if (first && 2 * q + h < D) dfq[q] = stage[li * 33 + 2 * q + h] * zraw[q];
+            }
+#pragma unroll
+            for (int q = 0; q < DQ; ++q) {
+                float v = dfq[q];
+                v += row_shl<8>(v);
+                v += row_shl<4>(v);
+                v += row_shl<2>(v);
+                v += row_shl<1>(v);
+                v += __shfl_xor(v, 16);
+                if (li == 0) sh.dfw[wave][2 * q + h] = v;
+            }
+        }
+        __syncthreads();
+        if (tid < D) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += sh.dfw[w][tid];
+            sh.dfp[tid] = s;
+        }
+        // ======== per edge: G_ij + G_ji, regulariser gradients, Adam in place on both directed entries, next Abar ========
+        const bool republish = iter + 1 < p.num_iters;  // the returned mask is the one of the LAST forward (explain.py:209-211)
+        for (int k = tid; k < eup; k += NT) {
+            const unsigned nd = eidx[2 * k], en = eidx[2 * k + 1];
+            const int i = nd & 4095u, j = (nd >> 12) & 4095u;
+            const bool near = (nd >> 24) & 1u;
+            const float* zi = gdZ1 + i * FS;
+            const float* zj = gdZ1 + j * FS;
+            const float* xi = gX + i * FS;
+            const float* xj = gX + j * FS;
+            float G0 = 0.0f, G1 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 2 * DQ; ++c) {
+                const float t1 = fmaf(zi[c], xj[c], zj[c] * xi[c]) * sh.phi[c];
+                G0 += (c < D) ? t1 : 0.0f;
+            }
+            if (near) {
+                const float* di = gdZ2 + i * FS;
+                const float* dj = gdZ2 + j * FS;
+                const float* ui = gU1 + i * FS;
+                const float* uj = gU1 + j * FS;
+#pragma unroll
+                for (int c = 0; c < 2 * HQ; ++c) {
+                    const float t2 = fmaf(di[c], relu_(uj[c]), dj[c] * relu_(ui[c]));
+                    G1 += (c < H) ? t2 : 0.0f;
+                }
+            }
+            float G = G0 + G1;
+            G += (i == tr) ? sG3[j] : 0.0f;
+            G += (j == tr) ? sG3[i] : 0.0f;
+            const float dy = sYhat[i] - sYhat[j];
+            const float w = Ag[(size_t)i * ld + j];
+            const float gc = (0.5f * G + p.c_lap * 0.5f * dy * dy * inv_n2) * w;
+            const size_t pij = (size_t)i * ld + j, pji = (size_t)j * ld + i;
+            float Mij = Mg[pij], Mji = Mg[pji], mij = mg[pij], mji = mg[pji], vij = vg[pij], vji = vg[pji];
+            {
+                const float S = sigmoidf_(Mij);
+                const float g = (gc + p.c_size - p.c_ent * Mij * inv_n2) * S * (1.0f - S);
+                adam_update(Mij, mij, vij, g, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+            }
+            {
+                const float S = sigmoidf_(Mji);
+                const float g = (gc + p.c_size - p.c_ent * Mji * inv_n2) * S * (1.0f - S);
+                adam_update(Mji, mji, vji, g, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+            }
+            Mg[pij] = Mij;
+            Mg[pji] = Mji;
+            mg[pij] = mij;
+            mg[pji] = mji;
+            vg[pij] = vij;
+            vg[pji] = vji;
+            if (republish) {  // nobody reads sAb any more in this iteration (the barrier above); sArt is rebuilt next iteration
+                const float a = w * (0.5f * (sigmoidf_(Mij) + sigmoidf_(Mji)));
+                sAb[en & 0xffffu] = a;
+                sAb[en >> 16] = a;
+            }
+        }
+        for (int r = tid; r < ld; r += NT) sArt[r] = 0.0f;
+        __syncthreads();
+        if (tid < D) {  // feature mask
+            const float ph = sh.phi[tid];
+            const float gf = (sh.dfp[tid] + p.c_feat_size / (float)D) * ph * (1.0f - ph);
+            float fn = sh.fcur[tid], m = sh.mf[tid], v = sh.vf[tid];
+            adam_update(fn, m, v, gf, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+            sh.fcur[tid] = fn;
+            sh.mf[tid] = m;
+            sh.vf[tid] = v;
+        }
+        __syncthreads();
+    }
+    // ---------------- results: dense Abar block (zero off the edges); M was updated in place; feature mask ----------------
+    {
+        f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int e = tid * 4; e < ld * ld; e += 4 * NT) *reinterpret_cast<f32x4*>(p.Abar + tm.offQ + e) = z4;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int k = tid; k < eup; k += NT) {
+        const unsigned nd = eidx[2 * k], en = eidx[2 * k + 1];
+        const int i = nd & 4095u, j = (nd >> 12) & 4095u;
+        const float a = sAb[en & 0xffffu];
+        p.Abar[tm.offQ + (size_t)i * ld + j] = a;
+        p.Abar[tm.offQ + (size_t)j * ld + i] = a;
+    }
+    if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = (tid < D) ? sh.fcur[tid] : 0.0f;
+}
+
+// gnnx_plan_analyze, large targets (512 < ld, n <= SPL_N_MAX): directed entries and the row slots (of SPL_CHUNK entries)
+// needed by the rows within two hops of the target - the same levels and placement as k_sparse_large computes.
+// out[2 t] = nnz, out[2 t + 1] = slots (-1: a row that cannot be placed); targets outside the range get (-1, -1).
+__global__ __launch_bounds__(256) void k_count_edges_large(const TargetMeta* meta, const float* A, int32_t* out) {
+    __shared__ int deg[SPL_N_MAX + 1];
+    __shared__ unsigned char level[SPL_N_MAX + 1];
+    __shared__ int part[4];
+    const TargetMeta tm = meta[blockIdx.x];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tm.ld <= SP_LD_MAX || tm.n > SPL_N_MAX) {
+        if (tid == 0) {
+            out[2 * blockIdx.x] = -1;
+            out[2 * blockIdx.x + 1] = -1;
+        }
+        return;
+    }
+    const float* Ag = A + tm.offQ;
+    int cnt = 0;
+    for (int r = wave; r < tm.n; r += 4) {
+        int d = 0;
+        for (int c0 = 0; c0 < tm.n; c0 += 64) {
+            const int c = c0 + lane;
+            const bool nz = (c < tm.n && c != r) ? (Ag[(size_t)r * tm.ld + c] != 0.0f) : false;
+            d += __popcll(__ballot(nz));
+        }
+        cnt += d;
+        if (lane == 0) deg[r] = d;
+    }
+    for (int r = tid; r < tm.n; r += 256) level[r] = (r == tm.t) ? 0 : 3;
+    if (lane == 0) part[wave] = cnt;
+    __syncthreads();
+    for (int d = 1; d <= 2; ++d) {  // hop levels from the dense rows
+        for (int r = wave; r < tm.n; r += 4) {
+            if (level[r] != d - 1) continue;  // uniform per wave
+            for (int c0 = 0; c0 < tm.n; c0 += 64) {
+                const int c = c0 + lane;
+                if (c < tm.n && c != r && Ag[(size_t)r * tm.ld + c] != 0.0f && level[c] > d) level[c] = (unsigned char)d;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int pos = 0, singles = 0;
+        bool placeable = true;
+        for (int r = 0; r < tm.n; ++r) {
+            if (level[r] > 2) continue;
+            if (deg[r] > SPL_CHUNK) {
+                const int ns = sparse_slots_of_c(deg[r], SPL_CHUNK);
+                placeable &= ns <= SP_MAX_SPLIT;
+                pos = sparse_place(pos, ns) + ns;
+            } else {
+                ++singles;
+            }
+        }
+        out[2 * blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+        out[2 * blockIdx.x + 1] = placeable ? pos + singles : -1;
+    }
+}
+
+}  // namespace gnnx

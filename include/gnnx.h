@@ -96,7 +96,9 @@ int gnnx_run(gnnx_handle h, const gnnx_hyper* hyper, const float* A, const float
 /* Inspect the packed adjacency A (DEVICE pointer, the layout of gnnx_get_layout) and choose the kernel of every target:
  * targets whose EDGE state fits a compute unit (n <= 512, <= 2048 undirected edges, rows of <= 256 entries, LDS
  * budget; node and graph mode) take the sparse on-chip-resident kernel in the smallest of its three size classes
- * that holds them (single-tile node-mode targets that fit none keep the dense on-chip-resident kernel), which
+ * that holds them (single-tile node-mode targets that fit none keep the dense on-chip-resident kernel); larger
+ * node-mode targets (n <= 4095, < 32768 undirected edges, <= 512 row slots within two hops of the target) take its
+ * large variant with the row arrays in the workspace; either way it
  * optimises only the mask entries on edges - the only ones that reach an output of the reference
  * (explain.py:665-678, 209-211; non-edge entries of M then keep their initial values); the rest streams.
  * Optional: without this call the plan uses the split described at gnnx_hyper.use_resident.  Synchronises `stream`.
@@ -105,13 +107,14 @@ int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream);
 
 /* The kernel every target is routed to (host array of num_targets entries): 0 = dense streaming kernels,
  * 1..3 = dense on-chip-resident kernel of that many 32-row blocks, 4 / 5 / 6 = sparse on-chip-resident kernel in its
- * 1024- / 256- / 64-thread size class (n <= 512 / 128 / 32). */
+ * 1024- / 256- / 64-thread size class (n <= 512 / 128 / 32), 7 = sparse kernel for larger node-mode targets
+ * (n <= 4095; edge state in LDS, row arrays in the workspace). */
 int gnnx_get_route(gnnx_handle h, int32_t* route);
 
 /* Measurement hook: device time (ms, HIP events on the side streams the kernels run on) of the on-chip-resident
  * launches of the LAST gnnx_run, in situ (i.e. while the other kernels of that run were executing):
  * ms[0..2] = dense resident kernels of 1..3 row blocks, ms[3..5] = sparse resident kernel, 1024- / 256- / 64-thread
- * size class (6 floats); 0 where nothing was launched.
+ * size class, ms[6] = sparse kernel for larger targets (7 floats); 0 where nothing was launched.
  * Waits for those launches to finish. */
 int gnnx_resident_times(gnnx_handle h, float* ms);
 

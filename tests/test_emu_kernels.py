@@ -270,3 +270,32 @@ def test_sparse_kernel_weighted_adjacency_and_self_loops(n):
     assert np.abs(res.masked_adj[0].astype(np.float64) * A - want).max() < 5e-6
     assert np.abs(res.mask[0] - o.M)[live].max() < 5e-5
     assert np.all(np.diag(res.masked_adj[0]) == 0)
+
+
+def test_large_target_sparse_kernel_with_split_hub_rows():
+    """n = 600 (beyond the LDS-resident classes): k_sparse_large keeps the edge state in LDS and the row arrays in the
+    workspace, updates M / m / v in place on the edges and splits a 150-neighbour hub row over three 64-entry slots."""
+    rng = np.random.default_rng(3)
+    sd = helpers.random_model(rng, 10, 20, 20, 4)
+    n = 600
+    A, X = helpers.random_graph(rng, n, 10, density=0.004)
+    hub = 7
+    idx = rng.choice(np.arange(n), 150, replace=False)
+    idx = idx[idx != hub]
+    A[hub, idx] = 1
+    A[idx, hub] = 1
+    m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
+    t = int(idx[0])                       # a target adjacent to the hub: the hub row is in both row sets
+    sg = Subgraph(A, X, 1, t, rng.integers(0, 4, n), m0)
+    job = emu_job([sg], sd)
+    assert list(job.route()) == [7]
+    res = job.run([m0], Hyper(num_iters=4))
+    o = closed_form.ClosedFormOracle(A, X, sd, 1, sg.pred_label, t, m0)
+    want = o.run(4)
+    live = A != 0
+    assert np.abs(res.masked_adj[0] - want).max() < 5e-6
+    assert np.abs(res.mask[0] - o.M)[live].max() < 5e-5 and np.abs(res.feat_mask[0] - o.f).max() < 5e-5
+    assert np.array_equal(res.mask[0][~live], m0[~live])
+    assert np.array_equal(res.masked_adj[0], res.masked_adj[0].T)
+    dense = emu_job([sg], sd, analyze=False).run([m0], Hyper(num_iters=4))      # dense streaming kernels
+    assert np.abs(res.masked_adj[0] - dense.masked_adj[0]).max() < 2e-6

@@ -196,6 +196,7 @@ def test_resident_only_batch_is_deterministic():
     (31, 8, 3, 2, 70, False, "resident"), (31, 8, 3, 2, 70, False, "sparse"), (10, 20, 20, 4, 96, False, "resident"),
     (7, 13, 9, 3, 130, False, "sparse"), (14, 20, 20, 2, 40, True, "stream"), (3, 9, 17, 9, 33, True, "stream"),
     (14, 20, 20, 2, 40, True, "sparse"), (3, 9, 17, 5, 70, True, "sparse"),
+    (10, 20, 20, 4, 700, False, "sparse"), (7, 13, 9, 3, 1500, False, "sparse"),
     (10, 20, 20, 4, 300, False, "stream"), (10, 20, 20, 4, 300, False, "sparse"), (10, 20, 20, 4, 400, False, "sparse"),
 ])
 def test_generic_shapes_match_closed_form(D, H, O, C, n, graph_mode, path):
@@ -203,7 +204,7 @@ def test_generic_shapes_match_closed_form(D, H, O, C, n, graph_mode, path):
     streaming kernels, the dense resident kernels (no analysis) and the sparse resident kernel."""
     rng = np.random.default_rng(D * 1000 + H * 10 + n)
     sd = helpers.random_model(rng, D, H, O, C)
-    A, X = helpers.random_graph(rng, n, D, density=0.15 if n < 100 else 0.03 if n < 400 else 0.01)
+    A, X = helpers.random_graph(rng, n, D, density=0.15 if n < 100 else 0.03 if n < 400 else 0.01 if n < 600 else 2.0 / n)
     m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
     t, gt = int(rng.integers(0, n)), int(rng.integers(0, C))
     yhat = None if graph_mode else rng.integers(0, C, n)
