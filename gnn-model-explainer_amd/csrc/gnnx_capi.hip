@@ -667,6 +667,12 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
             if (new_cat[t] == CAT_SPARSE + 1) new_cat[t] = CAT_SPARSE;
             if (new_cat[t] == CAT_SPARSE + 2 && !graph && h->res_nbmax >= 1) new_cat[t] = 1;
         }
+    if (std::getenv("GNNX_DEBUG_ROUTE"))
+        for (int t = 0; t < T; ++t)
+            if (new_cat[t] == 0)
+                std::fprintf(stderr, "gnnx route: target %d n=%d ld=%d streams: nnz=%d slots=%d | large: nnz=%d slots=%d\n", t,
+                             h->meta[t].n, h->meta[t].ld, h->nnz[2 * t], h->nnz[2 * t + 1], h->nnz[2 * T + 2 * t],
+                             h->nnz[2 * T + 2 * t + 1]);
     for (int t = 0; t < T; ++t) {
         changed |= (new_cat[t] != h->cat[t]);
         h->cat[t] = new_cat[t];

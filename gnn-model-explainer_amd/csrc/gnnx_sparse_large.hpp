@@ -23,7 +23,9 @@ constexpr int SPL_THREADS = 1024;
 constexpr int SPL_CHUNK = 64;               // entries per row slot
 constexpr int SPL_N_MAX = 4095;             // node ids are packed in 12 bits
 constexpr int SPL_POOL_FLOATS = 39168;      // 153 KB of LDS
-constexpr int SPL_STAGE = 16 * TILE * 33;   // one staging tile per wave (dZ1 for the feature-mask gradient)
+__host__ __device__ constexpr int spl_stage_floats(int D) { return 16 * TILE * (D | 1); }  // a [32][D|1] dZ1 tile per wave
+
+struct SlotRec { unsigned x, y; };  // see k_sparse_large: x = row | nsplit << 12 | wsplit << 17 | first << 22, y = e0 | len << 16
 
 __host__ __device__ inline int sparse_slots_of_c(int deg, int chunk) { return deg <= chunk ? 1 : (deg + chunk - 1) / chunk; }
 
@@ -41,15 +43,16 @@ __host__ __device__ inline SparseLargeLayout sparse_large_layout(int ld, int nnz
     L.oG3 = o;     o += ld;
     L.oW = o;      o += (D + 2 * H) * 33;
     L.oWp = o;     o += C * 96;
-    L.oStage = o;  o += SPL_STAGE;
+    L.oStage = o;  o += spl_stage_floats(D);
     L.oAb = o;     o += nnz;
     L.oCol = o;    o += (nnz + 1) / 2;
     L.total = o;
     return L;
 }
-// slots: row slots of 64 entries needed by the rows within two hops of the target (k_count_edges)
+// slots: row slots of 64 entries needed by the rows within two hops of the target (k_count_edges_large); they are
+// processed 512 at a time, their records (both row sets) live in a workspace array of 16 ld entries
 __host__ __device__ inline bool sparse_large_fits(int n, int ld, int nnz, int slots, int D, int H, int C) {
-    return n <= SPL_N_MAX && nnz < 65536 && nnz <= 32 * ld && slots >= 0 && slots <= SPL_THREADS / 2 && C <= RES_CMAX &&
+    return n <= SPL_N_MAX && nnz < 65536 && nnz <= 32 * ld && slots >= 0 && 2 * slots + 64 <= 16 * ld && C <= RES_CMAX &&
            H >= 2 && 10 * ld >= 7 * ld + 2 * SPL_CHUNK + 16 && sparse_large_layout(ld, nnz, D, H, C).total <= SPL_POOL_FLOATS;
 }
 
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         for (int e = tid; e < ld * ld; e += NT) p.Abar[tm.offQ + e] = qnan;
         if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = qnan;
     };
-    if (n > SPL_N_MAX || 6 * ld + 1 + (D + 2 * H) * 33 + C * 96 + SPL_STAGE > SPL_POOL_FLOATS) {  // uniform
+    if (n > SPL_N_MAX || 6 * ld + 1 + (D + 2 * H) * 33 + C * 96 + spl_stage_floats(D) > SPL_POOL_FLOATS) {  // uniform
         fail_nan();
         return;
     }
@@ -137,7 +140,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     float* sW2 = sW1 + D * 33;
     float* sW3 = sW2 + H * 33;
     float* sWp = pool + L.oWp;
-    float* stage = pool + L.oStage + wave * (TILE * 33);
+    const int sS = D | 1;
+    float* stage = pool + L.oStage + wave * (TILE * sS);
     float* sAb = pool + L.oAb;
     unsigned short* scol = reinterpret_cast<unsigned short*>(pool + L.oCol);
 
@@ -221,50 +225,74 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         slot_start[cnt] = (unsigned short)(pos + (cnt - pcount));
         sh.set_rows[set] = cnt;
         sh.set_slots[set] = pos + (cnt - pcount);
-        if (pos + (cnt - pcount) > NT / 2) sh.bad = 1;
+        if (2 * (pos + (cnt - pcount)) + 64 > 16 * ld) sh.bad = 1;
     }
     __syncthreads();
     const int eup = sh.eup;
-    RowSlot rs[2];
-#pragma unroll
+    // slot records -> workspace (set A first, then set B, each padded to whole waves): the phases walk them 512 at a time
+    //   x = row | nsplit << 12 | wsplit << 17 | first << 22,   y = e0 | len << 16   (x = y = 0: empty slot)
+    SlotRec* srec = reinterpret_cast<SlotRec*>(p.UT[1] + tm.offR * FS);
+    const int slotsA = sh.bad ? 0 : sh.set_slots[0], slotsB = sh.bad ? 0 : sh.set_slots[1];
+    const int padA = (slotsA + 31) & ~31, padB = (slotsB + 31) & ~31;
     for (int k = 0; k < 2; ++k) {
         const unsigned short* slot_start = slot_tab + k * (2 * ld + SETSZ_EXTRA);
         const unsigned short* order = slot_start + ld + 1;
-        RowSlot z;
-        z.row = 0;
-        z.e0 = z.e1 = 0;
-        z.nsplit = 1;
-        z.first = false;
-        const int sl = wave * TILE + li, cnt = sh.set_rows[k];
-        if (sl < sh.set_slots[k] && !sh.bad) {
-            int lo = 0, hi = cnt;
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if ((int)slot_start[mid] <= sl) lo = mid; else hi = mid;
+        const int cnt = sh.set_rows[k], nslots = k ? slotsB : slotsA, npad = k ? padB : padA, base = k ? padA : 0;
+        for (int s0 = wave * TILE; s0 < npad; s0 += NW * TILE) {  // one wave per 32 slots (both half-waves compute the same)
+            const int sl = s0 + li;
+            int zrow = 0, ze0 = 0, zlen = 0, zns = 1;
+            bool zfirst = false;
+            if (sl < nslots) {
+                int lo = 0, hi = cnt;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((int)slot_start[mid] <= sl) lo = mid; else hi = mid;
+                }
+                const int row = order[lo];
+                const int ra = rowptr[row], rb = rowptr[row + 1];
+                const int ns = sparse_slots_of_c(rb - ra, SPL_CHUNK), kk = sl - (int)slot_start[lo];
+                if (kk < ns) {
+                    zrow = row;
+                    ze0 = ra + kk * SPL_CHUNK;
+                    zlen = ((ze0 + SPL_CHUNK < rb) ? ze0 + SPL_CHUNK : rb) - ze0;
+                    zns = ns;
+                    zfirst = (kk == 0);
+                }
             }
-            const int row = order[lo];
-            const int ra = rowptr[row], rb = rowptr[row + 1];
-            const int ns = sparse_slots_of_c(rb - ra, SPL_CHUNK), kk = sl - (int)slot_start[lo];
-            if (kk < ns) {
-                z.row = row;
-                z.e0 = ra + kk * SPL_CHUNK;
-                z.e1 = (z.e0 + SPL_CHUNK < rb) ? z.e0 + SPL_CHUNK : rb;
-                z.nsplit = ns;
-                z.first = (kk == 0);
-            }
-        }
-        int wsplit = z.first ? z.nsplit : 1;
+            int wsplit = zfirst ? zns : 1;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int other = __shfl_xor(wsplit, o);
-            wsplit = other > wsplit ? other : wsplit;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int other = __shfl_xor(wsplit, o);
+                wsplit = other > wsplit ? other : wsplit;
+            }
+            if (h == 0) {
+                SlotRec rec;
+                rec.x = (unsigned)zrow | ((unsigned)zns << 12) | ((unsigned)wsplit << 17) | ((unsigned)zfirst << 22);
+                rec.y = (unsigned)ze0 | ((unsigned)zlen << 16);
+                srec[base + sl] = rec;
+            }
         }
-        z.wsplit = wsplit;
-        z.wave_active = wave * TILE < sh.set_slots[k];
-        rs[k] = z;
     }
-    const RowSlot& SA = rs[0];
-    const RowSlot& SB = rs[1];
+    auto slot_of = [&](int set, int round) -> RowSlot {  // this lane's slot in the given round (512 slots per round)
+        const int sl = round * (NT / 2) + wave * TILE + li;
+        const int npad = set ? padB : padA;
+        RowSlot z;
+        SlotRec rec;
+        rec.x = rec.y = 0u;
+        if (sl < npad) rec = srec[(set ? padA : 0) + sl];
+        z.row = rec.x & 4095u;
+        z.nsplit = (rec.x >> 12) & 31u;
+        z.wsplit = (rec.x >> 17) & 31u;
+        z.first = (rec.x >> 22) & 1u;
+        z.e0 = rec.y & 0xffffu;
+        z.e1 = z.e0 + (int)(rec.y >> 16);
+        z.wave_active = round * (NT / 2) + wave * TILE < npad;
+        if (z.nsplit == 0) z.nsplit = 1;
+        if (z.wsplit == 0) z.wsplit = 1;
+        return z;
+    };
+    const int roundsA = (padA + NT / 2 - 1) / (NT / 2), roundsB = (padB + NT / 2 - 1) / (NT / 2);
+    float* gZraw = p.Zraw + tm.offR * FS;
     // per-edge indices -> global; Adam moments of the live entries start at zero; symmetry check
     {
         bool asym = (2 * eup != nnz);
@@ -320,7 +348,6 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     }
     const float inv_n2 = 1.0f / ((float)n * (float)n);
     const int rt0 = rowptr[tr], rt1 = rowptr[tr + 1];
-    float zraw[DQ];
     // sigma(M) -> symmetrised masked adjacency, one float per directed entry
     for (int k = tid; k < eup; k += NT) {
         const unsigned nd = eidx[2 * k], en = eidx[2 * k + 1];
@@ -338,7 +365,9 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         const float step_size = adam_tab[2 * iter], inv_bc2s = 1.0f / adam_tab[2 * iter + 1];
 
         // ======== layer 1 on the rows within two hops: Zraw = Abar . X (kept in registers), U1 ========
-        if (SA.wave_active) {
+        for (int round = 0; round < roundsA; ++round) {
+            const RowSlot SA = slot_of(0, round);
+            if (!SA.wave_active) continue;  // uniform per wave
             const bool first = SA.first;
             const int r = first ? SA.row : 0;
             float acc[DQ];
@@ -348,14 +377,16 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             sparse_combine<DQ>(acc, lane, first, SA.nsplit, SA.wsplit);
 #pragma unroll
             for (int q = 0; q < DQ; ++q) {
-                zraw[q] = acc[q];
+                if (first && 2 * q + h < D) gZraw[r * FS + 2 * q + h] = acc[q];  // for the feature-mask gradient
                 acc[q] = (first && 2 * q + h < D) ? acc[q] * sh.phi[2 * q + h] : 0.0f;
             }
             sparse_forward_rowlocal<DQ>(acc, sW1, sh.bias[0], D, H, li, h, first, gU1 + r * FS, sRn1 + r);
         }
         __syncthreads();
         // ======== layer 2 on the target and its neighbours: U2 ========
-        if (SB.wave_active) {
+        for (int round = 0; round < roundsB; ++round) {
+            const RowSlot SB = slot_of(1, round);
+            if (!SB.wave_active) continue;
             const bool first = SB.first;
             const int r = first ? SB.row : 0;
             float acc[HQ];
@@ -445,7 +476,9 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         }
         __syncthreads();
         // ======== dZ2 (rank-1) on the target and its neighbours, g3; dZ2 overwrites U2 row by row ========
-        if (SB.wave_active) {
+        for (int round = 0; round < roundsB; ++round) {
+            const RowSlot SB = slot_of(1, round);
+            if (!SB.wave_active) continue;
             const bool first = SB.first;
             const int r = first ? SB.row : 0;
             const float art = sArt[r];
@@ -474,7 +507,9 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             float dfq[DQ];
 #pragma unroll
             for (int q = 0; q < DQ; ++q) dfq[q] = 0.0f;
-            if (SA.wave_active) {
+            for (int round = 0; round < roundsA; ++round) {
+                const RowSlot SA = slot_of(0, round);
+                if (!SA.wave_active) continue;
                 const bool first = SA.first;
                 const int r = first ? SA.row : 0;
                 float acc[HQ], uu[HQ];
@@ -493,11 +528,12 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 }
                 const f32x16 c16 = sparse_backward_rowlocal<HQ>(acc, uu, first ? sRn1[r] : 1.0f, sW1, D, H, li, h);
                 sparse_store_cols(c16, gdZ1 + r * FS, D, first, h);
-                sparse_store_cols(c16, stage + li * 33, D, true, h);  // same values through LDS for the other half-lane
+                sparse_store_cols(c16, stage + li * sS, D, true, h);  // same values through LDS for the other half-lane
                 wave_sync();
 #pragma unroll
                 for (int q = 0; q < DQ; ++q)
-                    if (first && 2 * q + h < D) dfq[q] = stage[li * 33 + 2 * q + h] * zraw[q];
+                    if (first && 2 * q + h < D) dfq[q] = fmaf(stage[li * sS + 2 * q + h], gZraw[r * FS + 2 * q + h], dfq[q]);
+                wave_sync();  // the staging tile is reused in the next round
             }
 #pragma unroll
             for (int q = 0; q < DQ; ++q) {
@@ -604,7 +640,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = (tid < D) ? sh.fcur[tid] : 0.0f;
 }
 
-// gnnx_plan_analyze, large targets (512 < ld, n <= SPL_N_MAX): directed entries and the row slots (of SPL_CHUNK entries)
+// gnnx_plan_analyze, every target with n <= SPL_N_MAX (also those of <= 512 rows that fit no resident class, e.g. more
+// than 2048 edges): directed entries and the row slots (of SPL_CHUNK entries)
 // needed by the rows within two hops of the target - the same levels and placement as k_sparse_large computes.
 // out[2 t] = nnz, out[2 t + 1] = slots (-1: a row that cannot be placed); targets outside the range get (-1, -1).
 __global__ __launch_bounds__(256) void k_count_edges_large(const TargetMeta* meta, const float* A, int32_t* out) {
@@ -613,7 +650,7 @@ __global__ __launch_bounds__(256) void k_count_edges_large(const TargetMeta* met
     __shared__ int part[4];
     const TargetMeta tm = meta[blockIdx.x];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tm.ld <= SP_LD_MAX || tm.n > SPL_N_MAX) {
+    if (tm.n > SPL_N_MAX) {
         if (tid == 0) {
             out[2 * blockIdx.x] = -1;
             out[2 * blockIdx.x + 1] = -1;

@@ -102,7 +102,8 @@ int gnnx_run(gnnx_handle h, const gnnx_hyper* hyper, const float* A, const float
  * optimises only the mask entries on edges - the only ones that reach an output of the reference
  * (explain.py:665-678, 209-211; non-edge entries of M then keep their initial values); the rest streams.
  * Optional: without this call the plan uses the split described at gnnx_hyper.use_resident.  Synchronises `stream`.
- * GNNX_SPARSE_RESIDENT=0 in the environment disables the sparse kernel. */
+ * Environment: GNNX_SPARSE_RESIDENT=0 disables the sparse kernels, GNNX_SPARSE_LARGE=0 / GNNX_TINY_SPARSE=0 the large
+ * variant / the 64-thread class, GNNX_DEBUG_ROUTE=1 prints the analysis of every target that ends up streaming. */
 int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream);
 
 /* The kernel every target is routed to (host array of num_targets entries): 0 = dense streaming kernels,
