@@ -41,7 +41,7 @@ struct GraphKey {
 };
 
 constexpr int N_SPC = 4;                       // size classes of k_sparse_resident (0..2) + k_sparse_large (3)
-constexpr int SPC_THREADS[N_SPC] = {1024, 256, 64, 1024};
+constexpr int SPC_THREADS[N_SPC] = {1024, 256, 64, SPL_THREADS};
 constexpr int SPC_LARGE = 3;
 constexpr int N_SIDE = RES_NBMAX + N_SPC;
 constexpr int CAT_SPARSE = RES_NBMAX + 1;      // CAT_SPARSE + k: sparse resident kernel of size class k
@@ -73,6 +73,9 @@ struct gnnx_plan_s {
     int32_t* d_sp[N_SPC] = {};
     int n_sparse() const { return n_sp[0] + n_sp[1] + n_sp[2] + n_sp[3]; }
     int32_t* d_nnz = nullptr;
+    int32_t* d_csr_rowptr = nullptr;   // CSR of the targets of k_sparse_large (gnnx_plan_analyze)
+    unsigned short* d_csr_col = nullptr;
+    long long* d_csr_off = nullptr;    // [2 T]: offsets of target t into the two arrays
     float* d_adam = nullptr;         // per-iteration Adam scalars for the resident kernel
     std::vector<float> adam_host;
     gnnx_hyper adam_for{};
@@ -318,6 +321,9 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
     for (int k = 0; k < N_SPC; ++k)
         if (h->d_sp[k]) (void)hipFree(h->d_sp[k]);
     if (h->d_nnz) (void)hipFree(h->d_nnz);
+    if (h->d_csr_rowptr) (void)hipFree(h->d_csr_rowptr);
+    if (h->d_csr_col) (void)hipFree(h->d_csr_col);
+    if (h->d_csr_off) (void)hipFree(h->d_csr_off);
     if (h->d_adam) (void)hipFree(h->d_adam);
     if (h->d_big) (void)hipFree(h->d_big);
     if (h->d_conv_big) (void)hipFree(h->d_conv_big);
@@ -489,9 +495,11 @@ static void launch_sparse(gnnx_handle h, const Params& p, int cls, const float* 
     if (cls == SPC_LARGE) {  // node-mode targets beyond the LDS-resident classes: row arrays in HBM / L2 (gnnx_sparse_large.hpp)
         const dim3 grid(h->n_sp[cls]), block(SPL_THREADS);
         if (h->prob.D <= 10 && std::max(h->prob.H, h->prob.O) <= 20)
-            hipLaunchKernelGGL((k_sparse_large<5, 10>), grid, block, 0, s, p, h->d_sp[cls], adam_tab);
+            hipLaunchKernelGGL((k_sparse_large<5, 10>), grid, block, 0, s, p, h->d_sp[cls], adam_tab, h->d_csr_rowptr,
+                               h->d_csr_col, h->d_csr_off);
         else
-            hipLaunchKernelGGL((k_sparse_large<16, 16>), grid, block, 0, s, p, h->d_sp[cls], adam_tab);
+            hipLaunchKernelGGL((k_sparse_large<16, 16>), grid, block, 0, s, p, h->d_sp[cls], adam_tab, h->d_csr_rowptr,
+                               h->d_csr_col, h->d_csr_off);
         return;
     }
     if (cls == 0) launch_sparse_nt<1024>(h, p, h->d_sp[0], h->n_sp[0], adam_tab, s);
@@ -677,7 +685,34 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
         changed |= (new_cat[t] != h->cat[t]);
         h->cat[t] = new_cat[t];
     }
-    return changed ? build_split(h) : 0;
+    if (changed)
+        if (int rc = build_split(h)) return rc;
+    // CSR of the large-class targets, built once per plan (the kernel would otherwise rescan its dense block per launch)
+    if (h->n_sp[SPC_LARGE] > 0) {
+        std::vector<long long> off(2 * (size_t)T, 0);
+        long long rp = 0, cl = 0;
+        for (int t = 0; t < T; ++t)
+            if (h->cat[t] == CAT_SPARSE + SPC_LARGE) {
+                off[2 * t] = rp;
+                off[2 * t + 1] = cl;
+                rp += h->meta[t].ld + 1;
+                cl += (h->nnz[2 * T + 2 * t] + 1) & ~1;
+            }
+        for (void* ptr : {(void*)h->d_csr_rowptr, (void*)h->d_csr_col, (void*)h->d_csr_off})
+            if (ptr) (void)hipFree(ptr);
+        h->d_csr_rowptr = nullptr;
+        h->d_csr_col = nullptr;
+        h->d_csr_off = nullptr;
+        HIPCK(hipMalloc(&h->d_csr_rowptr, sizeof(int32_t) * (size_t)rp));
+        HIPCK(hipMalloc(&h->d_csr_col, sizeof(unsigned short) * (size_t)std::max<long long>(cl, 2)));
+        HIPCK(hipMalloc(&h->d_csr_off, sizeof(long long) * off.size()));
+        HIPCK(hipMemcpy(h->d_csr_off, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_build_csr_large, dim3(h->n_sp[SPC_LARGE]), dim3(512), 0, s, h->d_meta, A, h->d_sp[SPC_LARGE], h->d_csr_off,
+                           h->d_csr_rowptr, h->d_csr_col);
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(s));
+    }
+    return 0;
 }
 
 extern "C" int gnnx_pack_csr(gnnx_handle h, const int64_t* indptr, const int32_t* indices, const float* weights,

@@ -140,10 +140,9 @@ __device__ __forceinline__ int lower_bound_u16(const unsigned short* a, int lo, 
 // max(x, 0) in one instruction (fmaxf costs two: it canonicalises its operands first)
 __device__ __forceinline__ float relu_(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
 
-template <bool RELU, int NQ, bool EXACT>
+template <bool RELU, int NQ, bool EXACT, int UN>
 __device__ __forceinline__ void sparse_gather_impl(const float* sAb, const unsigned short* scol, const float* B, int stride,
                                                    int W, int e0, int e1, int half, float (&acc)[NQ]) {
-    constexpr int UN = SP_GATHER_UNROLL;
     // Software pipeline over groups of UN entries: the (Abar, column) pairs of the NEXT group are loaded while the
     // rows of the current one are in flight, so a group costs one LDS round trip, not two.  A short last group is
     // padded with zero-weight copies of the row's first entry (no tail loop).
@@ -193,13 +192,13 @@ __device__ __forceinline__ void sparse_gather_impl(const float* sAb, const unsig
 }
 
 // W == 2 NQ (every column of the trip count is real: the reference's D = 10, H = 20) needs no column selects
-template <bool RELU, int NQ>
+template <bool RELU, int NQ, int UN = SP_GATHER_UNROLL>
 __device__ __forceinline__ void sparse_gather(const float* sAb, const unsigned short* scol, const float* B, int stride, int W,
                                               int e0, int e1, int half, float (&acc)[NQ]) {
     if (W == 2 * NQ)
-        sparse_gather_impl<RELU, NQ, true>(sAb, scol, B, stride, W, e0, e1, half, acc);
+        sparse_gather_impl<RELU, NQ, true, UN>(sAb, scol, B, stride, W, e0, e1, half, acc);
     else
-        sparse_gather_impl<RELU, NQ, false>(sAb, scol, B, stride, W, e0, e1, half, acc);
+        sparse_gather_impl<RELU, NQ, false, UN>(sAb, scol, B, stride, W, e0, e1, half, acc);
 }
 
 // forward row-local part for the lane's row: Y^T[c][r] = sum_k W[k][c] Z[r][k] on MFMA (the lane's registers zq[u] =

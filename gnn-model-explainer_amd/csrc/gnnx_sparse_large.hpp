@@ -7,8 +7,10 @@
 //     rowptr - and the per-row scalars (norms, labels, g3) and weights;
 //   * the row arrays X, U1, U2 (= dZ2), dZ1 are the caller's workspace arrays in HBM / L2 (stride 32 floats), written
 //     and re-read by the same workgroup, i.e. through one CU's L1/L2 path (__syncthreads makes them visible);
-//   * the mask entries on edges and their Adam moments are updated IN PLACE in the dense M / m / v arrays (two entries
-//     per undirected edge), the per-edge indices sit in the (otherwise unused) transposed workspace array;
+//   * the mask entries on edges, their Adam moments and the edge weights are gathered once into compact per-edge planes
+//     (coalesced; in an otherwise unused transposed workspace array, like the per-edge indices and the slot records)
+//     and scattered back into the dense M at the end - random accesses into a 24 MB dense block cost 67 us per iteration
+//     on the largest BA-House x100k target, the planes 10;
 //   * rows of up to 1024 entries are split into slots of 64 (the BA-House x100k hubs), loops run over rows / edges
 //     instead of one item per thread.
 // Hop pruning is what makes this affordable: on the BA-House x100k sample a 2460-node sub-graph has a few hundred rows
@@ -19,7 +21,8 @@
 
 namespace gnnx {
 
-constexpr int SPL_THREADS = 1024;
+constexpr int SPL_THREADS = 512;            // 8 waves: two per SIMD leave 256 VGPRs per lane (the 1024-thread build spilled 120)
+constexpr int SPL_GATHER_UNROLL = 4;        // entries in flight per lane: the rows come from L2, not LDS
 constexpr int SPL_CHUNK = 64;               // entries per row slot
 constexpr int SPL_N_MAX = 4095;             // node ids are packed in 12 bits
 constexpr int SPL_POOL_FLOATS = 39168;      // 153 KB of LDS
@@ -52,7 +55,7 @@ __host__ __device__ inline SparseLargeLayout sparse_large_layout(int ld, int nnz
 // slots: row slots of 64 entries needed by the rows within two hops of the target (k_count_edges_large); they are
 // processed 512 at a time, their records (both row sets) live in a workspace array of 16 ld entries
 __host__ __device__ inline bool sparse_large_fits(int n, int ld, int nnz, int slots, int D, int H, int C) {
-    return n <= SPL_N_MAX && nnz < 65536 && nnz <= 32 * ld && slots >= 0 && 2 * slots + 64 <= 16 * ld && C <= RES_CMAX &&
+    return n <= SPL_N_MAX && nnz < 65536 && 7 * (nnz / 2) <= 32 * ld && slots >= 0 && 2 * slots + 64 <= 16 * ld && C <= RES_CMAX &&
            H >= 2 && 10 * ld >= 7 * ld + 2 * SPL_CHUNK + 16 && sparse_large_layout(ld, nnz, D, H, C).total <= SPL_POOL_FLOATS;
 }
 
@@ -73,8 +76,12 @@ __device__ __forceinline__ int wave_exclusive_scan_array(T* a, int len, int lane
     return __shfl(incl, 63);
 }
 
+// csr_*: the targets' CSR structure, built once per plan by k_build_csr_large (scanning a 24 MB dense block with one
+// workgroup takes 4 ms per pass - too much to repeat in every launch): rowptr at csr_off[2 t], columns at csr_off[2 t + 1]
 template <int DQ, int HQ>
-__global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const int32_t* targets, const float* adam_tab) {
+__global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const int32_t* targets, const float* adam_tab,
+                                                              const int32_t* csr_rowptr, const unsigned short* csr_col,
+                                                              const long long* csr_off) {
     constexpr int NT = SPL_THREADS, NW = NT / 64;
     __shared__ float pool[SPL_POOL_FLOATS];
     __shared__ SparseFixed sh;
@@ -85,14 +92,13 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     const int D = p.D, H = p.H, O = p.O, C = p.C;
     const float* Ag = p.A + tm.offQ;
     float* Mg = p.M + tm.offQ;
-    float* mg = p.mM + tm.offQ;
-    float* vg = p.vM + tm.offQ;
+    float* est = p.UT[2] + tm.offR * FS;  // per-edge planes [7][eup]: M_ij, M_ji, m_ij, m_ji, v_ij, v_ji, weight
     // row arrays in the caller's workspace (stride FS); dZ2 overwrites U2 row by row as in the resident kernel
     const float* gX = p.X + tm.offR * FS;
     float* gU1 = p.U[0] + tm.offR * FS;
     float* gU2 = p.U[1] + tm.offR * FS;
     float* gdZ1 = p.dZ[0] + tm.offR * FS;
-    unsigned* eidx = reinterpret_cast<unsigned*>(p.UT[0] + tm.offR * FS);  // [eup][2]: i | j << 12 | near << 24, e_ij | e_ji << 16
+    unsigned* eidx = reinterpret_cast<unsigned*>(p.UT[0] + tm.offR * FS);  // [eup][2]: i | j << 12 | near << 24 | near2 << 25, e_ij | e_ji << 16
 
     auto fail_nan = [&]() {
         const float qnan = __builtin_nanf("");
@@ -103,26 +109,13 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         fail_nan();
         return;
     }
-    // ---------------- setup 1: degrees -> rowptr (the nnz-independent part of the layout comes first) ----------------
+    // ---------------- setup 1: rowptr from the plan's CSR (the nnz-independent part of the layout comes first) ----------------
     int* rowptr = reinterpret_cast<int*>(pool);
-    for (int r = wave; r < ld; r += NW) {
-        int cnt = 0;
-        if (r < n)
-            for (int c0 = 0; c0 < n; c0 += 64) {
-                const int c = c0 + lane;
-                const bool nz = (c < n && c != r) ? (Ag[(size_t)r * ld + c] != 0.0f) : false;
-                cnt += __popcll(__ballot(nz));
-            }
-        if (lane == 0) rowptr[r] = cnt;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        const int total = wave_exclusive_scan_array(rowptr, ld, lane);
-        if (lane == 0) {
-            rowptr[ld] = total;
-            sh.nnz = total;
-            sh.bad = 0;
-        }
+    const int32_t* grp = csr_rowptr + csr_off[2 * t];
+    for (int r = tid; r <= ld; r += NT) rowptr[r] = grp[r];
+    if (tid == 0) {
+        sh.nnz = grp[ld];
+        sh.bad = 0;
     }
     __syncthreads();
     const int nnz = sh.nnz;
@@ -145,16 +138,10 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     float* sAb = pool + L.oAb;
     unsigned short* scol = reinterpret_cast<unsigned short*>(pool + L.oCol);
 
-    // ---------------- setup 2: sorted column lists ----------------
-    for (int r = wave; r < n; r += NW) {
-        int base = rowptr[r];
-        for (int c0 = 0; c0 < n; c0 += 64) {
-            const int c = c0 + lane;
-            const bool nz = (c < n && c != r) ? (Ag[(size_t)r * ld + c] != 0.0f) : false;
-            const unsigned long long bal = __ballot(nz);
-            if (nz) scol[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)c;
-            base += __popcll(bal);
-        }
+    // ---------------- setup 2: sorted column lists from the plan's CSR ----------------
+    {
+        const unsigned short* gcol = csr_col + csr_off[2 * t + 1];
+        for (int e = tid; e < nnz; e += NT) scol[e] = gcol[e];
     }
     __syncthreads();
     // ---------------- setup 3: uint16 temporaries in the Art .. G3 region ----------------
@@ -311,12 +298,16 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             if (Ag[(size_t)j * ld + i] != Ag[(size_t)i * ld + j]) asym = true;
             const int pi = lower_bound_u16(scol, t0, t1, i), pj = lower_bound_u16(scol, t0, t1, j);
             const bool near = i == tr || j == tr || (pi < t1 && (int)scol[pi] == i) || (pj < t1 && (int)scol[pj] == j);
-            eidx[2 * k] = (unsigned)i | ((unsigned)j << 12) | ((unsigned)near << 24);
+            const bool near2 = level[i] <= 2 || level[j] <= 2;  // else dZ1 is exactly zero on both endpoints: regularisers only
+            eidx[2 * k] = (unsigned)i | ((unsigned)j << 12) | ((unsigned)near << 24) | ((unsigned)near2 << 25);
             eidx[2 * k + 1] = (unsigned)e | ((unsigned)(asym ? e : em) << 16);
-            mg[(size_t)i * ld + j] = 0.0f;
-            mg[(size_t)j * ld + i] = 0.0f;
-            vg[(size_t)i * ld + j] = 0.0f;
-            vg[(size_t)j * ld + i] = 0.0f;
+            est[0 * eup + k] = Mg[(size_t)i * ld + j];
+            est[1 * eup + k] = Mg[(size_t)j * ld + i];
+            est[2 * eup + k] = 0.0f;
+            est[3 * eup + k] = 0.0f;
+            est[4 * eup + k] = 0.0f;
+            est[5 * eup + k] = 0.0f;
+            est[6 * eup + k] = Ag[(size_t)i * ld + j];
         }
         if (asym) sh.bad = 1;
     }
@@ -350,9 +341,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     const int rt0 = rowptr[tr], rt1 = rowptr[tr + 1];
     // sigma(M) -> symmetrised masked adjacency, one float per directed entry
     for (int k = tid; k < eup; k += NT) {
-        const unsigned nd = eidx[2 * k], en = eidx[2 * k + 1];
-        const int i = nd & 4095u, j = (nd >> 12) & 4095u;
-        const float a = Ag[(size_t)i * ld + j] * (0.5f * (sigmoidf_(Mg[(size_t)i * ld + j]) + sigmoidf_(Mg[(size_t)j * ld + i])));
+        const unsigned en = eidx[2 * k + 1];
+        const float a = est[6 * eup + k] * (0.5f * (sigmoidf_(est[0 * eup + k]) + sigmoidf_(est[1 * eup + k])));
         sAb[en & 0xffffu] = a;
         sAb[en >> 16] = a;
     }
@@ -373,7 +363,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             float acc[DQ];
 #pragma unroll
             for (int q = 0; q < DQ; ++q) acc[q] = 0.0f;
-            sparse_gather<false, DQ>(sAb, scol, gX, FS, D, SA.e0, SA.e1, h, acc);
+            sparse_gather<false, DQ, SPL_GATHER_UNROLL>(sAb, scol, gX, FS, D, SA.e0, SA.e1, h, acc);
             sparse_combine<DQ>(acc, lane, first, SA.nsplit, SA.wsplit);
 #pragma unroll
             for (int q = 0; q < DQ; ++q) {
@@ -392,7 +382,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             float acc[HQ];
 #pragma unroll
             for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
-            sparse_gather<true, HQ>(sAb, scol, gU1, FS, H, SB.e0, SB.e1, h, acc);
+            sparse_gather<true, HQ, SPL_GATHER_UNROLL>(sAb, scol, gU1, FS, H, SB.e0, SB.e1, h, acc);
             sparse_combine<HQ>(acc, lane, first, SB.nsplit, SB.wsplit);
 #pragma unroll
             for (int q = 0; q < HQ; ++q) acc[q] = first ? acc[q] : 0.0f;
@@ -515,7 +505,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 float acc[HQ], uu[HQ];
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
-                sparse_gather<false, HQ>(sAb, scol, gdZ2, FS, H, SA.e0, SA.e1, h, acc);
+                sparse_gather<false, HQ, SPL_GATHER_UNROLL>(sAb, scol, gdZ2, FS, H, SA.e0, SA.e1, h, acc);
                 sparse_combine<HQ>(acc, lane, first, SA.nsplit, SA.wsplit);
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) {
@@ -558,16 +548,18 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         for (int k = tid; k < eup; k += NT) {
             const unsigned nd = eidx[2 * k], en = eidx[2 * k + 1];
             const int i = nd & 4095u, j = (nd >> 12) & 4095u;
-            const bool near = (nd >> 24) & 1u;
-            const float* zi = gdZ1 + i * FS;
-            const float* zj = gdZ1 + j * FS;
-            const float* xi = gX + i * FS;
-            const float* xj = gX + j * FS;
+            const bool near = (nd >> 24) & 1u, near2 = (nd >> 25) & 1u;
             float G0 = 0.0f, G1 = 0.0f;
+            if (near2) {
+                const float* zi = gdZ1 + i * FS;
+                const float* zj = gdZ1 + j * FS;
+                const float* xi = gX + i * FS;
+                const float* xj = gX + j * FS;
 #pragma unroll
-            for (int c = 0; c < 2 * DQ; ++c) {
-                const float t1 = fmaf(zi[c], xj[c], zj[c] * xi[c]) * sh.phi[c];
-                G0 += (c < D) ? t1 : 0.0f;
+                for (int c = 0; c < 2 * DQ; ++c) {
+                    const float t1 = fmaf(zi[c], xj[c], zj[c] * xi[c]) * sh.phi[c];
+                    G0 += (c < D) ? t1 : 0.0f;
+                }
             }
             if (near) {
                 const float* di = gdZ2 + i * FS;
@@ -584,10 +576,10 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             G += (i == tr) ? sG3[j] : 0.0f;
             G += (j == tr) ? sG3[i] : 0.0f;
             const float dy = sYhat[i] - sYhat[j];
-            const float w = Ag[(size_t)i * ld + j];
+            const float w = est[6 * eup + k];
             const float gc = (0.5f * G + p.c_lap * 0.5f * dy * dy * inv_n2) * w;
-            const size_t pij = (size_t)i * ld + j, pji = (size_t)j * ld + i;
-            float Mij = Mg[pij], Mji = Mg[pji], mij = mg[pij], mji = mg[pji], vij = vg[pij], vji = vg[pji];
+            float Mij = est[0 * eup + k], Mji = est[1 * eup + k], mij = est[2 * eup + k], mji = est[3 * eup + k],
+                  vij = est[4 * eup + k], vji = est[5 * eup + k];
             {
                 const float S = sigmoidf_(Mij);
                 const float g = (gc + p.c_size - p.c_ent * Mij * inv_n2) * S * (1.0f - S);
@@ -598,12 +590,12 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 const float g = (gc + p.c_size - p.c_ent * Mji * inv_n2) * S * (1.0f - S);
                 adam_update(Mji, mji, vji, g, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
             }
-            Mg[pij] = Mij;
-            Mg[pji] = Mji;
-            mg[pij] = mij;
-            mg[pji] = mji;
-            vg[pij] = vij;
-            vg[pji] = vji;
+            est[0 * eup + k] = Mij;
+            est[1 * eup + k] = Mji;
+            est[2 * eup + k] = mij;
+            est[3 * eup + k] = mji;
+            est[4 * eup + k] = vij;
+            est[5 * eup + k] = vji;
             if (republish) {  // nobody reads sAb any more in this iteration (the barrier above); sArt is rebuilt next iteration
                 const float a = w * (0.5f * (sigmoidf_(Mij) + sigmoidf_(Mji)));
                 sAb[en & 0xffffu] = a;
@@ -623,7 +615,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         }
         __syncthreads();
     }
-    // ---------------- results: dense Abar block (zero off the edges); M was updated in place; feature mask ----------------
+    // ---------------- results: dense Abar block (zero off the edges), M on the edges, feature mask ----------------
     {
         f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int e = tid * 4; e < ld * ld; e += 4 * NT) *reinterpret_cast<f32x4*>(p.Abar + tm.offQ + e) = z4;
@@ -636,6 +628,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         const float a = sAb[en & 0xffffu];
         p.Abar[tm.offQ + (size_t)i * ld + j] = a;
         p.Abar[tm.offQ + (size_t)j * ld + i] = a;
+        Mg[(size_t)i * ld + j] = est[0 * eup + k];
+        Mg[(size_t)j * ld + i] = est[1 * eup + k];
     }
     if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = (tid < D) ? sh.fcur[tid] : 0.0f;
 }
@@ -697,6 +691,61 @@ __global__ __launch_bounds__(256) void k_count_edges_large(const TargetMeta* met
         }
         out[2 * blockIdx.x] = part[0] + part[1] + part[2] + part[3];
         out[2 * blockIdx.x + 1] = placeable ? pos + singles : -1;
+    }
+}
+
+// gnnx_plan_analyze: CSR (rowptr [ld + 1], ascending columns) of every target routed to k_sparse_large, from its block
+// of the packed dense adjacency; one workgroup per target, rows by waves, 4 chunks of 64 columns in flight per wave.
+__global__ __launch_bounds__(512) void k_build_csr_large(const TargetMeta* meta, const float* A, const int32_t* targets,
+                                                         const long long* csr_off, int32_t* csr_rowptr, unsigned short* csr_col) {
+    const int t = targets[blockIdx.x];
+    const TargetMeta tm = meta[t];
+    const int n = tm.n, ld = tm.ld;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr int NW = 8;
+    const float* Ag = A + tm.offQ;
+    int32_t* rowptr = csr_rowptr + csr_off[2 * t];
+    unsigned short* col = csr_col + csr_off[2 * t + 1];
+    __shared__ int srp[SPL_N_MAX + 34];
+    for (int r = wave; r < ld; r += NW) {
+        int cnt = 0;
+        if (r < n)
+            for (int c0 = 0; c0 < n; c0 += 256) {
+                float a[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = c0 + 64 * u + lane;
+                    a[u] = (c < n && c != r) ? Ag[(size_t)r * ld + c] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) cnt += __popcll(__ballot(a[u] != 0.0f));
+            }
+        if (lane == 0) srp[r] = cnt;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int total = wave_exclusive_scan_array(srp, ld, lane);
+        if (lane == 0) srp[ld] = total;
+    }
+    __syncthreads();
+    for (int r = tid; r <= ld; r += 512) rowptr[r] = srp[r];
+    for (int r = wave; r < n; r += NW) {
+        int base = srp[r];
+        for (int c0 = 0; c0 < n; c0 += 256) {
+            float a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + 64 * u + lane;
+                a[u] = (c < n && c != r) ? Ag[(size_t)r * ld + c] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool nz = a[u] != 0.0f;
+                const unsigned long long bal = __ballot(nz);
+                if (nz) col[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(c0 + 64 * u + lane);
+                base += __popcll(bal);
+            }
+        }
     }
 }
 

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Measurement tool (GPU box): device-side phase timeline of one iteration of k_sparse_large for one BA-House x100k target
+(default: the largest of the 2048-target sample), via wall_clock64() stamps injected into a TEMPORARY copy of the sources."""
+import ctypes, os, subprocess, sys, tempfile
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+CSRC = os.path.join(ROOT, "gnn-model-explainer_amd", "csrc")
+src = open(os.path.join(CSRC, "gnnx_sparse_large.hpp")).read()
+capi = open(os.path.join(CSRC, "gnnx_capi.hip")).read()
+NP = 32
+src = src.replace("namespace gnnx {\n", "namespace gnnx {\n__device__ unsigned long long g_probe[%d];\n"
+                  "#define PROBE(k) do { if (iter == 5 && threadIdx.x == 0 && blockIdx.x == 0) g_probe[(k)] = wall_clock64(); } while (0)\n" % NP, 1)
+src = src.replace("#define PROBE(k)", "#define PROBE0(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_probe[(k)] = wall_clock64(); } while (0)\n#define PROBE(k)", 1)
+setup_marks = [("    // ---------------- setup 1: rowptr from the plan", 16), ("    // ---------------- setup 2: sorted column lists", 17),
+               ("    // ---------------- setup 3: uint16 temporaries", 18), ("    constexpr int SETSZ_EXTRA", 19),
+               ("    const int eup = sh.eup;\n    // slot records", 20), ("    // per-edge indices -> global", 21),
+               ("    // ---------------- row arrays (never-written rows", 22), ("    for (int iter = 0; iter < p.num_iters; ++iter) {", 23),
+               ("    // ---------------- results: dense Abar block", 24)]
+for mark, idx in setup_marks:
+    assert mark in src, mark
+    src = src.replace(mark, "    PROBE0(%d);\n" % idx + mark, 1)
+src = src.replace("    if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = (tid < D) ? sh.fcur[tid] : 0.0f;\n}", "    if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = (tid < D) ? sh.fcur[tid] : 0.0f;\n    PROBE0(25);\n}", 1)
+anchors = [l for l in src.split("\n") if l.strip().startswith("// ========")]
+names = []
+for k, a in enumerate(anchors):
+    src = src.replace(a + "\n", "        PROBE(%d);\n" % k + a + "\n", 1)
+    names.append(a.strip(" /="))
+k = len(anchors)
+end_anchor = "        if (tid < D) {  // feature mask\n"
+assert end_anchor in src
+src = src.replace(end_anchor, "        PROBE(%d);\n" % k + end_anchor, 1)
+capi = capi.replace('#include "../../include/gnnx.h"', '#include "%s"' % os.path.join(ROOT, "include", "gnnx.h"))
+capi += '\nextern "C" int gnnx_probe_read(unsigned long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gnnx::g_probe), sizeof(unsigned long long) * n); }\n'
+tmp = tempfile.mkdtemp()
+for f in ("gnnx_kernels.hpp", "gnnx_resident.hpp", "gnnx_sparse.hpp"):   # unpatched copies next to the patched sources
+    open(os.path.join(tmp, f), "w").write(open(os.path.join(CSRC, f)).read())
+open(os.path.join(tmp, "gnnx_sparse_large.hpp"), "w").write(src)
+open(os.path.join(tmp, "capi_probe.hip"), "w").write(capi)
+so = os.path.join(tmp, "libprobe.so")
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+                       os.path.join(tmp, "capi_probe.hip"), "-o", so])
+import bench
+from gnn_model_explainer_amd import engine
+lib = engine.bind(ctypes.CDLL(so))
+wl = bench.Workload("ba100k", 0, 2048); wl.prepare()
+order = np.argsort([-len(x) for x in wl.nbs])
+sel = [int(order[int(sys.argv[1]) if len(sys.argv) > 1 else 0])]
+subs = [wl.dense_subgraph(k) for k in sel]
+print("target n =", subs[0].adj.shape[0], "undirected edges =", int((subs[0].adj != 0).sum() // 2))
+job = engine.MaskOptimJob(subs, wl.ck["sd"], lib=lib)
+print("route", job.route())
+job.run([s.mask0 for s in subs], engine.Hyper(num_iters=20))
+buf = (ctypes.c_ulonglong * NP)()
+lib.gnnx_probe_read(buf, NP)
+a = np.frombuffer(buf, dtype=np.uint64)[:len(names) + 1].astype(np.int64)
+d = np.diff(a) * 10.0 / 1e3
+for nme, v in zip(names, d):
+    print("%-100s %7.2f us" % (nme[:100], v))
+print("iteration (without the feature-mask tail) %7.2f us" % ((a[len(names)] - a[0]) * 10.0 / 1e3))
+b = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
+lab = ["rowptr from the plan CSR", "column lists from the plan CSR", "upper counts, hop levels", "slot tables (one thread per set)",
+       "slot records", "edge indices + state planes", "row arrays / model / first Abar", "20 iterations", "dense Abar + M scatter"]
+for i, nme in enumerate(lab):
+    print("%-50s %9.1f us" % (nme, (b[17 + i] - b[16 + i]) / 100.0))
