@@ -224,8 +224,8 @@ def main():
         # the longest resident launch: route 1 = k_resident<1>, 4 / 5 / 6 = k_sparse_resident with 1024 / 256 / 64 threads,
         # 7 = k_sparse_large
         res_names = {1: "k_resident<1>", 4: "k_sparse_resident<.., 1024>", 5: "k_sparse_resident<.., 256>", 6: "k_sparse_resident<.., 64>",
-                     7: "k_sparse_large"}
-        res_ms = {1: rt[0], 4: rt[3], 5: rt[4], 6: rt[5], 7: rt[6]}
+                     7: "k_sparse_large", 8: "k_sparse_resident<.., 512>"}
+        res_ms = {1: rt[0], 4: rt[3], 5: rt[4], 6: rt[5], 7: rt[6], 8: rt[7]}
         for rv, ms_v in res_ms.items():
             if ms_v:
                 launches[res_names[rv]] = {"targets": int((route == rv).sum()), "ms_total": ms_v}

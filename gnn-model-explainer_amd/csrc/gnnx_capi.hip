@@ -40,9 +40,9 @@ struct GraphKey {
     bool operator==(const GraphKey& o) const { return std::memcmp(this, &o, sizeof(GraphKey)) == 0; }
 };
 
-constexpr int N_SPC = 4;                       // size classes of k_sparse_resident (0..2) + k_sparse_large (3)
-constexpr int SPC_THREADS[N_SPC] = {1024, 256, 64, SPL_THREADS};
-constexpr int SPC_LARGE = 3;
+constexpr int N_SPC = 5;                       // size classes of k_sparse_resident (0..2, 4) + k_sparse_large (3)
+constexpr int SPC_THREADS[N_SPC] = {1024, 256, 64, SPL_THREADS, 512};
+constexpr int SPC_LARGE = 3, SPC_512 = 4;
 constexpr int N_SIDE = RES_NBMAX + N_SPC;
 constexpr int CAT_SPARSE = RES_NBMAX + 1;      // CAT_SPARSE + k: sparse resident kernel of size class k
 
@@ -71,7 +71,7 @@ struct gnnx_plan_s {
     std::vector<int32_t> nnz;        // per target (directed edge entries, row slots) from gnnx_plan_analyze, empty before
     int n_sp[N_SPC] = {};            // targets of the sparse resident kernel, per size class (1024 / 256 / 64 threads)
     int32_t* d_sp[N_SPC] = {};
-    int n_sparse() const { return n_sp[0] + n_sp[1] + n_sp[2] + n_sp[3]; }
+    int n_sparse() const { return n_sp[0] + n_sp[1] + n_sp[2] + n_sp[3] + n_sp[4]; }
     int32_t* d_nnz = nullptr;
     int32_t* d_csr_rowptr = nullptr;   // CSR of the targets of k_sparse_large (gnnx_plan_analyze)
     unsigned short* d_csr_col = nullptr;
@@ -104,7 +104,7 @@ static int build_split(gnnx_handle h) {
         (void)hipGraphExecDestroy(h->gexec);
         h->gexec = nullptr;
     }
-    for (void* ptr : {(void*)h->d_res, (void*)h->d_sp[0], (void*)h->d_sp[1], (void*)h->d_sp[2], (void*)h->d_sp[3],
+    for (void* ptr : {(void*)h->d_res, (void*)h->d_sp[0], (void*)h->d_sp[1], (void*)h->d_sp[2], (void*)h->d_sp[3], (void*)h->d_sp[4],
                       (void*)h->d_big, (void*)h->d_conv_big, (void*)h->d_mask_big})
         if (ptr) (void)hipFree(ptr);
     h->d_res = h->d_big = nullptr;
@@ -502,7 +502,8 @@ static void launch_sparse(gnnx_handle h, const Params& p, int cls, const float* 
                                h->d_csr_col, h->d_csr_off);
         return;
     }
-    if (cls == 0) launch_sparse_nt<1024>(h, p, h->d_sp[0], h->n_sp[0], adam_tab, s);
+    if (cls == SPC_512) launch_sparse_nt<512>(h, p, h->d_sp[cls], h->n_sp[cls], adam_tab, s);
+    else if (cls == 0) launch_sparse_nt<1024>(h, p, h->d_sp[0], h->n_sp[0], adam_tab, s);
     else if (cls == 1) launch_sparse_nt<256>(h, p, h->d_sp[1], h->n_sp[1], adam_tab, s);
     else launch_sparse_nt<64>(h, p, h->d_sp[2], h->n_sp[2], adam_tab, s);
 }
@@ -539,7 +540,8 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
         // side stream.  (Running the last group on the caller's stream instead of a side stream serialised it behind
         // another group, and a 40-200 us delay kernel in front of the small launches changed nothing - measured, not
         // used; see gnnx_plan_analyze for which groups are allowed to meet.)
-        auto group_stream = [&](int k) -> hipStream_t { return h->side[k]; };
+        // the 64-thread sparse class and the dense single-tile group never meet in one batch: they share side[0]
+        auto group_stream = [&](int k) -> hipStream_t { return (k == RES_NBMAX + 2 && h->side[0] && !h->res_count[1]) ? h->side[0] : h->side[k]; };
         for (int k = 0; k < N_SPC; ++k) {
             if (!h->n_sp[k]) continue;
             const int g = RES_NBMAX + k;
@@ -626,12 +628,13 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
     if (!h || !A) return fail("null argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int T = h->prob.num_targets;
-    if (!h->d_nnz) HIPCK(hipMalloc(&h->d_nnz, sizeof(int32_t) * 4 * T));
+    if (!h->d_nnz) HIPCK(hipMalloc(&h->d_nnz, sizeof(int32_t) * 5 * T));
     hipLaunchKernelGGL(k_count_edges, dim3(T), dim3(256), 0, s, h->d_meta, A, h->d_nnz);
     if (!h->prob.graph_mode) hipLaunchKernelGGL(k_count_edges_large, dim3(T), dim3(256), 0, s, h->d_meta, A, h->d_nnz + 2 * T);
     HIPCK(hipGetLastError());
-    h->nnz.assign(4 * (size_t)T, -1);  // per target: (directed entries, row slots); then the same for the large class
-    HIPCK(hipMemcpyAsync(h->nnz.data(), h->d_nnz, sizeof(int32_t) * (h->prob.graph_mode ? 2 : 4) * T, hipMemcpyDeviceToHost, s));
+    // per target: (directed entries, row slots over all rows); then (entries, slots of 64, slots of 16 within two hops)
+    h->nnz.assign(5 * (size_t)T, -1);
+    HIPCK(hipMemcpyAsync(h->nnz.data(), h->d_nnz, sizeof(int32_t) * (h->prob.graph_mode ? 2 : 5) * T, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
     const bool graph = h->prob.graph_mode != 0;
     if (h->prob.C > RES_CMAX) return 0;
@@ -641,7 +644,8 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
     // every target takes the smallest size class of the sparse resident kernel its rows / edges / LDS fit (64 threads:
     // n <= 32; 256: n <= 128; 1024: n <= 512); single-tile node-mode targets that fit none keep the dense resident
     // kernel; the rest streams.  GNNX_TINY_SPARSE=0 keeps every single-tile target on the dense resident kernel.
-    int tiny_on = 1, large_on = 1;
+    int tiny_on = 1, large_on = 1, c512_on = 1;
+    if (const char* env = std::getenv("GNNX_SPARSE_512")) c512_on = std::atoi(env);
     if (const char* env = std::getenv("GNNX_TINY_SPARSE")) tiny_on = std::atoi(env);
     if (const char* env = std::getenv("GNNX_SPARSE_LARGE")) large_on = std::atoi(env);  // 0: those targets stream (dense)
     bool changed = false;
@@ -657,30 +661,41 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
                     (k < 2 || tiny_on))
                     c = CAT_SPARSE + k;
         if (!graph && nb == 1 && h->res_nbmax >= 1 && (!c || !tiny_on)) c = 1;  // dense resident: node mode only
-        if (!c && !graph && large_on && h->nnz[2 * T + 2 * t] >= 0 &&
-            sparse_large_fits(m.n, m.ld, h->nnz[2 * T + 2 * t], h->nnz[2 * T + 2 * t + 1], h->prob.D, h->prob.H, h->prob.C))
+        const int* lg = &h->nnz[2 * (size_t)T + 3 * (size_t)t];  // (entries, slots of 64, slots of 16) within two hops
+        // node mode, beyond the 256-thread class: the 512-thread class when the rows within two hops fit its 256 slots
+        // (no scratch, cheaper barriers), else the 1024-thread class chosen above
+        if (!graph && c512_on && (c == 0 || c == CAT_SPARSE) && lg[0] >= 0 &&
+            sparse_fits(512, m.n, m.ld, lg[0], lg[2], h->prob.D, h->prob.H, h->prob.C, 0, h->prob.O))
+            c = CAT_SPARSE + SPC_512;
+        if (!c && !graph && large_on && lg[0] >= 0 && sparse_large_fits(m.n, m.ld, lg[0], lg[1], h->prob.D, h->prob.H, h->prob.C))
             c = CAT_SPARSE + SPC_LARGE;
         new_cat[t] = c;
     }
-    // Batches that need the 1024-thread class keep to it and the dense single-tile kernel: measured on syn1, the 1024-thread
-    // launch runs back to back with a concurrent 64- or 256-thread sparse launch (10.2-11.3 ms per batch; its
-    // workgroups need empty CUs and its dispatch - 160 KB of LDS, scratch - does not interleave with theirs), while
-    // it overlaps with k_resident<1> (8.5 ms).  So there the middle class joins the large one (whatever fits 256
-    // threads fits 1024) and the single-tile node-mode targets stay on k_resident<1>.  Batches without such a target
-    // (syn4, syn5, graph mode) use the small classes: 1.2-2.7x faster than the alternatives.
+    // Batches that need the 512- / 1024-thread classes keep to them and the dense single-tile kernel: measured on syn1,
+    // such a launch runs back to back with a concurrent 64- or 256-thread sparse launch (9.4-11.3 ms per batch, with or
+    // without scratch in the big kernel: it is the stream-to-hardware-queue mapping), while it overlaps with
+    // k_resident<1> (7.3-8.1 ms).  So there the middle class joins the big one and the single-tile node-mode targets
+    // stay on k_resident<1>.  Batches without such a target (syn4, syn5, graph mode) use the small classes: 1.2-2.7x
+    // faster than the alternatives.
     bool has_large = false;
-    for (int t = 0; t < T; ++t) has_large |= (new_cat[t] == CAT_SPARSE);
+    for (int t = 0; t < T; ++t) has_large |= (new_cat[t] == CAT_SPARSE || new_cat[t] == CAT_SPARSE + SPC_512);
     if (has_large)
         for (int t = 0; t < T; ++t) {
-            if (new_cat[t] == CAT_SPARSE + 1) new_cat[t] = CAT_SPARSE;
+            if (new_cat[t] == CAT_SPARSE + 1) {  // a 256-thread target in such a batch joins the 512-thread class (else the 1024 one)
+                const TargetMeta& m = h->meta[t];
+                const int* lg = &h->nnz[2 * (size_t)T + 3 * (size_t)t];
+                const bool f512 = !graph && c512_on && lg[0] >= 0 &&
+                                  sparse_fits(512, m.n, m.ld, lg[0], lg[2], h->prob.D, h->prob.H, h->prob.C, 0, h->prob.O);
+                new_cat[t] = f512 ? CAT_SPARSE + SPC_512 : CAT_SPARSE;
+            }
             if (new_cat[t] == CAT_SPARSE + 2 && !graph && h->res_nbmax >= 1) new_cat[t] = 1;
         }
     if (std::getenv("GNNX_DEBUG_ROUTE"))
         for (int t = 0; t < T; ++t)
             if (new_cat[t] == 0)
-                std::fprintf(stderr, "gnnx route: target %d n=%d ld=%d streams: nnz=%d slots=%d | large: nnz=%d slots=%d\n", t,
-                             h->meta[t].n, h->meta[t].ld, h->nnz[2 * t], h->nnz[2 * t + 1], h->nnz[2 * T + 2 * t],
-                             h->nnz[2 * T + 2 * t + 1]);
+                std::fprintf(stderr, "gnnx route: target %d n=%d ld=%d streams: nnz=%d slots=%d | two hops: nnz=%d slots64=%d slots16=%d\n",
+                             t, h->meta[t].n, h->meta[t].ld, h->nnz[2 * t], h->nnz[2 * t + 1], h->nnz[2 * (size_t)T + 3 * (size_t)t],
+                             h->nnz[2 * (size_t)T + 3 * (size_t)t + 1], h->nnz[2 * (size_t)T + 3 * (size_t)t + 2]);
     for (int t = 0; t < T; ++t) {
         changed |= (new_cat[t] != h->cat[t]);
         h->cat[t] = new_cat[t];
@@ -696,7 +711,7 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
                 off[2 * t] = rp;
                 off[2 * t + 1] = cl;
                 rp += h->meta[t].ld + 1;
-                cl += (h->nnz[2 * T + 2 * t] + 1) & ~1;
+                cl += (h->nnz[2 * (size_t)T + 3 * (size_t)t] + 1) & ~1;
             }
         for (void* ptr : {(void*)h->d_csr_rowptr, (void*)h->d_csr_col, (void*)h->d_csr_off})
             if (ptr) (void)hipFree(ptr);

@@ -32,10 +32,13 @@ namespace gnnx {
 //   NT = 1024: n <= 512, E <= 2048, 153 KB of LDS  (one workgroup per CU: 16 waves x 128 VGPRs fill its register file)
 //   NT =  256: n <= 128, E <=  512,  72 KB         (two per CU)
 //   NT =   64: n <=  32, E <=  128,  20 KB         (one wave: every barrier is wave-local; six and more per CU)
+//   NT =  512: n <= 512, E <= 2048, 153 KB         (node mode; 8 waves = 256 row slots are plenty once the rows beyond
+//              two hops need none, 4 edges per thread; two waves per SIMD leave 256 VGPRs: no spills, no scratch)
 constexpr int SP_THREADS = 1024;             // the largest class (bounds shared tables)
-constexpr int SP_QMAX = 2;                   // undirected edges per thread
+__host__ __device__ constexpr int sp_qmax(int nt) { return nt == 512 ? 4 : 2; }             // undirected edges per thread
+__host__ __device__ constexpr int sp_ld_max(int nt) { return nt == 512 ? 512 : 32 * (nt / 64); }
 constexpr int SP_LD_MAX = 32 * (SP_THREADS / 64);
-__host__ __device__ constexpr int sp_pool_floats(int nt) { return nt >= 1024 ? 39168 : nt >= 256 ? 18432 : 5120; }
+__host__ __device__ constexpr int sp_pool_floats(int nt) { return nt >= 512 ? 39168 : nt >= 256 ? 18432 : 5120; }
 constexpr int SP_GATHER_UNROLL = 2;          // entries in flight per lane in the sparse gathers
 constexpr int SP_CHUNK = 16;                 // entries per row slot: longer rows are split over adjacent lanes of one wave
 // row slots of a class: NT / 2 (two lanes = column halves per slot)
@@ -86,7 +89,7 @@ __host__ __device__ inline SparseLayout sparse_layout(int n, int ld, int nnz, in
 __host__ __device__ inline bool sparse_fits(int nt, int n, int ld, int nnz, int slots, int D, int H, int C, int graph = 0,
                                             int O = 0) {
     // the setup's temporaries (7 ld + 2 SP_CHUNK + 8 ints) live in the X / U1 / U2 / dZ1 arrays, which are contiguous
-    return ld <= 32 * (nt / 64) && nnz / 2 <= SP_QMAX * nt && nnz < 65536 && slots >= 0 && slots <= nt / 2 &&
+    return ld <= sp_ld_max(nt) && nnz / 2 <= sp_qmax(nt) * nt && nnz < 65536 && slots >= 0 && slots <= nt / 2 &&
            C <= RES_CMAX && H >= 2 && 2 * n * ((H | 1) + (D | 1)) >= 7 * ld + 2 * SP_CHUNK + 8 &&
            sparse_layout(n, ld, nnz, D, H, C, graph, O).total <= sp_pool_floats(nt);
 }
@@ -343,7 +346,8 @@ __device__ __forceinline__ void sparse_combine(float (&acc)[NQ], int lane, bool 
 // layers, per-layer max-pool over all rows, no Laplacian term) instead of GcnEncoderNode (models.py:363-376).
 template <int DQ, int HQ, bool GRAPH, int NT>
 __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t* targets, const float* adam_tab) {
-    constexpr int SCAN = (32 * (NT / 64) + 63) / 64;  // rows per lane in the setup prefix scans
+    constexpr int SCAN = (sp_ld_max(NT) + 63) / 64;  // rows per lane in the setup prefix scans
+    constexpr int SP_QMAX = sp_qmax(NT);
     __shared__ float pool[sp_pool_floats(NT)];
     __shared__ SparseFixed sh;
     const int t = targets[blockIdx.x];
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
 
     // ---------------- setup 1: degrees (wave per row, ballot over 64-column chunks) ----------------
     int* tmp_deg = reinterpret_cast<int*>(pool);  // the pool is free until the layout is fixed
-    const bool ld_ok = ld <= 32 * NW;
+    const bool ld_ok = ld <= sp_ld_max(NT);
     if (ld_ok)
         for (int r = wave; r < ld; r += NW) {
             int cnt = 0;
@@ -403,7 +407,8 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
     const int rp_keep = (tid < ld) ? tmp_deg[tid] : nnz;
     __syncthreads();
     int* rowptr = reinterpret_cast<int*>(pool + L.oRowptr);
-    if (tid <= ld) rowptr[tid] = rp_keep;
+    if (tid < ld) rowptr[tid] = rp_keep;
+    if (tid == 0) rowptr[ld] = nnz;
     if (tid == 0) sh.bad = 0;
     __syncthreads();
     float* sX = pool + L.oX;

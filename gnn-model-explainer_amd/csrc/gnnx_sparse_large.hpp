@@ -636,8 +636,10 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
 
 // gnnx_plan_analyze, every target with n <= SPL_N_MAX (also those of <= 512 rows that fit no resident class, e.g. more
 // than 2048 edges): directed entries and the row slots (of SPL_CHUNK entries)
-// needed by the rows within two hops of the target - the same levels and placement as k_sparse_large computes.
-// out[2 t] = nnz, out[2 t + 1] = slots (-1: a row that cannot be placed); targets outside the range get (-1, -1).
+// needed by the rows within two hops of the target - the same levels and placement as k_sparse_large computes - and the
+// same count for slots of SP_CHUNK entries (the 512-thread class of k_sparse_resident).
+// out[3 t] = nnz, out[3 t + 1] = slots of 64 (-1: a row that cannot be placed), out[3 t + 2] = slots of 16 (-1 likewise);
+// targets outside the range get -1 everywhere.
 __global__ __launch_bounds__(256) void k_count_edges_large(const TargetMeta* meta, const float* A, int32_t* out) {
     __shared__ int deg[SPL_N_MAX + 1];
     __shared__ unsigned char level[SPL_N_MAX + 1];
@@ -646,8 +648,9 @@ __global__ __launch_bounds__(256) void k_count_edges_large(const TargetMeta* met
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tm.n > SPL_N_MAX) {
         if (tid == 0) {
-            out[2 * blockIdx.x] = -1;
-            out[2 * blockIdx.x + 1] = -1;
+            out[3 * blockIdx.x] = -1;
+            out[3 * blockIdx.x + 1] = -1;
+            out[3 * blockIdx.x + 2] = -1;
         }
         return;
     }
@@ -676,21 +679,22 @@ __global__ __launch_bounds__(256) void k_count_edges_large(const TargetMeta* met
         }
         __syncthreads();
     }
-    if (tid == 0) {
+    if (tid < 2) {  // thread 0: slots of SPL_CHUNK entries, thread 1: slots of SP_CHUNK entries
+        const int chunk = tid ? SP_CHUNK : SPL_CHUNK;
         int pos = 0, singles = 0;
         bool placeable = true;
         for (int r = 0; r < tm.n; ++r) {
             if (level[r] > 2) continue;
-            if (deg[r] > SPL_CHUNK) {
-                const int ns = sparse_slots_of_c(deg[r], SPL_CHUNK);
+            if (deg[r] > chunk) {
+                const int ns = sparse_slots_of_c(deg[r], chunk);
                 placeable &= ns <= SP_MAX_SPLIT;
                 pos = sparse_place(pos, ns) + ns;
             } else {
                 ++singles;
             }
         }
-        out[2 * blockIdx.x] = part[0] + part[1] + part[2] + part[3];
-        out[2 * blockIdx.x + 1] = placeable ? pos + singles : -1;
+        if (tid == 0) out[3 * blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+        out[3 * blockIdx.x + 1 + tid] = placeable ? pos + singles : -1;
     }
 }
 

@@ -429,14 +429,15 @@ class MaskOptimJob:
 
     def resident_times(self):
         """In-situ device time (ms) of the resident launches of the last launch():
-        [dense nb=1, nb=2, nb=3, sparse 1024-thread class, sparse 256, sparse 64, sparse large]."""
-        ms = (ctypes.c_float * 7)()
+        [dense nb=1, nb=2, nb=3, sparse 1024-thread class, sparse 256, sparse 64, sparse large, sparse 512]."""
+        ms = (ctypes.c_float * 8)()
         _check(self.lib, self.lib.gnnx_resident_times(self.handle, ms))
         return [float(x) for x in ms]
 
     def route(self):
         """Kernel of every target: 0 dense streaming, 1..3 dense resident (row blocks), 4 / 5 / 6 sparse resident
-        (1024- / 256- / 64-thread size class), 7 sparse kernel for larger targets (row arrays in the workspace)."""
+        (1024- / 256- / 64-thread size class), 7 sparse kernel for larger targets (row arrays in the workspace), 8 sparse
+        resident, 512-thread class."""
         r = np.zeros(self.T, np.int32)
         _check(self.lib, self.lib.gnnx_get_route(self.handle, r.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
         return r

@@ -109,13 +109,15 @@ int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream);
 /* The kernel every target is routed to (host array of num_targets entries): 0 = dense streaming kernels,
  * 1..3 = dense on-chip-resident kernel of that many 32-row blocks, 4 / 5 / 6 = sparse on-chip-resident kernel in its
  * 1024- / 256- / 64-thread size class (n <= 512 / 128 / 32), 7 = sparse kernel for larger node-mode targets
- * (n <= 4095; edge state in LDS, row arrays in the workspace). */
+ * (n <= 4095; edge state in LDS, row arrays in the workspace), 8 = sparse on-chip-resident kernel, 512-thread class
+ * (node mode, n <= 512, at most 256 row slots within two hops of the target). */
 int gnnx_get_route(gnnx_handle h, int32_t* route);
 
 /* Measurement hook: device time (ms, HIP events on the side streams the kernels run on) of the on-chip-resident
  * launches of the LAST gnnx_run, in situ (i.e. while the other kernels of that run were executing):
  * ms[0..2] = dense resident kernels of 1..3 row blocks, ms[3..5] = sparse resident kernel, 1024- / 256- / 64-thread
- * size class, ms[6] = sparse kernel for larger targets (7 floats); 0 where nothing was launched.
+ * size class, ms[6] = sparse kernel for larger targets, ms[7] = sparse resident kernel, 512-thread class (8 floats);
+ * 0 where nothing was launched.
  * Waits for those launches to finish. */
 int gnnx_resident_times(gnnx_handle h, float* ms);
 
