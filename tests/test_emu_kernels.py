@@ -301,3 +301,29 @@ def test_large_target_sparse_kernel_with_split_hub_rows():
     assert np.array_equal(res.masked_adj[0], res.masked_adj[0].T)
     dense = emu_job([sg], sd, analyze=False).run([m0], Hyper(num_iters=4))      # dense streaming kernels
     assert np.abs(res.masked_adj[0] - dense.masked_adj[0]).max() < 2e-6
+
+
+def test_large_target_more_than_512_row_slots():
+    """A target next to a 700-neighbour hub (n = 1400): more than 512 row slots within two hops, so k_sparse_large walks
+    its slot records in two rounds; the hub row takes 11 slots of 64 entries."""
+    rng = np.random.default_rng(5)
+    sd = helpers.random_model(rng, 10, 20, 20, 4)
+    n = 1400
+    A, X = helpers.random_graph(rng, n, 10, density=1.0 / n)
+    hub = 11
+    idx = rng.choice(np.arange(n), 700, replace=False)
+    idx = idx[idx != hub]
+    A[hub, idx] = 1
+    A[idx, hub] = 1
+    m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
+    t = int(idx[0])
+    sg = Subgraph(A, X, 1, t, rng.integers(0, 4, n), m0)
+    job = emu_job([sg], sd)
+    assert list(job.route()) == [7]
+    res = job.run([m0], Hyper(num_iters=3))
+    o = closed_form.ClosedFormOracle(A, X, sd, 1, sg.pred_label, t, m0)
+    want = o.run(3)
+    live = A != 0
+    assert np.abs(res.masked_adj[0] - want).max() < 1e-5          # a 700-term row sum in another order
+    assert np.abs(res.mask[0] - o.M)[live].max() < 5e-5 and np.abs(res.feat_mask[0] - o.f).max() < 5e-5
+    assert np.array_equal(res.mask[0][~live], m0[~live])
