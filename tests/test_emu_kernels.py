@@ -327,3 +327,29 @@ def test_large_target_more_than_512_row_slots():
     assert np.abs(res.masked_adj[0] - want).max() < 1e-5          # a 700-term row sum in another order
     assert np.abs(res.mask[0] - o.M)[live].max() < 5e-5 and np.abs(res.feat_mask[0] - o.f).max() < 5e-5
     assert np.array_equal(res.mask[0][~live], m0[~live])
+
+
+@pytest.mark.parametrize("case,n", [("edgeless", 40), ("isolated target", 60), ("isolated target", 700)])
+def test_sparse_kernels_degenerate_graphs(case, n):
+    """No edge at all / a target without neighbours (its row of every layer is the bias direction, the edge masks only
+    get their regulariser gradients): the sparse kernels must stay finite and agree with the closed form."""
+    rng = np.random.default_rng(n)
+    sd = helpers.random_model(rng, 10, 20, 20, 4)
+    A, X = helpers.random_graph(rng, n, 10, density=0.05 if n < 100 else 0.004)
+    if case == "edgeless":
+        A = A * 0
+    else:
+        A[5, :] = 0
+        A[:, 5] = 0
+    m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
+    sg = Subgraph(A, X, 1, 5, rng.integers(0, 4, n), m0)
+    job = emu_job([sg], sd)
+    assert job.route()[0] >= 4
+    res = job.run([m0], Hyper(num_iters=3))
+    o = closed_form.ClosedFormOracle(A, X, sd, 1, sg.pred_label, 5, m0)
+    want = o.run(3)
+    assert np.isfinite(res.masked_adj[0]).all() and np.isfinite(res.feat_mask[0]).all()
+    assert np.abs(res.masked_adj[0] - want).max() < 5e-6 and np.abs(res.feat_mask[0] - o.f).max() < 5e-5
+    live = A != 0
+    if live.any():
+        assert np.abs(res.mask[0] - o.M)[live].max() < 5e-5
