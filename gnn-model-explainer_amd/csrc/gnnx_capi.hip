@@ -542,14 +542,26 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
         // used; see gnnx_plan_analyze for which groups are allowed to meet.)
         // the 64-thread sparse class and the dense single-tile group never meet in one batch: they share side[0]
         auto group_stream = [&](int k) -> hipStream_t { return (k == RES_NBMAX + 2 && h->side[0] && !h->res_count[1]) ? h->side[0] : h->side[k]; };
+        // node-mode batches of 512-thread and single-tile (64-thread class) targets: ONE launch (k_sparse_resident_mixed)
+        const bool mixed = !h->prob.graph_mode && h->n_sp[SPC_512] > 0 && h->n_sp[2] > 0;
         for (int k = 0; k < N_SPC; ++k) {
-            if (!h->n_sp[k]) continue;
+            if (!h->n_sp[k] || (mixed && k == 2)) continue;
             const int g = RES_NBMAX + k;
             hipStream_t ss = group_stream(g);
             if (ss != s) HIPCK(hipStreamWaitEvent(ss, h->ev_in, 0));
             HIPCK(hipEventRecord(h->ev_t0[g], ss));
             h->launched[g] = true;
-            launch_sparse(h, p, k, h->d_adam, ss);
+            if (mixed && k == SPC_512) {
+                const dim3 grid(h->n_sp[SPC_512] + (h->n_sp[2] + SP_MIX_TINY - 1) / SP_MIX_TINY), block(512);
+                if (h->prob.D <= 10 && std::max(h->prob.H, h->prob.O) <= 20)
+                    hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
+                                       h->d_sp[2], h->n_sp[2], h->d_adam);
+                else
+                    hipLaunchKernelGGL((k_sparse_resident_mixed<16, 16>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
+                                       h->d_sp[2], h->n_sp[2], h->d_adam);
+            } else {
+                launch_sparse(h, p, k, h->d_adam, ss);
+            }
             HIPCK(hipEventRecord(h->ev_out[g], ss));
         }
         for (int nb = RES_NBMAX; nb >= 1; --nb) {  // largest targets first
@@ -598,7 +610,7 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
         for (int k = 0; k < RES_NBMAX; ++k)
             if (h->res_count[k + 1]) HIPCK(hipStreamWaitEvent(s, h->ev_out[k], 0));
         for (int k = 0; k < N_SPC; ++k)
-            if (h->n_sp[k]) HIPCK(hipStreamWaitEvent(s, h->ev_out[RES_NBMAX + k], 0));
+            if (h->n_sp[k] && h->launched[RES_NBMAX + k]) HIPCK(hipStreamWaitEvent(s, h->ev_out[RES_NBMAX + k], 0));
     }
     if (feat_mask)
         HIPCK(hipMemcpyAsync(feat_mask, p.f[hy->num_iters & 1], sizeof(float) * h->prob.num_targets * FS,
@@ -677,8 +689,16 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
     // k_resident<1> (7.3-8.1 ms).  So there the middle class joins the big one and the single-tile node-mode targets
     // stay on k_resident<1>.  Batches without such a target (syn4, syn5, graph mode) use the small classes: 1.2-2.7x
     // faster than the alternatives.
-    bool has_large = false;
-    for (int t = 0; t < T; ++t) has_large |= (new_cat[t] == CAT_SPARSE || new_cat[t] == CAT_SPARSE + SPC_512);
+    bool has_large = false, has_1024 = false;
+    for (int t = 0; t < T; ++t) {
+        has_large |= (new_cat[t] == CAT_SPARSE || new_cat[t] == CAT_SPARSE + SPC_512);
+        has_1024 |= (new_cat[t] == CAT_SPARSE);
+    }
+    int mix_on = 1;
+    if (const char* env = std::getenv("GNNX_SPARSE_MIXED")) mix_on = std::atoi(env);
+    // ... unless the big targets all take the 512-thread class: then they and the single-tile targets (64-thread code path,
+    // six per workgroup) share ONE launch, k_sparse_resident_mixed, and nothing needs to overlap
+    const bool mixable = !graph && mix_on && tiny_on && has_large && !has_1024;
     if (has_large)
         for (int t = 0; t < T; ++t) {
             if (new_cat[t] == CAT_SPARSE + 1) {  // a 256-thread target in such a batch joins the 512-thread class (else the 1024 one)
@@ -688,7 +708,7 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
                                   sparse_fits(512, m.n, m.ld, lg[0], lg[2], h->prob.D, h->prob.H, h->prob.C, 0, h->prob.O);
                 new_cat[t] = f512 ? CAT_SPARSE + SPC_512 : CAT_SPARSE;
             }
-            if (new_cat[t] == CAT_SPARSE + 2 && !graph && h->res_nbmax >= 1) new_cat[t] = 1;
+            if (new_cat[t] == CAT_SPARSE + 2 && !graph && h->res_nbmax >= 1 && !mixable) new_cat[t] = 1;
         }
     if (std::getenv("GNNX_DEBUG_ROUTE"))
         for (int t = 0; t < T; ++t)

@@ -344,16 +344,20 @@ __device__ __forceinline__ void sparse_combine(float (&acc)[NQ], int lane, bool 
 // DQ >= ceil(D / 2), HQ >= ceil(max(H, O) / 2): compile-time trip counts of the column loops (instantiated for the
 // reference's encoders and for the general 32-wide case).  GRAPH: GcnEncoderGraph (models.py:269-316: three full
 // layers, per-layer max-pool over all rows, no Laplacian term) instead of GcnEncoderNode (models.py:363-376).
+// The body works on NT consecutive threads tid = 0 .. NT-1 with their own LDS pool and SparseFixed: a whole workgroup
+// (k_sparse_resident) or, for NT = 64, one wave of a larger workgroup (k_sparse_resident_mixed) - a single wave
+// synchronises with itself, so its barriers are wave-level.
 template <int DQ, int HQ, bool GRAPH, int NT>
-__global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t* targets, const float* adam_tab) {
+__device__ __forceinline__ void sparse_resident_body(const Params& p, int t, const float* adam_tab, float* pool, SparseFixed& sh,
+                                                     int tid) {
     constexpr int SCAN = (sp_ld_max(NT) + 63) / 64;  // rows per lane in the setup prefix scans
     constexpr int SP_QMAX = sp_qmax(NT);
-    __shared__ float pool[sp_pool_floats(NT)];
-    __shared__ SparseFixed sh;
-    const int t = targets[blockIdx.x];
+    auto SYNC = []() {
+        if constexpr (NT == 64) wave_sync(); else __syncthreads();
+    };
     const TargetMeta tm = p.meta[t];
     const int n = tm.n, ld = tm.ld, tr = tm.t;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     constexpr int NW = NT / 64;
     const int D = p.D, H = p.H, O = p.O, C = p.C;
     const float* Ag = p.A + tm.offQ;
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
                 }
             if (lane == 0) tmp_deg[r] = cnt;
         }
-    __syncthreads();
+    SYNC();
     if (wave == 0 && ld_ok) {  // exclusive prefix sum over the rows: SCAN rows per lane
         int loc[SCAN], s = 0;
 #pragma unroll
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
         }
         if (lane == 63) sh.nnz = incl;
     }
-    __syncthreads();
+    SYNC();
     const int nnz = ld_ok ? sh.nnz : 0;
     const bool fits = ld_ok && sparse_fits(NT, n, ld, nnz, 0, D, H, C, GRAPH, O);  // the slot count is checked once the slots are placed
     if (!fits) {
@@ -405,12 +409,12 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
     const SparseLayout L = sparse_layout(n, ld, nnz, D, H, C, GRAPH, O);
     // rowptr currently sits at the start of the pool = inside the future sX region: move it through registers
     const int rp_keep = (tid < ld) ? tmp_deg[tid] : nnz;
-    __syncthreads();
+    SYNC();
     int* rowptr = reinterpret_cast<int*>(pool + L.oRowptr);
     if (tid < ld) rowptr[tid] = rp_keep;
     if (tid == 0) rowptr[ld] = nnz;
     if (tid == 0) sh.bad = 0;
-    __syncthreads();
+    SYNC();
     float* sX = pool + L.oX;
     float* sU1 = pool + L.oU1;
     float* sU2 = pool + L.oU2;   // node mode: == sdZ2 (see SparseLayout)
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
             base += __popcll(bal);
         }
     }
-    __syncthreads();
+    SYNC();
     // ---------------- setup 3: upper entries (col > row) are the tail of every row; prefix of their counts ----------------
     int* u0 = reinterpret_cast<int*>(sX);  // [ld] first upper entry of the row   (X, U1, U2, dZ1 are free during setup)
     int* upptr = u0 + ld;                    // [ld + 1]
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
         u0[tid] = f;
         upptr[tid] = b - f;  // count, scanned below
     }
-    __syncthreads();
+    SYNC();
     if (wave == 0) {
         int loc[SCAN], s = 0;
 #pragma unroll
@@ -481,13 +485,13 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
     // mask entries, which keep receiving their regulariser gradients in the edge phase.  Graph mode pools over all rows.
     int* level = upptr + ld + 1;  // [ld]
     if (tid < ld) level[tid] = (GRAPH || tid == tr) ? 0 : 3;
-    __syncthreads();
+    SYNC();
     if (!GRAPH)
         for (int d = 1; d <= 2; ++d) {
             if (tid < n && level[tid] == d - 1)
                 for (int e = rowptr[tid]; e < rowptr[tid + 1]; ++e)
                     if (level[scol[e]] > d) level[scol[e]] = d;  // benign race: every writer stores d
-            __syncthreads();
+            SYNC();
         }
     // Row slots in "slot order", one table per row set (A: level <= 2, layer 1 and its backward; B: level <= 1, layer 2
     // and its backward): rows longer than SP_CHUNK first (row order, never straddling a 16-lane DPP row), then the
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
         sh.set_slots[set] = pos + (cnt - p);
         if (pos + (cnt - p) > NT / 2) sh.bad = 1;
     }
-    __syncthreads();
+    SYNC();
     const int eup = sh.eup;
     // this lane's row slot in every set: lanes (li, half 0) and (li, half 1) of wave w share slot 32 w + li
     RowSlot rs[NSET];
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
         }
         if (asym) sh.bad = 1;  // benign race: every writer stores 1
     }
-    __syncthreads();  // the setup temporaries (aliasing X .. dZ1) are dead from here on
+    SYNC();  // the setup temporaries (aliasing X .. dZ1) are dead from here on
     if (sh.bad) {     // asymmetric adjacency: not a graph the reference explains; fail loudly
         const float qnan = __builtin_nanf("");
         for (int e = tid; e < ld * ld; e += NT) p.Abar[tm.offQ + e] = qnan;
@@ -662,7 +666,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
                 sAb[eji[q]] = a;
             }
         if (tid < ld) sArt[tid] = 0.0f;
-        __syncthreads();
+        SYNC();
     };
     publish_abar();
 
@@ -671,7 +675,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
         // Abar[t][.] as a dense row (rank-1 layer-3 backward): scatter row t's entries (sArt was zeroed by publish_abar)
         if (!GRAPH)
             for (int e = rt0 + tid; e < rt1; e += NT) sArt[scol[e]] = sAb[e];
-        __syncthreads();
+        SYNC();
         const float step_size = adam_tab[2 * iter], inv_bc2s = 1.0f / adam_tab[2 * iter + 1];
 
         // ======== layer 1: Zraw = Abar . X (kept in registers for the feature-mask gradient), U1 ========
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
             }
             sparse_forward_rowlocal<DQ>(acc, sW1, sh.bias[0], D, H, li, h, first, sU1 + r * sH, sRn1 + r);
         }
-        __syncthreads();
+        SYNC();
         // ======== layer 2: U2 ========
         if (SB.wave_active) {
             const bool first = SB.first;
@@ -704,7 +708,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
             for (int q = 0; q < HQ; ++q) acc[q] = first ? acc[q] : 0.0f;
             sparse_forward_rowlocal<HQ>(acc, sW2, sh.bias[1], H, H, li, h, first, sU2 + r * sH, sRn2 + r);
         }
-        __syncthreads();
+        SYNC();
         if constexpr (GRAPH) {
         // ======== graph mode: layer 3 in full (no ReLU), U3 ========
         if (SA.wave_active) {
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
             for (int q = 0; q < HQ; ++q) acc[q] = first ? acc[q] : 0.0f;
             sparse_forward_rowlocal<HQ>(acc, sW3, sh.bias[2], H, O, li, h, first, sU3 + r * sO, sRn3 + r);
         }
-        __syncthreads();
+        SYNC();
         // ======== graph mode: per-layer max-pool over ALL n rows (models.py:283, 291, 300; first maximal row wins), head, dE ========
         {   // thread = pooled column (96 of them), rows scanned in order: no cross-lane reduction needed
             for (int col = tid; col < 96; col += NT) {
@@ -744,7 +748,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
                 sh.erow[col] = barg;
             }
         }
-        __syncthreads();
+        SYNC();
         if (wave == 0) {  // softmax head (explain.py:710-711, 750-753): g = p - onehot(label), dE = Wp^T g
             {
                 const int cls = lane >> 3, part = lane & 7;
@@ -780,7 +784,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
                 }
             }
         }
-        __syncthreads();
+        SYNC();
         // ======== graph mode: dZ3 (row-local backward of layer 3; dE3 lands on the arg-max rows), overwrites U3 ========
         if (SA.wave_active) {
             const bool first = SA.first;
@@ -796,7 +800,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
             const f32x16 c16 = sparse_backward_rowlocal<HQ>(du, uu, first ? sRn3[r] : 1.0f, sW3, H, O, li, h);
             sparse_store_cols(c16, sU3 + r * sO, H, first, h);  // dZ3[r][.]
         }
-        __syncthreads();
+        SYNC();
         // ======== graph mode: dX2 = Abar . dZ3 (+ dE2 on the arg-max rows) -> dZ2 ========
         if (SA.wave_active) {
             const bool first = SA.first;
@@ -819,7 +823,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
             const f32x16 c16 = sparse_backward_rowlocal<HQ>(acc, uu, first ? sRn2[r] : 1.0f, sW2, H, H, li, h);
             sparse_store_cols(c16, sdZ2w + r * sH, H, first, h);
         }
-        __syncthreads();
+        SYNC();
         } else {
         // ======== row t of layer 3 (the only row the reference reads, explain.py:713), head, dE, dZ3[t] ========
         {   // row t of Abar . relu(U2): its entries dealt over the 16 waves, lane = column; partials summed in wave order
@@ -830,7 +834,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
             z += __shfl_xor(z, 32);
             if (h == 0) sh.dfw[wave][li] = z;  // dfw is free until the layer-1 backward
         }
-        __syncthreads();
+        SYNC();
         if (wave == 0) {  // the head is a chain of tiny dependent steps: one wave, wave-level syncs only
             const int c = li;
             float z = 0.0f;
@@ -912,7 +916,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
             }
             if (h == 0) sh.dz3[c] = (c < H) ? v : 0.0f;
         }
-        __syncthreads();
+        SYNC();
         // ======== dZ2 (rank-1: dX2[r] = Abar[r][t] dZ3[t] + dE2 on row t) and g3; dZ2 overwrites U2 row by row ========
         if (SB.wave_active) {
             const bool first = SB.first;
@@ -936,7 +940,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
             const f32x16 c16 = sparse_backward_rowlocal<HQ>(du, uu, first ? sRn2[r] : 1.0f, sW2, H, H, li, h);
             sparse_store_cols(c16, sU2 + r * sH, H, first, h);  // dZ2[r][.]: every U2 value of this row is already in registers
         }
-        __syncthreads();
+        SYNC();
         }
         const float* sdZ2 = sdZ2w;  // node mode: the U2 array (overwritten above); graph mode: its own array
         // ======== dX1 = Abar . dZ2 (+ dE1 on row t) -> dZ1 ; feature-mask gradient partials ========
@@ -981,7 +985,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
                 if (li == 0) sh.dfw[wave][2 * q + h] = v;
             }
         }
-        __syncthreads();
+        SYNC();
         if (tid < D) {
             float s = 0.0f;
 #pragma unroll
@@ -1046,7 +1050,7 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
                     adam_update(Mji[q], mji[q], vji[q], g, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
                 }
             }
-        __syncthreads();  // dfp complete; every reader of sAb / sArt of this iteration is done
+        SYNC();  // dfp complete; every reader of sAb / sArt of this iteration is done
         if (tid < D) {  // feature mask
             const float ph = sh.phi[tid];
             const float gf = (sh.dfp[tid] + p.c_feat_size / (float)D) * ph * (1.0f - ph);
@@ -1058,14 +1062,14 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
         }
         if (iter + 1 < p.num_iters) publish_abar();  // the returned mask is the one of the LAST forward (explain.py:209-211)
     }
-    __syncthreads();
+    SYNC();
     // ---------------- results: dense Abar block (zero off the edges), M on the edges, feature mask ----------------
     {
         f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int e = tid * 4; e < ld * ld; e += 4 * NT) *reinterpret_cast<f32x4*>(p.Abar + tm.offQ + e) = z4;
     }
     __threadfence_block();
-    __syncthreads();
+    SYNC();
 #pragma unroll
     for (int q = 0; q < SP_QMAX; ++q)
         if (tid + NT * q < eup) {
@@ -1077,6 +1081,37 @@ __global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t*
             Mg[(size_t)j * ld + i] = Mji[q];
         }
     if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = (tid < D) ? sh.fcur[tid] : 0.0f;
+}
+
+
+template <int DQ, int HQ, bool GRAPH, int NT>
+__global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t* targets, const float* adam_tab) {
+    __shared__ float pool[sp_pool_floats(NT)];
+    __shared__ SparseFixed sh;
+    sparse_resident_body<DQ, HQ, GRAPH, NT>(p, targets[blockIdx.x], adam_tab, pool, sh, (int)threadIdx.x);
+}
+
+// One launch for a node-mode batch of larger targets (512-thread class) and single-tile targets (64-thread code path):
+// workgroups [0, n_big) take one larger target each, the others six single-tile targets each - one per wave, in a
+// slice of the same LDS pool.  (Separate launches of the two groups overlap only partly: measured on syn1, the
+// single-tile launch took 6.6 ms beside the big one against 3.8 ms alone.)
+constexpr int SP_MIX_TINY = 6;
+template <int DQ, int HQ>
+__global__ __launch_bounds__(512) void k_sparse_resident_mixed(Params p, const int32_t* big_ids, int n_big, const int32_t* tiny_ids,
+                                                               int n_tiny, const float* adam_tab) {
+    __shared__ float pool[sp_pool_floats(512)];
+    __shared__ SparseFixed sh_big;
+    static_assert(SP_MIX_TINY * sp_pool_floats(64) + SP_MIX_TINY * (int)((sizeof(SparseFixed) + 3) / 4) <= sp_pool_floats(512),
+                  "the single-tile slices and their SparseFixed blocks must fit the 512-thread pool");
+    if ((int)blockIdx.x < n_big) {
+        sparse_resident_body<DQ, HQ, false, 512>(p, big_ids[blockIdx.x], adam_tab, pool, sh_big, (int)threadIdx.x);
+        return;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int idx = ((int)blockIdx.x - n_big) * SP_MIX_TINY + wave;
+    if (wave >= SP_MIX_TINY || idx >= n_tiny) return;  // whole waves leave: the 64-thread body has no workgroup barrier
+    SparseFixed* shp = reinterpret_cast<SparseFixed*>(pool + SP_MIX_TINY * sp_pool_floats(64)) + wave;
+    sparse_resident_body<DQ, HQ, false, 64>(p, tiny_ids[idx], adam_tab, pool + wave * sp_pool_floats(64), *shp, lane);
 }
 
 // per target: directed off-diagonal non-zeros of its block of the packed adjacency and the row slots the sparse

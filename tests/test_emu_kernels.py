@@ -239,8 +239,9 @@ def test_plan_routing_by_size_and_edge_count():
     subs = [sub(20, 0.2), sub(60, 0.1), sub(200, 0.02), sub(120, 0.5)]
     assert (subs[3].adj != 0).sum() // 2 > 2048
     route = list(emu_job(subs, sd).route())
-    assert route[0] == 1 and route[1] in (4, 8) and route[2] in (4, 8) and route[3] == 0   # a 512 / 1024-thread target in the batch:
-    #                                                                                     # only those classes + k_resident<1>
+    # a 512-thread target in the batch: the mid-size target joins its class, the single-tile one stays in the 64-thread
+    # class and shares the launch (k_sparse_resident_mixed)
+    assert route == [6, 8, 8, 0]
     assert list(emu_job(subs[:2], sd).route()) == [6, 5]
     assert list(emu_job(subs, sd, analyze=False).route()) == [1, 0, 0, 0]
     small = [sub(20, 0.2), sub(60, 0.1)]
@@ -353,3 +354,28 @@ def test_sparse_kernels_degenerate_graphs(case, n):
     live = A != 0
     if live.any():
         assert np.abs(res.mask[0] - o.M)[live].max() < 5e-5
+
+
+def test_mixed_launch_of_large_and_single_tile_targets():
+    """One launch for a 512-thread target and nine single-tile targets (k_sparse_resident_mixed: six single-tile targets
+    per workgroup, one per wave; the second such workgroup is half empty): every target must match its solo run bit
+    for bit (same code path, other workgroup shape) and the closed form."""
+    rng = np.random.default_rng(9)
+    sd = helpers.random_model(rng, 10, 20, 20, 4)
+
+    def sub(n, density, t):
+        A, X = helpers.random_graph(rng, n, 10, density=density)
+        m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
+        return Subgraph(A, X, 1, t, rng.integers(0, 4, n), m0)
+
+    subs = [sub(200, 0.02, 3)] + [sub(int(rng.integers(6, 33)), 0.2, 2) for _ in range(9)]
+    job = emu_job(subs, sd)
+    assert list(job.route()) == [8] + [6] * 9
+    hy = Hyper(num_iters=4)
+    res = job.run([s.mask0 for s in subs], hy)
+    for i, s in enumerate(subs):
+        o = closed_form.ClosedFormOracle(s.adj, s.feat, sd, s.gt_label, s.pred_label, s.target_row, s.mask0)
+        assert np.abs(res.masked_adj[i] - o.run(4)).max() < 5e-6
+        solo = emu_job([s], sd).run([s.mask0], hy)
+        assert np.array_equal(solo.masked_adj[0], res.masked_adj[i])
+        assert np.array_equal(solo.feat_mask[0], res.feat_mask[i])
