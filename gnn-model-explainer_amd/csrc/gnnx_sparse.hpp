@@ -348,7 +348,7 @@ __device__ __forceinline__ void sparse_combine(float (&acc)[NQ], int lane, bool 
 // (k_sparse_resident) or, for NT = 64, one wave of a larger workgroup (k_sparse_resident_mixed) - a single wave
 // synchronises with itself, so its barriers are wave-level.
 template <int DQ, int HQ, bool GRAPH, int NT>
-__device__ __forceinline__ void sparse_resident_body(const Params& p, int t, const float* adam_tab, float* pool, SparseFixed& sh,
+__device__ __forceinline__ void sparse_resident_body(const Params p, int t, const float* adam_tab, float* pool, SparseFixed& sh,
                                                      int tid) {
     constexpr int SCAN = (sp_ld_max(NT) + 63) / 64;  // rows per lane in the setup prefix scans
     constexpr int SP_QMAX = sp_qmax(NT);
@@ -1084,8 +1084,10 @@ __device__ __forceinline__ void sparse_resident_body(const Params& p, int t, con
 }
 
 
+// second launch bound = waves per SIMD the register allocation must leave room for: two 256-thread workgroups (or six
+// 64-thread ones) per CU need 2; without it the 256-thread graph-mode build took 266 registers and ran one per CU
 template <int DQ, int HQ, bool GRAPH, int NT>
-__global__ __launch_bounds__(NT) void k_sparse_resident(Params p, const int32_t* targets, const float* adam_tab) {
+__global__ __launch_bounds__(NT, NT >= 1024 ? 4 : 2) void k_sparse_resident(Params p, const int32_t* targets, const float* adam_tab) {
     __shared__ float pool[sp_pool_floats(NT)];
     __shared__ SparseFixed sh;
     sparse_resident_body<DQ, HQ, GRAPH, NT>(p, targets[blockIdx.x], adam_tab, pool, sh, (int)threadIdx.x);
