@@ -585,7 +585,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     // owned undirected edges: k = tid + NT q; mask entries and Adam moments stay in registers
     float Mij[SP_QMAX], Mji[SP_QMAX], mij[SP_QMAX], mji[SP_QMAX], vij[SP_QMAX], vji[SP_QMAX], wgt[SP_QMAX];
     int eij[SP_QMAX], eji[SP_QMAX], ni[SP_QMAX], nj[SP_QMAX];
-    bool near[SP_QMAX];  // an endpoint is t or a neighbour of t: only then dZ2 has a non-zero row on this edge
+    bool near[SP_QMAX];   // an endpoint is t or a neighbour of t: only then dZ2 has a non-zero row on this edge
+    bool near2[SP_QMAX];  // an endpoint lies within two hops of t: only then dZ1 has a non-zero row on this edge
     {
         bool asym = (2 * eup != nnz);
 #pragma unroll
@@ -593,7 +594,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             const int k = tid + NT * q;
             Mij[q] = Mji[q] = mij[q] = mji[q] = vij[q] = vji[q] = wgt[q] = 0.0f;
             eij[q] = eji[q] = ni[q] = nj[q] = 0;
-            near[q] = false;
+            near[q] = near2[q] = false;
             if (k < eup) {
                 int lo = 0, hi = ld;  // largest row i with upptr[i] <= k
                 while (hi - lo > 1) {
@@ -616,6 +617,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 const int t0 = rowptr[tr], t1 = rowptr[tr + 1];
                 const int pi = lower_bound_u16(scol, t0, t1, i), pj = lower_bound_u16(scol, t0, t1, j);
                 near[q] = GRAPH || i == tr || j == tr || (pi < t1 && (int)scol[pi] == i) || (pj < t1 && (int)scol[pj] == j);
+                near2[q] = GRAPH || level[i] <= 2 || level[j] <= 2;
             }
         }
         if (asym) sh.bad = 1;  // benign race: every writer stores 1
@@ -1000,8 +1002,9 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 // compile-time trip counts: all loads of an edge are issued before the first use; columns beyond
                 // D / H are read from the row padding / the next row and dropped by the select
                 float G0 = 0.0f, G1 = 0.0f;
+                // dZ1 is exactly zero beyond two hops of t: such edges only get their regulariser gradients
 #pragma unroll 1
-                for (int c0 = 0; c0 < 2 * DQ; c0 += 2 * DQ / 2) {
+                for (int c0 = 0; near2[q] && c0 < 2 * DQ; c0 += 2 * DQ / 2) {
 #pragma unroll
                     for (int cc = 0; cc < 2 * DQ / 2; ++cc) {
                         const int c = c0 + cc;
