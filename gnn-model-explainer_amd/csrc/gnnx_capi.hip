@@ -17,6 +17,7 @@
 #include "gnnx_resident.hpp"
 #include "gnnx_sparse.hpp"
 #include "gnnx_sparse_large.hpp"
+#include "gnnx_graph.hpp"
 
 using namespace gnnx;
 
@@ -77,6 +78,8 @@ struct gnnx_plan_s {
     unsigned short* d_csr_col = nullptr;
     long long* d_csr_off = nullptr;    // [2 T]: offsets of target t into the two arrays
     float* d_adam = nullptr;         // per-iteration Adam scalars for the resident kernel
+    int64_t* d_raw_off = nullptr;    // [T] float offset of target t's n x n block in the unpadded RNG stream (gnnx_scatter_masks)
+    int64_t total_raw = 0;
     std::vector<float> adam_host;
     gnnx_hyper adam_for{};
     TargetMeta* d_meta = nullptr;
@@ -267,6 +270,15 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
     PLANCK(hipMemcpy(h->d_conv, conv.data(), sizeof(ConvTile) * conv.size(), hipMemcpyHostToDevice));
     PLANCK(hipMemcpy(h->d_mask, mask.data(), sizeof(MaskTile) * mask.size(), hipMemcpyHostToDevice));
     PLANCK(hipMemcpy(h->d_wts, w.data(), sizeof(float) * WT_TOTAL, hipMemcpyHostToDevice));
+    {
+        std::vector<int64_t> ro(T);
+        for (int t = 0; t < T; ++t) {
+            ro[t] = h->total_raw;
+            h->total_raw += (int64_t)h->meta[t].n * h->meta[t].n;
+        }
+        PLANCK(hipMalloc(&h->d_raw_off, sizeof(int64_t) * T));
+        PLANCK(hipMemcpy(h->d_raw_off, ro.data(), sizeof(int64_t) * T, hipMemcpyHostToDevice));
+    }
 #undef PLANCK
     if (int rc = build_split(h)) {
         gnnx_destroy(h);
@@ -325,6 +337,7 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
     if (h->d_csr_col) (void)hipFree(h->d_csr_col);
     if (h->d_csr_off) (void)hipFree(h->d_csr_off);
     if (h->d_adam) (void)hipFree(h->d_adam);
+    if (h->d_raw_off) (void)hipFree(h->d_raw_off);
     if (h->d_big) (void)hipFree(h->d_big);
     if (h->d_conv_big) (void)hipFree(h->d_conv_big);
     if (h->d_mask_big) (void)hipFree(h->d_mask_big);
@@ -761,6 +774,64 @@ extern "C" int gnnx_pack_csr(gnnx_handle h, const int64_t* indptr, const int32_t
     if (yhat) HIPCK(hipMemsetAsync(yhat, 0, sizeof(float) * (size_t)h->R, s));
     PackArgs a{indptr, indices, weights, feat, feat_stride, pred_label, nb, nb_off, A, X, yhat, h->prob.D};
     hipLaunchKernelGGL(k_pack, dim3(h->n_conv), dim3(256), 0, s, a, h->d_conv);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" size_t gnnx_khop_scratch_bytes(int32_t num_nodes, int32_t num_targets) {
+    const size_t words = ((size_t)num_nodes + 31) / 32;
+    if (words <= (size_t)KH_LDS_WORDS) return 0;
+    const size_t grid = (size_t)std::min(num_targets, 1024);
+    return grid * 3 * words * sizeof(uint32_t);
+}
+
+extern "C" int gnnx_khop(const int64_t* indptr, const int32_t* indices, int32_t num_nodes, int32_t n_hops, const int32_t* targets,
+                         int32_t num_targets, int32_t* sizes, const int64_t* nb_off, int32_t* nb, int32_t* target_row,
+                         void* scratch, size_t scratch_bytes, void* stream) {
+    if (!indptr || !indices || !targets || num_nodes < 1 || num_targets < 1 || n_hops < 1) return fail("bad argument");
+    const bool emit = nb != nullptr;
+    if (emit ? (!nb_off || !target_row) : !sizes) return fail("null output");
+    const int words = (num_nodes + 31) / 32;
+    const bool in_lds = words <= KH_LDS_WORDS;
+    if (!in_lds && (!scratch || scratch_bytes < gnnx_khop_scratch_bytes(num_nodes, num_targets))) return fail("k-hop scratch too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    KhopArgs a{indptr, indices, num_nodes, n_hops, targets, num_targets, sizes, nb_off, nb, target_row,
+               static_cast<uint32_t*>(scratch), words};
+    const dim3 grid(in_lds ? num_targets : std::min(num_targets, 1024)), block(KH_THREADS);
+    if (emit) {
+        if (in_lds) hipLaunchKernelGGL((k_khop<true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_khop<true, false>), grid, block, 0, s, a);
+    } else {
+        if (in_lds) hipLaunchKernelGGL((k_khop<false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_khop<false, false>), grid, block, 0, s, a);
+    }
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int64_t gnnx_total_raw(gnnx_handle h) { return h ? h->total_raw : -1; }
+
+extern "C" int gnnx_scatter_masks(gnnx_handle h, const float* raw, float* M, void* stream) {
+    if (!h || !raw || !M) return fail("null argument");
+    hipLaunchKernelGGL(k_scatter_masks, dim3(h->n_conv), dim3(256), 0, static_cast<hipStream_t>(stream), raw, h->d_raw_off, M, h->d_conv);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gnnx_edge_counts(gnnx_handle h, const float* A, int64_t* counts, void* stream) {
+    if (!h || !A || !counts) return fail("null argument");
+    hipLaunchKernelGGL(k_edge_counts, dim3(h->prob.num_targets), dim3(256), 0, static_cast<hipStream_t>(stream), h->d_meta, A, counts);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gnnx_gather_edges(gnnx_handle h, const float* A, const float* Abar, const float* M, const int64_t* eoff, int32_t* rc,
+                                 float* abar, float* m_rc, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !A || !eoff || !rc || !workspace) return fail("null argument");
+    if ((abar && !Abar) || (m_rc && !M)) return fail("values requested without their source array");
+    if (workspace_bytes < h->ws_bytes) return fail("workspace too small");
+    EdgeOut o{eoff, rc, abar, m_rc, reinterpret_cast<int32_t*>(static_cast<char*>(workspace) + h->o_g3)};
+    hipLaunchKernelGGL(k_gather_edges, dim3(h->prob.num_targets), dim3(256), 0, static_cast<hipStream_t>(stream), h->d_meta, A, Abar, M, o);
     HIPCK(hipGetLastError());
     return 0;
 }

@@ -97,6 +97,13 @@ _API = {
     "gnnx_time_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper), ctypes.c_int32, ctypes.c_int32] +
                          [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
                                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "gnnx_khop_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
+    "gnnx_khop": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32] +
+                  [ctypes.c_void_p] * 5 + [ctypes.c_size_t, ctypes.c_void_p]),
+    "gnnx_total_raw": (ctypes.c_int64, [ctypes.c_void_p]),
+    "gnnx_scatter_masks": (ctypes.c_int, [ctypes.c_void_p] * 4),
+    "gnnx_edge_counts": (ctypes.c_int, [ctypes.c_void_p] * 4),
+    "gnnx_gather_edges": (ctypes.c_int, [ctypes.c_void_p] * 9 + [ctypes.c_size_t, ctypes.c_void_p]),
     "gnnx_last_error": (ctypes.c_char_p, []),
     "gnnx_version": (ctypes.c_char_p, []),
 }
@@ -184,6 +191,68 @@ class DeviceGraph:
     binary: bool
 
 
+@dataclass
+class DeviceNeighbors:
+    """k-hop neighbour lists of a batch of targets, resident on the device (khop_device)."""
+    sizes: np.ndarray          # host int32 [T]
+    rows: np.ndarray           # host int32 [T]: node_idx_new of every target (-1: the target is not in its own set)
+    nb_flat: torch.Tensor      # device int32 [sum sizes], ascending per target
+    nb_off: torch.Tensor       # device int64 [T + 1]
+
+    def __len__(self):
+        return len(self.sizes)
+
+    def lists(self):
+        """Host copies, one ascending id array per target (tests / inspection)."""
+        flat, off = self.nb_flat.cpu().numpy(), self.nb_off.cpu().numpy()
+        return [flat[off[t]:off[t + 1]].astype(np.int64) for t in range(len(self.sizes))]
+
+
+@dataclass
+class EdgeMasks:
+    """The explanation of a batch as edge lists: for target t the upper-triangle edges eoff[t]:eoff[t+1] of its
+    sub-graph in row-major order (r < c), with the masked adjacency of the last forward (explain.py:209-211)."""
+    n: np.ndarray              # [T] sub-graph sizes
+    eoff: np.ndarray           # int64 [T + 1]
+    rc: np.ndarray             # int32 [E, 2]
+    masked_adj: np.ndarray     # float32 [E]
+    feat_mask: np.ndarray      # [T, D] final feature-mask parameter (pre-sigmoid)
+    mask_rc: Optional[np.ndarray] = None   # float32 [E, 2]: final mask parameters M[r][c], M[c][r]
+
+    def dense(self, t, dtype=np.float64):
+        """The reference's return value for target t: dense symmetric [n, n] (explain.py:209-211)."""
+        a, b = int(self.eoff[t]), int(self.eoff[t + 1])
+        out = np.zeros((int(self.n[t]), int(self.n[t])), dtype)
+        r, c = self.rc[a:b, 0], self.rc[a:b, 1]
+        out[r, c] = self.masked_adj[a:b]
+        out[c, r] = self.masked_adj[a:b]
+        return out
+
+
+def khop_device(graph, targets, n_hops, lib=None) -> DeviceNeighbors:
+    """k-hop walk sets of `targets` on the device from the resident CSR graph (gnnx_khop): the neighbour lists of
+    graph_utils.neighborhoods + Explainer.extract_neighborhood (utils/graph_utils.py:147-158, explain.py:492-501)
+    without the host.  Two passes: sizes (the host needs them for the plan), then the ascending lists + node_idx_new."""
+    lib = lib if lib is not None else get_library()
+    dev = graph.feat.device
+    T = len(targets)
+    tg = torch.from_numpy(np.ascontiguousarray(targets, dtype=np.int32)).to(dev)
+    sizes_d = torch.empty(T, dtype=torch.int32, device=dev)
+    sb = int(lib.gnnx_khop_scratch_bytes(graph.num_nodes, T))
+    scratch = torch.empty(max(sb, 1), dtype=torch.uint8, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream if dev.type == _DEVICE_TYPE else 0)
+    args = (graph.indptr.data_ptr(), graph.indices.data_ptr(), graph.num_nodes, int(n_hops), tg.data_ptr(), T)
+    _check(lib, lib.gnnx_khop(*args, sizes_d.data_ptr(), None, None, None, scratch.data_ptr(), sb, stream))
+    sizes = sizes_d.cpu().numpy()                      # synchronises
+    off = np.zeros(T + 1, np.int64)
+    np.cumsum(sizes, out=off[1:])
+    nb_off = torch.from_numpy(off).to(dev)
+    nb_flat = torch.empty(max(int(off[-1]), 1), dtype=torch.int32, device=dev)
+    rows_d = torch.empty(T, dtype=torch.int32, device=dev)
+    _check(lib, lib.gnnx_khop(*args, None, nb_off.data_ptr(), nb_flat.data_ptr(), rows_d.data_ptr(), scratch.data_ptr(), sb, stream))
+    return DeviceNeighbors(sizes.astype(np.int32), rows_d.cpu().numpy(), nb_flat, nb_off)
+
+
 def device_graph(csr, feat, pred=None, device=None):
     """Upload a scipy CSR adjacency + features (+ argmax of the model's predictions) for device-side packing."""
     import scipy.sparse as sp
@@ -222,13 +291,19 @@ class MaskOptimJob:
         self.T = len(neighbors)
         if self.T == 0:
             raise ValueError("empty batch")
-        self.n = np.asarray([len(nb) for nb in neighbors], np.int32)
+        on_device = isinstance(neighbors, DeviceNeighbors)
+        self.n = np.ascontiguousarray(neighbors.sizes, np.int32) if on_device else np.asarray([len(nb) for nb in neighbors], np.int32)
+        if on_device and target_rows is None:
+            target_rows = neighbors.rows
         self._create_plan(np.asarray(target_rows, np.int32), np.asarray(gt_labels, np.int32))
         self._alloc_device()
-        nb_off = np.zeros(self.T + 1, np.int64)
-        np.cumsum(self.n, out=nb_off[1:])
-        nb_flat = torch.from_numpy(np.concatenate(neighbors).astype(np.int32)).to(self.device)
-        nb_off_d = torch.from_numpy(nb_off).to(self.device)
+        if on_device:        # lists produced by khop_device: nothing crosses PCIe
+            nb_flat, nb_off_d = neighbors.nb_flat, neighbors.nb_off
+        else:
+            nb_off = np.zeros(self.T + 1, np.int64)
+            np.cumsum(self.n, out=nb_off[1:])
+            nb_flat = torch.from_numpy(np.concatenate(neighbors).astype(np.int32)).to(self.device)
+            nb_off_d = torch.from_numpy(nb_off).to(self.device)
         self._enter()
         _check(self.lib, self.lib.gnnx_pack_csr(
             self.handle, graph.indptr.data_ptr(), graph.indices.data_ptr(),
@@ -353,6 +428,42 @@ class MaskOptimJob:
             v[:n, :n] = m
         self.M.copy_(torch.from_numpy(M), non_blocking=False)
 
+    def set_masks_raw(self, raw: torch.Tensor):
+        """Upload the initial edge masks as the host generator produced them - ONE contiguous n x n draw per target,
+        concatenated in target order (init_edge_masks_raw) - and spread them over the padded layout on the device
+        (gnnx_scatter_masks): one H2D copy, no host-side packing."""
+        if raw.dtype != torch.float32 or raw.numel() != int(self.lib.gnnx_total_raw(self.handle)):
+            raise ValueError("raw mask stream must hold sum(n^2) float32 values")
+        self._raw = raw.to(self.device, non_blocking=True)
+        self._enter()
+        _check(self.lib, self.lib.gnnx_scatter_masks(self.handle, self._raw.data_ptr(), self.M.data_ptr(), self._stream()))
+        self._leave()
+
+    def fetch_edges(self, with_mask=False) -> EdgeMasks:
+        """The result as edge lists (gnnx_edge_counts / gnnx_gather_edges): only the live entries cross PCIe."""
+        dev = self.device
+        if getattr(self, "_eoff", None) is None:      # the edge structure of the batch is fixed: count once
+            counts = torch.empty(self.T, dtype=torch.int64, device=dev)
+            self._enter()
+            _check(self.lib, self.lib.gnnx_edge_counts(self.handle, self.A.data_ptr(), counts.data_ptr(), self._stream()))
+            self._leave()
+            eoff = np.zeros(self.T + 1, np.int64)
+            np.cumsum(counts.cpu().numpy(), out=eoff[1:])
+            self._eoff, self._eoff_d = eoff, torch.from_numpy(eoff).to(dev)
+            E = max(int(eoff[-1]), 1)
+            self._rc = torch.empty(E, 2, dtype=torch.int32, device=dev)
+            self._ev = torch.empty(E, dtype=torch.float32, device=dev)
+            self._em = torch.empty(E, 2, dtype=torch.float32, device=dev)
+        self._enter()
+        _check(self.lib, self.lib.gnnx_gather_edges(self.handle, self.A.data_ptr(), self.Abar.data_ptr(), self.M.data_ptr(),
+                                                    self._eoff_d.data_ptr(), self._rc.data_ptr(), self._ev.data_ptr(),
+                                                    self._em.data_ptr() if with_mask else None, self.ws.data_ptr(), self.ws_bytes,
+                                                    self._stream()))
+        self._leave()
+        E = int(self._eoff[-1])
+        return EdgeMasks(self.n.copy(), self._eoff, self._rc.cpu().numpy()[:E], self._ev.cpu().numpy()[:E],
+                         self.fmask.cpu().numpy()[:, :self.D].copy(), self._em.cpu().numpy()[:E] if with_mask else None)
+
     def _stream(self):
         return ctypes.c_void_p(self.stream.cuda_stream if self.stream is not None else 0)
 
@@ -456,6 +567,25 @@ class MaskOptimJob:
             self.close()
         except Exception:
             pass
+
+
+def init_edge_masks_raw(sizes, generator=None, seeds=None, pin=False):
+    """The initial edge masks of a whole batch as ONE host buffer: target after target the n x n values of the single
+    normal_(1, std) draw construct_edge_mask makes (explain.py:645-652), generated in place (a draw into a contiguous
+    slice consumes the generator exactly like a draw into a fresh [n, n] tensor).  `seeds`: re-seed a PRIVATE generator
+    before every target (the seed protocol of the golden runs) instead of consuming the caller's global stream."""
+    sizes = [int(n) for n in sizes]
+    buf = torch.empty(sum(n * n for n in sizes), dtype=torch.float32, pin_memory=bool(pin))
+    gen = generator
+    if seeds is not None:
+        gen = torch.Generator()
+    o = 0
+    for k, n in enumerate(sizes):
+        if seeds is not None:
+            gen.manual_seed(int(seeds[k]))
+        buf[o:o + n * n].normal_(1.0, math.sqrt(2.0) * math.sqrt(2.0 / (n + n)), generator=gen)
+        o += n * n
+    return buf
 
 
 def init_edge_mask(n, generator=None):

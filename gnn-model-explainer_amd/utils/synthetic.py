@@ -61,3 +61,28 @@ def sparse_gcn_predict(csr, feat, sd):
         x = np.maximum(y, 0) if l < 2 else y
         hs.append(x)
     return np.concatenate(hs, 1) @ np.asarray(sd["pred_model.weight"], f32).T + np.asarray(sd["pred_model.bias"], f32)
+
+
+def molecule_like_graphs(num_graphs, seed=0, max_nodes=100, num_feat=14):
+    """BASELINE.json configs[3] stand-in (the real Mutagenicity TU files are not available offline): molecule-like
+    graphs - a random tree plus a few ring closures, 10..max_nodes atoms, one-hot atom types, binary class label -
+    padded to max_nodes x max_nodes like the reference's GraphSampler (utils/graph_utils.py:11-145).
+    -> (adj [G, max_nodes, max_nodes] f32, feat [G, max_nodes, num_feat] f32, num_nodes [G], label [G]); graph g is the
+    same whatever num_graphs is (one generator, consumed in graph order)."""
+    rng = np.random.default_rng(seed)
+    A = np.zeros((num_graphs, max_nodes, max_nodes), np.float32)
+    X = np.zeros((num_graphs, max_nodes, num_feat), np.float32)
+    nn_, y = np.zeros(num_graphs, np.int64), np.zeros(num_graphs, np.int64)
+    for g in range(num_graphs):
+        n = int(rng.integers(10, max_nodes + 1))
+        for v in range(1, n):
+            u = int(rng.integers(max(0, v - 4), v))
+            A[g, u, v] = A[g, v, u] = 1
+        for _ in range(max(1, n // 8)):
+            u, v = rng.integers(0, n, 2)
+            if u != v:
+                A[g, u, v] = A[g, v, u] = 1
+        X[g, np.arange(n), rng.integers(0, num_feat, n)] = 1
+        nn_[g] = n
+        y[g] = int(rng.integers(0, 2))
+    return A, X, nn_, y

@@ -149,6 +149,36 @@ int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hyper, int32_t kind, int32
                      const float* X, const float* yhat, float* M, float* Abar, void* workspace,
                      size_t workspace_bytes, void* stream, float* ms_avg, double* alg_bytes, double* alg_flops);
 
+/* ---- index work either side of the loop (csrc/gnnx_graph.hpp) ------------------------------------------------------ */
+
+/* k-hop walk sets of a batch of targets over the resident CSR graph (all pointers DEVICE pointers): the set
+ * {u : (A + A^2 + ... + A^k)[v][u] > 0} of graph_utils.neighborhoods (utils/graph_utils.py:147-158; a dense O(N^3)
+ * product on the whole graph in the reference) as the ascending id list Explainer.extract_neighborhood builds from it
+ * (explain.py:492-501), plus node_idx_new = the target's position in its own list (explain.py:496).  Two passes:
+ *   nb == NULL : sizes[t] = |set| for every target (the host needs them for gnnx_plan_create);
+ *   nb != NULL : nb[nb_off[t] .. nb_off[t+1]) = the list, target_row[t] = position of the target (-1: not in its own
+ *                set, i.e. an isolated node - the reference then fails on an empty neighbourhood).
+ * scratch: gnnx_khop_scratch_bytes(num_nodes, num_targets) bytes (0 when the bitmaps fit LDS: num_nodes <= 131072). */
+size_t gnnx_khop_scratch_bytes(int32_t num_nodes, int32_t num_targets);
+int gnnx_khop(const int64_t* indptr, const int32_t* indices, int32_t num_nodes, int32_t n_hops, const int32_t* targets,
+              int32_t num_targets, int32_t* sizes, const int64_t* nb_off, int32_t* nb, int32_t* target_row, void* scratch,
+              size_t scratch_bytes, void* stream);
+
+/* Initial edge masks from the host's RNG stream: `raw` (DEVICE, gnnx_total_raw(h) floats) holds, target after target, the
+ * n_t x n_t values of the ONE normal_ draw construct_edge_mask makes per target (explain.py:645-652), unpadded; this
+ * spreads them over the padded blocks of M (padding = 0). */
+int64_t gnnx_total_raw(gnnx_handle h);
+int gnnx_scatter_masks(gnnx_handle h, const float* raw, float* M, void* stream);
+
+/* The explanation as edge lists - the returned masks are exactly zero off the sub-graph's edges (explain.py:209-211).
+ * gnnx_edge_counts: counts[t] (DEVICE int64 [T]) = upper-triangle (r < c) non-zeros of target t's block of A.
+ * gnnx_gather_edges: for those edges in row-major order, at eoff[t] (DEVICE int64 [T+1], the prefix sums of counts):
+ *   rc [E][2] = (r, c);  abar [E] = Abar[r][c] (the masked adjacency of the last forward) or NULL;
+ *   m_rc [E][2] = M[r][c], M[c][r] (final mask parameters) or NULL.  Uses the workspace of gnnx_run as scratch. */
+int gnnx_edge_counts(gnnx_handle h, const float* A, int64_t* counts, void* stream);
+int gnnx_gather_edges(gnnx_handle h, const float* A, const float* Abar, const float* M, const int64_t* eoff, int32_t* rc,
+                      float* abar, float* m_rc, void* workspace, size_t workspace_bytes, void* stream);
+
 const char* gnnx_last_error(void);
 const char* gnnx_version(void);
 

@@ -77,6 +77,9 @@ inline float emu_fmed3f(float a, float b, float c) { return std::fmax(std::fmin(
 #define __builtin_amdgcn_sqrtf(x) std::sqrt(x)
 #define __expf(x) std::exp(x)
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __ffs(int v) { return __builtin_ffs(v); }
 
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "ok" : "emulator: unsupported"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
