@@ -439,8 +439,13 @@ class MaskOptimJob:
         _check(self.lib, self.lib.gnnx_scatter_masks(self.handle, self._raw.data_ptr(), self.M.data_ptr(), self._stream()))
         self._leave()
 
-    def fetch_edges(self, with_mask=False) -> EdgeMasks:
-        """The result as edge lists (gnnx_edge_counts / gnnx_gather_edges): only the live entries cross PCIe."""
+    def set_masks_raw_resident(self):
+        """Reset M to the initial masks from the RNG stream uploaded by the last set_masks_raw (a device-only op)."""
+        self._enter()
+        _check(self.lib, self.lib.gnnx_scatter_masks(self.handle, self._raw.data_ptr(), self.M.data_ptr(), self._stream()))
+        self._leave()
+
+    def _edge_layout(self):
         dev = self.device
         if getattr(self, "_eoff", None) is None:      # the edge structure of the batch is fixed: count once
             counts = torch.empty(self.T, dtype=torch.int64, device=dev)
@@ -454,12 +459,22 @@ class MaskOptimJob:
             self._rc = torch.empty(E, 2, dtype=torch.int32, device=dev)
             self._ev = torch.empty(E, dtype=torch.float32, device=dev)
             self._em = torch.empty(E, 2, dtype=torch.float32, device=dev)
+
+    def gather_edges_device(self, with_mask=False) -> torch.Tensor:
+        """Masked adjacency of the last forward on the upper-triangle edges of every target, as ONE device tensor [E]
+        (asynchronous; what a multi-GPU gather ships instead of dense blocks)."""
+        self._edge_layout()
         self._enter()
         _check(self.lib, self.lib.gnnx_gather_edges(self.handle, self.A.data_ptr(), self.Abar.data_ptr(), self.M.data_ptr(),
                                                     self._eoff_d.data_ptr(), self._rc.data_ptr(), self._ev.data_ptr(),
                                                     self._em.data_ptr() if with_mask else None, self.ws.data_ptr(), self.ws_bytes,
                                                     self._stream()))
         self._leave()
+        return self._ev[:int(self._eoff[-1])]
+
+    def fetch_edges(self, with_mask=False) -> EdgeMasks:
+        """The result as edge lists (gnnx_edge_counts / gnnx_gather_edges): only the live entries cross PCIe."""
+        self.gather_edges_device(with_mask)
         E = int(self._eoff[-1])
         return EdgeMasks(self.n.copy(), self._eoff, self._rc.cpu().numpy()[:E], self._ev.cpu().numpy()[:E],
                          self.fmask.cpu().numpy()[:, :self.D].copy(), self._em.cpu().numpy()[:E] if with_mask else None)

@@ -12,8 +12,9 @@ mask-optimisation path (`model="exp"`, `unconstrained=False`, sigmoid mask, Adam
     in list order, exactly like `construct_edge_mask` (explain.py:645-652), so seeded runs reproduce the
     reference's masks.
 
+`--mask-bias` is accepted (the reference's bias mask provably stays exactly 0, see _check_supported).
 Options the HIP path does not implement raise NotImplementedError (never a silent difference):
-`mask_act="ReLU"`, `--mask-bias`, `--bn`, `method="att"`, non-Adam optimisers / LR schedulers,
+`mask_act="ReLU"`, `--bn`, `method="att"`, non-Adam optimisers / LR schedulers,
 `unconstrained=True`, `model="grad"/"att"`, num_gc_layers != 3.
 Plotting / TensorBoard / alignment post-processing of the reference is out of scope.
 """
@@ -24,7 +25,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ..engine import FEAT_STRIDE, Hyper, MaskOptimJob, Subgraph, device_graph, init_edge_mask
+from ..engine import (FEAT_STRIDE, Hyper, MaskOptimJob, Subgraph, device_graph, init_edge_mask, init_edge_masks_raw,
+                      khop_device)
 from ..utils import io_utils
 from ..utils.graph_utils import KHopIndex
 
@@ -34,8 +36,11 @@ COEFFS = {"size": 0.005, "feat_size": 1.0, "ent": 1.0, "feat_ent": 0.1, "grad": 
 def _check_supported(args):
     if getattr(args, "mask_act", "sigmoid") != "sigmoid":
         raise NotImplementedError("mask_act=%r: the HIP path implements the sigmoid mask" % args.mask_act)
-    if getattr(args, "mask_bias", False):
-        raise NotImplementedError("--mask-bias is not implemented on the HIP path")
+    # --mask-bias (explain.py:657-661, 674-677) is accepted: the reference creates mask_bias = 0 and adds
+    # sym(ReLU6(6 sym(mask_bias)) / 6) to the masked adjacency.  ReLU6 has zero gradient at 0 (torch: hardtanh backward is
+    # strict), so mask_bias never receives a gradient, Adam leaves it at exactly 0 and the added term is exactly 0 in every
+    # epoch: the reference's outputs with and without the flag are bit-identical (pinned by tests/golden/flags_explain.npz,
+    # produced by running the reference with mask_bias=True).  The same kernels therefore serve both settings.
     if getattr(args, "bn", False):
         raise NotImplementedError("--bn is not implemented on the HIP path")
     if getattr(args, "method", "base") != "base":
@@ -53,6 +58,20 @@ def _hyper(args, **kw):
 
 def _np(a):
     return a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+
+
+# which build of the engine the classes below drive: None = libgnnx_hip.so on the current HIP device.  The CPU-only tests
+# point this at the emulator build of the same sources (tests/emu) with host memory standing in for device memory.
+_ENGINE = {"lib": None, "device": None}
+
+
+class _Result:
+    """What the most recent batch left behind besides the returned masks."""
+
+    def __init__(self, feat_mask, loss, edges):
+        self.feat_mask = feat_mask      # [T, D] final feature-mask parameters (the reference discards them, explain.py:108, 221)
+        self.loss = loss                # [T, iters, 8] loss terms when logging was on
+        self.edges = edges              # engine.EdgeMasks of the batch (binary adjacency)
 
 
 class Explainer:
@@ -137,49 +156,84 @@ class Explainer:
     def _device_graph(self, graph_idx):
         if graph_idx not in self._dev_graph:
             self._dev_graph[graph_idx] = device_graph(self._index(graph_idx).csr, _np(self.feat)[graph_idx],
-                                                      _np(self.pred)[graph_idx])
+                                                      _np(self.pred)[graph_idx], device=_ENGINE["device"])
         return self._dev_graph[graph_idx]
 
-    def explain_batch(self, node_indices=None, graph_indices=None, graph_idx=0, record_loss=False, use_graph=True):
+    def explain_batch(self, node_indices=None, graph_indices=None, graph_idx=0, record_loss=False, use_graph=False):
         """All targets as ONE job on the GPU. Returns list of float64 masked adjacencies (reference layout).
 
-        Node mode: only the k-hop neighbour lists are computed on the host; the dense sub-adjacencies, feature
-        rows and predicted labels are sliced on the device from the CSR graph (gnnx_pack_csr)."""
+        Node mode runs device-side end to end: the k-hop walk sets (gnnx_khop), the dense sub-adjacencies, feature rows
+        and predicted labels (gnnx_pack_csr) all come from the CSR graph resident on the GPU; the host only draws the
+        initial masks (the caller's torch CPU generator, one normal_ per target in list order, like
+        construct_edge_mask) and receives the masks as edge lists (gnnx_gather_edges).  With torch.distributed
+        initialised (one process per GPU) the targets are sharded over the ranks by n^2 (parallel.run_sharded) and
+        every rank returns the full list."""
         begin = time.time()
-        if self.graph_mode or graph_indices is not None:
+        lib, device = _ENGINE["lib"], _ENGINE["device"]
+        sd = self.model.state_dict()
+        if graph_indices is not None:
+            if not self.graph_mode:
+                raise ValueError("graph_indices given to a node-mode Explainer")
             targets = list(graph_indices)
             built = [self._graph_subgraph(g) for g in targets]
             subs = [b[0] for b in built]
-            sizes = [s.adj.shape[0] for s in subs]
-            make_job = lambda: MaskOptimJob(subs, self.model.state_dict(), graph_mode=True)
-            sub_adjs = lambda job: [np.asarray(b[1], np.float64) for b in built]
-        else:
-            targets = [int(v) for v in node_indices]
-            idx = self._index(graph_idx)
-            nbs = idx.neighbors_batch(targets)
-            for v, nb in zip(targets, nbs):
-                if len(nb) == 0:
-                    raise IndexError("node %d has an empty %d-hop neighbourhood" % (v, self.n_hops))
-            rows = [int(np.searchsorted(nb, v)) for v, nb in zip(targets, nbs)]          # explain.py:496
-            labels = _np(self.label)[graph_idx][np.asarray(targets)]                      # explain.py:751
-            sizes = [len(nb) for nb in nbs]
-            graph = self._device_graph(graph_idx)
-            make_job = lambda: self._job_from_csr(graph, nbs, rows, labels)
-            # explain.py:209-211 multiplies by sub_adj: a no-op for a 0/1 adjacency, otherwise fetched back once
-            sub_adjs = lambda job: [None] * len(targets) if graph.binary else [a.astype(np.float64) for a in job.adjacency()]
-        masks = [init_edge_mask(n) for n in sizes]          # same RNG stream as ExplainModule.__init__ per target
-        job = make_job()
+            masks = [init_edge_mask(s.adj.shape[0]) for s in subs]     # same RNG stream as ExplainModule.__init__ per target
+            job = MaskOptimJob(subs, sd, graph_mode=True, device=device, lib=lib)
+            res = job.run(masks, _hyper(self.args, record_loss=record_loss, use_graph=use_graph and len(targets) > 1))
+            job.close()
+            self.last_time = time.time() - begin
+            self.last_result = res
+            # explain.py:209-211: float32 mask * float64 sub_adj -> float64
+            return [ma.astype(np.float64) * np.asarray(b[1], np.float64) for ma, b in zip(res.masked_adj, built)]
+        if self.graph_mode:
+            # the reference's CLI allows --graph-idx N --explain-node K on a graph-mode Explainer (explain(node, graph_mode=False));
+            # that combination needs the node head on a graph encoder, which the HIP path does not implement
+            raise NotImplementedError("node explanations on a graph-mode Explainer are not implemented on the HIP path")
+        targets = np.asarray([int(v) for v in node_indices], np.int64)
+        graph = self._device_graph(graph_idx)
+        dn = khop_device(graph, targets, self.n_hops, lib=lib)
+        for v, n in zip(targets, dn.sizes):
+            if n == 0:
+                raise IndexError("node %d has an empty %d-hop neighbourhood" % (v, self.n_hops))
+        raw = init_edge_masks_raw(dn.sizes)                              # global generator, target order
+        labels = _np(self.label)[graph_idx][targets]                    # explain.py:751
+        raw_off = np.zeros(len(targets) + 1, np.int64)
+        np.cumsum(dn.sizes.astype(np.int64) ** 2, out=raw_off[1:])
         hy = _hyper(self.args, record_loss=record_loss, use_graph=use_graph and len(targets) > 1)
-        res = job.run(masks, hy)
-        adjs = sub_adjs(job)
-        job.close()
-        self.last_time = time.time() - begin
-        self.last_result = res
-        # explain.py:209-211: float32 mask * float64 sub_adj -> float64
-        return [ma.astype(np.float64) if sa is None else ma.astype(np.float64) * sa for ma, sa in zip(res.masked_adj, adjs)]
+        last = {}
 
-    def _job_from_csr(self, graph, nbs, rows, labels):
-        return MaskOptimJob.from_csr(graph, nbs, rows, labels, self.model.state_dict())
+        def compute(idxs):
+            """This rank's shard (all targets on one GPU): -> one float64 masked adjacency per target."""
+            if len(idxs) == len(targets):
+                sub_dn, sub_raw = dn, raw
+            else:
+                sub_dn = khop_device(graph, targets[idxs], self.n_hops, lib=lib)
+                sub_raw = torch.cat([raw[raw_off[i]:raw_off[i + 1]] for i in idxs])
+            job = MaskOptimJob.from_csr(graph, sub_dn, None, labels[idxs], sd, lib=lib)
+            job.set_masks_raw(sub_raw)
+            job.launch(hy)
+            if graph.binary:            # explain.py:209-211 multiplies by sub_adj: a no-op for a 0/1 adjacency
+                em = job.fetch_edges()
+                out = [em.dense(k) for k in range(len(idxs))]
+                last.update(feat_mask=em.feat_mask, loss=job.loss.cpu().numpy() if record_loss else None, edges=em, rows=sub_dn.rows)
+            else:
+                res = job.fetch(hy)
+                out = [ma.astype(np.float64) * a.astype(np.float64) for ma, a in zip(res.masked_adj, job.adjacency())]
+                last.update(feat_mask=res.feat_mask, loss=res.loss, edges=None, rows=sub_dn.rows)
+            job.close()
+            return out
+
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from ..parallel import run_sharded
+            got = run_sharded(list(range(len(targets))), dn.sizes.astype(np.float64) ** 2, compute)
+            out = [got[i] for i in range(len(targets))]
+        else:
+            out = compute(list(range(len(targets))))
+        self.last_time = time.time() - begin
+        self.last_result = _Result(last.get("feat_mask"), last.get("loss"), last.get("edges"))
+        self.last_rows = dn.rows
+        return out
 
     def _save(self, masked_adj, node_idx):
         fname = "masked_adj_" + io_utils.gen_explainer_prefix(self.args) + (
@@ -217,27 +271,24 @@ class Explainer:
         return masked_adjs
 
     def explain_nodes_gnn_stats(self, node_indices, args, graph_idx=0, model="exp"):
-        """explain.py:295-353: batch explanation + the ROC-AUC text file (no plots)."""
+        """explain.py:295-353: batch explanation + the ROC-AUC text file (no plots).  Like the reference this needs a
+        dataset with motif ground truth (make_pred_real: syn1 / syn2 / syn4) and raises otherwise."""
         if model != "exp":
             raise NotImplementedError("model=%r: only 'exp' is implemented" % model)
         node_indices = list(node_indices)
         masked_adjs = self.explain_batch(node_indices=node_indices, graph_idx=graph_idx)
         pred_all, real_all = [], []
-        for v, ma in zip(node_indices, masked_adjs):
+        for v, ma, new_idx in zip(node_indices, masked_adjs, self.last_rows):     # node_idx_new came with the k-hop lists
             self._save(ma, v)
-            new_idx = self._index(graph_idx).extract(v)[0]
-            pr = self.make_pred_real(ma, new_idx)
-            if pr is not None:
-                pred_all.append(pr[0])
-                real_all.append(pr[1])
-        if pred_all:
-            from sklearn.metrics import roc_auc_score
-            pred_all, real_all = np.concatenate(pred_all), np.concatenate(real_all)
-            if 0 < real_all.sum() < len(real_all):
-                self.last_auc = float(roc_auc_score(real_all, pred_all))
-                os.makedirs("log/pr", exist_ok=True)
-                with open("log/pr/auc_" + self.args.dataset + "_" + model + ".txt", "w") as f:
-                    f.write("dataset: {}, model: {}, auc: {}\n".format(self.args.dataset, "exp", str(self.last_auc)))
+            pred, real = self.make_pred_real(ma, int(new_idx))
+            pred_all.append(pred)
+            real_all.append(real)
+        from sklearn.metrics import roc_auc_score
+        pred_all, real_all = np.concatenate(pred_all), np.concatenate(real_all)
+        self.last_auc = float(roc_auc_score(real_all, pred_all))                  # raises on single-class labels, as the reference does
+        os.makedirs("log/pr", exist_ok=True)
+        with open("log/pr/auc_" + self.args.dataset + "_" + model + ".txt", "w") as f:
+            f.write("dataset: {}, model: {}, auc: {}\n".format(self.args.dataset, "exp", str(self.last_auc)))
         return masked_adjs
 
     def explain_graphs(self, graph_indices):
@@ -249,16 +300,17 @@ class Explainer:
         return masked_adjs
 
     def make_pred_real(self, adj, start):
-        """Motif ground truth for syn1/syn2 (house) and syn4 (cycle) — explain.py:535-579."""
+        """Motif ground truth for syn1/syn2 (house) and syn4 (cycle) — explain.py:535-579.  Other datasets have none:
+        the reference fails there (its `real` is never bound); so does this."""
         ds = getattr(self.args, "dataset", None)
         if ds in ("syn1", "syn2"):
             motif = [(0, 1), (1, 2), (2, 3), (0, 3), (0, 4), (1, 4)]
         elif ds == "syn4":
             motif = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (0, 5)]
         else:
-            return None
+            raise ValueError("no motif ground truth for dataset %r (explain.py:535-579 covers syn1, syn2, syn4)" % ds)
         if start + max(max(m) for m in motif) >= adj.shape[0]:
-            return None
+            raise IndexError("motif of node_idx_new=%d reaches beyond the %d-node sub-graph" % (start, adj.shape[0]))
         pred = adj[np.triu(adj) > 0]
         real = adj.copy()
         for a, b in motif:
@@ -289,7 +341,8 @@ class ExplainModule(nn.Module):
         n = adj.size()[1]
         self.mask = nn.Parameter(torch.from_numpy(init_edge_mask(n)))          # explain.py:645-652
         self.feat_mask = nn.Parameter(torch.zeros(x.size(-1)))                  # explain.py:639-641
-        self.mask_bias = None
+        # explain.py:657-661: a zero Parameter that provably never moves (see _check_supported)
+        self.mask_bias = nn.Parameter(torch.zeros(n, n)) if getattr(args, "mask_bias", False) else None
         self.diag_mask = torch.ones(n, n) - torch.eye(n)
         self.coeffs = dict(COEFFS)
         self.scheduler = None
@@ -299,7 +352,7 @@ class ExplainModule(nn.Module):
         gt = int(lab) if graph_mode else int(lab.reshape(-1)[self._node_idx])
         self._sub = Subgraph(_np(adj)[0].astype(np.float32), _np(x)[0].astype(np.float32), gt, self._node_idx,
                              None if graph_mode else np.asarray(pred_label), None)
-        self._job = MaskOptimJob([self._sub], model.state_dict(), graph_mode=graph_mode)
+        self._job = MaskOptimJob([self._sub], model.state_dict(), graph_mode=graph_mode, device=_ENGINE["device"], lib=_ENGINE["lib"])
 
     def forward(self, node_idx, unconstrained=False, mask_features=True, marginalize=False):
         if unconstrained or marginalize or not mask_features:
@@ -331,7 +384,9 @@ class ExplainModule(nn.Module):
 
     def optimize(self, num_epochs=None, record_loss=False):
         """The hot loop (explain.py:137-146) on the GPU; updates mask / feat_mask / masked_adj in place."""
-        hy = _hyper(self.args, record_loss=record_loss)
+        # the streaming kernels keep EVERY entry of the dense mask up to date (the edge-sparse resident kernels only the
+        # entries on edges), so `self.mask` - and a later `loss()` over all n^2 entries - match the reference's parameter
+        hy = _hyper(self.args, record_loss=record_loss, use_resident=False)
         if num_epochs is not None:
             hy.num_iters = int(num_epochs)
         res = self._job.run([self.mask.detach().numpy()], hy)

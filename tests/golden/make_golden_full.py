@@ -48,13 +48,24 @@ def _setup(threads=1):
     return mg
 
 
-def _closed_form_dev(sub_adj, sub_feat, sd, gt, pred_label, new_idx, mask0, ma_ref, fsig_ref, epochs, graph_mode=False):
+EARLY = 50   # second, early horizon: every target is still well conditioned there (round-off has not been amplified yet)
+
+
+def _closed_form_dev(sub_adj, sub_feat, sd, gt, pred_label, new_idx, mask0, ma_ref, fsig_ref, epochs, graph_mode=False, early=None):
+    """Deviation of the closed-form fp32 oracle from the reference on the same inputs (CPU vs CPU) at `epochs`
+    (and, with early = (masked_adj, feat_sig) of the reference after EARLY epochs, at that horizon too)."""
     from oracle import closed_form
     o = closed_form.ClosedFormOracle(sub_adj.astype(np.float32), sub_feat.astype(np.float32), sd, gt, pred_label, new_idx, mask0,
                                      graph_mode=graph_mode)
-    got = o.run(epochs)
-    fs = 1.0 / (1.0 + np.exp(-o.f.astype(np.float64)))
-    return float(np.abs(got - ma_ref).max()), float(np.abs(fs - fsig_ref).max())
+    sig = lambda f: 1.0 / (1.0 + np.exp(-f.astype(np.float64)))
+    out = []
+    done = 0
+    if early is not None:
+        got = o.run(EARLY)
+        done = EARLY
+        out += [float(np.abs(got - early[0]).max()), float(np.abs(sig(o.f) - early[1]).max())]
+    got = o.run(epochs - done)
+    return [float(np.abs(got - ma_ref).max()), float(np.abs(sig(o.f) - fsig_ref).max())] + out
 
 
 def _node_worker(job):
@@ -80,9 +91,14 @@ def _node_worker(job):
                                graph_idx=-1)
     out = []
     for t in targets:
-        torch.manual_seed(1000 + t)
         with mg.quiet():
             new_idx, sub_adj, sub_feat, sub_label, nb = ex.extract_neighborhood(t)
+            args.num_epochs = EARLY                      # same seed, same trajectory: its first EARLY epochs
+            torch.manual_seed(1000 + t)
+            ma_e = ex.explain(t)
+            fsig_e = torch.sigmoid(built[-1].feat_mask).detach().numpy()
+            args.num_epochs = epochs
+            torch.manual_seed(1000 + t)
             ma = ex.explain(t)
         mod = built[-1]
         del built[:]
@@ -91,10 +107,11 @@ def _node_worker(job):
         r, c = np.nonzero(np.triu(sub_adj, 1))
         fsig = torch.sigmoid(mod.feat_mask).detach().numpy()
         pred_label = np.argmax(cg["pred"][0][nb], axis=1)
-        cm, cf = _closed_form_dev(sub_adj, sub_feat, sd, int(sub_label[new_idx]), pred_label, int(new_idx), mod.mask0.numpy(), ma, fsig,
-                                  epochs)
+        cm, cf, cme, cfe = _closed_form_dev(sub_adj, sub_feat, sd, int(sub_label[new_idx]), pred_label, int(new_idx), mod.mask0.numpy(),
+                                            ma, fsig, epochs, early=(ma_e, fsig_e))
         out.append(dict(t=t, nb=nb.astype(np.int32), new=int(new_idx), vals=ma[r, c].astype(np.float32), fsig=fsig,
-                        loss=float(mod.loss_trace[-1]), maxm=float(mod.mask.detach().abs().max()), cm=cm, cf=cf))
+                        loss=float(mod.loss_trace[-1]), maxm=float(mod.mask.detach().abs().max()), cm=cm, cf=cf,
+                        vals_e=ma_e[r, c].astype(np.float32), fsig_e=fsig_e, cme=cme, cfe=cfe))
         os.remove(os.path.join(args.logdir, [f for f in os.listdir(args.logdir) if f.endswith(f"node_idx_{t}graph_idx_-1.npy")][0]))
     return out
 
@@ -117,11 +134,15 @@ def node_full(dataset, work, procs, epochs=300, limit=None):
                eoff=np.cumsum([0] + [len(r["vals"]) for r in res]).astype(np.int64),
                vals=np.concatenate([r["vals"] for r in res]), feat_sig=np.stack([r["fsig"] for r in res]).astype(np.float32),
                loss_last=np.asarray([r["loss"] for r in res], np.float32), max_abs_mask=np.asarray([r["maxm"] for r in res], np.float32),
-               cond_mask=np.asarray([r["cm"] for r in res], np.float32), cond_feat=np.asarray([r["cf"] for r in res], np.float32))
+               cond_mask=np.asarray([r["cm"] for r in res], np.float32), cond_feat=np.asarray([r["cf"] for r in res], np.float32),
+               early_epochs=np.int64(EARLY), vals_early=np.concatenate([r["vals_e"] for r in res]),
+               feat_sig_early=np.stack([r["fsig_e"] for r in res]).astype(np.float32),
+               cond_mask_early=np.asarray([r["cme"] for r in res], np.float32), cond_feat_early=np.asarray([r["cfe"] for r in res], np.float32))
     np.savez_compressed(os.path.join(HERE, dataset + "_full_explain.npz"), **out)
-    cm = out["cond_mask"]
+    cm, ce = out["cond_mask"], out["cond_mask_early"]
     print(f"{dataset}: {len(res)} targets in {time.time() - t0:.0f} s; max|M| = {out['max_abs_mask'].max():.2f}; "
-          f"closed-form vs reference: {np.sum(cm <= 2e-6)} targets <= 2e-6, {np.sum(cm > 1e-5)} > 1e-5 (max {cm.max():.2e})", flush=True)
+          f"closed-form vs reference: {np.sum(cm <= 2e-6)} targets <= 2e-6, {np.sum(cm > 1e-5)} > 1e-5 (max {cm.max():.2e}); "
+          f"after {EARLY} epochs: {np.sum(ce <= 2e-6)} <= 2e-6, {np.sum(ce > 1e-5)} > 1e-5 (max {ce.max():.2e})", flush=True)
 
 
 # ---------------------------------------------------------------- config 4 (graph mode) ----------------------------------------------------------------
@@ -150,17 +171,24 @@ def _graph_worker(job):
                            print_training=False, graph_mode=True, graph_idx=0)
     out = []
     for k, g in enumerate(gids):
-        torch.manual_seed(1000 + g)
         with mg.quiet():
+            args.num_epochs = EARLY
+            torch.manual_seed(1000 + g)
+            ma_e = ex.explain(node_idx=0, graph_idx=k, graph_mode=True)
+            fsig_e = torch.sigmoid(built[-1].feat_mask).detach().numpy()
+            args.num_epochs = epochs
+            torch.manual_seed(1000 + g)
             ma = ex.explain(node_idx=0, graph_idx=k, graph_mode=True)
         mod = built[-1]
         del built[:]
         assert not np.isnan(ma).any()
         fsig = torch.sigmoid(mod.feat_mask).detach().numpy()
-        cm, cf = _closed_form_dev(A_all[g], X_all[g], wts, int(y_all[g]), None, 0, mod.mask0.numpy(), ma, fsig, epochs, graph_mode=True)
+        cm, cf, cme, cfe = _closed_form_dev(A_all[g], X_all[g], wts, int(y_all[g]), None, 0, mod.mask0.numpy(), ma, fsig, epochs,
+                                            graph_mode=True, early=(ma_e, fsig_e))
         r, c = np.nonzero(np.triu(A_all[g], 1))
         out.append(dict(g=g, vals=ma[r, c].astype(np.float32), fsig=fsig, loss=float(mod.loss_trace[-1]),
-                        maxm=float(mod.mask.detach().abs().max()), cm=cm, cf=cf))
+                        maxm=float(mod.mask.detach().abs().max()), cm=cm, cf=cf, vals_e=ma_e[r, c].astype(np.float32), fsig_e=fsig_e,
+                        cme=cme, cfe=cfe))
     return out
 
 
@@ -186,13 +214,17 @@ def config4(work, procs, epochs=300, num=64, total=4337):
                eoff=np.cumsum([0] + [len(r["vals"]) for r in res]).astype(np.int64), vals=np.concatenate([r["vals"] for r in res]),
                feat_sig=np.stack([r["fsig"] for r in res]).astype(np.float32), loss_last=np.asarray([r["loss"] for r in res], np.float32),
                max_abs_mask=np.asarray([r["maxm"] for r in res], np.float32), cond_mask=np.asarray([r["cm"] for r in res], np.float32),
-               cond_feat=np.asarray([r["cf"] for r in res], np.float32))
+               cond_feat=np.asarray([r["cf"] for r in res], np.float32),
+               early_epochs=np.int64(EARLY), vals_early=np.concatenate([r["vals_e"] for r in res]),
+               feat_sig_early=np.stack([r["fsig_e"] for r in res]).astype(np.float32),
+               cond_mask_early=np.asarray([r["cme"] for r in res], np.float32), cond_feat_early=np.asarray([r["cfe"] for r in res], np.float32))
     for k, v in wts.items():
         out["w:" + k] = v
     np.savez_compressed(os.path.join(HERE, "config4_explain.npz"), **out)
-    cm = out["cond_mask"]
+    cm, ce = out["cond_mask"], out["cond_mask_early"]
     print(f"config4: {len(res)} graphs in {time.time() - t0:.0f} s; max|M| = {out['max_abs_mask'].max():.2f}; closed-form vs reference: "
-          f"{np.sum(cm <= 2e-6)} <= 2e-6, {np.sum(cm > 1e-5)} > 1e-5 (max {cm.max():.2e})", flush=True)
+          f"{np.sum(cm <= 2e-6)} <= 2e-6, {np.sum(cm > 1e-5)} > 1e-5 (max {cm.max():.2e}); after {EARLY} epochs: "
+          f"{np.sum(ce <= 2e-6)} <= 2e-6, {np.sum(ce > 1e-5)} > 1e-5 (max {ce.max():.2e})", flush=True)
 
 
 # ---------------------------------------------------------------- config 5 (BA-House x100k) ----------------------------------------------------------------

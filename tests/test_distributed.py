@@ -52,3 +52,57 @@ def test_two_rank_sharding_equals_single_process(tmp_path):
         s = Subgraph(A, X, int(lab[new]), new, yhat, helpers.seeded_mask0(int(t), len(nb)).numpy())
         solo = emu_job([s], ck["sd"]).run([s.mask0], Hyper(num_iters=6)).masked_adj[0]
         assert np.array_equal(r0[str(t)], solo) and np.array_equal(r1[str(t)], solo)   # sharding changes no bit
+
+
+def _api_worker(rank, world, port, out_dir):
+    """The reference-shaped API under torch.distributed: Explainer.explain_nodes shards the targets over the ranks
+    (parallel.lpt_shards on n^2) and returns the FULL list on every rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import argparse
+    from emu.emu_engine import emu_library
+    from gnn_model_explainer_amd import models
+    from gnn_model_explainer_amd.explainer import explain
+    explain._ENGINE.update(lib=emu_library(), device="cpu")
+    ck = helpers.load_ckpt("syn1")
+    args = argparse.Namespace(logdir=out_dir, ckptdir=out_dir, dataset="syn1", bmname=None, opt="adam", opt_scheduler="none",
+                              lr=0.1, num_epochs=4, hidden_dim=20, output_dim=20, num_gc_layers=3, method="base", name_suffix="",
+                              explainer_suffix="r%d" % rank, graph_idx=-1, mask_act="sigmoid", mask_bias=False, bn=False, bias=True, gpu=True)
+    model = models.GcnEncoderNode(10, 20, 20, 4, 3, bn=False, args=args)
+    model.load_state_dict({k: torch.tensor(v) for k, v in ck["sd"].items()})
+    ex = explain.Explainer(model, ck["adj"][None].astype(np.float64), ck["feat"][None].astype(np.float64), ck["label"][None],
+                           ck["pred"][None], None, args, writer=None, print_training=False, graph_mode=False, graph_idx=-1)
+    torch.manual_seed(11)
+    out = ex.explain_nodes([302, 555, 309, 640, 699], args)
+    np.savez(os.path.join(out_dir, f"api_rank{rank}.npz"), *out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_explainer_api_shards_targets_over_ranks(tmp_path):
+    world, port = 2, 30131 + os.getpid() % 500
+    mp.spawn(_api_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "api_rank0.npz"), np.load(tmp_path / "api_rank1.npz")
+    # the single-process answer with the same RNG stream
+    import argparse
+    from emu.emu_engine import emu_library
+    from gnn_model_explainer_amd import models
+    from gnn_model_explainer_amd.explainer import explain
+    explain._ENGINE.update(lib=emu_library(), device="cpu")
+    try:
+        ck = helpers.load_ckpt("syn1")
+        args = argparse.Namespace(logdir=str(tmp_path), ckptdir=str(tmp_path), dataset="syn1", bmname=None, opt="adam",
+                                  opt_scheduler="none", lr=0.1, num_epochs=4, hidden_dim=20, output_dim=20, num_gc_layers=3,
+                                  method="base", name_suffix="", explainer_suffix="solo", graph_idx=-1, mask_act="sigmoid",
+                                  mask_bias=False, bn=False, bias=True, gpu=True)
+        model = models.GcnEncoderNode(10, 20, 20, 4, 3, bn=False, args=args)
+        model.load_state_dict({k: torch.tensor(v) for k, v in ck["sd"].items()})
+        ex = explain.Explainer(model, ck["adj"][None].astype(np.float64), ck["feat"][None].astype(np.float64), ck["label"][None],
+                               ck["pred"][None], None, args, writer=None, print_training=False, graph_mode=False, graph_idx=-1)
+        torch.manual_seed(11)
+        solo = ex.explain_nodes([302, 555, 309, 640, 699], args)
+    finally:
+        explain._ENGINE.update(lib=None, device=None)
+    assert len(r0.files) == 5
+    for k, want in enumerate(solo):
+        assert np.array_equal(r0[f"arr_{k}"], want) and np.array_equal(r1[f"arr_{k}"], want)      # sharding changes no bit

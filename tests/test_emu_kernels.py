@@ -1,13 +1,38 @@
-"""CPU-only: the product's kernel + host source, compiled against tests/emu (a HIP emulator), must agree
-with the oracle stage by stage and over short optimisation runs.  The GPU parity tests proper are in
-test_gpu_parity.py; this file exists because the build container has no GPU."""
+"""The product's kernel + host source against the oracle, stage by stage and over short optimisation runs - every case
+on TWO backends through one body:
+  * "emu": the SAME sources compiled against tests/emu (a HIP emulator), because the build container has no GPU
+    (`-m "not gpu"`);
+  * "gpu": libgnnx_hip.so on a real MI355X through the C ABI (`-m gpu`) - the emulator runs waves as sequential
+    fibers and cannot see a missing wave_sync, a DPP shift that differs on hardware, a spill miscompile or an LDS race,
+    so every edge case (hub rows split over slots, > 512 row slots, edgeless / isolated targets, weighted adjacency with
+    self-loops, the mixed launch, ...) has its hardware twin here."""
 import numpy as np
 import pytest
 
 import helpers
-from emu.emu_engine import emu_job
+from gnn_model_explainer_amd import engine
 from gnn_model_explainer_amd.engine import Hyper, Subgraph
 from oracle import closed_form
+
+
+class _Backend:
+    def __init__(self, name):
+        self.name = name
+        if name == "emu":
+            from emu.emu_engine import emu_library
+            self.lib, self.device = emu_library(), "cpu"
+        else:
+            import torch
+            assert torch.cuda.is_available(), "the gpu twins need an MI355X"
+            self.lib, self.device = engine.get_library(), "cuda:0"
+
+    def job(self, subgraphs, state_dict, graph_mode=False, analyze=True):
+        return engine.MaskOptimJob(subgraphs, state_dict, graph_mode=graph_mode, device=self.device, lib=self.lib, analyze=analyze)
+
+
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def be(request):
+    return _Backend(request.param)
 
 
 def _node_case(name, t):
@@ -20,9 +45,9 @@ def _node_case(name, t):
 
 
 @pytest.mark.parametrize("name,t", [("syn1", 302), ("syn4", 511), ("syn1", 309)])
-def test_forward_probs_and_masked_adj(name, t):
+def test_forward_probs_and_masked_adj(be, name, t):
     ck, gx, sg = _node_case(name, t)
-    job = emu_job([sg], ck["sd"])
+    job = be.job([sg], ck["sd"])
     probs, ma = job.forward([sg.mask0])
     o = closed_form.ClosedFormOracle(sg.adj, sg.feat, ck["sd"], sg.gt_label, sg.pred_label, sg.target_row, sg.mask0)
     o.iterate()
@@ -31,9 +56,9 @@ def test_forward_probs_and_masked_adj(name, t):
 
 
 @pytest.mark.parametrize("name,t,iters", [("syn1", 302, 12), ("syn4", 511, 12), ("syn1", 309, 6)])
-def test_short_run_matches_closed_form(name, t, iters):
+def test_short_run_matches_closed_form(be, name, t, iters):
     ck, gx, sg = _node_case(name, t)
-    job = emu_job([sg], ck["sd"])
+    job = be.job([sg], ck["sd"])
     hy = Hyper(num_iters=iters, record_loss=True)
     res = job.run([sg.mask0], hy)
     o = closed_form.ClosedFormOracle(sg.adj, sg.feat, ck["sd"], sg.gt_label, sg.pred_label, sg.target_row, sg.mask0)
@@ -50,12 +75,12 @@ def test_short_run_matches_closed_form(name, t, iters):
     assert np.allclose(got[:, 4], tr[:, 5], rtol=1e-6)
 
 
-def test_batch_of_ragged_targets_matches_individual_runs():
+def test_batch_of_ragged_targets_matches_individual_runs(be):
     ck, gx, a = _node_case("syn1", 302)
     _, _, b = _node_case("syn1", 309)
     ck4, _, c = _node_case("syn1", 302)
     hy = Hyper(num_iters=4)
-    job = emu_job([a, b, c], ck["sd"])
+    job = be.job([a, b, c], ck["sd"])
     res = job.run([a.mask0, b.mask0, c.mask0], hy)
     for i, s in enumerate((a, b, c)):
         o = closed_form.ClosedFormOracle(s.adj, s.feat, ck["sd"], s.gt_label, s.pred_label, s.target_row, s.mask0)
@@ -63,13 +88,13 @@ def test_batch_of_ragged_targets_matches_individual_runs():
     assert np.array_equal(res.masked_adj[0], res.masked_adj[2])
 
 
-def test_graph_mode_short_run_matches_closed_form():
+def test_graph_mode_short_run_matches_closed_form(be):
     z = np.load(helpers.GOLDEN + "/graphmode_explain.npz")
     sd = {k[2:]: z[k] for k in z.files if k.startswith("w:")}
     g = 4
     A, X, lab = z["adj"][g], z["feat"][g], int(z["label"][g])
     m0 = helpers.seeded_mask0(g, A.shape[0]).numpy()
-    job = emu_job([Subgraph(A, X, lab, 0, None, m0)], sd, graph_mode=True)
+    job = be.job([Subgraph(A, X, lab, 0, None, m0)], sd, graph_mode=True)
     res = job.run([m0], Hyper(num_iters=5, record_loss=True))
     o = closed_form.ClosedFormOracle(A, X, sd, lab, None, 0, m0, graph_mode=True)
     want = o.run(5)
@@ -78,20 +103,20 @@ def test_graph_mode_short_run_matches_closed_form():
     assert np.allclose(res.loss[0][:, :5].sum(1), np.asarray(o.trace)[:, 0], rtol=1e-5)
 
 
-def test_outputs_are_bitwise_symmetric_and_zero_off_edges():
+def test_outputs_are_bitwise_symmetric_and_zero_off_edges(be):
     ck, gx, sg = _node_case("syn1", 309)       # n = 48 -> 2x2 tiles: diagonal and off-diagonal tile pairs
-    res = emu_job([sg], ck["sd"]).run([sg.mask0], Hyper(num_iters=5))
+    res = be.job([sg], ck["sd"]).run([sg.mask0], Hyper(num_iters=5))
     ma = res.masked_adj[0]
     assert np.array_equal(ma, ma.T) and np.all(ma[sg.adj == 0] == 0) and np.all(np.diag(ma) == 0)
 
 
 @pytest.mark.parametrize("sparse", [False, True])
-def test_large_target_many_row_blocks(sparse):
+def test_large_target_many_row_blocks(be, sparse):
     """n = 310 -> ld = 320: 10 row blocks.  Dense streaming kernels (55 tile pairs, per-block partials summed over 10
     slots) and the sparse on-chip-resident kernel (1432 undirected edges, 3 row blocks per wave)."""
     ck, gx, sg = _node_case("syn1", 300)
     assert sg.adj.shape[0] == 310
-    res = emu_job([sg], ck["sd"], analyze=sparse).run([sg.mask0], Hyper(num_iters=2))
+    res = be.job([sg], ck["sd"], analyze=sparse).run([sg.mask0], Hyper(num_iters=2))
     o = closed_form.ClosedFormOracle(sg.adj, sg.feat, ck["sd"], sg.gt_label, sg.pred_label, sg.target_row, sg.mask0)
     want = o.run(2)
     edges = sg.adj != 0
@@ -105,17 +130,17 @@ def test_large_target_many_row_blocks(sparse):
 
 
 @pytest.mark.parametrize("analyze", [False, True])
-def test_resident_kernel_matches_streaming_and_reference(analyze):
+def test_resident_kernel_matches_streaming_and_reference(be, analyze):
     """Single-tile targets (n <= 32) run on chip: in the dense resident kernel k_resident<1> (plan not analysed) or in the
     64-thread class of the sparse resident kernel; an all-resident batch launches no streaming kernel at all.  Both must
     agree with the streaming path and with the closed form."""
     ck, gx = helpers.load_ckpt("syn4"), helpers.load_explain("syn4")
     subs = [_node_case("syn4", t)[2] for t in (511, 870)]
     iters = 40
-    job = emu_job(subs, ck["sd"], analyze=analyze)
+    job = be.job(subs, ck["sd"], analyze=analyze)
     assert list(job.route()) == ([6, 6] if analyze else [1, 1])
     res = job.run([s.mask0 for s in subs], Hyper(num_iters=iters, use_resident=True))
-    stream = emu_job(subs, ck["sd"]).run([s.mask0 for s in subs], Hyper(num_iters=iters, use_resident=False))
+    stream = be.job(subs, ck["sd"]).run([s.mask0 for s in subs], Hyper(num_iters=iters, use_resident=False))
     for a, b, fa, fb in zip(res.masked_adj, stream.masked_adj, res.feat_mask, stream.feat_mask):
         assert np.abs(a - b).max() < 1e-6 and np.abs(fa - fb).max() < 1e-5
         assert np.array_equal(a, a.T)
@@ -127,47 +152,45 @@ def test_resident_kernel_matches_streaming_and_reference(analyze):
 
 
 @pytest.mark.parametrize("analyze", [False, True])
-def test_resident_kernel_full_run_vs_golden(analyze):
+def test_resident_kernel_full_run_vs_golden(be, analyze):
     ck, gx, sg = _node_case("syn1", 302)
-    res = emu_job([sg], ck["sd"], analyze=analyze).run([sg.mask0], Hyper(num_iters=300))
+    res = be.job([sg], ck["sd"], analyze=analyze).run([sg.mask0], Hyper(num_iters=300))
     rc = gx["302:edge_rc"]
     assert np.abs(res.masked_adj[0][rc[:, 0], rc[:, 1]] - gx["302:masked_adj_edges"]).max() <= 1e-5
     assert np.abs(1 / (1 + np.exp(-res.feat_mask[0])) - gx["302:feat_mask_sigmoid"]).max() <= 1e-5
 
 
-def test_two_block_resident_kernel_vs_streaming_and_golden():
+def test_two_block_resident_kernel_vs_streaming_and_golden(be):
     """syn1 target 309 (n = 48 -> 2 row blocks: diagonal and off-diagonal tile pairs, mirror entries in registers)
     through the resident kernel: 300 iterations against the reference's golden mask, and against the streaming path."""
     ck, gx, sg = _node_case("syn1", 309)
-    res = emu_job([sg], ck["sd"], analyze=False).run([sg.mask0], Hyper(num_iters=300, use_resident=True))
+    res = be.job([sg], ck["sd"], analyze=False).run([sg.mask0], Hyper(num_iters=300, use_resident=True))
     rc = gx["309:edge_rc"]
     assert np.abs(res.masked_adj[0][rc[:, 0], rc[:, 1]] - gx["309:masked_adj_edges"]).max() <= 1e-5
     assert np.abs(1 / (1 + np.exp(-res.feat_mask[0])) - gx["309:feat_mask_sigmoid"]).max() <= 1e-5
-    short = emu_job([sg], ck["sd"], analyze=False).run([sg.mask0], Hyper(num_iters=20, use_resident=True))
-    stream = emu_job([sg], ck["sd"]).run([sg.mask0], Hyper(num_iters=20, use_resident=False))
+    short = be.job([sg], ck["sd"], analyze=False).run([sg.mask0], Hyper(num_iters=20, use_resident=True))
+    stream = be.job([sg], ck["sd"]).run([sg.mask0], Hyper(num_iters=20, use_resident=False))
     assert np.abs(short.masked_adj[0] - stream.masked_adj[0]).max() < 1e-6
     assert np.abs(short.mask[0] - stream.mask[0]).max() < 1e-5
     assert np.array_equal(short.masked_adj[0], short.masked_adj[0].T)
 
 
-def test_device_side_packing_equals_host_packing():
+def test_device_side_packing_equals_host_packing(be):
     """gnnx_pack_csr (sub-graphs sliced from CSR on the device) must build exactly the buffers the host packer builds."""
     import torch
-    from emu.emu_engine import emu_library
-    from gnn_model_explainer_amd import engine
     from gnn_model_explainer_amd.utils.graph_utils import KHopIndex
     ck = helpers.load_ckpt("syn1")
     idx = KHopIndex((ck["num_nodes"], ck["edges"]), 3)
     targets = [302, 309, 555, 300]
     nbs = idx.neighbors_batch(targets)
     rows = [int(np.searchsorted(nb, v)) for v, nb in zip(targets, nbs)]
-    graph = engine.device_graph(idx.csr, ck["feat"], ck["pred"], device="cpu")
+    graph = engine.device_graph(idx.csr, ck["feat"], ck["pred"], device=be.device)
     assert graph.binary
-    dev = engine.MaskOptimJob.from_csr(graph, nbs, rows, ck["label"][targets], ck["sd"], lib=emu_library())
+    dev = engine.MaskOptimJob.from_csr(graph, nbs, rows, ck["label"][targets], ck["sd"], lib=be.lib)
     subs = [Subgraph(ck["adj"][np.ix_(nb, nb)], ck["feat"][nb], int(ck["label"][t]), r, np.argmax(ck["pred"][nb], 1), None)
             for t, nb, r in zip(targets, nbs, rows)]
-    host = emu_job(subs, ck["sd"])
-    assert torch.equal(dev.A, host.A) and torch.equal(dev.X, host.X) and torch.equal(dev.yhat, host.yhat)
+    host = be.job(subs, ck["sd"])
+    assert torch.equal(dev.A.cpu(), host.A.cpu()) and torch.equal(dev.X.cpu(), host.X.cpu()) and torch.equal(dev.yhat.cpu(), host.yhat.cpu())
     for a, s in zip(dev.adjacency(), subs):
         assert np.array_equal(a, s.adj)
 
@@ -188,7 +211,7 @@ def test_device_side_packing_equals_host_packing():
     (14, 20, 20, 2, 40, True, "sparse"),      # graph mode in the sparse resident kernel (three full layers, max-pool head)
     (3, 9, 17, 5, 70, True, "sparse"),        # ... odd widths, O > H
 ])
-def test_generic_shapes_match_closed_form(D, H, O, C, n, graph_mode, path):
+def test_generic_shapes_match_closed_form(be, D, H, O, C, n, graph_mode, path):
     rng = np.random.default_rng(D * 1000 + H * 10 + n)
     sd = helpers.random_model(rng, D, H, O, C)
     A, X = helpers.random_graph(rng, n, D)
@@ -197,7 +220,7 @@ def test_generic_shapes_match_closed_form(D, H, O, C, n, graph_mode, path):
     yhat = None if graph_mode else rng.integers(0, C, n)
     sg = Subgraph(A, X, gt, 0 if graph_mode else t, yhat, m0)
     iters = 4
-    job = emu_job([sg], sd, graph_mode=graph_mode, analyze=(path == "sparse"))
+    job = be.job([sg], sd, graph_mode=graph_mode, analyze=(path == "sparse"))
     res = job.run([m0], Hyper(num_iters=iters, use_resident=(path != "stream")))
     o = closed_form.ClosedFormOracle(A, X, sd, gt, yhat, 0 if graph_mode else t, m0, graph_mode=graph_mode)
     want = o.run(iters)
@@ -209,13 +232,13 @@ def test_generic_shapes_match_closed_form(D, H, O, C, n, graph_mode, path):
         assert np.array_equal(res.mask[0][~live], m0[~live])
 
 
-def test_sparse_resident_kernel_full_run_vs_golden():
+def test_sparse_resident_kernel_full_run_vs_golden(be):
     """syn1 targets 555 (n = 104) and 309 (n = 48) as one batch with 302 (n = 6, dense single-tile kernel): 300
     iterations in the sparse on-chip-resident kernel against the reference's golden masks."""
     ck, gx = helpers.load_ckpt("syn1"), helpers.load_explain("syn1")
     targets = (555, 309, 302)
     subs = [_node_case("syn1", t)[2] for t in targets]
-    res = emu_job(subs, ck["sd"]).run([s.mask0 for s in subs], Hyper(num_iters=300))
+    res = be.job(subs, ck["sd"]).run([s.mask0 for s in subs], Hyper(num_iters=300))
     for i, t in enumerate(targets):
         rc = gx[f"{t}:edge_rc"]
         assert np.abs(res.masked_adj[i][rc[:, 0], rc[:, 1]] - gx[f"{t}:masked_adj_edges"]).max() <= 1e-5
@@ -224,7 +247,7 @@ def test_sparse_resident_kernel_full_run_vs_golden():
         assert np.all(res.masked_adj[i][subs[i].adj == 0] == 0)
 
 
-def test_plan_routing_by_size_and_edge_count():
+def test_plan_routing_by_size_and_edge_count(be):
     """gnnx_plan_analyze routes every target by what it finds in the packed adjacency (gnnx_get_route): targets whose edge
     state fits a CU -> sparse resident kernel in the smallest size class that holds them (6: 64 threads, n <= 32;
     5: 256 threads, n <= 128; 4: 1024 threads, n <= 512; a batch that needs class 4 uses only it and the dense single-tile
@@ -238,22 +261,22 @@ def test_plan_routing_by_size_and_edge_count():
 
     subs = [sub(20, 0.2), sub(60, 0.1), sub(200, 0.02), sub(120, 0.5)]
     assert (subs[3].adj != 0).sum() // 2 > 2048
-    route = list(emu_job(subs, sd).route())
+    route = list(be.job(subs, sd).route())
     # a 512-thread target in the batch: the mid-size target joins its class, the single-tile one stays in the 64-thread
     # class and shares the launch (k_sparse_resident_mixed)
     assert route == [6, 8, 8, 0]
-    assert list(emu_job(subs[:2], sd).route()) == [6, 5]
-    assert list(emu_job(subs, sd, analyze=False).route()) == [1, 0, 0, 0]
+    assert list(be.job(subs[:2], sd).route()) == [6, 5]
+    assert list(be.job(subs, sd, analyze=False).route()) == [1, 0, 0, 0]
     small = [sub(20, 0.2), sub(60, 0.1)]
-    assert list(emu_job(small, sd, analyze=False).route()) == [1, 2]      # all-small batch: dense resident kernels
-    res = emu_job(subs, sd).run([s.mask0 for s in subs], Hyper(num_iters=2))
+    assert list(be.job(small, sd, analyze=False).route()) == [1, 2]      # all-small batch: dense resident kernels
+    res = be.job(subs, sd).run([s.mask0 for s in subs], Hyper(num_iters=2))
     for s_, ma in zip(subs, res.masked_adj):
         o = closed_form.ClosedFormOracle(s_.adj, s_.feat, sd, s_.gt_label, s_.pred_label, s_.target_row, s_.mask0)
         assert np.abs(ma - o.run(2)).max() < 5e-6
 
 
 @pytest.mark.parametrize("n", [24, 70, 200])
-def test_sparse_kernel_weighted_adjacency_and_self_loops(n):
+def test_sparse_kernel_weighted_adjacency_and_self_loops(be, n):
     """Non-binary symmetric edge weights and a non-zero diagonal (masked out by the reference, explain.py:618, 678)
     through the three size classes of the sparse resident kernel."""
     rng = np.random.default_rng(n)
@@ -264,7 +287,7 @@ def test_sparse_kernel_weighted_adjacency_and_self_loops(n):
     A = A + A.T + np.diag(rng.uniform(0.5, 1.5, n).astype(np.float32))
     m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
     sg = Subgraph(A, X, 2, 5, rng.integers(0, 4, n), m0)
-    job = emu_job([sg], sd)
+    job = be.job([sg], sd)
     assert job.route()[0] in {24: (6,), 70: (5,), 200: (4, 8)}[n]
     res = job.run([m0], Hyper(num_iters=5))
     o = closed_form.ClosedFormOracle(A, X, sd, 2, sg.pred_label, 5, m0)
@@ -275,7 +298,7 @@ def test_sparse_kernel_weighted_adjacency_and_self_loops(n):
     assert np.all(np.diag(res.masked_adj[0]) == 0)
 
 
-def test_large_target_sparse_kernel_with_split_hub_rows():
+def test_large_target_sparse_kernel_with_split_hub_rows(be):
     """n = 600 (beyond the LDS-resident classes): k_sparse_large keeps the edge state in LDS and the row arrays in the
     workspace, updates M / m / v in place on the edges and splits a 150-neighbour hub row over three 64-entry slots."""
     rng = np.random.default_rng(3)
@@ -290,7 +313,7 @@ def test_large_target_sparse_kernel_with_split_hub_rows():
     m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
     t = int(idx[0])                       # a target adjacent to the hub: the hub row is in both row sets
     sg = Subgraph(A, X, 1, t, rng.integers(0, 4, n), m0)
-    job = emu_job([sg], sd)
+    job = be.job([sg], sd)
     assert list(job.route()) == [7]
     res = job.run([m0], Hyper(num_iters=4))
     o = closed_form.ClosedFormOracle(A, X, sd, 1, sg.pred_label, t, m0)
@@ -300,11 +323,11 @@ def test_large_target_sparse_kernel_with_split_hub_rows():
     assert np.abs(res.mask[0] - o.M)[live].max() < 5e-5 and np.abs(res.feat_mask[0] - o.f).max() < 5e-5
     assert np.array_equal(res.mask[0][~live], m0[~live])
     assert np.array_equal(res.masked_adj[0], res.masked_adj[0].T)
-    dense = emu_job([sg], sd, analyze=False).run([m0], Hyper(num_iters=4))      # dense streaming kernels
+    dense = be.job([sg], sd, analyze=False).run([m0], Hyper(num_iters=4))      # dense streaming kernels
     assert np.abs(res.masked_adj[0] - dense.masked_adj[0]).max() < 2e-6
 
 
-def test_large_target_more_than_512_row_slots():
+def test_large_target_more_than_512_row_slots(be):
     """A target next to a 700-neighbour hub (n = 1400): more than 512 row slots within two hops, so k_sparse_large walks
     its slot records in two rounds; the hub row takes 11 slots of 64 entries."""
     rng = np.random.default_rng(5)
@@ -319,7 +342,7 @@ def test_large_target_more_than_512_row_slots():
     m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
     t = int(idx[0])
     sg = Subgraph(A, X, 1, t, rng.integers(0, 4, n), m0)
-    job = emu_job([sg], sd)
+    job = be.job([sg], sd)
     assert list(job.route()) == [7]
     res = job.run([m0], Hyper(num_iters=3))
     o = closed_form.ClosedFormOracle(A, X, sd, 1, sg.pred_label, t, m0)
@@ -331,7 +354,7 @@ def test_large_target_more_than_512_row_slots():
 
 
 @pytest.mark.parametrize("case,n", [("edgeless", 40), ("isolated target", 60), ("isolated target", 700)])
-def test_sparse_kernels_degenerate_graphs(case, n):
+def test_sparse_kernels_degenerate_graphs(be, case, n):
     """No edge at all / a target without neighbours (its row of every layer is the bias direction, the edge masks only
     get their regulariser gradients): the sparse kernels must stay finite and agree with the closed form."""
     rng = np.random.default_rng(n)
@@ -344,7 +367,7 @@ def test_sparse_kernels_degenerate_graphs(case, n):
         A[:, 5] = 0
     m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
     sg = Subgraph(A, X, 1, 5, rng.integers(0, 4, n), m0)
-    job = emu_job([sg], sd)
+    job = be.job([sg], sd)
     assert job.route()[0] >= 4
     res = job.run([m0], Hyper(num_iters=3))
     o = closed_form.ClosedFormOracle(A, X, sd, 1, sg.pred_label, 5, m0)
@@ -356,7 +379,7 @@ def test_sparse_kernels_degenerate_graphs(case, n):
         assert np.abs(res.mask[0] - o.M)[live].max() < 5e-5
 
 
-def test_mixed_launch_of_large_and_single_tile_targets():
+def test_mixed_launch_of_large_and_single_tile_targets(be):
     """One launch for a 512-thread target and nine single-tile targets (k_sparse_resident_mixed: six single-tile targets
     per workgroup, one per wave; the second such workgroup is half empty): every target must match its solo run bit
     for bit (same code path, other workgroup shape) and the closed form."""
@@ -369,13 +392,83 @@ def test_mixed_launch_of_large_and_single_tile_targets():
         return Subgraph(A, X, 1, t, rng.integers(0, 4, n), m0)
 
     subs = [sub(200, 0.02, 3)] + [sub(int(rng.integers(6, 33)), 0.2, 2) for _ in range(9)]
-    job = emu_job(subs, sd)
+    job = be.job(subs, sd)
     assert list(job.route()) == [8] + [6] * 9
     hy = Hyper(num_iters=4)
     res = job.run([s.mask0 for s in subs], hy)
     for i, s in enumerate(subs):
         o = closed_form.ClosedFormOracle(s.adj, s.feat, sd, s.gt_label, s.pred_label, s.target_row, s.mask0)
         assert np.abs(res.masked_adj[i] - o.run(4)).max() < 5e-6
-        solo = emu_job([s], sd).run([s.mask0], hy)
+        solo = be.job([s], sd).run([s.mask0], hy)
         assert np.array_equal(solo.masked_adj[0], res.masked_adj[i])
         assert np.array_equal(solo.feat_mask[0], res.feat_mask[i])
+
+
+def test_device_khop_equals_reference_neighbor_lists(be):
+    """gnnx_khop vs the neighbour lists of the reference's own neighborhoods / extract_neighborhood (stored by
+    tests/golden/make_golden_full.py for every syn1 motif node) - bit for bit, including node_idx_new - and vs the host
+    walk sets on nodes of the BA part (hubs, larger sets)."""
+    from gnn_model_explainer_amd.utils.graph_utils import KHopIndex
+    ck = helpers.load_ckpt("syn1")
+    z = np.load(helpers.GOLDEN + "/syn1_full_explain.npz")
+    idx = KHopIndex((ck["num_nodes"], ck["edges"]), 3)
+    graph = engine.device_graph(idx.csr, ck["feat"], ck["pred"], device=be.device)
+    sel = np.arange(0, len(z["targets"]), 1 if be.name == "gpu" else 16)
+    targets = z["targets"][sel]
+    dn = engine.khop_device(graph, targets, 3, lib=be.lib)
+    for k, (s, nb) in enumerate(zip(sel, dn.lists())):
+        assert np.array_equal(nb, z["nb_flat"][z["nb_off"][s]:z["nb_off"][s + 1]])
+        assert dn.rows[k] == z["node_idx_new"][s] and dn.sizes[k] == len(nb)
+    more = np.asarray([0, 1, 17, 150, 299])
+    dn = engine.khop_device(graph, more, 3, lib=be.lib)
+    for v, nb, row in zip(more, dn.lists(), dn.rows):
+        want = idx.neighbors(int(v))
+        assert np.array_equal(nb, want) and row == np.searchsorted(want, v)
+    for hops in (1, 2):          # other depths; with one hop a node is not in its own set
+        dn = engine.khop_device(graph, more, hops, lib=be.lib)
+        for v, nb, row in zip(more, dn.lists(), dn.rows):
+            want = KHopIndex(idx.csr, hops).neighbors(int(v))
+            assert np.array_equal(nb, want) and row == (np.searchsorted(want, v) if v in want else -1)
+
+
+def test_device_khop_isolated_node_has_empty_set(be):
+    """Reference semantics (utils/graph_utils.py:152-157): no explicit self term, so an isolated node has an EMPTY set."""
+    import scipy.sparse as sp
+    n = 70
+    rng = np.random.default_rng(1)
+    A, X = helpers.random_graph(rng, n, 4, density=0.05)
+    A[5, :] = 0
+    A[:, 5] = 0
+    graph = engine.device_graph(sp.csr_matrix(A), X, None, device=be.device)
+    dn = engine.khop_device(graph, np.asarray([5, 6]), 3, lib=be.lib)
+    assert dn.sizes[0] == 0 and dn.rows[0] == -1 and dn.sizes[1] > 0
+
+
+def test_raw_mask_stream_and_edge_lists(be):
+    """gnnx_scatter_masks spreads the host's RNG stream (one contiguous n x n draw per target) exactly like the host
+    packer; gnnx_gather_edges returns exactly the non-zero entries of the dense result, in row-major order."""
+    from gnn_model_explainer_amd.utils.graph_utils import KHopIndex
+    ck = helpers.load_ckpt("syn1")
+    idx = KHopIndex((ck["num_nodes"], ck["edges"]), 3)
+    targets = np.asarray([302, 309, 555, 300, 699])
+    graph = engine.device_graph(idx.csr, ck["feat"], ck["pred"], device=be.device)
+    dn = engine.khop_device(graph, targets, 3, lib=be.lib)
+    job = engine.MaskOptimJob.from_csr(graph, dn, None, ck["label"][targets], ck["sd"], lib=be.lib)
+    job.set_masks_raw(engine.init_edge_masks_raw(dn.sizes, seeds=1000 + targets))
+    M = job.M.cpu().numpy()
+    for v, n, t in zip(job._square_views(M), dn.sizes, targets):
+        assert np.array_equal(v[:n, :n], helpers.seeded_mask0(int(t), int(n)).numpy()) and not v[n:].any() and not v[:, n:].any()
+    hy = Hyper(num_iters=3)
+    job.launch(hy)
+    dense, em = job.fetch(hy), job.fetch_edges(with_mask=True)
+    for k in range(len(targets)):
+        assert np.array_equal(em.dense(k, np.float32), dense.masked_adj[k])
+        a, b = em.eoff[k], em.eoff[k + 1]
+        r, c = em.rc[a:b, 0], em.rc[a:b, 1]
+        rr, cc = np.nonzero(np.triu(job.adjacency()[k], 1))
+        assert np.array_equal(r, rr) and np.array_equal(c, cc)
+        assert np.array_equal(em.mask_rc[a:b, 0], dense.mask[k][r, c]) and np.array_equal(em.mask_rc[a:b, 1], dense.mask[k][c, r])
+    job.set_masks_raw_resident()            # a second run from the resident stream reproduces the first bit for bit
+    job.launch(hy)
+    again = job.fetch_edges()
+    assert np.array_equal(again.masked_adj, em.masked_adj) and np.array_equal(again.feat_mask, em.feat_mask)
