@@ -97,6 +97,7 @@ __host__ __device__ inline bool sparse_fits(int nt, int n, int ld, int nnz, int 
 // a lane's row slot in one row set: the row (valid when first), its chunk of entries, the split bookkeeping
 struct RowSlot {
     int row, e0, e1, nsplit, wsplit;
+    int rem;  // slots from this one to the last slot of its row, itself included (1: nothing to add)
     bool first, wave_active;
 };
 
@@ -107,6 +108,7 @@ struct SparseFixed {
     float sr3;
     int nnz, eup, bad;
     int set_rows[2], set_slots[2];
+    int set_chunk[2];  // entries per row slot of the set: the smallest of {4, 8, 16} (8, 16 for set A) whose slots fit the class
     int erow[96];  // graph mode: arg-max row of every pooled column
 };
 
@@ -319,26 +321,27 @@ __device__ __forceinline__ float sum_lanes_0_31(float v) {
     return bcast_first(r + __shfl_xor(r, 16));
 }
 
+// Rows split over several slots (adjacent lanes of one 16-lane DPP row, same column half): a segmented suffix sum in
+// log2(16) = 4 DPP steps - after the steps S = 1, 2, 4, 8 the row's FIRST slot holds the sum of all its slots (lane l adds
+// lane l + S while that lane still belongs to its row: S < rem).  wsplit = the wave's longest split (uniform): later
+// steps are skipped.  Fixed order, no LDS traffic.
 template <int NQ, int S>
-__device__ __forceinline__ void sparse_combine_step(float (&acc)[NQ], bool first, int nsplit, int wsplit) {
+__device__ __forceinline__ void sparse_combine_step(float (&acc)[NQ], int rem, int wsplit) {
     if constexpr (S < SP_MAX_SPLIT) {
         if (S < wsplit) {  // uniform per wave
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const float v = row_shl<S>(acc[q]);
-                if (first && S < nsplit) acc[q] += v;
+                acc[q] += (S < rem) ? v : 0.0f;
             }
-            sparse_combine_step<NQ, S + 1>(acc, first, nsplit, wsplit);
+            sparse_combine_step<NQ, 2 * S>(acc, rem, wsplit);
         }
     }
 }
 
-// rows split over several slots: the first slot's lanes add the partial sums of the following lanes (same column half,
-// same 16-lane row) in slot order; wsplit = the wave's longest split (uniform), nsplit = this row's
 template <int NQ>
-__device__ __forceinline__ void sparse_combine(float (&acc)[NQ], int lane, bool first, int nsplit, int wsplit) {
-    (void)lane;
-    sparse_combine_step<NQ, 1>(acc, first, nsplit, wsplit);
+__device__ __forceinline__ void sparse_combine(float (&acc)[NQ], int rem, int wsplit) {
+    sparse_combine_step<NQ, 1>(acc, rem, wsplit);
 }
 
 // DQ >= ceil(D / 2), HQ >= ceil(max(H, O) / 2): compile-time trip counts of the column loops (instantiated for the
@@ -504,14 +507,38 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         int* slot_start = slot_tab + set * (2 * ld + SP_CHUNK + 2);
         int* order = slot_start + ld + 1;
         int* bucket = order + ld;
+        // Slot width of this set.  The plan's fit test guarantees SP_CHUNK-entry slots; the gathers are latency chains over a
+        // slot's entries, so when the class has slots to spare the rows are cut into shorter chunks (more lanes per row):
+        // the smallest width whose slots fit (<= NT / 2 slots, <= 16 slots per row = one DPP row).
+        int ch = SP_CHUNK;
+        for (int cand = (set == NSET - 1 && !GRAPH) ? 4 : 8; cand < SP_CHUNK; cand <<= 1) {
+            int tot = 0, singles = 0;
+            bool ok = true;
+            for (int rr = 0; rr < n; ++rr) {
+                if (level[rr] > lvlmax) continue;
+                const int d = rowptr[rr + 1] - rowptr[rr];
+                if (d > cand) {
+                    const int ns = (d + cand - 1) / cand;
+                    ok &= ns <= SP_MAX_SPLIT;
+                    tot = sparse_place(tot, ns) + ns;
+                } else {
+                    ++singles;
+                }
+            }
+            if (ok && tot + singles <= NT / 2) {
+                ch = cand;
+                break;
+            }
+        }
+        sh.set_chunk[set] = ch;
         int pos = 0, p = 0, cnt = 0;
         for (int d = 0; d <= SP_CHUNK; ++d) bucket[d] = 0;
         for (int rr = 0; rr < n; ++rr) {
             if (level[rr] > lvlmax) continue;
             ++cnt;
             const int d = rowptr[rr + 1] - rowptr[rr];
-            if (d > SP_CHUNK) {
-                const int ns = sparse_slots_of(d);
+            if (d > ch) {
+                const int ns = (d + ch - 1) / ch;
                 if (ns > SP_MAX_SPLIT) sh.bad = 1;
                 pos = sparse_place(pos, ns);
                 order[p] = rr;
@@ -523,7 +550,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             }
         }
         int run = p;
-        for (int d = SP_CHUNK; d >= 0; --d) {
+        for (int d = ch; d >= 0; --d) {
             const int c = bucket[d];
             bucket[d] = run;
             run += c;
@@ -531,7 +558,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         for (int rr = 0; rr < n; ++rr) {
             if (level[rr] > lvlmax) continue;
             const int d = rowptr[rr + 1] - rowptr[rr];
-            if (d <= SP_CHUNK) order[bucket[d]++] = rr;
+            if (d <= ch) order[bucket[d]++] = rr;
         }
         for (int q = p; q < cnt; ++q) slot_start[q] = pos + (q - p);
         slot_start[cnt] = pos + (cnt - p);
@@ -551,6 +578,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         z.row = 0;
         z.e0 = z.e1 = 0;
         z.nsplit = 1;
+        z.rem = 1;
         z.first = false;
         const int sl = wave * TILE + li, cnt = sh.set_rows[k];
         if (sl < sh.set_slots[k] && !sh.bad) {
@@ -561,12 +589,14 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             }
             const int row = order[lo];
             const int ra = rowptr[row], rb = rowptr[row + 1];
-            const int ns = sparse_slots_of(rb - ra), kk = sl - slot_start[lo];
+            const int ch = sh.set_chunk[k];
+            const int ns = (rb - ra <= ch) ? 1 : (rb - ra + ch - 1) / ch, kk = sl - slot_start[lo];
             if (kk < ns) {  // otherwise: padding slot in front of a split row
                 z.row = row;
-                z.e0 = ra + kk * SP_CHUNK;
-                z.e1 = (z.e0 + SP_CHUNK < rb) ? z.e0 + SP_CHUNK : rb;
+                z.e0 = ra + kk * ch;
+                z.e1 = (z.e0 + ch < rb) ? z.e0 + ch : rb;
                 z.nsplit = ns;
+                z.rem = ns - kk;
                 z.first = (kk == 0);
             }
         }
@@ -582,11 +612,19 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     }
     const RowSlot& SA = rs[0];         // rows of layer 1 / its backward (all rows in graph mode)
     const RowSlot& SB = rs[NSET - 1];  // rows of layer 2 / its backward
+    // Node mode: layer 2, row t of layer 3, the head and dZ2 only concern t and its neighbours.  When their row slots fit one
+    // wave (the usual case: a motif node has a handful of neighbours), wave 0 runs those four phases back to back with
+    // wave-level syncs while the other waves wait at ONE workgroup barrier instead of four.
+    const bool fuseB = !GRAPH && sh.set_slots[NSET - 1] <= TILE;
+    auto SYNC_B = [&]() {
+        if (!fuseB) SYNC();
+        else if (wave == 0) wave_sync();
+    };
     // owned undirected edges: k = tid + NT q; mask entries and Adam moments stay in registers
     float Mij[SP_QMAX], Mji[SP_QMAX], mij[SP_QMAX], mji[SP_QMAX], vij[SP_QMAX], vji[SP_QMAX], wgt[SP_QMAX];
     int eij[SP_QMAX], eji[SP_QMAX], ni[SP_QMAX], nj[SP_QMAX];
-    bool near[SP_QMAX];   // an endpoint is t or a neighbour of t: only then dZ2 has a non-zero row on this edge
-    bool near2[SP_QMAX];  // an endpoint lies within two hops of t: only then dZ1 has a non-zero row on this edge
+    int eflag[SP_QMAX];   // bit 0 / 1: row i / j lies within two hops of t (dZ1 can be non-zero there); bit 2 / 3: row i / j is t
+                          // or a neighbour of t (dZ2 can be non-zero there); graph mode: all set
     {
         bool asym = (2 * eup != nnz);
 #pragma unroll
@@ -594,7 +632,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             const int k = tid + NT * q;
             Mij[q] = Mji[q] = mij[q] = mji[q] = vij[q] = vji[q] = wgt[q] = 0.0f;
             eij[q] = eji[q] = ni[q] = nj[q] = 0;
-            near[q] = near2[q] = false;
+            eflag[q] = 0;
             if (k < eup) {
                 int lo = 0, hi = ld;  // largest row i with upptr[i] <= k
                 while (hi - lo > 1) {
@@ -614,10 +652,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 if (Ag[(size_t)j * ld + i] != wgt[q]) asym = true;
                 Mij[q] = Mg[(size_t)i * ld + j];
                 Mji[q] = Mg[(size_t)j * ld + i];
-                const int t0 = rowptr[tr], t1 = rowptr[tr + 1];
-                const int pi = lower_bound_u16(scol, t0, t1, i), pj = lower_bound_u16(scol, t0, t1, j);
-                near[q] = GRAPH || i == tr || j == tr || (pi < t1 && (int)scol[pi] == i) || (pj < t1 && (int)scol[pj] == j);
-                near2[q] = GRAPH || level[i] <= 2 || level[j] <= 2;
+                eflag[q] = GRAPH ? 15 : ((level[i] <= 2) | ((level[j] <= 2) << 1) | ((level[i] <= 1) << 2) | ((level[j] <= 1) << 3));
             }
         }
         if (asym) sh.bad = 1;  // benign race: every writer stores 1
@@ -659,6 +694,11 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     float zraw[DQ];
 
     // sigma(M) -> symmetrised masked adjacency, one float per directed entry
+    // sArt = Abar[t][.] as a dense row (rank-1 layer-3 backward): zero except on t's neighbours, whose entries the owners of
+    // the edges at t refresh in publish_abar
+    if (tid < ld) sArt[tid] = 0.0f;
+    if (tid < 32) sh.phi[tid] = (tid < D) ? 0.5f : 0.0f;  // sigmoid of the initial feature mask (0)
+    SYNC();
     auto publish_abar = [&]() {
 #pragma unroll
         for (int q = 0; q < SP_QMAX; ++q)
@@ -666,18 +706,16 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 const float a = wgt[q] * (0.5f * (sigmoidf_(Mij[q]) + sigmoidf_(Mji[q])));
                 sAb[eij[q]] = a;
                 sAb[eji[q]] = a;
+                if (!GRAPH) {
+                    if (ni[q] == tr) sArt[nj[q]] = a;
+                    if (nj[q] == tr) sArt[ni[q]] = a;
+                }
             }
-        if (tid < ld) sArt[tid] = 0.0f;
         SYNC();
     };
     publish_abar();
 
     for (int iter = 0; iter < p.num_iters; ++iter) {
-        if (tid < 32) sh.phi[tid] = (tid < D) ? sigmoidf_(sh.fcur[tid]) : 0.0f;
-        // Abar[t][.] as a dense row (rank-1 layer-3 backward): scatter row t's entries (sArt was zeroed by publish_abar)
-        if (!GRAPH)
-            for (int e = rt0 + tid; e < rt1; e += NT) sArt[scol[e]] = sAb[e];
-        SYNC();
         const float step_size = adam_tab[2 * iter], inv_bc2s = 1.0f / adam_tab[2 * iter + 1];
 
         // ======== layer 1: Zraw = Abar . X (kept in registers for the feature-mask gradient), U1 ========
@@ -688,7 +726,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
 #pragma unroll
             for (int q = 0; q < DQ; ++q) acc[q] = 0.0f;
             sparse_gather<false, DQ>(sAb, scol, sX, sD, D, re0, re1, h, acc);
-            sparse_combine<DQ>(acc, lane, first, nsplit, wsplit);
+            sparse_combine<DQ>(acc, SA.rem, wsplit);
 #pragma unroll
             for (int q = 0; q < DQ; ++q) {
                 zraw[q] = acc[q];
@@ -705,12 +743,12 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
 #pragma unroll
             for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
             sparse_gather<true, HQ>(sAb, scol, sU1, sH, H, re0, re1, h, acc);
-            sparse_combine<HQ>(acc, lane, first, nsplit, wsplit);
+            sparse_combine<HQ>(acc, SB.rem, wsplit);
 #pragma unroll
             for (int q = 0; q < HQ; ++q) acc[q] = first ? acc[q] : 0.0f;
             sparse_forward_rowlocal<HQ>(acc, sW2, sh.bias[1], H, H, li, h, first, sU2 + r * sH, sRn2 + r);
         }
-        SYNC();
+        SYNC_B();
         if constexpr (GRAPH) {
         // ======== graph mode: layer 3 in full (no ReLU), U3 ========
         if (SA.wave_active) {
@@ -720,7 +758,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
 #pragma unroll
             for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
             sparse_gather<true, HQ>(sAb, scol, sU2, sH, H, re0, re1, h, acc);
-            sparse_combine<HQ>(acc, lane, first, nsplit, wsplit);
+            sparse_combine<HQ>(acc, SA.rem, wsplit);
 #pragma unroll
             for (int q = 0; q < HQ; ++q) acc[q] = first ? acc[q] : 0.0f;
             sparse_forward_rowlocal<HQ>(acc, sW3, sh.bias[2], H, O, li, h, first, sU3 + r * sO, sRn3 + r);
@@ -811,7 +849,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
 #pragma unroll
             for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
             sparse_gather<false, HQ>(sAb, scol, sU3, sO, H, re0, re1, h, acc);
-            sparse_combine<HQ>(acc, lane, first, nsplit, wsplit);
+            sparse_combine<HQ>(acc, SA.rem, wsplit);
 #pragma unroll
             for (int q = 0; q < HQ; ++q) {
                 const int c = 2 * q + h;
@@ -828,20 +866,21 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         SYNC();
         } else {
         // ======== row t of layer 3 (the only row the reference reads, explain.py:713), head, dE, dZ3[t] ========
-        {   // row t of Abar . relu(U2): its entries dealt over the 16 waves, lane = column; partials summed in wave order
+        const int nwz = fuseB ? 1 : NW;  // waves that share row t's entries
+        if (!fuseB || wave == 0) {   // row t of Abar . relu(U2): its entries dealt over the waves, lane = column; partials summed in wave order
             float z = 0.0f;
             if (li < H)
-                for (int e = rt0 + 2 * wave + h; e < rt1; e += 2 * NW)
+                for (int e = rt0 + 2 * wave + h; e < rt1; e += 2 * nwz)
                     z = fmaf(sAb[e], relu_(sU2[(int)scol[e] * sH + li]), z);
             z += __shfl_xor(z, 32);
             if (h == 0) sh.dfw[wave][li] = z;  // dfw is free until the layer-1 backward
         }
-        SYNC();
+        SYNC_B();
         if (wave == 0) {  // the head is a chain of tiny dependent steps: one wave, wave-level syncs only
             const int c = li;
             float z = 0.0f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) z += sh.dfw[w][c];
+            for (int w = 0; w < NW; ++w) z += (w < nwz) ? sh.dfw[w][c] : 0.0f;
             // layer 3 for row t: y = z W3 + b3, normalised (z staged in LDS so the H products' loads are independent)
             if (h == 0) sh.z3[c] = z;
             wave_sync();
@@ -918,7 +957,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             }
             if (h == 0) sh.dz3[c] = (c < H) ? v : 0.0f;
         }
-        SYNC();
+        SYNC_B();
         // ======== dZ2 (rank-1: dX2[r] = Abar[r][t] dZ3[t] + dE2 on row t) and g3; dZ2 overwrites U2 row by row ========
         if (SB.wave_active) {
             const bool first = SB.first;
@@ -957,7 +996,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
                 sparse_gather<false, HQ>(sAb, scol, sdZ2, sH, H, re0, re1, h, acc);
-                sparse_combine<HQ>(acc, lane, first, nsplit, wsplit);
+                sparse_combine<HQ>(acc, SA.rem, wsplit);
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) {
                     const int c = 2 * q + h;
@@ -1002,9 +1041,12 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 // compile-time trip counts: all loads of an edge are issued before the first use; columns beyond
                 // D / H are read from the row padding / the next row and dropped by the select
                 float G0 = 0.0f, G1 = 0.0f;
-                // dZ1 is exactly zero beyond two hops of t: such edges only get their regulariser gradients
+                const int fl = eflag[q];
+                // dZ1 is exactly zero beyond two hops of t: such edges only get their regulariser gradients.  (Forming the two
+                // products of an edge separately, each only when its dZ row can be non-zero, was measured and is slower: four
+                // dependent load groups instead of two - 4.9 against 3.6 us per iteration on syn1's largest target.)
 #pragma unroll 1
-                for (int c0 = 0; near2[q] && c0 < 2 * DQ; c0 += 2 * DQ / 2) {
+                for (int c0 = 0; (fl & 3) && c0 < 2 * DQ; c0 += 2 * DQ / 2) {
 #pragma unroll
                     for (int cc = 0; cc < 2 * DQ / 2; ++cc) {
                         const int c = c0 + cc;
@@ -1014,7 +1056,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 }
                 // dZ2 is exactly zero outside row t and its neighbours (rank-1 layer-3 backward): skip the products
 #pragma unroll 1
-                for (int c0 = 0; near[q] && c0 < 2 * HQ; c0 += 2 * HQ / 4) {
+                for (int c0 = 0; (fl & 12) && c0 < 2 * HQ; c0 += 2 * HQ / 4) {
 #pragma unroll
                     for (int cc = 0; cc < 2 * HQ / 4; ++cc) {
                         const int c = c0 + cc;
@@ -1062,6 +1104,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             sh.fcur[tid] = fn;
             sh.mf[tid] = m;
             sh.vf[tid] = v;
+            sh.phi[tid] = sigmoidf_(fn);  // for the next iteration's layer 1 / edge phase (this iteration's readers are done)
         }
         if (iter + 1 < p.num_iters) publish_abar();  // the returned mask is the one of the LAST forward (explain.py:209-211)
     }

@@ -28,7 +28,7 @@ constexpr int SPL_N_MAX = 4095;             // node ids are packed in 12 bits
 constexpr int SPL_POOL_FLOATS = 39168;      // 153 KB of LDS
 __host__ __device__ constexpr int spl_stage_floats(int D) { return 16 * TILE * (D | 1); }  // a [32][D|1] dZ1 tile per wave
 
-struct SlotRec { unsigned x, y; };  // see k_sparse_large: x = row | nsplit << 12 | wsplit << 17 | first << 22, y = e0 | len << 16
+struct SlotRec { unsigned x, y; };  // see k_sparse_large: x = row | nsplit << 12 | wsplit << 17 | first << 22 | rem << 23, y = e0 | len << 16
 
 __host__ __device__ inline int sparse_slots_of_c(int deg, int chunk) { return deg <= chunk ? 1 : (deg + chunk - 1) / chunk; }
 
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     __syncthreads();
     const int eup = sh.eup;
     // slot records -> workspace (set A first, then set B, each padded to whole waves): the phases walk them 512 at a time
-    //   x = row | nsplit << 12 | wsplit << 17 | first << 22,   y = e0 | len << 16   (x = y = 0: empty slot)
+    //   x = row | nsplit << 12 | wsplit << 17 | first << 22 | rem << 23,   y = e0 | len << 16   (x = y = 0: empty slot; rem: RowSlot)
     SlotRec* srec = reinterpret_cast<SlotRec*>(p.UT[1] + tm.offR * FS);
     const int slotsA = sh.bad ? 0 : sh.set_slots[0], slotsB = sh.bad ? 0 : sh.set_slots[1];
     const int padA = (slotsA + 31) & ~31, padB = (slotsB + 31) & ~31;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         const int cnt = sh.set_rows[k], nslots = k ? slotsB : slotsA, npad = k ? padB : padA, base = k ? padA : 0;
         for (int s0 = wave * TILE; s0 < npad; s0 += NW * TILE) {  // one wave per 32 slots (both half-waves compute the same)
             const int sl = s0 + li;
-            int zrow = 0, ze0 = 0, zlen = 0, zns = 1;
+            int zrow = 0, ze0 = 0, zlen = 0, zns = 1, zrem = 1;
             bool zfirst = false;
             if (sl < nslots) {
                 int lo = 0, hi = cnt;
@@ -243,6 +243,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                     ze0 = ra + kk * SPL_CHUNK;
                     zlen = ((ze0 + SPL_CHUNK < rb) ? ze0 + SPL_CHUNK : rb) - ze0;
                     zns = ns;
+                    zrem = ns - kk;
                     zfirst = (kk == 0);
                 }
             }
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             }
             if (h == 0) {
                 SlotRec rec;
-                rec.x = (unsigned)zrow | ((unsigned)zns << 12) | ((unsigned)wsplit << 17) | ((unsigned)zfirst << 22);
+                rec.x = (unsigned)zrow | ((unsigned)zns << 12) | ((unsigned)wsplit << 17) | ((unsigned)zfirst << 22) | ((unsigned)zrem << 23);
                 rec.y = (unsigned)ze0 | ((unsigned)zlen << 16);
                 srec[base + sl] = rec;
             }
@@ -271,6 +272,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         z.nsplit = (rec.x >> 12) & 31u;
         z.wsplit = (rec.x >> 17) & 31u;
         z.first = (rec.x >> 22) & 1u;
+        z.rem = (rec.x >> 23) & 31u;
+        if (z.rem == 0) z.rem = 1;
         z.e0 = rec.y & 0xffffu;
         z.e1 = z.e0 + (int)(rec.y >> 16);
         z.wave_active = round * (NT / 2) + wave * TILE < npad;
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
 #pragma unroll
             for (int q = 0; q < DQ; ++q) acc[q] = 0.0f;
             sparse_gather<false, DQ, SPL_GATHER_UNROLL>(sAb, scol, gX, FS, D, SA.e0, SA.e1, h, acc);
-            sparse_combine<DQ>(acc, lane, first, SA.nsplit, SA.wsplit);
+            sparse_combine<DQ>(acc, SA.rem, SA.wsplit);
 #pragma unroll
             for (int q = 0; q < DQ; ++q) {
                 if (first && 2 * q + h < D) gZraw[r * FS + 2 * q + h] = acc[q];  // for the feature-mask gradient
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
 #pragma unroll
             for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
             sparse_gather<true, HQ, SPL_GATHER_UNROLL>(sAb, scol, gU1, FS, H, SB.e0, SB.e1, h, acc);
-            sparse_combine<HQ>(acc, lane, first, SB.nsplit, SB.wsplit);
+            sparse_combine<HQ>(acc, SB.rem, SB.wsplit);
 #pragma unroll
             for (int q = 0; q < HQ; ++q) acc[q] = first ? acc[q] : 0.0f;
             sparse_forward_rowlocal<HQ>(acc, sW2, sh.bias[1], H, H, li, h, first, gU2 + r * FS, sRn2 + r);
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
                 sparse_gather<false, HQ, SPL_GATHER_UNROLL>(sAb, scol, gdZ2, FS, H, SA.e0, SA.e1, h, acc);
-                sparse_combine<HQ>(acc, lane, first, SA.nsplit, SA.wsplit);
+                sparse_combine<HQ>(acc, SA.rem, SA.wsplit);
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) {
                     const int c = 2 * q + h;

@@ -584,22 +584,31 @@ class MaskOptimJob:
             pass
 
 
-def init_edge_masks_raw(sizes, generator=None, seeds=None, pin=False):
+def init_edge_masks_raw(sizes, generator=None, seeds=None, pin=False, threads=1):
     """The initial edge masks of a whole batch as ONE host buffer: target after target the n x n values of the single
     normal_(1, std) draw construct_edge_mask makes (explain.py:645-652), generated in place (a draw into a contiguous
     slice consumes the generator exactly like a draw into a fresh [n, n] tensor).  `seeds`: re-seed a PRIVATE generator
-    before every target (the seed protocol of the golden runs) instead of consuming the caller's global stream."""
+    before every target (the seed protocol of the golden runs) instead of consuming the caller's global stream; the
+    targets are then independent and `threads` > 1 draws them on several host threads (normal_ releases the GIL)."""
     sizes = [int(n) for n in sizes]
-    buf = torch.empty(sum(n * n for n in sizes), dtype=torch.float32, pin_memory=bool(pin))
-    gen = generator
-    if seeds is not None:
-        gen = torch.Generator()
-    o = 0
-    for k, n in enumerate(sizes):
-        if seeds is not None:
-            gen.manual_seed(int(seeds[k]))
-        buf[o:o + n * n].normal_(1.0, math.sqrt(2.0) * math.sqrt(2.0 / (n + n)), generator=gen)
-        o += n * n
+    off = np.zeros(len(sizes) + 1, np.int64)
+    np.cumsum(np.asarray(sizes, np.int64) ** 2, out=off[1:])
+    buf = torch.empty(int(off[-1]), dtype=torch.float32, pin_memory=bool(pin))
+
+    def fill(lo, hi, gen):
+        for k in range(lo, hi):
+            n = sizes[k]
+            if seeds is not None:
+                gen.manual_seed(int(seeds[k]))
+            buf[off[k]:off[k + 1]].normal_(1.0, math.sqrt(2.0) * math.sqrt(2.0 / (n + n)), generator=gen)
+
+    if seeds is None or threads <= 1 or len(sizes) < 2 * threads:
+        fill(0, len(sizes), torch.Generator() if seeds is not None else generator)
+        return buf
+    from concurrent.futures import ThreadPoolExecutor
+    cuts = [0] + [int(np.searchsorted(off, off[-1] * i / threads)) for i in range(1, threads)] + [len(sizes)]   # equal shares of the floats
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(lambda i: fill(cuts[i], cuts[i + 1], torch.Generator()), range(threads)))
     return buf
 
 

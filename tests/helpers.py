@@ -64,3 +64,32 @@ def random_graph(rng, n, D, density=0.15):
     for i in range(n - 1):          # keep it connected-ish
         A[i, i + 1] = A[i + 1, i] = 1
     return A, rng.standard_normal((n, D)).astype(np.float32)
+
+
+def load_branches(name):
+    """Alternate outcomes of the reference under 1-ulp perturbations of the initial mask (make_golden_branches.py)."""
+    p = os.path.join(GOLDEN, name + "_branches.npz")
+    return np.load(p) if os.path.exists(p) else None
+
+
+def branch_errors(z, br, eoff, vals, feat_sig, early=False):
+    """Per target: (err_mask, err_feat, matched) = distance of a result to the NEAREST legitimate outcome of the reference -
+    its own output (fixture z, `vals` / `feat_sig`, or the `_early` horizon) or one of the alternate outcomes it produces
+    under a 1-ulp perturbation of the initial mask (fixture br) - and which one matched (-1: the unperturbed output)."""
+    sfx = "_early" if early else ""
+    want_v, want_f = z["vals" + sfx].astype(np.float64), z["feat_sig" + sfx].astype(np.float64)
+    vals, feat_sig = np.asarray(vals, np.float64), np.asarray(feat_sig, np.float64)
+    T = len(eoff) - 1
+    em = np.asarray([np.abs(vals[a:b] - want_v[a:b]).max() if b > a else 0.0 for a, b in zip(eoff[:-1], eoff[1:])])
+    ef = np.abs(feat_sig - want_f).max(1)
+    matched = np.full(T, -1, np.int64)
+    if br is not None:
+        for j in np.nonzero(br["alt_early"] == (1 if early else 0))[0]:
+            k = int(br["alt_target"][j])
+            a, b = eoff[k], eoff[k + 1]
+            av = br["alt_vals"][br["alt_off"][j]:br["alt_off"][j + 1]].astype(np.float64)
+            dm = np.abs(vals[a:b] - av).max() if b > a else 0.0
+            df = np.abs(feat_sig[k] - br["alt_feat"][j]).max()
+            if max(dm, df) < max(em[k], ef[k]):
+                em[k], ef[k], matched[k] = dm, df, j
+    return em, ef, matched

@@ -1,0 +1,10 @@
+#!/bin/bash
+O=gpurun_out/$1; mkdir -p $O
+export TMPDIR=/tmp
+export GNNX_DUMP_OUTLIERS=$PWD/$O/outliers.json
+timeout 900 python -m pytest tests/test_emu_kernels.py tests/test_gpu_full_configs.py tests/test_gpu_parity.py -m gpu -q --timeout=600 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+timeout 600 python bench.py --steps 20 --warmup 5 --no-parity-gate --no-cpu-baseline > $O/bench_syn1.json 2> $O/bench_syn1.err; echo "bench rc=$?" >> $O/bench_syn1.err
+timeout 300 python tools/probe_sparse.py 0 > $O/probe_sparse_0.log 2>&1
+tail -4 $O/pytest_gpu.log; tail -2 $O/bench_syn1.err; python -c "
+import json;d=json.loads(open('$O/bench_syn1.json').read().strip().splitlines()[-1]);print('value',d['value'],'ms',d['ms_per_step'],'e2e',d['pcie_inclusive']['value'], d['pcie_inclusive']['warm_batch']); print(d.get('parity'))"
+tail -12 $O/probe_sparse_0.log

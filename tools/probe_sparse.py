@@ -19,7 +19,7 @@ for k, a in enumerate(anchors):
 k = len(anchors)
 # finer stamps inside layer 2 (wave 0 = the hub rows): after the gather, after the split-row combine, after MFMA + epilogue
 SUB = 20
-l2 = "            sparse_gather<true, HQ>(sAb, scol, sU1, sH, H, re0, re1, h, acc);\n            sparse_combine<HQ>(acc, lane, first, nsplit, wsplit);\n"
+l2 = "            sparse_gather<true, HQ>(sAb, scol, sU1, sH, H, re0, re1, h, acc);\n            sparse_combine<HQ>(acc, SB.rem, wsplit);\n"
 assert l2 in src
 src = src.replace(l2, l2.replace(";\n            sparse_combine", ";\n            PROBE(%d);\n            sparse_combine" % SUB) + "            PROBE(%d);\n" % (SUB + 1), 1)
 l2b = "            sparse_forward_rowlocal<HQ>(acc, sW2, sh.bias[1], H, H, li, h, first, sU2 + r * sH, sRn2 + r);\n"
