@@ -211,7 +211,7 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
     h->order.resize(T);
     for (int t = 0; t < T; ++t) h->order[t] = t;
     std::stable_sort(h->order.begin(), h->order.end(), [&](int a, int b) { return h->meta[a].ld > h->meta[b].ld; });
-    const bool resident_ok = !prob->graph_mode && prob->C <= RES_CMAX;
+    const bool resident_ok = !prob->graph_mode && prob->C <= RES_CMAX && !prob->mask_relu;
     if (const char* env = std::getenv("GNNX_RESIDENT_MAX_BLOCKS")) {  // tuning knob, see include/gnnx.h
         const int v = std::atoi(env);
         h->res_nbmax = v < 0 ? 0 : (v > RES_NBMAX ? RES_NBMAX : v);
@@ -442,6 +442,11 @@ template <bool UPDATE, bool WRITE_ABAR>
 static void launch_mask(gnnx_handle h, const Tables& tb, const Params& p, int it, float ss, float b2, hipStream_t s) {
     const dim3 g(tb.n_mask), b(256);
     const bool node = !h->prob.graph_mode, loss = UPDATE && p.loss != nullptr;
+    if (h->prob.mask_relu) {  // mask_act == "ReLU": no loss logging (gnnx_run rejects the combination)
+        if (node) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, true, false, true>), g, b, 0, s, p, tb.mask, it, ss, b2);
+        else hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, false, false, true>), g, b, 0, s, p, tb.mask, it, ss, b2);
+        return;
+    }
     if (node && loss) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, true, UPDATE>), g, b, 0, s, p, tb.mask, it, ss, b2);
     else if (node) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, true, false>), g, b, 0, s, p, tb.mask, it, ss, b2);
     else if (loss) hipLaunchKernelGGL((k_mask<UPDATE, WRITE_ABAR, false, UPDATE>), g, b, 0, s, p, tb.mask, it, ss, b2);
@@ -531,6 +536,7 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* lossp = hy->record_loss ? loss : nullptr;
     if (hy->record_loss && !loss) return fail("record_loss set but loss buffer is null");
+    if (hy->record_loss && h->prob.mask_relu) return fail("loss logging is not implemented for mask_act = ReLU (the reference's loss is NaN there)");
     Params p = make_params(h, hy, A, X, yhat, M, Abar, lossp, workspace);
     // hybrid split: small targets (<= res_nbmax row blocks) -> on-chip-resident kernels on side streams (overlap with the
     // streaming launches of the other targets); loss logging is a streaming-path feature
@@ -662,7 +668,7 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
     HIPCK(hipMemcpyAsync(h->nnz.data(), h->d_nnz, sizeof(int32_t) * (h->prob.graph_mode ? 2 : 5) * T, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
     const bool graph = h->prob.graph_mode != 0;
-    if (h->prob.C > RES_CMAX) return 0;
+    if (h->prob.C > RES_CMAX || h->prob.mask_relu) return 0;   // mask_act = "ReLU" runs on the dense streaming kernels only
     int sparse_on = 1;
     if (const char* env = std::getenv("GNNX_SPARSE_RESIDENT")) sparse_on = std::atoi(env);
     if (!sparse_on) return 0;
@@ -836,6 +842,31 @@ extern "C" int gnnx_gather_edges(gnnx_handle h, const float* A, const float* Aba
     return 0;
 }
 
+extern "C" int gnnx_denoise_edges(gnnx_handle h, const int64_t* eoff, const int32_t* rc, const float* vals, int32_t threshold_num,
+                                  uint8_t* keep, float* threshold, int32_t* stats, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !eoff || !rc || !vals || !keep || !threshold || !stats || !workspace) return fail("null argument");
+    if (threshold_num < 1) return fail("threshold_num must be positive");
+    if (workspace_bytes < h->ws_bytes) return fail("workspace too small");
+    char* w = static_cast<char*>(workspace);
+    DenoiseArgs a{h->d_meta, eoff, rc, vals, threshold_num, keep, threshold, stats, reinterpret_cast<int32_t*>(w + h->o_g3),
+                  reinterpret_cast<int32_t*>(w + h->o_z3p)};
+    hipLaunchKernelGGL(k_denoise, dim3(h->prob.num_targets), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gnnx_auc_counts(const float* vals, const uint8_t* real, int64_t num_edges, float* pos_scratch, unsigned long long* counts,
+                               void* stream) {
+    if (!vals || !real || !pos_scratch || !counts || num_edges < 1) return fail("bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIPCK(hipMemsetAsync(counts, 0, 4 * sizeof(unsigned long long), s));
+    const dim3 grid((unsigned)((num_edges + 255) / 256)), block(256);
+    hipLaunchKernelGGL(k_auc_compact, grid, block, 0, s, vals, real, num_edges, pos_scratch, counts);
+    hipLaunchKernelGGL(k_auc_count, grid, block, 0, s, vals, real, num_edges, (const float*)pos_scratch, counts);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int gnnx_forward(gnnx_handle h, const float* A, const float* X, const float* M, const float* feat_mask_in,
                             float* Abar, float* probs, void* workspace, size_t workspace_bytes, void* stream) {
     if (!h || !A || !X || !M || !Abar || !probs || !workspace) return fail("null argument");
@@ -848,6 +879,30 @@ extern "C" int gnnx_forward(gnnx_handle h, const float* A, const float* X, const
     launch_mask<false, true>(h, tb, p, 0, 0.0f, 1.0f, s);
     launch_forward(h, tb, p, 0, s);
     HIPCK(hipMemcpyAsync(probs, p.probs, sizeof(float) * h->prob.num_targets * CMAX, hipMemcpyDeviceToDevice, s));
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gnnx_grad_baseline(gnnx_handle h, const float* A, const float* X, float* out, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    if (!h || !A || !X || !out || !workspace) return fail("null argument");
+    if (h->prob.graph_mode) return fail("the gradient baseline is a node-mode path (the reference indexes pred_label[node_idx], explain.py:130)");
+    if (workspace_bytes < h->ws_bytes) return fail("workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // the streaming forward / backward with Abar := A (unmasked adjacency, diagonal included as the reference's model(x, adj))
+    Params p = make_params(h, nullptr, A, X, nullptr, nullptr, const_cast<float*>(A), nullptr, workspace);
+    p.num_iters = 1;
+    const Tables tb = tables_all(h);
+    // phi := 1: a feature-mask parameter of 40 (sigmoid(40) == 1.0f), staged in the (yet unused) df array
+    const size_t nf = (size_t)h->prob.num_targets * FS;
+    std::vector<float> f40(nf, 40.0f);
+    float* d_f = reinterpret_cast<float*>(static_cast<char*>(workspace) + h->o_dE);   // T * 96 floats >= T * 32; rewritten by the head later
+    HIPCK(hipMemcpyAsync(d_f, f40.data(), sizeof(float) * nf, hipMemcpyHostToDevice, s));
+    HIPCK(hipStreamSynchronize(s));   // f40 is a host temporary
+    hipLaunchKernelGGL(k_prep, dim3(h->prob.num_targets), dim3(256), 0, s, p, (const float*)d_f, (const int32_t*)nullptr);
+    launch_forward(h, tb, p, 0, s);
+    launch_backward(h, tb, p, 0, s);
+    hipLaunchKernelGGL(k_grad_edges, dim3(tb.n_mask), dim3(256), 0, s, p, tb.mask, out);
     HIPCK(hipGetLastError());
     return 0;
 }

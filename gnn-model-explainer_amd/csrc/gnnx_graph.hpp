@@ -228,3 +228,202 @@ __global__ __launch_bounds__(256) void k_gather_edges(const TargetMeta* meta, co
 }
 
 }  // namespace gnnx
+
+namespace gnnx {
+
+// ---------------------------------------------------------------------------------------------
+// Post-processing of the explanations on the device (explain_nodes_gnn_stats / explain_graphs, explain.py:306-351, with
+// io_utils.denoise_graph, utils/io_utils.py:193-245), on the edge lists of k_gather_edges:
+//   k_denoise     per target: the threshold that keeps the `threshold_num` heaviest undirected edges (ties kept, as the
+//                 reference's `adj >= np.sort(adj[adj > 0])[-2 threshold_num]`), then the largest connected component of
+//                 the kept edges over all n nodes (first one in node order among equals, as max(nx.connected_components));
+//   k_auc_*       ROC-AUC of all targets' edge scores against the motif ground truth as exact pair counts
+//                 (#{pos > neg}, #{pos == neg}): AUC = (gt + eq / 2) / (P N) - what sklearn's trapezoid rule evaluates.
+// ---------------------------------------------------------------------------------------------
+struct DenoiseArgs {
+    const TargetMeta* meta;
+    const int64_t* eoff;   // [T + 1]
+    const int32_t* rc;     // [E][2]
+    const float* vals;     // [E] masked adjacency on the upper-triangle edges
+    int32_t threshold_num; // undirected edges to keep (the reference's threshold_num; it doubles it for the symmetric matrix)
+    uint8_t* keep;         // [E] out: edge belongs to the denoised explanation
+    float* threshold;      // [T] out (0 when the target has no positive edge)
+    int32_t* stats;        // [T][3] out: nodes and edges of the kept component, its smallest node id
+    int32_t* comp;         // scratch [R]: component label of every node
+    int32_t* cnt;          // scratch [R]: nodes per label
+};
+
+// comp / cnt live in global memory and are updated with atomics (performed at L2): read them past this CU's L1
+__device__ __forceinline__ int dn_load(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ float dn_block_max(float v, float* s4) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3]));
+}
+__device__ __forceinline__ int dn_block_sum(int v, int* s4) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s4[0] + s4[1] + s4[2] + s4[3];
+}
+
+__global__ __launch_bounds__(256) void k_denoise(DenoiseArgs a) {
+    __shared__ float sf[4];
+    __shared__ int si[4];
+    __shared__ int s_changed;
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const TargetMeta tm = a.meta[t];
+    const int64_t e0 = a.eoff[t];
+    const int E = (int)(a.eoff[t + 1] - e0);
+    const int32_t* rc = a.rc + 2 * e0;
+    const float* v = a.vals + e0;
+    uint8_t* keep = a.keep + e0;
+    int32_t* comp = a.comp + tm.offR;
+    int32_t* cnt = a.cnt + tm.offR;
+    // ---- threshold: the k-th largest positive value with multiplicity (every undirected edge counts once) ----
+    float cur = __builtin_inff(), thr = 0.0f;
+    int remaining = a.threshold_num;
+    bool any = false;
+    for (int it = 0; it < a.threshold_num; ++it) {   // at most k distinct values are visited
+        float m = 0.0f;
+        for (int e = tid; e < E; e += 256) {
+            const float x = v[e];
+            if (x > 0.0f && x < cur) m = fmaxf(m, x);
+        }
+        m = dn_block_max(m, sf);
+        if (m <= 0.0f) break;                       // fewer than k positive edges: keep them all (threshold = the smallest)
+        any = true;
+        thr = m;
+        int c = 0;
+        for (int e = tid; e < E; e += 256) c += (v[e] == m);
+        c = dn_block_sum(c, si);
+        if (c >= remaining) break;
+        remaining -= c;
+        cur = m;
+    }
+    if (tid == 0) a.threshold[t] = any ? thr : 0.0f;
+    // ---- connected components of the kept edges by min-label propagation ----
+    for (int i = tid; i < tm.n; i += 256) {
+        comp[i] = i;
+        cnt[i] = 0;
+    }
+    for (int e = tid; e < E; e += 256) keep[e] = (any && v[e] >= thr && v[e] > 0.0f) ? 1 : 0;
+    __syncthreads();
+    for (int round = 0; round < tm.n; ++round) {
+        if (tid == 0) s_changed = 0;
+        __syncthreads();
+        for (int e = tid; e < E; e += 256)
+            if (keep[e]) {
+                const int r = rc[2 * e], c = rc[2 * e + 1];
+                const int x = dn_load(&comp[r]), y = dn_load(&comp[c]);
+                if (x != y) {
+                    const int m = x < y ? x : y;
+                    atomicMin(&comp[r], m);
+                    atomicMin(&comp[c], m);
+                    s_changed = 1;
+                }
+            }
+        __syncthreads();
+        const int ch = s_changed;
+        __syncthreads();
+        if (!ch) break;
+    }
+    // labels are not yet roots everywhere (a node keeps the smallest label it has seen): chase them to the fixed point
+    for (int i = tid; i < tm.n; i += 256) {
+        int l = dn_load(&comp[i]);
+        for (int nx = dn_load(&comp[l]); nx != l; nx = dn_load(&comp[l])) l = nx;
+        atomicMin(&comp[i], l);          // labels only ever decrease: concurrent chasers stay consistent
+    }
+    __syncthreads();
+    for (int i = tid; i < tm.n; i += 256) atomicAdd(&cnt[dn_load(&comp[i])], 1);
+    __syncthreads();
+    // largest component; among equals the one with the smallest label (= smallest node id: the first nx would yield)
+    int best = 0, bl = 0x7fffffff;
+    for (int i = tid; i < tm.n; i += 256) {
+        const int c = dn_load(&cnt[i]);
+        if (c > best || (c == best && c > 0 && i < bl)) {
+            best = c;
+            bl = i;
+        }
+    }
+    {
+        __shared__ int sb[256], sl[256];
+        sb[tid] = best;
+        sl[tid] = bl;
+        __syncthreads();
+        for (int s = 128; s >= 1; s >>= 1) {
+            if (tid < s) {
+                const int c = sb[tid + s], l = sl[tid + s];
+                if (c > sb[tid] || (c == sb[tid] && l < sl[tid])) {
+                    sb[tid] = c;
+                    sl[tid] = l;
+                }
+            }
+            __syncthreads();
+        }
+        best = sb[0];
+        bl = sl[0];
+    }
+    int ne = 0;
+    for (int e = tid; e < E; e += 256) {
+        const bool k = keep[e] && dn_load(&comp[rc[2 * e]]) == bl;
+        keep[e] = k ? 1 : 0;
+        ne += k;
+    }
+    ne = dn_block_sum(ne, si);
+    if (tid == 0) {
+        a.stats[3 * t] = best;
+        a.stats[3 * t + 1] = ne;
+        a.stats[3 * t + 2] = bl;
+    }
+}
+
+// positives (real == 1) compacted into pos[] (order irrelevant for counting); counts[0] = P
+__global__ __launch_bounds__(256) void k_auc_compact(const float* vals, const uint8_t* real, int64_t E, float* pos, unsigned long long* counts) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < E && real[e]) pos[atomicAdd(&counts[0], 1ull)] = vals[e];
+}
+// every negative against every positive: counts[1] += #{pos > neg}, counts[2] += #{pos == neg}, counts[3] += negatives
+__global__ __launch_bounds__(256) void k_auc_count(const float* vals, const uint8_t* real, int64_t E, const float* pos,
+                                                   unsigned long long* counts) {
+    __shared__ float sp[1024];
+    __shared__ unsigned long long sred[3][4];
+    const unsigned long long P = counts[0];
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool neg = e < E && !real[e];
+    const float x = neg ? vals[e] : 0.0f;
+    unsigned long long gt = 0, eq = 0;
+    for (unsigned long long p0 = 0; p0 < P; p0 += 1024) {
+        const int chunk = (int)((P - p0 < 1024ull) ? (P - p0) : 1024ull);
+        __syncthreads();
+        for (int k = threadIdx.x; k < chunk; k += 256) sp[k] = pos[p0 + k];
+        __syncthreads();
+        if (neg)
+            for (int k = 0; k < chunk; ++k) {
+                gt += (sp[k] > x);
+                eq += (sp[k] == x);
+            }
+    }
+    unsigned long long r[3] = {gt, eq, neg ? 1ull : 0ull};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        unsigned lo = (unsigned)r[j], hi = (unsigned)(r[j] >> 32);   // hi stays 0 for any realistic E; summed separately
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned lo2 = (unsigned)__shfl_xor((int)lo, o), hi2 = (unsigned)__shfl_xor((int)hi, o);
+            const unsigned long long s = (((unsigned long long)hi << 32) | lo) + (((unsigned long long)hi2 << 32) | lo2);
+            lo = (unsigned)s;
+            hi = (unsigned)(s >> 32);
+        }
+        if ((threadIdx.x & 63) == 0) sred[j][threadIdx.x >> 6] = ((unsigned long long)hi << 32) | lo;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicAdd(&counts[1 + threadIdx.x], sred[threadIdx.x][0] + sred[threadIdx.x][1] + sred[threadIdx.x][2] + sred[threadIdx.x][3]);
+}
+
+}  // namespace gnnx

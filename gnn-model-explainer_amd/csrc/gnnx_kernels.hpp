@@ -629,6 +629,15 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
     }
 }
 
+// mask activation (explain.py:667-670), its derivative and d(entropy)/dS of explain.py:769 for both settings of mask_act
+template <bool RELU>
+__device__ __forceinline__ float mask_act(float m) { return RELU ? ((m <= 0.0f) ? 0.0f : m) : sigmoidf_(m); }  // NaN stays NaN, as torch.relu
+template <bool RELU>
+__device__ __forceinline__ float mask_dact(float m, float s) { return RELU ? ((m > 0.0f) ? 1.0f : 0.0f) : s * (1.0f - s); }
+// sigmoid: log(1 - S) - log(S) == -M exactly; ReLU: the logs themselves (NaN for S > 1, -inf * 0 for S == 0 - as torch)
+template <bool RELU>
+__device__ __forceinline__ float mask_dent(float m, float s) { return RELU ? (logf(1.0f - s) - logf(s)) : -m; }
+
 // ---------------------------------------------------------------------------------------------
 // Fused mask kernel: one workgroup (4 waves) per tile pair {(I,J),(J,I)}, I <= J.
 //   * thread (i = tid/8, c4 = 4 (tid%8)) owns the 4 entries (i, c4..c4+3) of tile (I,J) AND their mirror
@@ -646,7 +655,10 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
 //   NODE         : layer-3 part of G is the rank-2 term built from g3 (node mode)
 //   LOSS         : also accumulate the size / entropy / Laplacian loss terms (logging)
 // ---------------------------------------------------------------------------------------------
-template <bool UPDATE, bool WRITE_ABAR, bool NODE, bool LOSS>
+//   RELU         : mask_act == "ReLU" (explain.py:669-670, 757-760): relu(M) instead of sigmoid(M) in the masked adjacency, the
+//                  size term and the entropy term - whose log(1 - relu(M)) is NaN for every entry > 1, exactly as in the
+//                  reference (its loss is NaN from the first epoch on a N(1, .) initialised mask)
+template <bool UPDATE, bool WRITE_ABAR, bool NODE, bool LOSS, bool RELU = false>
 __global__ __launch_bounds__(256, 4) void k_mask(Params p, const MaskTile* tiles, int iter, float step_size, float bc2s) {
     constexpr int LS = 33;  // LDS row stride
     __shared__ float sGp[4 * TILE * LS];                             // per-wave partial G tiles, [w][i][j]
@@ -770,21 +782,22 @@ __global__ __launch_bounds__(256, 4) void k_mask(Params p, const MaskTile* tiles
                 Gs += p.c_lap * 0.5f * dy * dy * inv_n2;
             }
             const float gc = Gs * Aij * offd;
-            const float Sij = sigmoidf_(Mij);
+            const float Sij = mask_act<RELU>(Mij);
             const float Mji_old = sPM[j * LS + i];
             const bool valid = LOSS && (gi < n) && (gj < n);
             float Sji_old = 0.0f;
             if (LOSS) Sji_old = sigmoidf_(Mji_old);
             if (!diag) {  // this thread also owns the mirror entry (j,i)
                 float Mji = Mji_old, mji = sPm[j * LS + i], vji = sPv[j * LS + i];
-                const float Sji = sigmoidf_(Mji);
+                const float Sji = mask_act<RELU>(Mji);
                 // d(entropy)/dS = log(1-S) - log(S) = -M exactly (S = sigma(M)): no logs on the update path
-                const float gji = (gc + p.c_size - p.c_ent * Mji * inv_n2) * Sji * (1.0f - Sji);
+                float gji = (gc + p.c_size + p.c_ent * mask_dent<RELU>(Mji, Sji) * inv_n2) * mask_dact<RELU>(Mji, Sji);
+                if (RELU && !(gi < n && gj < n)) gji = 0.0f;  // padding entries (M = 0) do not exist in the reference: relu'(0) * log(0) is NaN
                 adam_update(Mji, mji, vji, gji, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
                 sPM[j * LS + i] = Mji;
                 sPm[j * LS + i] = mji;
                 sPv[j * LS + i] = vji;
-                sS[j * LS + i] = sigmoidf_(Mji);
+                sS[j * LS + i] = mask_act<RELU>(Mji);
                 if (valid) {
                     s_size += Sji;
                     s_ent += -Sji * logf(Sji) - (1.0f - Sji) * logf(1.0f - Sji);
@@ -799,16 +812,17 @@ __global__ __launch_bounds__(256, 4) void k_mask(Params p, const MaskTile* tiles
                     if (!diag) s_lap += ab * (yi * yi - yi * yj);
                 }
             }
-            const float gij = (gc + p.c_size - p.c_ent * Mij * inv_n2) * Sij * (1.0f - Sij);
+            float gij = (gc + p.c_size + p.c_ent * mask_dent<RELU>(Mij, Sij) * inv_n2) * mask_dact<RELU>(Mij, Sij);
+            if (RELU && !(gi < n && gj < n)) gij = 0.0f;
             float mij = mo[e], vij = vo[e];
             adam_update(Mij, mij, vij, gij, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
             Mo[e] = Mij;
             mo[e] = mij;
             vo[e] = vij;
         } else if (!diag) {
-            sS[j * LS + i] = sigmoidf_(sPM[j * LS + i]);
+            sS[j * LS + i] = mask_act<RELU>(sPM[j * LS + i]);
         }
-        Sown[e] = sigmoidf_(Mij);
+        Sown[e] = mask_act<RELU>(Mij);
         if (diag) sS[i * LS + j] = Sown[e];  // diagonal tile: publish, the mirror thread reads it transposed
     }
     if (UPDATE) {
@@ -823,7 +837,9 @@ __global__ __launch_bounds__(256, 4) void k_mask(Params p, const MaskTile* tiles
         for (int e = 0; e < 4; ++e) {
             const int j = c4 + e;
             const float Sother = sS[j * LS + i];
-            ab4[e] = (gi != J0 + j) ? Ao[e] * (0.5f * (Sown[e] + Sother)) : 0.0f;  // A = 0 on padding
+            const float ab = Ao[e] * (0.5f * (Sown[e] + Sother));
+            // the reference MULTIPLIES by (1 - I) (explain.py:678): a NaN on the diagonal stays NaN (only reachable with ReLU)
+            ab4[e] = RELU ? ab * ((gi != J0 + j) ? 1.0f : 0.0f) : ((gi != J0 + j) ? ab : 0.0f);  // A = 0 on padding
         }
         *reinterpret_cast<f32x4*>(p.Abar + own) = ab4;
         if (!diag) {  // same values for (j,i): stage for the row-wise store of the mirror tile
@@ -876,6 +892,83 @@ __global__ __launch_bounds__(256, 4) void k_mask(Params p, const MaskTile* tiles
         p.mf[o] = m;
         p.vf[o] = v;
         p.f[(iter + 1) & 1][o] = fnew;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gradient baseline (`model="grad"`, explain.py:125-133 with adj_feat_grad :717-738): ONE forward + backward of the
+// encoder on the UNMASKED sub-graph with loss -log softmax(.)[predicted label], then
+//     out = sigmoid(|dL/dA| + |dL/dA|^T) * A .
+// The forward / backward launches are the streaming kernels with Abar := A and phi := 1; this kernel forms the two
+// tiles G[i][j] = sum_l dZ_l[i] . X_{l-1}[j] and G[j][i] of a tile pair on MFMA (K = D + 2H split over the 4 waves, two
+// accumulators because the absolute values are taken before the sum), adds the rank-1 layer-3 part (row t: g3) and
+// writes tile (I,J) and its mirror.  One workgroup per tile pair, as k_mask.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_grad_edges(Params p, const MaskTile* tiles, float* out) {
+    constexpr int LS = 33;
+    __shared__ float sGa[4 * TILE * LS], sGb[4 * TILE * LS];
+    __shared__ float sS[TILE * LS];
+    const MaskTile tl = tiles[blockIdx.x];
+    const TargetMeta tm = tl.tm;
+    const int ld = tm.ld;
+    const int I0 = tl.I * TILE, J0 = tl.J * TILE;
+    const bool diag = (tl.I == tl.J);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int i = tid >> 3, c4 = (tid & 7) * 4;
+    const int gi = I0 + i;
+    const size_t own = tm.offQ + (size_t)gi * ld + J0 + c4;
+    const size_t par = tm.offQ + (size_t)(J0 + i) * ld + I0 + c4;
+    const f32x4 Ao = *reinterpret_cast<const f32x4*>(p.A + own);
+    const f32x4 g3j4 = *reinterpret_cast<const f32x4*>(p.g3 + tm.offR + J0 + c4);
+    const float g3i = p.g3[tm.offR + gi];
+    f32x16 accA, accB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accA[r] = accB[r] = 0.0f;
+    const size_t ro = (size_t)tm.offR * FS;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const int d = (l == 0) ? p.D : p.H;
+        const float* zT = p.dZT[l] + ro;
+        const float* xT = (l == 0) ? p.XT + ro : p.UT[l - 1] + ro;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (2 * (wave + 4 * u) < d) {
+                const int k = 2 * (wave + 4 * u) + h;  // columns >= d hold zeros
+                const float zi = zT[(size_t)k * ld + I0 + li], zj = zT[(size_t)k * ld + J0 + li];
+                float xi = xT[(size_t)k * ld + I0 + li], xj = xT[(size_t)k * ld + J0 + li];
+                if (l == 1) {
+                    xi = fmaxf(xi, 0.0f);
+                    xj = fmaxf(xj, 0.0f);
+                }
+                accA = __builtin_amdgcn_mfma_f32_32x32x2f32(zi, xj, accA, 0, 0, 0);  // G[I0+i][J0+j]
+                accB = __builtin_amdgcn_mfma_f32_32x32x2f32(xi, zj, accB, 0, 0, 0);  // G[J0+j][I0+i]
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        sGa[(wave * TILE + acc_row(r, h)) * LS + li] = accA[r];
+        sGb[(wave * TILE + acc_row(r, h)) * LS + li] = accB[r];
+    }
+    __syncthreads();
+    f32x4 o4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int j = c4 + e, gj = J0 + j;
+        float ga = (sGa[(0 * TILE + i) * LS + j] + sGa[(1 * TILE + i) * LS + j]) + (sGa[(2 * TILE + i) * LS + j] + sGa[(3 * TILE + i) * LS + j]);
+        float gb = (sGb[(0 * TILE + i) * LS + j] + sGb[(1 * TILE + i) * LS + j]) + (sGb[(2 * TILE + i) * LS + j] + sGb[(3 * TILE + i) * LS + j]);
+        ga += (gi == tm.t) ? g3j4[e] : 0.0f;   // layer 3: dZ3 is non-zero on row t only, G3[t][j] = dZ3[t] . relu(U2[j]) = g3[j]
+        gb += (gj == tm.t) ? g3i : 0.0f;
+        o4[e] = sigmoidf_(fabsf(ga) + fabsf(gb)) * Ao[e];
+        if (!diag) sS[j * LS + i] = o4[e];
+    }
+    *reinterpret_cast<f32x4*>(out + own) = o4;
+    if (!diag) {
+        __syncthreads();
+        f32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = sS[i * LS + c4 + e];
+        *reinterpret_cast<f32x4*>(out + par) = w;
     }
 }
 

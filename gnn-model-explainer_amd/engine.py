@@ -30,7 +30,7 @@ class _Problem(ctypes.Structure):
     _fields_ = [("num_targets", ctypes.c_int32), ("n", ctypes.POINTER(ctypes.c_int32)),
                 ("target_row", ctypes.POINTER(ctypes.c_int32)), ("gt_label", ctypes.POINTER(ctypes.c_int32)),
                 ("D", ctypes.c_int32), ("H", ctypes.c_int32), ("O", ctypes.c_int32), ("C", ctypes.c_int32),
-                ("graph_mode", ctypes.c_int32)]
+                ("graph_mode", ctypes.c_int32), ("mask_relu", ctypes.c_int32)]
 
 
 class _Model(ctypes.Structure):
@@ -97,6 +97,9 @@ _API = {
     "gnnx_time_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper), ctypes.c_int32, ctypes.c_int32] +
                          [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
                                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "gnnx_grad_baseline": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_size_t, ctypes.c_void_p]),
+    "gnnx_denoise_edges": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_void_p]),
+    "gnnx_auc_counts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "gnnx_khop_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
     "gnnx_khop": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32] +
                   [ctypes.c_void_p] * 5 + [ctypes.c_size_t, ctypes.c_void_p]),
@@ -278,13 +281,14 @@ class MaskOptimJob:
 
     @classmethod
     def from_csr(cls, graph: DeviceGraph, neighbors: Sequence[np.ndarray], target_rows, gt_labels, state_dict, lib=None,
-                 analyze=True):
+                 analyze=True, mask_relu=False):
         """Node-mode batch whose sub-graphs are sliced ON THE DEVICE from the CSR graph (gnnx_pack_csr): the host
         only supplies the ascending k-hop neighbour list of every target (explain.py:492-501)."""
         self = cls.__new__(cls)
         self.lib = lib if lib is not None else get_library()
         self.device = graph.feat.device
         self.graph_mode = False
+        self.mask_relu = bool(mask_relu)
         self._init_model(state_dict)
         if graph.feat.shape[1] != self.D:
             raise ValueError("feature width does not match the encoder")
@@ -328,7 +332,7 @@ class MaskOptimJob:
         A = self.A.cpu().numpy()
         return [v[:n, :n].copy() for v, n in zip(self._square_views(A), self.n)]
 
-    def __init__(self, subgraphs: Sequence[Subgraph], state_dict, graph_mode=False, device=None, lib=None, analyze=True):
+    def __init__(self, subgraphs: Sequence[Subgraph], state_dict, graph_mode=False, device=None, lib=None, analyze=True, mask_relu=False):
         self.lib = lib if lib is not None else get_library()
         if device is None:
             if not torch.cuda.is_available():
@@ -336,6 +340,7 @@ class MaskOptimJob:
             device = torch.device(_DEVICE_TYPE, torch.cuda.current_device())
         self.device = torch.device(device)
         self.graph_mode = bool(graph_mode)
+        self.mask_relu = bool(mask_relu)   # mask_act = "ReLU" (explain.py:669-670): dense streaming kernels
         self._init_model(state_dict)
         self.T = len(subgraphs)
         if self.T == 0:
@@ -369,7 +374,7 @@ class MaskOptimJob:
         prob = _Problem(self.T, self.n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                         rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                         labels.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), self.D, self.H, self.O, self.C,
-                        int(self.graph_mode))
+                        int(self.graph_mode), int(getattr(self, "mask_relu", False)))
         mdl = _Model()
         for l, k in enumerate(("conv_first", "conv_block.0", "conv_last")):
             mdl.W[l] = _fptr(self.w[k + ".weight"])
@@ -459,6 +464,10 @@ class MaskOptimJob:
             self._rc = torch.empty(E, 2, dtype=torch.int32, device=dev)
             self._ev = torch.empty(E, dtype=torch.float32, device=dev)
             self._em = torch.empty(E, 2, dtype=torch.float32, device=dev)
+            self._enter()        # fill the (fixed) edge structure rc once; the values are refreshed by every gather_edges_device()
+            _check(self.lib, self.lib.gnnx_gather_edges(self.handle, self.A.data_ptr(), None, None, self._eoff_d.data_ptr(), self._rc.data_ptr(),
+                                                        None, None, self.ws.data_ptr(), self.ws_bytes, self._stream()))
+            self._leave()
 
     def gather_edges_device(self, with_mask=False) -> torch.Tensor:
         """Masked adjacency of the last forward on the upper-triangle edges of every target, as ONE device tensor [E]
@@ -471,6 +480,42 @@ class MaskOptimJob:
                                                     self._stream()))
         self._leave()
         return self._ev[:int(self._eoff[-1])]
+
+    def denoise(self, threshold_num=20, vals: Optional[torch.Tensor] = None):
+        """io_utils.denoise_graph(masked_adj, node_idx, threshold_num=k, max_component=True) (utils/io_utils.py:193-245;
+        explain.py:306-308) for every target of the batch, on the device (gnnx_denoise_edges), applied to the edge values of
+        the last run (or to `vals`, a device tensor laid out like gather_edges_device()).
+        -> (keep uint8 [E]: edge is in the denoised explanation, threshold [T], stats [T, 3]: nodes, edges, smallest node)."""
+        if vals is None:
+            vals = self.gather_edges_device()
+        self._edge_layout()
+        E = max(int(self._eoff[-1]), 1)
+        keep = torch.zeros(E, dtype=torch.uint8, device=self.device)
+        thr = torch.empty(self.T, dtype=torch.float32, device=self.device)
+        stats = torch.empty(self.T, 3, dtype=torch.int32, device=self.device)
+        self._enter()
+        _check(self.lib, self.lib.gnnx_denoise_edges(self.handle, self._eoff_d.data_ptr(), self._rc.data_ptr(), vals.data_ptr(), int(threshold_num),
+                                                     keep.data_ptr(), thr.data_ptr(), stats.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
+                                                     self._stream()))
+        self._leave()
+        return keep.cpu().numpy()[:int(self._eoff[-1])].astype(bool), thr.cpu().numpy(), stats.cpu().numpy()
+
+    def auc(self, real, vals: Optional[torch.Tensor] = None):
+        """ROC-AUC of the batch's edge scores against 0/1 ground truth `real` [E] (explain.py:325-328) from exact pair counts
+        computed on the device (gnnx_auc_counts).  -> (auc, positives, negatives)"""
+        if vals is None:
+            vals = self.gather_edges_device()
+        E = int(self._eoff[-1])
+        real_d = torch.from_numpy(np.ascontiguousarray(real, np.uint8)).to(self.device)
+        scratch = torch.empty(max(E, 1), dtype=torch.float32, device=self.device)
+        counts = torch.zeros(4, dtype=torch.int64, device=self.device)
+        self._enter()
+        _check(self.lib, self.lib.gnnx_auc_counts(vals.data_ptr(), real_d.data_ptr(), E, scratch.data_ptr(), counts.data_ptr(), self._stream()))
+        self._leave()
+        P, gt, eq, N = (int(x) for x in counts.cpu().numpy())
+        if P == 0 or N == 0:
+            raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")   # sklearn's message
+        return (gt + 0.5 * eq) / (float(P) * float(N)), P, N
 
     def fetch_edges(self, with_mask=False) -> EdgeMasks:
         """The result as edge lists (gnnx_edge_counts / gnnx_gather_edges): only the live entries cross PCIe."""
@@ -538,6 +583,20 @@ class MaskOptimJob:
         Abar = self.Abar.cpu().numpy()
         ma = [v[:n, :n].copy() for v, n in zip(self._square_views(Abar), self.n)]
         return probs.cpu().numpy()[:, :self.C], ma
+
+    def grad_baseline(self):
+        """The reference's gradient baseline (`model="grad"`, explain.py:125-133, 717-738) for every target of the batch:
+        sigmoid(|dL/dA| + |dL/dA|^T) * A of the UNMASKED sub-graph, loss = -log softmax(logits[target])[label] with the
+        plan's labels (the caller passes the PREDICTED label of each target).  -> list of [n, n] float32."""
+        out = torch.empty(self.Q, dtype=torch.float32, device=self.device)
+        self._enter()
+        _check(self.lib, self.lib.gnnx_grad_baseline(self.handle, self.A.data_ptr(), self.X.data_ptr(), out.data_ptr(), self.ws.data_ptr(),
+                                                     self.ws_bytes, self._stream()))
+        self._leave()
+        if self.device.type == _DEVICE_TYPE:
+            torch.cuda.synchronize(self.device)
+        o = out.cpu().numpy()
+        return [v[:n, :n].copy() for v, n in zip(self._square_views(o), self.n)]
 
     def time_kernel(self, hyper: Hyper, kind: int, reps: int):
         """(avg ms per launch, algorithmic bytes, algorithmic flops) of one kernel class — bench.py's roofline."""

@@ -12,10 +12,12 @@ mask-optimisation path (`model="exp"`, `unconstrained=False`, sigmoid mask, Adam
     in list order, exactly like `construct_edge_mask` (explain.py:645-652), so seeded runs reproduce the
     reference's masks.
 
-`--mask-bias` is accepted (the reference's bias mask provably stays exactly 0, see _check_supported).
+`--mask-bias` is accepted (the reference's bias mask provably stays exactly 0, see _check_supported); `mask_act="ReLU"` runs on
+the dense streaming kernels and reproduces the reference's NaN behaviour.
 Options the HIP path does not implement raise NotImplementedError (never a silent difference):
-`mask_act="ReLU"`, `--bn`, `method="att"`, non-Adam optimisers / LR schedulers,
-`unconstrained=True`, `model="grad"/"att"`, num_gc_layers != 3.
+`--bn`, `method="att"`, non-Adam optimisers / LR schedulers,
+`unconstrained=True`, `model="att"`, num_gc_layers != 3.  `model="grad"` (the gradient baseline, explain.py:125-133)
+runs on the engine too (Explainer.explain_grad).
 Plotting / TensorBoard / alignment post-processing of the reference is out of scope.
 """
 import os
@@ -34,8 +36,11 @@ COEFFS = {"size": 0.005, "feat_size": 1.0, "ent": 1.0, "feat_ent": 0.1, "grad": 
 
 
 def _check_supported(args):
-    if getattr(args, "mask_act", "sigmoid") != "sigmoid":
-        raise NotImplementedError("mask_act=%r: the HIP path implements the sigmoid mask" % args.mask_act)
+    # mask_act: "sigmoid", or "ReLU" (explain.py:669-670, 757-760) on the dense streaming kernels.  Like the reference, ReLU
+    # yields NaN masks whenever an initial mask entry lies outside (0, 1] (its entropy term takes log(1 - relu(M))) - i.e.
+    # always with the reference's own N(1, .) initialisation (tests/golden/flags_explain.npz: 100 % NaN).
+    if getattr(args, "mask_act", "sigmoid") not in ("sigmoid", "ReLU"):
+        raise NotImplementedError("mask_act=%r: 'sigmoid' and 'ReLU' are implemented" % args.mask_act)
     # --mask-bias (explain.py:657-661, 674-677) is accepted: the reference creates mask_bias = 0 and adds
     # sym(ReLU6(6 sym(mask_bias)) / 6) to the masked adjacency.  ReLU6 has zero gradient at 0 (torch: hardtanh backward is
     # strict), so mask_bias never receives a gradient, Adam leaves it at exactly 0 and the added term is exactly 0 in every
@@ -72,6 +77,8 @@ class _Result:
         self.feat_mask = feat_mask      # [T, D] final feature-mask parameters (the reference discards them, explain.py:108, 221)
         self.loss = loss                # [T, iters, 8] loss terms when logging was on
         self.edges = edges              # engine.EdgeMasks of the batch (binary adjacency)
+        self.denoised = None            # (keep [E], threshold [T], stats [T, 3]) of engine.MaskOptimJob.denoise, when requested
+        self.auc = None                 # ROC-AUC against the motif ground truth computed on the device, when requested
 
 
 class Explainer:
@@ -159,7 +166,7 @@ class Explainer:
                                                       _np(self.pred)[graph_idx], device=_ENGINE["device"])
         return self._dev_graph[graph_idx]
 
-    def explain_batch(self, node_indices=None, graph_indices=None, graph_idx=0, record_loss=False, use_graph=False):
+    def explain_batch(self, node_indices=None, graph_indices=None, graph_idx=0, record_loss=False, use_graph=False, stats=False):
         """All targets as ONE job on the GPU. Returns list of float64 masked adjacencies (reference layout).
 
         Node mode runs device-side end to end: the k-hop walk sets (gnnx_khop), the dense sub-adjacencies, feature rows
@@ -171,6 +178,8 @@ class Explainer:
         begin = time.time()
         lib, device = _ENGINE["lib"], _ENGINE["device"]
         sd = self.model.state_dict()
+        relu = getattr(self.args, "mask_act", "sigmoid") == "ReLU"
+        record_loss = record_loss and not relu          # the reference's loss is NaN there; nothing to log
         if graph_indices is not None:
             if not self.graph_mode:
                 raise ValueError("graph_indices given to a node-mode Explainer")
@@ -178,7 +187,7 @@ class Explainer:
             built = [self._graph_subgraph(g) for g in targets]
             subs = [b[0] for b in built]
             masks = [init_edge_mask(s.adj.shape[0]) for s in subs]     # same RNG stream as ExplainModule.__init__ per target
-            job = MaskOptimJob(subs, sd, graph_mode=True, device=device, lib=lib)
+            job = MaskOptimJob(subs, sd, graph_mode=True, device=device, lib=lib, mask_relu=relu)
             res = job.run(masks, _hyper(self.args, record_loss=record_loss, use_graph=use_graph and len(targets) > 1))
             job.close()
             self.last_time = time.time() - begin
@@ -209,13 +218,18 @@ class Explainer:
             else:
                 sub_dn = khop_device(graph, targets[idxs], self.n_hops, lib=lib)
                 sub_raw = torch.cat([raw[raw_off[i]:raw_off[i + 1]] for i in idxs])
-            job = MaskOptimJob.from_csr(graph, sub_dn, None, labels[idxs], sd, lib=lib)
+            job = MaskOptimJob.from_csr(graph, sub_dn, None, labels[idxs], sd, lib=lib, mask_relu=relu)
             job.set_masks_raw(sub_raw)
             job.launch(hy)
             if graph.binary:            # explain.py:209-211 multiplies by sub_adj: a no-op for a 0/1 adjacency
                 em = job.fetch_edges()
                 out = [em.dense(k) for k in range(len(idxs))]
                 last.update(feat_mask=em.feat_mask, loss=job.loss.cpu().numpy() if record_loss else None, edges=em, rows=sub_dn.rows)
+                if stats and len(idxs) == len(targets):
+                    # explain.py:306-351 on the device, on the edge lists: denoise_graph(threshold_num=20) per target and the
+                    # ROC-AUC of all targets' edge scores against the motif ground truth
+                    real = self._motif_truth(em, sub_dn.rows)
+                    last.update(denoised=job.denoise(20), auc=job.auc(real)[0])
             else:
                 res = job.fetch(hy)
                 out = [ma.astype(np.float64) * a.astype(np.float64) for ma, a in zip(res.masked_adj, job.adjacency())]
@@ -232,7 +246,29 @@ class Explainer:
             out = compute(list(range(len(targets))))
         self.last_time = time.time() - begin
         self.last_result = _Result(last.get("feat_mask"), last.get("loss"), last.get("edges"))
+        self.last_result.denoised, self.last_result.auc = last.get("denoised"), last.get("auc")
         self.last_rows = dn.rows
+        return out
+
+    def explain_grad(self, node_indices, graph_idx=0, graph_mode=False):
+        """The gradient baseline of the reference (`explain(..., model="grad")`, explain.py:125-133 with adj_feat_grad
+        :717-738) for a list of targets as ONE batched job: one forward + backward of the encoder on every unmasked
+        sub-graph, loss = -log softmax(logits[node])[predicted label], result sigmoid(|dL/dA| + |dL/dA|^T) * sub_adj
+        (float64, like the reference's float32 tensor times the float64 sub_adj)."""
+        if graph_mode or self.graph_mode:
+            # the reference indexes pred_label[node_idx_new] (explain.py:130), which only exists in node mode
+            raise NotImplementedError("the gradient baseline is a node-mode path")
+        lib = _ENGINE["lib"]
+        targets = np.asarray([int(v) for v in node_indices], np.int64)
+        graph = self._device_graph(graph_idx)
+        dn = khop_device(graph, targets, self.n_hops, lib=lib)
+        for v, n in zip(targets, dn.sizes):
+            if n == 0:
+                raise IndexError("node %d has an empty %d-hop neighbourhood" % (v, self.n_hops))
+        pred_label = np.argmax(_np(self.pred)[graph_idx][targets], axis=1)          # explain.py:105, 130: pred_label[node_idx_new]
+        job = MaskOptimJob.from_csr(graph, dn, None, pred_label, self.model.state_dict(), lib=lib, analyze=False)
+        out = [g.astype(np.float64) for g in job.grad_baseline()]                    # already multiplied by sub_adj on the device
+        job.close()
         return out
 
     def _save(self, masked_adj, node_idx):
@@ -247,8 +283,13 @@ class Explainer:
         """Explain a single node (or graph) prediction — explain.py:74-221."""
         if unconstrained:
             raise NotImplementedError("unconstrained=True is not implemented on the HIP path")
+        if model == "grad":
+            masked_adj = self.explain_grad([node_idx], graph_idx=graph_idx, graph_mode=graph_mode)[0]
+            fname = self._save(masked_adj, node_idx)
+            print("Saved adjacency matrix to ", fname)
+            return masked_adj
         if model != "exp":
-            raise NotImplementedError("model=%r: only the mask optimisation ('exp') is implemented" % model)
+            raise NotImplementedError("model=%r: the mask optimisation ('exp') and the gradient baseline ('grad') are implemented" % model)
         if graph_mode:
             masked_adj = self.explain_batch(graph_indices=[graph_idx], record_loss=self.print_training)[0]
         else:
@@ -273,22 +314,30 @@ class Explainer:
     def explain_nodes_gnn_stats(self, node_indices, args, graph_idx=0, model="exp"):
         """explain.py:295-353: batch explanation + the ROC-AUC text file (no plots).  Like the reference this needs a
         dataset with motif ground truth (make_pred_real: syn1 / syn2 / syn4) and raises otherwise."""
-        if model != "exp":
-            raise NotImplementedError("model=%r: only 'exp' is implemented" % model)
+        if model not in ("exp", "grad"):
+            raise NotImplementedError("model=%r: 'exp' and 'grad' are implemented" % model)
         node_indices = list(node_indices)
-        masked_adjs = self.explain_batch(node_indices=node_indices, graph_idx=graph_idx)
-        pred_all, real_all = [], []
-        for v, ma, new_idx in zip(node_indices, masked_adjs, self.last_rows):     # node_idx_new came with the k-hop lists
+        if model == "grad":        # explain.py:296-299 with model="grad": the baseline's masks through the same AUC evaluation
+            masked_adjs = self.explain_grad(node_indices, graph_idx=graph_idx)
+            nbs = khop_device(self._device_graph(graph_idx), np.asarray(node_indices, np.int64), self.n_hops, lib=_ENGINE["lib"])
+            self.last_rows = nbs.rows
+        else:
+            masked_adjs = self.explain_batch(node_indices=node_indices, graph_idx=graph_idx, stats=True)
+        for v, ma in zip(node_indices, masked_adjs):
             self._save(ma, v)
-            pred, real = self.make_pred_real(ma, int(new_idx))
-            pred_all.append(pred)
-            real_all.append(real)
-        from sklearn.metrics import roc_auc_score
-        pred_all, real_all = np.concatenate(pred_all), np.concatenate(real_all)
-        self.last_auc = float(roc_auc_score(real_all, pred_all))                  # raises on single-class labels, as the reference does
+        if model == "exp" and self.last_result.auc is not None:
+            self.last_auc = float(self.last_result.auc)                               # pair counts from the device (gnnx_auc_counts)
+        else:                                                                         # sharded / weighted / grad runs: on the host
+            pred_all, real_all = [], []
+            for ma, new_idx in zip(masked_adjs, self.last_rows):                      # node_idx_new came with the k-hop lists
+                pred, real = self.make_pred_real(ma, int(new_idx))
+                pred_all.append(pred)
+                real_all.append(real)
+            from sklearn.metrics import roc_auc_score
+            self.last_auc = float(roc_auc_score(np.concatenate(real_all), np.concatenate(pred_all)))   # raises on single-class labels, as the reference
         os.makedirs("log/pr", exist_ok=True)
         with open("log/pr/auc_" + self.args.dataset + "_" + model + ".txt", "w") as f:
-            f.write("dataset: {}, model: {}, auc: {}\n".format(self.args.dataset, "exp", str(self.last_auc)))
+            f.write("dataset: {}, model: {}, auc: {}\n".format(self.args.dataset, "exp", str(self.last_auc)))   # "exp" is hard-coded in the reference too (explain.py:349)
         return masked_adjs
 
     def explain_graphs(self, graph_indices):
@@ -298,6 +347,30 @@ class Explainer:
         for g, ma in zip(graph_indices, masked_adjs):
             self._save(ma, 0)
         return masked_adjs
+
+    def _motif(self):
+        ds = getattr(self.args, "dataset", None)
+        if ds in ("syn1", "syn2"):
+            return [(0, 1), (1, 2), (2, 3), (0, 3), (0, 4), (1, 4)]
+        if ds == "syn4":
+            return [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (0, 5)]
+        raise ValueError("no motif ground truth for dataset %r (explain.py:535-579 covers syn1, syn2, syn4)" % ds)
+
+    def _motif_truth(self, em, rows):
+        """make_pred_real (explain.py:535-579) on edge lists: 0/1 per upper-triangle edge of every target."""
+        motif = self._motif()
+        span = max(max(m) for m in motif)
+        real = np.zeros(int(em.eoff[-1]), np.uint8)
+        for k, st in enumerate(rows):
+            if st + span >= em.n[k]:
+                raise IndexError("motif of node_idx_new=%d reaches beyond the %d-node sub-graph" % (st, em.n[k]))
+            a, b = int(em.eoff[k]), int(em.eoff[k + 1])
+            r, c = em.rc[a:b, 0] - st, em.rc[a:b, 1] - st
+            hit = np.zeros(b - a, bool)
+            for x, y in motif:
+                hit |= (r == x) & (c == y)
+            real[a:b] = hit
+        return real
 
     def make_pred_real(self, adj, start):
         """Motif ground truth for syn1/syn2 (house) and syn4 (cycle) — explain.py:535-579.  Other datasets have none:
@@ -352,7 +425,8 @@ class ExplainModule(nn.Module):
         gt = int(lab) if graph_mode else int(lab.reshape(-1)[self._node_idx])
         self._sub = Subgraph(_np(adj)[0].astype(np.float32), _np(x)[0].astype(np.float32), gt, self._node_idx,
                              None if graph_mode else np.asarray(pred_label), None)
-        self._job = MaskOptimJob([self._sub], model.state_dict(), graph_mode=graph_mode, device=_ENGINE["device"], lib=_ENGINE["lib"])
+        self._job = MaskOptimJob([self._sub], model.state_dict(), graph_mode=graph_mode, device=_ENGINE["device"], lib=_ENGINE["lib"],
+                                 mask_relu=(args.mask_act == "ReLU"))
 
     def forward(self, node_idx, unconstrained=False, mask_features=True, marginalize=False):
         if unconstrained or marginalize or not mask_features:
@@ -371,7 +445,7 @@ class ExplainModule(nn.Module):
     def loss(self, pred, pred_label, node_idx, epoch):
         """Scalar loss of the current parameters (explain.py:740-808), evaluated on the host from the engine's
         forward; logging only — the optimisation itself is `optimize()`."""
-        m = torch.sigmoid(self.mask.detach())
+        m = torch.sigmoid(self.mask.detach()) if self.mask_act == "sigmoid" else torch.relu(self.mask.detach())   # explain.py:757-760
         fm = torch.sigmoid(self.feat_mask.detach())
         gt = self._sub.gt_label
         out = -torch.log(pred[gt]) + self.coeffs["size"] * m.sum() + self.coeffs["feat_size"] * fm.mean()

@@ -41,6 +41,8 @@ typedef struct {
     const int32_t* gt_label;   /* host [T] label used by the prediction loss (explain.py:750-753) */
     int32_t D, H, O, C;        /* input dim, hidden dim, embedding dim, classes (models.py:83-132) */
     int32_t graph_mode;        /* 0: GcnEncoderNode head (models.py:363-376); 1: GcnEncoderGraph max-pool head (models.py:269-316) */
+    int32_t mask_relu;         /* 0: mask_act = "sigmoid"; 1: mask_act = "ReLU" (explain.py:669-670, 757-760) - dense streaming
+                                * kernels only; like the reference it yields NaN masks whenever an entry of M0 lies outside (0, 1] */
 } gnnx_problem;
 
 /* Frozen encoder parameters, HOST pointers in the reference state_dict layouts:
@@ -137,6 +139,13 @@ int gnnx_pack_csr(gnnx_handle h, const int64_t* indptr, const int32_t* indices, 
 int gnnx_forward(gnnx_handle h, const float* A, const float* X, const float* M, const float* feat_mask_in,
                  float* Abar, float* probs, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Gradient baseline (`model="grad"`, explain.py:125-133, adj_feat_grad :717-738), node mode: one forward + backward of the
+ * encoder on the UNMASKED sub-graphs (no edge mask, no feature mask) with loss -log softmax(logits[target])[label], where the
+ * plan's gt_label holds the PREDICTED label of every target (explain.py:130), then
+ *     out = sigmoid(|dL/dA| + |dL/dA|^T) * A      (out: device, packed square layout). */
+int gnnx_grad_baseline(gnnx_handle h, const float* A, const float* X, float* out, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
 /* Measurement hook for bench.py: relaunch one kernel class `reps` times on the current workspace
  * state between two hipEvents on `stream`; returns the average launch duration in milliseconds and
  * the algorithmic bytes / flops of one launch.  kind: 0 = fused mask/regulariser/Adam kernel, 1/2 = forward
@@ -178,6 +187,18 @@ int gnnx_scatter_masks(gnnx_handle h, const float* raw, float* M, void* stream);
 int gnnx_edge_counts(gnnx_handle h, const float* A, int64_t* counts, void* stream);
 int gnnx_gather_edges(gnnx_handle h, const float* A, const float* Abar, const float* M, const int64_t* eoff, int32_t* rc,
                       float* abar, float* m_rc, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Post-processing of a batch of explanations on the device, on the edge lists of gnnx_gather_edges (all pointers DEVICE):
+ * gnnx_denoise_edges = io_utils.denoise_graph(masked_adj, node_idx, threshold_num=k, max_component=True)
+ * (utils/io_utils.py:193-245, called at explain.py:306-308, 364-370) for every target: keep[e] = 1 for the edges of the largest
+ * connected component of the graph made of the k heaviest undirected edges (ties at the threshold kept; first component in
+ * node order among equals); threshold [T]; stats [T][3] = nodes, edges, smallest node id of that component. */
+int gnnx_denoise_edges(gnnx_handle h, const int64_t* eoff, const int32_t* rc, const float* vals, int32_t threshold_num,
+                       uint8_t* keep, float* threshold, int32_t* stats, void* workspace, size_t workspace_bytes, void* stream);
+/* ROC-AUC of edge scores against 0/1 ground truth (explain.py:325-328: roc_auc_score over the concatenated pred / real of all
+ * targets) as exact pair counts: counts (DEVICE, 4 x uint64) = positives, #{pos > neg}, #{pos == neg}, negatives;
+ * AUC = (counts[1] + counts[2] / 2) / (counts[0] counts[3]).  pos_scratch: DEVICE, E floats. */
+int gnnx_auc_counts(const float* vals, const uint8_t* real, int64_t num_edges, float* pos_scratch, unsigned long long* counts, void* stream);
 
 const char* gnnx_last_error(void);
 const char* gnnx_version(void);

@@ -82,7 +82,8 @@ class MaskOptimOracle:
     """
 
     def __init__(self, adj, x, wts, gt_label, pred_label, node_idx, graph_mode=False,
-                 lr=0.1, mask0=None):
+                 lr=0.1, mask0=None, mask_act="sigmoid"):
+        self.mask_act = mask_act          # explain.py:603, 667-670, 757-760: "sigmoid" or "ReLU"
         self.adj = adj.reshape(1, *adj.shape).float()
         self.x = x.reshape(1, *x.shape).float()
         self.wts = {k: v.float() for k, v in wts.items()}
@@ -99,8 +100,11 @@ class MaskOptimOracle:
             self.pred_label_t = torch.tensor(np.asarray(pred_label), dtype=torch.float)
         self.masked_adj = None
 
+    def _act(self):
+        return torch.sigmoid(self.mask) if self.mask_act == "sigmoid" else torch.relu(self.mask)
+
     def _masked_adj(self):
-        s = torch.sigmoid(self.mask)
+        s = self._act()
         s = (s + s.t()) / 2
         return (self.adj * s) * self.diag_mask
 
@@ -115,7 +119,7 @@ class MaskOptimOracle:
 
     def loss(self, pred):
         pred_loss = -torch.log(pred[self.gt_label])
-        m = torch.sigmoid(self.mask)
+        m = self._act()
         size_loss = COEFF_SIZE * torch.sum(m)
         fm = torch.sigmoid(self.feat_mask)
         feat_size_loss = COEFF_FEAT_SIZE * torch.mean(fm)

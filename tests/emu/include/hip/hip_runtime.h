@@ -78,6 +78,12 @@ inline float emu_fmed3f(float a, float b, float c) { return std::fmax(std::fmin(
 #define __expf(x) std::exp(x)
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+#ifndef __HIP_MEMORY_SCOPE_AGENT
+#define __HIP_MEMORY_SCOPE_AGENT 4   // clang's __hip_atomic_load builtin is available in plain C++ too
+#endif
+inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
+inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
 

@@ -472,3 +472,108 @@ def test_raw_mask_stream_and_edge_lists(be):
     job.launch(hy)
     again = job.fetch_edges()
     assert np.array_equal(again.masked_adj, em.masked_adj) and np.array_equal(again.feat_mask, em.feat_mask)
+
+
+def test_gradient_baseline_vs_reference(be):
+    """model="grad" (explain.py:125-133, adj_feat_grad :717-738): sigmoid(|dL/dA| + |dL/dA|^T) * A of the unmasked
+    sub-graph against the REAL reference's outputs (tests/golden/flags_explain.npz), n = 6 ... 310, as one batched job."""
+    z = np.load(helpers.GOLDEN + "/flags_explain.npz")
+    ck = helpers.load_ckpt("syn1")
+    targets = [302, 309, 555] if be.name == "emu" else [302, 309, 555, 330, 400, 300]
+    subs = []
+    for t in targets:
+        nb = z[f"grad:{t}:neighbors"]
+        A, X, lab, yhat = helpers.subgraph(ck, nb)
+        new = int(np.searchsorted(nb, t))
+        subs.append(Subgraph(A, X, int(yhat[new]), new, yhat, None))        # label = the PREDICTED label of the target (explain.py:130)
+    job = be.job(subs, ck["sd"], analyze=False)
+    for s, t, got in zip(subs, targets, job.grad_baseline()):
+        r, c = np.nonzero(np.triu(s.adj, 1))
+        assert np.array_equal(got, got.T) and np.all(got[s.adj == 0] == 0)
+        want = z[f"grad:{t}:masked_adj_edges"]
+        assert np.abs(got[r, c] - want).max() <= 1e-6, (t, np.abs(got[r, c] - want).max())
+        # the information is in the logit |G_ij| + |G_ji| (the sigmoid squeezes it into [0.5, 0.54]): compare it too
+        logit = lambda v: np.log(v.astype(np.float64) / (1.0 - v.astype(np.float64)))
+        assert np.abs(logit(got[r, c]) - logit(want)).max() <= 5e-6
+
+
+@pytest.mark.parametrize("graph_mode", [False, True])
+def test_mask_act_relu_matches_restatement_and_reproduces_nan(be, graph_mode):
+    """mask_act="ReLU" (explain.py:669-670, 757-760) on the dense streaming kernels: relu(M) in the masked adjacency, the
+    size term and the entropy term.  With every mask entry inside (0, 1) the run is finite and must match the torch
+    restatement of the reference; with the reference's own N(1, .) initialisation the entropy's log(1 - relu(M)) is NaN for
+    every entry > 1 and - exactly like the reference (tests/golden/flags_explain.npz: 100 % NaN) - the result is all NaN."""
+    import torch
+    from oracle import reference_restatement as rr
+    rng = np.random.default_rng(11)
+    D, H, O, C, n = (14, 20, 20, 2, 40) if graph_mode else (10, 20, 20, 4, 37)
+    sd = helpers.random_model(rng, D, H, O, C)
+    A, X = helpers.random_graph(rng, n, D, density=0.1)
+    yhat = None if graph_mode else rng.integers(0, C, n)
+    m0 = rng.uniform(0.3, 0.7, (n, n)).astype(np.float32)
+    sg = Subgraph(A, X, 1, 0 if graph_mode else 3, yhat, m0)
+    iters = 3
+    job = engine.MaskOptimJob([sg], sd, graph_mode=graph_mode, device=be.device, lib=be.lib, mask_relu=True)
+    assert job.route()[0] == 0                                   # dense streaming kernels
+    res = job.run([m0], Hyper(num_iters=iters))
+    o = rr.MaskOptimOracle(torch.tensor(A), torch.tensor(X), {k: torch.tensor(v) for k, v in sd.items()}, 1, yhat, sg.target_row,
+                           graph_mode=graph_mode, mask0=torch.tensor(m0), mask_act="ReLU")
+    want = o.run(iters)
+    assert np.isfinite(want).all()
+    assert np.abs(res.masked_adj[0] - want).max() < 5e-6
+    assert np.abs(res.mask[0] - o.mask.detach().numpy()).max() < 5e-5
+    assert np.abs(res.feat_mask[0] - o.feat_mask.detach().numpy()).max() < 5e-5
+    bad = helpers.seeded_mask0(5, n).numpy()                     # N(1, sqrt(2 / n)): about half of the entries exceed 1
+    res = job.run([bad], Hyper(num_iters=4))
+    assert np.isnan(res.masked_adj[0]).all()
+
+
+def test_device_denoise_and_auc_equal_reference_postprocessing(be):
+    """gnnx_denoise_edges vs the node / edge sets the REAL reference's io_utils.denoise_graph(threshold_num=20) produced
+    on its own masks (stored in tests/golden/syn1_explain.npz), and gnnx_auc_counts vs sklearn's roc_auc_score on the same
+    scores - the post-processing of explain_nodes_gnn_stats (explain.py:306-351) without leaving the device."""
+    import torch
+    from sklearn.metrics import roc_auc_score
+    ck, gx = helpers.load_ckpt("syn1"), helpers.load_explain("syn1")
+    targets = [int(t) for t in gx["targets"]]
+    subs = []
+    for t in targets:
+        nb = gx[f"{t}:neighbors"]
+        A, X, lab, yhat = helpers.subgraph(ck, nb)
+        new = int(gx[f"{t}:node_idx_new"])
+        subs.append(Subgraph(A, X, int(lab[new]), new, yhat, None))
+    job = be.job(subs, ck["sd"], analyze=False)
+    job._edge_layout()
+    # feed the REFERENCE's masks (edge values in the layout of gather_edges_device: upper triangle, row-major)
+    vals = []
+    for t, s in zip(targets, subs):
+        rc = gx[f"{t}:edge_rc"]
+        d = np.zeros_like(s.adj)
+        d[rc[:, 0], rc[:, 1]] = gx[f"{t}:masked_adj_edges"]
+        r, c = np.nonzero(np.triu(s.adj, 1))
+        vals.append(d[r, c])
+    vals = np.concatenate(vals).astype(np.float32)
+    vals_d = torch.from_numpy(vals).to(job.device)
+    keep, thr, stats = job.denoise(20, vals_d)
+    rc_all = job._rc.cpu().numpy()
+    for k, t in enumerate(targets):
+        a, b = job._eoff[k], job._eoff[k + 1]
+        kept = rc_all[a:b][keep[a:b]]
+        want_e = gx[f"{t}:denoised_edges"]
+        assert np.array_equal(kept[np.lexsort((kept[:, 1], kept[:, 0]))], want_e), t
+        assert np.array_equal(np.unique(kept), gx[f"{t}:denoised_nodes"]) and stats[k][0] == len(gx[f"{t}:denoised_nodes"])
+        assert stats[k][1] == len(want_e)
+        pos = np.sort(vals[a:b][vals[a:b] > 0])
+        assert thr[k] == pos[-min(20, len(pos))]
+    # AUC: motif ground truth of make_pred_real (explain.py:535-579) as 0/1 per edge
+    real = np.zeros(len(vals), np.uint8)
+    motif = {(0, 1), (1, 2), (2, 3), (0, 3), (0, 4), (1, 4)}
+    for k, (t, s) in enumerate(zip(targets, subs)):
+        a, b = job._eoff[k], job._eoff[k + 1]
+        st = s.target_row
+        for e in range(a, b):
+            r, c = rc_all[e]
+            real[e] = (int(r) - st, int(c) - st) in motif
+    auc, P, N = job.auc(real, vals_d)
+    assert P == int(real.sum()) and N == len(real) - P
+    assert abs(auc - roc_auc_score(real, vals)) < 1e-12

@@ -87,14 +87,61 @@ def test_batched_list_api_equals_sequential_explains(tmp_path, emu_engine):
 
 
 def test_unsupported_options_raise(tmp_path):
-    for kw in ({"mask_act": "ReLU"}, {"bn": True}, {"opt": "sgd"}, {"num_gc_layers": 4}):
+    for kw in ({"mask_act": "tanh"}, {"bn": True}, {"opt": "sgd"}, {"num_gc_layers": 4}):
         with pytest.raises(NotImplementedError):
             _explainer(tmp_path, 3, **kw)
     ck, args, ex = _explainer(tmp_path, 3)
     with pytest.raises(NotImplementedError):
         ex.explain(302, unconstrained=True)
     with pytest.raises(NotImplementedError):
-        ex.explain(302, model="grad")
+        ex.explain(302, model="att")
+
+
+def test_grad_baseline_and_mask_bias_through_the_api_emulated(tmp_path, emu_engine):
+    """`explain(node, model="grad")` (explain.py:125-133) and `--mask-bias` (explain.py:657-661, 674-677) against the REAL
+    reference's outputs under those options (tests/golden/flags_explain.npz)."""
+    z = np.load(helpers.GOLDEN + "/flags_explain.npz")
+    ck, args, ex = _explainer(tmp_path, 300)
+    ma = ex.explain(309, model="grad")
+    nb = z["grad:309:neighbors"]
+    r, c = np.nonzero(np.triu(ck["adj"][np.ix_(nb, nb)], 1))
+    assert ma.dtype == np.float64 and ma.shape == (len(nb), len(nb)) and np.array_equal(ma, ma.T)
+    assert np.abs(ma[r, c] - z["grad:309:masked_adj_edges"]).max() <= 1e-6
+    assert os.path.exists(os.path.join(str(tmp_path), "masked_adj_syn1_base_h20_o20_explainnode_idx_309graph_idx_-1.npy"))
+    # --mask-bias: the reference's bias mask stays exactly 0, its output equals the plain run bit for bit
+    ck, args, ex = _explainer(tmp_path, 300, mask_bias=True)
+    torch.manual_seed(1000 + 302)
+    ma = ex.explain(302)
+    nb = helpers.load_explain("syn1")["302:neighbors"]
+    r, c = np.nonzero(np.triu(ck["adj"][np.ix_(nb, nb)], 1))
+    assert np.abs(ma[r, c] - z["mask_bias:302:masked_adj_edges"]).max() <= TOL
+    gx = helpers.load_explain("syn1")                         # ... and the fixture of the flag run IS the plain run's output
+    plain = np.zeros((len(nb), len(nb)), np.float32)
+    plain[gx["302:edge_rc"][:, 0], gx["302:edge_rc"][:, 1]] = gx["302:masked_adj_edges"]
+    assert np.array_equal(plain[r, c], z["mask_bias:302:masked_adj_edges"])
+
+
+def test_gnn_stats_device_auc_and_denoise_equal_host_postprocessing_emulated(tmp_path, emu_engine, monkeypatch):
+    """explain_nodes_gnn_stats (explain.py:295-353): the ROC-AUC from the device's pair counts equals sklearn's on the returned
+    masks, and the device's denoised edge sets equal io_utils.denoise_graph(threshold_num=20) on them."""
+    from sklearn.metrics import roc_auc_score
+    from gnn_model_explainer_amd.utils import io_utils
+    monkeypatch.chdir(tmp_path)
+    ck, args, ex = _explainer(tmp_path, 3)
+    nodes = [400, 405, 555, 600]
+    torch.manual_seed(3)
+    out = ex.explain_nodes_gnn_stats(nodes, args)
+    pr = [ex.make_pred_real(ma, int(st)) for ma, st in zip(out, ex.last_rows)]
+    want = roc_auc_score(np.concatenate([p[1] for p in pr]), np.concatenate([p[0] for p in pr]))
+    assert abs(ex.last_auc - want) < 1e-12 and os.path.exists("log/pr/auc_syn1_exp.txt")
+    keep, thr, stats = ex.last_result.denoised
+    em = ex.last_result.edges
+    for k, (ma, st) in enumerate(zip(out, ex.last_rows)):
+        G = io_utils.denoise_graph(ma, int(st), threshold_num=20)
+        a, b = em.eoff[k], em.eoff[k + 1]
+        kept = em.rc[a:b][keep[a:b]]
+        assert sorted(map(tuple, kept.tolist())) == sorted((min(u, v), max(u, v)) for u, v in G.edges())
+        assert stats[k][0] == G.number_of_nodes() and stats[k][1] == G.number_of_edges()
 
 
 def test_explain_module_surface_emulated(tmp_path, emu_engine):
@@ -133,6 +180,23 @@ def test_explain_nodes_gnn_stats_auc_on_gpu(tmp_path, monkeypatch):
     out = ex.explain_nodes_gnn_stats(range(400, 700, 5), args)
     assert len(out) == 60 and ex.last_auc > 0.8
     assert os.path.exists("log/pr/auc_syn1_exp.txt")
+
+
+@pytest.mark.gpu
+def test_grad_baseline_batch_and_auc_on_gpu(tmp_path, monkeypatch):
+    """The gradient baseline through the batched API on the GPU: golden parity on six targets (n = 6 ... 310) and the
+    reference's AUC evaluation (explain_nodes_gnn_stats(..., model="grad"))."""
+    monkeypatch.chdir(tmp_path)
+    z = np.load(helpers.GOLDEN + "/flags_explain.npz")
+    ck, args, ex = _explainer(tmp_path, 100)
+    targets = [302, 309, 555, 330, 400, 300]
+    for t, ma in zip(targets, ex.explain_grad(targets)):
+        nb = z[f"grad:{t}:neighbors"]
+        r, c = np.nonzero(np.triu(ck["adj"][np.ix_(nb, nb)], 1))
+        assert np.abs(ma[r, c] - z[f"grad:{t}:masked_adj_edges"]).max() <= 1e-6
+    out = ex.explain_nodes_gnn_stats(range(400, 700, 5), args, model="grad")
+    assert len(out) == 60 and 0.5 < ex.last_auc <= 1.0
+    assert os.path.exists("log/pr/auc_syn1_grad.txt")
 
 
 def _write_reference_format_ckpt(tmp, name="syn1"):
