@@ -89,7 +89,7 @@ struct gnnx_plan_s {
     double sum_n2 = 0;
     // workspace offsets in bytes
     size_t o_mM, o_vM, o_XT, o_Zraw, o_g3, o_z3p, o_U[3], o_UT[3], o_rn[3], o_dZ[3], o_dZT[3], o_dE, o_arg, o_df, o_f[2], o_mf, o_vf,
-        o_probs, ws_bytes;
+        o_probs, o_Xn[2], o_XnT[2], o_bnr[2], ws_bytes;
     hipGraphExec_t gexec = nullptr;
     GraphKey gkey{};
 };
@@ -211,7 +211,7 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
     h->order.resize(T);
     for (int t = 0; t < T; ++t) h->order[t] = t;
     std::stable_sort(h->order.begin(), h->order.end(), [&](int a, int b) { return h->meta[a].ld > h->meta[b].ld; });
-    const bool resident_ok = !prob->graph_mode && prob->C <= RES_CMAX && !prob->mask_relu;
+    const bool resident_ok = !prob->graph_mode && prob->C <= RES_CMAX && !prob->mask_relu && !prob->bn;
     if (const char* env = std::getenv("GNNX_RESIDENT_MAX_BLOCKS")) {  // tuning knob, see include/gnnx.h
         const int v = std::atoi(env);
         h->res_nbmax = v < 0 ? 0 : (v > RES_NBMAX ? RES_NBMAX : v);
@@ -314,6 +314,11 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
     h->o_mf = take(sizeof(float) * T * FS);
     h->o_vf = take(sizeof(float) * T * FS);
     h->o_probs = take(sizeof(float) * T * CMAX);
+    for (int l = 0; l < 2; ++l) {  // --bn: standardised activations of the two hidden layers and 1 / std per row
+        h->o_Xn[l] = prob->bn ? take(rb32) : 0;
+        h->o_XnT[l] = prob->bn ? take(rb32) : 0;
+        h->o_bnr[l] = prob->bn ? take(rb1) : 0;
+    }
     h->ws_bytes = o;
     *out = h;
     return 0;
@@ -393,6 +398,12 @@ static Params make_params(gnnx_handle h, const gnnx_hyper* hy, const float* A, c
     p.mf = reinterpret_cast<float*>(w + h->o_mf);
     p.vf = reinterpret_cast<float*>(w + h->o_vf);
     p.probs = reinterpret_cast<float*>(w + h->o_probs);
+    p.bn = h->prob.bn;
+    for (int l = 0; l < 2; ++l) {
+        p.Xn[l] = h->prob.bn ? reinterpret_cast<float*>(w + h->o_Xn[l]) : nullptr;
+        p.XnT[l] = h->prob.bn ? reinterpret_cast<float*>(w + h->o_XnT[l]) : nullptr;
+        p.bnr[l] = h->prob.bn ? reinterpret_cast<float*>(w + h->o_bnr[l]) : nullptr;
+    }
     p.loss = loss;
     p.wts = h->d_wts;
     p.D = h->prob.D;
@@ -668,7 +679,7 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
     HIPCK(hipMemcpyAsync(h->nnz.data(), h->d_nnz, sizeof(int32_t) * (h->prob.graph_mode ? 2 : 5) * T, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
     const bool graph = h->prob.graph_mode != 0;
-    if (h->prob.C > RES_CMAX || h->prob.mask_relu) return 0;   // mask_act = "ReLU" runs on the dense streaming kernels only
+    if (h->prob.C > RES_CMAX || h->prob.mask_relu || h->prob.bn) return 0;   // mask_act = "ReLU" and --bn run on the dense streaming kernels only
     int sparse_on = 1;
     if (const char* env = std::getenv("GNNX_SPARSE_RESIDENT")) sparse_on = std::atoi(env);
     if (!sparse_on) return 0;
@@ -887,6 +898,7 @@ extern "C" int gnnx_grad_baseline(gnnx_handle h, const float* A, const float* X,
                                   void* stream) {
     if (!h || !A || !X || !out || !workspace) return fail("null argument");
     if (h->prob.graph_mode) return fail("the gradient baseline is a node-mode path (the reference indexes pred_label[node_idx], explain.py:130)");
+    if (h->prob.bn) return fail("the gradient baseline with --bn is not implemented");
     if (workspace_bytes < h->ws_bytes) return fail("workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     // the streaming forward / backward with Abar := A (unmasked adjacency, diagonal included as the reference's model(x, adj))

@@ -80,6 +80,14 @@ struct Params {
     float* probs;       // softmax of the head [T][CMAX]
     float* loss;        // [T][num_iters][NLOSS] or null
     const float* wts;   // packed model block
+    // --bn (apply_bn, models.py:222-228, 241-253): after the ReLU of the two hidden layers every node's activation row is
+    // standardised over its features (a fresh BatchNorm1d(num_nodes) in training mode: biased variance, eps 1e-5, weight 1,
+    // bias 0).  Xn[l] / XnT[l] = the standardised activations of layer l (what the next layer, the head and the G product
+    // consume instead of relu(U[l])), bnr[l] = 1 / std per row.  Null unless bn.
+    float* Xn[2];
+    float* XnT[2];
+    float* bnr[2];
+    int32_t bn;
     int32_t D, H, O, C;
     int32_t graph_mode;
     int32_t num_iters;
@@ -134,6 +142,45 @@ __device__ __forceinline__ void rowlocal_backward(const float (&du)[4], const fl
     }
 }
 
+constexpr float BN_EPS = 1e-5f;
+// sum over the 8 lanes (4 columns each) that share a row in the epilogues
+__device__ __forceinline__ float row8_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    return v;
+}
+// forward of apply_bn for one row: a[j] (columns cg + j < dout, others 0) -> x_hat[j]; returns 1 / std
+__device__ __forceinline__ float bn_forward_row(float (&a)[4], int cg, int dout) {
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += (cg + j < dout) ? a[j] : 0.0f;
+    const float mu = row8_sum(s) / (float)dout;
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a[j] = (cg + j < dout) ? a[j] - mu : 0.0f;
+        q = fmaf(a[j], a[j], q);
+    }
+    const float rs = 1.0f / sqrtf(row8_sum(q) / (float)dout + BN_EPS);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] *= rs;
+    return rs;
+}
+// backward of apply_bn for one row: dx[j] = dL/dx_hat -> dL/da = rs (dx - mean(dx) - x_hat mean(dx x_hat))
+__device__ __forceinline__ void bn_backward_row(float (&dx)[4], const float (&xh)[4], float rs, int cg, int dout) {
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float d = (cg + j < dout) ? dx[j] : 0.0f;
+        s1 += d;
+        s2 = fmaf(d, xh[j], s2);
+    }
+    const float m1 = row8_sum(s1) / (float)dout, m2 = row8_sum(s2) / (float)dout;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dx[j] = (cg + j < dout) ? rs * (dx[j] - m1 - xh[j] * m2) : 0.0f;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Masked-adjacency contraction + fused row-local epilogue: one workgroup (4 waves) per 32-row block; the K
 // range (all ld columns of Abar) is split over the 4 waves and reduced through LDS.  (A 128-row / 16-B-per-lane
@@ -152,7 +199,7 @@ struct ConvShared {
 template <int MODE>
 __device__ __forceinline__ void conv_epilogue(const Params& p, const ConvTile& tl, const TargetMeta& tm, ConvShared& sh,
                                               float (&z4)[4], int irow, int slot, const f32x4& pre_a, const f32x4& pre_b,
-                                              const f32x4& pre_c, const int (&pre_ar)[4], float pre_rn) {
+                                              const f32x4& pre_c, const int (&pre_ar)[4], float pre_rn, const f32x4& pre_x, float pre_rs) {
     constexpr int layer = (MODE == FWD1 || MODE == BWD1) ? 0 : (MODE == FWD2 || MODE == BWD2) ? 1 : 2;
     constexpr bool IS_FWD = (MODE == FWD1 || MODE == FWD2 || MODE == FWD3);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -200,13 +247,27 @@ __device__ __forceinline__ void conv_epilogue(const Params& p, const ConvTile& t
             UT[(size_t)(cg + j) * ld + irow] = u;
         }
         if ((tid & 7) == 0) p.rn[layer][grow] = rnorm;
+        float xh[4];  // the layer's output activation: relu(U), standardised per row with --bn
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xh[j] = fmaxf(y[j] / rnorm, 0.0f);
+        if (MODE != FWD3 && p.bn) {
+            const float rs = bn_forward_row(xh, cg, dout);
+            float* Xn = p.Xn[layer] + grow * FS;
+            float* XnT = p.XnT[layer] + tm.offR * FS;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Xn[cg + j] = xh[j];
+                XnT[(size_t)(cg + j) * ld + irow] = xh[j];
+            }
+            if ((tid & 7) == 0) p.bnr[layer][grow] = rs;
+        }
         if (MODE == FWD2 && !p.graph_mode) {
             // node mode reads only row t of layer 3 (explain.py:713): this row set's share of
-            // Z3[t] = sum_k Abar[t][k] relu(U2[k]) is reduced here so the head never walks all n rows
+            // Z3[t] = sum_k Abar[t][k] X2[k] is reduced here so the head never walks all n rows
             float part[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                part[j] = pre_rn * fmaxf(y[j] / rnorm, 0.0f);
+                part[j] = pre_rn * xh[j];
                 part[j] += __shfl_xor(part[j], 8);
                 part[j] += __shfl_xor(part[j], 16);
                 part[j] += __shfl_xor(part[j], 32);
@@ -232,8 +293,15 @@ __device__ __forceinline__ void conv_epilogue(const Params& p, const ConvTile& t
             float dx = (MODE == BWD3) ? 0.0f : z4[j];
             u[j] = pre_a[j];
             if (c < dout && pre_ar[j] == irow) dx += pre_b[j];
-            if (layer < 2) dx = (u[j] > 0.0f) ? dx : 0.0f;
             du[j] = (c < dout) ? dx : 0.0f;
+        }
+        if (layer < 2) {
+            if (p.bn) {  // through the row-wise standardisation first (dx is the gradient w.r.t. the standardised activation)
+                const float xh4[4] = {pre_x[0], pre_x[1], pre_x[2], pre_x[3]};
+                bn_backward_row(du, xh4, pre_rs, cg, dout);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) du[j] = (u[j] > 0.0f) ? du[j] : 0.0f;
         }
         rowlocal_backward(du, u, pre_rn, dout, row, cg, sh.zs, sh.wl, dz);
         float* dZ = p.dZ[layer] + grow * FS;
@@ -271,7 +339,7 @@ __device__ __forceinline__ void conv_epilogue(const Params& p, const ConvTile& t
 template <int MODE>
 __device__ __forceinline__ void conv_epilogue_operands(const Params& p, const ConvTile& tl, const TargetMeta& tm, int irow,
                                                        int cg, f32x4& pre_a, f32x4& pre_b, f32x4& pre_c, int (&pre_ar)[4],
-                                                       float& pre_rn) {
+                                                       float& pre_rn, f32x4& pre_x, float& pre_rs) {
     constexpr int layer = (MODE == FWD1 || MODE == BWD1) ? 0 : (MODE == FWD2 || MODE == BWD2) ? 1 : 2;
     constexpr bool IS_FWD = (MODE == FWD1 || MODE == FWD2 || MODE == FWD3);
     const size_t grow = (size_t)tm.offR + irow;
@@ -285,6 +353,10 @@ __device__ __forceinline__ void conv_epilogue_operands(const Params& p, const Co
         for (int j = 0; j < 4; ++j) pre_ar[j] = p.argrow[(tl.t * 3 + layer) * FS + cg + j];
         pre_rn = p.rn[layer][grow];
         if (MODE == BWD1) pre_c = *reinterpret_cast<const f32x4*>(p.Zraw + grow * FS + cg);
+        if (layer < 2 && p.bn) {
+            pre_x = *reinterpret_cast<const f32x4*>(p.Xn[layer] + grow * FS + cg);
+            pre_rs = p.bnr[layer][grow];
+        }
     }
 }
 
@@ -299,6 +371,7 @@ __device__ __forceinline__ void conv_stage_weights(const Params& p, const ConvTi
 
 template <int MODE>
 __device__ __forceinline__ const float* conv_b_source(const Params& p) {
+    if (p.bn && (MODE == FWD2 || MODE == FWD3)) return p.Xn[MODE == FWD2 ? 0 : 1];  // standardised activations, no ReLU on top
     return (MODE == FWD1) ? p.X : (MODE == FWD2) ? p.U[0] : (MODE == FWD3) ? p.U[1] : (MODE == BWD2) ? p.dZ[2] : p.dZ[1];
 }
 
@@ -318,14 +391,16 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
     const int irow = row0 + row;
     f32x4 pre_a = {0.0f, 0.0f, 0.0f, 0.0f}, pre_b = pre_a, pre_c = pre_a;
     int pre_ar[4] = {-1, -1, -1, -1};
-    float pre_rn = 1.0f;
-    conv_epilogue_operands<MODE>(p, tl, tm, irow, cg, pre_a, pre_b, pre_c, pre_ar, pre_rn);
+    float pre_rn = 1.0f, pre_rs = 1.0f;
+    f32x4 pre_x = pre_a;
+    conv_epilogue_operands<MODE>(p, tl, tm, irow, cg, pre_a, pre_b, pre_c, pre_ar, pre_rn, pre_x, pre_rs);
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     if (MODE != BWD3) {
         const float* Bsrc = conv_b_source<MODE>(p) + tm.offR * FS + li;
+        const bool relu_b = (MODE == FWD2 || MODE == FWD3) && !p.bn;
         const int kchunk = ld >> 2;  // multiple of 8
         if (ld < 256) {
             // small targets (latency-bound): lane (i = li, half h) reads 16 B of row row0+i,
@@ -352,7 +427,7 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float bb = b[sl][e];
-                            if (MODE == FWD2 || MODE == FWD3) bb = fmaxf(bb, 0.0f);
+                            if (relu_b) bb = fmaxf(bb, 0.0f);
                             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sl][e], bb, acc, 0, 0, 0);
                         }
                         if (kk + 8 * (sl + NB) < kchunk) load(sl, kk + 8 * (sl + NB));
@@ -379,7 +454,7 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     float bb = b[u];
-                    if (MODE == FWD2 || MODE == FWD3) bb = fmaxf(bb, 0.0f);
+                    if (relu_b) bb = fmaxf(bb, 0.0f);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bb, acc, 0, 0, 0);
                 }
             };
@@ -406,7 +481,7 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
         for (int w = 0; w < 4; ++w) s += sh.red[(w * TILE + row) * 33 + cg + j];
         z4[j] = s;
     }
-    conv_epilogue<MODE>(p, tl, tm, sh, z4, irow, tl.rb, pre_a, pre_b, pre_c, pre_ar, pre_rn);
+    conv_epilogue<MODE>(p, tl, tm, sh, z4, irow, tl.rb, pre_a, pre_b, pre_c, pre_ar, pre_rn, pre_x, pre_rs);
 }
 
 // softmax head shared by both modes: e[96] (concatenated embedding) -> probs, g = p - onehot, dE = Wp^T g.
@@ -477,10 +552,11 @@ __global__ __launch_bounds__(256) void k_head(Params p, int iter) {
         float best = -3.0e38f;
         int barg = 0;
         if (c < dims[l]) {
-            const float* UT = p.UT[l] + tm.offR * FS + (size_t)c * tm.ld;
+            const bool std_act = p.bn && l < 2;   // --bn: the pooled activation is the standardised one
+            const float* UT = (std_act ? p.XnT[l] : p.UT[l]) + tm.offR * FS + (size_t)c * tm.ld;
             for (int i = lane; i < tm.n; i += 64) {
                 float v = UT[i];
-                if (l < 2) v = fmaxf(v, 0.0f);
+                if (l < 2 && !std_act) v = fmaxf(v, 0.0f);
                 if (v > best) { best = v; barg = i; }
             }
 #pragma unroll
@@ -528,12 +604,21 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
     // operands of the later phases, loaded up-front (their latency hides under the mat-vec below)
     const int row = tid >> 3, cg = (tid & 7) * 4;
     const int i = tl.rb * TILE + row;
-    const float u1t = (tid < 32) ? U1[(size_t)tr * FS + tid] : 0.0f;
-    const float u2t = (tid < 32) ? U2[(size_t)tr * FS + tid] : 0.0f;
+    // row t of the two hidden activations: relu(U), or the standardised rows with --bn (no ReLU on top)
+    const float* X1a = p.bn ? p.Xn[0] + tm.offR * FS : U1;
+    const float* X2a = p.bn ? p.Xn[1] + tm.offR * FS : U2;
+    const float u1t = (tid < 32) ? X1a[(size_t)tr * FS + tid] : 0.0f;
+    const float u2t = (tid < 32) ? X2a[(size_t)tr * FS + tid] : 0.0f;
     const float b3 = (tid < 32) ? p.wts[WT_B + 2 * 32 + tid] : 0.0f;
     const float ait = Ab[(size_t)tr * ld + i];  // Abar[t][i] == Abar[i][t]
     const f32x4 u2i = *reinterpret_cast<const f32x4*>(U2 + (size_t)i * FS + cg);
     const float rn2i = p.rn[1][tm.offR + i];
+    f32x4 x2i = u2i;      // --bn: standardised row i of layer 2 and its 1 / std
+    float rs2i = 1.0f;
+    if (p.bn) {
+        x2i = *reinterpret_cast<const f32x4*>(p.Xn[1] + (tm.offR + i) * FS + cg);
+        rs2i = p.bnr[1][tm.offR + i];
+    }
 
     // Z3[t][c] = sum_k Abar[t][k] relu(U2[k][c]): the per-row-block partials were reduced by k_conv<FWD2>;
     // sum them in a fixed order (8 slices x 32 columns)
@@ -569,8 +654,8 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
             const float u = y / rnorm;
             y3[tid] = u;
             e[64 + tid] = u;
-            e[tid] = (tid < p.H) ? fmaxf(u1t, 0.0f) : 0.0f;
-            e[32 + tid] = (tid < p.H) ? fmaxf(u2t, 0.0f) : 0.0f;
+            e[tid] = (tid < p.H) ? (p.bn ? u1t : fmaxf(u1t, 0.0f)) : 0.0f;
+            e[32 + tid] = (tid < p.H) ? (p.bn ? u2t : fmaxf(u2t, 0.0f)) : 0.0f;
         }
         if (tid == 0) sr3 = rnorm;
     }
@@ -604,12 +689,17 @@ __global__ __launch_bounds__(256) void k_node_head(Params p, const ConvTile* til
     for (int j = 0; j < 4; ++j) {
         const int c = cg + j;
         u[j] = u2i[j];
-        gpart = fmaf(dz3[c], fmaxf(u[j], 0.0f), gpart);  // dz3[c] == 0 for c >= H
+        gpart = fmaf(dz3[c], p.bn ? x2i[j] : fmaxf(u[j], 0.0f), gpart);  // dz3[c] == 0 for c >= H
         float dx = ait * dz3[c];
         if (i == tr) dx += dEs[32 + c];
-        dx = (u[j] > 0.0f) ? dx : 0.0f;
         du[j] = (c < p.H) ? dx : 0.0f;
     }
+    if (p.bn) {
+        const float xh4[4] = {x2i[0], x2i[1], x2i[2], x2i[3]};
+        bn_backward_row(du, xh4, rs2i, cg, p.H);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) du[j] = (u[j] > 0.0f) ? du[j] : 0.0f;
     gpart += __shfl_xor(gpart, 1);
     gpart += __shfl_xor(gpart, 2);
     gpart += __shfl_xor(gpart, 4);
@@ -706,7 +796,7 @@ __global__ __launch_bounds__(256, 4) void k_mask(Params p, const MaskTile* tiles
         for (int l = 0; l < NL; ++l) {
             const int d = (l == 0) ? p.D : p.H;
             const float* zT = p.dZT[l] + ro;
-            const float* xT = (l == 0) ? p.XT + ro : p.UT[l - 1] + ro;
+            const float* xT = (l == 0) ? p.XT + ro : (p.bn ? p.XnT[l - 1] : p.UT[l - 1]) + ro;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int k = 2 * (wave + 4 * u) + h;  // < 32; columns >= d hold zeros
@@ -721,7 +811,7 @@ __global__ __launch_bounds__(256, 4) void k_mask(Params p, const MaskTile* tiles
                         const float phi = (k < p.D) ? sigmoidf_(fcur[k]) : 0.0f;
                         c *= phi;
                         e *= phi;
-                    } else {
+                    } else if (!p.bn) {   // --bn: the standardised activations are the layer inputs as they are
                         c = fmaxf(c, 0.0f);
                         e = fmaxf(e, 0.0f);
                     }

@@ -30,7 +30,7 @@ class _Problem(ctypes.Structure):
     _fields_ = [("num_targets", ctypes.c_int32), ("n", ctypes.POINTER(ctypes.c_int32)),
                 ("target_row", ctypes.POINTER(ctypes.c_int32)), ("gt_label", ctypes.POINTER(ctypes.c_int32)),
                 ("D", ctypes.c_int32), ("H", ctypes.c_int32), ("O", ctypes.c_int32), ("C", ctypes.c_int32),
-                ("graph_mode", ctypes.c_int32), ("mask_relu", ctypes.c_int32)]
+                ("graph_mode", ctypes.c_int32), ("mask_relu", ctypes.c_int32), ("bn", ctypes.c_int32)]
 
 
 class _Model(ctypes.Structure):
@@ -281,7 +281,7 @@ class MaskOptimJob:
 
     @classmethod
     def from_csr(cls, graph: DeviceGraph, neighbors: Sequence[np.ndarray], target_rows, gt_labels, state_dict, lib=None,
-                 analyze=True, mask_relu=False):
+                 analyze=True, mask_relu=False, bn=False):
         """Node-mode batch whose sub-graphs are sliced ON THE DEVICE from the CSR graph (gnnx_pack_csr): the host
         only supplies the ascending k-hop neighbour list of every target (explain.py:492-501)."""
         self = cls.__new__(cls)
@@ -289,6 +289,7 @@ class MaskOptimJob:
         self.device = graph.feat.device
         self.graph_mode = False
         self.mask_relu = bool(mask_relu)
+        self.bn = bool(bn)
         self._init_model(state_dict)
         if graph.feat.shape[1] != self.D:
             raise ValueError("feature width does not match the encoder")
@@ -332,7 +333,7 @@ class MaskOptimJob:
         A = self.A.cpu().numpy()
         return [v[:n, :n].copy() for v, n in zip(self._square_views(A), self.n)]
 
-    def __init__(self, subgraphs: Sequence[Subgraph], state_dict, graph_mode=False, device=None, lib=None, analyze=True, mask_relu=False):
+    def __init__(self, subgraphs: Sequence[Subgraph], state_dict, graph_mode=False, device=None, lib=None, analyze=True, mask_relu=False, bn=False):
         self.lib = lib if lib is not None else get_library()
         if device is None:
             if not torch.cuda.is_available():
@@ -341,6 +342,7 @@ class MaskOptimJob:
         self.device = torch.device(device)
         self.graph_mode = bool(graph_mode)
         self.mask_relu = bool(mask_relu)   # mask_act = "ReLU" (explain.py:669-670): dense streaming kernels
+        self.bn = bool(bn)                 # --bn (models.py:222-228): dense streaming kernels
         self._init_model(state_dict)
         self.T = len(subgraphs)
         if self.T == 0:
@@ -374,7 +376,7 @@ class MaskOptimJob:
         prob = _Problem(self.T, self.n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                         rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                         labels.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), self.D, self.H, self.O, self.C,
-                        int(self.graph_mode), int(getattr(self, "mask_relu", False)))
+                        int(self.graph_mode), int(getattr(self, "mask_relu", False)), int(getattr(self, "bn", False)))
         mdl = _Model()
         for l, k in enumerate(("conv_first", "conv_block.0", "conv_last")):
             mdl.W[l] = _fptr(self.w[k + ".weight"])

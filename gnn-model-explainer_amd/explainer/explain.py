@@ -13,9 +13,9 @@ mask-optimisation path (`model="exp"`, `unconstrained=False`, sigmoid mask, Adam
     reference's masks.
 
 `--mask-bias` is accepted (the reference's bias mask provably stays exactly 0, see _check_supported); `mask_act="ReLU"` runs on
-the dense streaming kernels and reproduces the reference's NaN behaviour.
+the dense streaming kernels and reproduces the reference's NaN behaviour; `--bn` runs on the dense streaming kernels.
 Options the HIP path does not implement raise NotImplementedError (never a silent difference):
-`--bn`, `method="att"`, non-Adam optimisers / LR schedulers,
+`method="att"`, non-Adam optimisers / LR schedulers,
 `unconstrained=True`, `model="att"`, num_gc_layers != 3.  `model="grad"` (the gradient baseline, explain.py:125-133)
 runs on the engine too (Explainer.explain_grad).
 Plotting / TensorBoard / alignment post-processing of the reference is out of scope.
@@ -46,8 +46,8 @@ def _check_supported(args):
     # strict), so mask_bias never receives a gradient, Adam leaves it at exactly 0 and the added term is exactly 0 in every
     # epoch: the reference's outputs with and without the flag are bit-identical (pinned by tests/golden/flags_explain.npz,
     # produced by running the reference with mask_bias=True).  The same kernels therefore serve both settings.
-    if getattr(args, "bn", False):
-        raise NotImplementedError("--bn is not implemented on the HIP path")
+    # --bn (apply_bn, models.py:222-228, 241-253) runs on the dense streaming kernels (forward and backward through the row-wise
+    # standardisation; pinned to the reference by tests/golden/flags_explain.npz)
     if getattr(args, "method", "base") != "base":
         raise NotImplementedError("method=%r: only 'base' is implemented on the HIP path" % args.method)
     if getattr(args, "opt", "adam") != "adam" or getattr(args, "opt_scheduler", "none") != "none":
@@ -179,6 +179,7 @@ class Explainer:
         lib, device = _ENGINE["lib"], _ENGINE["device"]
         sd = self.model.state_dict()
         relu = getattr(self.args, "mask_act", "sigmoid") == "ReLU"
+        bn = bool(getattr(self.args, "bn", False))
         record_loss = record_loss and not relu          # the reference's loss is NaN there; nothing to log
         if graph_indices is not None:
             if not self.graph_mode:
@@ -187,7 +188,7 @@ class Explainer:
             built = [self._graph_subgraph(g) for g in targets]
             subs = [b[0] for b in built]
             masks = [init_edge_mask(s.adj.shape[0]) for s in subs]     # same RNG stream as ExplainModule.__init__ per target
-            job = MaskOptimJob(subs, sd, graph_mode=True, device=device, lib=lib, mask_relu=relu)
+            job = MaskOptimJob(subs, sd, graph_mode=True, device=device, lib=lib, mask_relu=relu, bn=bn)
             res = job.run(masks, _hyper(self.args, record_loss=record_loss, use_graph=use_graph and len(targets) > 1))
             job.close()
             self.last_time = time.time() - begin
@@ -218,7 +219,7 @@ class Explainer:
             else:
                 sub_dn = khop_device(graph, targets[idxs], self.n_hops, lib=lib)
                 sub_raw = torch.cat([raw[raw_off[i]:raw_off[i + 1]] for i in idxs])
-            job = MaskOptimJob.from_csr(graph, sub_dn, None, labels[idxs], sd, lib=lib, mask_relu=relu)
+            job = MaskOptimJob.from_csr(graph, sub_dn, None, labels[idxs], sd, lib=lib, mask_relu=relu, bn=bn)
             job.set_masks_raw(sub_raw)
             job.launch(hy)
             if graph.binary:            # explain.py:209-211 multiplies by sub_adj: a no-op for a 0/1 adjacency
@@ -258,6 +259,8 @@ class Explainer:
         if graph_mode or self.graph_mode:
             # the reference indexes pred_label[node_idx_new] (explain.py:130), which only exists in node mode
             raise NotImplementedError("the gradient baseline is a node-mode path")
+        if getattr(self.args, "bn", False):
+            raise NotImplementedError("the gradient baseline with --bn is not implemented on the HIP path")
         lib = _ENGINE["lib"]
         targets = np.asarray([int(v) for v in node_indices], np.int64)
         graph = self._device_graph(graph_idx)
@@ -426,7 +429,7 @@ class ExplainModule(nn.Module):
         self._sub = Subgraph(_np(adj)[0].astype(np.float32), _np(x)[0].astype(np.float32), gt, self._node_idx,
                              None if graph_mode else np.asarray(pred_label), None)
         self._job = MaskOptimJob([self._sub], model.state_dict(), graph_mode=graph_mode, device=_ENGINE["device"], lib=_ENGINE["lib"],
-                                 mask_relu=(args.mask_act == "ReLU"))
+                                 mask_relu=(args.mask_act == "ReLU"), bn=bool(getattr(args, "bn", False)))
 
     def forward(self, node_idx, unconstrained=False, mask_features=True, marginalize=False):
         if unconstrained or marginalize or not mask_features:

@@ -4,7 +4,7 @@ The HIP engine only needs the frozen weights (it reads `model.state_dict()`), so
 must be able to rebuild the encoder and `load_state_dict` a reference checkpoint without importing the
 reference.  `forward` is a plain dense restatement used for predictions outside the hot path
 (models.py:58-80 GraphConv, :230-267 gcn_forward, :269-316 graph head, :363-376 node head); only the
-default configuration is provided: 3 layers, bias, normalize_embedding=True, concat, no bn/att/dropout.
+default configuration is provided: 3 layers, bias, normalize_embedding=True, concat, optional bn, no att/dropout.
 """
 import torch
 import torch.nn as nn
@@ -29,8 +29,9 @@ class GcnEncoderGraph(nn.Module):
     def __init__(self, input_dim, hidden_dim, embedding_dim, label_dim, num_layers, pred_hidden_dims=(), concat=True,
                  bn=False, dropout=0.0, add_self=False, args=None):
         super().__init__()
-        if num_layers != 3 or len(pred_hidden_dims) or not concat or bn or dropout > 0 or add_self:
-            raise NotImplementedError("only the explainer_main.py default encoder (3 layers, concat, no bn) is provided")
+        if num_layers != 3 or len(pred_hidden_dims) or not concat or dropout > 0 or add_self:
+            raise NotImplementedError("only the explainer_main.py default encoder (3 layers, concat) is provided")
+        self.bn = bool(bn)
         if args is not None and getattr(args, "method", "base") == "att":
             raise NotImplementedError("method='att' is outside the accelerated path")
         bias = True if args is None else getattr(args, "bias", True)
@@ -40,9 +41,17 @@ class GcnEncoderGraph(nn.Module):
         self.pred_model = nn.Linear(hidden_dim * 2 + embedding_dim, label_dim)
         self.att = False
 
+    def apply_bn(self, x):
+        """models.py:222-228: a fresh BatchNorm1d(num_nodes) in training mode - every node standardised over its features."""
+        return F.batch_norm(x, None, None, None, None, True, 0.1, 1e-5)
+
     def _layers(self, x, adj):
         h1 = torch.relu(self.conv_first(x, adj))
+        if self.bn:
+            h1 = self.apply_bn(h1)
         h2 = torch.relu(self.conv_block[0](h1, adj))
+        if self.bn:
+            h2 = self.apply_bn(h2)
         return h1, h2, self.conv_last(h2, adj)
 
     def forward(self, x, adj, batch_num_nodes=None, **kwargs):

@@ -43,6 +43,8 @@ typedef struct {
     int32_t graph_mode;        /* 0: GcnEncoderNode head (models.py:363-376); 1: GcnEncoderGraph max-pool head (models.py:269-316) */
     int32_t mask_relu;         /* 0: mask_act = "sigmoid"; 1: mask_act = "ReLU" (explain.py:669-670, 757-760) - dense streaming
                                 * kernels only; like the reference it yields NaN masks whenever an entry of M0 lies outside (0, 1] */
+    int32_t bn;                /* 1: --bn (apply_bn, models.py:222-228, 241-253): every node's hidden activation standardised over its
+                                * features after the ReLU of the two hidden layers; dense streaming kernels only */
 } gnnx_problem;
 
 /* Frozen encoder parameters, HOST pointers in the reference state_dict layouts:

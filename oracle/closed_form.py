@@ -23,6 +23,7 @@ F32 = np.float32
 C_SIZE, C_FEAT_SIZE, C_ENT, C_LAP = F32(0.005), F32(1.0), F32(1.0), F32(1.0)
 BETA1, BETA2, EPS = 0.9, 0.999, 1e-8
 NORM_EPS = F32(1e-12)   # F.normalize eps
+BN_EPS = F32(1e-5)      # nn.BatchNorm1d default eps (apply_bn, models.py:222-228)
 
 
 def sigmoid(x):
@@ -50,9 +51,18 @@ def masked_adj(M, A):
     return Abar, S
 
 
-def forward(Abar, X0, wts):
+def batch_norm_rows(a):
+    """apply_bn (models.py:222-228) on a [1, n, d] activation: a FRESH BatchNorm1d(n) in training mode, i.e. every node
+    (= channel) is standardised over its d features with the biased variance, weight 1, bias 0.  -> (x_hat, 1 / std)"""
+    mu = a.mean(1, dtype=F32)[:, None]
+    var = ((a - mu) ** 2).mean(1, dtype=F32)[:, None]
+    rs = (F32(1) / np.sqrt(var + BN_EPS)).astype(F32)
+    return ((a - mu) * rs).astype(F32), rs
+
+
+def forward(Abar, X0, wts, bn=False):
     """3 GraphConv layers. Returns per-layer (U_l = normalised pre-activation, r_l = row norm)."""
-    U, R, Xin = [], [], [X0]
+    U, R, Xin, RS = [], [], [X0], []
     x = X0
     for l in range(3):
         z = (Abar @ x).astype(F32)
@@ -62,14 +72,21 @@ def forward(Abar, X0, wts):
         U.append(u)
         R.append(r)
         x = np.maximum(u, 0) if l < 2 else u
+        if bn and l < 2:                      # gcn_forward (models.py:241-253): ReLU, then apply_bn
+            x, rs = batch_norm_rows(x)
+            RS.append(rs)
         if l < 2:
             Xin.append(x)
+    if bn:
+        return U, R, Xin, RS
     return U, R, Xin   # Xin = [X0, X1, X2] (inputs of the three layers)
 
 
-def head_node(U, wts, t, y_gt):
-    """Logits/softmax of row t, -log p[y_gt], and the direct gradient dE[t] (length H+H+O)."""
-    e = np.concatenate([np.maximum(U[0][t], 0), np.maximum(U[1][t], 0), U[2][t]]).astype(F32)
+def head_node(U, wts, t, y_gt, Xin=None):
+    """Logits/softmax of row t, -log p[y_gt], and the direct gradient dE[t] (length H+H+O).
+    Xin: the layer inputs [X0, X1, X2] when they are not relu(U) (batch norm)."""
+    a1, a2 = (np.maximum(U[0][t], 0), np.maximum(U[1][t], 0)) if Xin is None else (Xin[1][t], Xin[2][t])
+    e = np.concatenate([a1, a2, U[2][t]]).astype(F32)
     z = (wts.Wp @ e + wts.bp).astype(F32)
     z = z - z.max()
     p = np.exp(z, dtype=F32)
@@ -80,10 +97,10 @@ def head_node(U, wts, t, y_gt):
     return p, F32(-np.log(p[y_gt])), dE
 
 
-def head_graph(U, wts, y_gt):
+def head_graph(U, wts, y_gt, Xin=None):
     """Graph mode: per-layer column-wise max over ALL rows (padded rows included)."""
     n = U[0].shape[0]
-    acts = [np.maximum(U[0], 0), np.maximum(U[1], 0), U[2]]
+    acts = [np.maximum(U[0], 0), np.maximum(U[1], 0), U[2]] if Xin is None else [Xin[1], Xin[2], U[2]]
     arg = [a.argmax(0) for a in acts]
     e = np.concatenate([a.max(0) for a in acts]).astype(F32)
     z = (wts.Wp @ e + wts.bp).astype(F32)
@@ -111,11 +128,15 @@ def direct_grads(dE, n, dims, rows):
     return out
 
 
-def backward(Abar, U, R, wts, dXd):
-    """dZ_l for l = 3, 2, 1 (as list index 2, 1, 0) and dX0 = Abar @ dZ_1."""
+def backward(Abar, U, R, wts, dXd, bn=None):
+    """dZ_l for l = 3, 2, 1 (as list index 2, 1, 0) and dX0 = Abar @ dZ_1.
+    bn = (Xin, RS): batch-normalised activations and 1 / std of the two hidden layers."""
     dZ = [None, None, None]
     dX = dXd[2]
     for l in (2, 1, 0):
+        if bn is not None and l < 2:          # backward of the row-wise standardisation: (dX - mean(dX) - x_hat mean(dX x_hat)) / std
+            xh, rs = bn[0][l + 1], bn[1][l]
+            dX = (rs * (dX - dX.mean(1, dtype=F32)[:, None] - xh * (dX * xh).mean(1, dtype=F32)[:, None])).astype(F32)
         dU = dX * (U[l] > 0) if l < 2 else dX
         dY = ((dU - U[l] * (dU * U[l]).sum(1, dtype=F32)[:, None]) / R[l][:, None]).astype(F32)
         dZ[l] = (dY @ wts.W[l].T).astype(F32)
@@ -155,7 +176,8 @@ def adam(theta, m, v, g, step, lr):
 class ClosedFormOracle:
     """Whole loop for one target; `stages` keeps the last iteration's intermediates."""
 
-    def __init__(self, A, X, sd, gt_label, pred_label, node_idx, M0, graph_mode=False, lr=0.1):
+    def __init__(self, A, X, sd, gt_label, pred_label, node_idx, M0, graph_mode=False, lr=0.1, bn=False):
+        self.bn = bool(bn)
         self.A = np.asarray(A, F32)
         self.X = np.asarray(X, F32)
         self.w = sd if isinstance(sd, Weights) else Weights(sd)
@@ -180,15 +202,19 @@ class ClosedFormOracle:
         Abar, S = masked_adj(self.M, self.A)
         phi = sigmoid(self.f)
         X0 = (self.X * phi).astype(F32)
-        U, R, Xin = forward(Abar, X0, w)
+        RS = None
+        if self.bn:
+            U, R, Xin, RS = forward(Abar, X0, w, bn=True)
+        else:
+            U, R, Xin = forward(Abar, X0, w)
         dims = [w.W[0].shape[1], w.W[1].shape[1], w.W[2].shape[1]]
         if self.graph_mode:
-            p, pred_loss, dE, arg = head_graph(U, w, self.y_gt)
+            p, pred_loss, dE, arg = head_graph(U, w, self.y_gt, Xin if self.bn else None)
             dXd = direct_grads(dE, n, dims, arg)
         else:
-            p, pred_loss, dE = head_node(U, w, self.t, self.y_gt)
+            p, pred_loss, dE = head_node(U, w, self.t, self.y_gt, Xin if self.bn else None)
             dXd = direct_grads(dE, n, dims, self.t)
-        dZ, dX0 = backward(Abar, U, R, w, dXd)
+        dZ, dX0 = backward(Abar, U, R, w, dXd, (Xin, RS) if self.bn else None)
         G = grad_Abar(dZ, Xin, self.yhat, n, not self.graph_mode)
         dM = mask_grad(G, self.A, S, n)
         df = (((dX0 * self.X).sum(0, dtype=F32) + C_FEAT_SIZE / F32(self.D)) * phi * (F32(1) - phi)).astype(F32)

@@ -51,20 +51,34 @@ def graph_conv(x, adj, w, b):
     return F.normalize(y, p=2, dim=2)
 
 
-def encoder_node(x, adj, wts):
-    """models.py:230-267 + 375 (bn off): returns logits for every row, [1, n, C]."""
+def apply_bn(x):
+    """models.py:222-228: a FRESH nn.BatchNorm1d(num_nodes) (training mode, weight 1, bias 0) applied to [1, n, d]: every
+    node is a channel, standardised over its d features with the biased variance, eps 1e-5."""
+    return F.batch_norm(x, None, None, None, None, True, 0.1, 1e-5)
+
+
+def encoder_node(x, adj, wts, bn=False):
+    """models.py:230-267 + 375: returns logits for every row, [1, n, C]."""
     h1 = torch.relu(graph_conv(x, adj, wts["conv_first.weight"], wts["conv_first.bias"]))
+    if bn:
+        h1 = apply_bn(h1)
     h2 = torch.relu(graph_conv(h1, adj, wts["conv_block.0.weight"], wts["conv_block.0.bias"]))
+    if bn:
+        h2 = apply_bn(h2)
     h3 = graph_conv(h2, adj, wts["conv_last.weight"], wts["conv_last.bias"])
     emb = torch.cat([h1, h2, h3], dim=2)
     return F.linear(emb, wts["pred_model.weight"], wts["pred_model.bias"])
 
 
-def encoder_graph(x, adj, wts):
-    """models.py:269-316 (bn off, num_aggs=1, concat): logits [1, C]."""
+def encoder_graph(x, adj, wts, bn=False):
+    """models.py:269-316 (num_aggs=1, concat): logits [1, C]."""
     h1 = torch.relu(graph_conv(x, adj, wts["conv_first.weight"], wts["conv_first.bias"]))
+    if bn:
+        h1 = apply_bn(h1)
     o1, _ = torch.max(h1, dim=1)
     h2 = torch.relu(graph_conv(h1, adj, wts["conv_block.0.weight"], wts["conv_block.0.bias"]))
+    if bn:
+        h2 = apply_bn(h2)
     o2, _ = torch.max(h2, dim=1)
     h3 = graph_conv(h2, adj, wts["conv_last.weight"], wts["conv_last.bias"])
     o3, _ = torch.max(h3, dim=1)
@@ -82,7 +96,8 @@ class MaskOptimOracle:
     """
 
     def __init__(self, adj, x, wts, gt_label, pred_label, node_idx, graph_mode=False,
-                 lr=0.1, mask0=None, mask_act="sigmoid"):
+                 lr=0.1, mask0=None, mask_act="sigmoid", bn=False):
+        self.bn = bool(bn)                # args.bn (models.py:222-228, 241-253)
         self.mask_act = mask_act          # explain.py:603, 667-670, 757-760: "sigmoid" or "ReLU"
         self.adj = adj.reshape(1, *adj.shape).float()
         self.x = x.reshape(1, *x.shape).float()
@@ -112,9 +127,9 @@ class MaskOptimOracle:
         self.masked_adj = self._masked_adj()
         x = self.x * torch.sigmoid(self.feat_mask)
         if self.graph_mode:
-            logits = encoder_graph(x, self.masked_adj, self.wts)
+            logits = encoder_graph(x, self.masked_adj, self.wts, self.bn)
             return torch.softmax(logits[0], dim=0)
-        logits = encoder_node(x, self.masked_adj, self.wts)
+        logits = encoder_node(x, self.masked_adj, self.wts, self.bn)
         return torch.softmax(logits[-1, self.node_idx, :], dim=0)
 
     def loss(self, pred):

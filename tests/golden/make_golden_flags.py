@@ -9,6 +9,9 @@ flags_explain.npz:
                                   (the bias mask is initialised to 0 and ReLU6 has no gradient there)
   relu:<t>:nan_fraction           mask_act="ReLU" (explain.py:669-670, 757-760): the reference's entropy term takes
                                   log(1 - relu(M)) of entries > 1 -> NaN loss -> NaN masks after the first step
+  bn:<t>:masked_adj_edges, bn:<t>:feat_sig, bn:<t>:cond
+                                  --bn run (apply_bn, models.py:222-228, 241-253): a fresh BatchNorm1d(num_nodes) in training mode
+                                  after the ReLU of the two hidden layers; cond = deviation of the closed-form fp32 oracle
   grad:<t>:masked_adj_edges       model="grad" baseline (explain.py:125-133, 717-738): sigmoid(|dL/dA| + |dL/dA|^T) * A
 """
 import argparse
@@ -55,6 +58,9 @@ def main():
             ma = ex.explain(t, model=model_kind)
         return ma, sub_adj, nb
 
+    built = mg.capture_module(explain)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import closed_form, reference_restatement as rr
     for t in (302, 555):
         base, sub, nb = run(t)
         r, c = np.nonzero(np.triu(sub, 1))
@@ -64,6 +70,29 @@ def main():
         ma, _, _ = run(t, mask_act="ReLU")
         out[f"relu:{t}:nan_fraction"] = np.float64(np.isnan(ma).mean())
         print(f"target {t}: --mask-bias bit-identical to the plain run; mask_act=ReLU -> {np.isnan(ma).mean():.0%} NaN")
+    ck = dict(np.load(os.path.join(HERE, "syn1_ckpt.npz")))
+    sd = {k[2:]: v for k, v in ck.items() if k.startswith("w:")}
+    for t in (302, 309, 555, 400):
+        ma, sub, nb = run(t, bn=True)
+        mod = built[-1]
+        r, c = np.nonzero(np.triu(sub, 1))
+        fsig = torch.sigmoid(mod.feat_mask).detach().numpy()
+        new = int(np.searchsorted(nb, t))
+        pl = np.argmax(ck["pred"][nb], 1)
+        o = closed_form.ClosedFormOracle(sub.astype(np.float32), ck["feat"][nb], sd, int(ck["label"][t]), pl, new, mod.mask0.numpy(), bn=True)
+        got = o.run(300)
+        cm = float(np.abs(got - ma).max())
+        cf = float(np.abs(1 / (1 + np.exp(-o.f.astype(np.float64))) - fsig).max())
+        # the torch restatement with bn=True must reproduce the reference bit for bit
+        oo = rr.MaskOptimOracle(torch.tensor(sub.astype(np.float32)), torch.tensor(ck["feat"][nb]), {k: torch.tensor(v) for k, v in sd.items()},
+                                int(ck["label"][t]), pl, new, mask0=mod.mask0.clone(), bn=True)
+        assert np.array_equal(oo.run(300), ma), "restatement (bn) is not bit-identical to the reference"
+        out[f"bn:{t}:neighbors"] = nb.astype(np.int32)
+        out[f"bn:{t}:masked_adj_edges"] = ma[r, c].astype(np.float32)
+        out[f"bn:{t}:feat_sig"] = fsig
+        out[f"bn:{t}:cond"] = np.asarray([cm, cf], np.float32)
+        print(f"target {t}: --bn n={len(nb)} loss {mod.loss_trace[0]:.4f} -> {mod.loss_trace[-1]:.4f}; closed form vs reference {cm:.2e} / {cf:.2e}; "
+              f"restatement bit-identical")
     for t in (302, 309, 555, 330, 400, 300):
         ma, sub, nb = run(t, model_kind="grad")
         r, c = np.nonzero(np.triu(sub, 1))

@@ -577,3 +577,50 @@ def test_device_denoise_and_auc_equal_reference_postprocessing(be):
     auc, P, N = job.auc(real, vals_d)
     assert P == int(real.sum()) and N == len(real) - P
     assert abs(auc - roc_auc_score(real, vals)) < 1e-12
+
+
+@pytest.mark.parametrize("graph_mode", [False, True])
+def test_batch_norm_matches_closed_form(be, graph_mode):
+    """--bn (apply_bn, models.py:222-228, 241-253): every node's hidden activation standardised over its features after the
+    ReLU of the two hidden layers - forward, backward through the standardisation, G product and heads on the dense
+    streaming kernels vs the closed form (itself checked against torch autograd and, through the restatement, bit-pinned
+    to the reference by tests/golden/make_golden_flags.py)."""
+    rng = np.random.default_rng(23)
+    D, H, O, C, n = (14, 20, 20, 2, 40) if graph_mode else (10, 20, 20, 4, 70)
+    sd = helpers.random_model(rng, D, H, O, C)
+    A, X = helpers.random_graph(rng, n, D, density=0.08)
+    yhat = None if graph_mode else rng.integers(0, C, n)
+    m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
+    sg = Subgraph(A, X, 1, 0 if graph_mode else 9, yhat, m0)
+    iters = 5
+    job = engine.MaskOptimJob([sg], sd, graph_mode=graph_mode, device=be.device, lib=be.lib, bn=True)
+    assert job.route()[0] == 0
+    res = job.run([m0], Hyper(num_iters=iters))
+    o = closed_form.ClosedFormOracle(A, X, sd, 1, yhat, sg.target_row, m0, graph_mode=graph_mode, bn=True)
+    want = o.run(iters)
+    assert np.abs(res.masked_adj[0] - want).max() < 5e-6
+    assert np.abs(res.mask[0] - o.M).max() < 5e-5 and np.abs(res.feat_mask[0] - o.f).max() < 5e-5
+    plain = engine.MaskOptimJob([sg], sd, graph_mode=graph_mode, device=be.device, lib=be.lib, analyze=False).run([m0], Hyper(num_iters=iters, use_resident=False))
+    assert np.abs(plain.masked_adj[0] - res.masked_adj[0]).max() > 1e-4          # the flag does change the answer
+
+
+def test_batch_norm_vs_reference_golden(be):
+    """The REAL reference run with --bn (tests/golden/flags_explain.npz): 300 epochs on syn1 targets (n = 6, 48, 104)."""
+    if be.name == "emu":
+        pytest.skip("300 epochs of the dense streaming kernels: hardware only (the emulator covers short runs above)")
+    z = np.load(helpers.GOLDEN + "/flags_explain.npz")
+    ck = helpers.load_ckpt("syn1")
+    targets = [302, 309, 555]
+    subs = []
+    for t in targets:
+        nb = z[f"bn:{t}:neighbors"]
+        A, X, lab, yhat = helpers.subgraph(ck, nb)
+        new = int(np.searchsorted(nb, t))
+        subs.append(Subgraph(A, X, int(lab[new]), new, yhat, helpers.seeded_mask0(t, len(nb)).numpy()))
+    job = engine.MaskOptimJob(subs, ck["sd"], device=be.device, lib=be.lib, bn=True)
+    res = job.run([s.mask0 for s in subs], Hyper(num_iters=300, use_graph=True))
+    for s, t, ma, fm in zip(subs, targets, res.masked_adj, res.feat_mask):
+        assert float(z[f"bn:{t}:cond"].max()) < 2e-6                             # well conditioned (CPU vs CPU)
+        r, c = np.nonzero(np.triu(s.adj, 1))
+        assert np.abs(ma[r, c] - z[f"bn:{t}:masked_adj_edges"]).max() <= 1e-5
+        assert np.abs(1 / (1 + np.exp(-fm.astype(np.float64))) - z[f"bn:{t}:feat_sig"]).max() <= 1e-5

@@ -87,7 +87,7 @@ def test_batched_list_api_equals_sequential_explains(tmp_path, emu_engine):
 
 
 def test_unsupported_options_raise(tmp_path):
-    for kw in ({"mask_act": "tanh"}, {"bn": True}, {"opt": "sgd"}, {"num_gc_layers": 4}):
+    for kw in ({"mask_act": "tanh"}, {"method": "att"}, {"opt": "sgd"}, {"num_gc_layers": 4}):
         with pytest.raises(NotImplementedError):
             _explainer(tmp_path, 3, **kw)
     ck, args, ex = _explainer(tmp_path, 3)

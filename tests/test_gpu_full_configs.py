@@ -131,7 +131,7 @@ def test_config4_graph_mode_64_of_4337_graphs_vs_reference():
         job.launch(Hyper(num_iters=iters))
         em = job.fetch_edges()
         assert np.array_equal(em.eoff, z["eoff"])
-        _check(z, em.masked_adj, em.feat_mask, em.eoff, horizon, "config4", 20 if horizon == "full" else 60)
+        _check(z, em.masked_adj, em.feat_mask, em.eoff, horizon, "config4", 20 if horizon == "full" else 60, helpers.load_branches("config4"))
 
 
 def test_config5_ba100k_route_stratified_targets_vs_reference():
