@@ -78,6 +78,7 @@ struct gnnx_plan_s {
     unsigned short* d_csr_col = nullptr;
     long long* d_csr_off = nullptr;    // [2 T]: offsets of target t into the two arrays
     float* d_adam = nullptr;         // per-iteration Adam scalars for the resident kernel
+    int32_t* d_rowcnt = nullptr;     // [R] scratch of gnnx_edge_counts
     int64_t* d_raw_off = nullptr;    // [T] float offset of target t's n x n block in the unpadded RNG stream (gnnx_scatter_masks)
     int64_t total_raw = 0;
     std::vector<float> adam_host;
@@ -343,6 +344,7 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
     if (h->d_csr_off) (void)hipFree(h->d_csr_off);
     if (h->d_adam) (void)hipFree(h->d_adam);
     if (h->d_raw_off) (void)hipFree(h->d_raw_off);
+    if (h->d_rowcnt) (void)hipFree(h->d_rowcnt);
     if (h->d_big) (void)hipFree(h->d_big);
     if (h->d_conv_big) (void)hipFree(h->d_conv_big);
     if (h->d_mask_big) (void)hipFree(h->d_mask_big);
@@ -835,9 +837,20 @@ extern "C" int gnnx_scatter_masks(gnnx_handle h, const float* raw, float* M, voi
     return 0;
 }
 
+static int32_t* edge_scratch(gnnx_handle h, void* workspace) { return reinterpret_cast<int32_t*>(static_cast<char*>(workspace) + h->o_g3); }
+// per-row counts of upper-triangle non-zeros, scanned per target (row starts stay in the scratch) -> optional per-target totals
+static void edge_rows(gnnx_handle h, const float* A, int32_t* rowcnt, int64_t* counts, hipStream_t s) {
+    hipLaunchKernelGGL(k_edge_rowcount, dim3(h->n_conv), dim3(256), 0, s, A, h->d_conv, rowcnt);
+    hipLaunchKernelGGL(k_edge_rowscan, dim3(h->prob.num_targets), dim3(64), 0, s, h->d_meta, rowcnt, counts);
+}
+
 extern "C" int gnnx_edge_counts(gnnx_handle h, const float* A, int64_t* counts, void* stream) {
     if (!h || !A || !counts) return fail("null argument");
-    hipLaunchKernelGGL(k_edge_counts, dim3(h->prob.num_targets), dim3(256), 0, static_cast<hipStream_t>(stream), h->d_meta, A, counts);
+    // scratch for the row counts: the tail of the plan's own device tables would do, but the counts are needed before the caller
+    // has a workspace only in theory - every caller has one by now; keep the ABI: a private scratch per plan
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!h->d_rowcnt) HIPCK(hipMalloc(&h->d_rowcnt, sizeof(int32_t) * (size_t)h->R));
+    edge_rows(h, A, h->d_rowcnt, counts, s);
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -847,8 +860,32 @@ extern "C" int gnnx_gather_edges(gnnx_handle h, const float* A, const float* Aba
     if (!h || !A || !eoff || !rc || !workspace) return fail("null argument");
     if ((abar && !Abar) || (m_rc && !M)) return fail("values requested without their source array");
     if (workspace_bytes < h->ws_bytes) return fail("workspace too small");
-    EdgeOut o{eoff, rc, abar, m_rc, reinterpret_cast<int32_t*>(static_cast<char*>(workspace) + h->o_g3)};
-    hipLaunchKernelGGL(k_gather_edges, dim3(h->prob.num_targets), dim3(256), 0, static_cast<hipStream_t>(stream), h->d_meta, A, Abar, M, o);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    EdgeOut o{eoff, rc, abar, m_rc, edge_scratch(h, workspace), nullptr};
+    edge_rows(h, A, o.rowcnt, nullptr, s);
+    hipLaunchKernelGGL(k_edge_emit, dim3(h->n_conv), dim3(256), 0, s, A, Abar, M, h->d_conv, o);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gnnx_edge_positions(gnnx_handle h, const float* A, const int64_t* eoff, int32_t* rc, int64_t* epos, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    if (!h || !A || !eoff || !rc || !epos || !workspace) return fail("null argument");
+    if (workspace_bytes < h->ws_bytes) return fail("workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    EdgeOut o{eoff, rc, nullptr, nullptr, edge_scratch(h, workspace), epos};
+    edge_rows(h, A, o.rowcnt, nullptr, s);
+    hipLaunchKernelGGL(k_edge_emit, dim3(h->n_conv), dim3(256), 0, s, A, (const float*)nullptr, (const float*)nullptr, h->d_conv, o);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gnnx_gather_values(const int64_t* epos, int64_t num_edges, const float* Abar, const float* M, float* abar, float* m_rc,
+                                  void* stream) {
+    if (!epos || num_edges < 0 || (abar && !Abar) || (m_rc && !M)) return fail("bad argument");
+    if (num_edges == 0) return 0;
+    hipLaunchKernelGGL(k_gather_values, dim3((unsigned)((num_edges + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), epos,
+                       num_edges, Abar, M, abar, m_rc);
     HIPCK(hipGetLastError());
     return 0;
 }

@@ -144,86 +144,103 @@ __global__ __launch_bounds__(256) void k_scatter_masks(const float* raw, const i
     }
 }
 
-// upper-triangle non-zeros (c > r) of every target's block of the packed adjacency -> counts[t]
-__global__ __launch_bounds__(256) void k_edge_counts(const TargetMeta* meta, const float* A, int64_t* counts) {
-    __shared__ int part[4];
-    const TargetMeta tm = meta[blockIdx.x];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int cnt = 0;
-    for (int r = wave; r < tm.n; r += 4) {
-        const float* row = A + tm.offQ + (size_t)r * tm.ld;
-        for (int c0 = (r + 1) & ~63; c0 < tm.n; c0 += 64) {
-            const int c = c0 + lane;
-            cnt += __popcll(__ballot(c > r && c < tm.n && row[c] != 0.0f));
-        }
-    }
-    if (lane == 0) part[wave] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = (int64_t)part[0] + part[1] + part[2] + part[3];
-}
-
-// The explanation of every target as an edge list: for the upper-triangle edges (r < c) of its sub-graph, in row-major
-// order, the pair (r, c), the masked adjacency of the last forward and the final mask parameters M[r][c], M[c][r].
-// One workgroup per target: pass 1 counts per row (ballots), a prefix scan places the rows, pass 2 writes.
+// ---- edge lists: upper-triangle non-zeros (c > r) of every target's block of the packed adjacency, row-major ----
+// Three small kernels over the 32-row blocks of the batch (so a 4000-node target is scanned by 125 workgroups, not one):
+//   k_edge_rowcount  per row: number of upper-triangle non-zeros (wave ballots over 64-column chunks) -> rowcnt[R]
+//   k_edge_rowscan   per target: exclusive scan of its rows' counts (in place) and the total -> counts[t]
+//   k_edge_emit      per row: (r, c) pairs, values and positions at eoff[t] + rowstart[r] + rank within the row
 struct EdgeOut {
-    const int64_t* eoff;  // [T + 1] prefix sums of k_edge_counts
+    const int64_t* eoff;  // [T + 1] prefix sums of the per-target counts
     int32_t* rc;          // [E][2]
     float* abar;          // [E]    or null
     float* m_rc;          // [E][2] or null: M[r][c], M[c][r]
-    int32_t* rowcnt;      // scratch [R] (one int per row of the batch)
+    int32_t* rowcnt;      // scratch [R] (one int per row of the batch): counts, then row starts
+    int64_t* epos;        // [E][2] or null: float index of (r, c) and of (c, r) in the packed square arrays (for k_gather_values)
 };
-__global__ __launch_bounds__(256) void k_gather_edges(const TargetMeta* meta, const float* A, const float* Abar, const float* M,
-                                                      EdgeOut o) {
-    const TargetMeta tm = meta[blockIdx.x];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    int32_t* rowcnt = o.rowcnt + tm.offR;
-    for (int r = wave; r < tm.n; r += 4) {
-        const float* row = A + tm.offQ + (size_t)r * tm.ld;
+
+__global__ __launch_bounds__(256) void k_edge_rowcount(const float* A, const ConvTile* tiles, int32_t* rowcnt) {
+    const ConvTile tl = tiles[blockIdx.x];
+    const TargetMeta tm = tl.tm;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int rr = wave; rr < TILE; rr += 4) {
+        const int r = tl.rb * TILE + rr;
         int cnt = 0;
-        for (int c0 = (r + 1) & ~63; c0 < tm.n; c0 += 64) {
-            const int c = c0 + lane;
-            cnt += __popcll(__ballot(c > r && c < tm.n && row[c] != 0.0f));
-        }
-        if (lane == 0) rowcnt[r] = cnt;
-    }
-    __syncthreads();
-    // exclusive scan of the row counts, 64 rows at a time (wave 0; the running total stays in a register)
-    if (wave == 0) {
-        int carry = 0;
-        for (int r0 = 0; r0 < tm.n; r0 += 64) {
-            const int r = r0 + lane;
-            const int v = (r < tm.n) ? rowcnt[r] : 0;
-            int incl = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int x = __shfl(incl, lane - d);
-                if (lane >= d) incl += x;
+        if (r < tm.n) {
+            const float* row = A + tm.offQ + (size_t)r * tm.ld;
+            for (int c0 = (r + 1) & ~63; c0 < tm.n; c0 += 64) {
+                const int c = c0 + lane;
+                cnt += __popcll(__ballot(c > r && c < tm.n && row[c] != 0.0f));
             }
-            if (r < tm.n) rowcnt[r] = carry + incl - v;
-            carry += __shfl(incl, 63);
         }
+        if (lane == 0) rowcnt[tm.offR + r] = cnt;
     }
-    __syncthreads();
-    const int64_t e0 = o.eoff[blockIdx.x];
-    for (int r = wave; r < tm.n; r += 4) {
+}
+
+__global__ __launch_bounds__(64) void k_edge_rowscan(const TargetMeta* meta, int32_t* rowcnt, int64_t* counts) {
+    const TargetMeta tm = meta[blockIdx.x];
+    const int lane = threadIdx.x;
+    int32_t* rc = rowcnt + tm.offR;
+    int carry = 0;
+    for (int r0 = 0; r0 < tm.n; r0 += 64) {
+        const int r = r0 + lane;
+        const int v = (r < tm.n) ? rc[r] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int x = __shfl(incl, lane - d);
+            if (lane >= d) incl += x;
+        }
+        if (r < tm.n) rc[r] = carry + incl - v;
+        carry += __shfl(incl, 63);
+    }
+    if (lane == 0 && counts) counts[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_edge_emit(const float* A, const float* Abar, const float* M, const ConvTile* tiles, EdgeOut o) {
+    const ConvTile tl = tiles[blockIdx.x];
+    const TargetMeta tm = tl.tm;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t e0 = o.eoff[tl.t];
+    for (int rr = wave; rr < TILE; rr += 4) {
+        const int r = tl.rb * TILE + rr;
+        if (r >= tm.n) continue;
         const float* row = A + tm.offQ + (size_t)r * tm.ld;
-        int pos = rowcnt[r];
+        int pos = o.rowcnt[tm.offR + r];
         for (int c0 = (r + 1) & ~63; c0 < tm.n; c0 += 64) {
             const int c = c0 + lane;
             const bool nz = c > r && c < tm.n && row[c] != 0.0f;
             const unsigned long long bal = __ballot(nz);
             if (nz) {
                 const int64_t e = e0 + pos + __popcll(bal & ((1ull << lane) - 1ull));
+                const int64_t prc = tm.offQ + (int64_t)r * tm.ld + c, pcr = tm.offQ + (int64_t)c * tm.ld + r;
                 o.rc[2 * e] = r;
                 o.rc[2 * e + 1] = c;
-                if (o.abar) o.abar[e] = Abar[tm.offQ + (size_t)r * tm.ld + c];
+                if (o.epos) {
+                    o.epos[2 * e] = prc;
+                    o.epos[2 * e + 1] = pcr;
+                }
+                if (o.abar) o.abar[e] = Abar[prc];
                 if (o.m_rc) {
-                    o.m_rc[2 * e] = M[tm.offQ + (size_t)r * tm.ld + c];
-                    o.m_rc[2 * e + 1] = M[tm.offQ + (size_t)c * tm.ld + r];
+                    o.m_rc[2 * e] = M[prc];
+                    o.m_rc[2 * e + 1] = M[pcr];
                 }
             }
             pos += __popcll(bal);
         }
+    }
+}
+
+// The edge structure of a batch is fixed: once k_edge_emit has recorded where every edge lives (epos), the values of a
+// new run are one indexed read each.
+__global__ __launch_bounds__(256) void k_gather_values(const int64_t* epos, int64_t E, const float* Abar, const float* M, float* abar,
+                                                       float* m_rc) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int64_t a = epos[2 * e], b = epos[2 * e + 1];
+    if (abar) abar[e] = Abar[a];
+    if (m_rc) {
+        m_rc[2 * e] = M[a];
+        m_rc[2 * e + 1] = M[b];
     }
 }
 

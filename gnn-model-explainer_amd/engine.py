@@ -98,6 +98,8 @@ _API = {
                          [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
                                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "gnnx_grad_baseline": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_size_t, ctypes.c_void_p]),
+    "gnnx_edge_positions": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p]),
+    "gnnx_gather_values": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 5),
     "gnnx_denoise_edges": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_void_p]),
     "gnnx_auc_counts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "gnnx_khop_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
@@ -466,9 +468,10 @@ class MaskOptimJob:
             self._rc = torch.empty(E, 2, dtype=torch.int32, device=dev)
             self._ev = torch.empty(E, dtype=torch.float32, device=dev)
             self._em = torch.empty(E, 2, dtype=torch.float32, device=dev)
-            self._enter()        # fill the (fixed) edge structure rc once; the values are refreshed by every gather_edges_device()
-            _check(self.lib, self.lib.gnnx_gather_edges(self.handle, self.A.data_ptr(), None, None, self._eoff_d.data_ptr(), self._rc.data_ptr(),
-                                                        None, None, self.ws.data_ptr(), self.ws_bytes, self._stream()))
+            self._epos = torch.empty(E, 2, dtype=torch.int64, device=dev)
+            self._enter()        # the (fixed) edge structure, once: rc and the position of every edge in the packed arrays
+            _check(self.lib, self.lib.gnnx_edge_positions(self.handle, self.A.data_ptr(), self._eoff_d.data_ptr(), self._rc.data_ptr(),
+                                                          self._epos.data_ptr(), self.ws.data_ptr(), self.ws_bytes, self._stream()))
             self._leave()
 
     def gather_edges_device(self, with_mask=False) -> torch.Tensor:
@@ -476,10 +479,8 @@ class MaskOptimJob:
         (asynchronous; what a multi-GPU gather ships instead of dense blocks)."""
         self._edge_layout()
         self._enter()
-        _check(self.lib, self.lib.gnnx_gather_edges(self.handle, self.A.data_ptr(), self.Abar.data_ptr(), self.M.data_ptr(),
-                                                    self._eoff_d.data_ptr(), self._rc.data_ptr(), self._ev.data_ptr(),
-                                                    self._em.data_ptr() if with_mask else None, self.ws.data_ptr(), self.ws_bytes,
-                                                    self._stream()))
+        _check(self.lib, self.lib.gnnx_gather_values(self._epos.data_ptr(), int(self._eoff[-1]), self.Abar.data_ptr(), self.M.data_ptr(),
+                                                     self._ev.data_ptr(), self._em.data_ptr() if with_mask else None, self._stream()))
         self._leave()
         return self._ev[:int(self._eoff[-1])]
 

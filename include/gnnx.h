@@ -189,6 +189,12 @@ int gnnx_scatter_masks(gnnx_handle h, const float* raw, float* M, void* stream);
 int gnnx_edge_counts(gnnx_handle h, const float* A, int64_t* counts, void* stream);
 int gnnx_gather_edges(gnnx_handle h, const float* A, const float* Abar, const float* M, const int64_t* eoff, int32_t* rc,
                       float* abar, float* m_rc, void* workspace, size_t workspace_bytes, void* stream);
+/* The edge structure of a batch never changes: gnnx_edge_positions records, in the order of gnnx_gather_edges, where every
+ * edge lives - epos [E][2] (DEVICE int64) = float index of (r, c) and of (c, r) in the packed square arrays (rc filled too) -
+ * and gnnx_gather_values then reads the values of any later run with one indexed load per edge. */
+int gnnx_edge_positions(gnnx_handle h, const float* A, const int64_t* eoff, int32_t* rc, int64_t* epos, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int gnnx_gather_values(const int64_t* epos, int64_t num_edges, const float* Abar, const float* M, float* abar, float* m_rc, void* stream);
 
 /* Post-processing of a batch of explanations on the device, on the edge lists of gnnx_gather_edges (all pointers DEVICE):
  * gnnx_denoise_edges = io_utils.denoise_graph(masked_adj, node_idx, threshold_num=k, max_component=True)
