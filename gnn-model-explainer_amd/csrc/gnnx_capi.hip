@@ -510,22 +510,24 @@ static int enqueue_job(gnnx_handle h, const Tables& tb, const gnnx_hyper* hy, co
 
 // the sparse resident kernel, instantiated per size class for the reference's encoders (node: D = 10, graph: D = 14;
 // hidden 20) and for the general 32-wide case
+// the specialised instantiations (compile-time widths) serve exactly the reference's encoders: D = 10 (node) / 14 (graph), H = O = 20
+static bool exact_shape(gnnx_handle h, int D) { return h->prob.D == D && h->prob.H == 20 && h->prob.O == 20; }
+
 template <int NT>
 static void launch_sparse_nt(gnnx_handle h, const Params& p, const int32_t* ids, int cnt, const float* adam_tab, hipStream_t s) {
     const dim3 grid(cnt), block(NT);
-    const int D = h->prob.D, HO = std::max(h->prob.H, h->prob.O);
     if (h->prob.graph_mode) {
-        if (D <= 14 && HO <= 20) hipLaunchKernelGGL((k_sparse_resident<7, 10, true, NT>), grid, block, 0, s, p, ids, adam_tab);
+        if (exact_shape(h, 14)) hipLaunchKernelGGL((k_sparse_resident<7, 10, true, NT>), grid, block, 0, s, p, ids, adam_tab);
         else hipLaunchKernelGGL((k_sparse_resident<16, 16, true, NT>), grid, block, 0, s, p, ids, adam_tab);
     } else {
-        if (D <= 10 && HO <= 20) hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT>), grid, block, 0, s, p, ids, adam_tab);
+        if (exact_shape(h, 10)) hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT>), grid, block, 0, s, p, ids, adam_tab);
         else hipLaunchKernelGGL((k_sparse_resident<16, 16, false, NT>), grid, block, 0, s, p, ids, adam_tab);
     }
 }
 static void launch_sparse(gnnx_handle h, const Params& p, int cls, const float* adam_tab, hipStream_t s) {
     if (cls == SPC_LARGE) {  // node-mode targets beyond the LDS-resident classes: row arrays in HBM / L2 (gnnx_sparse_large.hpp)
         const dim3 grid(h->n_sp[cls]), block(SPL_THREADS);
-        if (h->prob.D <= 10 && std::max(h->prob.H, h->prob.O) <= 20)
+        if (exact_shape(h, 10))
             hipLaunchKernelGGL((k_sparse_large<5, 10>), grid, block, 0, s, p, h->d_sp[cls], adam_tab, h->d_csr_rowptr,
                                h->d_csr_col, h->d_csr_off);
         else
@@ -585,7 +587,7 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
             h->launched[g] = true;
             if (mixed && k == SPC_512) {
                 const dim3 grid(h->n_sp[SPC_512] + (h->n_sp[2] + SP_MIX_TINY - 1) / SP_MIX_TINY), block(512);
-                if (h->prob.D <= 10 && std::max(h->prob.H, h->prob.O) <= 20)
+                if (exact_shape(h, 10))
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
                                        h->d_sp[2], h->n_sp[2], h->d_adam);
                 else

@@ -362,7 +362,10 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     const int n = tm.n, ld = tm.ld, tr = tm.t;
     const int wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     constexpr int NW = NT / 64;
-    const int D = p.D, H = p.H, O = p.O, C = p.C;
+    // The <5, 10> / <7, 10> instantiations serve exactly the reference's encoders (node: D = 10, graph: D = 14; H = O = 20): the
+    // widths are compile-time constants there (every column predicate, row stride and trip count folds); other shapes take <16, 16>.
+    constexpr bool EXACT = (DQ != 16);
+    const int D = EXACT ? 2 * DQ : p.D, H = EXACT ? 2 * HQ : p.H, O = EXACT ? 2 * HQ : p.O, C = p.C;
     const float* Ag = p.A + tm.offQ;
     float* Mg = p.M + tm.offQ;
 
@@ -1042,13 +1045,16 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 // D / H are read from the row padding / the next row and dropped by the select
                 float G0 = 0.0f, G1 = 0.0f;
                 const int fl = eflag[q];
+                // columns per load group (one LDS round trip each): the reference's widths take the whole dZ1 . X product in one
+                // group and the dZ2 . relu(U1) product in two
+                constexpr int EC0 = (DQ <= 8) ? 2 * DQ : DQ, EC1 = (HQ <= 10) ? HQ : HQ / 2;
                 // dZ1 is exactly zero beyond two hops of t: such edges only get their regulariser gradients.  (Forming the two
                 // products of an edge separately, each only when its dZ row can be non-zero, was measured and is slower: four
                 // dependent load groups instead of two - 4.9 against 3.6 us per iteration on syn1's largest target.)
 #pragma unroll 1
-                for (int c0 = 0; (fl & 3) && c0 < 2 * DQ; c0 += 2 * DQ / 2) {
+                for (int c0 = 0; (fl & 3) && c0 < 2 * DQ; c0 += EC0) {
 #pragma unroll
-                    for (int cc = 0; cc < 2 * DQ / 2; ++cc) {
+                    for (int cc = 0; cc < EC0; ++cc) {
                         const int c = c0 + cc;
                         const float t1 = fmaf(sdZ1[i * sD + c], sX[j * sD + c], sdZ1[j * sD + c] * sX[i * sD + c]) * sh.phi[c];
                         G0 += (c < D) ? t1 : 0.0f;
@@ -1056,9 +1062,9 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 }
                 // dZ2 is exactly zero outside row t and its neighbours (rank-1 layer-3 backward): skip the products
 #pragma unroll 1
-                for (int c0 = 0; (fl & 12) && c0 < 2 * HQ; c0 += 2 * HQ / 4) {
+                for (int c0 = 0; (fl & 12) && c0 < 2 * HQ; c0 += EC1) {
 #pragma unroll
-                    for (int cc = 0; cc < 2 * HQ / 4; ++cc) {
+                    for (int cc = 0; cc < EC1; ++cc) {
                         const int c = c0 + cc;
                         const float t2 = fmaf(sdZ2[i * sH + c], relu_(sU1[j * sH + c]),
                                               sdZ2[j * sH + c] * relu_(sU1[i * sH + c]));

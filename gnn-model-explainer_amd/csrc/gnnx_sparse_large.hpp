@@ -89,7 +89,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     const TargetMeta tm = p.meta[t];
     const int n = tm.n, ld = tm.ld, tr = tm.t;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
-    const int D = p.D, H = p.H, O = p.O, C = p.C;
+    constexpr bool EXACT = (DQ != 16);   // <5, 10>: exactly D = 10, H = O = 20 (compile-time widths); other shapes take <16, 16>
+    const int D = EXACT ? 2 * DQ : p.D, H = EXACT ? 2 * HQ : p.H, O = EXACT ? 2 * HQ : p.O, C = p.C;
     const float* Ag = p.A + tm.offQ;
     float* Mg = p.M + tm.offQ;
     float* est = p.UT[2] + tm.offR * FS;  // per-edge planes [7][eup]: M_ij, M_ji, m_ij, m_ji, v_ij, v_ji, weight

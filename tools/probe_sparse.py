@@ -25,6 +25,19 @@ src = src.replace(l2, l2.replace(";\n            sparse_combine", ";\n          
 l2b = "            sparse_forward_rowlocal<HQ>(acc, sW2, sh.bias[1], H, H, li, h, first, sU2 + r * sH, sRn2 + r);\n"
 assert l2b in src
 src = src.replace(l2b, l2b + "            PROBE(%d);\n" % (SUB + 2), 1)
+# finer stamps inside the layer-1 backward (thread 0 = wave 0 = the hub rows)
+d1 = "                sparse_gather<false, HQ>(sAb, scol, sdZ2, sH, H, re0, re1, h, acc);\n                sparse_combine<HQ>(acc, SA.rem, wsplit);\n"
+assert d1 in src
+src = src.replace(d1, d1.replace(";\n                sparse_combine", ";\n                PROBE(24);\n                sparse_combine") + "                PROBE(25);\n", 1)
+d2 = "                sparse_store_cols(c16, sdZ1 + r * sD, D, first, h);\n                wave_sync();  // the other half-lane"
+assert d2 in src
+src = src.replace(d2, "                PROBE(26);\n" + d2, 1)
+d3 = "            // colsum(dZ1 * Zraw): over the 16 lanes of a DPP row"
+assert d3 in src
+src = src.replace(d3, "            PROBE(27);\n" + d3, 1)
+d4 = "        SYNC();\n        if (tid < D) {\n            float s = 0.0f;\n#pragma unroll\n            for (int w = 0; w < NW; ++w) s += sh.dfw[w][tid];"
+assert d4 in src
+src = src.replace(d4, "        PROBE(28);\n" + d4, 1)
 src = src.replace("        if (iter + 1 < p.num_iters) publish_abar();  // the returned mask", "        PROBE(%d);\n        if (iter + 1 < p.num_iters) publish_abar();\n        PROBE(%d);  // the returned mask" % (k, k + 1), 1)
 names += ["publish Abar"]
 capi += '\nextern "C" int gnnx_probe_read(unsigned long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gnnx::g_probe), sizeof(unsigned long long) * n); }\n'
@@ -68,5 +81,7 @@ for nme, v in zip(names, d):
     print("%-100s %7.2f us" % (nme[:100], v))
 print("iteration total %7.2f us" % ((a[len(names)] - a[0]) * 10.0 / 1e3))
 b = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
+print("layer-1 backward, wave 0: gather %.2f us, combine %.2f, gating + MFMA %.2f, store + sync + df products %.2f, df reductions %.2f, wait at barrier + dfp %.2f" % (
+    (b[24] - b[4]) / 100.0, (b[25] - b[24]) / 100.0, (b[26] - b[25]) / 100.0, (b[27] - b[26]) / 100.0, (b[28] - b[27]) / 100.0, (b[5] - b[28]) / 100.0))
 print("layer 2, wave 0: gather %.2f us, combine %.2f us, MFMA + epilogue %.2f us, wait at barrier %.2f us" % (
     (b[20] - b[1]) / 100.0, (b[21] - b[20]) / 100.0, (b[22] - b[21]) / 100.0, (b[2] - b[22]) / 100.0))
