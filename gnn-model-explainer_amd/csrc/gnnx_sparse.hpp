@@ -625,6 +625,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     };
     // owned undirected edges: k = tid + NT q; mask entries and Adam moments stay in registers
     float Mij[SP_QMAX], Mji[SP_QMAX], mij[SP_QMAX], mji[SP_QMAX], vij[SP_QMAX], vji[SP_QMAX], wgt[SP_QMAX];
+    float Sij[SP_QMAX], Sji[SP_QMAX];  // sigma(M) of the current iterate (computed when the masked adjacency is published)
     int eij[SP_QMAX], eji[SP_QMAX], ni[SP_QMAX], nj[SP_QMAX];
     int eflag[SP_QMAX];   // bit 0 / 1: row i / j lies within two hops of t (dZ1 can be non-zero there); bit 2 / 3: row i / j is t
                           // or a neighbour of t (dZ2 can be non-zero there); graph mode: all set
@@ -634,6 +635,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         for (int q = 0; q < SP_QMAX; ++q) {
             const int k = tid + NT * q;
             Mij[q] = Mji[q] = mij[q] = mji[q] = vij[q] = vji[q] = wgt[q] = 0.0f;
+            Sij[q] = Sji[q] = 0.5f;
             eij[q] = eji[q] = ni[q] = nj[q] = 0;
             eflag[q] = 0;
             if (k < eup) {
@@ -706,7 +708,9 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
 #pragma unroll
         for (int q = 0; q < SP_QMAX; ++q)
             if (tid + NT * q < eup) {
-                const float a = wgt[q] * (0.5f * (sigmoidf_(Mij[q]) + sigmoidf_(Mji[q])));
+                Sij[q] = sigmoidf_(Mij[q]);   // kept for the next update: sigma'(M) = S (1 - S)
+                Sji[q] = sigmoidf_(Mji[q]);
+                const float a = wgt[q] * (0.5f * (Sij[q] + Sji[q]));
                 sAb[eij[q]] = a;
                 sAb[eji[q]] = a;
                 if (!GRAPH) {
@@ -1091,12 +1095,12 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 const float dy = sYhat[i] - sYhat[j];
                 const float gc = (0.5f * G + p.c_lap * 0.5f * dy * dy * inv_n2) * wgt[q];
                 {
-                    const float S = sigmoidf_(Mij[q]);
+                    const float S = Sij[q];
                     const float g = (gc + p.c_size - p.c_ent * Mij[q] * inv_n2) * S * (1.0f - S);
                     adam_update(Mij[q], mij[q], vij[q], g, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
                 }
                 {
-                    const float S = sigmoidf_(Mji[q]);
+                    const float S = Sji[q];
                     const float g = (gc + p.c_size - p.c_ent * Mji[q] * inv_n2) * S * (1.0f - S);
                     adam_update(Mji[q], mji[q], vji[q], g, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
                 }
