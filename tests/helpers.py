@@ -98,9 +98,13 @@ def branch_errors(z, br, eoff, vals, feat_sig, early=False):
 PARITY_TOL = 1e-5        # masked_adj and sigmoid(feat_mask), BASELINE.md section 3
 WELL = 2e-6              # CPU-vs-CPU deviation (reference vs closed-form fp32 oracle) up to which a target is not chaotic
 BRANCH_JUMP_MAX = 5e-3   # largest distance between two outcomes of one non-chaotic target seen under 1-ulp perturbations (syn4: 3.2e-3)
+# Graph mode (config 4) after 300 epochs: the max-pool's arg-max rows switch on ties, 42 of the 64 fixture graphs move under a 1-ulp
+# perturbation of the initial mask (38 by more than 1e-5, up to 6e-2 - make_golden_branches.py), so the full horizon only asks for
+# 70 % within 1e-5 and bounds the rest by that jump; after 50 epochs every graph must agree to 1e-5.
+CONFIG4_FULL_RULE = dict(min_frac=0.70, jump_max=6e-2)
 
 
-def parity_verdict(err, ferr, well, min_frac=0.99):
+def parity_verdict(err, ferr, well, min_frac=0.99, jump_max=None):
     """The parity rule of the full-config tests and of bench.py.  On the targets the two CPU implementations agree on (`well`):
       * at least `min_frac` of them lie within 1e-5 (mask AND feature mask) of an outcome the reference itself produces -
         its output or an alternate outcome under a 1-ulp perturbation of the initial mask (helpers.branch_errors);
@@ -111,6 +115,7 @@ def parity_verdict(err, ferr, well, min_frac=0.99):
     inside = int((e <= PARITY_TOL).sum())
     frac = inside / max(1, len(e))
     worst = float(e.max()) if len(e) else 0.0
-    ok = frac >= min_frac and worst <= BRANCH_JUMP_MAX
+    jump_max = BRANCH_JUMP_MAX if jump_max is None else jump_max
+    ok = frac >= min_frac and worst <= jump_max
     return ok, (f"{inside} / {len(e)} non-chaotic targets within 1e-5 of an outcome of the reference ({100 * frac:.1f} %, need "
-                f"{100 * min_frac:.0f} %), worst {worst:.2e} (limit {BRANCH_JUMP_MAX:.0e})")
+                f"{100 * min_frac:.0f} %), worst {worst:.2e} (limit {jump_max:.0e})")

@@ -70,7 +70,7 @@ def _run_node_config(name, iters):
     return z, em, job.route()
 
 
-def _check(z, em_vals, em_feat, eoff, horizon, what, min_well, br=None, min_frac=0.99):
+def _check(z, em_vals, em_feat, eoff, horizon, what, min_well, br=None, min_frac=0.99, jump_max=None):
     """helpers.parity_verdict on the distance to the NEAREST legitimate outcome of the reference (helpers.branch_errors)."""
     early = horizon == "early"
     sfx = "_early" if early else ""
@@ -78,7 +78,7 @@ def _check(z, em_vals, em_feat, eoff, horizon, what, min_well, br=None, min_frac
     err, ferr, matched = helpers.branch_errors(z, br, eoff, em_vals, _sig(em_feat), early)
     well = (cm <= WELL) & (cf <= WELL)
     assert well.sum() >= min_well, f"{what}: only {well.sum()} non-chaotic targets in the fixture"
-    ok, msg = helpers.parity_verdict(err, ferr, well, min_frac)
+    ok, msg = helpers.parity_verdict(err, ferr, well, min_frac, jump_max)
     bad = np.nonzero(well & ((err > TOL) | (ferr > TOL)))[0]
     ids = z["targets"] if "targets" in z.files else z["graphs"]
     print(f"{what} [{horizon}]: {msg}; {int((matched[well] >= 0).sum())} on an alternate branch; beyond 1e-5: "
@@ -136,10 +136,8 @@ def test_config4_graph_mode_64_of_4337_graphs_vs_reference():
         job.launch(Hyper(num_iters=iters))
         em = job.fetch_edges()
         assert np.array_equal(em.eoff, z["eoff"])
-        # graph mode is the most branch-prone configuration (max-pool arg-max ties: 42 of the 64 graphs move under a 1-ulp
-        # perturbation after 300 epochs), so the full horizon only asks for 85 %; after 50 epochs every graph must agree
-        _check(z, em.masked_adj, em.feat_mask, em.eoff, horizon, "config4", 20 if horizon == "full" else 60, helpers.load_branches("config4"),
-               min_frac=0.85 if horizon == "full" else 1.0)
+        rule = helpers.CONFIG4_FULL_RULE if horizon == "full" else dict(min_frac=1.0)     # see helpers.CONFIG4_FULL_RULE
+        _check(z, em.masked_adj, em.feat_mask, em.eoff, horizon, "config4", 20 if horizon == "full" else 60, helpers.load_branches("config4"), **rule)
 
 
 def test_config5_ba100k_route_stratified_targets_vs_reference():
