@@ -100,8 +100,12 @@ WELL = 2e-6              # CPU-vs-CPU deviation (reference vs closed-form fp32 o
 BRANCH_JUMP_MAX = 5e-3   # largest distance between two outcomes of one non-chaotic target seen under 1-ulp perturbations (syn4: 3.2e-3)
 # Graph mode (config 4) after 300 epochs: the max-pool's arg-max rows switch on ties, 42 of the 64 fixture graphs move under a 1-ulp
 # perturbation of the initial mask (38 by more than 1e-5, up to 6e-2 - make_golden_branches.py), so the full horizon only asks for
-# 70 % within 1e-5 and bounds the rest by that jump; after 50 epochs every graph must agree to 1e-5.
+# 70 % within 1e-5 and bounds the rest by that jump; after 50 epochs 95 % (molecule-like graphs are full of symmetric atoms whose
+# activations are equal in exact arithmetic: which of them wins the max-pool is decided by the summation order of each
+# implementation - graph 2477 switches rows at epoch ~32 in the edge-sparse kernel while the dense streaming kernels stay with the
+# reference, both on the same GPU; tools/debug_graph2477.py).
 CONFIG4_FULL_RULE = dict(min_frac=0.70, jump_max=6e-2)
+CONFIG4_EARLY_RULE = dict(min_frac=0.95, jump_max=6e-2)
 
 
 def parity_verdict(err, ferr, well, min_frac=0.99, jump_max=None):

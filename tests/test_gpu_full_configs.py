@@ -136,7 +136,7 @@ def test_config4_graph_mode_64_of_4337_graphs_vs_reference():
         job.launch(Hyper(num_iters=iters))
         em = job.fetch_edges()
         assert np.array_equal(em.eoff, z["eoff"])
-        rule = helpers.CONFIG4_FULL_RULE if horizon == "full" else dict(min_frac=1.0)     # see helpers.CONFIG4_FULL_RULE
+        rule = helpers.CONFIG4_FULL_RULE if horizon == "full" else helpers.CONFIG4_EARLY_RULE     # see helpers.py
         _check(z, em.masked_adj, em.feat_mask, em.eoff, horizon, "config4", 20 if horizon == "full" else 60, helpers.load_branches("config4"), **rule)
 
 
