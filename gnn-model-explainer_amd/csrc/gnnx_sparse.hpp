@@ -53,7 +53,7 @@ __host__ __device__ inline int sparse_place(int pos, int ns) { return ((pos & 15
 // carve-out of the LDS pool (float offsets) for a target of ld rows and nnz directed entries
 struct SparseLayout {
     int sD, sH, sO;  // row strides (odd: conflict-free row-strided access)
-    int oX, oU1, oU2, oU3, odZ2, odZ1, oAb, oCol, oRowptr, oArt, oRn1, oRn2, oRn3, oYhat, oG3, oW, oWp, total;
+    int oX, oU1, oU2, oU3, odZ2, odZ1, oAb, oGe, oCol, oRowptr, oArt, oRn1, oRn2, oRn3, oYhat, oG3, oW, oWp, total;
 };
 // graph = 0: node mode (GcnEncoderNode: only row t of layer 3 is needed; dZ2 overwrites U2);
 // graph = 1: graph mode (GcnEncoderGraph: all three layers in full, U3 [ld][max(H, O)] overwritten by dZ3, dZ2 separate)
@@ -72,6 +72,7 @@ __host__ __device__ inline SparseLayout sparse_layout(int n, int ld, int nnz, in
     o += graph ? n * L.sH : 0;
     L.odZ1 = o;    o += n * L.sD;
     L.oAb = o;     o += nnz;
+    L.oGe = o;     o += graph ? 0 : nnz;  // node mode: dL/dAbar per directed entry (row-side product), written by the layer-1 backward
     L.oCol = o;    o += (nnz + 1) / 2;  // uint16 columns
     L.oRowptr = o; o += ld + 1;         // int
     L.oArt = o;    o += ld;
@@ -99,6 +100,8 @@ struct RowSlot {
     int row, e0, e1, nsplit, wsplit;
     int rem;  // slots from this one to the last slot of its row, itself included (1: nothing to add)
     bool first, wave_active;
+    bool inB;  // the slot's row is t or a neighbour of t (its dZ2 row can be non-zero)
+    unsigned bmask;  // bit k: entry e0 + k of the slot points at t or a neighbour of t (the only entries with a non-zero dZ2 row)
 };
 
 struct SparseFixed {
@@ -429,6 +432,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     float* sRn3 = pool + L.oRn3;
     float* sdZ1 = pool + L.odZ1;
     float* sAb = pool + L.oAb;
+    float* sGe = pool + L.oGe;
     unsigned short* scol = reinterpret_cast<unsigned short*>(pool + L.oCol);
     float* sArt = pool + L.oArt;
     float* sRn1 = pool + L.oRn1;
@@ -583,6 +587,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         z.nsplit = 1;
         z.rem = 1;
         z.first = false;
+        z.inB = false;
+        z.bmask = 0u;
         const int sl = wave * TILE + li, cnt = sh.set_rows[k];
         if (sl < sh.set_slots[k] && !sh.bad) {
             int lo = 0, hi = cnt;  // largest position in slot order with slot_start[.] <= sl
@@ -601,6 +607,9 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 z.nsplit = ns;
                 z.rem = ns - kk;
                 z.first = (kk == 0);
+                z.inB = GRAPH || level[row] <= 1;
+                for (int e = z.e0; e < z.e1; ++e)
+                    if (GRAPH || level[scol[e]] <= 1) z.bmask |= 1u << (e - z.e0);
             }
         }
         int wsplit = z.first ? z.nsplit : 1;  // longest split row of this wave in this set (uniform)
@@ -676,6 +685,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         sU2[e] = 0.0f;
     }
     for (int e = tid; e < n * sD; e += NT) sdZ1[e] = 0.0f;
+    if (!GRAPH)  // entries of rows beyond two hops are never written: their row-side products are exactly zero
+        for (int e = tid; e < nnz; e += NT) sGe[e] = 0.0f;
     // ---------------- load features, model, labels ----------------
     for (int e = tid; e < n * 32; e += NT) {
         const int r = e >> 5, c = e & 31;
@@ -1002,7 +1013,19 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 float acc[HQ], uu[HQ];
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
-                sparse_gather<false, HQ>(sAb, scol, sdZ2, sH, H, re0, re1, h, acc);
+                if constexpr (GRAPH) {
+                    sparse_gather<false, HQ>(sAb, scol, sdZ2, sH, H, re0, re1, h, acc);
+                } else {
+                    // dZ2 is non-zero only on t and its neighbours: of this slot's entries only those pointing there contribute
+                    // (typically none or one - marked in SA.bmask at setup), instead of a walk over the whole row
+                    for (unsigned m = SA.bmask; m; m &= m - 1u) {
+                        const int e = re0 + __ffs((int)m) - 1;
+                        const float a = sAb[e];
+                        const float* br = sdZ2 + (int)scol[e] * sH + h;
+#pragma unroll
+                        for (int q = 0; q < HQ; ++q) acc[q] = fmaf(a, (2 * q + h < H) ? br[2 * q] : 0.0f, acc[q]);
+                    }
+                }
                 sparse_combine<HQ>(acc, SA.rem, wsplit);
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) {
@@ -1019,6 +1042,50 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
 #pragma unroll
                 for (int q = 0; q < DQ; ++q)
                     if (first && 2 * q + h < D) dfq[q] = sdZ1[r * sD + 2 * q + h] * zraw[q];
+                if constexpr (!GRAPH) {
+                    // dL/dAbar on this slot's entries, row side: G[i][j] = dZ1[i] . (X[j] * phi) + dZ2[i] . relu(U1[j]).  Every slot
+                    // of the row (not only its first) takes its own entries; the two half-lanes take alternate entries with ALL
+                    // columns, so nothing is reduced across lanes.  The edge owners then read two floats per edge instead of
+                    // 40 - 120 (the rows of both endpoints): the work sits on the lanes that already own the rows within two hops.
+                    const int ri = SA.row;
+                    if (re0 < re1) {
+                        const bool inB = SA.inB;
+                        float dz[2 * DQ], d2[2 * HQ];
+#pragma unroll
+                        for (int c = 0; c < 2 * DQ; ++c) dz[c] = (c < D) ? sdZ1[ri * sD + c] * sh.phi[c] : 0.0f;
+#pragma unroll
+                        for (int c = 0; c < 2 * HQ; ++c) d2[c] = (inB && c < H) ? sdZ2[ri * sH + c] : 0.0f;
+                        // two entries per trip (e, e + 2: this half-lane's next two), two accumulators per entry: the loads of
+                        // both entries are in flight together and no FMA chain is longer than half a row
+                        for (int e = re0 + h; e < re1; e += 4) {
+                            const bool two = e + 2 < re1;
+                            const int j0 = scol[e], j1 = scol[two ? e + 2 : e];
+                            const float* x0 = sX + j0 * sD;
+                            const float* x1 = sX + j1 * sD;
+                            float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+#pragma unroll
+                            for (int c = 0; c < 2 * DQ; c += 2) {
+                                a0 = fmaf(dz[c], x0[c], a0);
+                                a1 = fmaf(dz[c + 1], x0[c + 1], a1);
+                                b0 = fmaf(dz[c], x1[c], b0);
+                                b1 = fmaf(dz[c + 1], x1[c + 1], b1);
+                            }
+                            if (inB) {
+                                const float* u0 = sU1 + j0 * sH;
+                                const float* u1 = sU1 + j1 * sH;
+#pragma unroll
+                                for (int c = 0; c < 2 * HQ; c += 2) {
+                                    a0 = fmaf(d2[c], relu_(u0[c]), a0);
+                                    a1 = fmaf(d2[c + 1], relu_(u0[c + 1]), a1);
+                                    b0 = fmaf(d2[c], relu_(u1[c]), b0);
+                                    b1 = fmaf(d2[c + 1], relu_(u1[c + 1]), b1);
+                                }
+                            }
+                            sGe[e] = a0 + a1;
+                            if (two) sGe[e + 2] = b0 + b1;
+                        }
+                    }
+                }
             }
             // colsum(dZ1 * Zraw): over the 16 lanes of a DPP row (row shifts), the two rows of a half (one shuffle), then
             // over the waves in fixed order
@@ -1048,13 +1115,14 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 // compile-time trip counts: all loads of an edge are issued before the first use; columns beyond
                 // D / H are read from the row padding / the next row and dropped by the select
                 float G0 = 0.0f, G1 = 0.0f;
+                if constexpr (!GRAPH) {
+                    G0 = sGe[eij[q]];   // row-side products of both directions, formed by the layer-1 backward
+                    G1 = sGe[eji[q]];
+                } else {
                 const int fl = eflag[q];
                 // columns per load group (one LDS round trip each): the reference's widths take the whole dZ1 . X product in one
                 // group and the dZ2 . relu(U1) product in two
                 constexpr int EC0 = (DQ <= 8) ? 2 * DQ : DQ, EC1 = (HQ <= 10) ? HQ : HQ / 2;
-                // dZ1 is exactly zero beyond two hops of t: such edges only get their regulariser gradients.  (Forming the two
-                // products of an edge separately, each only when its dZ row can be non-zero, was measured and is slower: four
-                // dependent load groups instead of two - 4.9 against 3.6 us per iteration on syn1's largest target.)
 #pragma unroll 1
                 for (int c0 = 0; (fl & 3) && c0 < 2 * DQ; c0 += EC0) {
 #pragma unroll
@@ -1064,7 +1132,6 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                         G0 += (c < D) ? t1 : 0.0f;
                     }
                 }
-                // dZ2 is exactly zero outside row t and its neighbours (rank-1 layer-3 backward): skip the products
 #pragma unroll 1
                 for (int c0 = 0; (fl & 12) && c0 < 2 * HQ; c0 += EC1) {
 #pragma unroll
@@ -1074,6 +1141,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                                               sdZ2[j * sH + c] * relu_(sU1[i * sH + c]));
                         G1 += (c < H) ? t2 : 0.0f;
                     }
+                }
                 }
                 float G = G0 + G1;
                 if constexpr (GRAPH) {

@@ -26,9 +26,9 @@ l2b = "            sparse_forward_rowlocal<HQ>(acc, sW2, sh.bias[1], H, H, li, h
 assert l2b in src
 src = src.replace(l2b, l2b + "            PROBE(%d);\n" % (SUB + 2), 1)
 # finer stamps inside the layer-1 backward (thread 0 = wave 0 = the hub rows)
-d1 = "                sparse_gather<false, HQ>(sAb, scol, sdZ2, sH, H, re0, re1, h, acc);\n                sparse_combine<HQ>(acc, SA.rem, wsplit);\n"
+d1 = "                sparse_combine<HQ>(acc, SA.rem, wsplit);\n#pragma unroll\n                for (int q = 0; q < HQ; ++q) {\n                    const int c = 2 * q + h;\n                    const float u = (first && c < H) ? sU1[r * sH + c] : 0.0f;\n                    float dx = acc[q];\n                    if (GRAPH ?"
 assert d1 in src
-src = src.replace(d1, d1.replace(";\n                sparse_combine", ";\n                PROBE(24);\n                sparse_combine") + "                PROBE(25);\n", 1)
+src = src.replace(d1, "                PROBE(24);\n" + d1.replace("wsplit);\n", "wsplit);\n                PROBE(25);\n", 1), 1)
 d2 = "                sparse_store_cols(c16, sdZ1 + r * sD, D, first, h);\n                wave_sync();  // the other half-lane"
 assert d2 in src
 src = src.replace(d2, "                PROBE(26);\n" + d2, 1)
