@@ -102,6 +102,7 @@ struct RowSlot {
     bool first, wave_active;
     bool inB;  // the slot's row is t or a neighbour of t (its dZ2 row can be non-zero)
     unsigned bmask;  // bit k: entry e0 + k of the slot points at t or a neighbour of t (the only entries with a non-zero dZ2 row)
+    unsigned bmask_hi;  // entries 32..63 (k_sparse_large: 64-entry slots)
 };
 
 struct SparseFixed {
@@ -589,6 +590,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         z.first = false;
         z.inB = false;
         z.bmask = 0u;
+        z.bmask_hi = 0u;
         const int sl = wave * TILE + li, cnt = sh.set_rows[k];
         if (sl < sh.set_slots[k] && !sh.bad) {
             int lo = 0, hi = cnt;  // largest position in slot order with slot_start[.] <= sl

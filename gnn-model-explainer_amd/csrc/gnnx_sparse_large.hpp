@@ -28,7 +28,7 @@ constexpr int SPL_N_MAX = 4095;             // node ids are packed in 12 bits
 constexpr int SPL_POOL_FLOATS = 39168;      // 153 KB of LDS
 __host__ __device__ constexpr int spl_stage_floats(int D) { return 16 * TILE * (D | 1); }  // a [32][D|1] dZ1 tile per wave
 
-struct SlotRec { unsigned x, y; };  // see k_sparse_large: x = row | nsplit << 12 | wsplit << 17 | first << 22 | rem << 23, y = e0 | len << 16
+struct SlotRec { unsigned x, y, m0, m1; };  // see k_sparse_large: x = row | nsplit << 12 | wsplit << 17 | first << 22 | rem << 23 | inB << 28, y = e0 | len << 16, m = entries pointing at t or its neighbours
 
 __host__ __device__ inline int sparse_slots_of_c(int deg, int chunk) { return deg <= chunk ? 1 : (deg + chunk - 1) / chunk; }
 
@@ -99,6 +99,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     float* gU1 = p.U[0] + tm.offR * FS;
     float* gU2 = p.U[1] + tm.offR * FS;
     float* gdZ1 = p.dZ[0] + tm.offR * FS;
+    float* gGe = p.dZT[0] + tm.offR * FS;   // dL/dAbar per directed entry (row-side products), nnz <= 32 ld floats
     unsigned* eidx = reinterpret_cast<unsigned*>(p.UT[0] + tm.offR * FS);  // [eup][2]: i | j << 12 | near << 24 | near2 << 25, e_ij | e_ji << 16
 
     auto fail_nan = [&]() {
@@ -213,12 +214,13 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         slot_start[cnt] = (unsigned short)(pos + (cnt - pcount));
         sh.set_rows[set] = cnt;
         sh.set_slots[set] = pos + (cnt - pcount);
-        if (2 * (pos + (cnt - pcount)) + 64 > 16 * ld) sh.bad = 1;
+        if (4 * (pos + (cnt - pcount)) + 128 > 32 * ld) sh.bad = 1;   // slot records: 4 words each in a [ld][32]-word array
     }
     __syncthreads();
     const int eup = sh.eup;
     // slot records -> workspace (set A first, then set B, each padded to whole waves): the phases walk them 512 at a time
-    //   x = row | nsplit << 12 | wsplit << 17 | first << 22 | rem << 23,   y = e0 | len << 16   (x = y = 0: empty slot; rem: RowSlot)
+    //   x = row | nsplit << 12 | wsplit << 17 | first << 22 | rem << 23 | inB << 28,   y = e0 | len << 16,   m0 / m1 = bit k: entry e0 + k
+    //   points at t or a neighbour of t   (x = y = 0: empty slot; rem, inB, bmask: RowSlot)
     SlotRec* srec = reinterpret_cast<SlotRec*>(p.UT[1] + tm.offR * FS);
     const int slotsA = sh.bad ? 0 : sh.set_slots[0], slotsB = sh.bad ? 0 : sh.set_slots[1];
     const int padA = (slotsA + 31) & ~31, padB = (slotsB + 31) & ~31;
@@ -229,7 +231,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         for (int s0 = wave * TILE; s0 < npad; s0 += NW * TILE) {  // one wave per 32 slots (both half-waves compute the same)
             const int sl = s0 + li;
             int zrow = 0, ze0 = 0, zlen = 0, zns = 1, zrem = 1;
-            bool zfirst = false;
+            bool zfirst = false, zinb = false;
+            unsigned zm0 = 0u, zm1 = 0u;
             if (sl < nslots) {
                 int lo = 0, hi = cnt;
                 while (hi - lo > 1) {
@@ -246,6 +249,9 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                     zns = ns;
                     zrem = ns - kk;
                     zfirst = (kk == 0);
+                    zinb = level[row] <= 1;
+                    for (int k2 = 0; k2 < zlen; ++k2)
+                        if (level[scol[ze0 + k2]] <= 1) (k2 < 32 ? zm0 : zm1) |= 1u << (k2 & 31);
                 }
             }
             int wsplit = zfirst ? zns : 1;
@@ -256,8 +262,11 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             }
             if (h == 0) {
                 SlotRec rec;
-                rec.x = (unsigned)zrow | ((unsigned)zns << 12) | ((unsigned)wsplit << 17) | ((unsigned)zfirst << 22) | ((unsigned)zrem << 23);
+                rec.x = (unsigned)zrow | ((unsigned)zns << 12) | ((unsigned)wsplit << 17) | ((unsigned)zfirst << 22) | ((unsigned)zrem << 23) |
+                        ((unsigned)zinb << 28);
                 rec.y = (unsigned)ze0 | ((unsigned)zlen << 16);
+                rec.m0 = zm0;
+                rec.m1 = zm1;
                 srec[base + sl] = rec;
             }
         }
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         const int npad = set ? padB : padA;
         RowSlot z;
         SlotRec rec;
-        rec.x = rec.y = 0u;
+        rec.x = rec.y = rec.m0 = rec.m1 = 0u;
         if (sl < npad) rec = srec[(set ? padA : 0) + sl];
         z.row = rec.x & 4095u;
         z.nsplit = (rec.x >> 12) & 31u;
@@ -275,6 +284,9 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         z.first = (rec.x >> 22) & 1u;
         z.rem = (rec.x >> 23) & 31u;
         if (z.rem == 0) z.rem = 1;
+        z.inB = (rec.x >> 28) & 1u;
+        z.bmask = rec.m0;
+        z.bmask_hi = rec.m1;
         z.e0 = rec.y & 0xffffu;
         z.e1 = z.e0 + (int)(rec.y >> 16);
         z.wave_active = round * (NT / 2) + wave * TILE < npad;
@@ -326,6 +338,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         gU2[e] = 0.0f;
         gdZ1[e] = 0.0f;
     }
+    for (int e = tid; e < nnz; e += NT) gGe[e] = 0.0f;   // entries of rows beyond two hops are never written
     for (int e = tid; e < D * 32; e += NT) sW1[(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + e];
     for (int e = tid; e < H * 32; e += NT) sW2[(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + 1024 + e];
     for (int e = tid; e < H * 32; e += NT) sW3[(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + 2048 + e];
@@ -509,7 +522,16 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 float acc[HQ], uu[HQ];
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
-                sparse_gather<false, HQ, SPL_GATHER_UNROLL>(sAb, scol, gdZ2, FS, H, SA.e0, SA.e1, h, acc);
+                // dZ2 is non-zero only on t and its neighbours: only this slot's entries that point there contribute (marked in the
+                // slot record), not the whole 64-entry chunk
+                for (int half = 0; half < 2; ++half)
+                    for (unsigned m = half ? SA.bmask_hi : SA.bmask; m; m &= m - 1u) {
+                        const int e = SA.e0 + 32 * half + __ffs((int)m) - 1;
+                        const float a = sAb[e];
+                        const float* br = gdZ2 + (int)scol[e] * FS + h;
+#pragma unroll
+                        for (int q = 0; q < HQ; ++q) acc[q] = fmaf(a, (2 * q + h < H) ? br[2 * q] : 0.0f, acc[q]);
+                    }
                 sparse_combine<HQ>(acc, SA.rem, SA.wsplit);
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) {
@@ -527,6 +549,44 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
 #pragma unroll
                 for (int q = 0; q < DQ; ++q)
                     if (first && 2 * q + h < D) dfq[q] = fmaf(stage[li * sS + 2 * q + h], gZraw[r * FS + 2 * q + h], dfq[q]);
+                if (SA.e0 < SA.e1) {
+                    // dL/dAbar on this slot's entries, row side (see k_sparse_resident): G[i][j] = dZ1[i] . (X[j] * phi) +
+                    // dZ2[i] . relu(U1[j]); the row's dZ1 sits in the staging tile at its FIRST slot's lane (same 16-lane group)
+                    const int ri = SA.row, lf = li - (SA.nsplit - SA.rem);
+                    const bool inB = SA.inB;
+                    float dz[2 * DQ], d2[2 * HQ];
+#pragma unroll
+                    for (int c = 0; c < 2 * DQ; ++c) dz[c] = (c < D) ? stage[lf * sS + c] * sh.phi[c] : 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 2 * HQ; ++c) d2[c] = (inB && c < H) ? gdZ2[ri * FS + c] : 0.0f;
+                    for (int e = SA.e0 + h; e < SA.e1; e += 4) {
+                        const bool two = e + 2 < SA.e1;
+                        const int j0 = scol[e], j1 = scol[two ? e + 2 : e];
+                        const float* x0 = gX + j0 * FS;
+                        const float* x1 = gX + j1 * FS;
+                        float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+#pragma unroll
+                        for (int c = 0; c < 2 * DQ; c += 2) {
+                            a0 = fmaf(dz[c], x0[c], a0);
+                            a1 = fmaf(dz[c + 1], x0[c + 1], a1);
+                            b0 = fmaf(dz[c], x1[c], b0);
+                            b1 = fmaf(dz[c + 1], x1[c + 1], b1);
+                        }
+                        if (inB) {
+                            const float* u0 = gU1 + j0 * FS;
+                            const float* u1 = gU1 + j1 * FS;
+#pragma unroll
+                            for (int c = 0; c < 2 * HQ; c += 2) {
+                                a0 = fmaf(d2[c], relu_(u0[c]), a0);
+                                a1 = fmaf(d2[c + 1], relu_(u0[c + 1]), a1);
+                                b0 = fmaf(d2[c], relu_(u1[c]), b0);
+                                b1 = fmaf(d2[c + 1], relu_(u1[c + 1]), b1);
+                            }
+                        }
+                        gGe[e] = a0 + a1;
+                        if (two) gGe[e + 2] = b0 + b1;
+                    }
+                }
                 wave_sync();  // the staging tile is reused in the next round
             }
 #pragma unroll
@@ -553,29 +613,9 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             const unsigned nd = eidx[2 * k], en = eidx[2 * k + 1];
             const int i = nd & 4095u, j = (nd >> 12) & 4095u;
             const bool near = (nd >> 24) & 1u, near2 = (nd >> 25) & 1u;
-            float G0 = 0.0f, G1 = 0.0f;
-            if (near2) {
-                const float* zi = gdZ1 + i * FS;
-                const float* zj = gdZ1 + j * FS;
-                const float* xi = gX + i * FS;
-                const float* xj = gX + j * FS;
-#pragma unroll
-                for (int c = 0; c < 2 * DQ; ++c) {
-                    const float t1 = fmaf(zi[c], xj[c], zj[c] * xi[c]) * sh.phi[c];
-                    G0 += (c < D) ? t1 : 0.0f;
-                }
-            }
-            if (near) {
-                const float* di = gdZ2 + i * FS;
-                const float* dj = gdZ2 + j * FS;
-                const float* ui = gU1 + i * FS;
-                const float* uj = gU1 + j * FS;
-#pragma unroll
-                for (int c = 0; c < 2 * HQ; ++c) {
-                    const float t2 = fmaf(di[c], relu_(uj[c]), dj[c] * relu_(ui[c]));
-                    G1 += (c < H) ? t2 : 0.0f;
-                }
-            }
+            (void)near;
+            (void)near2;
+            const float G0 = gGe[en & 0xffffu], G1 = gGe[en >> 16];   // row-side products of both directions (layer-1 backward)
             float G = G0 + G1;
             G += (i == tr) ? sG3[j] : 0.0f;
             G += (j == tr) ? sG3[i] : 0.0f;

@@ -30,23 +30,33 @@ k = len(anchors)
 end_anchor = "        if (tid < D) {  // feature mask\n"
 assert end_anchor in src
 src = src.replace(end_anchor, "        PROBE(%d);\n" % k + end_anchor, 1)
-capi = capi.replace('#include "../../include/gnnx.h"', '#include "%s"' % os.path.join(ROOT, "include", "gnnx.h"))
+capi = capi.replace('#include "../../include/gnnx.h"', '#include "../../../include/gnnx.h"')
 capi += '\nextern "C" int gnnx_probe_read(unsigned long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gnnx::g_probe), sizeof(unsigned long long) * n); }\n'
-tmp = tempfile.mkdtemp()
-for f in ("gnnx_kernels.hpp", "gnnx_resident.hpp", "gnnx_sparse.hpp"):   # unpatched copies next to the patched sources
-    open(os.path.join(tmp, f), "w").write(open(os.path.join(CSRC, f)).read())
-open(os.path.join(tmp, "gnnx_sparse_large.hpp"), "w").write(src)
-open(os.path.join(tmp, "capi_probe.hip"), "w").write(capi)
+# `--build`: cross-compile here (no GPU needed) into tools/_build_large/ - the .so travels with the gpurun snapshot
+tmp = os.path.join(ROOT, "tools", "_build", "large")
+os.makedirs(tmp, exist_ok=True)
 so = os.path.join(tmp, "libprobe.so")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-                       os.path.join(tmp, "capi_probe.hip"), "-o", so])
-import bench
+srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".hip"))]
+if "--build" in sys.argv or not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in srcs):
+    for f in os.listdir(CSRC):   # unpatched copies next to the patched source
+        if f.endswith(".hpp"):
+            open(os.path.join(tmp, f), "w").write(open(os.path.join(CSRC, f)).read())
+    open(os.path.join(tmp, "gnnx_sparse_large.hpp"), "w").write(src)
+    open(os.path.join(tmp, "capi_probe.hip"), "w").write(capi)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "capi_probe.hip", "-o", "libprobe.so"], cwd=tmp)
+if "--build" in sys.argv:
+    print("built", so)
+    sys.exit(0)
+import bench, helpers
 from gnn_model_explainer_amd import engine
 lib = engine.bind(ctypes.CDLL(so))
-wl = bench.Workload("ba100k", 0, 2048); wl.prepare()
-order = np.argsort([-len(x) for x in wl.nbs])
-sel = [int(order[int(sys.argv[1]) if len(sys.argv) > 1 else 0])]
-subs = [wl.dense_subgraph(k) for k in sel]
+wl = bench.Workload("ba100k", 2048)
+nbs = wl.idx.neighbors_batch(wl.targets)
+route_all = None
+order = np.argsort([-len(x) for x in nbs])
+kk = int(order[int(sys.argv[1]) if len(sys.argv) > 1 else 0])
+tt, nb = int(wl.targets[kk]), nbs[kk]
+subs = [wl.dense_subgraph(tt, nb, int(np.searchsorted(nb, tt)), helpers.seeded_mask0(tt, len(nb)).numpy())]
 print("target n =", subs[0].adj.shape[0], "undirected edges =", int((subs[0].adj != 0).sum() // 2))
 job = engine.MaskOptimJob(subs, wl.ck["sd"], lib=lib)
 print("route", job.route())
