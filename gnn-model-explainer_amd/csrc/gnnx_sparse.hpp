@@ -278,7 +278,7 @@ __device__ __forceinline__ void sparse_store_cols(const f32x16& c16, float* row,
 
 // backward row-local part for the lane's row: dY = (dU - U (dU.U)) / r (dU, U in registers, columns 2q + half), then
 // dZ^T[k][r] = sum_c W[k][c] dY[r][c] on MFMA; returns dZ[r][acc_row(g, half)] in c16
-template <int NQ>
+template <int NQ, bool WIDE = false>
 __device__ __forceinline__ f32x16 sparse_backward_rowlocal(const float (&du)[NQ], const float (&uu)[NQ], float rnorm,
                                                           const float* sW, int din, int dout, int li, int h) {
     float sdot = 0.0f;
@@ -292,7 +292,10 @@ __device__ __forceinline__ f32x16 sparse_backward_rowlocal(const float (&du)[NQ]
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
         const int c = 2 * u + h;
-        const float a = (li < din && c < dout) ? sW[li * 33 + c] : 0.0f;
+        // unconditional load + select where the address is in range by construction (rows li < 32 of a (D + 2H >= 32)-row weight
+        // block): a lane-varying condition around a load costs an exec-mask region, a select one instruction
+        const float aw = (WIDE || (li < din && c < dout)) ? sW[li * 33 + c] : 0.0f;
+        const float a = (li < din && c < dout) ? aw : 0.0f;
         const float b = (c < dout) ? (du[u] - uu[u] * sdot) * rinv : 0.0f;
         c16 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c16, 0, 0, 0);
     }
@@ -750,7 +753,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
 #pragma unroll
             for (int q = 0; q < DQ; ++q) {
                 zraw[q] = acc[q];
-                acc[q] = (first && 2 * q + h < D) ? acc[q] * sh.phi[2 * q + h] : 0.0f;
+                const float ph = sh.phi[2 * q + h];   // phi[32]: always in range
+                acc[q] = (first && 2 * q + h < D) ? acc[q] * ph : 0.0f;
             }
             sparse_forward_rowlocal<DQ>(acc, sW1, sh.bias[0], D, H, li, h, first, sU1 + r * sH, sRn1 + r);
         }
@@ -857,7 +861,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 uu[q] = in ? sU3[r * sO + c] : 0.0f;
                 du[q] = (in && sh.erow[64 + c] == r) ? sh.dEs[64 + c] : 0.0f;
             }
-            const f32x16 c16 = sparse_backward_rowlocal<HQ>(du, uu, first ? sRn3[r] : 1.0f, sW3, H, O, li, h);
+            const f32x16 c16 = sparse_backward_rowlocal<HQ, EXACT>(du, uu, first ? sRn3[r] : 1.0f, sW3, H, O, li, h);
             sparse_store_cols(c16, sU3 + r * sO, H, first, h);  // dZ3[r][.]
         }
         SYNC();
@@ -880,7 +884,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 acc[q] = (u > 0.0f) ? dx : 0.0f;
                 uu[q] = u;
             }
-            const f32x16 c16 = sparse_backward_rowlocal<HQ>(acc, uu, first ? sRn2[r] : 1.0f, sW2, H, H, li, h);
+            const f32x16 c16 = sparse_backward_rowlocal<HQ, EXACT>(acc, uu, first ? sRn2[r] : 1.0f, sW2, H, H, li, h);
             sparse_store_cols(c16, sdZ2w + r * sH, H, first, h);
         }
         SYNC();
@@ -988,17 +992,19 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
 #pragma unroll
             for (int q = 0; q < HQ; ++q) {
                 const int c = 2 * q + h;
-                const float u = (first && c < H) ? sU2[r * sH + c] : 0.0f;
+                const float ul = (EXACT || c < H) ? sU2[r * sH + c] : 0.0f;   // r is a valid row for every lane
+                const float u = (first && c < H) ? ul : 0.0f;
                 const float dz = (c < H) ? sh.dz3[c] : 0.0f;
                 gpart = fmaf(dz, relu_(u), gpart);
                 float dx = art * dz;
-                if (first && r == tr && c < H) dx += sh.dEs[32 + c];
+                const float de = sh.dEs[32 + c];
+                dx += (first && r == tr && c < H) ? de : 0.0f;
                 du[q] = (u > 0.0f) ? dx : 0.0f;
                 uu[q] = u;
             }
             gpart += __shfl_xor(gpart, 32);
             if (first && h == 0) sG3[r] = gpart;
-            const f32x16 c16 = sparse_backward_rowlocal<HQ>(du, uu, first ? sRn2[r] : 1.0f, sW2, H, H, li, h);
+            const f32x16 c16 = sparse_backward_rowlocal<HQ, EXACT>(du, uu, first ? sRn2[r] : 1.0f, sW2, H, H, li, h);
             sparse_store_cols(c16, sU2 + r * sH, H, first, h);  // dZ2[r][.]: every U2 value of this row is already in registers
         }
         SYNC();
@@ -1032,18 +1038,23 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) {
                     const int c = 2 * q + h;
-                    const float u = (first && c < H) ? sU1[r * sH + c] : 0.0f;
+                    const float ul = (EXACT || c < H) ? sU1[r * sH + c] : 0.0f;
+                    const float u = (first && c < H) ? ul : 0.0f;
                     float dx = acc[q];
-                    if (GRAPH ? (first && c < H && sh.erow[c] == r) : (first && r == tr && c < H)) dx += sh.dEs[c];
+                    const float de = sh.dEs[c];
+                    dx += (GRAPH ? (first && c < H && sh.erow[c] == r) : (first && r == tr && c < H)) ? de : 0.0f;
                     acc[q] = (u > 0.0f) ? dx : 0.0f;
                     uu[q] = u;
                 }
-                const f32x16 c16 = sparse_backward_rowlocal<HQ>(acc, uu, first ? sRn1[r] : 1.0f, sW1, D, H, li, h);
+                const f32x16 c16 = sparse_backward_rowlocal<HQ, EXACT>(acc, uu, first ? sRn1[r] : 1.0f, sW1, D, H, li, h);
                 sparse_store_cols(c16, sdZ1 + r * sD, D, first, h);
                 wave_sync();  // the other half-lane of this row wrote the columns this lane reads next
 #pragma unroll
                 for (int q = 0; q < DQ; ++q)
-                    if (first && 2 * q + h < D) dfq[q] = sdZ1[r * sD + 2 * q + h] * zraw[q];
+                    {
+                        const float dzl = (EXACT || 2 * q + h < D) ? sdZ1[r * sD + 2 * q + h] : 0.0f;
+                        dfq[q] = (first && 2 * q + h < D) ? dzl * zraw[q] : 0.0f;
+                    }
                 if constexpr (!GRAPH) {
                     // dL/dAbar on this slot's entries, row side: G[i][j] = dZ1[i] . (X[j] * phi) + dZ2[i] . relu(U1[j]).  Every slot
                     // of the row (not only its first) takes its own entries; the two half-lanes take alternate entries with ALL
@@ -1056,7 +1067,10 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
 #pragma unroll
                         for (int c = 0; c < 2 * DQ; ++c) dz[c] = (c < D) ? sdZ1[ri * sD + c] * sh.phi[c] : 0.0f;
 #pragma unroll
-                        for (int c = 0; c < 2 * HQ; ++c) d2[c] = (inB && c < H) ? sdZ2[ri * sH + c] : 0.0f;
+                        for (int c = 0; c < 2 * HQ; ++c) {
+                            const float dl = (EXACT || (inB && c < H)) ? sdZ2[ri * sH + c] : 0.0f;
+                            d2[c] = (inB && c < H) ? dl : 0.0f;
+                        }
                         // two entries per trip (e, e + 2: this half-lane's next two), two accumulators per entry: the loads of
                         // both entries are in flight together and no FMA chain is longer than half a row
                         for (int e = re0 + h; e < re1; e += 4) {

@@ -26,7 +26,7 @@ l2b = "            sparse_forward_rowlocal<HQ>(acc, sW2, sh.bias[1], H, H, li, h
 assert l2b in src
 src = src.replace(l2b, l2b + "            PROBE(%d);\n" % (SUB + 2), 1)
 # finer stamps inside the layer-1 backward (thread 0 = wave 0 = the hub rows)
-d1 = "                sparse_combine<HQ>(acc, SA.rem, wsplit);\n#pragma unroll\n                for (int q = 0; q < HQ; ++q) {\n                    const int c = 2 * q + h;\n                    const float u = (first && c < H) ? sU1[r * sH + c] : 0.0f;\n                    float dx = acc[q];\n                    if (GRAPH ?"
+d1 = "                sparse_combine<HQ>(acc, SA.rem, wsplit);\n#pragma unroll\n                for (int q = 0; q < HQ; ++q) {\n                    const int c = 2 * q + h;\n                    const float ul = (EXACT || c < H) ? sU1[r * sH + c] : 0.0f;"
 assert d1 in src
 src = src.replace(d1, "                PROBE(24);\n" + d1.replace("wsplit);\n", "wsplit);\n                PROBE(25);\n", 1), 1)
 d2 = "                sparse_store_cols(c16, sdZ1 + r * sD, D, first, h);\n                wave_sync();  // the other half-lane"
@@ -62,16 +62,28 @@ if "--build" in sys.argv:
 sys.argv = [a for a in sys.argv if a != "--build"]
 import bench
 from gnn_model_explainer_amd import engine
+engine_mod = engine
 lib = engine.bind(ctypes.CDLL(so))
 import helpers
-wl = bench.Workload("syn1")
+wname = sys.argv[2] if len(sys.argv) > 2 else "syn1"
+wl = bench.Workload(wname, 2048)
 nbs = wl.idx.neighbors_batch(wl.targets)
-order = np.argsort([-len(x) for x in nbs])
+if wname == "syn1":
+    order = np.argsort([-len(x) for x in nbs])
+else:   # the heaviest targets the plan routes to the 512-thread class (route 8): most edges first
+    graph = engine_mod.device_graph(wl.idx.csr, wl.feat, wl.pred)
+    dn = engine_mod.khop_device(graph, wl.targets, 3)
+    full = engine_mod.MaskOptimJob.from_csr(graph, dn, None, wl.label[wl.targets], wl.ck["sd"])
+    rt = full.route()
+    nnz = np.asarray([wl.idx.csr[nb][:, nb].nnz if r == 8 else -1 for nb, r in zip(nbs, rt)])
+    order = np.argsort(-nnz)
+    full.close()
 k = int(order[int(sys.argv[1]) if len(sys.argv) > 1 else 0])
 t, nb = int(wl.targets[k]), nbs[k]
 subs = [wl.dense_subgraph(t, nb, int(np.searchsorted(nb, t)), helpers.seeded_mask0(t, len(nb)).numpy())]
 print("target n =", subs[0].adj.shape[0], "undirected edges =", int((subs[0].adj != 0).sum() // 2))
 job = engine.MaskOptimJob(subs, wl.ck["sd"], lib=lib)
+print("route", job.route())
 job.run([s.mask0 for s in subs], engine.Hyper(num_iters=20))
 buf = (ctypes.c_ulonglong * NP)()
 lib.gnnx_probe_read(buf, NP)
