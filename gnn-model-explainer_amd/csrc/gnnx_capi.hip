@@ -76,6 +76,7 @@ struct gnnx_plan_s {
     int32_t* d_nnz = nullptr;
     int32_t* d_csr_rowptr = nullptr;   // CSR of the targets of k_sparse_large (gnnx_plan_analyze)
     unsigned short* d_csr_col = nullptr;
+    unsigned short* d_csr_row = nullptr;   // row of every directed entry
     long long* d_csr_off = nullptr;    // [2 T]: offsets of target t into the two arrays
     float* d_adam = nullptr;         // per-iteration Adam scalars for the resident kernel
     int32_t* d_rowcnt = nullptr;     // [R] scratch of gnnx_edge_counts
@@ -341,6 +342,7 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
     if (h->d_nnz) (void)hipFree(h->d_nnz);
     if (h->d_csr_rowptr) (void)hipFree(h->d_csr_rowptr);
     if (h->d_csr_col) (void)hipFree(h->d_csr_col);
+    if (h->d_csr_row) (void)hipFree(h->d_csr_row);
     if (h->d_csr_off) (void)hipFree(h->d_csr_off);
     if (h->d_adam) (void)hipFree(h->d_adam);
     if (h->d_raw_off) (void)hipFree(h->d_raw_off);
@@ -529,10 +531,10 @@ static void launch_sparse(gnnx_handle h, const Params& p, int cls, const float* 
         const dim3 grid(h->n_sp[cls]), block(SPL_THREADS);
         if (exact_shape(h, 10))
             hipLaunchKernelGGL((k_sparse_large<5, 10>), grid, block, 0, s, p, h->d_sp[cls], adam_tab, h->d_csr_rowptr,
-                               h->d_csr_col, h->d_csr_off);
+                               h->d_csr_col, h->d_csr_row, h->d_csr_off, h->d_nnz + 2 * h->prob.num_targets);
         else
             hipLaunchKernelGGL((k_sparse_large<16, 16>), grid, block, 0, s, p, h->d_sp[cls], adam_tab, h->d_csr_rowptr,
-                               h->d_csr_col, h->d_csr_off);
+                               h->d_csr_col, h->d_csr_row, h->d_csr_off, h->d_nnz + 2 * h->prob.num_targets);
         return;
     }
     if (cls == SPC_512) launch_sparse_nt<512>(h, p, h->d_sp[cls], h->n_sp[cls], adam_tab, s);
@@ -674,13 +676,19 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
     if (!h || !A) return fail("null argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int T = h->prob.num_targets;
-    if (!h->d_nnz) HIPCK(hipMalloc(&h->d_nnz, sizeof(int32_t) * 5 * T));
+    if (!h->d_nnz) HIPCK(hipMalloc(&h->d_nnz, sizeof(int32_t) * (2 + SPL_COUNTS) * T));
     hipLaunchKernelGGL(k_count_edges, dim3(T), dim3(256), 0, s, h->d_meta, A, h->d_nnz);
-    if (!h->prob.graph_mode) hipLaunchKernelGGL(k_count_edges_large, dim3(T), dim3(256), 0, s, h->d_meta, A, h->d_nnz + 2 * T);
+    if (!h->prob.graph_mode) {
+        int nmax = 0;
+        for (int t = 0; t < T; ++t) nmax = std::max(nmax, h->meta[t].n);
+        hipLaunchKernelGGL((k_count_edges_large<0, 4095>), dim3(T), dim3(256), 0, s, h->d_meta, A, h->d_nnz + 2 * T);
+        if (nmax > 4095)
+            hipLaunchKernelGGL((k_count_edges_large<4095, SPL_N_MAX>), dim3(T), dim3(256), 0, s, h->d_meta, A, h->d_nnz + 2 * T);
+    }
     HIPCK(hipGetLastError());
-    // per target: (directed entries, row slots over all rows); then (entries, slots of 64, slots of 16 within two hops)
-    h->nnz.assign(5 * (size_t)T, -1);
-    HIPCK(hipMemcpyAsync(h->nnz.data(), h->d_nnz, sizeof(int32_t) * (h->prob.graph_mode ? 2 : 5) * T, hipMemcpyDeviceToHost, s));
+    // per target: (directed entries, row slots over all rows); then k_count_edges_large's SPL_COUNTS figures
+    h->nnz.assign((2 + SPL_COUNTS) * (size_t)T, -1);
+    HIPCK(hipMemcpyAsync(h->nnz.data(), h->d_nnz, sizeof(int32_t) * (h->prob.graph_mode ? 2 : 2 + SPL_COUNTS) * T, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
     const bool graph = h->prob.graph_mode != 0;
     if (h->prob.C > RES_CMAX || h->prob.mask_relu || h->prob.bn) return 0;   // mask_act = "ReLU" and --bn run on the dense streaming kernels only
@@ -707,13 +715,13 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
                     (k < 2 || tiny_on))
                     c = CAT_SPARSE + k;
         if (!graph && nb == 1 && h->res_nbmax >= 1 && (!c || !tiny_on)) c = 1;  // dense resident: node mode only
-        const int* lg = &h->nnz[2 * (size_t)T + 3 * (size_t)t];  // (entries, slots of 64, slots of 16) within two hops
+        const int* lg = &h->nnz[2 * (size_t)T + SPL_COUNTS * (size_t)t];  // directed entries, slots of 64, slots of 16 (rows within two hops), ...
         // node mode, beyond the 256-thread class: the 512-thread class when the rows within two hops fit its 256 slots
         // (no scratch, cheaper barriers), else the 1024-thread class chosen above
         if (!graph && c512_on && (c == 0 || c == CAT_SPARSE) && lg[0] >= 0 &&
             sparse_fits(512, m.n, m.ld, lg[0], lg[2], h->prob.D, h->prob.H, h->prob.C, 0, h->prob.O))
             c = CAT_SPARSE + SPC_512;
-        if (!c && !graph && large_on && lg[0] >= 0 && sparse_large_fits(m.n, m.ld, lg[0], lg[1], h->prob.D, h->prob.H, h->prob.C))
+        if (!c && !graph && large_on && lg[0] >= 0 && sparse_large_fits(m.n, m.ld, lg, h->prob.D, h->prob.H, h->prob.C))
             c = CAT_SPARSE + SPC_LARGE;
         new_cat[t] = c;
     }
@@ -737,7 +745,7 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
         for (int t = 0; t < T; ++t) {
             if (new_cat[t] == CAT_SPARSE + 1) {  // a 256-thread target in such a batch joins the 512-thread class (else the 1024 one)
                 const TargetMeta& m = h->meta[t];
-                const int* lg = &h->nnz[2 * (size_t)T + 3 * (size_t)t];
+                const int* lg = &h->nnz[2 * (size_t)T + SPL_COUNTS * (size_t)t];
                 const bool f512 = !graph && c512_on && lg[0] >= 0 &&
                                   sparse_fits(512, m.n, m.ld, lg[0], lg[2], h->prob.D, h->prob.H, h->prob.C, 0, h->prob.O);
                 new_cat[t] = f512 ? CAT_SPARSE + SPC_512 : CAT_SPARSE;
@@ -748,8 +756,8 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
         for (int t = 0; t < T; ++t)
             if (new_cat[t] == 0)
                 std::fprintf(stderr, "gnnx route: target %d n=%d ld=%d streams: nnz=%d slots=%d | two hops: nnz=%d slots64=%d slots16=%d\n",
-                             t, h->meta[t].n, h->meta[t].ld, h->nnz[2 * t], h->nnz[2 * t + 1], h->nnz[2 * (size_t)T + 3 * (size_t)t],
-                             h->nnz[2 * (size_t)T + 3 * (size_t)t + 1], h->nnz[2 * (size_t)T + 3 * (size_t)t + 2]);
+                             t, h->meta[t].n, h->meta[t].ld, h->nnz[2 * t], h->nnz[2 * t + 1], h->nnz[2 * (size_t)T + SPL_COUNTS * (size_t)t],
+                             h->nnz[2 * (size_t)T + SPL_COUNTS * (size_t)t + 1], h->nnz[2 * (size_t)T + SPL_COUNTS * (size_t)t + 2]);
     for (int t = 0; t < T; ++t) {
         changed |= (new_cat[t] != h->cat[t]);
         h->cat[t] = new_cat[t];
@@ -765,19 +773,21 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
                 off[2 * t] = rp;
                 off[2 * t + 1] = cl;
                 rp += h->meta[t].ld + 1;
-                cl += (h->nnz[2 * (size_t)T + 3 * (size_t)t] + 1) & ~1;
+                cl += (h->nnz[2 * (size_t)T + SPL_COUNTS * (size_t)t] + 1) & ~1;
             }
-        for (void* ptr : {(void*)h->d_csr_rowptr, (void*)h->d_csr_col, (void*)h->d_csr_off})
+        for (void* ptr : {(void*)h->d_csr_rowptr, (void*)h->d_csr_col, (void*)h->d_csr_row, (void*)h->d_csr_off})
             if (ptr) (void)hipFree(ptr);
         h->d_csr_rowptr = nullptr;
         h->d_csr_col = nullptr;
+        h->d_csr_row = nullptr;
         h->d_csr_off = nullptr;
         HIPCK(hipMalloc(&h->d_csr_rowptr, sizeof(int32_t) * (size_t)rp));
         HIPCK(hipMalloc(&h->d_csr_col, sizeof(unsigned short) * (size_t)std::max<long long>(cl, 2)));
+        HIPCK(hipMalloc(&h->d_csr_row, sizeof(unsigned short) * (size_t)std::max<long long>(cl, 2)));
         HIPCK(hipMalloc(&h->d_csr_off, sizeof(long long) * off.size()));
         HIPCK(hipMemcpy(h->d_csr_off, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_build_csr_large, dim3(h->n_sp[SPC_LARGE]), dim3(512), 0, s, h->d_meta, A, h->d_sp[SPC_LARGE], h->d_csr_off,
-                           h->d_csr_rowptr, h->d_csr_col);
+                           h->d_csr_rowptr, h->d_csr_col, h->d_csr_row);
         HIPCK(hipGetLastError());
         HIPCK(hipStreamSynchronize(s));
     }

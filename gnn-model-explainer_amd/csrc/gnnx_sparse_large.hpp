@@ -1,21 +1,23 @@
 // gnnx_sparse_large.hpp — the edge-sparse, one-workgroup-per-target optimisation for targets that are too large for
-// k_sparse_resident's LDS (512 < n <= 4095 here; node mode).
+// k_sparse_resident's LDS (up to SPL_N_MAX = 16383 nodes; node mode).
 //
-// Same mathematics, row slots, hop pruning, lane mapping and helpers as k_sparse_resident (gnnx_sparse.hpp); what
-// changes is where things live:
-//   * LDS keeps what every gather chases through - the masked adjacency per directed entry, the sorted column lists,
-//     rowptr - and the per-row scalars (norms, labels, g3) and weights;
-//   * the row arrays X, U1, U2 (= dZ2), dZ1 are the caller's workspace arrays in HBM / L2 (stride 32 floats), written
-//     and re-read by the same workgroup, i.e. through one CU's L1/L2 path (__syncthreads makes them visible);
-//   * the mask entries on edges, their Adam moments and the edge weights are gathered once into compact per-edge planes
-//     (coalesced; in an otherwise unused transposed workspace array, like the per-edge indices and the slot records)
-//     and scattered back into the dense M at the end - random accesses into a 24 MB dense block cost 67 us per iteration
-//     on the largest BA-House x100k target, the planes 10;
+// Same mathematics, row slots, hop pruning, lane mapping and helpers as k_sparse_resident (gnnx_sparse.hpp).  What the
+// kernel exploits beyond that is how little of a large sub-graph the prediction loss can see:
+//   * the loss reads row t of layer 3 only (explain.py:713), so layer 2 is needed on t and its neighbours (row set B),
+//     layer 1 on the rows within two hops (row set A), and dL/dAbar is non-zero only on entries of rows in A.  On the
+//     BA-House x100k target set a 5600-node sub-graph has ~150 rows in A holding ~6400 of its 29200 directed entries;
+//   * LDS therefore keeps only the ACTIVE entries - the masked adjacency and the column ids of the rows in A, renumbered
+//     compactly with row t's entries first - plus per-slot norms and the weights.  Nothing in LDS scales with n;
+//   * an edge with BOTH endpoints beyond two hops ("far") never receives a prediction gradient: its two mask entries
+//     follow a closed scalar recursion (size + entropy + Laplacian terms through Adam) that depends on nothing else.  The
+//     iteration loop skips them; each thread runs its far edges' whole trajectories in registers afterwards (no barrier,
+//     no memory traffic).  Near edges are ordered first in the per-edge planes;
+//   * the row arrays X, U1, U2 (= dZ2) are the caller's workspace arrays in HBM / L2 (stride 32 floats, indexed by the
+//     original row id), written and re-read by the same workgroup through one CU's L1 / L2 path;
+//   * the mask entries on edges, their Adam moments, the edge weights and the Laplacian constants are gathered once into
+//     compact per-edge planes (coalesced) and scattered back into the dense M at the end;
 //   * rows of up to 1024 entries are split into slots of 64 (the BA-House x100k hubs), loops run over rows / edges
 //     instead of one item per thread.
-// Hop pruning is what makes this affordable: on the BA-House x100k sample a 2460-node sub-graph has a few hundred rows
-// within two hops of its target, so the row phases touch a small fraction of the sub-graph and the rest only costs
-// its edges' regulariser updates.
 #pragma once
 #include "gnnx_sparse.hpp"
 
@@ -24,39 +26,58 @@ namespace gnnx {
 constexpr int SPL_THREADS = 512;            // 8 waves: two per SIMD leave 256 VGPRs per lane (the 1024-thread build spilled 120)
 constexpr int SPL_GATHER_UNROLL = 4;        // entries in flight per lane: the rows come from L2, not LDS
 constexpr int SPL_CHUNK = 64;               // entries per row slot
-constexpr int SPL_N_MAX = 4095;             // node ids are packed in 12 bits
+constexpr int SPL_N_MAX = 16383;            // rows of a sub-graph (row ids are packed in 15 / 16 bits)
+constexpr int SPL_A_MAX = 8192;             // rows within two hops of the target
+constexpr int SPL_TDEG_MAX = SP_MAX_SPLIT * SPL_CHUNK;   // entries of one row in A (1024), also of row t
 constexpr int SPL_POOL_FLOATS = 39168;      // 153 KB of LDS
+constexpr int SPL_COUNTS = 6;               // k_count_edges_large: nnz, slots of 64 (A), slots of 16 (A), active entries, rows in A, slots of 64 (B)
 __host__ __device__ constexpr int spl_stage_floats(int D) { return 16 * TILE * (D | 1); }  // a [32][D|1] dZ1 tile per wave
 
-struct SlotRec { unsigned x, y, m0, m1; };  // see k_sparse_large: x = row | nsplit << 12 | wsplit << 17 | first << 22 | rem << 23 | inB << 28, y = e0 | len << 16, m = entries pointing at t or its neighbours
+// x = row | nsplit << 15 | wsplit << 20 | first << 25 | rem << 26 | inB << 31, y = e0 (compact) | len << 16,
+// set A: m0 / m1 = bit k: entry e0 + k points at t or a neighbour of t;  set B: m0 = compact index of the entry (t, row), ~0 for t itself
+struct SlotRec { unsigned x, y, m0, m1; };
 
 __host__ __device__ inline int sparse_slots_of_c(int deg, int chunk) { return deg <= chunk ? 1 : (deg + chunk - 1) / chunk; }
 
+// LDS, in floats.  Kept through the iterations: the weights, the active entries (+ one dummy entry that absorbs the
+// mirror of an entry whose row is not in A), then the dZ1 staging tiles, the per-slot row norms and the layer-3 partials of
+// t's neighbours.  The setup's temporaries overlay everything behind the active entries.
 struct SparseLargeLayout {
-    int oRowptr, oArt, oRn1, oRn2, oYhat, oG3, oW, oWp, oStage, oAb, oCol, total;
+    int oW, oWp, oAb, oCol, oStage, oRn1, oRn2, oG3, persist;
+    int tLevel, tAidx, tAlist, tAdeg, tArp, tCbase, tSlot, total;
 };
-__host__ __device__ inline SparseLargeLayout sparse_large_layout(int ld, int nnz, int D, int H, int C) {
+__host__ __device__ inline SparseLargeLayout sparse_large_layout(int ld, int nact, int nA, int padA, int padB, int D, int H, int C) {
     SparseLargeLayout L;
     int o = 0;
-    L.oRowptr = o; o += ld + 1;   // int; the degrees are counted straight into it
-    L.oArt = o;    o += ld;       // Art .. G3 (5 ld floats) double as the setup's uint16 temporaries
-    L.oRn1 = o;    o += ld;
-    L.oRn2 = o;    o += ld;
-    L.oYhat = o;   o += ld;
-    L.oG3 = o;     o += ld;
     L.oW = o;      o += (D + 2 * H) * 33;
     L.oWp = o;     o += C * 96;
-    L.oStage = o;  o += spl_stage_floats(D);
-    L.oAb = o;     o += nnz;
-    L.oCol = o;    o += (nnz + 1) / 2;
-    L.total = o;
+    L.oAb = o;     o += nact + 1;
+    L.oCol = o;    o += (nact + 2) / 2;
+    L.oStage = o;
+    int q = o;
+    q += spl_stage_floats(D);
+    L.oRn1 = q;    q += padA;
+    L.oRn2 = q;    q += padB;
+    L.oG3 = q;     q += SPL_TDEG_MAX;
+    L.persist = q;
+    L.tLevel = o;  o += (ld + 3) / 4;          // uint8 hop level per row
+    L.tAidx = o;   o += (ld + 1) / 2;          // uint16 index into the A list per row (0xffff: not in A)
+    L.tAlist = o;  o += (nA + 1) / 2;          // uint16 rows of A, ascending
+    L.tAdeg = o;   o += (nA + 1) / 2;          // uint16 their degrees
+    L.tArp = o;    o += nA;                    // int: their first entry in the full CSR
+    L.tCbase = o;  o += nA + 1;                // int: their first compact entry
+    L.tSlot = o;   o += 2 * (nA + 1 + (nA + 1) / 2 + (SPL_CHUNK + 4) / 2);   // per set: slot_start [nA + 1] (int), order [nA], bucket [CHUNK + 1] (uint16)
+    L.total = o > q ? o : q;
     return L;
 }
-// slots: row slots of 64 entries needed by the rows within two hops of the target (k_count_edges_large); they are
-// processed 512 at a time, their records (both row sets) live in a workspace array of 16 ld entries
-__host__ __device__ inline bool sparse_large_fits(int n, int ld, int nnz, int slots, int D, int H, int C) {
-    return n <= SPL_N_MAX && nnz < 65536 && 7 * (nnz / 2) <= 32 * ld && slots >= 0 && 2 * slots + 64 <= 16 * ld && C <= RES_CMAX &&
-           H >= 2 && 10 * ld >= 7 * ld + 2 * SPL_CHUNK + 16 && sparse_large_layout(ld, nnz, D, H, C).total <= SPL_POOL_FLOATS;
+// counts: what k_count_edges_large found (SPL_COUNTS ints)
+__host__ __device__ inline bool sparse_large_fits(int n, int ld, const int* counts, int D, int H, int C) {
+    const int nnz = counts[0], slotsA = counts[1], nact = counts[3], nA = counts[4], slotsB = counts[5];
+    if (nnz < 0 || slotsA < 0 || slotsB < 0 || nact < 0 || nA <= 0) return false;
+    const int padA = (slotsA + 31) & ~31, padB = (slotsB + 31) & ~31, eup = nnz / 2;
+    return n <= SPL_N_MAX && nA <= SPL_A_MAX && nact + 1 < 65536 && (nnz & 1) == 0 && 7 * eup <= 32 * ld && nact + 1 <= 32 * ld &&
+           4 * (padA + padB) <= 32 * ld && C <= RES_CMAX && H >= 2 &&
+           sparse_large_layout(ld, nact, nA, padA, padB, D, H, C).total <= SPL_POOL_FLOATS;
 }
 
 // exclusive prefix sum of a[0..len) in place by one wave (lane = tid & 63); returns the total
@@ -76,15 +97,19 @@ __device__ __forceinline__ int wave_exclusive_scan_array(T* a, int len, int lane
     return __shfl(incl, 63);
 }
 
-// csr_*: the targets' CSR structure, built once per plan by k_build_csr_large (scanning a 24 MB dense block with one
-// workgroup takes 4 ms per pass - too much to repeat in every launch): rowptr at csr_off[2 t], columns at csr_off[2 t + 1]
+// csr_*: the targets' CSR structure, built once per plan by k_build_csr_large (scanning a dense block with one
+// workgroup takes milliseconds - too much to repeat in every launch): rowptr at csr_off[2 t], the ascending columns and
+// the row of every directed entry at csr_off[2 t + 1]; counts: k_count_edges_large's output
 template <int DQ, int HQ>
-__global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const int32_t* targets, const float* adam_tab,
-                                                              const int32_t* csr_rowptr, const unsigned short* csr_col,
-                                                              const long long* csr_off) {
+__global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const int32_t* targets, const float* __restrict__ adam_tab,
+                                                              const int32_t* __restrict__ csr_rowptr,
+                                                              const unsigned short* __restrict__ csr_col,
+                                                              const unsigned short* __restrict__ csr_row,
+                                                              const long long* __restrict__ csr_off, const int32_t* __restrict__ counts) {
     constexpr int NT = SPL_THREADS, NW = NT / 64;
     __shared__ float pool[SPL_POOL_FLOATS];
     __shared__ SparseFixed sh;
+    __shared__ int s_wn[NW], s_wf[NW], s_misc[4];
     const int t = targets[blockIdx.x];
     const TargetMeta tm = p.meta[t];
     const int n = tm.n, ld = tm.ld, tr = tm.t;
@@ -93,106 +118,157 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     const int D = EXACT ? 2 * DQ : p.D, H = EXACT ? 2 * HQ : p.H, O = EXACT ? 2 * HQ : p.O, C = p.C;
     const float* Ag = p.A + tm.offQ;
     float* Mg = p.M + tm.offQ;
-    float* est = p.UT[2] + tm.offR * FS;  // per-edge planes [7][eup]: M_ij, M_ji, m_ij, m_ji, v_ij, v_ji, weight
     // row arrays in the caller's workspace (stride FS); dZ2 overwrites U2 row by row as in the resident kernel
     const float* gX = p.X + tm.offR * FS;
     float* gU1 = p.U[0] + tm.offR * FS;
     float* gU2 = p.U[1] + tm.offR * FS;
-    float* gdZ1 = p.dZ[0] + tm.offR * FS;
-    float* gGe = p.dZT[0] + tm.offR * FS;   // dL/dAbar per directed entry (row-side products), nnz <= 32 ld floats
-    unsigned* eidx = reinterpret_cast<unsigned*>(p.UT[0] + tm.offR * FS);  // [eup][2]: i | j << 12 | near << 24 | near2 << 25, e_ij | e_ji << 16
+    float* gZraw = p.Zraw + tm.offR * FS;
+    float* gGe = p.dZT[0] + tm.offR * FS;   // dL/dAbar per active entry (row-side products), [nact + 1]: the dummy stays zero
+    float* glap = p.dZT[1] + tm.offR * FS;  // per edge: c_lap / 2 (yhat_i - yhat_j)^2 / n^2 (explain.py:793-811 on a 0/1 label vector pair)
+    float* est = p.UT[2] + tm.offR * FS;    // per-edge planes [7][eup]: M_ij, M_ji, m_ij, m_ji, v_ij, v_ji, weight
+    unsigned* eidx = reinterpret_cast<unsigned*>(p.UT[0] + tm.offR * FS);  // [eup][2]: i | j << 16, c_ij | c_ji << 16 (compact entries; near edges)
+    SlotRec* srec = reinterpret_cast<SlotRec*>(p.UT[1] + tm.offR * FS);
 
     auto fail_nan = [&]() {
         const float qnan = __builtin_nanf("");
-        for (int e = tid; e < ld * ld; e += NT) p.Abar[tm.offQ + e] = qnan;
+        for (size_t e = tid; e < (size_t)ld * ld; e += NT) p.Abar[tm.offQ + e] = qnan;
         if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = qnan;
     };
-    if (n > SPL_N_MAX || 6 * ld + 1 + (D + 2 * H) * 33 + C * 96 + spl_stage_floats(D) > SPL_POOL_FLOATS) {  // uniform
-        fail_nan();
-        return;
-    }
-    // ---------------- setup 1: rowptr from the plan's CSR (the nnz-independent part of the layout comes first) ----------------
-    int* rowptr = reinterpret_cast<int*>(pool);
     const int32_t* grp = csr_rowptr + csr_off[2 * t];
-    for (int r = tid; r <= ld; r += NT) rowptr[r] = grp[r];
-    if (tid == 0) {
-        sh.nnz = grp[ld];
-        sh.bad = 0;
+    const unsigned short* gcol = csr_col + csr_off[2 * t + 1];
+    const unsigned short* grow = csr_row + csr_off[2 * t + 1];
+    const int32_t* cn = counts + (size_t)SPL_COUNTS * t;
+    const int nnz = cn[0], slotsA = cn[1], nact = cn[3], nA = cn[4], slotsB = cn[5];
+    const int eup = nnz >> 1;
+    const int padA = (slotsA + 31) & ~31, padB = (slotsB + 31) & ~31;
+    {
+        int cc[SPL_COUNTS];
+#pragma unroll
+        for (int k = 0; k < SPL_COUNTS; ++k) cc[k] = cn[k];
+        if (!sparse_large_fits(n, ld, cc, D, H, C) || grp[ld] != nnz) {  // uniform
+            fail_nan();
+            return;
+        }
     }
-    __syncthreads();
-    const int nnz = sh.nnz;
-    if (!sparse_large_fits(n, ld, nnz, 0, D, H, C)) {
+    const int rt0 = grp[tr], degT = grp[tr + 1] - rt0;
+    if (degT > SPL_TDEG_MAX) {
         fail_nan();
         return;
     }
-    const SparseLargeLayout L = sparse_large_layout(ld, nnz, D, H, C);
-    float* sArt = pool + L.oArt;
-    float* sRn1 = pool + L.oRn1;
-    float* sRn2 = pool + L.oRn2;
-    float* sYhat = pool + L.oYhat;
-    float* sG3 = pool + L.oG3;
+    const SparseLargeLayout L = sparse_large_layout(ld, nact, nA, padA, padB, D, H, C);
     float* sW1 = pool + L.oW;
     float* sW2 = sW1 + D * 33;
     float* sW3 = sW2 + H * 33;
     float* sWp = pool + L.oWp;
-    const int sS = D | 1;
-    float* stage = pool + L.oStage + wave * (TILE * sS);
     float* sAb = pool + L.oAb;
     unsigned short* scol = reinterpret_cast<unsigned short*>(pool + L.oCol);
+    const int sS = D | 1;
+    float* stage = pool + L.oStage + wave * (TILE * sS);
+    float* sRn1 = pool + L.oRn1;
+    float* sRn2 = pool + L.oRn2;
+    float* sG3 = pool + L.oG3;
+    // setup temporaries
+    unsigned char* level = reinterpret_cast<unsigned char*>(pool + L.tLevel);
+    unsigned short* aidx = reinterpret_cast<unsigned short*>(pool + L.tAidx);
+    unsigned short* alist = reinterpret_cast<unsigned short*>(pool + L.tAlist);
+    unsigned short* adeg = reinterpret_cast<unsigned short*>(pool + L.tAdeg);
+    int* arp = reinterpret_cast<int*>(pool + L.tArp);
+    int* cbase = reinterpret_cast<int*>(pool + L.tCbase);
 
-    // ---------------- setup 2: sorted column lists from the plan's CSR ----------------
-    {
-        const unsigned short* gcol = csr_col + csr_off[2 * t + 1];
-        for (int e = tid; e < nnz; e += NT) scol[e] = gcol[e];
-    }
-    __syncthreads();
-    // ---------------- setup 3: uint16 temporaries in the Art .. G3 region ----------------
-    unsigned short* u0 = reinterpret_cast<unsigned short*>(sArt);  // [ld] first upper entry (col > row) of the row
-    unsigned short* upptr = u0 + ld;                                // [ld + 1] prefix of the upper counts
-    unsigned short* level = upptr + ld + 1;                         // [ld] hop level 0..3
-    unsigned short* slot_tab = level + ld;                          // per set: slot_start [ld + 1], order [ld], bucket [CHUNK + 1]
+    // ---------------- setup 1: hop levels 0..3 from the plan's CSR ----------------
     for (int r = tid; r < ld; r += NT) {
-        const int a = rowptr[r], b = rowptr[r + 1];
-        const int f = lower_bound_u16(scol, a, b, r + 1);
-        u0[r] = (unsigned short)f;
-        upptr[r] = (unsigned short)(b - f);
         level[r] = (r == tr) ? 0 : 3;
+        aidx[r] = 0xffffu;
     }
+    if (tid == 0) sh.bad = 0;
     __syncthreads();
-    if (wave == 0) {
-        const int total = wave_exclusive_scan_array(upptr, ld, lane);
-        if (lane == 0) {
-            upptr[ld] = (unsigned short)total;
-            sh.eup = total;
+    for (int e = tid; e < degT; e += NT) level[gcol[rt0 + e]] = 1;
+    __syncthreads();
+    for (int e = wave; e < degT; e += NW) {  // one wave per neighbour of t
+        const int r = gcol[rt0 + e];
+        const int ra = grp[r], rb = grp[r + 1];
+        for (int e2 = ra + lane; e2 < rb; e2 += 64) {
+            const int c = gcol[e2];
+            if (level[c] == 3) level[c] = 2;  // benign race
         }
     }
     __syncthreads();
-    for (int d = 1; d <= 2; ++d) {  // hop levels (see k_sparse_resident)
-        for (int r = tid; r < n; r += NT)
-            if (level[r] == d - 1)
-                for (int e = rowptr[r]; e < rowptr[r + 1]; ++e)
-                    if (level[scol[e]] > d) level[scol[e]] = (unsigned short)d;  // benign race
+    // ---------------- setup 2: the rows of A (ascending), their degrees and compact entry ranges (row t first) ----------------
+    int cntA = 0;
+    for (int r0 = 0; r0 < ld; r0 += NT) {
+        const int r = r0 + tid;
+        const bool inA = r < n && level[r] <= 2;
+        const unsigned long long b = __ballot(inA);
+        if (lane == 0) s_wn[wave] = __popcll(b);
+        __syncthreads();
+        int base = cntA, tot = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int c = s_wn[w];
+            base += (w < wave) ? c : 0;
+            tot += c;
+        }
+        if (inA) {
+            const int k = base + __popcll(b & ((1ull << lane) - 1ull));
+            if (k < nA) {
+                alist[k] = (unsigned short)r;
+                aidx[r] = (unsigned short)k;
+            }
+        }
+        cntA += tot;
         __syncthreads();
     }
-    constexpr int SETSZ_EXTRA = SPL_CHUNK + 2;
+    if (cntA != nA) {  // uniform: the plan's counts do not describe this adjacency
+        fail_nan();
+        return;
+    }
+    for (int k = tid; k < nA; k += NT) {
+        const int r = alist[k];
+        const int ra = grp[r], rb = grp[r + 1];
+        arp[k] = ra;
+        adeg[k] = (unsigned short)(rb - ra);
+        cbase[k] = (r == tr) ? 0 : rb - ra;
+        if (rb - ra > SPL_TDEG_MAX) sh.bad = 1;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int total = wave_exclusive_scan_array(cbase, nA, lane);
+        if (lane == 0) s_misc[0] = total + degT;
+    }
+    __syncthreads();
+    for (int k = tid; k < nA; k += NT) cbase[k] = ((int)alist[k] == tr) ? 0 : cbase[k] + degT;
+    if (s_misc[0] != nact || sh.bad) {  // uniform
+        __syncthreads();
+        fail_nan();
+        return;
+    }
+    __syncthreads();
+    // column ids of the active entries (one pass over the directed entries, coalesced)
+    for (int e = tid; e < nnz; e += NT) {
+        const int ai = aidx[grow[e]];
+        if (ai != 0xffff) scol[cbase[ai] + (e - arp[ai])] = gcol[e];
+    }
+    __syncthreads();
+    // ---------------- setup 3: row slots of the two row sets ----------------
+    constexpr int SETSZ_U16 = SPL_CHUNK + 4;
+    const int set_words = nA + 1 + (nA + 1) / 2 + SETSZ_U16 / 2;  // ints per set: slot_start [nA + 1], then uint16 order [nA], bucket [CHUNK + 1]
     if ((tid & 31) == 0 && (tid >> 5) < 2) {  // one thread per row set: A (level <= 2), B (level <= 1)
         const int set = tid >> 5;
         const int lvlmax = 2 - set;
-        unsigned short* slot_start = slot_tab + set * (2 * ld + SETSZ_EXTRA);
-        unsigned short* order = slot_start + ld + 1;
-        unsigned short* bucket = order + ld;
+        int* slot_start = reinterpret_cast<int*>(pool + L.tSlot) + set * set_words;
+        unsigned short* order = reinterpret_cast<unsigned short*>(slot_start + nA + 1);
+        unsigned short* bucket = order + ((nA + 1) & ~1);
         int pos = 0, pcount = 0, cnt = 0;
         for (int d = 0; d <= SPL_CHUNK; ++d) bucket[d] = 0;
-        for (int rr = 0; rr < n; ++rr) {
-            if (level[rr] > lvlmax) continue;
+        for (int k = 0; k < nA; ++k) {
+            if (level[alist[k]] > lvlmax) continue;
             ++cnt;
-            const int d = rowptr[rr + 1] - rowptr[rr];
+            const int d = adeg[k];
             if (d > SPL_CHUNK) {
                 const int ns = sparse_slots_of_c(d, SPL_CHUNK);
-                if (ns > SP_MAX_SPLIT) sh.bad = 1;
                 pos = sparse_place(pos, ns);
-                order[pcount] = (unsigned short)rr;
-                slot_start[pcount] = (unsigned short)pos;
+                order[pcount] = (unsigned short)k;
+                slot_start[pcount] = pos;
                 pos += ns;
                 ++pcount;
             } else {
@@ -205,28 +281,26 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             bucket[d] = (unsigned short)run;
             run += c;
         }
-        for (int rr = 0; rr < n; ++rr) {
-            if (level[rr] > lvlmax) continue;
-            const int d = rowptr[rr + 1] - rowptr[rr];
-            if (d <= SPL_CHUNK) order[bucket[d]++] = (unsigned short)rr;
+        for (int k = 0; k < nA; ++k) {
+            if (level[alist[k]] > lvlmax) continue;
+            const int d = adeg[k];
+            if (d <= SPL_CHUNK) order[bucket[d]++] = (unsigned short)k;
         }
-        for (int q = pcount; q < cnt; ++q) slot_start[q] = (unsigned short)(pos + (q - pcount));
-        slot_start[cnt] = (unsigned short)(pos + (cnt - pcount));
+        for (int q = pcount; q < cnt; ++q) slot_start[q] = pos + (q - pcount);
+        slot_start[cnt] = pos + (cnt - pcount);
         sh.set_rows[set] = cnt;
         sh.set_slots[set] = pos + (cnt - pcount);
-        if (4 * (pos + (cnt - pcount)) + 128 > 32 * ld) sh.bad = 1;   // slot records: 4 words each in a [ld][32]-word array
+        if (pos + (cnt - pcount) != (set ? slotsB : slotsA)) sh.bad = 1;
     }
     __syncthreads();
-    const int eup = sh.eup;
-    // slot records -> workspace (set A first, then set B, each padded to whole waves): the phases walk them 512 at a time
-    //   x = row | nsplit << 12 | wsplit << 17 | first << 22 | rem << 23 | inB << 28,   y = e0 | len << 16,   m0 / m1 = bit k: entry e0 + k
-    //   points at t or a neighbour of t   (x = y = 0: empty slot; rem, inB, bmask: RowSlot)
-    SlotRec* srec = reinterpret_cast<SlotRec*>(p.UT[1] + tm.offR * FS);
-    const int slotsA = sh.bad ? 0 : sh.set_slots[0], slotsB = sh.bad ? 0 : sh.set_slots[1];
-    const int padA = (slotsA + 31) & ~31, padB = (slotsB + 31) & ~31;
+    if (sh.bad) {
+        fail_nan();
+        return;
+    }
+    // slot records -> workspace (set A first, then set B, each padded to whole half-waves): the phases walk them 256 at a time
     for (int k = 0; k < 2; ++k) {
-        const unsigned short* slot_start = slot_tab + k * (2 * ld + SETSZ_EXTRA);
-        const unsigned short* order = slot_start + ld + 1;
+        const int* slot_start = reinterpret_cast<const int*>(pool + L.tSlot) + k * set_words;
+        const unsigned short* order = reinterpret_cast<const unsigned short*>(slot_start + nA + 1);
         const int cnt = sh.set_rows[k], nslots = k ? slotsB : slotsA, npad = k ? padB : padA, base = k ? padA : 0;
         for (int s0 = wave * TILE; s0 < npad; s0 += NW * TILE) {  // one wave per 32 slots (both half-waves compute the same)
             const int sl = s0 + li;
@@ -237,11 +311,12 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 int lo = 0, hi = cnt;
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
-                    if ((int)slot_start[mid] <= sl) lo = mid; else hi = mid;
+                    if (slot_start[mid] <= sl) lo = mid; else hi = mid;
                 }
-                const int row = order[lo];
-                const int ra = rowptr[row], rb = rowptr[row + 1];
-                const int ns = sparse_slots_of_c(rb - ra, SPL_CHUNK), kk = sl - (int)slot_start[lo];
+                const int ka = order[lo];
+                const int row = alist[ka];
+                const int ra = cbase[ka], rb = ra + (int)adeg[ka];
+                const int ns = sparse_slots_of_c(rb - ra, SPL_CHUNK), kk = sl - slot_start[lo];
                 if (kk < ns) {
                     zrow = row;
                     ze0 = ra + kk * SPL_CHUNK;
@@ -250,8 +325,13 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                     zrem = ns - kk;
                     zfirst = (kk == 0);
                     zinb = level[row] <= 1;
-                    for (int k2 = 0; k2 < zlen; ++k2)
-                        if (level[scol[ze0 + k2]] <= 1) (k2 < 32 ? zm0 : zm1) |= 1u << (k2 & 31);
+                    if (k == 0) {
+                        for (int k2 = 0; k2 < zlen; ++k2)
+                            if (level[scol[ze0 + k2]] <= 1) (k2 < 32 ? zm0 : zm1) |= 1u << (k2 & 31);
+                    } else {  // the entry (t, row): row t's compact entries are 0 .. degT - 1, ascending columns
+                        const int pe = lower_bound_u16(scol, 0, degT, row);
+                        zm0 = (row != tr && pe < degT && (int)scol[pe] == row) ? (unsigned)pe : 0xffffffffu;
+                    }
                 }
             }
             int wsplit = zfirst ? zns : 1;
@@ -262,8 +342,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             }
             if (h == 0) {
                 SlotRec rec;
-                rec.x = (unsigned)zrow | ((unsigned)zns << 12) | ((unsigned)wsplit << 17) | ((unsigned)zfirst << 22) | ((unsigned)zrem << 23) |
-                        ((unsigned)zinb << 28);
+                rec.x = (unsigned)zrow | ((unsigned)zns << 15) | ((unsigned)wsplit << 20) | ((unsigned)zfirst << 25) | ((unsigned)zrem << 26) |
+                        ((unsigned)zinb << 31);
                 rec.y = (unsigned)ze0 | ((unsigned)zlen << 16);
                 rec.m0 = zm0;
                 rec.m1 = zm1;
@@ -271,20 +351,20 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             }
         }
     }
-    auto slot_of = [&](int set, int round) -> RowSlot {  // this lane's slot in the given round (512 slots per round)
+    auto slot_of = [&](int set, int round) -> RowSlot {  // this lane's slot in the given round (256 slots per round)
         const int sl = round * (NT / 2) + wave * TILE + li;
         const int npad = set ? padB : padA;
         RowSlot z;
         SlotRec rec;
         rec.x = rec.y = rec.m0 = rec.m1 = 0u;
         if (sl < npad) rec = srec[(set ? padA : 0) + sl];
-        z.row = rec.x & 4095u;
-        z.nsplit = (rec.x >> 12) & 31u;
-        z.wsplit = (rec.x >> 17) & 31u;
-        z.first = (rec.x >> 22) & 1u;
-        z.rem = (rec.x >> 23) & 31u;
+        z.row = rec.x & 32767u;
+        z.nsplit = (rec.x >> 15) & 31u;
+        z.wsplit = (rec.x >> 20) & 31u;
+        z.first = (rec.x >> 25) & 1u;
+        z.rem = (rec.x >> 26) & 31u;
         if (z.rem == 0) z.rem = 1;
-        z.inB = (rec.x >> 28) & 1u;
+        z.inB = (rec.x >> 31) & 1u;
         z.bmask = rec.m0;
         z.bmask_hi = rec.m1;
         z.e0 = rec.y & 0xffffu;
@@ -295,69 +375,101 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         return z;
     };
     const int roundsA = (padA + NT / 2 - 1) / (NT / 2), roundsB = (padB + NT / 2 - 1) / (NT / 2);
-    float* gZraw = p.Zraw + tm.offR * FS;
-    // per-edge indices -> global; Adam moments of the live entries start at zero; symmetry check
+    const float inv_n2 = 1.0f / ((float)n * (float)n);
+    // ---------------- setup 4: the undirected edges, near ones (an endpoint within two hops) first; per-edge planes ----------------
+    int eupN = 0, eupF = 0;
     {
-        bool asym = (2 * eup != nnz);
-        const int t0 = rowptr[tr], t1 = rowptr[tr + 1];
-        for (int k = tid; k < eup; k += NT) {
-            int lo = 0, hi = ld;  // largest row i with upptr[i] <= k
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if ((int)upptr[mid] <= k) lo = mid; else hi = mid;
+        bool asym = false;
+        for (int e0 = 0; e0 < nnz; e0 += NT) {
+            const int e = e0 + tid;
+            int i = 0, j = 0;
+            bool up = false;
+            if (e < nnz) {
+                i = grow[e];
+                j = gcol[e];
+                up = j > i;
             }
-            const int i = lo;
-            const int e = (int)u0[i] + (k - (int)upptr[i]);
-            const int j = scol[e];
-            const int em = lower_bound_u16(scol, rowptr[j], rowptr[j + 1], i);
-            if (em >= rowptr[j + 1] || (int)scol[em] != i) asym = true;
-            if (Ag[(size_t)j * ld + i] != Ag[(size_t)i * ld + j]) asym = true;
-            const int pi = lower_bound_u16(scol, t0, t1, i), pj = lower_bound_u16(scol, t0, t1, j);
-            const bool near = i == tr || j == tr || (pi < t1 && (int)scol[pi] == i) || (pj < t1 && (int)scol[pj] == j);
-            const bool near2 = level[i] <= 2 || level[j] <= 2;  // else dZ1 is exactly zero on both endpoints: regularisers only
-            eidx[2 * k] = (unsigned)i | ((unsigned)j << 12) | ((unsigned)near << 24) | ((unsigned)near2 << 25);
-            eidx[2 * k + 1] = (unsigned)e | ((unsigned)(asym ? e : em) << 16);
-            est[0 * eup + k] = Mg[(size_t)i * ld + j];
-            est[1 * eup + k] = Mg[(size_t)j * ld + i];
-            est[2 * eup + k] = 0.0f;
-            est[3 * eup + k] = 0.0f;
-            est[4 * eup + k] = 0.0f;
-            est[5 * eup + k] = 0.0f;
-            est[6 * eup + k] = Ag[(size_t)i * ld + j];
+            const int ai = up ? (int)aidx[i] : 0xffff, aj = up ? (int)aidx[j] : 0xffff;
+            const bool near = up && (ai != 0xffff || aj != 0xffff);
+            const bool far = up && !near;
+            const unsigned long long bn = __ballot(near), bf = __ballot(far);
+            if (lane == 0) {
+                s_wn[wave] = __popcll(bn);
+                s_wf[wave] = __popcll(bf);
+            }
+            __syncthreads();
+            int nb = eupN, fb = eupF, nt = 0, ft = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int a = s_wn[w], b = s_wf[w];
+                nb += (w < wave) ? a : 0;
+                fb += (w < wave) ? b : 0;
+                nt += a;
+                ft += b;
+            }
+            if (up) {
+                const unsigned long long lower = (1ull << lane) - 1ull;
+                const int k = near ? nb + __popcll(bn & lower) : eup - 1 - (fb + __popcll(bf & lower));
+                const float w = Ag[(size_t)i * ld + j];
+                if (Ag[(size_t)j * ld + i] != w) asym = true;
+                if (k >= 0 && k < eup) {
+                    int cij = nact, cji = nact;
+                    if (ai != 0xffff) cij = cbase[ai] + (e - arp[ai]);
+                    if (aj != 0xffff) {
+                        const int lo = cbase[aj], hi = lo + (int)adeg[aj];
+                        cji = lower_bound_u16(scol, lo, hi, i);
+                        if (cji >= hi || (int)scol[cji] != i) {
+                            asym = true;
+                            cji = nact;
+                        }
+                    }
+                    eidx[2 * k] = (unsigned)i | ((unsigned)j << 16);
+                    eidx[2 * k + 1] = (unsigned)cij | ((unsigned)cji << 16);
+                    est[0 * eup + k] = Mg[(size_t)i * ld + j];
+                    est[1 * eup + k] = Mg[(size_t)j * ld + i];
+                    est[2 * eup + k] = 0.0f;
+                    est[3 * eup + k] = 0.0f;
+                    est[4 * eup + k] = 0.0f;
+                    est[5 * eup + k] = 0.0f;
+                    est[6 * eup + k] = w;
+                    const float dy = p.yhat[tm.offR + i] - p.yhat[tm.offR + j];
+                    glap[k] = p.c_lap * 0.5f * dy * dy * inv_n2;
+                } else {
+                    asym = true;
+                }
+            }
+            eupN += nt;
+            eupF += ft;
+            __syncthreads();
         }
-        if (asym) sh.bad = 1;
+        if (asym || eupN + eupF != eup) sh.bad = 1;
     }
-    __syncthreads();  // the uint16 temporaries are dead from here on
+    __syncthreads();  // the setup temporaries are dead from here on
     if (sh.bad) {
         fail_nan();
         return;
     }
-    // ---------------- row arrays (never-written rows must read as zero), model, labels ----------------
+    // ---------------- row arrays (columns beyond the widths must read as zero), model ----------------
     for (int e = tid; e < n * FS; e += NT) {
         gU1[e] = 0.0f;
         gU2[e] = 0.0f;
-        gdZ1[e] = 0.0f;
     }
-    for (int e = tid; e < nnz; e += NT) gGe[e] = 0.0f;   // entries of rows beyond two hops are never written
+    for (int e = tid; e <= nact; e += NT) gGe[e] = 0.0f;
     for (int e = tid; e < D * 32; e += NT) sW1[(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + e];
     for (int e = tid; e < H * 32; e += NT) sW2[(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + 1024 + e];
     for (int e = tid; e < H * 32; e += NT) sW3[(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + 2048 + e];
     if (tid < 96) sh.bias[tid >> 5][tid & 31] = p.wts[WT_B + tid];
     for (int e = tid; e < C * 96; e += NT) sWp[e] = p.wts[WT_WP + e];
     if (tid < CMAX) sh.sbp[tid] = p.wts[WT_BP + tid];
-    for (int r = tid; r < ld; r += NT) {
-        sYhat[r] = p.yhat[tm.offR + r];
-        sArt[r] = 0.0f;
-    }
+    for (int e = tid; e < SPL_TDEG_MAX; e += NT) sG3[e] = 0.0f;
     if (tid < 32) {
         sh.fcur[tid] = 0.0f;  // construct_feat_mask: constant 0 (explain.py:639-641)
         sh.mf[tid] = 0.0f;
         sh.vf[tid] = 0.0f;
     }
-    const float inv_n2 = 1.0f / ((float)n * (float)n);
-    const int rt0 = rowptr[tr], rt1 = rowptr[tr + 1];
-    // sigma(M) -> symmetrised masked adjacency, one float per directed entry
-    for (int k = tid; k < eup; k += NT) {
+    if (tid == 0) sAb[nact] = 0.0f;
+    // sigma(M) -> symmetrised masked adjacency, one float per active directed entry
+    for (int k = tid; k < eupN; k += NT) {
         const unsigned en = eidx[2 * k + 1];
         const float a = est[6 * eup + k] * (0.5f * (sigmoidf_(est[0 * eup + k]) + sigmoidf_(est[1 * eup + k])));
         sAb[en & 0xffffu] = a;
@@ -367,11 +479,10 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
 
     for (int iter = 0; iter < p.num_iters; ++iter) {
         if (tid < 32) sh.phi[tid] = (tid < D) ? sigmoidf_(sh.fcur[tid]) : 0.0f;
-        for (int e = rt0 + tid; e < rt1; e += NT) sArt[scol[e]] = sAb[e];  // Abar[t][.] as a dense row (zero elsewhere)
         __syncthreads();
         const float step_size = adam_tab[2 * iter], inv_bc2s = 1.0f / adam_tab[2 * iter + 1];
 
-        // ======== layer 1 on the rows within two hops: Zraw = Abar . X (kept in registers), U1 ========
+        // ======== layer 1 on the rows within two hops: Zraw = Abar . X (kept for the feature-mask gradient), U1 ========
         for (int round = 0; round < roundsA; ++round) {
             const RowSlot SA = slot_of(0, round);
             if (!SA.wave_active) continue;  // uniform per wave
@@ -387,7 +498,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 if (first && 2 * q + h < D) gZraw[r * FS + 2 * q + h] = acc[q];  // for the feature-mask gradient
                 acc[q] = (first && 2 * q + h < D) ? acc[q] * sh.phi[2 * q + h] : 0.0f;
             }
-            sparse_forward_rowlocal<DQ>(acc, sW1, sh.bias[0], D, H, li, h, first, gU1 + r * FS, sRn1 + r);
+            sparse_forward_rowlocal<DQ>(acc, sW1, sh.bias[0], D, H, li, h, first, gU1 + r * FS,
+                                        sRn1 + round * (NT / 2) + wave * TILE + li);
         }
         __syncthreads();
         // ======== layer 2 on the target and its neighbours: U2 ========
@@ -403,14 +515,15 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             sparse_combine<HQ>(acc, SB.rem, SB.wsplit);
 #pragma unroll
             for (int q = 0; q < HQ; ++q) acc[q] = first ? acc[q] : 0.0f;
-            sparse_forward_rowlocal<HQ>(acc, sW2, sh.bias[1], H, H, li, h, first, gU2 + r * FS, sRn2 + r);
+            sparse_forward_rowlocal<HQ>(acc, sW2, sh.bias[1], H, H, li, h, first, gU2 + r * FS,
+                                        sRn2 + round * (NT / 2) + wave * TILE + li);
         }
         __syncthreads();
         // ======== row t of layer 3, head, dE, dZ3[t] ========
         {
             float z = 0.0f;
             if (li < H)
-                for (int e = rt0 + 2 * wave + h; e < rt1; e += 2 * NW) z = fmaf(sAb[e], relu_(gU2[(int)scol[e] * FS + li]), z);
+                for (int e = 2 * wave + h; e < degT; e += 2 * NW) z = fmaf(sAb[e], relu_(gU2[(int)scol[e] * FS + li]), z);
             z += __shfl_xor(z, 32);
             if (h == 0) sh.dfw[wave][li] = z;
         }
@@ -488,7 +601,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             if (!SB.wave_active) continue;
             const bool first = SB.first;
             const int r = first ? SB.row : 0;
-            const float art = sArt[r];
+            const bool nbr = first && SB.bmask != 0xffffffffu;            // a neighbour of t: Abar[t][r] is the active entry SB.bmask
+            const float art = nbr ? sAb[SB.bmask] : 0.0f;
             float du[HQ], uu[HQ];
             float gpart = 0.0f;
 #pragma unroll
@@ -503,8 +617,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 uu[q] = u;
             }
             gpart += __shfl_xor(gpart, 32);
-            if (first && h == 0) sG3[r] = gpart;
-            const f32x16 c16 = sparse_backward_rowlocal<HQ>(du, uu, first ? sRn2[r] : 1.0f, sW2, H, H, li, h);
+            if (nbr && h == 0) sG3[SB.bmask] = gpart;
+            const f32x16 c16 = sparse_backward_rowlocal<HQ>(du, uu, first ? sRn2[round * (NT / 2) + wave * TILE + li] : 1.0f, sW2, H, H, li, h);
             sparse_store_cols(c16, gU2 + r * FS, H, first, h);
         }
         __syncthreads();
@@ -542,9 +656,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                     acc[q] = (u > 0.0f) ? dx : 0.0f;
                     uu[q] = u;
                 }
-                const f32x16 c16 = sparse_backward_rowlocal<HQ>(acc, uu, first ? sRn1[r] : 1.0f, sW1, D, H, li, h);
-                sparse_store_cols(c16, gdZ1 + r * FS, D, first, h);
-                sparse_store_cols(c16, stage + li * sS, D, true, h);  // same values through LDS for the other half-lane
+                const f32x16 c16 = sparse_backward_rowlocal<HQ>(acc, uu, first ? sRn1[round * (NT / 2) + wave * TILE + li] : 1.0f, sW1, D, H, li, h);
+                sparse_store_cols(c16, stage + li * sS, D, true, h);  // dZ1 of the lane's row, through LDS for the other half-lane
                 wave_sync();
 #pragma unroll
                 for (int q = 0; q < DQ; ++q)
@@ -607,21 +720,16 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             for (int w = 0; w < NW; ++w) s += sh.dfw[w][tid];
             sh.dfp[tid] = s;
         }
-        // ======== per edge: G_ij + G_ji, regulariser gradients, Adam in place on both directed entries, next Abar ========
+        // ======== per near edge: G_ij + G_ji, regulariser gradients, Adam in place on both directed entries, next Abar ========
         const bool republish = iter + 1 < p.num_iters;  // the returned mask is the one of the LAST forward (explain.py:209-211)
-        for (int k = tid; k < eup; k += NT) {
-            const unsigned nd = eidx[2 * k], en = eidx[2 * k + 1];
-            const int i = nd & 4095u, j = (nd >> 12) & 4095u;
-            const bool near = (nd >> 24) & 1u, near2 = (nd >> 25) & 1u;
-            (void)near;
-            (void)near2;
-            const float G0 = gGe[en & 0xffffu], G1 = gGe[en >> 16];   // row-side products of both directions (layer-1 backward)
-            float G = G0 + G1;
-            G += (i == tr) ? sG3[j] : 0.0f;
-            G += (j == tr) ? sG3[i] : 0.0f;
-            const float dy = sYhat[i] - sYhat[j];
+        for (int k = tid; k < eupN; k += NT) {
+            const unsigned en = eidx[2 * k + 1];
+            const int cij = en & 0xffffu, cji = en >> 16;
+            float G = gGe[cij] + gGe[cji];                 // row-side products of both directions (layer-1 backward)
+            G += (cij < degT) ? sG3[cij] : 0.0f;           // i == t: the layer-3 part of row t of G (row t's entries come first)
+            G += (cji < degT) ? sG3[cji] : 0.0f;
             const float w = est[6 * eup + k];
-            const float gc = (0.5f * G + p.c_lap * 0.5f * dy * dy * inv_n2) * w;
+            const float gc = (0.5f * G + glap[k]) * w;
             float Mij = est[0 * eup + k], Mji = est[1 * eup + k], mij = est[2 * eup + k], mji = est[3 * eup + k],
                   vij = est[4 * eup + k], vji = est[5 * eup + k];
             {
@@ -640,13 +748,12 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             est[3 * eup + k] = mji;
             est[4 * eup + k] = vij;
             est[5 * eup + k] = vji;
-            if (republish) {  // nobody reads sAb any more in this iteration (the barrier above); sArt is rebuilt next iteration
+            if (republish) {  // nobody reads sAb any more in this iteration (the barrier above)
                 const float a = w * (0.5f * (sigmoidf_(Mij) + sigmoidf_(Mji)));
-                sAb[en & 0xffffu] = a;
-                sAb[en >> 16] = a;
+                sAb[cij] = a;
+                sAb[cji] = a;
             }
         }
-        for (int r = tid; r < ld; r += NT) sArt[r] = 0.0f;
         __syncthreads();
         if (tid < D) {  // feature mask
             const float ph = sh.phi[tid];
@@ -662,50 +769,77 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     // ---------------- results: dense Abar block (zero off the edges), M on the edges, feature mask ----------------
     {
         f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int e = tid * 4; e < ld * ld; e += 4 * NT) *reinterpret_cast<f32x4*>(p.Abar + tm.offQ + e) = z4;
+        for (size_t e = (size_t)tid * 4; e < (size_t)ld * ld; e += 4 * NT) *reinterpret_cast<f32x4*>(p.Abar + tm.offQ + e) = z4;
     }
     __threadfence_block();
     __syncthreads();
-    for (int k = tid; k < eup; k += NT) {
+    for (int k = tid; k < eupN; k += NT) {
         const unsigned nd = eidx[2 * k], en = eidx[2 * k + 1];
-        const int i = nd & 4095u, j = (nd >> 12) & 4095u;
-        const float a = sAb[en & 0xffffu];
+        const int i = nd & 0xffffu, j = nd >> 16;
+        const int cij = en & 0xffffu, cji = en >> 16;
+        const float a = sAb[cij != nact ? cij : cji];   // a near edge has at least one of its two entries in a row of A
         p.Abar[tm.offQ + (size_t)i * ld + j] = a;
         p.Abar[tm.offQ + (size_t)j * ld + i] = a;
         Mg[(size_t)i * ld + j] = est[0 * eup + k];
         Mg[(size_t)j * ld + i] = est[1 * eup + k];
     }
+    // ---------------- far edges: the whole trajectory of both mask entries in registers ----------------
+    for (int k = eupN + tid; k < eup; k += NT) {
+        const unsigned nd = eidx[2 * k];
+        const int i = nd & 0xffffu, j = nd >> 16;
+        const float w = est[6 * eup + k];
+        const float gc = glap[k] * w;   // (0.5 G + lap) w with G = 0 exactly
+        float Mij = est[0 * eup + k], Mji = est[1 * eup + k], mij = 0.0f, mji = 0.0f, vij = 0.0f, vji = 0.0f;
+        float a = w * (0.5f * (sigmoidf_(Mij) + sigmoidf_(Mji)));
+        for (int iter = 0; iter < p.num_iters; ++iter) {
+            const float step_size = adam_tab[2 * iter], inv_bc2s = 1.0f / adam_tab[2 * iter + 1];
+            const float Si = sigmoidf_(Mij), Sj = sigmoidf_(Mji);
+            a = w * (0.5f * (Si + Sj));   // the mask of this iteration's forward
+            const float gi = (gc + p.c_size - p.c_ent * Mij * inv_n2) * Si * (1.0f - Si);
+            const float gj = (gc + p.c_size - p.c_ent * Mji * inv_n2) * Sj * (1.0f - Sj);
+            adam_update(Mij, mij, vij, gi, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+            adam_update(Mji, mji, vji, gj, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+        }
+        p.Abar[tm.offQ + (size_t)i * ld + j] = a;
+        p.Abar[tm.offQ + (size_t)j * ld + i] = a;
+        Mg[(size_t)i * ld + j] = Mij;
+        Mg[(size_t)j * ld + i] = Mji;
+    }
     if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = (tid < D) ? sh.fcur[tid] : 0.0f;
 }
 
 // gnnx_plan_analyze, every target with n <= SPL_N_MAX (also those of <= 512 rows that fit no resident class, e.g. more
-// than 2048 edges): directed entries and the row slots (of SPL_CHUNK entries)
-// needed by the rows within two hops of the target - the same levels and placement as k_sparse_large computes - and the
-// same count for slots of SP_CHUNK entries (the 512-thread class of k_sparse_resident).
-// out[3 t] = nnz, out[3 t + 1] = slots of 64 (-1: a row that cannot be placed), out[3 t + 2] = slots of 16 (-1 likewise);
-// targets outside the range get -1 everywhere.
+// than 2048 edges): the quantities k_sparse_large's layout depends on, with the same hop levels and slot placement as the
+// kernel computes.  out[SPL_COUNTS t ..] = directed entries, row slots of SPL_CHUNK entries of the rows within two hops
+// (-1: a row that cannot be placed), the same for slots of SP_CHUNK entries (the 512-thread class of k_sparse_resident),
+// directed entries of the rows within two hops, rows within two hops, row slots of SPL_CHUNK entries of t and its
+// neighbours.  Targets outside (NLO, NMAX] are left alone (two instantiations: the LDS tables of the large one would
+// halve the occupancy of a launch over thousands of small targets).
+template <int NLO, int NMAX>
 __global__ __launch_bounds__(256) void k_count_edges_large(const TargetMeta* meta, const float* A, int32_t* out) {
-    __shared__ int deg[SPL_N_MAX + 1];
-    __shared__ unsigned char level[SPL_N_MAX + 1];
+    __shared__ int deg[NMAX + 1];
+    __shared__ unsigned char level[NMAX + 1];
     __shared__ int part[4];
     const TargetMeta tm = meta[blockIdx.x];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tm.n > SPL_N_MAX) {
-        if (tid == 0) {
-            out[3 * blockIdx.x] = -1;
-            out[3 * blockIdx.x + 1] = -1;
-            out[3 * blockIdx.x + 2] = -1;
-        }
+    int32_t* o = out + (size_t)SPL_COUNTS * blockIdx.x;
+    if (tm.n <= NLO || tm.n > NMAX) {
+        if (tm.n > SPL_N_MAX && tid < SPL_COUNTS) o[tid] = -1;
         return;
     }
     const float* Ag = A + tm.offQ;
     int cnt = 0;
     for (int r = wave; r < tm.n; r += 4) {
         int d = 0;
-        for (int c0 = 0; c0 < tm.n; c0 += 64) {
-            const int c = c0 + lane;
-            const bool nz = (c < tm.n && c != r) ? (Ag[(size_t)r * tm.ld + c] != 0.0f) : false;
-            d += __popcll(__ballot(nz));
+        for (int c0 = 0; c0 < tm.n; c0 += 256) {
+            float a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + 64 * u + lane;
+                a[u] = (c < tm.n && c != r) ? Ag[(size_t)r * tm.ld + c] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) d += __popcll(__ballot(a[u] != 0.0f));
         }
         cnt += d;
         if (lane == 0) deg[r] = d;
@@ -723,12 +857,15 @@ __global__ __launch_bounds__(256) void k_count_edges_large(const TargetMeta* met
         }
         __syncthreads();
     }
-    if (tid < 2) {  // thread 0: slots of SPL_CHUNK entries, thread 1: slots of SP_CHUNK entries
-        const int chunk = tid ? SP_CHUNK : SPL_CHUNK;
-        int pos = 0, singles = 0;
+    if (tid < 3) {  // thread 0: slots of SPL_CHUNK entries (A), thread 1: slots of SP_CHUNK entries (A), thread 2: slots of SPL_CHUNK (B)
+        const int chunk = (tid == 1) ? SP_CHUNK : SPL_CHUNK;
+        const int lvlmax = (tid == 2) ? 1 : 2;
+        int pos = 0, singles = 0, rows = 0, entries = 0;
         bool placeable = true;
         for (int r = 0; r < tm.n; ++r) {
-            if (level[r] > 2) continue;
+            if (level[r] > lvlmax) continue;
+            ++rows;
+            entries += deg[r];
             if (deg[r] > chunk) {
                 const int ns = sparse_slots_of_c(deg[r], chunk);
                 placeable &= ns <= SP_MAX_SPLIT;
@@ -737,15 +874,26 @@ __global__ __launch_bounds__(256) void k_count_edges_large(const TargetMeta* met
                 ++singles;
             }
         }
-        if (tid == 0) out[3 * blockIdx.x] = part[0] + part[1] + part[2] + part[3];
-        out[3 * blockIdx.x + 1 + tid] = placeable ? pos + singles : -1;
+        const int slots = placeable ? pos + singles : -1;
+        if (tid == 0) {
+            o[0] = part[0] + part[1] + part[2] + part[3];
+            o[1] = slots;
+            o[3] = entries;
+            o[4] = rows;
+        } else if (tid == 1) {
+            o[2] = slots;
+        } else {
+            o[5] = slots;
+        }
     }
 }
 
-// gnnx_plan_analyze: CSR (rowptr [ld + 1], ascending columns) of every target routed to k_sparse_large, from its block
-// of the packed dense adjacency; one workgroup per target, rows by waves, 4 chunks of 64 columns in flight per wave.
+// gnnx_plan_analyze: CSR (rowptr [ld + 1], ascending columns, the row of every entry) of every target routed to
+// k_sparse_large, from its block of the packed dense adjacency; one workgroup per target, rows by waves, 4 chunks of 64
+// columns in flight per wave.
 __global__ __launch_bounds__(512) void k_build_csr_large(const TargetMeta* meta, const float* A, const int32_t* targets,
-                                                         const long long* csr_off, int32_t* csr_rowptr, unsigned short* csr_col) {
+                                                         const long long* csr_off, int32_t* csr_rowptr, unsigned short* csr_col,
+                                                         unsigned short* csr_row) {
     const int t = targets[blockIdx.x];
     const TargetMeta tm = meta[t];
     const int n = tm.n, ld = tm.ld;
@@ -754,6 +902,7 @@ __global__ __launch_bounds__(512) void k_build_csr_large(const TargetMeta* meta,
     const float* Ag = A + tm.offQ;
     int32_t* rowptr = csr_rowptr + csr_off[2 * t];
     unsigned short* col = csr_col + csr_off[2 * t + 1];
+    unsigned short* row = csr_row + csr_off[2 * t + 1];
     __shared__ int srp[SPL_N_MAX + 34];
     for (int r = wave; r < ld; r += NW) {
         int cnt = 0;
@@ -790,7 +939,11 @@ __global__ __launch_bounds__(512) void k_build_csr_large(const TargetMeta* meta,
             for (int u = 0; u < 4; ++u) {
                 const bool nz = a[u] != 0.0f;
                 const unsigned long long bal = __ballot(nz);
-                if (nz) col[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(c0 + 64 * u + lane);
+                if (nz) {
+                    const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                    col[pos] = (unsigned short)(c0 + 64 * u + lane);
+                    row[pos] = (unsigned short)r;
+                }
                 base += __popcll(bal);
             }
         }

@@ -353,6 +353,65 @@ def test_large_target_more_than_512_row_slots(be):
     assert np.array_equal(res.mask[0][~live], m0[~live])
 
 
+def test_large_target_far_edges_run_their_own_recursion(be):
+    """A sparse graph of large diameter (n = 900, average degree 2.4): most edges have both endpoints more than two hops
+    from the target, never see a prediction gradient and are optimised by k_sparse_large outside its iteration loop (a
+    closed scalar recursion per mask entry: size + entropy + Laplacian terms through Adam); 12 iterations against the
+    closed form on every entry."""
+    rng = np.random.default_rng(17)
+    sd = helpers.random_model(rng, 10, 20, 20, 4)
+    n = 900
+    A, X = helpers.random_graph(rng, n, 10, density=2.4 / n)
+    t = int(np.argmax(A.sum(1)))
+    m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
+    sg = Subgraph(A, X, 1, t, rng.integers(0, 4, n), m0)
+    lvl = np.full(n, 9)
+    lvl[t] = 0
+    for d in (1, 2):
+        lvl[(A[lvl == d - 1].sum(0) > 0) & (lvl > d)] = d
+    far = (A != 0) & (lvl[:, None] > 2) & (lvl[None, :] > 2)
+    assert far.sum() > 0.5 * (A != 0).sum()
+    job = be.job([sg], sd)
+    assert list(job.route()) == [7]
+    res = job.run([m0], Hyper(num_iters=12))
+    o = closed_form.ClosedFormOracle(A, X, sd, 1, sg.pred_label, t, m0)
+    want = o.run(12)
+    live = A != 0
+    assert np.abs(res.masked_adj[0] - want).max() < 5e-6
+    assert np.abs(res.masked_adj[0] - want)[far].max() < 1e-6
+    assert np.abs(res.mask[0] - o.M)[live].max() < 5e-5 and np.abs(res.feat_mask[0] - o.f).max() < 5e-5
+    assert np.array_equal(res.mask[0][~live], m0[~live])
+    assert np.array_equal(res.masked_adj[0], res.masked_adj[0].T)
+
+
+def test_large_target_beyond_4095_rows(be):
+    """n = 4300 with a 300-neighbour hub next to the target: nothing k_sparse_large keeps in LDS scales with n (only the
+    entries of the rows within two hops do), so the target takes the sparse kernel instead of streaming 4320^2 dense
+    blocks through every iteration."""
+    rng = np.random.default_rng(23)
+    sd = helpers.random_model(rng, 10, 20, 20, 4)
+    n = 4300
+    A, X = helpers.random_graph(rng, n, 10, density=2.0 / n)
+    hub = 4200
+    idx = rng.choice(np.arange(n), 300, replace=False)
+    idx = idx[idx != hub]
+    A[hub, idx] = 1
+    A[idx, hub] = 1
+    t = int(idx.max())
+    m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
+    sg = Subgraph(A, X, 2, t, rng.integers(0, 4, n), m0)
+    job = be.job([sg], sd)
+    assert list(job.route()) == [7]
+    res = job.run([m0], Hyper(num_iters=3))
+    o = closed_form.ClosedFormOracle(A, X, sd, 2, sg.pred_label, t, m0)
+    want = o.run(3)
+    live = A != 0
+    assert np.abs(res.masked_adj[0] - want).max() < 5e-6
+    assert np.abs(res.mask[0] - o.M)[live].max() < 5e-5 and np.abs(res.feat_mask[0] - o.f).max() < 5e-5
+    assert np.array_equal(res.mask[0][~live], m0[~live])
+    assert np.all(res.masked_adj[0][~live] == 0)
+
+
 @pytest.mark.parametrize("case,n", [("edgeless", 40), ("isolated target", 60), ("isolated target", 700)])
 def test_sparse_kernels_degenerate_graphs(be, case, n):
     """No edge at all / a target without neighbours (its row of every layer is the bias direction, the edge masks only

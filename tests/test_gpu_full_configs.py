@@ -142,8 +142,9 @@ def test_config4_graph_mode_64_of_4337_graphs_vs_reference():
 
 def test_config5_ba100k_route_stratified_targets_vs_reference():
     """BASELINE config 5 (BA-House x100k, 99 997 nodes): real targets from n = 6 to n > 4095, hubs of up to 749
-    neighbours, one per kernel route - 64- / 256- / 512-thread sparse resident classes, k_sparse_large (n > 2000, hub rows
-    split over 64-entry slots) and the dense streaming kernels (n > 4095) - against the reference's ExplainModule."""
+    neighbours, one per kernel route - 64- / 256- / 512-thread sparse resident classes, k_sparse_large (n > 2000 and
+    n > 4095, hub rows split over 64-entry slots) and, for the largest one, also the dense streaming kernels - against the
+    reference's ExplainModule."""
     z = _full("ba100k_explain.npz")
     ck = helpers.load_ckpt("syn1")
     N, edges, label = synthetic.ba_house(42857, 11428, seed=0)
@@ -159,7 +160,8 @@ def test_config5_ba100k_route_stratified_targets_vs_reference():
     job = MaskOptimJob.from_csr(graph, dn, None, label[targets], ck["sd"])
     route = job.route()
     print("ba100k routes:", {int(t): (int(n), int(r)) for t, n, r in zip(targets, dn.sizes, route)})
-    assert {0, 7}.issubset(set(route)) and (6 in route) and ((8 in route) or (4 in route)), route
+    assert (7 in route) and (6 in route) and ((8 in route) or (4 in route)) and 0 not in route, route
+    assert all(r == 7 for r, nn in zip(route, dn.sizes) if nn > 4095) and max(dn.sizes) > 4095   # k_sparse_large takes them since round 2
     job.set_masks_raw(engine.init_edge_masks_raw(dn.sizes, seeds=1000 + targets))
     job.launch(Hyper(num_iters=int(z["epochs"])))
     em = job.fetch_edges()
@@ -170,6 +172,19 @@ def test_config5_ba100k_route_stratified_targets_vs_reference():
         ferr = np.abs(_sig(em.feat_mask[k]) - z[f"{t}:feat_sig"]).max()
         print(f"  target {t}: n={dn.sizes[k]} route={route[k]} err={err:.2e} feat={ferr:.2e}")
         assert err <= TOL and ferr <= TOL, (t, dn.sizes[k], route[k], err, ferr)
+    # the largest target once more on the dense streaming kernels (what loss logging, mask_act = ReLU and --bn run on)
+    k = int(np.argmax(dn.sizes))
+    t = int(targets[k])
+    nb = [dn.lists()[k]]
+    job = MaskOptimJob.from_csr(graph, nb, [dn.rows[k]], label[[t]], ck["sd"], analyze=False)
+    assert list(job.route()) == [0]
+    job.set_masks_raw(engine.init_edge_masks_raw(dn.sizes[k:k + 1], seeds=1000 + targets[k:k + 1]))
+    job.launch(Hyper(num_iters=int(z["epochs"])))
+    em = job.fetch_edges()
+    err = np.abs(em.masked_adj - z[f"{t}:vals"]).max()
+    ferr = np.abs(_sig(em.feat_mask[0]) - z[f"{t}:feat_sig"]).max()
+    print(f"  target {t} on the streaming kernels: n={dn.sizes[k]} err={err:.2e} feat={ferr:.2e}")
+    assert err <= TOL and ferr <= TOL
 
 
 def test_edge_list_results_equal_dense_results():

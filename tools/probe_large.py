@@ -12,15 +12,15 @@ NP = 32
 src = src.replace("namespace gnnx {\n", "namespace gnnx {\n__device__ unsigned long long g_probe[%d];\n"
                   "#define PROBE(k) do { if (iter == 5 && threadIdx.x == 0 && blockIdx.x == 0) g_probe[(k)] = wall_clock64(); } while (0)\n" % NP, 1)
 src = src.replace("#define PROBE(k)", "#define PROBE0(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_probe[(k)] = wall_clock64(); } while (0)\n#define PROBE(k)", 1)
-setup_marks = [("    // ---------------- setup 1: rowptr from the plan", 16), ("    // ---------------- setup 2: sorted column lists", 17),
-               ("    // ---------------- setup 3: uint16 temporaries", 18), ("    constexpr int SETSZ_EXTRA", 19),
-               ("    const int eup = sh.eup;\n    // slot records", 20), ("    // per-edge indices -> global", 21),
-               ("    // ---------------- row arrays (never-written rows", 22), ("    for (int iter = 0; iter < p.num_iters; ++iter) {", 23),
-               ("    // ---------------- results: dense Abar block", 24)]
+setup_marks = [("    // ---------------- setup 1: hop levels", 16), ("    // ---------------- setup 2: the rows of A", 17),
+               ("    // column ids of the active entries", 18), ("    // ---------------- setup 3: row slots", 19),
+               ("    // slot records -> workspace", 20), ("    // ---------------- setup 4: the undirected edges", 21),
+               ("    // ---------------- row arrays (columns beyond", 22), ("    for (int iter = 0; iter < p.num_iters; ++iter) {", 23),
+               ("    // ---------------- results: dense Abar block", 24), ("    // ---------------- far edges: the whole trajectory", 25)]
 for mark, idx in setup_marks:
     assert mark in src, mark
     src = src.replace(mark, "    PROBE0(%d);\n" % idx + mark, 1)
-src = src.replace("    if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = (tid < D) ? sh.fcur[tid] : 0.0f;\n}", "    if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = (tid < D) ? sh.fcur[tid] : 0.0f;\n    PROBE0(25);\n}", 1)
+src = src.replace("    if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = (tid < D) ? sh.fcur[tid] : 0.0f;\n}", "    if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = (tid < D) ? sh.fcur[tid] : 0.0f;\n    PROBE0(26);\n}", 1)
 anchors = [l for l in src.split("\n") if l.strip().startswith("// ========")]
 names = []
 for k, a in enumerate(anchors):
@@ -50,7 +50,8 @@ if "--build" in sys.argv:
 import bench, helpers
 from gnn_model_explainer_amd import engine
 lib = engine.bind(ctypes.CDLL(so))
-wl = bench.Workload("ba100k", 2048)
+NTARGETS = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+wl = bench.Workload("ba100k", NTARGETS)
 nbs = wl.idx.neighbors_batch(wl.targets)
 route_all = None
 order = np.argsort([-len(x) for x in nbs])
@@ -69,7 +70,8 @@ for nme, v in zip(names, d):
     print("%-100s %7.2f us" % (nme[:100], v))
 print("iteration (without the feature-mask tail) %7.2f us" % ((a[len(names)] - a[0]) * 10.0 / 1e3))
 b = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
-lab = ["rowptr from the plan CSR", "column lists from the plan CSR", "upper counts, hop levels", "slot tables (one thread per set)",
-       "slot records", "edge indices + state planes", "row arrays / model / first Abar", "20 iterations", "dense Abar + M scatter"]
+lab = ["hop levels", "rows of A, compact entry ranges", "active column ids", "slot tables (one thread per set)",
+       "slot records", "edges (near first) + state planes", "row arrays / model / first Abar", "20 iterations", "dense Abar + near scatter",
+       "far edges (20 iterations in registers)"]
 for i, nme in enumerate(lab):
     print("%-50s %9.1f us" % (nme, (b[17 + i] - b[16 + i]) / 100.0))
