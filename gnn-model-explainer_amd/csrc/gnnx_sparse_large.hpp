@@ -24,7 +24,9 @@
 namespace gnnx {
 
 constexpr int SPL_THREADS = 512;            // 8 waves: two per SIMD leave 256 VGPRs per lane (the 1024-thread build spilled 120)
-constexpr int SPL_GATHER_UNROLL = 4;        // entries in flight per lane: the rows come from L2, not LDS
+// entries in flight per lane in the row gathers: the rows come from L2 (~1 us per dependent round trip), so as many as the
+// register file allows - NQ floats per entry per lane
+__host__ __device__ constexpr int spl_gather_unroll(int nq) { return nq <= 5 ? 8 : nq <= 10 ? 4 : 2; }
 constexpr int SPL_CHUNK = 64;               // entries per row slot
 constexpr int SPL_N_MAX = 16383;            // rows of a sub-graph (row ids are packed in 15 / 16 bits)
 constexpr int SPL_A_MAX = 8192;             // rows within two hops of the target
@@ -95,6 +97,51 @@ __device__ __forceinline__ int wave_exclusive_scan_array(T* a, int len, int lane
         run += v;
     }
     return __shfl(incl, 63);
+}
+
+// Row gather from a row array in global memory (stride FS): acc[q] += sum_e Abar_e * f(B[col_e][2 q + half]).
+// What limits these gathers is the L1's line rate - every lane addresses another row, so a load instruction costs one
+// cache-line access per lane whatever its width.  The slot's two lanes therefore split its ENTRIES (parity), load whole
+// rows with 16-byte loads (3 accesses per 10-column row instead of 10) and swap the column sums they owe each other at
+// the end.  UN entries in flight per lane.
+template <bool RELU, int NQ, int UN>
+__device__ __forceinline__ void sparse_gather_rows(const float* sAb, const unsigned short* scol, const float* B, int W, int e0,
+                                                   int e1, int half, float (&acc)[NQ]) {
+    constexpr int NV = (2 * NQ + 3) / 4;
+    float full[2 * NQ];
+#pragma unroll
+    for (int c = 0; c < 2 * NQ; ++c) full[c] = 0.0f;
+#pragma unroll 1
+    for (int e = e0 + half; e < e1; e += 2 * UN) {
+        float a[UN];
+        const float* br[UN];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const bool in = e + 2 * j < e1;
+            const int idx = in ? e + 2 * j : e;
+            a[j] = in ? sAb[idx] : 0.0f;
+            br[j] = B + (int)scol[idx] * FS;
+        }
+        f32x4 v[UN][NV];
+#pragma unroll
+        for (int j = 0; j < UN; ++j)
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[j][k] = *reinterpret_cast<const f32x4*>(br[j] + 4 * k);
+#pragma unroll
+        for (int j = 0; j < UN; ++j)
+#pragma unroll
+            for (int c = 0; c < 2 * NQ; ++c) {
+                float x = (W == 2 * NQ || c < W) ? v[j][c >> 2][c & 3] : 0.0f;
+                if (RELU) x = relu_(x);
+                full[c] = fmaf(a[j], x, full[c]);
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const float mine = half ? full[2 * q + 1] : full[2 * q];
+        const float owed = half ? full[2 * q] : full[2 * q + 1];   // the other half's column
+        acc[q] += mine + __shfl_xor(owed, 32);
+    }
 }
 
 // csr_*: the targets' CSR structure, built once per plan by k_build_csr_large (scanning a dense block with one
@@ -491,7 +538,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             float acc[DQ];
 #pragma unroll
             for (int q = 0; q < DQ; ++q) acc[q] = 0.0f;
-            sparse_gather<false, DQ, SPL_GATHER_UNROLL>(sAb, scol, gX, FS, D, SA.e0, SA.e1, h, acc);
+            sparse_gather_rows<false, DQ, spl_gather_unroll(DQ)>(sAb, scol, gX, D, SA.e0, SA.e1, h, acc);
             sparse_combine<DQ>(acc, SA.rem, SA.wsplit);
 #pragma unroll
             for (int q = 0; q < DQ; ++q) {
@@ -511,7 +558,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             float acc[HQ];
 #pragma unroll
             for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
-            sparse_gather<true, HQ, SPL_GATHER_UNROLL>(sAb, scol, gU1, FS, H, SB.e0, SB.e1, h, acc);
+            sparse_gather_rows<true, HQ, spl_gather_unroll(HQ)>(sAb, scol, gU1, H, SB.e0, SB.e1, h, acc);
             sparse_combine<HQ>(acc, SB.rem, SB.wsplit);
 #pragma unroll
             for (int q = 0; q < HQ; ++q) acc[q] = first ? acc[q] : 0.0f;
@@ -638,14 +685,34 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
                 // dZ2 is non-zero only on t and its neighbours: only this slot's entries that point there contribute (marked in the
                 // slot record), not the whole 64-entry chunk
-                for (int half = 0; half < 2; ++half)
-                    for (unsigned m = half ? SA.bmask_hi : SA.bmask; m; m &= m - 1u) {
-                        const int e = SA.e0 + 32 * half + __ffs((int)m) - 1;
-                        const float a = sAb[e];
-                        const float* br = gdZ2 + (int)scol[e] * FS + h;
+                // (two marked entries per trip, one per lane of the slot, whole rows in 16-byte loads: see sparse_gather_rows)
+                {
+                    constexpr int NV = (2 * HQ + 3) / 4;
+                    float full[2 * HQ];
 #pragma unroll
-                        for (int q = 0; q < HQ; ++q) acc[q] = fmaf(a, (2 * q + h < H) ? br[2 * q] : 0.0f, acc[q]);
+                    for (int c = 0; c < 2 * HQ; ++c) full[c] = 0.0f;
+                    unsigned long long m = (unsigned long long)SA.bmask | ((unsigned long long)SA.bmask_hi << 32);
+                    while (m) {
+                        const unsigned long long m1 = m & (m - 1ull);             // without the lowest marked entry
+                        const unsigned long long mine = h ? m1 : m;               // lane 1 of the slot takes the second lowest
+                        const bool have = mine != 0ull;
+                        const int e = SA.e0 + (have ? __ffsll((long long)mine) - 1 : 0);
+                        const float a = have ? sAb[e] : 0.0f;
+                        const float* br = gdZ2 + (int)scol[e] * FS;
+                        f32x4 v[NV];
+#pragma unroll
+                        for (int k = 0; k < NV; ++k) v[k] = *reinterpret_cast<const f32x4*>(br + 4 * k);
+#pragma unroll
+                        for (int c = 0; c < 2 * HQ; ++c) full[c] = fmaf(a, (EXACT || c < H) ? v[c >> 2][c & 3] : 0.0f, full[c]);
+                        m = m1 & (m1 - 1ull);
                     }
+#pragma unroll
+                    for (int q = 0; q < HQ; ++q) {
+                        const float mine = h ? full[2 * q + 1] : full[2 * q];
+                        const float owed = h ? full[2 * q] : full[2 * q + 1];
+                        acc[q] = mine + __shfl_xor(owed, 32);
+                    }
+                }
                 sparse_combine<HQ>(acc, SA.rem, SA.wsplit);
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) {
@@ -672,32 +739,40 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                     for (int c = 0; c < 2 * DQ; ++c) dz[c] = (c < D) ? stage[lf * sS + c] * sh.phi[c] : 0.0f;
 #pragma unroll
                     for (int c = 0; c < 2 * HQ; ++c) d2[c] = (inB && c < H) ? gdZ2[ri * FS + c] : 0.0f;
-                    for (int e = SA.e0 + h; e < SA.e1; e += 4) {
-                        const bool two = e + 2 < SA.e1;
-                        const int j0 = scol[e], j1 = scol[two ? e + 2 : e];
-                        const float* x0 = gX + j0 * FS;
-                        const float* x1 = gX + j1 * FS;
-                        float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+                    // PK entries per trip and lane: their X / U1 rows (L2) are all requested before the first product
+                    constexpr int PK = EXACT ? 4 : 1;
+                    for (int e = SA.e0 + h; e < SA.e1; e += 2 * PK) {
+                        int jj[PK];
+                        float s0[PK], s1[PK];
 #pragma unroll
-                        for (int c = 0; c < 2 * DQ; c += 2) {
-                            a0 = fmaf(dz[c], x0[c], a0);
-                            a1 = fmaf(dz[c + 1], x0[c + 1], a1);
-                            b0 = fmaf(dz[c], x1[c], b0);
-                            b1 = fmaf(dz[c + 1], x1[c + 1], b1);
+                        for (int k = 0; k < PK; ++k) {
+                            jj[k] = scol[(e + 2 * k < SA.e1) ? e + 2 * k : e];
+                            s0[k] = 0.0f;
+                            s1[k] = 0.0f;
                         }
-                        if (inB) {
-                            const float* u0 = gU1 + j0 * FS;
-                            const float* u1 = gU1 + j1 * FS;
 #pragma unroll
-                            for (int c = 0; c < 2 * HQ; c += 2) {
-                                a0 = fmaf(d2[c], relu_(u0[c]), a0);
-                                a1 = fmaf(d2[c + 1], relu_(u0[c + 1]), a1);
-                                b0 = fmaf(d2[c], relu_(u1[c]), b0);
-                                b1 = fmaf(d2[c + 1], relu_(u1[c + 1]), b1);
+                        for (int k = 0; k < PK; ++k) {
+                            const float* x = gX + jj[k] * FS;
+#pragma unroll
+                            for (int c = 0; c < 2 * DQ; c += 2) {
+                                s0[k] = fmaf(dz[c], x[c], s0[k]);
+                                s1[k] = fmaf(dz[c + 1], x[c + 1], s1[k]);
                             }
                         }
-                        gGe[e] = a0 + a1;
-                        if (two) gGe[e + 2] = b0 + b1;
+                        if (inB) {
+#pragma unroll
+                            for (int k = 0; k < PK; ++k) {
+                                const float* u = gU1 + jj[k] * FS;
+#pragma unroll
+                                for (int c = 0; c < 2 * HQ; c += 2) {
+                                    s0[k] = fmaf(d2[c], relu_(u[c]), s0[k]);
+                                    s1[k] = fmaf(d2[c + 1], relu_(u[c + 1]), s1[k]);
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < PK; ++k)
+                            if (e + 2 * k < SA.e1) gGe[e + 2 * k] = s0[k] + s1[k];
                     }
                 }
                 wave_sync();  // the staging tile is reused in the next round

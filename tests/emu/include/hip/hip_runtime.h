@@ -86,6 +86,7 @@ inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "ok" : "emulator: unsupported"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
