@@ -14,7 +14,7 @@ before the timed region (`value`); the end-to-end rate of one batch - device-sid
 optimisation, edge-list D2H - is reported beside it as `pcie_inclusive`.
 
 N > 1 (BASELINE.json configs[4], the north-star scaling curve): BA-House scaled to 100k nodes, ONE fixed set of 16384
-motif targets (seed-fixed) split over the ranks by longest-processing-time-first on n^2 (parallel.lpt_shards); every
+motif targets (seed-fixed) split over the ranks by longest-processing-time-first on parallel.target_cost(n); every
 rank optimises its shard as one batched job and the masks are gathered as edge entries through RCCL INSIDE the timed
 region.  Strong scaling: the total work is fixed, value = 16384 * K / max-over-ranks time.
 
@@ -41,7 +41,7 @@ MFMA_F32_PEAK = 157.3e12     # flop/s, dense f32 MFMA
 LDS_PEAK_PER_CU = 128 * 2.4e9   # B/s: ds_read_b32 = 128 B/clk/CU at ~2.4 GHz (MI355X_MICROARCH.md, LDS table)
 NUM_CUS = 256
 PARITY_TOL = 1e-5
-RNG_THREADS = 4              # host threads drawing the seeded initial masks (targets are independent under the seed protocol)
+RNG_THREADS = max(4, min(16, (os.cpu_count() or 4) // 8))   # host threads drawing the seeded initial masks (targets are independent under the seed protocol; 8 ranks share the host)
 WELL = 2e-6                  # CPU-vs-CPU deviation (reference vs closed-form oracle) up to which a target is well conditioned
 
 
@@ -213,7 +213,7 @@ def main():
 
     if world > 1:
         sizes = engine.khop_device(graph, wl.targets, 3).sizes.astype(np.float64)
-        shard = parallel.lpt_shards(sizes ** 2, world)[rank]
+        shard = parallel.lpt_shards(parallel.target_cost(sizes), world)[rank]
         my_targets = wl.targets[np.asarray(shard, np.int64)]
     else:
         shard, my_targets = list(range(len(wl.targets))), wl.targets
@@ -409,7 +409,7 @@ def main():
                           "launch": "plain" if args.no_graph else "hipGraph", "resident_path": not args.no_resident,
                           "routing_rank0": {"streaming": int((route == 0).sum()), "dense_resident": int(((route >= 1) & (route <= 3)).sum()),
                                             "sparse_resident": int(((route >= 4) & (route != 7)).sum()), "sparse_large": int((route == 7).sum())},
-                          "parallelism": (f"target-sharded x{world}: LPT on n^2, masks all-gathered as edge entries over RCCL inside the timed region"
+                          "parallelism": (f"target-sharded x{world}: LPT on the per-class GPU-time model (parallel.target_cost), masks all-gathered as edge entries over RCCL inside the timed region"
                                           if world > 1 else "single GPU")},
                "roofline": roof}
         if parity is not None:
@@ -431,8 +431,11 @@ def main():
         # per-rank load (sum n^2) and, on rank 0, the SAME workload on one GPU (for the scaling denominator)
         loads = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(loads, torch.tensor([job.sum_n2], device=dev, dtype=torch.float64))
+        costs = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(costs, torch.tensor([float(parallel.target_cost(job.n).sum())], device=dev, dtype=torch.float64))
         if rank == 0:
             out["config"]["sum_n2_per_rank"] = [float(x.item()) for x in loads]
+            out["config"]["modelled_gpu_us_per_rank"] = [float(x.item()) for x in costs]
             out["config"]["gathered_edge_entries_per_rank"] = gather_bufs["counts"]
         job.close()
         del job

@@ -681,9 +681,9 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
     if (!h->prob.graph_mode) {
         int nmax = 0;
         for (int t = 0; t < T; ++t) nmax = std::max(nmax, h->meta[t].n);
-        hipLaunchKernelGGL((k_count_edges_large<0, 4095>), dim3(T), dim3(256), 0, s, h->d_meta, A, h->d_nnz + 2 * T);
+        hipLaunchKernelGGL((k_count_edges_large<0, 4095>), dim3(T), dim3(1024), 0, s, h->d_meta, A, h->d_nnz + 2 * T);
         if (nmax > 4095)
-            hipLaunchKernelGGL((k_count_edges_large<4095, SPL_N_MAX>), dim3(T), dim3(256), 0, s, h->d_meta, A, h->d_nnz + 2 * T);
+            hipLaunchKernelGGL((k_count_edges_large<4095, SPL_N_MAX>), dim3(T), dim3(1024), 0, s, h->d_meta, A, h->d_nnz + 2 * T);
     }
     HIPCK(hipGetLastError());
     // per target: (directed entries, row slots over all rows); then k_count_edges_large's SPL_COUNTS figures
@@ -741,9 +741,17 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
     // ... unless the big targets all take the 512-thread class: then they and the single-tile targets (64-thread code path,
     // six per workgroup) share ONE launch, k_sparse_resident_mixed, and nothing needs to overlap
     const bool mixable = !graph && mix_on && tiny_on && has_large && !has_1024;
+    // Throughput regime: with more big workgroups than the chip has CUs nothing needs to overlap - every launch fills the
+    // GPU by itself - and what counts is workgroups per CU: a 256-thread target (n <= 128) then keeps its own class (two per
+    // CU, 72 KB of LDS each) instead of taking a whole CU as a 512-thread workgroup.  Measured on the BA-House x100k set:
+    // see DESIGN.md.  GNNX_KEEP_256 = 0 / 1 overrides.
+    int n_bigwg = 0;
+    for (int t = 0; t < T; ++t) n_bigwg += (new_cat[t] == CAT_SPARSE || new_cat[t] == CAT_SPARSE + 1 || new_cat[t] == CAT_SPARSE + SPC_512);
+    bool keep256 = n_bigwg > 2 * 256;
+    if (const char* env = std::getenv("GNNX_KEEP_256")) keep256 = std::atoi(env) != 0;
     if (has_large)
         for (int t = 0; t < T; ++t) {
-            if (new_cat[t] == CAT_SPARSE + 1) {  // a 256-thread target in such a batch joins the 512-thread class (else the 1024 one)
+            if (new_cat[t] == CAT_SPARSE + 1 && !keep256) {  // a 256-thread target in such a batch joins the 512-thread class (else the 1024 one)
                 const TargetMeta& m = h->meta[t];
                 const int* lg = &h->nnz[2 * (size_t)T + SPL_COUNTS * (size_t)t];
                 const bool f512 = !graph && c512_on && lg[0] >= 0 &&
@@ -786,7 +794,7 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
         HIPCK(hipMalloc(&h->d_csr_row, sizeof(unsigned short) * (size_t)std::max<long long>(cl, 2)));
         HIPCK(hipMalloc(&h->d_csr_off, sizeof(long long) * off.size()));
         HIPCK(hipMemcpy(h->d_csr_off, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_build_csr_large, dim3(h->n_sp[SPC_LARGE]), dim3(512), 0, s, h->d_meta, A, h->d_sp[SPC_LARGE], h->d_csr_off,
+        hipLaunchKernelGGL(k_build_csr_large, dim3(h->n_sp[SPC_LARGE]), dim3(1024), 0, s, h->d_meta, A, h->d_sp[SPC_LARGE], h->d_csr_off,
                            h->d_csr_rowptr, h->d_csr_col, h->d_csr_row);
         HIPCK(hipGetLastError());
         HIPCK(hipStreamSynchronize(s));

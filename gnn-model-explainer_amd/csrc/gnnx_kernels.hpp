@@ -440,32 +440,35 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
             // cache lines per wave instruction and was 12 % slower here (BA-House x100k: 152-162 vs 171-181 us).
             const float* Ab = p.Abar + tm.offQ + row0 + li;
             const int k0 = wave * kchunk + h;
-            float a0[8], b0[8], a1[8], b1[8];
-            auto load8 = [&](float (&a)[8], float (&b)[8], int s0) {
+            // the launch ends with the workgroups of the largest target, and their K loop is a chain of dependent round
+            // trips to HBM: KB k pairs per batch, two batches in flight per wave (KB = 8: 39 round trips for ld = 2464)
+            constexpr int KB = 16;
+            float a0[KB], b0[KB], a1[KB], b1[KB];
+            auto loadb = [&](float (&a)[KB], float (&b)[KB], int s0) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const bool on = (s0 + 2 * u) < kchunk;  // a batch spans 16 k values, kchunk is a multiple of 8
+                for (int u = 0; u < KB; ++u) {
+                    const bool on = (s0 + 2 * u) < kchunk;  // a batch spans 2 KB k values, kchunk is a multiple of 8
                     const int k = k0 + s0 + 2 * u;
                     a[u] = on ? Ab[(size_t)k * ld] : 0.0f;
                     b[u] = on ? Bsrc[(size_t)k * FS] : 0.0f;
                 }
             };
-            auto mma8 = [&](const float (&a)[8], const float (&b)[8]) {
+            auto mmab = [&](const float (&a)[KB], const float (&b)[KB]) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < KB; ++u) {
                     float bb = b[u];
                     if (relu_b) bb = fmaxf(bb, 0.0f);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bb, acc, 0, 0, 0);
                 }
             };
-            load8(a0, b0, 0);
-            for (int s0 = 0; s0 < kchunk; s0 += 32) {
-                const bool more1 = s0 + 16 < kchunk;
-                if (more1) load8(a1, b1, s0 + 16);
-                mma8(a0, b0);
-                const bool more0 = s0 + 32 < kchunk;
-                if (more0) load8(a0, b0, s0 + 32);
-                if (more1) mma8(a1, b1);
+            loadb(a0, b0, 0);
+            for (int s0 = 0; s0 < kchunk; s0 += 4 * KB) {
+                const bool more1 = s0 + 2 * KB < kchunk;
+                if (more1) loadb(a1, b1, s0 + 2 * KB);
+                mmab(a0, b0);
+                const bool more0 = s0 + 4 * KB < kchunk;
+                if (more0) loadb(a0, b0, s0 + 4 * KB);
+                if (more1) mmab(a1, b1);
             }
         }
     }

@@ -891,10 +891,11 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
 // neighbours.  Targets outside (NLO, NMAX] are left alone (two instantiations: the LDS tables of the large one would
 // halve the occupancy of a launch over thousands of small targets).
 template <int NLO, int NMAX>
-__global__ __launch_bounds__(256) void k_count_edges_large(const TargetMeta* meta, const float* A, int32_t* out) {
+__global__ __launch_bounds__(1024) void k_count_edges_large(const TargetMeta* meta, const float* A, int32_t* out) {
+    constexpr int NW = 16, UN = 8;   // the scan of a dense block is latency-bound: 16 waves x 8 chunks of 64 columns in flight
     __shared__ int deg[NMAX + 1];
     __shared__ unsigned char level[NMAX + 1];
-    __shared__ int part[4];
+    __shared__ int part[NW];
     const TargetMeta tm = meta[blockIdx.x];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int32_t* o = out + (size_t)SPL_COUNTS * blockIdx.x;
@@ -904,30 +905,39 @@ __global__ __launch_bounds__(256) void k_count_edges_large(const TargetMeta* met
     }
     const float* Ag = A + tm.offQ;
     int cnt = 0;
-    for (int r = wave; r < tm.n; r += 4) {
+    for (int r = wave; r < tm.n; r += NW) {
         int d = 0;
-        for (int c0 = 0; c0 < tm.n; c0 += 256) {
-            float a[4];
+        for (int c0 = 0; c0 < tm.n; c0 += 64 * UN) {
+            float a[UN];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UN; ++u) {
                 const int c = c0 + 64 * u + lane;
                 a[u] = (c < tm.n && c != r) ? Ag[(size_t)r * tm.ld + c] : 0.0f;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) d += __popcll(__ballot(a[u] != 0.0f));
+            for (int u = 0; u < UN; ++u) d += __popcll(__ballot(a[u] != 0.0f));
         }
         cnt += d;
         if (lane == 0) deg[r] = d;
     }
-    for (int r = tid; r < tm.n; r += 256) level[r] = (r == tm.t) ? 0 : 3;
+    for (int r = tid; r < tm.n; r += 64 * NW) level[r] = (r == tm.t) ? 0 : 3;
     if (lane == 0) part[wave] = cnt;
     __syncthreads();
     for (int d = 1; d <= 2; ++d) {  // hop levels from the dense rows
-        for (int r = wave; r < tm.n; r += 4) {
+        for (int r = wave; r < tm.n; r += NW) {
             if (level[r] != d - 1) continue;  // uniform per wave
-            for (int c0 = 0; c0 < tm.n; c0 += 64) {
-                const int c = c0 + lane;
-                if (c < tm.n && c != r && Ag[(size_t)r * tm.ld + c] != 0.0f && level[c] > d) level[c] = (unsigned char)d;
+            for (int c0 = 0; c0 < tm.n; c0 += 64 * UN) {
+                float a[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int c = c0 + 64 * u + lane;
+                    a[u] = (c < tm.n && c != r) ? Ag[(size_t)r * tm.ld + c] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int c = c0 + 64 * u + lane;
+                    if (a[u] != 0.0f && level[c] > d) level[c] = (unsigned char)d;
+                }
             }
         }
         __syncthreads();
@@ -951,7 +961,9 @@ __global__ __launch_bounds__(256) void k_count_edges_large(const TargetMeta* met
         }
         const int slots = placeable ? pos + singles : -1;
         if (tid == 0) {
-            o[0] = part[0] + part[1] + part[2] + part[3];
+            int total = 0;
+            for (int w = 0; w < NW; ++w) total += part[w];
+            o[0] = total;
             o[1] = slots;
             o[3] = entries;
             o[4] = rows;
@@ -966,14 +978,14 @@ __global__ __launch_bounds__(256) void k_count_edges_large(const TargetMeta* met
 // gnnx_plan_analyze: CSR (rowptr [ld + 1], ascending columns, the row of every entry) of every target routed to
 // k_sparse_large, from its block of the packed dense adjacency; one workgroup per target, rows by waves, 4 chunks of 64
 // columns in flight per wave.
-__global__ __launch_bounds__(512) void k_build_csr_large(const TargetMeta* meta, const float* A, const int32_t* targets,
+__global__ __launch_bounds__(1024) void k_build_csr_large(const TargetMeta* meta, const float* A, const int32_t* targets,
                                                          const long long* csr_off, int32_t* csr_rowptr, unsigned short* csr_col,
                                                          unsigned short* csr_row) {
     const int t = targets[blockIdx.x];
     const TargetMeta tm = meta[t];
     const int n = tm.n, ld = tm.ld;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    constexpr int NW = 8;
+    constexpr int NW = 16, UN = 8;   // latency-bound scan: 16 waves x 8 chunks of 64 columns in flight
     const float* Ag = A + tm.offQ;
     int32_t* rowptr = csr_rowptr + csr_off[2 * t];
     unsigned short* col = csr_col + csr_off[2 * t + 1];
@@ -982,15 +994,15 @@ __global__ __launch_bounds__(512) void k_build_csr_large(const TargetMeta* meta,
     for (int r = wave; r < ld; r += NW) {
         int cnt = 0;
         if (r < n)
-            for (int c0 = 0; c0 < n; c0 += 256) {
-                float a[4];
+            for (int c0 = 0; c0 < n; c0 += 64 * UN) {
+                float a[UN];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < UN; ++u) {
                     const int c = c0 + 64 * u + lane;
                     a[u] = (c < n && c != r) ? Ag[(size_t)r * ld + c] : 0.0f;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) cnt += __popcll(__ballot(a[u] != 0.0f));
+                for (int u = 0; u < UN; ++u) cnt += __popcll(__ballot(a[u] != 0.0f));
             }
         if (lane == 0) srp[r] = cnt;
     }
@@ -1000,18 +1012,18 @@ __global__ __launch_bounds__(512) void k_build_csr_large(const TargetMeta* meta,
         if (lane == 0) srp[ld] = total;
     }
     __syncthreads();
-    for (int r = tid; r <= ld; r += 512) rowptr[r] = srp[r];
+    for (int r = tid; r <= ld; r += 64 * NW) rowptr[r] = srp[r];
     for (int r = wave; r < n; r += NW) {
         int base = srp[r];
-        for (int c0 = 0; c0 < n; c0 += 256) {
-            float a[4];
+        for (int c0 = 0; c0 < n; c0 += 64 * UN) {
+            float a[UN];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UN; ++u) {
                 const int c = c0 + 64 * u + lane;
                 a[u] = (c < n && c != r) ? Ag[(size_t)r * ld + c] : 0.0f;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UN; ++u) {
                 const bool nz = a[u] != 0.0f;
                 const unsigned long long bal = __ballot(nz);
                 if (nz) {

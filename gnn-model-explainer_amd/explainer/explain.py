@@ -173,7 +173,7 @@ class Explainer:
         and predicted labels (gnnx_pack_csr) all come from the CSR graph resident on the GPU; the host only draws the
         initial masks (the caller's torch CPU generator, one normal_ per target in list order, like
         construct_edge_mask) and receives the masks as edge lists (gnnx_gather_edges).  With torch.distributed
-        initialised (one process per GPU) the targets are sharded over the ranks by n^2 (parallel.run_sharded) and
+        initialised (one process per GPU) the targets are sharded over the ranks by modelled GPU time (parallel.target_cost, parallel.run_sharded) and
         every rank returns the full list."""
         begin = time.time()
         lib, device = _ENGINE["lib"], _ENGINE["device"]
@@ -240,8 +240,8 @@ class Explainer:
 
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            from ..parallel import run_sharded
-            got = run_sharded(list(range(len(targets))), dn.sizes.astype(np.float64) ** 2, compute)
+            from ..parallel import run_sharded, target_cost
+            got = run_sharded(list(range(len(targets))), target_cost(dn.sizes), compute)
             out = [got[i] for i in range(len(targets))]
         else:
             out = compute(list(range(len(targets))))

@@ -1,9 +1,10 @@
 """Multi-GPU target sharding (one process per GPU, torch.distributed; backend "nccl" = RCCL over xGMI).
 
 Targets are independent: the only communication is distributing the target list and
-collecting the finished masks — there is NO collective inside the 300-iteration loop.  Cost model: a target's
-work is proportional to n_t^2 (dense mask); shards are balanced by longest-processing-time-first, which matters
-because the size distribution is heavy-tailed (on BA-House x100k one target is 0.08 % of the whole job).
+collecting the finished masks — there is NO collective inside the 300-iteration loop.  Cost model: `target_cost`
+(GPU time a target adds to a saturated batch, by kernel class); shards are balanced by
+longest-processing-time-first, which matters because the size distribution is heavy-tailed (BA-House x100k: 74 %
+of the targets have n <= 32 and cost 2.5 us each, the 757 with n > 512 cost ~45 us each).
 
 The reference has no distributed code at all; this replaces the sequential
 `[self.explain(i) for i in node_indices]` (explainer/explain.py:296-299) across devices.
@@ -11,6 +12,19 @@ The reference has no distributed code at all; this replaces the sequential
 from typing import Callable, Dict, List, Sequence
 
 import numpy as np
+
+
+def target_cost(sizes) -> np.ndarray:
+    """GPU time (microseconds) one target of n nodes adds to a batch that fills an MI355X, 300 iterations: the quantity the
+    shards must balance.  Measured by size class on the BA-House x100k target set (tools/probe_classes.py, round 2): the
+    edge-sparse kernels cost per workgroup slot, not per n^2 - 2.2-3.1 us for the one-wave class (n <= 32, six or seven
+    targets per CU), ~11 us for the 256-thread class (n <= 128, two per CU), 14-20 us for the 512-thread class (one per CU,
+    ~10-13 us per iteration whatever n), ~45 us for k_sparse_large (n ~ 900 on average; its iteration grows with the
+    entries of the rows within two hops).  Targets beyond its range stream dense n x n blocks: ~28 n^2 bytes per iteration
+    at ~4 TB/s."""
+    n = np.asarray(sizes, np.float64)
+    cost = np.where(n <= 32, 2.5, np.where(n <= 128, 11.0, np.where(n <= 512, 10.0 + 0.02 * n, 25.0 + 0.025 * n)))
+    return np.where(n > 16383, 300 * 28.0 * n * n / 4e6, cost)
 
 
 def lpt_shards(costs: Sequence[float], world_size: int) -> List[List[int]]:

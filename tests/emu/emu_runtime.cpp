@@ -1,3 +1,5 @@
+#include <cstdlib>
+#include <cmath>
 // TEST INFRASTRUCTURE ONLY — fiber scheduler behind tests/emu/include/hip/hip_runtime.h.
 #include <hip/hip_runtime.h>
 
@@ -120,6 +122,22 @@ int shfl_xor_i(int v, int mask) {
 
 // v_mfma_f32_32x32x2_f32: A[i][k] from lane i + 32k, B[k][j] from lane j + 32k,
 // D[i][j] in lane j + 32*((i>>2)&1), register (i&3) + 4*(i>>3); k-ordered fma chain.
+// GNNX_EMU_ULP_NOISE=<seed>: the results of the "hardware form" intrinsics move by -1 / 0 / +1 ulp at random - a stand-in for
+// v_rcp_f32 / v_sqrt_f32 / v_exp_f32, used to ask which targets' trajectories depend on that last bit (tools/ulp_sensitivity.py)
+float hw_form(float v) {
+    static int mode = -1;
+    static unsigned long long state = 0;
+    if (mode < 0) {
+        const char* env = std::getenv("GNNX_EMU_ULP_NOISE");
+        mode = env ? 1 : 0;
+        state = env ? 0x9E3779B97F4A7C15ull * (unsigned long long)(std::atoll(env) + 1) : 0;
+    }
+    if (!mode || !std::isfinite(v) || v == 0.0f) return v;
+    state = state * 6364136223846793005ull + 1442695040888963407ull;
+    const int k = (int)((state >> 33) % 3) - 1;
+    return k == 0 ? v : std::nextafter(v, k > 0 ? INFINITY : -INFINITY);
+}
+
 f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
     int buf = 0, lane = 0;
     wave_collective([&](WaveSlot& w, int bf, int ln) { w.fa[bf][ln] = a; w.fb[bf][ln] = b; buf = bf; lane = ln; });

@@ -51,6 +51,7 @@ void wave_sync();
 int dpp_row_shl(int v, int shift);
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 f32x16 mfma_32x32x2(float a, float b, f32x16 c);
+float hw_form(float v);   // identity, or +-1 ulp at random when GNNX_EMU_ULP_NOISE=<seed> (the hardware's v_rcp / v_sqrt / v_exp are ~1 ulp forms)
 }  // namespace emu
 
 inline void __syncthreads() { emu::syncthreads(); }
@@ -71,11 +72,11 @@ inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mas
 }
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2((a), (b), (c))
-#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_rcpf(x) emu::hw_form(1.0f / (x))
 inline float emu_fmed3f(float a, float b, float c) { return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c)); }
 #define __builtin_amdgcn_fmed3f(a, b, c) emu_fmed3f((a), (b), (c))
-#define __builtin_amdgcn_sqrtf(x) std::sqrt(x)
-#define __expf(x) std::exp(x)
+#define __builtin_amdgcn_sqrtf(x) emu::hw_form(std::sqrt(x))
+#define __expf(x) emu::hw_form(std::exp(x))
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
 #ifndef __HIP_MEMORY_SCOPE_AGENT

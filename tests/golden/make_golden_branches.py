@@ -91,7 +91,7 @@ def _worker(job):
     return out
 
 
-def run(name, trials, watch_trials, procs):
+def run(name, trials, watch_trials, procs, only=None):
     graph_mode = name == "config4"
     z = np.load(os.path.join(HERE, name + ("_explain.npz" if graph_mode else "_full_explain.npz")))
     ids = z["graphs"] if graph_mode else z["targets"]
@@ -101,6 +101,10 @@ def run(name, trials, watch_trials, procs):
     if os.path.exists(wp):
         watch = {int(t) for t in json.load(open(wp)).get(name, [])}
     items = [(k, watch_trials if int(ids[k]) in watch else trials) for k in range(T)]
+    old = None
+    if only:      # --only: re-sample just these targets (with the watch budget) and keep the stored outcomes of all the others
+        old = np.load(os.path.join(HERE, name + "_branches.npz"))
+        items = [(k, watch_trials) for k in range(T) if int(ids[k]) in only]
     items.sort(key=lambda it: -it[1] * (100 if graph_mode else int(z["nb_off"][it[0] + 1] - z["nb_off"][it[0]])))     # long jobs first
     jobs = [(name, items[p::procs * 8]) for p in range(procs * 8)]
     t0 = time.time()
@@ -108,11 +112,27 @@ def run(name, trials, watch_trials, procs):
         res = sorted((r for part in pool.map(_worker, jobs) for r in part), key=lambda r: r[0])
     D = z["feat_sig"].shape[1]
     at, ae, av, af = [], [], [], []
+    if old is not None:
+        redo = {r[0] for r in res}
+        tr, pd, pde = old["trials"].copy(), old["pert_dev"].copy(), old["pert_dev_early"].copy()
+        for j, k in enumerate(old["alt_target"]):
+            if int(k) not in redo:
+                at.append(int(k)); ae.append(int(old["alt_early"][j])); af.append(old["alt_feat"][j])
+                av.append(old["alt_vals"][old["alt_off"][j]:old["alt_off"][j + 1]])
+        for k, n_tr, dev, _ in res:
+            tr[k], pd[k], pde[k] = n_tr, dev[0], dev[1]
     for k, _, _, alts in res:
         for hz, v, fs in alts:
             at.append(k); ae.append(hz); av.append(v); af.append(fs)
-    out = dict(trials=np.asarray([r[1] for r in res], np.int32), pert_dev=np.asarray([r[2][0] for r in res], np.float32),
-               pert_dev_early=np.asarray([r[2][1] for r in res], np.float32), eps=np.float64(EPS),
+    if old is not None:
+        order = np.argsort(np.asarray(at), kind="stable")
+        at, ae, av, af = [at[i] for i in order], [ae[i] for i in order], [av[i] for i in order], [af[i] for i in order]
+    else:
+        tr = np.asarray([r[1] for r in res], np.int32)
+        pd = np.asarray([r[2][0] for r in res], np.float32)
+        pde = np.asarray([r[2][1] for r in res], np.float32)
+    out = dict(trials=np.asarray(tr, np.int32), pert_dev=np.asarray(pd, np.float32),
+               pert_dev_early=np.asarray(pde, np.float32), eps=np.float64(EPS),
                alt_target=np.asarray(at, np.int32), alt_early=np.asarray(ae, np.int8),
                alt_off=np.cumsum([0] + [len(v) for v in av]).astype(np.int64),
                alt_vals=np.concatenate(av) if av else np.zeros(0, np.float32),
@@ -130,9 +150,11 @@ def main():
     ap.add_argument("--trials", type=int, default=24)
     ap.add_argument("--watch-trials", type=int, default=400)
     ap.add_argument("--procs", type=int, default=6)
+    ap.add_argument("--only", default="", help="comma-separated target ids: re-sample only these (one dataset in --what)")
     a = ap.parse_args()
+    only = {int(t) for t in a.only.split(",") if t}
     for name in a.what.split(","):
-        run(name, a.trials, a.watch_trials, a.procs)
+        run(name, a.trials, a.watch_trials, a.procs, only)
 
 
 if __name__ == "__main__":

@@ -56,7 +56,7 @@ def test_two_rank_sharding_equals_single_process(tmp_path):
 
 def _api_worker(rank, world, port, out_dir):
     """The reference-shaped API under torch.distributed: Explainer.explain_nodes shards the targets over the ranks
-    (parallel.lpt_shards on n^2) and returns the FULL list on every rank."""
+    (parallel.lpt_shards on parallel.target_cost) and returns the FULL list on every rank."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import argparse
