@@ -797,36 +797,62 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         }
         // ======== per near edge: G_ij + G_ji, regulariser gradients, Adam in place on both directed entries, next Abar ========
         const bool republish = iter + 1 < p.num_iters;  // the returned mask is the one of the LAST forward (explain.py:209-211)
-        for (int k = tid; k < eupN; k += NT) {
-            const unsigned en = eidx[2 * k + 1];
-            const int cij = en & 0xffffu, cji = en >> 16;
-            float G = gGe[cij] + gGe[cji];                 // row-side products of both directions (layer-1 backward)
-            G += (cij < degT) ? sG3[cij] : 0.0f;           // i == t: the layer-3 part of row t of G (row t's entries come first)
-            G += (cji < degT) ? sG3[cji] : 0.0f;
-            const float w = est[6 * eup + k];
-            const float gc = (0.5f * G + glap[k]) * w;
-            float Mij = est[0 * eup + k], Mji = est[1 * eup + k], mij = est[2 * eup + k], mji = est[3 * eup + k],
-                  vij = est[4 * eup + k], vji = est[5 * eup + k];
-            {
-                const float S = sigmoidf_(Mij);
-                const float g = (gc + p.c_size - p.c_ent * Mij * inv_n2) * S * (1.0f - S);
-                adam_update(Mij, mij, vij, g, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+        // two edges per trip: the planes come from L2, and the loads of the second edge are in flight while the first is updated
+        for (int k0 = tid; k0 < eupN; k0 += 2 * NT) {
+            constexpr int EU = 2;
+            int kk[EU], cij[EU], cji[EU];
+            bool on[EU];
+            float w[EU], lap[EU], Mij[EU], Mji[EU], mij[EU], mji[EU], vij[EU], vji[EU], G[EU];
+#pragma unroll
+            for (int u = 0; u < EU; ++u) {
+                on[u] = k0 + u * NT < eupN;
+                kk[u] = on[u] ? k0 + u * NT : k0;
+                const unsigned en = eidx[2 * kk[u] + 1];
+                cij[u] = en & 0xffffu;
+                cji[u] = en >> 16;
+                w[u] = est[6 * eup + kk[u]];
+                lap[u] = glap[kk[u]];
+                Mij[u] = est[0 * eup + kk[u]];
+                Mji[u] = est[1 * eup + kk[u]];
+                mij[u] = est[2 * eup + kk[u]];
+                mji[u] = est[3 * eup + kk[u]];
+                vij[u] = est[4 * eup + kk[u]];
+                vji[u] = est[5 * eup + kk[u]];
             }
-            {
-                const float S = sigmoidf_(Mji);
-                const float g = (gc + p.c_size - p.c_ent * Mji * inv_n2) * S * (1.0f - S);
-                adam_update(Mji, mji, vji, g, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+#pragma unroll
+            for (int u = 0; u < EU; ++u) {
+                G[u] = gGe[cij[u]] + gGe[cji[u]];                    // row-side products of both directions (layer-1 backward)
+                G[u] += (cij[u] < degT) ? sG3[cij[u]] : 0.0f;        // i == t: the layer-3 part of row t of G (row t's entries come first)
+                G[u] += (cji[u] < degT) ? sG3[cji[u]] : 0.0f;
             }
-            est[0 * eup + k] = Mij;
-            est[1 * eup + k] = Mji;
-            est[2 * eup + k] = mij;
-            est[3 * eup + k] = mji;
-            est[4 * eup + k] = vij;
-            est[5 * eup + k] = vji;
-            if (republish) {  // nobody reads sAb any more in this iteration (the barrier above)
-                const float a = w * (0.5f * (sigmoidf_(Mij) + sigmoidf_(Mji)));
-                sAb[cij] = a;
-                sAb[cji] = a;
+#pragma unroll
+            for (int u = 0; u < EU; ++u) {
+                const float gc = (0.5f * G[u] + lap[u]) * w[u];
+                {
+                    const float S = sigmoidf_(Mij[u]);
+                    const float g = (gc + p.c_size - p.c_ent * Mij[u] * inv_n2) * S * (1.0f - S);
+                    adam_update(Mij[u], mij[u], vij[u], g, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+                }
+                {
+                    const float S = sigmoidf_(Mji[u]);
+                    const float g = (gc + p.c_size - p.c_ent * Mji[u] * inv_n2) * S * (1.0f - S);
+                    adam_update(Mji[u], mji[u], vji[u], g, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < EU; ++u) {
+                if (!on[u]) continue;
+                est[0 * eup + kk[u]] = Mij[u];
+                est[1 * eup + kk[u]] = Mji[u];
+                est[2 * eup + kk[u]] = mij[u];
+                est[3 * eup + kk[u]] = mji[u];
+                est[4 * eup + kk[u]] = vij[u];
+                est[5 * eup + kk[u]] = vji[u];
+                if (republish) {  // nobody reads sAb any more in this iteration (the barrier above)
+                    const float a = w[u] * (0.5f * (sigmoidf_(Mij[u]) + sigmoidf_(Mji[u])));
+                    sAb[cij[u]] = a;
+                    sAb[cji[u]] = a;
+                }
             }
         }
         __syncthreads();
@@ -842,6 +868,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         __syncthreads();
     }
     // ---------------- results: dense Abar block (zero off the edges), M on the edges, feature mask ----------------
+    // (a separate zero-fill kernel in front of this launch was measured: it queues behind the resident launch on the other
+    // stream and delays this one by more than the 0.2-0.8 ms the fill costs here)
     {
         f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
         for (size_t e = (size_t)tid * 4; e < (size_t)ld * ld; e += 4 * NT) *reinterpret_cast<f32x4*>(p.Abar + tm.offQ + e) = z4;
