@@ -384,6 +384,37 @@ def test_large_target_far_edges_run_their_own_recursion(be):
     assert np.array_equal(res.masked_adj[0], res.masked_adj[0].T)
 
 
+@pytest.mark.parametrize("iters", [1, 2])
+def test_large_target_weighted_self_loops_and_short_runs(be, iters):
+    """k_sparse_large with non-binary symmetric weights and a non-zero diagonal, for 1 / 2 iterations: the returned mask is the
+    one of the LAST forward (explain.py:209-211) - the initial one after a single iteration - for the near edges (kept in LDS)
+    and for the far edges (their own recursion) alike, while the mask parameters have taken `iters` Adam steps."""
+    rng = np.random.default_rng(41)
+    sd = helpers.random_model(rng, 10, 20, 20, 4)
+    n = 700
+    A, X = helpers.random_graph(rng, n, 10, density=2.2 / n)
+    W = rng.uniform(0.25, 2.0, (n, n)).astype(np.float32)
+    A = A * np.triu(W, 1)
+    A = A + A.T + np.diag(rng.uniform(0.5, 1.5, n).astype(np.float32))
+    t = int(np.argmax((A != 0).sum(1)))
+    m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
+    sg = Subgraph(A, X, 3, t, rng.integers(0, 4, n), m0)
+    job = be.job([sg], sd)
+    assert list(job.route()) == [7]
+    res = job.run([m0], Hyper(num_iters=iters))
+    o = closed_form.ClosedFormOracle(A, X, sd, 3, sg.pred_label, t, m0)
+    want = o.run(iters)
+    live = (A != 0) & ~np.eye(n, dtype=bool)
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v.astype(np.float64)))
+    first = 0.5 * (sig(m0) + sig(m0.T)) * A * live                  # A . sym(sigma(M0)), off the diagonal (explain.py:665-678)
+    got = res.masked_adj[0].astype(np.float64)
+    if iters == 1:
+        assert np.abs(got - first).max() < 1e-6
+    assert np.abs(got * A - want).max() < 5e-6
+    assert np.abs(res.mask[0] - o.M)[live].max() < 5e-5
+    assert np.all(np.diag(res.masked_adj[0]) == 0) and np.all(got[~live] == 0)
+
+
 def test_large_target_beyond_4095_rows(be):
     """n = 4300 with a 300-neighbour hub next to the target: nothing k_sparse_large keeps in LDS scales with n (only the
     entries of the rows within two hops do), so the target takes the sparse kernel instead of streaming 4320^2 dense

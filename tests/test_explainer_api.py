@@ -144,7 +144,7 @@ def test_gnn_stats_device_auc_and_denoise_equal_host_postprocessing_emulated(tmp
         assert stats[k][0] == G.number_of_nodes() and stats[k][1] == G.number_of_edges()
 
 
-def test_explain_module_surface_emulated(tmp_path, emu_engine):
+def _explain_module_surface(tmp_path):
     gx = helpers.load_explain("syn1")
     ck, args, ex = _explainer(tmp_path, 5)
     t = 302
@@ -158,9 +158,24 @@ def test_explain_module_surface_emulated(tmp_path, emu_engine):
     assert abs(float(pred.sum()) - 1) < 1e-5 and mod.masked_adj.shape == (1, len(nb), len(nb))
     loss0 = float(mod.loss(pred, pl, new, 0))
     assert abs(loss0 - float(gx[f"{t}:loss"][0])) < 1e-4                     # reference's epoch-0 loss
-    assert 0 < float(mod.mask_density()) < 1
+    # mask_density (explain.py:822-825): sum of the masked adjacency over the number of edge entries of the sub-graph
+    ma0 = mod.masked_adj.detach().cpu().numpy()[0]
+    want = float(ma0.sum() / (sub_adj != 0).sum())
+    assert abs(float(mod.mask_density()) - want) < 1e-6 and 0 < want < 1
     mod.optimize(5)
     assert not np.array_equal(mod.mask.detach().numpy(), gx[f"{t}:mask0"])
+    pred5, _ = mod.forward(new)
+    assert float(mod.loss(pred5, pl, new, 5)) < loss0                         # five Adam steps lowered the loss
+
+
+def test_explain_module_surface_emulated(tmp_path, emu_engine):
+    _explain_module_surface(tmp_path)
+
+
+@pytest.mark.gpu
+def test_explain_module_surface_on_gpu(tmp_path):
+    """forward / loss / mask_density / optimize of the ExplainModule mirror through libgnnx_hip.so."""
+    _explain_module_surface(tmp_path)
 
 
 @pytest.mark.gpu
