@@ -357,8 +357,9 @@ def main():
                      7: "k_sparse_large", 8: "k_sparse_resident<.., 512>"}
         res_ms = {1: rt[0], 4: rt[3], 5: rt[4], 6: rt[5], 7: rt[6], 8: rt[7]}
         mixed = bool((route == 6).any() and (route == 8).any() and not rt[5] and rt[7])   # one launch for both groups
+        tiny_per_wg = 8 if (job.D + 2 * job.H) * 33 + job.C * 96 >= 1658 else 6   # sp_mix_tiny() of gnnx_sparse.hpp
         if mixed:
-            res_names[8] = "k_sparse_resident_mixed (512-thread targets + six single-tile targets per workgroup)"
+            res_names[8] = f"k_sparse_resident_mixed (512-thread targets + {tiny_per_wg} single-tile targets per workgroup)"
         sel_of = {rv: ((route == 8) | (route == 6)) if (mixed and rv == 8) else (route == rv) for rv in res_ms}
         for rv, ms_v in res_ms.items():
             if ms_v:
@@ -381,7 +382,7 @@ def main():
             ms = res_ms[top]
             f_edge = 6.0 * nnz[sel].sum() * kagg * args.iters
             b_lds = (3.0 * kagg * 4.0 + 12.0) * nnz[sel].sum() * args.iters
-            n_wg = int((route[sel] != 6).sum() + math.ceil((route[sel] == 6).sum() / 6.0)) if mixed and top == 8 else int(sel.sum())
+            n_wg = int((route[sel] != 6).sum() + math.ceil((route[sel] == 6).sum() / float(tiny_per_wg))) if mixed and top == 8 else int(sel.sum())
             roof = {"kernel": res_names[top] + " (edge-sparse on-chip-resident optimisation, one workgroup per target, all iterations in one launch)",
                     "bound": "mfma", "achieved": f_edge / (ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                     "frac": f_edge / (ms * 1e-3) / MFMA_F32_PEAK, "traffic": None, "avg_launch_us": ms * 1e3,

@@ -588,13 +588,14 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
             HIPCK(hipEventRecord(h->ev_t0[g], ss));
             h->launched[g] = true;
             if (mixed && k == SPC_512) {
-                const dim3 grid(h->n_sp[SPC_512] + (h->n_sp[2] + SP_MIX_TINY - 1) / SP_MIX_TINY), block(512);
+                const int per_wg = sp_mix_tiny(h->prob.D, h->prob.H, h->prob.C);   // single-tile targets per workgroup
+                const dim3 grid(h->n_sp[SPC_512] + (h->n_sp[2] + per_wg - 1) / per_wg), block(512);
                 if (exact_shape(h, 10))
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
-                                       h->d_sp[2], h->n_sp[2], h->d_adam);
+                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C));
                 else
                     hipLaunchKernelGGL((k_sparse_resident_mixed<16, 16>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
-                                       h->d_sp[2], h->n_sp[2], h->d_adam);
+                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C));
             } else {
                 launch_sparse(h, p, k, h->d_adam, ss);
             }

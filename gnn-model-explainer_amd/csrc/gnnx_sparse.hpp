@@ -359,7 +359,7 @@ __device__ __forceinline__ void sparse_combine(float (&acc)[NQ], int rem, int ws
 // synchronises with itself, so its barriers are wave-level.
 template <int DQ, int HQ, bool GRAPH, int NT>
 __device__ __forceinline__ void sparse_resident_body(const Params p, int t, const float* adam_tab, float* pool, SparseFixed& sh,
-                                                     int tid) {
+                                                     int tid, float* shared_w = nullptr) {
     constexpr int SCAN = (sp_ld_max(NT) + 63) / 64;  // rows per lane in the setup prefix scans
     constexpr int SP_QMAX = sp_qmax(NT);
     auto SYNC = []() {
@@ -443,10 +443,12 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     float* sRn2 = pool + L.oRn2;
     float* sYhat = pool + L.oYhat;
     float* sG3 = pool + L.oG3;
-    float* sW1 = pool + L.oW;
+    // the model block (W1 | W2 | W3 | Wp, read-only): the target's own copy at the end of its pool, or one staged by the caller
+    // for all the targets of a workgroup (k_sparse_resident_mixed: the single-tile targets then fit eight to a workgroup)
+    float* sW1 = shared_w ? shared_w : pool + L.oW;
     float* sW2 = sW1 + D * 33;
     float* sW3 = sW2 + H * 33;
-    float* sWp = pool + L.oWp;
+    float* sWp = shared_w ? shared_w + (D + 2 * H) * 33 : pool + L.oWp;
     const int sD = L.sD, sH = L.sH, sO = L.sO;
 
     // ---------------- setup 2: sorted column lists ----------------
@@ -697,6 +699,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         const int r = e >> 5, c = e & 31;
         if (c < D) sX[r * sD + c] = p.X[(tm.offR + r) * FS + c];
     }
+    // (a shared model block is written by every wave that uses it - the same values to the same addresses, so each wave only
+    // needs its own writes to have landed, which its next wave-level sync guarantees: no workgroup barrier)
     for (int e = tid; e < D * 32; e += NT) sW1[(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + e];
     for (int e = tid; e < H * 32; e += NT) sW2[(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + 1024 + e];
     for (int e = tid; e < H * 32; e += NT) sW3[(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + 2048 + e];
@@ -1234,26 +1238,37 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : 2) void k_sparse_resident(Para
 }
 
 // One launch for a node-mode batch of larger targets (512-thread class) and single-tile targets (64-thread code path):
-// workgroups [0, n_big) take one larger target each, the others six single-tile targets each - one per wave, in a
-// slice of the same LDS pool.  (Separate launches of the two groups overlap only partly: measured on syn1, the
-// single-tile launch took 6.6 ms beside the big one against 3.8 ms alone.)
-constexpr int SP_MIX_TINY = 6;
+// workgroups [0, n_big) take one larger target each, the others sp_mix_tiny() single-tile targets each - one per wave, in a
+// slice of the same LDS pool, the model block shared by the workgroup (with a private copy of its 8 KB per target only six
+// fit).  (Separate launches of the two groups overlap only partly: measured on syn1, the single-tile launch took 6.6 ms
+// beside the big one against 3.8 ms alone.)
+__host__ __device__ inline int sp_model_floats(int D, int H, int C) { return (D + 2 * H) * 33 + C * 96; }
+__host__ __device__ inline int sp_fixed_floats() { return (int)((sizeof(SparseFixed) + 3) / 4); }
+// single-tile targets per workgroup: eight (one per wave) when eight slices (a 64-thread pool minus the shared model block)
+// and their SparseFixed blocks fit the 512-thread pool, else six
+__host__ __device__ inline int sp_mix_tiny(int D, int H, int C) {
+    const int wsz = sp_model_floats(D, H, C);
+    return wsz + 8 * (sp_pool_floats(64) - wsz) + 8 * sp_fixed_floats() <= sp_pool_floats(512) ? 8 : 6;
+}
 template <int DQ, int HQ>
 __global__ __launch_bounds__(512) void k_sparse_resident_mixed(Params p, const int32_t* big_ids, int n_big, const int32_t* tiny_ids,
-                                                               int n_tiny, const float* adam_tab) {
+                                                               int n_tiny, const float* adam_tab, int per_wg, int wsz) {
     __shared__ float pool[sp_pool_floats(512)];
     __shared__ SparseFixed sh_big;
-    static_assert(SP_MIX_TINY * sp_pool_floats(64) + SP_MIX_TINY * (int)((sizeof(SparseFixed) + 3) / 4) <= sp_pool_floats(512),
-                  "the single-tile slices and their SparseFixed blocks must fit the 512-thread pool");
+    static_assert(6 * sp_pool_floats(64) + 6 * (int)((sizeof(SparseFixed) + 3) / 4) <= sp_pool_floats(512),
+                  "six single-tile slices and their SparseFixed blocks must fit the 512-thread pool whatever the model");
     if ((int)blockIdx.x < n_big) {
         sparse_resident_body<DQ, HQ, false, 512>(p, big_ids[blockIdx.x], adam_tab, pool, sh_big, (int)threadIdx.x);
         return;
     }
+    // per_wg = sp_mix_tiny(D, H, C), wsz = sp_model_floats(D, H, C) from the host (reading a field of p here makes the compiler
+    // pass the by-value Params of the bodies through scratch: 416 bytes per lane)
+    const int slice = sp_pool_floats(64) - wsz;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int idx = ((int)blockIdx.x - n_big) * SP_MIX_TINY + wave;
-    if (wave >= SP_MIX_TINY || idx >= n_tiny) return;  // whole waves leave: the 64-thread body has no workgroup barrier
-    SparseFixed* shp = reinterpret_cast<SparseFixed*>(pool + SP_MIX_TINY * sp_pool_floats(64)) + wave;
-    sparse_resident_body<DQ, HQ, false, 64>(p, tiny_ids[idx], adam_tab, pool + wave * sp_pool_floats(64), *shp, lane);
+    const int idx = ((int)blockIdx.x - n_big) * per_wg + wave;
+    if (wave >= per_wg || idx >= n_tiny) return;  // whole waves leave: the 64-thread body has no workgroup barrier
+    SparseFixed* shp = reinterpret_cast<SparseFixed*>(pool + wsz + per_wg * slice) + wave;
+    sparse_resident_body<DQ, HQ, false, 64>(p, tiny_ids[idx], adam_tab, pool + wsz + wave * slice, *shp, lane, pool);
 }
 
 // per target: directed off-diagonal non-zeros of its block of the packed adjacency and the row slots the sparse

@@ -470,8 +470,8 @@ def test_sparse_kernels_degenerate_graphs(be, case, n):
 
 
 def test_mixed_launch_of_large_and_single_tile_targets(be):
-    """One launch for a 512-thread target and nine single-tile targets (k_sparse_resident_mixed: six single-tile targets
-    per workgroup, one per wave; the second such workgroup is half empty): every target must match its solo run bit
+    """One launch for a 512-thread target and nine single-tile targets (k_sparse_resident_mixed: eight single-tile targets
+    per workgroup, one per wave; the second such workgroup holds a single one): every target must match its solo run bit
     for bit (same code path, other workgroup shape) and the closed form."""
     rng = np.random.default_rng(9)
     sd = helpers.random_model(rng, 10, 20, 20, 4)
