@@ -45,6 +45,21 @@ constexpr int N_SPC = 5;                       // size classes of k_sparse_resid
 constexpr int SPC_THREADS[N_SPC] = {1024, 256, 64, SPL_THREADS, 512};
 constexpr int SPC_LARGE = 3, SPC_512 = 4;
 constexpr int N_SIDE = RES_NBMAX + N_SPC;
+// Resident launches of one run that must overlap go to different LANES: a small process-wide set of side streams, created
+// once per device and never destroyed.  A HIP stream is bound to one of a handful of hardware queues when it is created, and
+// two streams on the same queue run their kernels back to back: with eight fresh streams per plan (round 1) which groups
+// overlapped depended on how many streams the process had created before (measured: the 64- and 256-thread launches of syn5
+// overlapped in one session, 3.6 ms, and serialised in the next, 6.3 ms).
+constexpr int N_LANES = 3;
+constexpr int MAX_DEVICES = 16;
+static hipStream_t g_lane[MAX_DEVICES][N_LANES] = {};
+static hipStream_t lane_stream(int i) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+    hipStream_t& st = g_lane[dev][i % N_LANES];
+    if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
+    return st;
+}
 constexpr int CAT_SPARSE = RES_NBMAX + 1;      // CAT_SPARSE + k: sparse resident kernel of size class k
 
 struct gnnx_plan_s {
@@ -63,7 +78,6 @@ struct gnnx_plan_s {
     MaskTile* d_mask_big = nullptr;
     // the resident kernels run beside the streaming launches, each group on its own stream:
     // [0..RES_NBMAX) dense resident kernels by row blocks, [RES_NBMAX + k] sparse resident kernel of size class k
-    hipStream_t side[N_SIDE] = {};
     hipEvent_t ev_in = nullptr, ev_out[N_SIDE] = {};
     hipEvent_t ev_t0[N_SIDE] = {};   // start of the resident launch on its side stream (timed, for gnnx_resident_times)
     bool launched[N_SIDE] = {};
@@ -159,8 +173,7 @@ static int build_split(gnnx_handle h) {
     // measured on syn1 and made the sparse launch slower, 9.7 vs 6.4 ms in situ: not used.)
     for (int k = 0; k < N_SIDE; ++k) {
         const bool need = k < RES_NBMAX ? h->res_count[k + 1] > 0 : h->n_sp[k - RES_NBMAX] > 0;
-        if (need && !h->side[k]) {
-            SPLITCK(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
+        if (need && !h->ev_out[k]) {
             SPLITCK(hipEventCreate(&h->ev_out[k]));
             SPLITCK(hipEventCreate(&h->ev_t0[k]));
         }
@@ -331,7 +344,6 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->d_meta) (void)hipFree(h->d_meta);
     for (int k = 0; k < N_SIDE; ++k) {
-        if (h->side[k]) (void)hipStreamDestroy(h->side[k]);
         if (h->ev_out[k]) (void)hipEventDestroy(h->ev_out[k]);
         if (h->ev_t0[k]) (void)hipEventDestroy(h->ev_t0[k]);
     }
@@ -576,8 +588,12 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
         // side stream.  (Running the last group on the caller's stream instead of a side stream serialised it behind
         // another group, and a 40-200 us delay kernel in front of the small launches changed nothing - measured, not
         // used; see gnnx_plan_analyze for which groups are allowed to meet.)
-        // the 64-thread sparse class and the dense single-tile group never meet in one batch: they share side[0]
-        auto group_stream = [&](int k) -> hipStream_t { return (k == RES_NBMAX + 2 && h->side[0] && !h->res_count[1]) ? h->side[0] : h->side[k]; };
+        // every group of this run takes the next lane (lane_stream above); a fourth group shares the first one's
+        int next_lane = 0;
+        auto group_stream = [&](int) -> hipStream_t {
+            hipStream_t st = lane_stream(next_lane++);
+            return st ? st : s;
+        };
         // node-mode batches of 512-thread and single-tile (64-thread class) targets: ONE launch (k_sparse_resident_mixed)
         const bool mixed = !h->prob.graph_mode && h->n_sp[SPC_512] > 0 && h->n_sp[2] > 0;
         for (int k = 0; k < N_SPC; ++k) {
@@ -739,6 +755,27 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
     }
     int mix_on = 1;
     if (const char* env = std::getenv("GNNX_SPARSE_MIXED")) mix_on = std::atoi(env);
+    // Node-mode batches of 256-thread and single-tile targets only (syn4, syn5): when all their workgroups fit the chip at
+    // once, the 256-thread targets take the 512-thread class and the batch becomes ONE mixed launch - as fast as the two
+    // small-class launches when those overlap (3.5 vs 3.6 ms on syn5) and not at the mercy of the queues when they do not (6.3 ms).
+    if (!graph && mix_on && tiny_on && c512_on && !has_large) {
+        int n1 = 0, n2 = 0;
+        bool all_fit = true;
+        for (int t = 0; t < T; ++t) {
+            if (new_cat[t] == CAT_SPARSE + 2) ++n2;
+            if (new_cat[t] != CAT_SPARSE + 1) continue;
+            ++n1;
+            const TargetMeta& m = h->meta[t];
+            const int* lg = &h->nnz[2 * (size_t)T + SPL_COUNTS * (size_t)t];
+            all_fit &= lg[0] >= 0 && sparse_fits(512, m.n, m.ld, lg[0], lg[2], h->prob.D, h->prob.H, h->prob.C, 0, h->prob.O);
+        }
+        const int per_wg = sp_mix_tiny(h->prob.D, h->prob.H, h->prob.C);
+        if (n1 > 0 && n2 > 0 && all_fit && n1 + (n2 + per_wg - 1) / per_wg <= 256) {
+            for (int t = 0; t < T; ++t)
+                if (new_cat[t] == CAT_SPARSE + 1) new_cat[t] = CAT_SPARSE + SPC_512;
+            has_large = true;
+        }
+    }
     // ... unless the big targets all take the 512-thread class: then they and the single-tile targets (64-thread code path,
     // six per workgroup) share ONE launch, k_sparse_resident_mixed, and nothing needs to overlap
     const bool mixable = !graph && mix_on && tiny_on && has_large && !has_1024;

@@ -111,6 +111,7 @@ inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
 }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 1; *greatest = -1; return hipSuccess; }

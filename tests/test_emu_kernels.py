@@ -265,7 +265,10 @@ def test_plan_routing_by_size_and_edge_count(be):
     # a 512-thread target in the batch: the mid-size target joins its class, the single-tile one stays in the 64-thread
     # class and shares the launch (k_sparse_resident_mixed)
     assert route == [6, 8, 8, 0]
-    assert list(be.job(subs[:2], sd).route()) == [6, 5]
+    # a small batch of 256-thread and single-tile targets becomes one mixed launch too (the 256-thread target takes the
+    # 512-thread class); a 256-thread target alone keeps its class
+    assert list(be.job(subs[:2], sd).route()) == [6, 8]
+    assert list(be.job(subs[1:2], sd).route()) == [5]
     assert list(be.job(subs, sd, analyze=False).route()) == [1, 0, 0, 0]
     small = [sub(20, 0.2), sub(60, 0.1)]
     assert list(be.job(small, sd, analyze=False).route()) == [1, 2]      # all-small batch: dense resident kernels
