@@ -596,7 +596,9 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
         };
         // node-mode batches of 512-thread and single-tile (64-thread class) targets: ONE launch (k_sparse_resident_mixed)
         const bool mixed = !h->prob.graph_mode && h->n_sp[SPC_512] > 0 && h->n_sp[2] > 0;
-        for (int k = 0; k < N_SPC; ++k) {
+        const int launch_order[N_SPC] = {SPC_LARGE, 0, SPC_512, 1, 2};   // the longest workgroups first, then the other whole-CU ones
+        for (int ko = 0; ko < N_SPC; ++ko) {
+            const int k = launch_order[ko];
             if (!h->n_sp[k] || (mixed && k == 2)) continue;
             const int g = RES_NBMAX + k;
             hipStream_t ss = group_stream(g);
