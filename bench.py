@@ -23,6 +23,7 @@ Every run checks parity in the same process: the GPU masks of all targets agains
 CPU-baseline sample; the run FAILS if a well-conditioned target deviates by more than 1e-5.
 """
 import argparse
+import gc
 import json
 import math
 import os
@@ -268,6 +269,8 @@ def main():
         # more than the batch itself): the steady-state cost of a batch.  The timed steps below run on this job.
         job.close()
         del job, dn
+        gc.collect()                 # the job's tensors go back to the caching allocator now, not whenever the cycle collector runs
+        torch.cuda.synchronize()
         warm = {}
         t_w = time.perf_counter()
         dn, job = build(my_targets, warm)

@@ -26,6 +26,16 @@ _DEVICE_TYPE = "cuda"          # PyTorch-ROCm exposes HIP devices as "cuda"
 _LIB_NAME = "libgnnx_hip.so"
 
 
+_ENGINE_STREAMS = {}
+
+
+def _engine_stream(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _ENGINE_STREAMS:
+        _ENGINE_STREAMS[key] = torch.cuda.Stream(dev)
+    return _ENGINE_STREAMS[key]
+
+
 class _Problem(ctypes.Structure):
     _fields_ = [("num_targets", ctypes.c_int32), ("n", ctypes.POINTER(ctypes.c_int32)),
                 ("target_row", ctypes.POINTER(ctypes.c_int32)), ("gt_label", ctypes.POINTER(ctypes.c_int32)),
@@ -408,8 +418,10 @@ class MaskOptimJob:
         self.fmask = torch.empty(self.T, FEAT_STRIDE, **f32)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
         self.loss = None
-        # the job owns a non-default stream: hipGraph capture is illegal on the legacy default stream
-        self.stream = torch.cuda.Stream(dev) if dev.type == _DEVICE_TYPE else None
+        # the jobs of a process run on ONE non-default stream per device (hipGraph capture is illegal on the legacy default
+        # stream): a fresh stream per job costs a hardware-queue set-up at its first use (~5 ms, measured in the plan + pack time of
+        # every batch), and the library's own side lanes (gnnx_capi.hip: lane_stream) are process-wide for the same reason
+        self.stream = _engine_stream(dev) if dev.type == _DEVICE_TYPE else None
 
     # -- packing -------------------------------------------------------------------------------
     def _square_views(self, flat):

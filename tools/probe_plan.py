@@ -10,9 +10,9 @@ import bench
 from gnn_model_explainer_amd import engine
 from gnn_model_explainer_amd.engine import MaskOptimJob
 
-wl = bench.Workload("ba100k", int(sys.argv[1]) if len(sys.argv) > 1 else 16384)
+wl = bench.Workload(sys.argv[2] if len(sys.argv) > 2 else "ba100k", int(sys.argv[1]) if len(sys.argv) > 1 else 16384)
 graph = engine.device_graph(wl.idx.csr, wl.feat, wl.pred)
-for rep in range(2):
+for rep in range(4):
     stamps = []
     def mark(name):
         torch.cuda.synchronize()
