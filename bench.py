@@ -268,6 +268,7 @@ def main():
         # recycles the previous batch's device buffers (a fresh 28 GB allocation for the 16 384-target set costs 0.7 s, far
         # more than the batch itself): the steady-state cost of a batch.  The timed steps below run on this job.
         job.close()
+        jobs[0] = None
         del job, dn
         gc.collect()                 # the job's tensors go back to the caching allocator now, not whenever the cycle collector runs
         torch.cuda.synchronize()
