@@ -16,6 +16,9 @@
 //     original row id), written and re-read by the same workgroup through one CU's L1 / L2 path;
 //   * the mask entries on edges, their Adam moments, the edge weights and the Laplacian constants are gathered once into
 //     compact per-edge planes (coalesced) and scattered back into the dense M at the end;
+//   * feature matrices with few distinct rows (constant, one-hot, categorical: every configuration of the reference) are
+//     kept as a dictionary of at most 32 rows + one byte per node in LDS, found by exact comparison at setup: the two passes
+//     that gather X rows (layer 1 and the per-entry products) then never leave the CU.  Other inputs take the L2 path;
 //   * rows of up to 1024 entries are split into slots of 64 (the BA-House x100k hubs), loops run over rows / edges
 //     instead of one item per thread.
 #pragma once
@@ -32,6 +35,7 @@ constexpr int SPL_N_MAX = 16383;            // rows of a sub-graph (row ids are 
 constexpr int SPL_A_MAX = 8192;             // rows within two hops of the target
 constexpr int SPL_TDEG_MAX = SP_MAX_SPLIT * SPL_CHUNK;   // entries of one row in A (1024), also of row t
 constexpr int SPL_POOL_FLOATS = 39168;      // 153 KB of LDS
+constexpr int SPL_XD_MAX = 32;              // distinct feature rows kept as a dictionary in LDS (constant / one-hot / categorical features)
 constexpr int SPL_COUNTS = 6;               // k_count_edges_large: nnz, slots of 64 (A), slots of 16 (A), active entries, rows in A, slots of 64 (B)
 __host__ __device__ constexpr int spl_stage_floats(int D) { return 16 * TILE * (D | 1); }  // a [32][D|1] dZ1 tile per wave
 
@@ -45,7 +49,7 @@ __host__ __device__ inline int sparse_slots_of_c(int deg, int chunk) { return de
 // mirror of an entry whose row is not in A), then the dZ1 staging tiles, the per-slot row norms and the layer-3 partials of
 // t's neighbours.  The setup's temporaries overlay everything behind the active entries.
 struct SparseLargeLayout {
-    int oW, oWp, oAb, oCol, oStage, oRn1, oRn2, oG3, persist;
+    int oW, oWp, oAb, oCol, oStage, oRn1, oRn2, oG3, oXd, oXi, persist;
     int tLevel, tAidx, tAlist, tAdeg, tArp, tCbase, tSlot, total;
 };
 __host__ __device__ inline SparseLargeLayout sparse_large_layout(int ld, int nact, int nA, int padA, int padB, int D, int H, int C) {
@@ -61,6 +65,8 @@ __host__ __device__ inline SparseLargeLayout sparse_large_layout(int ld, int nac
     L.oRn1 = q;    q += padA;
     L.oRn2 = q;    q += padB;
     L.oG3 = q;     q += SPL_TDEG_MAX;
+    L.oXd = q;     q += SPL_XD_MAX * (D | 1);  // the distinct feature rows (when there are few)
+    L.oXi = q;     q += (ld + 3) / 4;          // uint8: which of them a row carries
     L.persist = q;
     L.tLevel = o;  o += (ld + 3) / 4;          // uint8 hop level per row
     L.tAidx = o;   o += (ld + 1) / 2;          // uint16 index into the A list per row (0xffff: not in A)
@@ -144,6 +150,47 @@ __device__ __forceinline__ void sparse_gather_rows(const float* sAb, const unsig
     }
 }
 
+// The same gather when the feature rows come from the LDS dictionary (xd [.][sS], xi = dictionary index per node).
+template <int NQ, int UN>
+__device__ __forceinline__ void sparse_gather_dict(const float* sAb, const unsigned short* scol, const unsigned char* xi, const float* xd,
+                                                   int sS, int W, int e0, int e1, int half, float (&acc)[NQ]) {
+    float full[2 * NQ];
+#pragma unroll
+    for (int c = 0; c < 2 * NQ; ++c) full[c] = 0.0f;
+#pragma unroll 1
+    for (int e = e0 + half; e < e1; e += 2 * UN) {
+        // every load of a trip is unconditional (a clamped index instead of a predicate) and issued before the first use: a
+        // predicated load becomes an exec-mask region with its own wait, and the three dependent LDS reads per entry
+        // (column -> dictionary index -> row) then serialise (measured: 8 us for a 64-entry slot instead of 1.5)
+        int idx[UN], cl[UN], xr[UN];
+        float a[UN], rv[UN][2 * NQ];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            idx[j] = (e + 2 * j < e1) ? e + 2 * j : e1 - 1;
+            cl[j] = scol[idx[j]];
+            a[j] = sAb[idx[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < UN; ++j) xr[j] = (int)xi[cl[j]] * sS;
+#pragma unroll
+        for (int j = 0; j < UN; ++j)
+#pragma unroll
+            for (int c = 0; c < 2 * NQ; ++c) rv[j][c] = xd[xr[j] + c];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const float aj = (e + 2 * j < e1) ? a[j] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 2 * NQ; ++c) full[c] = fmaf(aj, (W == 2 * NQ || c < W) ? rv[j][c] : 0.0f, full[c]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const float mine = half ? full[2 * q + 1] : full[2 * q];
+        const float owed = half ? full[2 * q] : full[2 * q + 1];
+        acc[q] += mine + __shfl_xor(owed, 32);
+    }
+}
+
 // csr_*: the targets' CSR structure, built once per plan by k_build_csr_large (scanning a dense block with one
 // workgroup takes milliseconds - too much to repeat in every launch): rowptr at csr_off[2 t], the ascending columns and
 // the row of every directed entry at csr_off[2 t + 1]; counts: k_count_edges_large's output
@@ -214,6 +261,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     float* sRn1 = pool + L.oRn1;
     float* sRn2 = pool + L.oRn2;
     float* sG3 = pool + L.oG3;
+    float* sXd = pool + L.oXd;
+    unsigned char* sXi = reinterpret_cast<unsigned char*>(pool + L.oXi);
     // setup temporaries
     unsigned char* level = reinterpret_cast<unsigned char*>(pool + L.tLevel);
     unsigned short* aidx = reinterpret_cast<unsigned short*>(pool + L.tAidx);
@@ -509,6 +558,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     for (int e = tid; e < C * 96; e += NT) sWp[e] = p.wts[WT_WP + e];
     if (tid < CMAX) sh.sbp[tid] = p.wts[WT_BP + tid];
     for (int e = tid; e < SPL_TDEG_MAX; e += NT) sG3[e] = 0.0f;
+    for (int r = tid; r < ld; r += NT) sXi[r] = 255;
+    if (tid == 0) s_misc[1] = 0;
     if (tid < 32) {
         sh.fcur[tid] = 0.0f;  // construct_feat_mask: constant 0 (explain.py:639-641)
         sh.mf[tid] = 0.0f;
@@ -523,6 +574,42 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         sAb[en >> 16] = a;
     }
     __syncthreads();
+    // ---------------- feature dictionary: the distinct rows of X, if there are at most SPL_XD_MAX (bit-exact comparison) ----------------
+    bool xdict = true;
+    {
+        int nd = 0;
+        for (;;) {
+            if (tid == 0) s_misc[0] = 0x7fffffff;
+            __syncthreads();
+            for (int r = tid; r < n; r += NT)
+                if (sXi[r] == 255) {  // the first row of this thread's stride that has no dictionary entry yet
+                    atomicMin(&s_misc[0], r);
+                    break;
+                }
+            __syncthreads();
+            const int c = s_misc[0];
+            if (c == 0x7fffffff) break;                       // every row is in the dictionary
+            if (nd == SPL_XD_MAX || (nd >= 4 && 2 * s_misc[1] < n)) {  // too many distinct rows (or clearly dense features): L2 path
+                xdict = false;
+                break;
+            }
+            if (tid < sS) sXd[nd * sS + tid] = (tid < D) ? gX[c * FS + tid] : 0.0f;
+            __syncthreads();
+            int mine = 0;
+            for (int r = tid; r < n; r += NT) {
+                if (sXi[r] != 255) continue;
+                bool eq = true;
+                for (int k = 0; k < D; ++k) eq &= __float_as_uint(gX[r * FS + k]) == __float_as_uint(sXd[nd * sS + k]);
+                if (eq) {
+                    sXi[r] = (unsigned char)nd;
+                    ++mine;
+                }
+            }
+            if (mine) atomicAdd(&s_misc[1], mine);
+            ++nd;
+            __syncthreads();
+        }
+    }
 
     for (int iter = 0; iter < p.num_iters; ++iter) {
         if (tid < 32) sh.phi[tid] = (tid < D) ? sigmoidf_(sh.fcur[tid]) : 0.0f;
@@ -538,7 +625,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             float acc[DQ];
 #pragma unroll
             for (int q = 0; q < DQ; ++q) acc[q] = 0.0f;
-            sparse_gather_rows<false, DQ, spl_gather_unroll(DQ)>(sAb, scol, gX, D, SA.e0, SA.e1, h, acc);
+            if (xdict) sparse_gather_dict<DQ, (DQ <= 5 ? 8 : 2)>(sAb, scol, sXi, sXd, sS, D, SA.e0, SA.e1, h, acc);
+            else sparse_gather_rows<false, DQ, spl_gather_unroll(DQ)>(sAb, scol, gX, D, SA.e0, SA.e1, h, acc);
             sparse_combine<DQ>(acc, SA.rem, SA.wsplit);
 #pragma unroll
             for (int q = 0; q < DQ; ++q) {
@@ -750,13 +838,25 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                             s0[k] = 0.0f;
                             s1[k] = 0.0f;
                         }
+                        if (xdict) {   // uniform: the feature rows come from the LDS dictionary
 #pragma unroll
-                        for (int k = 0; k < PK; ++k) {
-                            const float* x = gX + jj[k] * FS;
+                            for (int k = 0; k < PK; ++k) {
+                                const float* x = sXd + (int)sXi[jj[k]] * sS;
 #pragma unroll
-                            for (int c = 0; c < 2 * DQ; c += 2) {
-                                s0[k] = fmaf(dz[c], x[c], s0[k]);
-                                s1[k] = fmaf(dz[c + 1], x[c + 1], s1[k]);
+                                for (int c = 0; c < 2 * DQ; c += 2) {
+                                    s0[k] = fmaf(dz[c], (EXACT || c < D) ? x[c] : 0.0f, s0[k]);
+                                    s1[k] = fmaf(dz[c + 1], (EXACT || c + 1 < D) ? x[c + 1] : 0.0f, s1[k]);
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < PK; ++k) {
+                                const float* x = gX + jj[k] * FS;
+#pragma unroll
+                                for (int c = 0; c < 2 * DQ; c += 2) {
+                                    s0[k] = fmaf(dz[c], x[c], s0[k]);
+                                    s1[k] = fmaf(dz[c + 1], x[c + 1], s1[k]);
+                                }
                             }
                         }
                         if (inB) {

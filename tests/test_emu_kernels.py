@@ -418,6 +418,36 @@ def test_large_target_weighted_self_loops_and_short_runs(be, iters):
     assert np.all(np.diag(res.masked_adj[0]) == 0) and np.all(got[~live] == 0)
 
 
+@pytest.mark.parametrize("kinds", [1, 7, 40])
+def test_large_target_feature_dictionary(be, kinds):
+    """Feature matrices with few distinct rows (constant features: every synthetic configuration of the reference; one-hot /
+    categorical ones) are kept by k_sparse_large as a dictionary in LDS - at most 32 rows, found by bit-exact comparison;
+    with 40 kinds the kernel must notice and gather the rows from the workspace as for dense features.  Same results."""
+    rng = np.random.default_rng(100 + kinds)
+    sd = helpers.random_model(rng, 10, 20, 20, 4)
+    n = 800
+    A, _ = helpers.random_graph(rng, n, 10, density=2.5 / n)
+    hub = 17
+    idx = rng.choice(np.arange(n), 100, replace=False)
+    idx = idx[idx != hub]
+    A[hub, idx] = 1
+    A[idx, hub] = 1
+    table = rng.standard_normal((kinds, 10)).astype(np.float32)
+    table[0, 3] = -0.0                                  # the comparison is on bit patterns
+    X = table[rng.integers(0, kinds, n)]
+    t = int(idx[0])
+    m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
+    sg = Subgraph(A, X, 2, t, rng.integers(0, 4, n), m0)
+    job = be.job([sg], sd)
+    assert list(job.route()) == [7]
+    res = job.run([m0], Hyper(num_iters=4))
+    o = closed_form.ClosedFormOracle(A, X, sd, 2, sg.pred_label, t, m0)
+    want = o.run(4)
+    live = A != 0
+    assert np.abs(res.masked_adj[0] - want).max() < 5e-6
+    assert np.abs(res.mask[0] - o.M)[live].max() < 5e-5 and np.abs(res.feat_mask[0] - o.f).max() < 5e-5
+
+
 def test_large_target_beyond_4095_rows(be):
     """n = 4300 with a 300-neighbour hub next to the target: nothing k_sparse_large keeps in LDS scales with n (only the
     entries of the rows within two hops do), so the target takes the sparse kernel instead of streaming 4320^2 dense

@@ -27,6 +27,13 @@ for k, a in enumerate(anchors):
     src = src.replace(a + "\n", "        PROBE(%d);\n" % k + a + "\n", 1)
     names.append(a.strip(" /="))
 k = len(anchors)
+# finer stamps inside layer 1 (wave 0's view): after the slot record, the gather, the combine, the row-local part
+fine = [("            const bool first = SA.first;\n            const int r = first ? SA.row : 0;\n            float acc[DQ];", 27),
+        ("            sparse_combine<DQ>(acc, SA.rem, SA.wsplit);\n#pragma unroll\n            for (int q = 0; q < DQ; ++q) {\n                if (first && 2 * q + h < D) gZraw", 28),
+        ("            sparse_forward_rowlocal<DQ>(acc, sW1, sh.bias[0]", 29)]
+for mark, idx in fine:
+    assert mark in src, mark
+    src = src.replace(mark, "            PROBE(%d);\n" % idx + mark, 1)
 end_anchor = "        if (tid < D) {  // feature mask\n"
 assert end_anchor in src
 src = src.replace(end_anchor, "        PROBE(%d);\n" % k + end_anchor, 1)
@@ -70,6 +77,8 @@ for nme, v in zip(names, d):
     print("%-100s %7.2f us" % (nme[:100], v))
 print("iteration (without the feature-mask tail) %7.2f us" % ((a[len(names)] - a[0]) * 10.0 / 1e3))
 b = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
+print("layer 1, wave 0: slot record %.2f us, gather %.2f, combine + Zraw %.2f, row-local + U1 store + barrier %.2f" % (
+    (b[27] - b[0]) / 100.0, (b[28] - b[27]) / 100.0, (b[29] - b[28]) / 100.0, (b[1] - b[29]) / 100.0))
 lab = ["hop levels", "rows of A, compact entry ranges", "active column ids", "slot tables (one thread per set)",
        "slot records", "edges (near first) + state planes", "row arrays / model / first Abar", "20 iterations", "dense Abar + near scatter",
        "far edges (20 iterations in registers)"]
