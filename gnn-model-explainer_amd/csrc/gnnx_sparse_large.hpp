@@ -122,11 +122,11 @@ __device__ __forceinline__ void sparse_gather_rows(const float* sAb, const unsig
         float a[UN];
         const float* br[UN];
 #pragma unroll
-        for (int j = 0; j < UN; ++j) {
-            const bool in = e + 2 * j < e1;
-            const int idx = in ? e + 2 * j : e;
-            a[j] = in ? sAb[idx] : 0.0f;
+        for (int j = 0; j < UN; ++j) {   // unconditional reads through a clamped index (see sparse_gather_dict)
+            const int idx = (e + 2 * j < e1) ? e + 2 * j : e1 - 1;
+            const float av = sAb[idx];
             br[j] = B + (int)scol[idx] * FS;
+            a[j] = (e + 2 * j < e1) ? av : 0.0f;
         }
         f32x4 v[UN][NV];
 #pragma unroll
