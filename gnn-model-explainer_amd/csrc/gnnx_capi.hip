@@ -779,7 +779,7 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
         }
     }
     // ... unless the big targets all take the 512-thread class: then they and the single-tile targets (64-thread code path,
-    // six per workgroup) share ONE launch, k_sparse_resident_mixed, and nothing needs to overlap
+    // eight per workgroup) share ONE launch, k_sparse_resident_mixed, and nothing needs to overlap
     const bool mixable = !graph && mix_on && tiny_on && has_large && !has_1024;
     // Throughput regime: with more big workgroups than the chip has CUs nothing needs to overlap - every launch fills the
     // GPU by itself - and what counts is workgroups per CU: a 256-thread target (n <= 128) then keeps its own class (two per
