@@ -1,0 +1,122 @@
+#!/usr/bin/env python
+"""Measurement tool (CPU): the reference restatement with ITS OWN elementary operations moved by +-1 ulp at random.
+
+tests/golden/make_golden_branches.py perturbs the initial mask; an implementation also differs from torch in the last bit of
+its divisions / square roots / exponentials (Adam's sqrt and division, the L2 normalisation's division, the sigmoid).  Here
+the bit-pinned oracle (oracle/reference_restatement.py) runs with
+  * a hand-written single-tensor Adam (the arithmetic of torch.optim.Adam, verified bit-identical to it without noise) whose
+    denominator takes a random -1 / 0 / +1 ulp, and
+  * F.normalize, torch.sigmoid, torch.softmax and torch.log results moved the same way,
+and prints how far the 300-epoch result moves from the unperturbed reference; `--append` stores the distinct outcomes as
+alternates of the target in tests/golden/<dataset>_branches.npz.  python tools/reference_ulp_sampler.py syn5 767 24 [--append]"""
+import os, sys
+import numpy as np
+import torch
+import torch.nn.functional as F
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+torch.set_num_threads(1)
+import helpers
+from oracle import reference_restatement as rr
+from gnn_model_explainer_amd.utils.graph_utils import KHopIndex
+
+name, tt, trials = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+z = np.load(os.path.join(ROOT, "tests", "golden", name + "_full_explain.npz"))
+ck = helpers.load_ckpt(name)
+idx = KHopIndex((ck["num_nodes"], ck["edges"]), 3)
+sd = {k: torch.tensor(v) for k, v in ck["sd"].items()}
+k = int(np.nonzero(z["targets"] == tt)[0][0])
+nb = z["nb_flat"][z["nb_off"][k]:z["nb_off"][k + 1]].astype(np.int64)
+new = int(z["node_idx_new"][k])
+A = idx.sub_adjacency(nb)
+X, pl, gt = ck["feat"][nb], np.argmax(ck["pred"][nb], 1), int(ck["label"][tt])
+r, c = np.nonzero(np.triu(A, 1))
+main = z["vals"][z["eoff"][k]:z["eoff"][k + 1]]
+GEN = [None]
+
+
+def ulp(y):
+    if GEN[0] is None:
+        return y
+    kk = torch.randint(-1, 2, y.shape, generator=GEN[0])
+    yd = y.detach()
+    moved = torch.where(kk == 0, yd, torch.nextafter(yd, torch.where(kk > 0, torch.full_like(yd, float("inf")), torch.full_like(yd, -float("inf")))))
+    return y + (moved - yd) if y.requires_grad else moved      # the value moves by one ulp, the derivative is the operation's own
+
+
+class Adam1:
+    """torch.optim.Adam (single-tensor path, defaults): exp_avg.lerp_, exp_avg_sq.mul_().addcmul_(), addcdiv_."""
+    def __init__(self, params, lr):
+        self.params, self.lr, self.t = list(params), lr, 0
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        self.t += 1
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        bc1, bc2 = 1 - b1 ** self.t, 1 - b2 ** self.t
+        for p, m, v in zip(self.params, self.m, self.v):
+            g = p.grad
+            m.lerp_(g, 1 - b1)
+            v.mul_(b2).addcmul_(g, g.conj(), value=1 - b2)
+            denom = ulp((v.sqrt() / (bc2 ** 0.5))).add_(eps)
+            p.addcdiv_(m, ulp(denom) if GEN[0] is not None else denom, value=-(self.lr / bc1))
+
+
+def run(noise_seed):
+    GEN[0] = None
+    o = rr.MaskOptimOracle(torch.tensor(A), torch.tensor(X), sd, gt, pl, new, graph_mode=False, mask0=helpers.seeded_mask0(tt, A.shape[0]))
+    o.opt = Adam1([o.mask, o.feat_mask], 0.1)
+    if noise_seed is not None:
+        GEN[0] = torch.Generator().manual_seed(noise_seed)
+    ma = o.run(300)
+    GEN[0] = None
+    return ma[r, c].astype(np.float32), orig_sig(o.feat_mask.detach()).numpy().astype(np.float32)
+
+
+orig_norm, orig_sig = F.normalize, torch.sigmoid
+base, base_f = run(None)
+print("hand-written Adam without noise vs the fixture (torch.optim.Adam): max |diff| = %.3e (mask), %.3e (feature mask)"
+      % (np.abs(base - main).max(), np.abs(base_f - z["feat_sig"][k]).max()))
+assert np.array_equal(base, main)
+F.normalize = lambda y, p=2, dim=2: ulp(orig_norm(y, p=p, dim=dim))
+rr.F.normalize = F.normalize
+torch.sigmoid = lambda x: ulp(orig_sig(x))
+orig_softmax, orig_log = torch.softmax, torch.log
+torch.softmax = lambda x, dim=0: ulp(orig_softmax(x, dim=dim))     # the head's exp / sum / divide
+torch.log = lambda x: ulp(orig_log(x))
+devs, outcomes = [], []
+for s in range(trials):
+    v, fs = run(1000 + s)
+    devs.append(float(max(np.abs(v - main).max(), np.abs(fs - z["feat_sig"][k]).max())))
+    print("seed %d: %.3e" % (s, devs[-1]), flush=True)
+    if devs[-1] > 2e-6 and not any(np.abs(v - ov).max() <= 1e-6 and np.abs(fs - of).max() <= 1e-6 for ov, of in outcomes):
+        outcomes.append((v, fs))
+devs = np.asarray(devs)
+print("%s target %d: %d runs of the reference restatement with +-1 ulp in Adam's denominator, the normalisation, the sigmoid, the softmax and the logarithm: max %.2e, %d beyond 1e-5, %d beyond 1e-4"
+      % (name, tt, trials, devs.max(), int((devs > 1e-5).sum()), int((devs > 1e-4).sum())))
+
+if "--append" in sys.argv:
+    # store the distinct outcomes as alternates of this target (300-epoch horizon) in tests/golden/<name>_branches.npz
+    bp = os.path.join(ROOT, "tests", "golden", name + "_branches.npz")
+    br = dict(np.load(bp))
+    have = [(br["alt_vals"][br["alt_off"][j]:br["alt_off"][j + 1]], br["alt_feat"][j]) for j in np.nonzero((br["alt_target"] == k) & (br["alt_early"] == 0))[0]]
+    new = [(v, fs) for v, fs in outcomes if not any(np.abs(v - hv).max() <= 1e-6 and np.abs(fs - hf).max() <= 1e-6 for hv, hf in have)]
+    at, ae = list(br["alt_target"]), list(br["alt_early"])
+    av = [br["alt_vals"][br["alt_off"][j]:br["alt_off"][j + 1]] for j in range(len(at))]
+    af = [br["alt_feat"][j] for j in range(len(at))]
+    for v, fs in new:
+        at.append(k); ae.append(0); av.append(v); af.append(fs)
+    order = np.argsort(np.asarray(at), kind="stable")
+    br["alt_target"] = np.asarray([at[i] for i in order], np.int32)
+    br["alt_early"] = np.asarray([ae[i] for i in order], np.int8)
+    br["alt_off"] = np.cumsum([0] + [len(av[i]) for i in order]).astype(np.int64)
+    br["alt_vals"] = np.concatenate([av[i] for i in order])
+    br["alt_feat"] = np.stack([af[i] for i in order]).astype(np.float32)
+    np.savez_compressed(bp, **br)
+    print("appended %d alternate outcome(s) of target %d to %s" % (len(new), tt, os.path.basename(bp)))

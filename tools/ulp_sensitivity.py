@@ -26,7 +26,8 @@ if len(sys.argv) > 4 and sys.argv[4] == "--child":
     main = z["vals"][z["eoff"][k]:z["eoff"][k + 1]]
     sg = Subgraph(A, ck["feat"][nb], int(ck["label"][tt]), new, np.argmax(ck["pred"][nb], 1), m0)
     res = engine.MaskOptimJob([sg], ck["sd"], device="cpu", lib=emu_library()).run([m0], Hyper(num_iters=300))
-    print("DEV %.3e" % np.abs((res.masked_adj[0] * A)[r, c] - main).max())
+    fs = 1.0 / (1.0 + np.exp(-res.feat_mask[0][:ck["feat"].shape[1]].astype(np.float64)))
+    print("DEV %.3e" % max(np.abs((res.masked_adj[0] * A)[r, c] - main).max(), np.abs(fs - z["feat_sig"][k]).max()))
     sys.exit(0)
 name, tt, trials = sys.argv[1], sys.argv[2], int(sys.argv[3])
 devs = []
