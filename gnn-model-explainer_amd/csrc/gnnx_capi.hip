@@ -10,6 +10,7 @@
 #include <cstring>
 #include <string>
 #include <type_traits>
+#include <mutex>
 #include <vector>
 
 #include "../../include/gnnx.h"
@@ -53,9 +54,11 @@ constexpr int N_SIDE = RES_NBMAX + N_SPC;
 constexpr int N_LANES = 3;
 constexpr int MAX_DEVICES = 16;
 static hipStream_t g_lane[MAX_DEVICES][N_LANES] = {};
+static std::mutex g_lane_mutex;   // gnnx_run may be entered from several host threads (ctypes releases the GIL)
 static hipStream_t lane_stream(int i) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+    std::lock_guard<std::mutex> lock(g_lane_mutex);
     hipStream_t& st = g_lane[dev][i % N_LANES];
     if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
     return st;
