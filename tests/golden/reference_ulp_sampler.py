@@ -8,12 +8,12 @@ the bit-pinned oracle (oracle/reference_restatement.py) runs with
     denominator takes a random -1 / 0 / +1 ulp, and
   * F.normalize, torch.sigmoid, torch.softmax and torch.log results moved the same way,
 and prints how far the 300-epoch result moves from the unperturbed reference; `--append` stores the distinct outcomes as
-alternates of the target in tests/golden/<dataset>_branches.npz.  python tools/reference_ulp_sampler.py syn5 767 24 [--append]"""
+alternates of the target in tests/golden/<dataset>_branches.npz.  python tests/golden/reference_ulp_sampler.py syn5 767 24 [--append]"""
 import os, sys
 import numpy as np
 import torch
 import torch.nn.functional as F
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 torch.set_num_threads(1)
 import helpers

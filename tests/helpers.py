@@ -103,7 +103,7 @@ BRANCH_JUMP_MAX = 5e-3   # largest distance between two outcomes of one non-chao
 # 70 % within 1e-5 and bounds the rest by that jump; after 50 epochs 95 % (molecule-like graphs are full of symmetric atoms whose
 # activations are equal in exact arithmetic: which of them wins the max-pool is decided by the summation order of each
 # implementation - graph 2477 switches rows at epoch ~32 in the edge-sparse kernel while the dense streaming kernels stay with the
-# reference, both on the same GPU; tools/debug_graph2477.py).
+# reference, both on the same GPU; tests/golden/debug_graph2477.py).
 CONFIG4_FULL_RULE = dict(min_frac=0.70, jump_max=6e-2)
 CONFIG4_EARLY_RULE = dict(min_frac=0.95, jump_max=6e-2)
 
