@@ -91,6 +91,7 @@ struct gnnx_plan_s {
     int32_t* d_sp[N_SPC] = {};
     int n_sparse() const { return n_sp[0] + n_sp[1] + n_sp[2] + n_sp[3] + n_sp[4]; }
     int32_t* d_nnz = nullptr;
+    int32_t* d_rowdeg = nullptr;       // off-diagonal non-zeros of every row of the batch (gnnx_plan_analyze, k_row_degrees)
     int32_t* d_csr_rowptr = nullptr;   // CSR of the targets of k_sparse_large (gnnx_plan_analyze)
     unsigned short* d_csr_col = nullptr;
     unsigned short* d_csr_row = nullptr;   // row of every directed entry
@@ -355,6 +356,7 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
     for (int k = 0; k < N_SPC; ++k)
         if (h->d_sp[k]) (void)hipFree(h->d_sp[k]);
     if (h->d_nnz) (void)hipFree(h->d_nnz);
+    if (h->d_rowdeg) (void)hipFree(h->d_rowdeg);
     if (h->d_csr_rowptr) (void)hipFree(h->d_csr_rowptr);
     if (h->d_csr_col) (void)hipFree(h->d_csr_col);
     if (h->d_csr_row) (void)hipFree(h->d_csr_row);
@@ -703,9 +705,12 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
     if (!h->prob.graph_mode) {
         int nmax = 0;
         for (int t = 0; t < T; ++t) nmax = std::max(nmax, h->meta[t].n);
-        hipLaunchKernelGGL((k_count_edges_large<0, 4095>), dim3(T), dim3(1024), 0, s, h->d_meta, A, h->d_nnz + 2 * T);
+        if (!h->d_rowdeg) HIPCK(hipMalloc(&h->d_rowdeg, sizeof(int32_t) * (size_t)h->R));
+        hipLaunchKernelGGL(k_row_degrees, dim3(h->n_conv), dim3(256), 0, s, A, h->d_conv, h->d_rowdeg);
+        hipLaunchKernelGGL((k_count_edges_large<0, 4095>), dim3(T), dim3(1024), 0, s, h->d_meta, A, h->d_rowdeg, h->d_nnz + 2 * T);
         if (nmax > 4095)
-            hipLaunchKernelGGL((k_count_edges_large<4095, SPL_N_MAX>), dim3(T), dim3(1024), 0, s, h->d_meta, A, h->d_nnz + 2 * T);
+            hipLaunchKernelGGL((k_count_edges_large<4095, SPL_N_MAX>), dim3(T), dim3(1024), 0, s, h->d_meta, A, h->d_rowdeg,
+                               h->d_nnz + 2 * T);
     }
     HIPCK(hipGetLastError());
     // per target: (directed entries, row slots over all rows); then k_count_edges_large's SPL_COUNTS figures
@@ -817,7 +822,7 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
         if (int rc = build_split(h)) return rc;
     // CSR of the large-class targets, built once per plan (the kernel would otherwise rescan its dense block per launch)
     if (h->n_sp[SPC_LARGE] > 0) {
-        std::vector<long long> off(2 * (size_t)T, 0);
+        std::vector<long long> off(2 * (size_t)T, -1);   // -1: not a target of k_sparse_large (k_csr_emit_large skips its row blocks)
         long long rp = 0, cl = 0;
         for (int t = 0; t < T; ++t)
             if (h->cat[t] == CAT_SPARSE + SPC_LARGE) {
@@ -837,8 +842,10 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
         HIPCK(hipMalloc(&h->d_csr_row, sizeof(unsigned short) * (size_t)std::max<long long>(cl, 2)));
         HIPCK(hipMalloc(&h->d_csr_off, sizeof(long long) * off.size()));
         HIPCK(hipMemcpy(h->d_csr_off, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_build_csr_large, dim3(h->n_sp[SPC_LARGE]), dim3(1024), 0, s, h->d_meta, A, h->d_sp[SPC_LARGE], h->d_csr_off,
-                           h->d_csr_rowptr, h->d_csr_col, h->d_csr_row);
+        hipLaunchKernelGGL(k_csr_rowptr_large, dim3(h->n_sp[SPC_LARGE]), dim3(1024), 0, s, h->d_meta, h->d_rowdeg, h->d_sp[SPC_LARGE],
+                           h->d_csr_off, h->d_csr_rowptr);
+        hipLaunchKernelGGL(k_csr_emit_large, dim3(h->n_conv), dim3(256), 0, s, A, h->d_conv, h->d_csr_off, h->d_csr_rowptr, h->d_csr_col,
+                           h->d_csr_row);
         HIPCK(hipGetLastError());
         HIPCK(hipStreamSynchronize(s));
     }

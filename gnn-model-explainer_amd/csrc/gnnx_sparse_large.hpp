@@ -1018,9 +1018,36 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
 // directed entries of the rows within two hops, rows within two hops, row slots of SPL_CHUNK entries of t and its
 // neighbours.  Targets outside (NLO, NMAX] are left alone (two instantiations: the LDS tables of the large one would
 // halve the occupancy of a launch over thousands of small targets).
+// every row's number of off-diagonal non-zeros, for the whole batch: one workgroup per 32-row block (a 5600-node block is
+// scanned by 175 workgroups instead of one) -> rowdeg[R]
+__global__ __launch_bounds__(256) void k_row_degrees(const float* A, const ConvTile* tiles, int32_t* rowdeg) {
+    const ConvTile tl = tiles[blockIdx.x];
+    const TargetMeta tm = tl.tm;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int UN = 4;
+    for (int rr = wave; rr < TILE; rr += 4) {
+        const int r = tl.rb * TILE + rr;
+        int cnt = 0;
+        if (r < tm.n) {
+            const float* row = A + tm.offQ + (size_t)r * tm.ld;
+            for (int c0 = 0; c0 < tm.n; c0 += 64 * UN) {
+                float a[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int c = c0 + 64 * u + lane;
+                    a[u] = (c < tm.n && c != r) ? row[c] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) cnt += __popcll(__ballot(a[u] != 0.0f));
+            }
+        }
+        if (lane == 0) rowdeg[tm.offR + r] = cnt;
+    }
+}
+
 template <int NLO, int NMAX>
-__global__ __launch_bounds__(1024) void k_count_edges_large(const TargetMeta* meta, const float* A, int32_t* out) {
-    constexpr int NW = 16, UN = 8;   // the scan of a dense block is latency-bound: 16 waves x 8 chunks of 64 columns in flight
+__global__ __launch_bounds__(1024) void k_count_edges_large(const TargetMeta* meta, const float* A, const int32_t* rowdeg, int32_t* out) {
+    constexpr int NW = 16, UN = 8;   // the dense rows of t and its neighbours are scanned for the hop levels: 16 waves x 8 chunks in flight
     __shared__ int deg[NMAX + 1];
     __shared__ unsigned char level[NMAX + 1];
     __shared__ int part[NW];
@@ -1033,21 +1060,13 @@ __global__ __launch_bounds__(1024) void k_count_edges_large(const TargetMeta* me
     }
     const float* Ag = A + tm.offQ;
     int cnt = 0;
-    for (int r = wave; r < tm.n; r += NW) {
-        int d = 0;
-        for (int c0 = 0; c0 < tm.n; c0 += 64 * UN) {
-            float a[UN];
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int c = c0 + 64 * u + lane;
-                a[u] = (c < tm.n && c != r) ? Ag[(size_t)r * tm.ld + c] : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < UN; ++u) d += __popcll(__ballot(a[u] != 0.0f));
-        }
+    for (int r = tid; r < tm.n; r += 64 * NW) {   // degrees: k_row_degrees counted them
+        const int d = rowdeg[tm.offR + r];
+        deg[r] = d;
         cnt += d;
-        if (lane == 0) deg[r] = d;
     }
+#pragma unroll
+    for (int o2 = 32; o2 >= 1; o2 >>= 1) cnt += __shfl_xor(cnt, o2);
     for (int r = tid; r < tm.n; r += 64 * NW) level[r] = (r == tm.t) ? 0 : 3;
     if (lane == 0) part[wave] = cnt;
     __syncthreads();
@@ -1104,51 +1123,49 @@ __global__ __launch_bounds__(1024) void k_count_edges_large(const TargetMeta* me
 }
 
 // gnnx_plan_analyze: CSR (rowptr [ld + 1], ascending columns, the row of every entry) of every target routed to
-// k_sparse_large, from its block of the packed dense adjacency; one workgroup per target, rows by waves, 4 chunks of 64
-// columns in flight per wave.
-__global__ __launch_bounds__(1024) void k_build_csr_large(const TargetMeta* meta, const float* A, const int32_t* targets,
-                                                         const long long* csr_off, int32_t* csr_rowptr, unsigned short* csr_col,
-                                                         unsigned short* csr_row) {
+// k_sparse_large, from its block of the packed dense adjacency.  k_csr_rowptr_large: one workgroup per such target turns the
+// row degrees (k_row_degrees) into rowptr; k_csr_emit_large: one workgroup per 32-row block of the batch (blocks of other
+// targets leave at once: csr_off[2 t] < 0) writes the columns and rows of its rows' entries.
+__global__ __launch_bounds__(1024) void k_csr_rowptr_large(const TargetMeta* meta, const int32_t* rowdeg, const int32_t* targets,
+                                                          const long long* csr_off, int32_t* csr_rowptr) {
     const int t = targets[blockIdx.x];
     const TargetMeta tm = meta[t];
     const int n = tm.n, ld = tm.ld;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    constexpr int NW = 16, UN = 8;   // latency-bound scan: 16 waves x 8 chunks of 64 columns in flight
-    const float* Ag = A + tm.offQ;
     int32_t* rowptr = csr_rowptr + csr_off[2 * t];
-    unsigned short* col = csr_col + csr_off[2 * t + 1];
-    unsigned short* row = csr_row + csr_off[2 * t + 1];
     __shared__ int srp[SPL_N_MAX + 34];
-    for (int r = wave; r < ld; r += NW) {
-        int cnt = 0;
-        if (r < n)
-            for (int c0 = 0; c0 < n; c0 += 64 * UN) {
-                float a[UN];
-#pragma unroll
-                for (int u = 0; u < UN; ++u) {
-                    const int c = c0 + 64 * u + lane;
-                    a[u] = (c < n && c != r) ? Ag[(size_t)r * ld + c] : 0.0f;
-                }
-#pragma unroll
-                for (int u = 0; u < UN; ++u) cnt += __popcll(__ballot(a[u] != 0.0f));
-            }
-        if (lane == 0) srp[r] = cnt;
-    }
+    for (int r = tid; r < ld; r += 1024) srp[r] = (r < n) ? rowdeg[tm.offR + r] : 0;
     __syncthreads();
     if (wave == 0) {
         const int total = wave_exclusive_scan_array(srp, ld, lane);
         if (lane == 0) srp[ld] = total;
     }
     __syncthreads();
-    for (int r = tid; r <= ld; r += 64 * NW) rowptr[r] = srp[r];
-    for (int r = wave; r < n; r += NW) {
-        int base = srp[r];
+    for (int r = tid; r <= ld; r += 1024) rowptr[r] = srp[r];
+}
+
+__global__ __launch_bounds__(256) void k_csr_emit_large(const float* A, const ConvTile* tiles, const long long* csr_off,
+                                                        const int32_t* csr_rowptr, unsigned short* csr_col, unsigned short* csr_row) {
+    const ConvTile tl = tiles[blockIdx.x];
+    if (csr_off[2 * tl.t] < 0) return;   // not a target of k_sparse_large
+    const TargetMeta tm = tl.tm;
+    const int n = tm.n, ld = tm.ld;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int UN = 4;
+    const int32_t* rowptr = csr_rowptr + csr_off[2 * tl.t];
+    unsigned short* col = csr_col + csr_off[2 * tl.t + 1];
+    unsigned short* row = csr_row + csr_off[2 * tl.t + 1];
+    for (int rr = wave; rr < TILE; rr += 4) {
+        const int r = tl.rb * TILE + rr;
+        if (r >= n) continue;   // uniform per wave
+        int base = rowptr[r];
+        const float* arow = A + tm.offQ + (size_t)r * ld;
         for (int c0 = 0; c0 < n; c0 += 64 * UN) {
             float a[UN];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 const int c = c0 + 64 * u + lane;
-                a[u] = (c < n && c != r) ? Ag[(size_t)r * ld + c] : 0.0f;
+                a[u] = (c < n && c != r) ? arow[c] : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
