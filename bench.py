@@ -42,9 +42,10 @@ MFMA_F32_PEAK = 157.3e12     # flop/s, dense f32 MFMA
 LDS_PEAK_PER_CU = 128 * 2.4e9   # B/s: ds_read_b32 = 128 B/clk/CU at ~2.4 GHz (MI355X_MICROARCH.md, LDS table)
 NUM_CUS = 256
 PARITY_TOL = 1e-5
-RNG_THREADS = 4              # host threads drawing the seeded initial masks (targets are independent under the seed protocol); per-call
-                             # overhead under the GIL bounds small batches (16 threads: 7.7 ms instead of 5.3 ms on syn1), big ones get more
-RNG_THREADS_BIG = max(4, min(16, (os.cpu_count() or 4) // 8))   # batches of > 2e7 normals (8 ranks share the host)
+RNG_THREADS = 2              # host threads drawing the seeded initial masks (targets are independent under the seed protocol); measured
+                             # on the box's EPYC (tools/probe_rng.py): syn1 4.9 / 3.3 / 3.7 / 6.0 ms with 1 / 2 / 4 / 8 threads (per-call
+                             # overhead under the GIL), the 2048-target BA-House x100k sample 222 / 59 / 34 / 36 ms with 1 / 4 / 8 / 16
+RNG_THREADS_BIG = max(2, min(8, (os.cpu_count() or 4) // 16))   # batches of > 2e7 normals (8 ranks share the host)
 WELL = 2e-6                  # CPU-vs-CPU deviation (reference vs closed-form oracle) up to which a target is well conditioned
 
 

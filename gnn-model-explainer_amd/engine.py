@@ -456,6 +456,10 @@ class MaskOptimJob:
         if raw.dtype != torch.float32 or raw.numel() != int(self.lib.gnnx_total_raw(self.handle)):
             raise ValueError("raw mask stream must hold sum(n^2) float32 values")
         self._raw = raw.to(self.device, non_blocking=True)
+        c = _PIN_CACHE
+        if c["buf"] is not None and raw.is_pinned() and raw.untyped_storage().data_ptr() == c["buf"].untyped_storage().data_ptr():
+            c["event"] = torch.cuda.Event()           # the shared pinned buffer may be refilled once this copy is done
+            c["event"].record(torch.cuda.current_stream(self.device))
         self._enter()
         _check(self.lib, self.lib.gnnx_scatter_masks(self.handle, self._raw.data_ptr(), self.M.data_ptr(), self._stream()))
         self._leave()
@@ -658,16 +662,41 @@ class MaskOptimJob:
             pass
 
 
+_PIN_CACHE = {"buf": None, "event": None}
+_RNG_POOL = []
+
+
+def _pinned_stream_buffer(total):
+    """One grow-only pinned host buffer per process for the RNG stream of a batch (allocating 8 MB of pinned memory costs about
+    as much as drawing the syn1 masks).  MaskOptimJob.set_masks_raw records an event behind its H2D copy; the buffer is not
+    rewritten before that copy has finished."""
+    c = _PIN_CACHE
+    if c["event"] is not None:
+        c["event"].synchronize()
+        c["event"] = None
+    if c["buf"] is None or c["buf"].numel() < total:
+        c["buf"] = torch.empty(int(total * 1.25) + 1024, dtype=torch.float32, pin_memory=True)
+    return c["buf"][:total]
+
+
+def _rng_pool():
+    if not _RNG_POOL:
+        from concurrent.futures import ThreadPoolExecutor
+        _RNG_POOL.append(ThreadPoolExecutor(32))
+    return _RNG_POOL[0]
+
+
 def init_edge_masks_raw(sizes, generator=None, seeds=None, pin=False, threads=1):
     """The initial edge masks of a whole batch as ONE host buffer: target after target the n x n values of the single
     normal_(1, std) draw construct_edge_mask makes (explain.py:645-652), generated in place (a draw into a contiguous
     slice consumes the generator exactly like a draw into a fresh [n, n] tensor).  `seeds`: re-seed a PRIVATE generator
     before every target (the seed protocol of the golden runs) instead of consuming the caller's global stream; the
-    targets are then independent and `threads` > 1 draws them on several host threads (normal_ releases the GIL)."""
+    targets are then independent and `threads` > 1 draws them on several host threads (normal_ releases the GIL).
+    `pin`: the result is a view of ONE process-wide pinned buffer - upload it (set_masks_raw) before the next pinned call."""
     sizes = [int(n) for n in sizes]
     off = np.zeros(len(sizes) + 1, np.int64)
     np.cumsum(np.asarray(sizes, np.int64) ** 2, out=off[1:])
-    buf = torch.empty(int(off[-1]), dtype=torch.float32, pin_memory=bool(pin))
+    buf = _pinned_stream_buffer(int(off[-1])) if pin else torch.empty(int(off[-1]), dtype=torch.float32)
 
     def fill(lo, hi, gen):
         for k in range(lo, hi):
@@ -679,10 +708,8 @@ def init_edge_masks_raw(sizes, generator=None, seeds=None, pin=False, threads=1)
     if seeds is None or threads <= 1 or len(sizes) < 2 * threads:
         fill(0, len(sizes), torch.Generator() if seeds is not None else generator)
         return buf
-    from concurrent.futures import ThreadPoolExecutor
     cuts = [0] + [int(np.searchsorted(off, off[-1] * i / threads)) for i in range(1, threads)] + [len(sizes)]   # equal shares of the floats
-    with ThreadPoolExecutor(threads) as ex:
-        list(ex.map(lambda i: fill(cuts[i], cuts[i + 1], torch.Generator()), range(threads)))
+    list(_rng_pool().map(lambda i: fill(cuts[i], cuts[i + 1], torch.Generator()), range(threads)))
     return buf
 
 
