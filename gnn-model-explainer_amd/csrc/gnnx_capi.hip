@@ -38,6 +38,7 @@ static_assert(GNNX_FEAT_STRIDE == FS && GNNX_MAX_CLASSES == CMAX && GNNX_LOSS_TE
 
 struct GraphKey {
     const void *A, *X, *yhat, *M, *Abar, *fm, *loss, *ws;
+    gnnx_resume rs;
     gnnx_hyper hy;
     bool operator==(const GraphKey& o) const { return std::memcmp(this, &o, sizeof(GraphKey)) == 0; }
 };
@@ -102,6 +103,7 @@ struct gnnx_plan_s {
     int64_t total_raw = 0;
     std::vector<float> adam_host;
     gnnx_hyper adam_for{};
+    int adam_first = 0;              // first_iter the table was built for (gnnx_run_resume)
     TargetMeta* d_meta = nullptr;
     ConvTile* d_conv = nullptr;   // every 32-row block of every target
     MaskTile* d_mask = nullptr;
@@ -506,10 +508,10 @@ static void launch_backward(gnnx_handle h, const Tables& tb, const Params& p, in
 }
 
 // the streaming job over the given tables, stream-ordered: usable directly or under stream capture
-static int enqueue_job(gnnx_handle h, const Tables& tb, const gnnx_hyper* hy, const Params& p, hipStream_t s) {
+// (the Adam moments of M are initialised by the caller, init_stream_state, BEFORE the resident launches of a hybrid run are
+// released: with gnnx_resume.m_out they live in the caller's buffer, which those launches write too)
+static int enqueue_job(gnnx_handle h, const Tables& tb, const gnnx_hyper* hy, const Params& p, int first_iter, hipStream_t s) {
     const int T = h->prob.num_targets;
-    HIPCK(hipMemsetAsync(p.mM, 0, sizeof(float) * (size_t)h->Q, s));
-    HIPCK(hipMemsetAsync(p.vM, 0, sizeof(float) * (size_t)h->Q, s));
     if (p.loss) HIPCK(hipMemsetAsync(p.loss, 0, sizeof(float) * (size_t)T * hy->num_iters * NLOSS, s));
     hipLaunchKernelGGL(k_prep, dim3(tb.n_targets), dim3(256), 0, s, p, (const float*)nullptr, tb.ids);
     launch_mask<false, true>(h, tb, p, 0, 0.0f, 1.0f, s);
@@ -517,13 +519,30 @@ static int enqueue_job(gnnx_handle h, const Tables& tb, const gnnx_hyper* hy, co
         launch_forward(h, tb, p, it, s);
         launch_backward(h, tb, p, it, s);
         float ss, b2;
-        adam_scalars(hy, it, &ss, &b2);
+        adam_scalars(hy, first_iter + it, &ss, &b2);
         if (it + 1 < hy->num_iters)
             launch_mask<true, true>(h, tb, p, it, ss, b2, s);
         else
             launch_mask<true, false>(h, tb, p, it, ss, b2, s);  // keep Abar of the LAST forward (explain.py:209-211)
     }
+    if (p.fs_out) hipLaunchKernelGGL(k_export_fstate, dim3(tb.n_targets), dim3(64), 0, s, p, tb.ids);
     HIPCK(hipGetLastError());
+    return 0;
+}
+
+// Adam moments of the streaming path: zeros (a fresh run) or the caller's state (gnnx_run_resume)
+static int init_stream_state(gnnx_handle h, const Params& p, hipStream_t s) {
+    const size_t qb = sizeof(float) * (size_t)h->Q;
+    if (p.m_in) {
+        if (p.m_in != p.mM) HIPCK(hipMemcpyAsync(p.mM, p.m_in, qb, hipMemcpyDeviceToDevice, s));
+    } else {
+        HIPCK(hipMemsetAsync(p.mM, 0, qb, s));
+    }
+    if (p.v_in) {
+        if (p.v_in != p.vM) HIPCK(hipMemcpyAsync(p.vM, p.v_in, qb, hipMemcpyDeviceToDevice, s));
+    } else {
+        HIPCK(hipMemsetAsync(p.vM, 0, qb, s));
+    }
     return 0;
 }
 
@@ -563,7 +582,25 @@ static void launch_sparse(gnnx_handle h, const Params& p, int cls, const float* 
 extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, const float* X, const float* yhat,
                         float* M, float* Abar, float* feat_mask, float* loss, void* workspace,
                         size_t workspace_bytes, void* stream) {
+    return gnnx_run_resume(h, hy, nullptr, A, X, yhat, M, Abar, feat_mask, loss, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_resume* resume, const float* A, const float* X,
+                               const float* yhat, float* M, float* Abar, float* feat_mask, float* loss, void* workspace,
+                               size_t workspace_bytes, void* stream) {
     if (!h || !hy || !A || !X || !M || !Abar || !workspace) return fail("null argument");
+    gnnx_resume rs;
+    std::memset(&rs, 0, sizeof rs);   // (padding included: the struct is part of the hipGraph key)
+    if (resume) {
+        rs.first_iter = resume->first_iter;
+        rs.m = resume->m;
+        rs.v = resume->v;
+        rs.feat = resume->feat;
+        rs.m_out = resume->m_out;
+        rs.v_out = resume->v_out;
+        rs.feat_out = resume->feat_out;
+    }
+    if (rs.first_iter < 0) return fail("first_iter must be >= 0");
     if (!h->prob.graph_mode && !yhat) return fail("yhat is required in node mode (Laplacian term)");
     if (workspace_bytes < h->ws_bytes) return fail("workspace too small");
     if (hy->num_iters < 1) return fail("num_iters must be >= 1");
@@ -572,20 +609,33 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
     if (hy->record_loss && !loss) return fail("record_loss set but loss buffer is null");
     if (hy->record_loss && h->prob.mask_relu) return fail("loss logging is not implemented for mask_act = ReLU (the reference's loss is NaN there)");
     Params p = make_params(h, hy, A, X, yhat, M, Abar, lossp, workspace);
+    p.m_in = rs.m;
+    p.v_in = rs.v;
+    p.fs_in = rs.feat;
+    p.m_out = rs.m_out;
+    p.v_out = rs.v_out;
+    p.fs_out = rs.feat_out;
+    if (rs.m_out) p.mM = rs.m_out;   // the streaming kernels keep their moments in the caller's arrays when it wants them back
+    if (rs.v_out) p.vM = rs.v_out;
     // hybrid split: small targets (<= res_nbmax row blocks) -> on-chip-resident kernels on side streams (overlap with the
     // streaming launches of the other targets); loss logging is a streaming-path feature
     const bool resident = hy->use_resident && (h->n_res > 0 || h->n_sparse() > 0) && !lossp;
     const Tables tb = (resident && h->n_big > 0) ? tables_big(h) : tables_all(h);
     const bool streaming = !resident || h->n_big > 0;
+    if (streaming)
+        if (int rc = init_stream_state(h, p, s)) return rc;
     if (resident) {
         HIPCK(hipEventRecord(h->ev_in, s));
-        if (!h->d_adam || std::memcmp(&h->adam_for, hy, sizeof(gnnx_hyper)) != 0) {
+        if (!h->d_adam || h->adam_first != rs.first_iter || std::memcmp(&h->adam_for, hy, sizeof(gnnx_hyper)) != 0) {
+            // (a table still read by an earlier launch must not be freed under it: hipFree synchronises the device)
             if (h->d_adam) (void)hipFree(h->d_adam);
             h->adam_host.resize(2 * (size_t)hy->num_iters);
-            for (int it = 0; it < hy->num_iters; ++it) adam_scalars(hy, it, &h->adam_host[2 * it], &h->adam_host[2 * it + 1]);
+            for (int it = 0; it < hy->num_iters; ++it)
+                adam_scalars(hy, rs.first_iter + it, &h->adam_host[2 * it], &h->adam_host[2 * it + 1]);
             HIPCK(hipMalloc(&h->d_adam, sizeof(float) * h->adam_host.size()));
             HIPCK(hipMemcpy(h->d_adam, h->adam_host.data(), sizeof(float) * h->adam_host.size(), hipMemcpyHostToDevice));
             h->adam_for = *hy;
+            h->adam_first = rs.first_iter;
         }
         // Launch order: sparse resident kernel (gnnx_plan_analyze), largest size class FIRST - its workgroups need a whole
         // CU (1024 threads x 128 VGPRs), so they must be placed before the small workgroups of the other launches spread
@@ -640,10 +690,13 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
     }
     if (streaming) {
         if (!hy->use_graph) {
-            int rc = enqueue_job(h, tb, hy, p, s);
+            int rc = enqueue_job(h, tb, hy, p, rs.first_iter, s);
             if (rc) return rc;
         } else {
-            GraphKey key{A, X, yhat, M, Abar, (const void*)(size_t)(resident ? 1 : 0), lossp, workspace, *hy};
+            GraphKey key;
+            std::memset(&key, 0, sizeof key);
+            key.A = A; key.X = X; key.yhat = yhat; key.M = M; key.Abar = Abar; key.fm = (const void*)(size_t)(resident ? 1 : 0);
+            key.loss = lossp; key.ws = workspace; key.rs = rs; key.hy = *hy;
             if (!h->gexec || !(key == h->gkey)) {
                 if (h->gexec) {
                     (void)hipGraphExecDestroy(h->gexec);
@@ -651,7 +704,7 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
                 }
                 hipGraph_t g = nullptr;
                 HIPCK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-                int rc = enqueue_job(h, tb, hy, p, s);
+                int rc = enqueue_job(h, tb, hy, p, rs.first_iter, s);
                 hipError_t e = hipStreamEndCapture(s, &g);
                 if (rc) return rc;
                 if (e != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));

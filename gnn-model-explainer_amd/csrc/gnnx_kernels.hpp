@@ -87,6 +87,13 @@ struct Params {
     float* Xn[2];
     float* XnT[2];
     float* bnr[2];
+    // resume (gnnx_run_resume): Adam state to start from / to hand back; null = zeros / not wanted
+    const float* m_in;   // exp_avg of M, packed square layout
+    const float* v_in;   // exp_avg_sq of M
+    const float* fs_in;  // [T][3][32]: feat_mask, exp_avg, exp_avg_sq
+    float* m_out;
+    float* v_out;
+    float* fs_out;
     int32_t bn;
     int32_t D, H, O, C;
     int32_t graph_mode;
@@ -1077,11 +1084,24 @@ __global__ __launch_bounds__(256) void k_prep(Params p, const float* f_init, con
     }
     if (threadIdx.x < FS) {
         const int o = t * FS + threadIdx.x;
-        const float f0 = f_init ? f_init[o] : 0.0f;
+        const float* fs = p.fs_in ? p.fs_in + (size_t)t * 3 * FS + threadIdx.x : nullptr;
+        const float f0 = f_init ? f_init[o] : fs ? fs[0] : 0.0f;
         p.f[0][o] = f0;
         p.f[1][o] = f0;
-        p.mf[o] = 0.0f;
-        p.vf[o] = 0.0f;
+        p.mf[o] = fs ? fs[FS] : 0.0f;
+        p.vf[o] = fs ? fs[2 * FS] : 0.0f;
+    }
+}
+
+// streaming path, end of a run: the feature-mask state after num_iters steps -> fs_out [T][3][32]  (gnnx_run_resume)
+__global__ __launch_bounds__(64) void k_export_fstate(Params p, const int32_t* ids) {
+    const int t = ids ? ids[blockIdx.x] : (int)blockIdx.x;
+    if (threadIdx.x < FS) {
+        const int o = t * FS + threadIdx.x;
+        float* fs = p.fs_out + (size_t)t * 3 * FS + threadIdx.x;
+        fs[0] = p.f[p.num_iters & 1][o];
+        fs[FS] = p.mf[o];
+        fs[2 * FS] = p.vf[o];
     }
 }
 

@@ -156,11 +156,12 @@ __global__ __launch_bounds__(256) void k_resident(Params p, const int32_t* targe
             Ao[pi] = *reinterpret_cast<const f32x4*>(p.A + own);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                mo[pi][e] = 0.0f;
-                vo[pi][e] = 0.0f;
-                mp[pi][e] = 0.0f;
-                vp[pi][e] = 0.0f;
-                Mp[pi][e] = (I != J) ? p.M[tm.offQ + (size_t)(J * TILE + c4 + e) * LD + I * TILE + i] : 0.0f;
+                const size_t mir = tm.offQ + (size_t)(J * TILE + c4 + e) * LD + I * TILE + i;
+                mo[pi][e] = p.m_in ? p.m_in[own + e] : 0.0f;   // gnnx_run_resume: Adam moments (zeros otherwise)
+                vo[pi][e] = p.v_in ? p.v_in[own + e] : 0.0f;
+                mp[pi][e] = (p.m_in && I != J) ? p.m_in[mir] : 0.0f;
+                vp[pi][e] = (p.v_in && I != J) ? p.v_in[mir] : 0.0f;
+                Mp[pi][e] = (I != J) ? p.M[mir] : 0.0f;
             }
         }
 #pragma unroll
@@ -176,9 +177,10 @@ __global__ __launch_bounds__(256) void k_resident(Params p, const int32_t* targe
     if (tid < CMAX) sh.sbp[tid] = p.wts[WT_BP + tid];
     if (tid < LD) sh.yhat[tid] = p.yhat[tm.offR + tid];
     if (tid < 32) {
-        sh.fcur[tid] = 0.0f;  // construct_feat_mask: constant 0 (explain.py:639-641)
-        sh.mf[tid] = 0.0f;
-        sh.vf[tid] = 0.0f;
+        const float* fs = p.fs_in ? p.fs_in + (size_t)t * 3 * FS + tid : nullptr;   // gnnx_run_resume
+        sh.fcur[tid] = (fs && tid < p.D) ? fs[0] : 0.0f;  // construct_feat_mask: constant 0 (explain.py:639-641)
+        sh.mf[tid] = (fs && tid < p.D) ? fs[FS] : 0.0f;
+        sh.vf[tid] = (fs && tid < p.D) ? fs[2 * FS] : 0.0f;
     }
     const float inv_n2 = 1.0f / ((float)n * (float)n);
 
@@ -464,6 +466,8 @@ __global__ __launch_bounds__(256) void k_resident(Params p, const int32_t* targe
             const int pi = res_pair_index(NB, I, J);
             const size_t own = tm.offQ + (size_t)(I * TILE + i) * LD + J * TILE + c4;
             *reinterpret_cast<f32x4*>(p.M + own) = Mo[pi];
+            if (p.m_out) *reinterpret_cast<f32x4*>(p.m_out + own) = mo[pi];
+            if (p.v_out) *reinterpret_cast<f32x4*>(p.v_out + own) = vo[pi];
             f32x4 ab;
 #pragma unroll
             for (int e = 0; e < 4; ++e) ab[e] = sh.sA[pi][i * 33 + c4 + e];
@@ -474,13 +478,22 @@ __global__ __launch_bounds__(256) void k_resident(Params p, const int32_t* targe
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     abT[e] = sh.sA[pi][(c4 + e) * 33 + i];
-                    p.M[tm.offQ + (size_t)(J * TILE + c4 + e) * LD + I * TILE + i] = Mp[pi][e];
+                    const size_t mir = tm.offQ + (size_t)(J * TILE + c4 + e) * LD + I * TILE + i;
+                    p.M[mir] = Mp[pi][e];
+                    if (p.m_out) p.m_out[mir] = mp[pi][e];
+                    if (p.v_out) p.v_out[mir] = vp[pi][e];
                 }
                 *reinterpret_cast<f32x4*>(p.Abar + mirror_row) = abT;
             }
         }
     // final feature mask into the slot the streaming path would have used (copied out by the host afterwards)
     if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = (tid < p.D) ? sh.fcur[tid] : 0.0f;
+    if (p.fs_out && tid < FS) {
+        float* fs = p.fs_out + (size_t)t * 3 * FS + tid;
+        fs[0] = (tid < p.D) ? sh.fcur[tid] : 0.0f;
+        fs[FS] = (tid < p.D) ? sh.mf[tid] : 0.0f;
+        fs[2 * FS] = (tid < p.D) ? sh.vf[tid] : 0.0f;
+    }
 }
 
 }  // namespace gnnx

@@ -673,6 +673,14 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 if (Ag[(size_t)j * ld + i] != wgt[q]) asym = true;
                 Mij[q] = Mg[(size_t)i * ld + j];
                 Mji[q] = Mg[(size_t)j * ld + i];
+                if (p.m_in) {  // gnnx_run_resume: Adam moments of the two entries
+                    mij[q] = p.m_in[tm.offQ + (size_t)i * ld + j];
+                    mji[q] = p.m_in[tm.offQ + (size_t)j * ld + i];
+                }
+                if (p.v_in) {
+                    vij[q] = p.v_in[tm.offQ + (size_t)i * ld + j];
+                    vji[q] = p.v_in[tm.offQ + (size_t)j * ld + i];
+                }
                 eflag[q] = GRAPH ? 15 : ((level[i] <= 2) | ((level[j] <= 2) << 1) | ((level[i] <= 1) << 2) | ((level[j] <= 1) << 3));
             }
         }
@@ -709,9 +717,10 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     if (tid < CMAX) sh.sbp[tid] = p.wts[WT_BP + tid];
     if (tid < ld) sYhat[tid] = GRAPH ? 0.0f : p.yhat[tm.offR + tid];  // graph mode has no Laplacian term (explain.py:780)
     if (tid < 32) {
-        sh.fcur[tid] = 0.0f;  // construct_feat_mask: constant 0 (explain.py:639-641)
-        sh.mf[tid] = 0.0f;
-        sh.vf[tid] = 0.0f;
+        const float* fs = p.fs_in ? p.fs_in + (size_t)t * 3 * FS + tid : nullptr;   // gnnx_run_resume
+        sh.fcur[tid] = (fs && tid < D) ? fs[0] : 0.0f;  // construct_feat_mask: constant 0 (explain.py:639-641)
+        sh.mf[tid] = (fs && tid < D) ? fs[FS] : 0.0f;
+        sh.vf[tid] = (fs && tid < D) ? fs[2 * FS] : 0.0f;
     }
     const float inv_n2 = 1.0f / ((float)n * (float)n);
     const int rt0 = rowptr[tr], rt1 = rowptr[tr + 1];
@@ -722,7 +731,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     // sArt = Abar[t][.] as a dense row (rank-1 layer-3 backward): zero except on t's neighbours, whose entries the owners of
     // the edges at t refresh in publish_abar
     if (tid < ld) sArt[tid] = 0.0f;
-    if (tid < 32) sh.phi[tid] = (tid < D) ? 0.5f : 0.0f;  // sigmoid of the initial feature mask (0)
+    if (tid < 32)   // sigmoid of the initial feature mask (0), or of the resumed one
+        sh.phi[tid] = (tid < D) ? (p.fs_in ? sigmoidf_(p.fs_in[(size_t)t * 3 * FS + tid]) : 0.5f) : 0.0f;
     SYNC();
     auto publish_abar = [&]() {
 #pragma unroll
@@ -1223,8 +1233,22 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             p.Abar[tm.offQ + (size_t)j * ld + i] = a;
             Mg[(size_t)i * ld + j] = Mij[q];
             Mg[(size_t)j * ld + i] = Mji[q];
+            if (p.m_out) {
+                p.m_out[tm.offQ + (size_t)i * ld + j] = mij[q];
+                p.m_out[tm.offQ + (size_t)j * ld + i] = mji[q];
+            }
+            if (p.v_out) {
+                p.v_out[tm.offQ + (size_t)i * ld + j] = vij[q];
+                p.v_out[tm.offQ + (size_t)j * ld + i] = vji[q];
+            }
         }
     if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = (tid < D) ? sh.fcur[tid] : 0.0f;
+    if (p.fs_out && tid < FS) {
+        float* fs = p.fs_out + (size_t)t * 3 * FS + tid;
+        fs[0] = (tid < D) ? sh.fcur[tid] : 0.0f;
+        fs[FS] = (tid < D) ? sh.mf[tid] : 0.0f;
+        fs[2 * FS] = (tid < D) ? sh.vf[tid] : 0.0f;
+    }
 }
 
 

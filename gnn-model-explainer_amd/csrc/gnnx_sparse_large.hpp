@@ -523,10 +523,10 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                     eidx[2 * k + 1] = (unsigned)cij | ((unsigned)cji << 16);
                     est[0 * eup + k] = Mg[(size_t)i * ld + j];
                     est[1 * eup + k] = Mg[(size_t)j * ld + i];
-                    est[2 * eup + k] = 0.0f;
-                    est[3 * eup + k] = 0.0f;
-                    est[4 * eup + k] = 0.0f;
-                    est[5 * eup + k] = 0.0f;
+                    est[2 * eup + k] = p.m_in ? p.m_in[tm.offQ + (size_t)i * ld + j] : 0.0f;   // gnnx_run_resume: Adam moments
+                    est[3 * eup + k] = p.m_in ? p.m_in[tm.offQ + (size_t)j * ld + i] : 0.0f;
+                    est[4 * eup + k] = p.v_in ? p.v_in[tm.offQ + (size_t)i * ld + j] : 0.0f;
+                    est[5 * eup + k] = p.v_in ? p.v_in[tm.offQ + (size_t)j * ld + i] : 0.0f;
                     est[6 * eup + k] = w;
                     const float dy = p.yhat[tm.offR + i] - p.yhat[tm.offR + j];
                     glap[k] = p.c_lap * 0.5f * dy * dy * inv_n2;
@@ -561,9 +561,10 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     for (int r = tid; r < ld; r += NT) sXi[r] = 255;
     if (tid == 0) s_misc[1] = 0;
     if (tid < 32) {
-        sh.fcur[tid] = 0.0f;  // construct_feat_mask: constant 0 (explain.py:639-641)
-        sh.mf[tid] = 0.0f;
-        sh.vf[tid] = 0.0f;
+        const float* fs = p.fs_in ? p.fs_in + (size_t)t * 3 * FS + tid : nullptr;   // gnnx_run_resume
+        sh.fcur[tid] = (fs && tid < D) ? fs[0] : 0.0f;  // construct_feat_mask: constant 0 (explain.py:639-641)
+        sh.mf[tid] = (fs && tid < D) ? fs[FS] : 0.0f;
+        sh.vf[tid] = (fs && tid < D) ? fs[2 * FS] : 0.0f;
     }
     if (tid == 0) sAb[nact] = 0.0f;
     // sigma(M) -> symmetrised masked adjacency, one float per active directed entry
@@ -985,6 +986,14 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         p.Abar[tm.offQ + (size_t)j * ld + i] = a;
         Mg[(size_t)i * ld + j] = est[0 * eup + k];
         Mg[(size_t)j * ld + i] = est[1 * eup + k];
+        if (p.m_out) {
+            p.m_out[tm.offQ + (size_t)i * ld + j] = est[2 * eup + k];
+            p.m_out[tm.offQ + (size_t)j * ld + i] = est[3 * eup + k];
+        }
+        if (p.v_out) {
+            p.v_out[tm.offQ + (size_t)i * ld + j] = est[4 * eup + k];
+            p.v_out[tm.offQ + (size_t)j * ld + i] = est[5 * eup + k];
+        }
     }
     // ---------------- far edges: the whole trajectory of both mask entries in registers ----------------
     for (int k = eupN + tid; k < eup; k += NT) {
@@ -992,7 +1001,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         const int i = nd & 0xffffu, j = nd >> 16;
         const float w = est[6 * eup + k];
         const float gc = glap[k] * w;   // (0.5 G + lap) w with G = 0 exactly
-        float Mij = est[0 * eup + k], Mji = est[1 * eup + k], mij = 0.0f, mji = 0.0f, vij = 0.0f, vji = 0.0f;
+        float Mij = est[0 * eup + k], Mji = est[1 * eup + k], mij = est[2 * eup + k], mji = est[3 * eup + k], vij = est[4 * eup + k],
+              vji = est[5 * eup + k];
         float a = w * (0.5f * (sigmoidf_(Mij) + sigmoidf_(Mji)));
         for (int iter = 0; iter < p.num_iters; ++iter) {
             const float step_size = adam_tab[2 * iter], inv_bc2s = 1.0f / adam_tab[2 * iter + 1];
@@ -1007,8 +1017,22 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         p.Abar[tm.offQ + (size_t)j * ld + i] = a;
         Mg[(size_t)i * ld + j] = Mij;
         Mg[(size_t)j * ld + i] = Mji;
+        if (p.m_out) {
+            p.m_out[tm.offQ + (size_t)i * ld + j] = mij;
+            p.m_out[tm.offQ + (size_t)j * ld + i] = mji;
+        }
+        if (p.v_out) {
+            p.v_out[tm.offQ + (size_t)i * ld + j] = vij;
+            p.v_out[tm.offQ + (size_t)j * ld + i] = vji;
+        }
     }
     if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = (tid < D) ? sh.fcur[tid] : 0.0f;
+    if (p.fs_out && tid < FS) {
+        float* fs = p.fs_out + (size_t)t * 3 * FS + tid;
+        fs[0] = (tid < D) ? sh.fcur[tid] : 0.0f;
+        fs[FS] = (tid < D) ? sh.mf[tid] : 0.0f;
+        fs[2 * FS] = (tid < D) ? sh.vf[tid] : 0.0f;
+    }
 }
 
 // gnnx_plan_analyze, every target with n <= SPL_N_MAX (also those of <= 512 rows that fit no resident class, e.g. more

@@ -55,6 +55,21 @@ class _Hyper(ctypes.Structure):
                 ("use_graph", ctypes.c_int32), ("use_resident", ctypes.c_int32)]
 
 
+class _Resume(ctypes.Structure):
+    _fields_ = [("first_iter", ctypes.c_int32), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("feat", ctypes.c_void_p),
+                ("m_out", ctypes.c_void_p), ("v_out", ctypes.c_void_p), ("feat_out", ctypes.c_void_p)]
+
+
+@dataclass
+class AdamState:
+    """Optimiser state of a batch (gnnx_resume, include/gnnx.h): what torch.optim.Adam keeps for ExplainModule's two
+    parameters (explain.py:622) after `first_iter` steps.  Device tensors in the packed layouts; None = zeros."""
+    first_iter: int = 0
+    m: Optional[torch.Tensor] = None       # [Q] exp_avg of the mask
+    v: Optional[torch.Tensor] = None       # [Q] exp_avg_sq
+    feat: Optional[torch.Tensor] = None    # [T, 3, 32]: feat_mask, exp_avg, exp_avg_sq
+
+
 @dataclass
 class Hyper:
     """Adam (utils/train_utils.py:9-10, torch defaults) + ExplainModule.coeffs (explain.py:624-631)."""
@@ -99,6 +114,8 @@ _API = {
     "gnnx_workspace_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
     "gnnx_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper)] + [ctypes.c_void_p] * 8 +
                  [ctypes.c_size_t, ctypes.c_void_p]),
+    "gnnx_run_resume": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper), ctypes.POINTER(_Resume)] + [ctypes.c_void_p] * 8 +
+                        [ctypes.c_size_t, ctypes.c_void_p]),
     "gnnx_plan_analyze": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "gnnx_get_route": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
     "gnnx_resident_times": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
@@ -555,18 +572,63 @@ class MaskOptimJob:
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
     # -- the hot loop --------------------------------------------------------------------------
-    def launch(self, hyper: Hyper):
-        """Enqueue the whole optimisation on the current stream (asynchronous)."""
+    def launch(self, hyper: Hyper, state: Optional[AdamState] = None, keep_state=False):
+        """Enqueue the whole optimisation on the current stream (asynchronous).  `state`: continue from an optimiser state
+        (gnnx_run_resume: self.M holds the mask after state.first_iter steps); `keep_state`: also hand the state after the run
+        back (self.state_out, an AdamState whose first_iter counts the steps taken so far)."""
         if hyper.record_loss and (self.loss is None or self.loss.shape[1] != hyper.num_iters):
             self.loss = torch.empty(self.T, hyper.num_iters, LOSS_TERMS, dtype=torch.float32, device=self.device)
         hy = hyper.c()
         loss_ptr = self.loss.data_ptr() if hyper.record_loss else None
+        rs = None
+        if state is not None or keep_state:
+            st = state if state is not None else AdamState()
+            ptr = lambda x: None if x is None else x.data_ptr()
+            rs = _Resume(int(st.first_iter), ptr(st.m), ptr(st.v), ptr(st.feat), None, None, None)
+            if keep_state:
+                f32 = dict(dtype=torch.float32, device=self.device)
+                out = AdamState(int(st.first_iter) + int(hyper.num_iters), torch.zeros(self.Q, **f32), torch.zeros(self.Q, **f32),
+                                torch.zeros(self.T, 3, FEAT_STRIDE, **f32))
+                rs.m_out, rs.v_out, rs.feat_out = out.m.data_ptr(), out.v.data_ptr(), out.feat.data_ptr()
+                self.state_out = out
+            self._state_keepalive = st
         self._enter()
-        _check(self.lib, self.lib.gnnx_run(self.handle, ctypes.byref(hy), self.A.data_ptr(), self.X.data_ptr(),
-                                           self.yhat.data_ptr(), self.M.data_ptr(), self.Abar.data_ptr(),
-                                           self.fmask.data_ptr(), loss_ptr, self.ws.data_ptr(), self.ws_bytes,
-                                           self._stream()))
+        _check(self.lib, self.lib.gnnx_run_resume(self.handle, ctypes.byref(hy), ctypes.byref(rs) if rs is not None else None,
+                                                  self.A.data_ptr(), self.X.data_ptr(), self.yhat.data_ptr(), self.M.data_ptr(),
+                                                  self.Abar.data_ptr(), self.fmask.data_ptr(), loss_ptr, self.ws.data_ptr(),
+                                                  self.ws_bytes, self._stream()))
         self._leave()
+
+    def set_state_edges(self, first_iter, mask_rc, m_rc, v_rc, feat=None, feat_m=None, feat_v=None) -> AdamState:
+        """Load an optimiser state given on the EDGES of the batch (the layout of fetch_edges: [E, 2] = entry (r, c), entry (c, r)
+        per upper-triangle edge; feat* [T, D]): the mask entries go into self.M (whose other entries keep what set_masks* put
+        there - they never reach an output), the moments into fresh packed arrays.  -> the AdamState for launch(state=...)."""
+        self._edge_layout()
+        E = int(self._eoff[-1])
+        dev = self.device
+        pos = self._epos[:E]
+        f32 = dict(dtype=torch.float32, device=dev)
+        to = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
+        st = AdamState(int(first_iter), torch.zeros(self.Q, **f32), torch.zeros(self.Q, **f32), torch.zeros(self.T, 3, FEAT_STRIDE, **f32))
+        for dst, src in ((self.M, mask_rc), (st.m, m_rc), (st.v, v_rc)):
+            if src is None or E == 0:
+                continue
+            src = to(src)
+            dst.index_put_((pos[:, 0],), src[:, 0])
+            dst.index_put_((pos[:, 1],), src[:, 1])
+        for k, src in enumerate((feat, feat_m, feat_v)):
+            if src is not None:
+                st.feat[:, k, :self.D] = to(src)
+        return st
+
+    def fetch_state_edges(self):
+        """The optimiser state after a launch(keep_state=True) on the edges of the batch: (mask_rc, m_rc, v_rc [E, 2], feat [T, 3, D])."""
+        self._edge_layout()
+        E = int(self._eoff[-1])
+        pos = self._epos[:E]
+        g = lambda a: torch.stack([a[pos[:, 0]], a[pos[:, 1]]], 1).cpu().numpy()
+        st = self.state_out
+        return g(self.M), g(st.m), g(st.v), st.feat[:, :, :self.D].cpu().numpy()
 
     def fetch(self, hyper: Hyper) -> JobResult:
         if self.device.type == _DEVICE_TYPE:

@@ -97,6 +97,30 @@ int gnnx_run(gnnx_handle h, const gnnx_hyper* hyper, const float* A, const float
              float* M, float* Abar, float* feat_mask, float* loss, void* workspace, size_t workspace_bytes,
              void* stream);
 
+/* Checkpoint / resume of the optimiser (and the hook of the windowed parity tests): the state torch.optim.Adam keeps for the
+ * two parameters of ExplainModule (explain.py:622; utils/train_utils.py:9-10) - `exp_avg`, `exp_avg_sq` and the step count.
+ * gnnx_run_resume(h, hyper, r, ...) == gnnx_run(...) started from that state: iteration k of the call applies Adam step
+ * first_iter + k + 1 (bias corrections 1 - beta^(first_iter + k + 1)), M (in/out) holds the mask after first_iter steps.
+ *   first_iter : steps already taken (0 with all-NULL inputs == gnnx_run)
+ *   m, v       : DEVICE, packed square layout like M: exp_avg / exp_avg_sq of the mask, or NULL = zeros
+ *   feat       : DEVICE [T][3][32]: feat_mask, its exp_avg, its exp_avg_sq (columns >= D ignored), or NULL = zeros
+ *   m_out, v_out, feat_out : optional DEVICE outputs in the same layouts = the state after the call.  On the edge-sparse routes
+ *                (gnnx_get_route 4..8) only the entries on edges of the sub-graph are written (the only live ones: the
+ *                others never reach an output, explain.py:665-678), so zero-fill m_out / v_out first if the rest is read.
+ * m_out / v_out must not alias m / v unless they are the same pointer (in-place continuation is allowed). */
+typedef struct {
+    int32_t first_iter;
+    const float* m;
+    const float* v;
+    const float* feat;
+    float* m_out;
+    float* v_out;
+    float* feat_out;
+} gnnx_resume;
+int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hyper, const gnnx_resume* resume, const float* A, const float* X,
+                    const float* yhat, float* M, float* Abar, float* feat_mask, float* loss, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
 /* Inspect the packed adjacency A (DEVICE pointer, the layout of gnnx_get_layout) and choose the kernel of every target:
  * targets whose EDGE state fits a compute unit (n <= 512, <= 2048 undirected edges, rows of <= 256 entries, LDS
  * budget; node and graph mode) take the sparse on-chip-resident kernel in the smallest of its three size classes

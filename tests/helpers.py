@@ -123,3 +123,89 @@ def parity_verdict(err, ferr, well, min_frac=0.99, jump_max=None):
     ok = frac >= min_frac and worst <= jump_max
     return ok, (f"{inside} / {len(e)} non-chaotic targets within 1e-5 of an outcome of the reference ({100 * frac:.1f} %, need "
                 f"{100 * min_frac:.0f} %), worst {worst:.2e} (limit {jump_max:.0e})")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Windowed ("teacher-forced") parity: tests/golden/<name>_windows.npz (make_golden_windows.py) holds the optimiser state of the
+# live reference every 50 epochs on every target (and every 10 epochs inside the windows two CPU implementations already
+# disagree on).  An implementation is started from the reference's state at a boundary and compared with the reference's
+# state at the next one: round-off has 50 (10) iterations to act, not 300.
+# ---------------------------------------------------------------------------------------------------------------------------
+WIN_TOL = 1e-5           # masked adjacency (from the mask entries of both directions) and sigmoid(feat_mask) at the end of a window
+WIN_FLAG = 2e-6          # CPU-vs-CPU deviation inside a window above which it is "flagged" (decided by make_golden_windows.py)
+
+
+def _sig64(x):
+    return 1.0 / (1.0 + np.exp(-np.asarray(x, np.float64)))
+
+
+def abar_from_mask_rc(mask_rc):
+    """masked adjacency on unit-weight edges from the two directed mask entries [E, 2] (explain.py:665-678), float64."""
+    return 0.5 * (_sig64(mask_rc[:, 0]) + _sig64(mask_rc[:, 1]))
+
+
+class Windows:
+    """Accessors of a <name>_windows.npz fixture.  Boundary b = 0..6 is the state after 50 b steps (b = 0: the seeded initial
+    mask with zero moments - not stored, None)."""
+
+    def __init__(self, name):
+        self.z = z = np.load(os.path.join(GOLDEN, name + "_windows.npz"))
+        self.ids = z["targets"] if "targets" in z.files else z["graphs"]
+        self.eoff = z["eoff"]
+        self.T, self.W = z["cond50"].shape
+        self.win = int(z["epochs"][0])
+        self.sub = int(z["sub"])
+        self.nsub = self.win // self.sub
+        self.flagged = z["cond50"] > WIN_FLAG                       # [T, W]
+        self.fine_row = {(int(k), int(w)): i for i, (k, w) in enumerate(z["fine_tw"])}
+
+    def edge_index(self, ks):
+        """indices into the fixture's edge arrays of the targets ks, concatenated in that order"""
+        parts = [np.arange(self.eoff[k], self.eoff[k + 1]) for k in ks]
+        return np.concatenate(parts) if parts else np.zeros(0, np.int64)
+
+    def boundary(self, b, ks):
+        """state after 50 b steps of the targets ks: (first_iter, M, m, v [E', 2], f, mf, vf [T', D]) or None for b = 0"""
+        if b == 0:
+            return None
+        z, e = self.z, self.edge_index(ks)
+        return (self.win * b, z["M"][b - 1][e], z["m"][b - 1][e], z["v"][b - 1][e], z["f"][b - 1][ks], z["mf"][b - 1][ks], z["vf"][b - 1][ks])
+
+    def fine(self, w, s, ks):
+        """state after 50 w + 10 s steps (s = 1..4) of targets ks whose window w is flagged"""
+        z = self.z
+        rows = [self.fine_row[(int(k), int(w))] for k in ks]
+        e = np.concatenate([np.arange(z["fine_off"][i], z["fine_off"][i + 1]) for i in rows]) if rows else np.zeros(0, np.int64)
+        return (self.win * w + self.sub * s, z["fine_M"][s - 1][e], z["fine_m"][s - 1][e], z["fine_v"][s - 1][e],
+                z["fine_f"][s - 1][rows], z["fine_mf"][s - 1][rows], z["fine_vf"][s - 1][rows])
+
+    def sub_state(self, w, s, ks):
+        """state at the start (s = 0..4) or end (s = 5) of 10-epoch sub-window s of window w"""
+        if s == 0:
+            return self.boundary(w, ks)
+        if s == self.nsub:
+            return self.boundary(w + 1, ks)
+        return self.fine(w, s, ks)
+
+    def cond10(self, w, ks):
+        return np.stack([self.z["cond10"][self.fine_row[(int(k), int(w))]] for k in ks]) if len(ks) else np.zeros((0, self.nsub))
+
+
+def run_window(job, start, iters):
+    """Start `job` (its M holding the seeded initial masks) from a fixture state (Windows.boundary / .fine; None = the initial
+    state) and run `iters` iterations.  -> (mask_rc [E, 2], feat_mask [T, D]) after them."""
+    from gnn_model_explainer_amd.engine import Hyper
+    st = None
+    if start is not None:
+        st = job.set_state_edges(*start)
+    job.launch(Hyper(num_iters=int(iters)), state=st, keep_state=True)
+    mask_rc, _, _, fs = job.fetch_state_edges()
+    return mask_rc, fs[:, 0, :]
+
+
+def window_errors(eoff, mask_rc, feat, want):
+    """per target: (|masked adjacency - reference's|_max on its edges, |sigmoid(feat_mask) - reference's|_max)"""
+    d = np.abs(abar_from_mask_rc(mask_rc) - abar_from_mask_rc(want[1]))
+    em = np.asarray([d[a:b].max() if b > a else 0.0 for a, b in zip(eoff[:-1], eoff[1:])])
+    ef = np.abs(_sig64(feat) - _sig64(want[4])).max(1)
+    return em, ef

@@ -356,6 +356,17 @@ def test_large_target_more_than_512_row_slots(be):
     assert np.array_equal(res.mask[0][~live], m0[~live])
 
 
+def _hub_case():
+    """A k_sparse_large target with far edges (used by tests/test_windowed_parity.py): (state_dict, [Subgraph])."""
+    rng = np.random.default_rng(17)
+    sd = helpers.random_model(rng, 10, 20, 20, 4)
+    n = 900
+    A, X = helpers.random_graph(rng, n, 10, density=2.4 / n)
+    t = int(np.argmax(A.sum(1)))
+    m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
+    return sd, [Subgraph(A, X, 1, t, rng.integers(0, 4, n), m0)]
+
+
 def test_large_target_far_edges_run_their_own_recursion(be):
     """A sparse graph of large diameter (n = 900, average degree 2.4): most edges have both endpoints more than two hops
     from the target, never see a prediction gradient and are optimised by k_sparse_large outside its iteration loop (a
