@@ -436,10 +436,11 @@ static Params make_params(gnnx_handle h, const gnnx_hyper* hy, const float* A, c
     p.graph_mode = h->prob.graph_mode;
     if (hy) {
         p.num_iters = hy->num_iters;
-        p.lr = hy->lr;
-        p.beta1 = hy->beta1;
-        p.beta2 = hy->beta2;
-        p.eps = hy->eps;
+        p.lr = (float)hy->lr;
+        p.beta2 = (float)hy->beta2;
+        p.omb1 = (float)(1.0 - hy->beta1);
+        p.omb2 = (float)(1.0 - hy->beta2);
+        p.eps = (float)hy->eps;
         p.c_size = hy->c_size;
         p.c_feat_size = hy->c_feat_size;
         p.c_ent = hy->c_ent;
@@ -449,9 +450,9 @@ static Params make_params(gnnx_handle h, const gnnx_hyper* hy, const float* A, c
 }
 
 static void adam_scalars(const gnnx_hyper* hy, int it, float* step_size, float* bc2s) {
-    const double b1 = 1.0 - std::pow((double)hy->beta1, (double)(it + 1));
-    const double b2 = 1.0 - std::pow((double)hy->beta2, (double)(it + 1));
-    *step_size = (float)((double)hy->lr / b1);
+    const double b1 = 1.0 - std::pow(hy->beta1, (double)(it + 1));
+    const double b2 = 1.0 - std::pow(hy->beta2, (double)(it + 1));
+    *step_size = (float)(hy->lr / b1);
     *bc2s = (float)std::sqrt(b2);
 }
 

@@ -98,7 +98,8 @@ struct Params {
     int32_t D, H, O, C;
     int32_t graph_mode;
     int32_t num_iters;
-    float lr, beta1, beta2, eps;
+    float lr, beta2, eps;
+    float omb1, omb2;   // (float)(1 - beta1), (float)(1 - beta2) with the subtraction in DOUBLE, as torch passes them to lerp_ / addcmul_
     float c_size, c_feat_size, c_ent, c_lap;
 };
 
@@ -114,12 +115,17 @@ __device__ __forceinline__ float sigmoidf_(float x) { return rcp_(1.0f + __expf(
 // row of the 32x32 MFMA accumulator held in register r of a lane in half h (lane>>5); column = lane&31
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// torch.optim.Adam, single-tensor form; step_size = lr/(1-beta1^k), bc2s = sqrt(1-beta2^k) from the host
-// inv_bc2s = 1 / sqrt(1 - beta2^k)
-__device__ __forceinline__ void adam_update(float& theta, float& m, float& v, float g, float beta1, float beta2,
+// torch.optim.Adam, single-tensor form (torch/optim/adam.py _single_tensor_adam, what utils/train_utils.py:9-10 builds):
+//   exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2);
+//   denom = (exp_avg_sq.sqrt() / sqrt(1 - beta2^k)).add_(eps); param.addcdiv_(exp_avg, denom, value=-lr / (1 - beta1^k))
+// The scalars are Python floats (doubles) there and reach the fp32 kernels as (float)(double expression): omb1 = (float)(1 - 0.9),
+// omb2 = (float)(1 - 0.999) - NOT 1.0f - (float)0.999, which is 1.3e-5 smaller and made every step 6e-6 too long (found by the
+// windowed parity test against the reference's own optimiser state, tests/test_windowed_parity.py).
+// step_size = lr / (1 - beta1^k), inv_bc2s = 1 / sqrt(1 - beta2^k), both evaluated in double on the host.
+__device__ __forceinline__ void adam_update(float& theta, float& m, float& v, float g, float omb1, float beta2, float omb2,
                                             float eps, float step_size, float inv_bc2s) {
-    m = m + (g - m) * (1.0f - beta1);
-    v = v * beta2 + (1.0f - beta2) * g * g;
+    m = m + (g - m) * omb1;
+    v = v * beta2 + omb2 * g * g;
     theta = theta - step_size * (m * rcp_(__builtin_amdgcn_sqrtf(v) * inv_bc2s + eps));
 }
 
@@ -893,7 +899,7 @@ __global__ __launch_bounds__(256, 4) void k_mask(Params p, const MaskTile* tiles
                 // d(entropy)/dS = log(1-S) - log(S) = -M exactly (S = sigma(M)): no logs on the update path
                 float gji = (gc + p.c_size + p.c_ent * mask_dent<RELU>(Mji, Sji) * inv_n2) * mask_dact<RELU>(Mji, Sji);
                 if (RELU && !(gi < n && gj < n)) gji = 0.0f;  // padding entries (M = 0) do not exist in the reference: relu'(0) * log(0) is NaN
-                adam_update(Mji, mji, vji, gji, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+                adam_update(Mji, mji, vji, gji, p.omb1, p.beta2, p.omb2, p.eps, step_size, inv_bc2s);
                 sPM[j * LS + i] = Mji;
                 sPm[j * LS + i] = mji;
                 sPv[j * LS + i] = vji;
@@ -915,7 +921,7 @@ __global__ __launch_bounds__(256, 4) void k_mask(Params p, const MaskTile* tiles
             float gij = (gc + p.c_size + p.c_ent * mask_dent<RELU>(Mij, Sij) * inv_n2) * mask_dact<RELU>(Mij, Sij);
             if (RELU && !(gi < n && gj < n)) gij = 0.0f;
             float mij = mo[e], vij = vo[e];
-            adam_update(Mij, mij, vij, gij, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+            adam_update(Mij, mij, vij, gij, p.omb1, p.beta2, p.omb2, p.eps, step_size, inv_bc2s);
             Mo[e] = Mij;
             mo[e] = mij;
             vo[e] = vij;
@@ -988,7 +994,7 @@ __global__ __launch_bounds__(256, 4) void k_mask(Params p, const MaskTile* tiles
         for (int rb = 0; rb < (ld >> 5); ++rb) dsum += p.df[((size_t)(tm.offR >> 5) + rb) * FS + tid];
         const float gf = (dsum + p.c_feat_size / (float)p.D) * ph * (1.0f - ph);
         float fnew = fcur, m = p.mf[o], v = p.vf[o];
-        adam_update(fnew, m, v, gf, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+        adam_update(fnew, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, inv_bc2s);
         p.mf[o] = m;
         p.vf[o] = v;
         p.f[(iter + 1) & 1][o] = fnew;

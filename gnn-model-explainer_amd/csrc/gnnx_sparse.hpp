@@ -1195,12 +1195,12 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 {
                     const float S = Sij[q];
                     const float g = (gc + p.c_size - p.c_ent * Mij[q] * inv_n2) * S * (1.0f - S);
-                    adam_update(Mij[q], mij[q], vij[q], g, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+                    adam_update(Mij[q], mij[q], vij[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, inv_bc2s);
                 }
                 {
                     const float S = Sji[q];
                     const float g = (gc + p.c_size - p.c_ent * Mji[q] * inv_n2) * S * (1.0f - S);
-                    adam_update(Mji[q], mji[q], vji[q], g, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+                    adam_update(Mji[q], mji[q], vji[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, inv_bc2s);
                 }
             }
         SYNC();  // dfp complete; every reader of sAb / sArt of this iteration is done
@@ -1208,7 +1208,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             const float ph = sh.phi[tid];
             const float gf = (sh.dfp[tid] + p.c_feat_size / (float)D) * ph * (1.0f - ph);
             float fn = sh.fcur[tid], m = sh.mf[tid], v = sh.vf[tid];
-            adam_update(fn, m, v, gf, p.beta1, p.beta2, p.eps, step_size, inv_bc2s);
+            adam_update(fn, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, inv_bc2s);
             sh.fcur[tid] = fn;
             sh.mf[tid] = m;
             sh.vf[tid] = v;

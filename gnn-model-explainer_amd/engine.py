@@ -49,7 +49,7 @@ class _Model(ctypes.Structure):
 
 
 class _Hyper(ctypes.Structure):
-    _fields_ = [("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
+    _fields_ = [("lr", ctypes.c_double), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double),
                 ("c_size", ctypes.c_float), ("c_feat_size", ctypes.c_float), ("c_ent", ctypes.c_float),
                 ("c_lap", ctypes.c_float), ("num_iters", ctypes.c_int32), ("record_loss", ctypes.c_int32),
                 ("use_graph", ctypes.c_int32), ("use_resident", ctypes.c_int32)]

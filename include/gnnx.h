@@ -60,7 +60,9 @@ typedef struct {
 /* Optimiser + regulariser constants: Adam of utils/train_utils.py:9-10 (torch defaults) and
  * ExplainModule.coeffs (explain.py:624-631). */
 typedef struct {
-    float lr, beta1, beta2, eps;
+    double lr, beta1, beta2, eps; /* DOUBLES, like the Python floats torch.optim.Adam holds: its bias corrections 1 - beta^k and the
+                                   * lerp / addcmul weights 1 - beta are evaluated in double and only then rounded to fp32
+                                   * ((float)(1 - 0.999) != 1.0f - 0.999f by 1.3e-5) */
     float c_size, c_feat_size, c_ent, c_lap;
     int32_t num_iters;   /* args.num_epochs (explain.py:137) */
     int32_t record_loss; /* 1: fill loss[T][num_iters][GNNX_LOSS_TERMS] (explain.py:808-819 scalars) */
