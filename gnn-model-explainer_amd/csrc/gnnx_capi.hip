@@ -13,6 +13,8 @@
 #include <mutex>
 #include <vector>
 
+constexpr int MAX_DEVICES_POOL = 16;
+
 #include "../../include/gnnx.h"
 #include "gnnx_kernels.hpp"
 #include "gnnx_resident.hpp"
@@ -33,6 +35,106 @@ static int fail(const std::string& m) {
         if (e_ != hipSuccess)                                                                      \
             return fail(std::string(#x) + ": " + hipGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
     } while (0)
+
+// ---- device-memory pool for the library's own tables ----------------------------------------------------------------------
+// A plan owns a dozen small device tables (tile tables, target meta, id lists, the CSR of the large-class targets, the Adam
+// scalar table).  hipFree synchronises the whole device and hipMalloc takes the driver's allocation lock: with one plan per
+// batch both sat on the critical path of a pipelined job (the next batch's plan is built while the previous batch's loop is
+// running - a hipFree there waits for that loop).  Blocks are therefore recycled: size classes of powers of two (8 MB steps
+// above 64 MB), per device, never returned to the driver before gnnx_pool_trim().  A block handed back by gnnx_destroy must
+// not be in use by work still in flight - the same contract hipFree imposed by synchronising.
+#include <map>
+#include <unordered_map>
+namespace {
+struct DevPool {
+    std::mutex mu;
+    std::unordered_map<void*, size_t> bucket_of;          // every block this pool ever allocated -> its size class
+    std::map<size_t, std::vector<void*>> free_blocks;     // size class -> idle blocks
+    size_t cached_bytes = 0;
+};
+DevPool g_pool[MAX_DEVICES_POOL];
+inline size_t pool_bucket(size_t bytes) {
+    if (bytes <= 256) return 256;
+    if (bytes > (size_t(64) << 20)) return (bytes + (size_t(8) << 20) - 1) / (size_t(8) << 20) * (size_t(8) << 20);
+    size_t b = 256;
+    while (b < bytes) b <<= 1;
+    return b;
+}
+inline DevPool& pool_here() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES_POOL) dev = 0;
+    return g_pool[dev];
+}
+}  // namespace
+template <class T>
+static hipError_t pool_malloc(T** out, size_t bytes) {
+    DevPool& P = pool_here();
+    const size_t b = pool_bucket(bytes);
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.free_blocks.find(b);
+        if (it != P.free_blocks.end() && !it->second.empty()) {
+            *out = static_cast<T*>(it->second.back());
+            it->second.pop_back();
+            P.cached_bytes -= b;
+            return hipSuccess;
+        }
+    }
+    void* ptr = nullptr;
+    hipError_t e = hipMalloc(&ptr, b);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        P.bucket_of[ptr] = b;
+    }
+    *out = static_cast<T*>(ptr);
+    return hipSuccess;
+}
+static hipError_t pool_free(void* ptr) {
+    if (!ptr) return hipSuccess;
+    DevPool& P = pool_here();
+    std::lock_guard<std::mutex> lk(P.mu);
+    auto it = P.bucket_of.find(ptr);
+    if (it == P.bucket_of.end()) return hipFree(ptr);   // not ours (cannot happen; stay correct)
+    P.free_blocks[it->second].push_back(ptr);
+    P.cached_bytes += it->second;
+    return hipSuccess;
+}
+extern "C" int gnnx_pool_trim(void) {
+    DevPool& P = pool_here();
+    std::lock_guard<std::mutex> lk(P.mu);
+    for (auto& kv : P.free_blocks) {
+        for (void* ptr : kv.second) {
+            (void)hipFree(ptr);
+            P.bucket_of.erase(ptr);
+        }
+        kv.second.clear();
+    }
+    P.cached_bytes = 0;
+    return 0;
+}
+
+// ---- table uploads ---------------------------------------------------------------------------------------------------------
+// A synchronous hipMemcpy runs on the null stream, whose hardware queue may be the one a 4 ms optimisation launch occupies: the
+// upload of the next batch's tile tables then waits for it.  The calling thread can name the stream its plan-building uploads go
+// to (gnnx_set_service_stream: the prepare stream of pipeline.BatchPipeline); default = the null stream as before.
+static thread_local hipStream_t g_service_stream = nullptr;
+extern "C" int gnnx_set_service_stream(void* stream) {
+    g_service_stream = static_cast<hipStream_t>(stream);
+    return 0;
+}
+static hipError_t upload_sync(void* dst, const void* src, size_t bytes) {
+    if (!g_service_stream) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_service_stream);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(g_service_stream);   // the sources are host temporaries
+}
+
+// measurement / calibration hooks: keep a stream busy for `micros` microseconds; the launch lanes as hipStream_t
+__global__ void k_spin(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
 
 static_assert(GNNX_FEAT_STRIDE == FS && GNNX_MAX_CLASSES == CMAX && GNNX_LOSS_TERMS == NLOSS, "header mismatch");
 
@@ -63,6 +165,15 @@ static hipStream_t lane_stream(int i) {
     hipStream_t& st = g_lane[dev][i % N_LANES];
     if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
     return st;
+}
+extern "C" void* gnnx_lane_stream(int32_t i) { return (i >= 0 && i < N_LANES) ? (void*)lane_stream(i) : nullptr; }
+extern "C" int gnnx_debug_spin(void* stream, int32_t micros) {
+    int rate_khz = 100000;   // wall_clock64 ticks at 100 MHz on gfx950
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev);
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), (long long)micros * rate_khz / 1000);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 constexpr int CAT_SPARSE = RES_NBMAX + 1;      // CAT_SPARSE + k: sparse resident kernel of size class k
 
@@ -131,7 +242,7 @@ static int build_split(gnnx_handle h) {
     }
     for (void* ptr : {(void*)h->d_res, (void*)h->d_sp[0], (void*)h->d_sp[1], (void*)h->d_sp[2], (void*)h->d_sp[3], (void*)h->d_sp[4],
                       (void*)h->d_big, (void*)h->d_conv_big, (void*)h->d_mask_big})
-        if (ptr) (void)hipFree(ptr);
+        if (ptr) (void)pool_free(ptr);
     h->d_res = h->d_big = nullptr;
     for (int k = 0; k < N_SPC; ++k) h->d_sp[k] = nullptr;
     h->d_conv_big = nullptr;
@@ -162,9 +273,9 @@ static int build_split(gnnx_handle h) {
     auto upload = [&](auto*& dst, const auto& v) -> hipError_t {
         using E = typename std::remove_reference<decltype(v)>::type::value_type;
         if (v.empty()) return hipSuccess;
-        hipError_t e = hipMalloc(&dst, sizeof(E) * v.size());
+        hipError_t e = pool_malloc(&dst, sizeof(E) * v.size());
         if (e != hipSuccess) return e;
-        return hipMemcpy(dst, v.data(), sizeof(E) * v.size(), hipMemcpyHostToDevice);
+        return upload_sync(dst, v.data(), sizeof(E) * v.size());
     };
     SPLITCK(upload(h->d_res, res_ids));
     for (int k = 0; k < N_SPC; ++k) SPLITCK(upload(h->d_sp[k], sp_ids[k]));
@@ -283,22 +394,22 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
             return fail(std::string(#x) + ": " + hipGetErrorString(e_));                               \
         }                                                                                              \
     } while (0)
-    PLANCK(hipMalloc(&h->d_meta, sizeof(TargetMeta) * T));
-    PLANCK(hipMalloc(&h->d_conv, sizeof(ConvTile) * conv.size()));
-    PLANCK(hipMalloc(&h->d_mask, sizeof(MaskTile) * mask.size()));
-    PLANCK(hipMalloc(&h->d_wts, sizeof(float) * WT_TOTAL));
-    PLANCK(hipMemcpy(h->d_meta, h->meta.data(), sizeof(TargetMeta) * T, hipMemcpyHostToDevice));
-    PLANCK(hipMemcpy(h->d_conv, conv.data(), sizeof(ConvTile) * conv.size(), hipMemcpyHostToDevice));
-    PLANCK(hipMemcpy(h->d_mask, mask.data(), sizeof(MaskTile) * mask.size(), hipMemcpyHostToDevice));
-    PLANCK(hipMemcpy(h->d_wts, w.data(), sizeof(float) * WT_TOTAL, hipMemcpyHostToDevice));
+    PLANCK(pool_malloc(&h->d_meta, sizeof(TargetMeta) * T));
+    PLANCK(pool_malloc(&h->d_conv, sizeof(ConvTile) * conv.size()));
+    PLANCK(pool_malloc(&h->d_mask, sizeof(MaskTile) * mask.size()));
+    PLANCK(pool_malloc(&h->d_wts, sizeof(float) * WT_TOTAL));
+    PLANCK(upload_sync(h->d_meta, h->meta.data(), sizeof(TargetMeta) * T));
+    PLANCK(upload_sync(h->d_conv, conv.data(), sizeof(ConvTile) * conv.size()));
+    PLANCK(upload_sync(h->d_mask, mask.data(), sizeof(MaskTile) * mask.size()));
+    PLANCK(upload_sync(h->d_wts, w.data(), sizeof(float) * WT_TOTAL));
     {
         std::vector<int64_t> ro(T);
         for (int t = 0; t < T; ++t) {
             ro[t] = h->total_raw;
             h->total_raw += (int64_t)h->meta[t].n * h->meta[t].n;
         }
-        PLANCK(hipMalloc(&h->d_raw_off, sizeof(int64_t) * T));
-        PLANCK(hipMemcpy(h->d_raw_off, ro.data(), sizeof(int64_t) * T, hipMemcpyHostToDevice));
+        PLANCK(pool_malloc(&h->d_raw_off, sizeof(int64_t) * T));
+        PLANCK(upload_sync(h->d_raw_off, ro.data(), sizeof(int64_t) * T));
     }
 #undef PLANCK
     if (int rc = build_split(h)) {
@@ -348,30 +459,30 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
 extern "C" int gnnx_destroy(gnnx_handle h) {
     if (!h) return 0;
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
-    if (h->d_meta) (void)hipFree(h->d_meta);
+    if (h->d_meta) (void)pool_free(h->d_meta);
     for (int k = 0; k < N_SIDE; ++k) {
         if (h->ev_out[k]) (void)hipEventDestroy(h->ev_out[k]);
         if (h->ev_t0[k]) (void)hipEventDestroy(h->ev_t0[k]);
     }
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
-    if (h->d_res) (void)hipFree(h->d_res);
+    if (h->d_res) (void)pool_free(h->d_res);
     for (int k = 0; k < N_SPC; ++k)
-        if (h->d_sp[k]) (void)hipFree(h->d_sp[k]);
-    if (h->d_nnz) (void)hipFree(h->d_nnz);
-    if (h->d_rowdeg) (void)hipFree(h->d_rowdeg);
-    if (h->d_csr_rowptr) (void)hipFree(h->d_csr_rowptr);
-    if (h->d_csr_col) (void)hipFree(h->d_csr_col);
-    if (h->d_csr_row) (void)hipFree(h->d_csr_row);
-    if (h->d_csr_off) (void)hipFree(h->d_csr_off);
-    if (h->d_adam) (void)hipFree(h->d_adam);
-    if (h->d_raw_off) (void)hipFree(h->d_raw_off);
-    if (h->d_rowcnt) (void)hipFree(h->d_rowcnt);
-    if (h->d_big) (void)hipFree(h->d_big);
-    if (h->d_conv_big) (void)hipFree(h->d_conv_big);
-    if (h->d_mask_big) (void)hipFree(h->d_mask_big);
-    if (h->d_conv) (void)hipFree(h->d_conv);
-    if (h->d_mask) (void)hipFree(h->d_mask);
-    if (h->d_wts) (void)hipFree(h->d_wts);
+        if (h->d_sp[k]) (void)pool_free(h->d_sp[k]);
+    if (h->d_nnz) (void)pool_free(h->d_nnz);
+    if (h->d_rowdeg) (void)pool_free(h->d_rowdeg);
+    if (h->d_csr_rowptr) (void)pool_free(h->d_csr_rowptr);
+    if (h->d_csr_col) (void)pool_free(h->d_csr_col);
+    if (h->d_csr_row) (void)pool_free(h->d_csr_row);
+    if (h->d_csr_off) (void)pool_free(h->d_csr_off);
+    if (h->d_adam) (void)pool_free(h->d_adam);
+    if (h->d_raw_off) (void)pool_free(h->d_raw_off);
+    if (h->d_rowcnt) (void)pool_free(h->d_rowcnt);
+    if (h->d_big) (void)pool_free(h->d_big);
+    if (h->d_conv_big) (void)pool_free(h->d_conv_big);
+    if (h->d_mask_big) (void)pool_free(h->d_mask_big);
+    if (h->d_conv) (void)pool_free(h->d_conv);
+    if (h->d_mask) (void)pool_free(h->d_mask);
+    if (h->d_wts) (void)pool_free(h->d_wts);
     delete h;
     return 0;
 }
@@ -628,13 +739,15 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
     if (resident) {
         HIPCK(hipEventRecord(h->ev_in, s));
         if (!h->d_adam || h->adam_first != rs.first_iter || std::memcmp(&h->adam_for, hy, sizeof(gnnx_hyper)) != 0) {
-            // (a table still read by an earlier launch must not be freed under it: hipFree synchronises the device)
-            if (h->d_adam) (void)hipFree(h->d_adam);
+            if (h->d_adam) {
+                HIPCK(hipStreamSynchronize(s));   // an earlier run of this plan may still be reading the table (its side lanes join `s`)
+                (void)pool_free(h->d_adam);
+            }
             h->adam_host.resize(2 * (size_t)hy->num_iters);
             for (int it = 0; it < hy->num_iters; ++it)
                 adam_scalars(hy, rs.first_iter + it, &h->adam_host[2 * it], &h->adam_host[2 * it + 1]);
-            HIPCK(hipMalloc(&h->d_adam, sizeof(float) * h->adam_host.size()));
-            HIPCK(hipMemcpy(h->d_adam, h->adam_host.data(), sizeof(float) * h->adam_host.size(), hipMemcpyHostToDevice));
+            HIPCK(pool_malloc(&h->d_adam, sizeof(float) * h->adam_host.size()));
+            HIPCK(upload_sync(h->d_adam, h->adam_host.data(), sizeof(float) * h->adam_host.size()));
             h->adam_for = *hy;
             h->adam_first = rs.first_iter;
         }
@@ -754,12 +867,12 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
     if (!h || !A) return fail("null argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int T = h->prob.num_targets;
-    if (!h->d_nnz) HIPCK(hipMalloc(&h->d_nnz, sizeof(int32_t) * (2 + SPL_COUNTS) * T));
+    if (!h->d_nnz) HIPCK(pool_malloc(&h->d_nnz, sizeof(int32_t) * (2 + SPL_COUNTS) * T));
     hipLaunchKernelGGL(k_count_edges, dim3(T), dim3(256), 0, s, h->d_meta, A, h->d_nnz);
     if (!h->prob.graph_mode) {
         int nmax = 0;
         for (int t = 0; t < T; ++t) nmax = std::max(nmax, h->meta[t].n);
-        if (!h->d_rowdeg) HIPCK(hipMalloc(&h->d_rowdeg, sizeof(int32_t) * (size_t)h->R));
+        if (!h->d_rowdeg) HIPCK(pool_malloc(&h->d_rowdeg, sizeof(int32_t) * (size_t)h->R));
         hipLaunchKernelGGL(k_row_degrees, dim3(h->n_conv), dim3(256), 0, s, A, h->d_conv, h->d_rowdeg);
         hipLaunchKernelGGL((k_count_edges_large<0, 4095>), dim3(T), dim3(1024), 0, s, h->d_meta, A, h->d_rowdeg, h->d_nnz + 2 * T);
         if (nmax > 4095)
@@ -886,16 +999,16 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
                 cl += (h->nnz[2 * (size_t)T + SPL_COUNTS * (size_t)t] + 1) & ~1;
             }
         for (void* ptr : {(void*)h->d_csr_rowptr, (void*)h->d_csr_col, (void*)h->d_csr_row, (void*)h->d_csr_off})
-            if (ptr) (void)hipFree(ptr);
+            if (ptr) (void)pool_free(ptr);
         h->d_csr_rowptr = nullptr;
         h->d_csr_col = nullptr;
         h->d_csr_row = nullptr;
         h->d_csr_off = nullptr;
-        HIPCK(hipMalloc(&h->d_csr_rowptr, sizeof(int32_t) * (size_t)rp));
-        HIPCK(hipMalloc(&h->d_csr_col, sizeof(unsigned short) * (size_t)std::max<long long>(cl, 2)));
-        HIPCK(hipMalloc(&h->d_csr_row, sizeof(unsigned short) * (size_t)std::max<long long>(cl, 2)));
-        HIPCK(hipMalloc(&h->d_csr_off, sizeof(long long) * off.size()));
-        HIPCK(hipMemcpy(h->d_csr_off, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice));
+        HIPCK(pool_malloc(&h->d_csr_rowptr, sizeof(int32_t) * (size_t)rp));
+        HIPCK(pool_malloc(&h->d_csr_col, sizeof(unsigned short) * (size_t)std::max<long long>(cl, 2)));
+        HIPCK(pool_malloc(&h->d_csr_row, sizeof(unsigned short) * (size_t)std::max<long long>(cl, 2)));
+        HIPCK(pool_malloc(&h->d_csr_off, sizeof(long long) * off.size()));
+        HIPCK(upload_sync(h->d_csr_off, off.data(), sizeof(long long) * off.size()));
         hipLaunchKernelGGL(k_csr_rowptr_large, dim3(h->n_sp[SPC_LARGE]), dim3(1024), 0, s, h->d_meta, h->d_rowdeg, h->d_sp[SPC_LARGE],
                            h->d_csr_off, h->d_csr_rowptr);
         hipLaunchKernelGGL(k_csr_emit_large, dim3(h->n_conv), dim3(256), 0, s, A, h->d_conv, h->d_csr_off, h->d_csr_rowptr, h->d_csr_col,
@@ -973,7 +1086,7 @@ extern "C" int gnnx_edge_counts(gnnx_handle h, const float* A, int64_t* counts, 
     // scratch for the row counts: the tail of the plan's own device tables would do, but the counts are needed before the caller
     // has a workspace only in theory - every caller has one by now; keep the ABI: a private scratch per plan
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!h->d_rowcnt) HIPCK(hipMalloc(&h->d_rowcnt, sizeof(int32_t) * (size_t)h->R));
+    if (!h->d_rowcnt) HIPCK(pool_malloc(&h->d_rowcnt, sizeof(int32_t) * (size_t)h->R));
     edge_rows(h, A, h->d_rowcnt, counts, s);
     HIPCK(hipGetLastError());
     return 0;
@@ -1105,8 +1218,8 @@ extern "C" int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hy, int32_t kin
         std::vector<float> tab(2 * (size_t)hy->num_iters);
         for (int it = 0; it < hy->num_iters; ++it) adam_scalars(hy, it, &tab[2 * it], &tab[2 * it + 1]);
         float* d_tab = nullptr;
-        HIPCK(hipMalloc(&d_tab, sizeof(float) * tab.size()));
-        HIPCK(hipMemcpy(d_tab, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice));
+        HIPCK(pool_malloc(&d_tab, sizeof(float) * tab.size()));
+        HIPCK(upload_sync(d_tab, tab.data(), sizeof(float) * tab.size()));
         auto launch = [&]() {
             if (kind == 9)
                 hipLaunchKernelGGL(k_resident<1>, dim3(cnt), dim3(256), 0, s, p, h->d_res + h->res_first[1], d_tab);
@@ -1122,7 +1235,7 @@ extern "C" int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hy, int32_t kin
         HIPCK(hipEventElapsedTime(&ms, e0, e1));
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
-        (void)hipFree(d_tab);
+        (void)pool_free(d_tab);
         *ms_avg = ms / reps;
         double sn2 = 0;
         for (int t = 0; t < h->prob.num_targets; ++t)

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_resident(Params p, const int32_t* targe
             sh.dfp[tid] = 0.0f;
         }
         __syncthreads();
-        const float step_size = adam_tab[2 * iter], inv_bc2s = 1.0f / adam_tab[2 * iter + 1];
+        const float step_size = adam_tab[2 * iter], bc2s = adam_tab[2 * iter + 1];
 
         float z4[4];
         // ---- layer 1: Zraw = Abar . X ; U1 ----
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void k_resident(Params p, const int32_t* targe
                         const float S = sigmoidf_(Mo[pi][e]);
                         const float gij = (gc + p.c_size - p.c_ent * Mo[pi][e] * inv_n2) * S * (1.0f - S);
                         float Mn = Mo[pi][e], mn = mo[pi][e], vn = vo[pi][e];
-                        adam_update(Mn, mn, vn, gij, p.omb1, p.beta2, p.omb2, p.eps, step_size, inv_bc2s);
+                        adam_update(Mn, mn, vn, gij, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
                         Mo[pi][e] = Mn;
                         mo[pi][e] = mn;
                         vo[pi][e] = vn;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void k_resident(Params p, const int32_t* targe
                         const float S = sigmoidf_(Mp[pi][e]);
                         const float gji = (gc + p.c_size - p.c_ent * Mp[pi][e] * inv_n2) * S * (1.0f - S);
                         float Mn = Mp[pi][e], mn = mp[pi][e], vn = vp[pi][e];
-                        adam_update(Mn, mn, vn, gji, p.omb1, p.beta2, p.omb2, p.eps, step_size, inv_bc2s);
+                        adam_update(Mn, mn, vn, gji, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
                         Mp[pi][e] = Mn;
                         mp[pi][e] = mn;
                         vp[pi][e] = vn;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void k_resident(Params p, const int32_t* targe
             const float ph = sh.phi[tid];
             const float gf = (sh.dfp[tid] + p.c_feat_size / (float)p.D) * ph * (1.0f - ph);
             float fn = sh.fcur[tid], m = sh.mf[tid], v = sh.vf[tid];
-            adam_update(fn, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, inv_bc2s);
+            adam_update(fn, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
             sh.fcur[tid] = fn;
             sh.mf[tid] = m;
             sh.vf[tid] = v;

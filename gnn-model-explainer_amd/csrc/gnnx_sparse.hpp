@@ -238,7 +238,7 @@ __device__ __forceinline__ void sparse_forward_rowlocal_impl(const float (&zq)[N
         ss = fmaf(c16[g], c16[g], ss);
     }
     ss += __shfl_xor(ss, 32);
-    const float rnorm = fmaxf(__builtin_amdgcn_sqrtf(ss), 1e-12f);  // hardware forms, ~1 ulp (as in k_mask)
+    const float rnorm = fmaxf(sqrt_(ss), 1e-12f);
     const float rinv = rcp_(rnorm);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -753,7 +753,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     publish_abar();
 
     for (int iter = 0; iter < p.num_iters; ++iter) {
-        const float step_size = adam_tab[2 * iter], inv_bc2s = 1.0f / adam_tab[2 * iter + 1];
+        const float step_size = adam_tab[2 * iter], bc2s = adam_tab[2 * iter + 1];
 
         // ======== layer 1: Zraw = Abar . X (kept in registers for the feature-mask gradient), U1 ========
         if (SA.wave_active) {
@@ -1195,12 +1195,12 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 {
                     const float S = Sij[q];
                     const float g = (gc + p.c_size - p.c_ent * Mij[q] * inv_n2) * S * (1.0f - S);
-                    adam_update(Mij[q], mij[q], vij[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, inv_bc2s);
+                    adam_update(Mij[q], mij[q], vij[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
                 }
                 {
                     const float S = Sji[q];
                     const float g = (gc + p.c_size - p.c_ent * Mji[q] * inv_n2) * S * (1.0f - S);
-                    adam_update(Mji[q], mji[q], vji[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, inv_bc2s);
+                    adam_update(Mji[q], mji[q], vji[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
                 }
             }
         SYNC();  // dfp complete; every reader of sAb / sArt of this iteration is done
@@ -1208,7 +1208,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             const float ph = sh.phi[tid];
             const float gf = (sh.dfp[tid] + p.c_feat_size / (float)D) * ph * (1.0f - ph);
             float fn = sh.fcur[tid], m = sh.mf[tid], v = sh.vf[tid];
-            adam_update(fn, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, inv_bc2s);
+            adam_update(fn, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
             sh.fcur[tid] = fn;
             sh.mf[tid] = m;
             sh.vf[tid] = v;

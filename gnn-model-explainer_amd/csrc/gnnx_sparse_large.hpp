@@ -615,7 +615,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     for (int iter = 0; iter < p.num_iters; ++iter) {
         if (tid < 32) sh.phi[tid] = (tid < D) ? sigmoidf_(sh.fcur[tid]) : 0.0f;
         __syncthreads();
-        const float step_size = adam_tab[2 * iter], inv_bc2s = 1.0f / adam_tab[2 * iter + 1];
+        const float step_size = adam_tab[2 * iter], bc2s = adam_tab[2 * iter + 1];
 
         // ======== layer 1 on the rows within two hops: Zraw = Abar . X (kept for the feature-mask gradient), U1 ========
         for (int round = 0; round < roundsA; ++round) {
@@ -932,12 +932,12 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 {
                     const float S = sigmoidf_(Mij[u]);
                     const float g = (gc + p.c_size - p.c_ent * Mij[u] * inv_n2) * S * (1.0f - S);
-                    adam_update(Mij[u], mij[u], vij[u], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, inv_bc2s);
+                    adam_update(Mij[u], mij[u], vij[u], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
                 }
                 {
                     const float S = sigmoidf_(Mji[u]);
                     const float g = (gc + p.c_size - p.c_ent * Mji[u] * inv_n2) * S * (1.0f - S);
-                    adam_update(Mji[u], mji[u], vji[u], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, inv_bc2s);
+                    adam_update(Mji[u], mji[u], vji[u], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
                 }
             }
 #pragma unroll
@@ -961,7 +961,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             const float ph = sh.phi[tid];
             const float gf = (sh.dfp[tid] + p.c_feat_size / (float)D) * ph * (1.0f - ph);
             float fn = sh.fcur[tid], m = sh.mf[tid], v = sh.vf[tid];
-            adam_update(fn, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, inv_bc2s);
+            adam_update(fn, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
             sh.fcur[tid] = fn;
             sh.mf[tid] = m;
             sh.vf[tid] = v;
@@ -1005,13 +1005,13 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
               vji = est[5 * eup + k];
         float a = w * (0.5f * (sigmoidf_(Mij) + sigmoidf_(Mji)));
         for (int iter = 0; iter < p.num_iters; ++iter) {
-            const float step_size = adam_tab[2 * iter], inv_bc2s = 1.0f / adam_tab[2 * iter + 1];
+            const float step_size = adam_tab[2 * iter], bc2s = adam_tab[2 * iter + 1];
             const float Si = sigmoidf_(Mij), Sj = sigmoidf_(Mji);
             a = w * (0.5f * (Si + Sj));   // the mask of this iteration's forward
             const float gi = (gc + p.c_size - p.c_ent * Mij * inv_n2) * Si * (1.0f - Si);
             const float gj = (gc + p.c_size - p.c_ent * Mji * inv_n2) * Sj * (1.0f - Sj);
-            adam_update(Mij, mij, vij, gi, p.omb1, p.beta2, p.omb2, p.eps, step_size, inv_bc2s);
-            adam_update(Mji, mji, vji, gj, p.omb1, p.beta2, p.omb2, p.eps, step_size, inv_bc2s);
+            adam_update(Mij, mij, vij, gi, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
+            adam_update(Mji, mji, vji, gj, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
         }
         p.Abar[tm.offQ + (size_t)i * ld + j] = a;
         p.Abar[tm.offQ + (size_t)j * ld + i] = a;

@@ -30,6 +30,11 @@ _ENGINE_STREAMS = {}
 
 
 def _engine_stream(dev):
+    """The stream a new job's work goes to: the caller's CURRENT stream when that is not the default stream (a pipeline stage
+    running under `with torch.cuda.stream(s)`: pipeline.BatchPipeline), else one process-wide engine stream per device."""
+    cur = torch.cuda.current_stream(dev)
+    if cur != torch.cuda.default_stream(dev):
+        return cur
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     if key not in _ENGINE_STREAMS:
         _ENGINE_STREAMS[key] = torch.cuda.Stream(dev)
@@ -92,7 +97,8 @@ class Hyper:
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", _LIB_NAME)
+    # GNNX_LIBRARY_PATH: measurement sessions load an A/B build of the same sources (tools/); never set in production
+    return os.environ.get("GNNX_LIBRARY_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", _LIB_NAME)
 
 
 def _load_hip_library():
@@ -136,6 +142,10 @@ _API = {
     "gnnx_scatter_masks": (ctypes.c_int, [ctypes.c_void_p] * 4),
     "gnnx_edge_counts": (ctypes.c_int, [ctypes.c_void_p] * 4),
     "gnnx_gather_edges": (ctypes.c_int, [ctypes.c_void_p] * 9 + [ctypes.c_size_t, ctypes.c_void_p]),
+    "gnnx_pool_trim": (ctypes.c_int, []),
+    "gnnx_set_service_stream": (ctypes.c_int, [ctypes.c_void_p]),
+    "gnnx_lane_stream": (ctypes.c_void_p, [ctypes.c_int32]),
+    "gnnx_debug_spin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "gnnx_last_error": (ctypes.c_char_p, []),
     "gnnx_version": (ctypes.c_char_p, []),
 }
@@ -563,13 +573,21 @@ class MaskOptimJob:
     def _stream(self):
         return ctypes.c_void_p(self.stream.cuda_stream if self.stream is not None else 0)
 
+    def use_stream(self, stream):
+        """Move the job's later work to another stream (the caller orders the two streams, e.g. with an event)."""
+        self.stream = stream
+
     def _enter(self):
         if self.stream is not None:
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            cur = torch.cuda.current_stream(self.device)
+            if cur != self.stream:
+                self.stream.wait_stream(cur)
 
     def _leave(self):
         if self.stream is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            cur = torch.cuda.current_stream(self.device)
+            if cur != self.stream:
+                cur.wait_stream(self.stream)
 
     # -- the hot loop --------------------------------------------------------------------------
     def launch(self, hyper: Hyper, state: Optional[AdamState] = None, keep_state=False):
@@ -748,17 +766,48 @@ def _rng_pool():
     return _RNG_POOL[0]
 
 
-def init_edge_masks_raw(sizes, generator=None, seeds=None, pin=False, threads=1):
+_HOST_LIB_NAME = "libgnnx_host.so"
+_host_lib_cache = []
+
+
+def host_library():
+    """libgnnx_host.so (include/gnnx_host.h): ATen's CPU normal_ called from C++ threads, no GIL.  None if it is not built (the
+    Python loop below then makes the very same ATen calls, bit for bit, only slower)."""
+    if not _host_lib_cache:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", _HOST_LIB_NAME)
+        lib = None
+        if os.path.exists(path):
+            lib = ctypes.CDLL(path)
+            lib.gnnx_host_draw_masks.restype = ctypes.c_int
+            lib.gnnx_host_draw_masks.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
+            lib.gnnx_host_last_error.restype = ctypes.c_char_p
+        _host_lib_cache.append(lib)
+    return _host_lib_cache[0]
+
+
+def default_rng_threads():
+    """Host threads for the seeded mask draw: the draw is memory-light and embarrassingly parallel over targets; beyond ~32 threads
+    the hand-off costs more than it saves (tools/probe_rng.py)."""
+    return max(1, min(32, (os.cpu_count() or 2) // 2))
+
+
+def init_edge_masks_raw(sizes, generator=None, seeds=None, pin=False, threads=1, out=None):
     """The initial edge masks of a whole batch as ONE host buffer: target after target the n x n values of the single
     normal_(1, std) draw construct_edge_mask makes (explain.py:645-652), generated in place (a draw into a contiguous
     slice consumes the generator exactly like a draw into a fresh [n, n] tensor).  `seeds`: re-seed a PRIVATE generator
     before every target (the seed protocol of the golden runs) instead of consuming the caller's global stream; the
     targets are then independent and `threads` > 1 draws them on several host threads (normal_ releases the GIL).
-    `pin`: the result is a view of ONE process-wide pinned buffer - upload it (set_masks_raw) before the next pinned call."""
+    `pin`: the result is a view of ONE process-wide pinned buffer - upload it (set_masks_raw) before the next pinned call;
+    `out`: draw into the caller's buffer instead."""
     sizes = [int(n) for n in sizes]
     off = np.zeros(len(sizes) + 1, np.int64)
     np.cumsum(np.asarray(sizes, np.int64) ** 2, out=off[1:])
-    buf = _pinned_stream_buffer(int(off[-1])) if pin else torch.empty(int(off[-1]), dtype=torch.float32)
+    if out is not None:        # the caller's own (e.g. pinned) staging buffer: pipeline.BatchPipeline keeps a ring of them
+        if out.dtype != torch.float32 or out.numel() != int(off[-1]) or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32 buffer of sum(n^2) values")
+        buf = out
+    else:
+        buf = _pinned_stream_buffer(int(off[-1])) if pin else torch.empty(int(off[-1]), dtype=torch.float32)
 
     def fill(lo, hi, gen):
         for k in range(lo, hi):
@@ -767,6 +816,13 @@ def init_edge_masks_raw(sizes, generator=None, seeds=None, pin=False, threads=1)
                 gen.manual_seed(int(seeds[k]))
             buf[off[k]:off[k + 1]].normal_(1.0, math.sqrt(2.0) * math.sqrt(2.0 / (n + n)), generator=gen)
 
+    hl = host_library() if seeds is not None else None
+    if hl is not None and len(sizes):       # the seed protocol makes targets independent: C++ threads, no GIL (gnnx_host_draw_masks)
+        n32 = np.ascontiguousarray(sizes, np.int32)
+        sd = np.ascontiguousarray(np.asarray(seeds).astype(np.int64))
+        if hl.gnnx_host_draw_masks(len(sizes), n32.ctypes.data, sd.ctypes.data, off.ctypes.data, buf.data_ptr(), int(max(1, threads))) != 0:
+            raise GnnxError(hl.gnnx_host_last_error().decode())
+        return buf
     if seeds is None or threads <= 1 or len(sizes) < 2 * threads:
         fill(0, len(sizes), torch.Generator() if seeds is not None else generator)
         return buf

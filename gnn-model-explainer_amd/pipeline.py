@@ -1,0 +1,200 @@
+"""Batches of targets through the whole hot path, stages overlapped: the steady state of `Explainer.explain_nodes` over many batches.
+
+One batch = what the reference does per target in Explainer.explain (explainer/explain.py:74-221): neighbourhood extraction
+(:492-501), ExplainModule construction with its seeded normal_ mask (:583-663), the optimisation loop (:137-146) and the masked
+adjacency handed back (:208-221).  Here a batch runs as three stages on three HIP streams:
+
+  prepare  (worker thread, stream P): k-hop walk sets on the device (gnnx_khop) -> plan -> device-side packing (gnnx_pack_csr) ->
+           routing (gnnx_plan_analyze) -> edge layout (gnnx_edge_counts / _positions; the edge ids (r, c) go back to the host
+           here, they do not depend on the optimisation), while C++ host threads draw the seeded initial masks
+           (gnnx_host_draw_masks) into a pinned buffer -> one H2D copy + gnnx_scatter_masks;
+  optimise (caller's thread, stream L): gnnx_run - all iterations;
+  fetch    (caller's thread, stream F): gnnx_gather_values + D2H of the edge values and the feature masks into pinned buffers.
+
+Batch k + 1 is prepared and batch k - 1 fetched while batch k optimises, so a long job costs max(stage) per batch instead of
+their sum; nothing is shared between batches but the resident graph.  Results come back in order as engine.EdgeMasks.
+"""
+import queue
+import threading
+import time
+from collections import deque
+
+import numpy as np
+import torch
+
+from . import engine
+
+
+class _Prepared:
+    __slots__ = ("targets", "job", "dn", "ready", "rc", "eoff", "E", "times", "error")
+
+
+class BatchPipeline:
+    def __init__(self, graph, state_dict, labels, hyper, n_hops=3, seed_base=1000, rng_threads=None, depth=2, lib=None):
+        """graph: engine.DeviceGraph (resident); labels [N]: the label the prediction loss uses (explain.py:750-753); the initial
+        mask of target v is drawn from a generator seeded with seed_base + v (the seed protocol of the golden runs)."""
+        self.graph, self.sd, self.labels, self.hyper = graph, state_dict, np.asarray(labels), hyper
+        self.n_hops, self.seed_base = int(n_hops), int(seed_base)
+        self.rng_threads = int(rng_threads) if rng_threads else engine.default_rng_threads()
+        self.depth = max(1, int(depth))
+        self.lib = lib if lib is not None else engine.get_library()
+        dev = graph.feat.device
+        self.device = dev
+        self.s_loop = torch.cuda.Stream(dev)
+        self._rejected = []        # streams that share a hardware queue with a launch lane (kept alive: their queue slot stays taken)
+        self.s_prep = self._free_stream()
+        self.s_fetch = self._free_stream()
+        self._pinned = {}          # name -> grow-only pinned host buffers (ring of `depth + 1` each)
+        self._ring = 0
+        self.stats = []            # per batch: host milliseconds of the stages (measurement)
+
+    # -- streams -------------------------------------------------------------------------------------------------------------
+    def _free_stream(self, tries=16, spin_us=3000):
+        """A new stream whose hardware queue is not the queue of a launch lane nor of the optimise stream.  HIP binds a stream to
+        one of GPU_MAX_HW_QUEUES queues when it is created and executes the packets of one queue in order, so a prepare / fetch
+        stream that lands on the queue of the lane running a 4 ms optimisation (or on the queue where the optimise stream's barrier
+        packet waits for it) makes the next batch's k-hop kernels wait for that launch - the stages would not overlap.  Found by
+        trial: keep the lanes and the optimise stream busy for 3 ms (gnnx_debug_spin), time a trivial operation on the candidate."""
+        dev = self.device
+        lanes = [self.lib.gnnx_lane_stream(i) for i in range(3)]
+        probe = torch.zeros(64, dtype=torch.int32, device=dev)
+        for _ in range(tries):
+            cand = torch.cuda.Stream(dev)
+            torch.cuda.synchronize(dev)
+            for ln in lanes:
+                if ln:
+                    self.lib.gnnx_debug_spin(ln, spin_us)
+            self.lib.gnnx_debug_spin(self.s_loop.cuda_stream, spin_us)
+            t0 = time.perf_counter()
+            with torch.cuda.stream(cand):
+                probe.add_(1)
+            cand.synchronize()
+            waited = time.perf_counter() - t0
+            torch.cuda.synchronize(dev)
+            if waited < 0.3 * spin_us * 1e-6:
+                return cand
+            self._rejected.append(cand)
+        return torch.cuda.Stream(dev)      # no free queue found (GPU_MAX_HW_QUEUES too small): the stages then serialise, correctly but slower
+
+    # -- pinned staging ----------------------------------------------------------------------------------------------------
+    def _pin(self, name, numel, dtype, slot):
+        key = (name, slot)
+        buf = self._pinned.get(key)
+        if buf is None or buf.numel() < numel:
+            buf = torch.empty(int(numel * 1.25) + 256, dtype=dtype, pin_memory=True)
+            self._pinned[key] = buf
+        return buf[:numel]
+
+    # -- stage 1 -----------------------------------------------------------------------------------------------------------
+    def _prepare(self, targets, slot):
+        p = _Prepared()
+        p.targets, p.error, p.times = targets, None, {}
+        t0 = time.perf_counter()
+        with torch.cuda.stream(self.s_prep):
+            dn = engine.khop_device(self.graph, targets, self.n_hops, lib=self.lib)
+            p.times["khop_ms"] = (time.perf_counter() - t0) * 1e3
+            if (dn.rows < 0).any():
+                raise ValueError("a target is not in its own %d-hop walk set (isolated node): the reference fails on it too" % self.n_hops)
+            # the seeded masks only need the sizes: C++ threads draw them while the device builds the plan
+            box = {}
+
+            def draw():
+                t_r = time.perf_counter()
+                total = int((dn.sizes.astype(np.int64) ** 2).sum())
+                try:
+                    box["raw"] = engine.init_edge_masks_raw(dn.sizes, seeds=self.seed_base + targets, threads=self.rng_threads,
+                                                            out=self._pin("raw", total, torch.float32, slot))
+                except Exception as e:      # noqa: BLE001 - re-raised on the preparing thread
+                    box["err"] = e
+                box["ms"] = (time.perf_counter() - t_r) * 1e3
+            th = threading.Thread(target=draw)
+            th.start()
+            t1 = time.perf_counter()
+            job = engine.MaskOptimJob.from_csr(self.graph, dn, None, self.labels[targets], self.sd, lib=self.lib)
+            job._edge_layout()
+            E = int(job._eoff[-1])
+            rc_host = self._pin("rc", 2 * max(E, 1), torch.int32, slot).view(-1, 2)
+            rc_host[:E].copy_(job._rc[:E], non_blocking=True)
+            p.times["plan_pack_route_layout_ms"] = (time.perf_counter() - t1) * 1e3
+            th.join()
+            if "err" in box:
+                raise box["err"]
+            p.times["host_rng_ms"] = box["ms"]
+            t2 = time.perf_counter()
+            job.set_masks_raw(box["raw"])
+            p.ready = torch.cuda.Event()
+            p.ready.record(self.s_prep)
+            p.times["h2d_scatter_enqueue_ms"] = (time.perf_counter() - t2) * 1e3
+        p.job, p.dn, p.rc, p.eoff, p.E = job, dn, rc_host, job._eoff, E
+        p.times["prepare_ms"] = (time.perf_counter() - t0) * 1e3
+        return p
+
+    def _worker(self, batches, out_q):
+        slot = 0
+        self.lib.gnnx_set_service_stream(self.s_prep.cuda_stream)    # this thread's plan-table uploads: not the null stream
+        try:
+            for targets in batches:
+                targets = np.ascontiguousarray(targets, np.int64)
+                try:
+                    out_q.put(self._prepare(targets, slot))
+                except Exception as e:      # noqa: BLE001 - handed to the consumer
+                    p = _Prepared()
+                    p.error = e
+                    out_q.put(p)
+                    return
+                slot = (slot + 1) % (self.depth + 2)
+        finally:
+            out_q.put(None)
+
+    # -- stages 2 + 3 ------------------------------------------------------------------------------------------------------
+    def _launch(self, p, slot):
+        job = p.job
+        with torch.cuda.stream(self.s_loop):
+            self.s_loop.wait_event(p.ready)
+            job.use_stream(self.s_loop)
+            job.launch(self.hyper)
+            done = torch.cuda.Event()
+            done.record(self.s_loop)
+        with torch.cuda.stream(self.s_fetch):
+            self.s_fetch.wait_event(done)
+            job.use_stream(self.s_fetch)
+            vals_d = job.gather_edges_device()
+            vals = self._pin("vals", max(p.E, 1), torch.float32, slot)
+            vals[:p.E].copy_(vals_d[:p.E], non_blocking=True)
+            fm = self._pin("fmask", job.T * engine.FEAT_STRIDE, torch.float32, slot).view(job.T, engine.FEAT_STRIDE)
+            fm.copy_(job.fmask, non_blocking=True)
+            fetched = torch.cuda.Event()
+            fetched.record(self.s_fetch)
+        return vals, fm, fetched
+
+    def run(self, batches):
+        """batches: iterable of int arrays of target node ids.  Yields one engine.EdgeMasks per batch, in order."""
+        q = queue.Queue(maxsize=self.depth)
+        th = threading.Thread(target=self._worker, args=(iter(batches), q), daemon=True)
+        th.start()
+        pending = deque()
+        slot = 0
+
+        def finish(item):
+            p, vals, fm, fetched = item
+            fetched.synchronize()
+            em = engine.EdgeMasks(p.job.n.copy(), p.eoff, p.rc[:p.E].numpy().copy(), vals[:p.E].numpy().copy(),
+                                  fm.numpy()[:, :p.job.D].copy())
+            em.neighbors = p.dn
+            self.stats.append(p.times)
+            p.job.close()          # the plan's device tables go back to the library's pool (no hipFree: gnnx_capi.hip)
+            return em
+
+        while True:
+            p = q.get()
+            if p is None:
+                break
+            if p.error is not None:
+                raise p.error
+            pending.append((p,) + self._launch(p, slot))
+            slot = (slot + 1) % (self.depth + 2)
+            while len(pending) > self.depth:
+                yield finish(pending.popleft())
+        while pending:
+            yield finish(pending.popleft())
+        th.join()

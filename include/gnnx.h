@@ -234,6 +234,20 @@ int gnnx_denoise_edges(gnnx_handle h, const int64_t* eoff, const int32_t* rc, co
  * AUC = (counts[1] + counts[2] / 2) / (counts[0] counts[3]).  pos_scratch: DEVICE, E floats. */
 int gnnx_auc_counts(const float* vals, const uint8_t* real, int64_t num_edges, float* pos_scratch, unsigned long long* counts, void* stream);
 
+/* Pipelined jobs (pipeline.BatchPipeline): the calling THREAD's plan-building uploads (gnnx_plan_create, gnnx_plan_analyze, the Adam
+ * table of gnnx_run) go to `stream` instead of the null stream, whose hardware queue may be busy with another batch's launch;
+ * NULL restores the default.  gnnx_lane_stream(i), i = 0..2: the library's process-wide launch lanes (hipStream_t) - the
+ * streams the resident launches of gnnx_run execute on; gnnx_debug_spin keeps a stream busy for `micros` microseconds.  The
+ * last two exist so that a caller can check which of ITS streams share a hardware queue with a lane (HIP binds streams to
+ * GPU_MAX_HW_QUEUES queues round-robin; streams on one queue execute in order). */
+int gnnx_set_service_stream(void* stream);
+void* gnnx_lane_stream(int32_t i);
+int gnnx_debug_spin(void* stream, int32_t micros);
+
+/* The library keeps the device blocks of destroyed plans for the next plan (hipMalloc / hipFree per batch serialise a pipelined
+ * job: hipFree synchronises the device); this returns the idle ones of the current device to the driver. */
+int gnnx_pool_trim(void);
+
 const char* gnnx_last_error(void);
 const char* gnnx_version(void);
 

@@ -1,0 +1,30 @@
+/* gnnx_host.h — host-side helper of the MI355X-native GNNExplainer engine (libgnnx_host.so): the initial edge masks.
+ *
+ * The reference draws every target's initial mask with ONE torch CPU-generator call,
+ *     mask = torch.FloatTensor(n, n); mask.normal_(1.0, calculate_gain("relu") * sqrt(2 / (n + n)))
+ * (construct_edge_mask, explainer/explain.py:645-652), and parity needs exactly those bits (torch's vectorised Box-Muller over
+ * mt19937 cannot be reproduced on the device).  In Python that call costs ~8 us of interpreter + dispatch per target under the
+ * GIL (3.2 ms of an 8.5 ms syn1 batch on two threads).  This library makes the SAME ATen call - at::Tensor::normal_
+ * on a view of the caller's buffer with a private at::Generator seeded per target - from plain C++ threads, no GIL, no Python.
+ * Plain C ABI (pointers and sizes); links libtorch_cpu / libc10 of the PyTorch the process already has loaded.
+ */
+#ifndef GNNX_HOST_H
+#define GNNX_HOST_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* out[off[k] .. off[k] + n[k]^2) = the n[k] x n[k] values of ONE normal_(1.0, sqrt(2) * sqrt(2 / (n + n))) draw from a CPU generator
+ * seeded with seeds[k] (the seed protocol of the golden runs: torch.manual_seed(1000 + target) immediately before the explanation,
+ * which makes the targets independent).  `out` is HOST memory (pinned or not), `threads` worker threads split the targets by
+ * equal shares of the values.  Returns 0, or non-zero with the text in gnnx_host_last_error(). */
+int gnnx_host_draw_masks(int32_t num_targets, const int32_t* n, const int64_t* seeds, const int64_t* off, float* out, int32_t threads);
+
+const char* gnnx_host_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNX_HOST_H */

@@ -14,14 +14,17 @@ Runs only in the build container.  Nothing from the reference is copied: it is i
 Outcome-blind window classification (decided on the CPU alone, before any GPU run): the closed-form fp32 oracle
 (oracle/closed_form.py: same mathematics, other summation order) is started from the reference's state at every 50-epoch
 boundary and run for 50 iterations; `cond50[t][w]` is its deviation (masked adjacency and sigmoid(feat_mask)) from the reference's state at
-the end of the window.  Windows with cond50 > 2e-6 ("flagged": a ReLU gate / max-pool tie flips inside them even between two CPU
-implementations) additionally get the four 10-epoch snapshots inside the window and `cond10` of their five sub-windows.
+the end of the window.  The two CPU implementations share their BLAS, so their agreement alone understates how sensitive a
+window is; `sens50[t][w]` therefore measures the window's own conditioning: the largest deviation of 4 closed-form runs whose
+starting mask entries are perturbed by +-1 ulp from the unperturbed closed-form run.  Windows with max(cond50, sens50) > 2e-6
+("flagged": a ReLU gate / max-pool tie flips inside them, or Adam amplifies a one-ulp difference beyond 2e-6 within 50 epochs)
+additionally get the four 10-epoch snapshots inside the window and `cond10` / `sens10` of their five sub-windows.
 
 Fixtures written (tests/golden/<name>_windows.npz):
   targets (or graphs) [T], eoff [T+1] (upper-triangle edges, order of <name>_full_explain.npz), epochs [6] = 50..300,
-  M / m / v [6][E][2] float32 (entry (r,c), entry (c,r)), f / mf / vf [6][T][D], cond50 [T][6],
+  M / m / v [6][E][2] float32 (entry (r,c), entry (c,r)), f / mf / vf [6][T][D], cond50 / sens50 [T][6],
   fine_tw [F][2] = (target index, window) of the flagged windows, fine_off [F+1] (edge offsets), fine_M / fine_m / fine_v [4][Ef][2]
-  (epochs 50 w + 10, 20, 30, 40), fine_f / fine_mf / fine_vf [4][F][D], cond10 [F][5];
+  (epochs 50 w + 10, 20, 30, 40), fine_f / fine_mf / fine_vf [4][F][D], cond10 / sens10 [F][5];
   config4 only: the whole job description (vals / feat_sig of the 300-epoch output, cond_mask / cond_feat, weights) because it
   covers 512 graphs where config4_explain.npz has 64.
 """
@@ -96,8 +99,31 @@ def abar_edges(Mrc, w=1.0):
     return w * 0.5 * (_sig64(Mrc[:, 0]) + _sig64(Mrc[:, 1]))
 
 
-def _oracle_dev(o, rc, state, ref_end, k0, steps):
-    """Closed-form oracle started from the reference's `state` (after k0 steps), `steps` iterations -> deviation from ref_end."""
+TRIALS, ULP = 4, 2e-7     # sensitivity probe: TRIALS runs with the mask entries on the edges multiplied by 1 + ULP (u - 0.5), u ~ U[0, 1): +-1 ulp
+
+
+def _oracle_dev(o, rc, state, ref_end, k0, steps, seed=None):
+    """Closed-form oracle started from the reference's `state` (after k0 steps), `steps` iterations -> deviation from ref_end
+    (seed None), or - sensitivity of the window to its own input - (deviation from ref_end, largest deviation of TRIALS runs from
+    1-ulp-perturbed starts from the unperturbed run)."""
+    if seed is not None:
+        base = _oracle_out(o, rc, state, k0, steps)
+        dev = _dev(base, ref_end)
+        rng = np.random.default_rng(seed)
+        sens = 0.0
+        for _ in range(TRIALS):
+            M = (state[0] * (1.0 + ULP * (rng.random(state[0].shape) - 0.5))).astype(np.float32)
+            sens = max(sens, _dev(_oracle_out(o, rc, (M,) + tuple(state[1:]), k0, steps), base))
+        return dev, sens
+    return _dev(_oracle_out(o, rc, state, k0, steps), ref_end)
+
+
+def _dev(got, want):
+    dm = float(np.abs(abar_edges(got[0]) - abar_edges(want[0])).max()) if len(got[0]) else 0.0
+    return max(dm, float(np.abs(_sig64(got[3]) - _sig64(want[3])).max()))
+
+
+def _oracle_out(o, rc, state, k0, steps):
     r, c = rc
     M, m, v, f, mf, vf = state
     o.M[r, c], o.M[c, r] = M[:, 0], M[:, 1]
@@ -110,14 +136,11 @@ def _oracle_dev(o, rc, state, ref_end, k0, steps):
     for _ in range(steps):
         o.iterate()
         o.M[o._off_edges] = o._M0[o._off_edges]      # dead entries (never reach an output): parked, so they cannot saturate the sigmoid
-    got = np.stack([o.M[r, c], o.M[c, r]], 1)
-    dm = float(np.abs(abar_edges(got) - abar_edges(ref_end[0])).max()) if len(r) else 0.0
-    df = float(np.abs(_sig64(o.f) - _sig64(ref_end[3])).max())
-    return max(dm, df)
+    return (np.stack([o.M[r, c], o.M[c, r]], 1), None, None, o.f.copy())
 
 
-def classify_windows(sub_adj, sub_feat, sd, gt, pred_label, new_idx, mask0, rec, graph_mode):
-    """cond50 [6] and, for the flagged windows, cond10 [5] each (CPU vs CPU, see the module docstring)."""
+def classify_windows(sub_adj, sub_feat, sd, gt, pred_label, new_idx, mask0, rec, graph_mode, seed):
+    """(cond50, sens50) [2][6] and, for the flagged windows, (cond10, sens10) [2][5] each (see the module docstring)."""
     from oracle import closed_form
     o = closed_form.ClosedFormOracle(sub_adj.astype(np.float32), sub_feat.astype(np.float32), sd, gt, pred_label, new_idx, mask0,
                                      graph_mode=graph_mode)
@@ -128,12 +151,12 @@ def classify_windows(sub_adj, sub_feat, sd, gt, pred_label, new_idx, mask0, rec,
     zd = np.zeros(D, np.float32)
     M0 = np.stack([mask0[rc[0], rc[1]], mask0[rc[1], rc[0]]], 1).astype(np.float32)
     state = lambda k: (M0, z2, z2, zd, zd, zd) if k == 0 else rec[k]
-    cond50, cond10 = np.zeros(EPOCHS // WIN, np.float32), {}
+    cond50, cond10 = np.zeros((2, EPOCHS // WIN), np.float32), {}     # [0]: CPU vs CPU, [1]: 1-ulp sensitivity
     for w in range(EPOCHS // WIN):
-        cond50[w] = _oracle_dev(o, rc, state(WIN * w), rec[WIN * (w + 1)], WIN * w, WIN)
-        if cond50[w] > FLAG:
-            cond10[w] = np.asarray([_oracle_dev(o, rc, state(WIN * w + SUB * s), rec[WIN * w + SUB * (s + 1)], WIN * w + SUB * s, SUB)
-                                    for s in range(WIN // SUB)], np.float32)
+        cond50[:, w] = _oracle_dev(o, rc, state(WIN * w), rec[WIN * (w + 1)], WIN * w, WIN, seed=(seed, w))
+        if cond50[:, w].max() > FLAG:
+            cond10[w] = np.asarray([_oracle_dev(o, rc, state(WIN * w + SUB * s), rec[WIN * w + SUB * (s + 1)], WIN * w + SUB * s, SUB,
+                                                seed=(seed, w, s)) for s in range(WIN // SUB)], np.float32).T      # [2][5]
     return cond50, cond10
 
 
@@ -183,7 +206,7 @@ def _node_worker(job):
         # (not stored), so check the next best thing: every stored M is finite and the edge structure is the fixture's
         assert not np.isnan(ma).any() and all(np.isfinite(x[0]).all() for x in rec.values())
         pl = np.argmax(cg["pred"][0][nb], axis=1)
-        cond50, cond10 = classify_windows(sub_adj, sub_feat, sd, int(sub_label[new_idx]), pl, int(new_idx), mod.mask0.numpy(), rec, False)
+        cond50, cond10 = classify_windows(sub_adj, sub_feat, sd, int(sub_label[new_idx]), pl, int(new_idx), mod.mask0.numpy(), rec, False, int(t))
         out.append(_pack_target(int(t), rec, cond50, cond10, dict(nedges=len(r))))
         for f in os.listdir(args.logdir):
             os.remove(os.path.join(args.logdir, f))
@@ -227,7 +250,7 @@ def _graph_worker(job):
         r, c = rc_box["rc"]
         fsig = torch.sigmoid(mod.feat_mask).detach().numpy()
         cm, cf = mgf._closed_form_dev(A_all[g], X_all[g], wts, int(y_all[g]), None, 0, mod.mask0.numpy(), ma, fsig, EPOCHS, graph_mode=True)
-        cond50, cond10 = classify_windows(A_all[g], X_all[g], wts, int(y_all[g]), None, 0, mod.mask0.numpy(), rec, True)
+        cond50, cond10 = classify_windows(A_all[g], X_all[g], wts, int(y_all[g]), None, 0, mod.mask0.numpy(), rec, True, int(g))
         out.append(_pack_target(int(g), rec, cond50, cond10,
                                 dict(nedges=len(r), vals=ma[r, c].astype(np.float32), fsig=fsig, cm=cm, cf=cf,
                                      maxm=float(mod.mask.detach().abs().max()), nn=int(n_all[g]))))
@@ -244,7 +267,8 @@ def assemble(res, id_name):
     cat = lambda i, j: np.concatenate([r["coarse"][i][j] for r in res]) if eoff[-1] else np.zeros((0, 2), np.float32)
     out = {id_name: np.asarray([r["key"] for r in res], np.int64), "eoff": eoff,
            "epochs": np.arange(WIN, EPOCHS + 1, WIN).astype(np.int64), "sub": np.int64(SUB), "flag": np.float64(FLAG),
-           "cond50": np.stack([r["cond50"] for r in res]).astype(np.float32)}
+           "cond50": np.stack([r["cond50"][0] for r in res]).astype(np.float32),
+           "sens50": np.stack([r["cond50"][1] for r in res]).astype(np.float32), "trials": np.int64(TRIALS), "ulp": np.float64(ULP)}
     for j, nm in enumerate(("M", "m", "v")):
         out[nm] = np.stack([cat(i, j) for i in range(nck)]).astype(np.float32)
     for j, nm in ((3, "f"), (4, "mf"), (5, "vf")):
@@ -253,7 +277,8 @@ def assemble(res, id_name):
     nsub = WIN // SUB - 1
     out["fine_tw"] = np.asarray([(k, w) for k, w, _, _ in fine], np.int32).reshape(-1, 2)
     out["fine_off"] = np.cumsum([0] + [res[k]["nedges"] for k, _, _, _ in fine]).astype(np.int64)
-    out["cond10"] = np.asarray([c10 for _, _, c10, _ in fine], np.float32).reshape(-1, WIN // SUB)
+    out["cond10"] = np.asarray([c10[0] for _, _, c10, _ in fine], np.float32).reshape(-1, WIN // SUB)
+    out["sens10"] = np.asarray([c10[1] for _, _, c10, _ in fine], np.float32).reshape(-1, WIN // SUB)
     D = res[0]["coarse"][0][3].shape[0]
     for j, nm in enumerate(("fine_M", "fine_m", "fine_v")):
         out[nm] = (np.stack([np.concatenate([st[s][j] for _, _, _, st in fine]) for s in range(nsub)]).astype(np.float32)
@@ -265,10 +290,11 @@ def assemble(res, id_name):
 
 
 def _report(name, out, t0):
-    c50, c10 = out["cond50"], out["cond10"]
+    c50, c10 = np.maximum(out["cond50"], out["sens50"]), np.maximum(out["cond10"], out["sens10"])
+    print(f"{name}: CPU vs CPU alone flags {int((out['cond50'] > FLAG).sum())} windows, the 1-ulp sensitivity probe alone {int((out['sens50'] > FLAG).sum())}")
     T, W = c50.shape
     fl = c50 > FLAG
-    print(f"{name}: {T} targets x {W} windows in {time.time() - t0:.0f} s; flagged 50-epoch windows (CPU vs CPU > 2e-6): {int(fl.sum())} of {T * W} "
+    print(f"{name}: {T} targets x {W} windows in {time.time() - t0:.0f} s; flagged 50-epoch windows (CPU vs CPU or 1-ulp sensitivity > 2e-6): {int(fl.sum())} of {T * W} "
           f"({int((c50 > 1e-5).sum())} > 1e-5, max {c50.max():.2e}; per window {fl.sum(0).tolist()}); targets with a flagged window: "
           f"{int(fl.any(1).sum())}; their 10-epoch sub-windows: {int((c10 > FLAG).sum())} of {c10.size} > 2e-6, {int((c10 > 1e-5).sum())} > 1e-5 "
           f"(max {c10.max() if c10.size else 0:.2e})", flush=True)

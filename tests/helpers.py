@@ -156,7 +156,10 @@ class Windows:
         self.win = int(z["epochs"][0])
         self.sub = int(z["sub"])
         self.nsub = self.win // self.sub
-        self.flagged = z["cond50"] > WIN_FLAG                       # [T, W]
+        # conditioning of a window = max(CPU-vs-CPU deviation, deviation under a 1-ulp perturbation of its own start) - both measured on
+        # the CPU by make_golden_windows.py before any implementation under test ran
+        self.cond50 = np.maximum(z["cond50"], z["sens50"]) if "sens50" in z.files else z["cond50"]
+        self.flagged = self.cond50 > WIN_FLAG                       # [T, W]
         self.fine_row = {(int(k), int(w)): i for i, (k, w) in enumerate(z["fine_tw"])}
 
     def edge_index(self, ks):
@@ -188,7 +191,8 @@ class Windows:
         return self.fine(w, s, ks)
 
     def cond10(self, w, ks):
-        return np.stack([self.z["cond10"][self.fine_row[(int(k), int(w))]] for k in ks]) if len(ks) else np.zeros((0, self.nsub))
+        c = np.maximum(self.z["cond10"], self.z["sens10"]) if "sens10" in self.z.files else self.z["cond10"]
+        return np.stack([c[self.fine_row[(int(k), int(w))]] for k in ks]) if len(ks) else np.zeros((0, self.nsub))
 
 
 def run_window(job, start, iters):

@@ -87,6 +87,30 @@ def test_c_abi_library_exports_every_declared_symbol():
         assert re.search(r"\bT %s\b" % name, syms), name
 
 
+def test_host_rng_library_draws_the_reference_masks_bit_for_bit():
+    """include/gnnx_host.h <-> libgnnx_host.so: every declared symbol exported, and the masks it draws from C++ threads are the
+    ones torch.manual_seed(1000 + target); torch.FloatTensor(n, n).normal_(1, std) gives (explain.py:645-652) - for every thread
+    count, ragged sizes, n = 1 (fewer than 16 values: ATen's scalar path) and an empty batch."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import __graft_entry__
+    __graft_entry__.build()
+    hdr = open(os.path.join(ROOT, "include", "gnnx_host.h")).read()
+    declared = set(re.findall(r"\b(gnnx_host_[a-z_]+)\s*\(", hdr))
+    path = os.path.join(os.path.dirname(engine.library_path()), "libgnnx_host.so")
+    syms = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+    for name in declared:
+        assert re.search(r"\bT %s\b" % name, syms), name
+    assert engine.host_library() is not None
+    sizes = [1, 3, 4, 5, 17, 40, 2, 31, 64, 7]
+    seeds = 1000 + np.arange(len(sizes)) * 7
+    want = torch.cat([helpers.seeded_mask0(int(s) - 1000, n).flatten() for s, n in zip(seeds, sizes)])
+    for threads in (1, 3, 16):
+        got = engine.init_edge_masks_raw(sizes, seeds=seeds, threads=threads)
+        assert torch.equal(got, want), threads
+    assert engine.init_edge_masks_raw([], seeds=[], threads=4).numel() == 0
+
+
 def test_engine_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

@@ -1,0 +1,50 @@
+"""pipeline.BatchPipeline: batches of targets through the whole hot path with the stages overlapped (prepare / optimise / fetch on
+three streams) must return, batch by batch and in order, exactly what the sequential device-side path returns."""
+import numpy as np
+import pytest
+
+import helpers
+from gnn_model_explainer_amd import engine
+from gnn_model_explainer_amd.engine import Hyper, MaskOptimJob
+from gnn_model_explainer_amd.pipeline import BatchPipeline
+from gnn_model_explainer_amd.utils.graph_utils import KHopIndex
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["syn4", "syn1"])
+def test_pipelined_batches_equal_sequential_jobs(name):
+    ck = helpers.load_ckpt(name)
+    idx = KHopIndex((ck["num_nodes"], ck["edges"]), 3)
+    graph = engine.device_graph(idx.csr, ck["feat"], ck["pred"])
+    first = 300 if name == "syn1" else 511
+    rng = np.random.default_rng(3)
+    batches = [np.sort(rng.choice(np.arange(first, ck["num_nodes"]), k, replace=False)) for k in (7, 64, 1, 33, 64)]   # ragged, one repeated size
+    hy = Hyper(num_iters=25)
+    pipe = BatchPipeline(graph, ck["sd"], ck["label"], hy, rng_threads=4)
+    got = list(pipe.run(batches))
+    assert len(got) == len(batches) and len(pipe.stats) == len(batches)
+    for targets, em in zip(batches, got):
+        dn = engine.khop_device(graph, targets, 3)
+        job = MaskOptimJob.from_csr(graph, dn, None, ck["label"][targets], ck["sd"])
+        job.set_masks_raw(engine.init_edge_masks_raw(dn.sizes, seeds=1000 + targets))
+        job.launch(hy)
+        want = job.fetch_edges()
+        assert np.array_equal(em.eoff, want.eoff) and np.array_equal(em.rc, want.rc)
+        assert np.array_equal(em.masked_adj, want.masked_adj) and np.array_equal(em.feat_mask, want.feat_mask)
+        assert np.array_equal(em.n, dn.sizes)
+
+
+def test_pipeline_reports_a_bad_target():
+    """An isolated node has an empty walk set (the reference fails on it too): the error reaches the caller, nothing hangs."""
+    import scipy.sparse as sp
+    ck = helpers.load_ckpt("syn4")
+    n = ck["num_nodes"] + 1                      # one extra, isolated node
+    e = ck["edges"]
+    csr = sp.csr_matrix((np.ones(2 * len(e), np.float32), (np.r_[e[:, 0], e[:, 1]], np.r_[e[:, 1], e[:, 0]])), shape=(n, n))
+    feat = np.vstack([ck["feat"], ck["feat"][:1]])
+    pred = np.vstack([ck["pred"], ck["pred"][:1]])
+    graph = engine.device_graph(csr, feat, pred)
+    pipe = BatchPipeline(graph, ck["sd"], np.r_[ck["label"], 0], Hyper(num_iters=3))
+    with pytest.raises(Exception):
+        list(pipe.run([np.asarray([600, 601]), np.asarray([n - 1])]))

@@ -92,6 +92,10 @@ def _verdict(what, rows):
            f"(worst {rows[agreed, 3].max() if agreed.any() else 0:.2e}); {len(loose)} sub-windows they disagree on: "
            f"{int((loose[:, 3] <= TOL).sum())} within 1e-5, worst {loose[:, 3].max() if len(loose) else 0:.2e} (CPU-vs-CPU up to {loose[:, 4].max() if len(loose) else 0:.2e})")
     print(msg)
+    dump = os.environ.get("GNNX_DUMP_WINDOWS")
+    if dump:       # measurement aid: every (id, window, sub-window, error, CPU-vs-CPU) row of this config
+        os.makedirs(dump, exist_ok=True)
+        np.save(os.path.join(dump, what.split(" ")[0] + "_windows_rows.npy"), rows)
     assert len(bad) == 0, msg + f"; beyond 1e-5: {[(int(r[0]), int(r[1]), int(r[2]), float(r[3])) for r in bad[:20]]}"
     assert not len(loose) or loose[:, 3].max() <= SUB_FLAG_BOUND, msg
     return msg
@@ -108,7 +112,7 @@ def _windows_of_job(W, make_job, ks_all, what, coarse_windows=None):
         em, ef = helpers.window_errors(eoff, mask_rc, feat, W.boundary(w + 1, ks_all))
         for i, k in enumerate(ks_all):
             if not W.flagged[k, w]:
-                rows.append((W.ids[k], w, -1, max(em[i], ef[i]), W.z["cond50"][k, w]))
+                rows.append((W.ids[k], w, -1, max(em[i], ef[i]), W.cond50[k, w]))
         ks = np.asarray([k for k in ks_all if W.flagged[k, w]], np.int64)
         if not len(ks):
             continue
