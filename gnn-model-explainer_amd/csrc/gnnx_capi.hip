@@ -547,10 +547,11 @@ static Params make_params(gnnx_handle h, const gnnx_hyper* hy, const float* A, c
     p.graph_mode = h->prob.graph_mode;
     if (hy) {
         p.num_iters = hy->num_iters;
+        p.opt = hy->opt;
         p.lr = (float)hy->lr;
-        p.beta2 = (float)hy->beta2;
+        p.beta2 = (float)(hy->opt == 2 ? hy->alpha : hy->beta2);
         p.omb1 = (float)(1.0 - hy->beta1);
-        p.omb2 = (float)(1.0 - hy->beta2);
+        p.omb2 = (float)(1.0 - (hy->opt == 2 ? hy->alpha : hy->beta2));
         p.eps = (float)hy->eps;
         p.c_size = hy->c_size;
         p.c_feat_size = hy->c_feat_size;
@@ -560,11 +561,19 @@ static Params make_params(gnnx_handle h, const gnnx_hyper* hy, const float* A, c
     return p;
 }
 
-static void adam_scalars(const gnnx_hyper* hy, int it, float* step_size, float* bc2s) {
-    const double b1 = 1.0 - std::pow(hy->beta1, (double)(it + 1));
-    const double b2 = 1.0 - std::pow(hy->beta2, (double)(it + 1));
-    *step_size = (float)(hy->lr / b1);
-    *bc2s = (float)std::sqrt(b2);
+// per-iteration scalars of the optimiser (adam_update, gnnx_kernels.hpp): `it` = steps already taken (first_iter + k), `k` = index
+// of the iteration within this call (the learning-rate schedule is per call)
+static void adam_scalars(const gnnx_hyper* hy, int it, float* step_size, float* bc2s, int k = -1) {
+    const double lr = (hy->lr_schedule && k >= 0) ? hy->lr_schedule[k] : hy->lr;
+    if (hy->opt == 0) {
+        const double b1 = 1.0 - std::pow(hy->beta1, (double)(it + 1));
+        const double b2 = 1.0 - std::pow(hy->beta2, (double)(it + 1));
+        *step_size = (float)(lr / b1);
+        *bc2s = (float)std::sqrt(b2);
+    } else {
+        *step_size = (float)lr;
+        *bc2s = (hy->opt == 1 && it > 0) ? (float)hy->momentum : 0.0f;   // SGD: the momentum buffer starts as the first gradient
+    }
 }
 
 // which tile tables a launch sequence walks: all targets, or only the streaming ("big") set of a hybrid run
@@ -631,7 +640,7 @@ static int enqueue_job(gnnx_handle h, const Tables& tb, const gnnx_hyper* hy, co
         launch_forward(h, tb, p, it, s);
         launch_backward(h, tb, p, it, s);
         float ss, b2;
-        adam_scalars(hy, first_iter + it, &ss, &b2);
+        adam_scalars(hy, first_iter + it, &ss, &b2, it);
         if (it + 1 < hy->num_iters)
             launch_mask<true, true>(h, tb, p, it, ss, b2, s);
         else
@@ -716,6 +725,8 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
     if (!h->prob.graph_mode && !yhat) return fail("yhat is required in node mode (Laplacian term)");
     if (workspace_bytes < h->ws_bytes) return fail("workspace too small");
     if (hy->num_iters < 1) return fail("num_iters must be >= 1");
+    if (hy->opt < 0 || hy->opt > 3) return fail("opt must be 0 (Adam), 1 (SGD), 2 (RMSprop) or 3 (Adagrad)");
+    if (hy->lr_schedule && hy->use_graph) return fail("a learning-rate schedule cannot be captured into a hipGraph (use_graph = 0)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* lossp = hy->record_loss ? loss : nullptr;
     if (hy->record_loss && !loss) return fail("record_loss set but loss buffer is null");
@@ -738,14 +749,14 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
         if (int rc = init_stream_state(h, p, s)) return rc;
     if (resident) {
         HIPCK(hipEventRecord(h->ev_in, s));
-        if (!h->d_adam || h->adam_first != rs.first_iter || std::memcmp(&h->adam_for, hy, sizeof(gnnx_hyper)) != 0) {
+        if (!h->d_adam || hy->lr_schedule || h->adam_first != rs.first_iter || std::memcmp(&h->adam_for, hy, sizeof(gnnx_hyper)) != 0) {
             if (h->d_adam) {
                 HIPCK(hipStreamSynchronize(s));   // an earlier run of this plan may still be reading the table (its side lanes join `s`)
                 (void)pool_free(h->d_adam);
             }
             h->adam_host.resize(2 * (size_t)hy->num_iters);
             for (int it = 0; it < hy->num_iters; ++it)
-                adam_scalars(hy, rs.first_iter + it, &h->adam_host[2 * it], &h->adam_host[2 * it + 1]);
+                adam_scalars(hy, rs.first_iter + it, &h->adam_host[2 * it], &h->adam_host[2 * it + 1], it);
             HIPCK(pool_malloc(&h->d_adam, sizeof(float) * h->adam_host.size()));
             HIPCK(upload_sync(h->d_adam, h->adam_host.data(), sizeof(float) * h->adam_host.size()));
             h->adam_for = *hy;

@@ -98,7 +98,8 @@ struct Params {
     int32_t D, H, O, C;
     int32_t graph_mode;
     int32_t num_iters;
-    float lr, beta2, eps;
+    int32_t opt;        // 0 Adam, 1 SGD with momentum, 2 RMSprop, 3 Adagrad (gnnx_hyper.opt)
+    float lr, beta2, eps;   // beta2: Adam's second-moment decay, or RMSprop's alpha
     float omb1, omb2;   // (float)(1 - beta1), (float)(1 - beta2) with the subtraction in DOUBLE, as torch passes them to lerp_ / addcmul_
     float c_size, c_feat_size, c_ent, c_lap;
 };
@@ -124,6 +125,12 @@ __device__ __forceinline__ float exp_(float x) { return expf(x); }
 #endif
 __device__ __forceinline__ float sigmoidf_(float x) { return rcp_(1.0f + exp_(-x)); }
 
+// v + v[lane ^ 32] / v + v[lane ^ 16].  (Measured in round 3: the gfx950 lane-swap instructions v_permlane32_swap_b32 /
+// v_permlane16_swap_b32 in place of the ds_bpermute_b32 these shuffles compile to changed the iteration of the sparse resident
+// kernel by 0.1 of 11.3 us - the LDS crossbar round trip is not what the chain waits for - so the portable form stays.)
+__device__ __forceinline__ float xor32_sum(float v) { return v + __shfl_xor(v, 32); }
+__device__ __forceinline__ float xor16_sum(float v) { return v + __shfl_xor(v, 16); }
+
 // row of the 32x32 MFMA accumulator held in register r of a lane in half h (lane>>5); column = lane&31
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -135,14 +142,29 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // windowed parity test against the reference's own optimiser state, tests/test_windowed_parity.py).
 // step_size = lr / (1 - beta1^k), bc2s = sqrt(1 - beta2^k), both evaluated in double on the host.
 __device__ __forceinline__ void adam_update(float& theta, float& m, float& v, float g, float omb1, float beta2, float omb2,
-                                            float eps, float step_size, float bc2s) {
-    m = m + (g - m) * omb1;
-    v = v * beta2 + omb2 * g * g;
+                                            float eps, float step_size, float bc2s, int opt = 0) {
+    if (opt == 0) {   // Adam (uniform branch: the optimiser is a property of the whole job)
+        m = m + (g - m) * omb1;
+        v = v * beta2 + omb2 * g * g;
 #ifndef GNNX_IEEE_MATH
-    theta = theta - step_size * (m * rcp_(sqrt_(v) * (1.0f / bc2s) + eps));   // (1 / bc2s: uniform, hoisted out of the per-entry code)
+        theta = theta - step_size * (m * rcp_(sqrt_(v) * (1.0f / bc2s) + eps));   // (1 / bc2s: uniform, hoisted out of the per-entry code)
 #else
-    theta = theta + (-step_size * m) / (sqrtf(v) / bc2s + eps);   // addcdiv_: self + value * t1 / t2, denom = sqrt(v) / bc2s + eps
+        theta = theta + (-step_size * m) / (sqrtf(v) / bc2s + eps);   // addcdiv_: self + value * t1 / t2, denom = sqrt(v) / bc2s + eps
 #endif
+        return;
+    }
+    // The other optimisers utils/train_utils.py:11-16 can build (torch defaults), same per-entry state slots (m, v), the scalars of
+    // iteration k from the host table: step_size = lr_k (after the scheduler), bc2s = momentum factor (SGD: 0 at the first step).
+    //   opt 1  SGD(momentum=0.95): buf = g at the first step, else buf * 0.95 + g; p += -lr * buf               (torch/optim/sgd.py)
+    //   opt 2  RMSprop(alpha=0.99, eps): sq = sq * alpha + (1 - alpha) g g; p += (-lr * g) / (sqrt(sq) + eps)   (rmsprop.py)
+    //   opt 3  Adagrad(eps=1e-10): sum += g g; p += (-lr * g) / (sqrt(sum) + eps)                               (adagrad.py)
+    if (opt == 1) {
+        m = m * bc2s + g;
+        theta = theta + (-step_size) * m;
+    } else {
+        v = (opt == 2) ? v * beta2 + omb2 * g * g : v + g * g;
+        theta = theta + (-step_size * g) / (sqrtf(v) + eps);
+    }
 }
 
 enum ConvMode { FWD1 = 0, FWD2 = 1, FWD3 = 2, BWD3 = 3, BWD2 = 4, BWD1 = 5 };
@@ -914,7 +936,7 @@ __global__ __launch_bounds__(256, 4) void k_mask(Params p, const MaskTile* tiles
                 // d(entropy)/dS = log(1-S) - log(S) = -M exactly (S = sigma(M)): no logs on the update path
                 float gji = (gc + p.c_size + p.c_ent * mask_dent<RELU>(Mji, Sji) * inv_n2) * mask_dact<RELU>(Mji, Sji);
                 if (RELU && !(gi < n && gj < n)) gji = 0.0f;  // padding entries (M = 0) do not exist in the reference: relu'(0) * log(0) is NaN
-                adam_update(Mji, mji, vji, gji, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
+                adam_update(Mji, mji, vji, gji, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
                 sPM[j * LS + i] = Mji;
                 sPm[j * LS + i] = mji;
                 sPv[j * LS + i] = vji;
@@ -936,7 +958,7 @@ __global__ __launch_bounds__(256, 4) void k_mask(Params p, const MaskTile* tiles
             float gij = (gc + p.c_size + p.c_ent * mask_dent<RELU>(Mij, Sij) * inv_n2) * mask_dact<RELU>(Mij, Sij);
             if (RELU && !(gi < n && gj < n)) gij = 0.0f;
             float mij = mo[e], vij = vo[e];
-            adam_update(Mij, mij, vij, gij, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
+            adam_update(Mij, mij, vij, gij, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
             Mo[e] = Mij;
             mo[e] = mij;
             vo[e] = vij;
@@ -1009,7 +1031,7 @@ __global__ __launch_bounds__(256, 4) void k_mask(Params p, const MaskTile* tiles
         for (int rb = 0; rb < (ld >> 5); ++rb) dsum += p.df[((size_t)(tm.offR >> 5) + rb) * FS + tid];
         const float gf = (dsum + p.c_feat_size / (float)p.D) * ph * (1.0f - ph);
         float fnew = fcur, m = p.mf[o], v = p.vf[o];
-        adam_update(fnew, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
+        adam_update(fnew, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
         p.mf[o] = m;
         p.vf[o] = v;
         p.f[(iter + 1) & 1][o] = fnew;

@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void k_resident(Params p, const int32_t* targe
                         const float S = sigmoidf_(Mo[pi][e]);
                         const float gij = (gc + p.c_size - p.c_ent * Mo[pi][e] * inv_n2) * S * (1.0f - S);
                         float Mn = Mo[pi][e], mn = mo[pi][e], vn = vo[pi][e];
-                        adam_update(Mn, mn, vn, gij, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
+                        adam_update(Mn, mn, vn, gij, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
                         Mo[pi][e] = Mn;
                         mo[pi][e] = mn;
                         vo[pi][e] = vn;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void k_resident(Params p, const int32_t* targe
                         const float S = sigmoidf_(Mp[pi][e]);
                         const float gji = (gc + p.c_size - p.c_ent * Mp[pi][e] * inv_n2) * S * (1.0f - S);
                         float Mn = Mp[pi][e], mn = mp[pi][e], vn = vp[pi][e];
-                        adam_update(Mn, mn, vn, gji, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
+                        adam_update(Mn, mn, vn, gji, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
                         Mp[pi][e] = Mn;
                         mp[pi][e] = mn;
                         vp[pi][e] = vn;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void k_resident(Params p, const int32_t* targe
             const float ph = sh.phi[tid];
             const float gf = (sh.dfp[tid] + p.c_feat_size / (float)p.D) * ph * (1.0f - ph);
             float fn = sh.fcur[tid], m = sh.mf[tid], v = sh.vf[tid];
-            adam_update(fn, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
+            adam_update(fn, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
             sh.fcur[tid] = fn;
             sh.mf[tid] = m;
             sh.vf[tid] = v;

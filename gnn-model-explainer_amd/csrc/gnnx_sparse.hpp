@@ -22,6 +22,7 @@
 // are needed only for the logged size/entropy scalars, so loss logging stays on the dense streaming path).
 // Mathematics as in gnnx_kernels.hpp / SURVEY.md Appendix A; parity: tests/test_emu_kernels.py, tests/test_gpu_parity.py.
 #pragma once
+#include <type_traits>
 #include "gnnx_kernels.hpp"
 #include "gnnx_resident.hpp"
 
@@ -230,14 +231,15 @@ __device__ __forceinline__ void sparse_forward_rowlocal_impl(const float (&zq)[N
         const float b = (k < din) ? zq[u] : 0.0f;
         c16 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c16, 0, 0, 0);
     }
-    float ss = 0.0f;
+    float sp[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // four partial sums: the 16 squares are not one dependent FMA chain
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
         const int c = acc_row(g, h);
         c16[g] = (c < dout) ? c16[g] + bv[g] : 0.0f;
-        ss = fmaf(c16[g], c16[g], ss);
+        sp[g & 3] = fmaf(c16[g], c16[g], sp[g & 3]);
     }
-    ss += __shfl_xor(ss, 32);
+    float ss = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+    ss = xor32_sum(ss);
     const float rnorm = fmaxf(sqrt_(ss), 1e-12f);
     const float rinv = rcp_(rnorm);
 #pragma unroll
@@ -281,10 +283,10 @@ __device__ __forceinline__ void sparse_store_cols(const f32x16& c16, float* row,
 template <int NQ, bool WIDE = false>
 __device__ __forceinline__ f32x16 sparse_backward_rowlocal(const float (&du)[NQ], const float (&uu)[NQ], float rnorm,
                                                           const float* sW, int din, int dout, int li, int h) {
-    float sdot = 0.0f;
+    float sd2[2] = {0.0f, 0.0f};
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) sdot = fmaf(du[q], uu[q], sdot);
-    sdot += __shfl_xor(sdot, 32);
+    for (int q = 0; q < NQ; ++q) sd2[q & 1] = fmaf(du[q], uu[q], sd2[q & 1]);
+    float sdot = xor32_sum(sd2[0] + sd2[1]);
     const float rinv = rcp_(rnorm);
     f32x16 c16;
 #pragma unroll
@@ -325,7 +327,7 @@ __device__ __forceinline__ float bcast_first(float v) {
 // every lane <- sum over lanes 0..31 (4 DPP shifts + one cross-row shuffle + SGPR broadcast instead of 5-6 ds_bpermute)
 __device__ __forceinline__ float sum_lanes_0_31(float v) {
     const float r = row_sum16(v);
-    return bcast_first(r + __shfl_xor(r, 16));
+    return bcast_first(xor16_sum(r));
 }
 
 // Rows split over several slots (adjacent lanes of one 16-lane DPP row, same column half): a segmented suffix sum in
@@ -904,13 +906,111 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         SYNC();
         } else {
         // ======== row t of layer 3 (the only row the reference reads, explain.py:713), head, dE, dZ3[t] ========
+        // Register form (wave 0 alone owns t and its neighbours - fuseB - and the class leaves room for its operands): the whole
+        // chain z -> y = z W3 + b -> normalise -> logits -> softmax -> dE -> dY3 -> dZ3 stays in registers.  Lane c holds column c
+        // of every vector; a vector is broadcast with v_readlane (SGPR operand of the FMA), reductions are DPP row sums; the
+        // weights a lane needs (column / row c of W3, its three entries of every head row) are loaded at the START of the phase,
+        // before anything that depends on this iteration, so their LDS latency hides behind the row-t gather.  The LDS form below
+        // (round 2) staged every intermediate through LDS: six store -> wave sync -> load round trips plus 100 dependent loads,
+        // 2.5 of the 12.5 us of an iteration of syn1's largest target.
+        const bool reg_head = (NT != 1024) && fuseB;
+        if (reg_head) {
+            if (wave == 0) {
+                // (class count as a compile-time bound of the unrolled loops: the reference's heads have 2 or 4 classes)
+                auto head = [&](auto CHc) {
+                constexpr int CH = decltype(CHc)::value;
+                const int c = li;
+                const int kc = (EXACT || c < H) ? c : 0;      // row of W3 this lane reads in the backward product (rows >= H do not exist)
+                float w3[2 * HQ];
+#pragma unroll
+                for (int k = 0; k < 2 * HQ; ++k) w3[k] = sW3[((EXACT || k < H) ? k : 0) * 33 + c];     // W3[k][c]: forward, output column c
+                const float b3 = sh.bias[2][c];
+                const float e1 = (c < H) ? relu_(sU1[tr * sH + kc]) : 0.0f;    // relu(U1[t]), relu(U2[t]): layer 2 of this iteration is done
+                const float e2 = (c < H) ? relu_(sU2[tr * sH + kc]) : 0.0f;
+                // row t of Abar . relu(U2): the two half-lanes take alternate entries
+                float z = 0.0f;
+                for (int e = rt0 + h; e < rt1; e += 2) z = fmaf(sAb[e], relu_(sU2[(int)scol[e] * sH + kc]), z);
+                z = (c < H) ? z : 0.0f;
+                z = xor32_sum(z);
+                const int zi = __builtin_bit_cast(int, z);
+                float y0 = 0.0f, y1 = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 2 * HQ; k += 2) {
+                    const float za = __builtin_bit_cast(float, __builtin_amdgcn_readlane(zi, k));
+                    const float zb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(zi, k + 1));
+                    y0 = fmaf((EXACT || k < H) ? za : 0.0f, w3[k], y0);
+                    y1 = fmaf((EXACT || k + 1 < H) ? zb : 0.0f, w3[k + 1], y1);
+                }
+                // the head rows (three entries per lane and class) are fetched while the norm is reduced
+                float wp[3][CH], bpv[CH];
+#pragma unroll
+                for (int cc = 0; cc < CH; ++cc) {
+                    const int cr = cc < C ? cc : 0;
+#pragma unroll
+                    for (int l = 0; l < 3; ++l) wp[l][cc] = sWp[cr * 96 + l * 32 + c];
+                    bpv[cc] = sh.sbp[cr];
+                }
+                const float y = (c < O) ? y0 + y1 + b3 : 0.0f;
+                const float ss = sum_lanes_0_31(y * y);
+                const float rnorm = fmaxf(sqrtf(ss), 1e-12f);
+                const float u3 = y / rnorm;  // U3[t][c]
+                // logits: three products per lane and class, one 32-lane sum per class
+                float zl[CH];
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int cc = 0; cc < CH; ++cc) {
+                    const float pc = fmaf(wp[0][cc], e1, fmaf(wp[1][cc], e2, wp[2][cc] * u3));
+                    zl[cc] = (cc < C) ? sum_lanes_0_31(pc) + bpv[cc] : -3.0e38f;
+                    mx = fmaxf(mx, zl[cc]);
+                }
+                float sum = 0.0f;
+#pragma unroll
+                for (int cc = 0; cc < CH; ++cc) {
+                    zl[cc] = (cc < C) ? expf(zl[cc] - mx) : 0.0f;
+                    sum += zl[cc];
+                }
+                // g = p - onehot(y_gt) (explain.py:713-714, 750-753); dE = Wp^T g, the lane's entry of each of the three slices
+                float dE1 = 0.0f, dE2 = 0.0f, dE3 = 0.0f;
+#pragma unroll
+                for (int cc = 0; cc < CH; ++cc) {
+                    const float g = (cc < C) ? zl[cc] / sum - ((cc == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
+                    dE1 = fmaf(wp[0][cc], g, dE1);
+                    dE2 = fmaf(wp[1][cc], g, dE2);
+                    dE3 = fmaf(wp[2][cc], g, dE3);
+                }
+                // the backward operand W3[c][k] takes the registers of the forward one; its latency hides behind the dY3 reduction
+#pragma unroll
+                for (int k = 0; k < 2 * HQ; ++k) w3[k] = sW3[kc * 33 + ((EXACT || k < O) ? k : 0)];
+                const float du3 = (c < O) ? dE3 : 0.0f;
+                const float sd = sum_lanes_0_31(du3 * u3);
+                const float dy3 = (du3 - u3 * sd) / rnorm;  // dY3[t][c]
+                const int di = __builtin_bit_cast(int, dy3);
+                float v0 = 0.0f, v1 = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 2 * HQ; k += 2) {
+                    const float da = __builtin_bit_cast(float, __builtin_amdgcn_readlane(di, k));
+                    const float db = __builtin_bit_cast(float, __builtin_amdgcn_readlane(di, k + 1));
+                    v0 = fmaf((EXACT || k < O) ? da : 0.0f, w3[k], v0);
+                    v1 = fmaf((EXACT || k + 1 < O) ? db : 0.0f, w3[k + 1], v1);
+                }
+                if (h == 0) {
+                    sh.dz3[c] = (c < H) ? v0 + v1 : 0.0f;
+                    sh.dEs[c] = dE1;
+                    sh.dEs[32 + c] = dE2;
+                    sh.dEs[64 + c] = dE3;
+                }
+                };
+                if (C <= 4) head(std::integral_constant<int, 4>{}); else head(std::integral_constant<int, RES_CMAX>{});
+            }
+            SYNC_B();
+        } else {
         const int nwz = fuseB ? 1 : NW;  // waves that share row t's entries
         if (!fuseB || wave == 0) {   // row t of Abar . relu(U2): its entries dealt over the waves, lane = column; partials summed in wave order
             float z = 0.0f;
             if (li < H)
                 for (int e = rt0 + 2 * wave + h; e < rt1; e += 2 * nwz)
                     z = fmaf(sAb[e], relu_(sU2[(int)scol[e] * sH + li]), z);
-            z += __shfl_xor(z, 32);
+            z = xor32_sum(z);
             if (h == 0) sh.dfw[wave][li] = z;  // dfw is free until the layer-1 backward
         }
         SYNC_B();
@@ -996,6 +1096,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             if (h == 0) sh.dz3[c] = (c < H) ? v : 0.0f;
         }
         SYNC_B();
+        }
         // ======== dZ2 (rank-1: dX2[r] = Abar[r][t] dZ3[t] + dE2 on row t) and g3; dZ2 overwrites U2 row by row ========
         if (SB.wave_active) {
             const bool first = SB.first;
@@ -1016,7 +1117,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 du[q] = (u > 0.0f) ? dx : 0.0f;
                 uu[q] = u;
             }
-            gpart += __shfl_xor(gpart, 32);
+            gpart = xor32_sum(gpart);
             if (first && h == 0) sG3[r] = gpart;
             const f32x16 c16 = sparse_backward_rowlocal<HQ, EXACT>(du, uu, first ? sRn2[r] : 1.0f, sW2, H, H, li, h);
             sparse_store_cols(c16, sU2 + r * sH, H, first, h);  // dZ2[r][.]: every U2 value of this row is already in registers
@@ -1126,7 +1227,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 v += row_shl<4>(v);
                 v += row_shl<2>(v);
                 v += row_shl<1>(v);
-                v += __shfl_xor(v, 16);
+                v = xor16_sum(v);
                 if (li == 0) sh.dfw[wave][2 * q + h] = v;
             }
         }
@@ -1195,12 +1296,12 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 {
                     const float S = Sij[q];
                     const float g = (gc + p.c_size - p.c_ent * Mij[q] * inv_n2) * S * (1.0f - S);
-                    adam_update(Mij[q], mij[q], vij[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
+                    adam_update(Mij[q], mij[q], vij[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
                 }
                 {
                     const float S = Sji[q];
                     const float g = (gc + p.c_size - p.c_ent * Mji[q] * inv_n2) * S * (1.0f - S);
-                    adam_update(Mji[q], mji[q], vji[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
+                    adam_update(Mji[q], mji[q], vji[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
                 }
             }
         SYNC();  // dfp complete; every reader of sAb / sArt of this iteration is done
@@ -1208,7 +1309,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             const float ph = sh.phi[tid];
             const float gf = (sh.dfp[tid] + p.c_feat_size / (float)D) * ph * (1.0f - ph);
             float fn = sh.fcur[tid], m = sh.mf[tid], v = sh.vf[tid];
-            adam_update(fn, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
+            adam_update(fn, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
             sh.fcur[tid] = fn;
             sh.mf[tid] = m;
             sh.vf[tid] = v;

@@ -660,7 +660,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             float z = 0.0f;
             if (li < H)
                 for (int e = 2 * wave + h; e < degT; e += 2 * NW) z = fmaf(sAb[e], relu_(gU2[(int)scol[e] * FS + li]), z);
-            z += __shfl_xor(z, 32);
+            z = xor32_sum(z);
             if (h == 0) sh.dfw[wave][li] = z;
         }
         __syncthreads();
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 du[q] = (u > 0.0f) ? dx : 0.0f;
                 uu[q] = u;
             }
-            gpart += __shfl_xor(gpart, 32);
+            gpart = xor32_sum(gpart);
             if (nbr && h == 0) sG3[SB.bmask] = gpart;
             const f32x16 c16 = sparse_backward_rowlocal<HQ>(du, uu, first ? sRn2[round * (NT / 2) + wave * TILE + li] : 1.0f, sW2, H, H, li, h);
             sparse_store_cols(c16, gU2 + r * FS, H, first, h);
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 v += row_shl<4>(v);
                 v += row_shl<2>(v);
                 v += row_shl<1>(v);
-                v += __shfl_xor(v, 16);
+                v = xor16_sum(v);
                 if (li == 0) sh.dfw[wave][2 * q + h] = v;
             }
         }
@@ -932,12 +932,12 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 {
                     const float S = sigmoidf_(Mij[u]);
                     const float g = (gc + p.c_size - p.c_ent * Mij[u] * inv_n2) * S * (1.0f - S);
-                    adam_update(Mij[u], mij[u], vij[u], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
+                    adam_update(Mij[u], mij[u], vij[u], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
                 }
                 {
                     const float S = sigmoidf_(Mji[u]);
                     const float g = (gc + p.c_size - p.c_ent * Mji[u] * inv_n2) * S * (1.0f - S);
-                    adam_update(Mji[u], mji[u], vji[u], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
+                    adam_update(Mji[u], mji[u], vji[u], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
                 }
             }
 #pragma unroll
@@ -961,7 +961,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             const float ph = sh.phi[tid];
             const float gf = (sh.dfp[tid] + p.c_feat_size / (float)D) * ph * (1.0f - ph);
             float fn = sh.fcur[tid], m = sh.mf[tid], v = sh.vf[tid];
-            adam_update(fn, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
+            adam_update(fn, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
             sh.fcur[tid] = fn;
             sh.mf[tid] = m;
             sh.vf[tid] = v;
@@ -1010,8 +1010,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             a = w * (0.5f * (Si + Sj));   // the mask of this iteration's forward
             const float gi = (gc + p.c_size - p.c_ent * Mij * inv_n2) * Si * (1.0f - Si);
             const float gj = (gc + p.c_size - p.c_ent * Mji * inv_n2) * Sj * (1.0f - Sj);
-            adam_update(Mij, mij, vij, gi, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
-            adam_update(Mji, mji, vji, gj, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s);
+            adam_update(Mij, mij, vij, gi, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
+            adam_update(Mji, mji, vji, gj, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
         }
         p.Abar[tm.offQ + (size_t)i * ld + j] = a;
         p.Abar[tm.offQ + (size_t)j * ld + i] = a;

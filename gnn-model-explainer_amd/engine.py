@@ -57,7 +57,11 @@ class _Hyper(ctypes.Structure):
     _fields_ = [("lr", ctypes.c_double), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double),
                 ("c_size", ctypes.c_float), ("c_feat_size", ctypes.c_float), ("c_ent", ctypes.c_float),
                 ("c_lap", ctypes.c_float), ("num_iters", ctypes.c_int32), ("record_loss", ctypes.c_int32),
-                ("use_graph", ctypes.c_int32), ("use_resident", ctypes.c_int32)]
+                ("use_graph", ctypes.c_int32), ("use_resident", ctypes.c_int32), ("opt", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("momentum", ctypes.c_double), ("alpha", ctypes.c_double), ("lr_schedule", ctypes.POINTER(ctypes.c_double))]
+
+
+OPTIMIZERS = {"adam": 0, "sgd": 1, "rmsprop": 2, "adagrad": 3}      # utils/train_utils.py:9-16
 
 
 class _Resume(ctypes.Structure):
@@ -89,11 +93,24 @@ class Hyper:
     c_lap: float = 1.0
     record_loss: bool = False
     use_graph: bool = False
-    use_resident: bool = True     # on-chip-resident kernels for small (n <= 96) node-mode targets
+    use_resident: bool = True     # the on-chip-resident kernels for the targets the plan routed to them
+    opt: str = "adam"             # "adam" | "sgd" (momentum) | "rmsprop" (alpha, eps) | "adagrad" (eps): utils/train_utils.py:9-16
+    momentum: float = 0.95        # train_utils.py:12
+    alpha: float = 0.99           # torch.optim.RMSprop default
+    lr_schedule: Optional[np.ndarray] = None   # [num_iters] learning rate of every iteration (an LR scheduler's trace), None = constant
 
     def c(self):
-        return _Hyper(self.lr, self.beta1, self.beta2, self.eps, self.c_size, self.c_feat_size, self.c_ent,
-                      self.c_lap, int(self.num_iters), int(self.record_loss), int(self.use_graph), int(self.use_resident))
+        hy = _Hyper(self.lr, self.beta1, self.beta2, self.eps, self.c_size, self.c_feat_size, self.c_ent,
+                    self.c_lap, int(self.num_iters), int(self.record_loss), int(self.use_graph), int(self.use_resident),
+                    OPTIMIZERS[self.opt], 0, self.momentum, self.alpha, None)
+        if self.lr_schedule is not None:
+            sch = np.ascontiguousarray(self.lr_schedule, np.float64)
+            if sch.shape != (int(self.num_iters),):
+                raise ValueError("lr_schedule must hold num_iters learning rates")
+            hy._keep = sch                      # the struct only borrows the host array
+            hy.lr_schedule = sch.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+            hy.use_graph = 0                    # a schedule is a per-launch argument of the streaming kernels: no hipGraph replay
+        return hy
 
 
 def library_path():

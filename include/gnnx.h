@@ -67,11 +67,18 @@ typedef struct {
     int32_t num_iters;   /* args.num_epochs (explain.py:137) */
     int32_t record_loss; /* 1: fill loss[T][num_iters][GNNX_LOSS_TERMS] (explain.py:808-819 scalars) */
     int32_t use_graph;   /* 1: capture the launch sequence once into a hipGraph and replay it */
-    int32_t use_resident; /* 1: use the on-chip-resident kernels (one workgroup per target, all iterations in one launch,
-                           * node mode): a batch whose targets all have n <= 96 (3 blocks of 32 rows) runs entirely
-                           * in them; otherwise its n <= 32 targets do, beside the streaming kernels of the others.
-                           * The environment variable GNNX_RESIDENT_MAX_BLOCKS=0..3, read by gnnx_plan_create, lowers
-                           * the block limit.  Ignored with record_loss. */
+    int32_t use_resident; /* 1: targets may take the on-chip-resident kernels gnnx_plan_analyze routed them to (gnnx_get_route);
+                           * 0: every target runs on the dense streaming kernels.  Ignored (= 0) with record_loss. */
+    /* The other optimisers / LR schedulers the reference's build_optimizer can return (utils/train_utils.py:7-22):
+     *   opt          0 = Adam (lr, beta1, beta2, eps above), 1 = SGD(momentum), 2 = RMSprop(alpha, eps), 3 = Adagrad(eps) - torch
+     *                defaults otherwise (no weight decay, dampening 0, not centered, lr_decay 0);
+     *   lr_schedule  HOST pointer to num_iters doubles = the learning rate of every iteration of this call, as the scheduler
+     *                (StepLR / CosineAnnealingLR, stepped after every optimiser step: explain.py:144-146) leaves it in
+     *                optimizer.param_groups[0]["lr"]; NULL = constant lr. */
+    int32_t opt;
+    int32_t reserved;
+    double momentum, alpha;
+    const double* lr_schedule;
 } gnnx_hyper;
 
 int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* model, gnnx_handle* out);

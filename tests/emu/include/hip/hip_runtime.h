@@ -65,6 +65,7 @@ inline void __threadfence_block() {}
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() emu::wave_sync()
 #define __builtin_amdgcn_readfirstlane(v) emu::shfl_i((v), 0)
+#define __builtin_amdgcn_readlane(v, k) emu::shfl_i((v), (k))
 // DPP row_shl:S (dpp_ctrl 0x100 + S, all rows / banks, bound_ctrl): lane l <- lane l + S of its 16-lane row, else 0
 inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     (void)old; (void)row_mask; (void)bank_mask; (void)bound_ctrl;

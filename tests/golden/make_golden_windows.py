@@ -19,12 +19,18 @@ window is; `sens50[t][w]` therefore measures the window's own conditioning: the 
 starting mask entries are perturbed by +-1 ulp from the unperturbed closed-form run.  Windows with max(cond50, sens50) > 2e-6
 ("flagged": a ReLU gate / max-pool tie flips inside them, or Adam amplifies a one-ulp difference beyond 2e-6 within 50 epochs)
 additionally get the four 10-epoch snapshots inside the window and `cond10` / `sens10` of their five sub-windows.
+Third criterion, `gate50[t][w]` (and `gate10`): the smallest distance of any decision that reaches the loss from its boundary during
+the window of the closed-form run - |U| at the ReLU gates (models.py:241, 251) of the rows the prediction reads, and in graph mode
+the margin of every max-pool (models.py:283-300).  A margin below 5e-7 is inside the fp32 round-off of the sum that produced
+it: which side of the gate an implementation lands on is then decided by its summation order, and Adam's scale-free step turns
+that one different gradient into a 1e-4 .. 1e-3 difference within a few iterations (every window in which the GPU kernels left
+the reference by more than 1e-5 while both CPU probes saw nothing had such a gate: 7e-8, 8e-8, 0, 1.4e-7, 0, 0, 1e-7, 0).
 
 Fixtures written (tests/golden/<name>_windows.npz):
   targets (or graphs) [T], eoff [T+1] (upper-triangle edges, order of <name>_full_explain.npz), epochs [6] = 50..300,
-  M / m / v [6][E][2] float32 (entry (r,c), entry (c,r)), f / mf / vf [6][T][D], cond50 / sens50 [T][6],
+  M / m / v [6][E][2] float32 (entry (r,c), entry (c,r)), f / mf / vf [6][T][D], cond50 / sens50 / gate50 [T][6],
   fine_tw [F][2] = (target index, window) of the flagged windows, fine_off [F+1] (edge offsets), fine_M / fine_m / fine_v [4][Ef][2]
-  (epochs 50 w + 10, 20, 30, 40), fine_f / fine_mf / fine_vf [4][F][D], cond10 / sens10 [F][5];
+  (epochs 50 w + 10, 20, 30, 40), fine_f / fine_mf / fine_vf [4][F][D], cond10 / sens10 / gate10 [F][5];
   config4 only: the whole job description (vals / feat_sig of the 300-epoch output, cond_mask / cond_feat, weights) because it
   covers 512 graphs where config4_explain.npz has 64.
 """
@@ -102,19 +108,42 @@ def abar_edges(Mrc, w=1.0):
 TRIALS, ULP = 4, 2e-7     # sensitivity probe: TRIALS runs with the mask entries on the edges multiplied by 1 + ULP (u - 0.5), u ~ U[0, 1): +-1 ulp
 
 
+GATE = 5e-7     # a ReLU input / max-pool margin this close to zero is inside fp32 round-off of a sum of <= 20 products of magnitude <= 1
+
+
+def gate_margin(o):
+    """Smallest distance from a decision boundary in the last iteration of closed-form oracle `o`: |U_l| at the ReLU gates that reach
+    the loss (node mode: layer 1 on the rows within two hops of the target, layer 2 on the target and its neighbours - the only rows
+    whose activations the prediction reads; graph mode: every row) and, in graph mode, the margin between the largest
+    and the next smaller value of every max-pooled column (models.py:283-300; bitwise equal rows - the zero-padded ones - tie
+    harmlessly: both implementations take the first)."""
+    U = o.stages["U"]
+    if not o.graph_mode:
+        return float(min(np.abs(U[0][o._lvl <= 2]).min(), np.abs(U[1][o._lvl <= 1]).min()))
+    g = float(min(np.abs(U[0]).min(), np.abs(U[1]).min()))
+    for a in (np.maximum(U[0], 0), np.maximum(U[1], 0), U[2]):
+        top = a.max(0)
+        below = np.where(a < top[None, :], a, -np.inf).max(0)
+        live = (top > 0) & np.isfinite(below)
+        if live.any():
+            g = min(g, float((top - below)[live].min()))
+    return g
+
+
 def _oracle_dev(o, rc, state, ref_end, k0, steps, seed=None):
     """Closed-form oracle started from the reference's `state` (after k0 steps), `steps` iterations -> deviation from ref_end
     (seed None), or - sensitivity of the window to its own input - (deviation from ref_end, largest deviation of TRIALS runs from
     1-ulp-perturbed starts from the unperturbed run)."""
     if seed is not None:
         base = _oracle_out(o, rc, state, k0, steps)
+        gate = o._gate_min
         dev = _dev(base, ref_end)
         rng = np.random.default_rng(seed)
         sens = 0.0
         for _ in range(TRIALS):
             M = (state[0] * (1.0 + ULP * (rng.random(state[0].shape) - 0.5))).astype(np.float32)
             sens = max(sens, _dev(_oracle_out(o, rc, (M,) + tuple(state[1:]), k0, steps), base))
-        return dev, sens
+        return dev, sens, gate
     return _dev(_oracle_out(o, rc, state, k0, steps), ref_end)
 
 
@@ -133,8 +162,10 @@ def _oracle_out(o, rc, state, k0, steps):
     o.vM[r, c], o.vM[c, r] = v[:, 0], v[:, 1]
     o.f, o.mf, o.vf = f.astype(np.float32).copy(), mf.astype(np.float32).copy(), vf.astype(np.float32).copy()
     o.step = k0
+    o._gate_min = np.inf
     for _ in range(steps):
         o.iterate()
+        o._gate_min = min(o._gate_min, gate_margin(o))
         o.M[o._off_edges] = o._M0[o._off_edges]      # dead entries (never reach an output): parked, so they cannot saturate the sigmoid
     return (np.stack([o.M[r, c], o.M[c, r]], 1), None, None, o.f.copy())
 
@@ -146,17 +177,25 @@ def classify_windows(sub_adj, sub_feat, sd, gt, pred_label, new_idx, mask0, rec,
                                      graph_mode=graph_mode)
     rc = np.nonzero(np.triu(sub_adj, 1))
     o._off_edges, o._M0 = (sub_adj == 0), np.asarray(mask0, np.float32)
+    n = sub_adj.shape[0]
+    o._lvl = np.zeros(n, np.int64)
+    if not graph_mode:       # hop level of every row from the target (off-diagonal pattern of the sub-adjacency)
+        pat = (sub_adj != 0) & ~np.eye(n, dtype=bool)
+        o._lvl[:] = 9
+        o._lvl[new_idx] = 0
+        for d in (1, 2):
+            o._lvl[(pat[o._lvl == d - 1].sum(0) > 0) & (o._lvl > d)] = d
     E, D = len(rc[0]), sub_feat.shape[1]
     z2 = np.zeros((E, 2), np.float32)
     zd = np.zeros(D, np.float32)
     M0 = np.stack([mask0[rc[0], rc[1]], mask0[rc[1], rc[0]]], 1).astype(np.float32)
     state = lambda k: (M0, z2, z2, zd, zd, zd) if k == 0 else rec[k]
-    cond50, cond10 = np.zeros((2, EPOCHS // WIN), np.float32), {}     # [0]: CPU vs CPU, [1]: 1-ulp sensitivity
+    cond50, cond10 = np.zeros((3, EPOCHS // WIN), np.float32), {}     # [0]: CPU vs CPU, [1]: 1-ulp sensitivity, [2]: smallest gate margin
     for w in range(EPOCHS // WIN):
         cond50[:, w] = _oracle_dev(o, rc, state(WIN * w), rec[WIN * (w + 1)], WIN * w, WIN, seed=(seed, w))
-        if cond50[:, w].max() > FLAG:
+        if cond50[:2, w].max() > FLAG or cond50[2, w] < GATE:
             cond10[w] = np.asarray([_oracle_dev(o, rc, state(WIN * w + SUB * s), rec[WIN * w + SUB * (s + 1)], WIN * w + SUB * s, SUB,
-                                                seed=(seed, w, s)) for s in range(WIN // SUB)], np.float32).T      # [2][5]
+                                                seed=(seed, w, s)) for s in range(WIN // SUB)], np.float32).T      # [3][5]
     return cond50, cond10
 
 
@@ -268,7 +307,8 @@ def assemble(res, id_name):
     out = {id_name: np.asarray([r["key"] for r in res], np.int64), "eoff": eoff,
            "epochs": np.arange(WIN, EPOCHS + 1, WIN).astype(np.int64), "sub": np.int64(SUB), "flag": np.float64(FLAG),
            "cond50": np.stack([r["cond50"][0] for r in res]).astype(np.float32),
-           "sens50": np.stack([r["cond50"][1] for r in res]).astype(np.float32), "trials": np.int64(TRIALS), "ulp": np.float64(ULP)}
+           "sens50": np.stack([r["cond50"][1] for r in res]).astype(np.float32), "trials": np.int64(TRIALS), "ulp": np.float64(ULP),
+           "gate50": np.stack([r["cond50"][2] for r in res]).astype(np.float32), "gate": np.float64(GATE)}
     for j, nm in enumerate(("M", "m", "v")):
         out[nm] = np.stack([cat(i, j) for i in range(nck)]).astype(np.float32)
     for j, nm in ((3, "f"), (4, "mf"), (5, "vf")):
@@ -279,6 +319,7 @@ def assemble(res, id_name):
     out["fine_off"] = np.cumsum([0] + [res[k]["nedges"] for k, _, _, _ in fine]).astype(np.int64)
     out["cond10"] = np.asarray([c10[0] for _, _, c10, _ in fine], np.float32).reshape(-1, WIN // SUB)
     out["sens10"] = np.asarray([c10[1] for _, _, c10, _ in fine], np.float32).reshape(-1, WIN // SUB)
+    out["gate10"] = np.asarray([c10[2] for _, _, c10, _ in fine], np.float32).reshape(-1, WIN // SUB)
     D = res[0]["coarse"][0][3].shape[0]
     for j, nm in enumerate(("fine_M", "fine_m", "fine_v")):
         out[nm] = (np.stack([np.concatenate([st[s][j] for _, _, _, st in fine]) for s in range(nsub)]).astype(np.float32)
@@ -291,10 +332,13 @@ def assemble(res, id_name):
 
 def _report(name, out, t0):
     c50, c10 = np.maximum(out["cond50"], out["sens50"]), np.maximum(out["cond10"], out["sens10"])
-    print(f"{name}: CPU vs CPU alone flags {int((out['cond50'] > FLAG).sum())} windows, the 1-ulp sensitivity probe alone {int((out['sens50'] > FLAG).sum())}")
+    c50 = np.where(out["gate50"] < GATE, np.maximum(c50, 1.0), c50)          # a gate inside round-off of zero flags the window whatever the probes saw
+    c10 = np.where(out["gate10"] < GATE, np.maximum(c10, 1.0), c10)
+    print(f"{name}: CPU vs CPU alone flags {int((out['cond50'] > FLAG).sum())} windows, the 1-ulp sensitivity probe alone {int((out['sens50'] > FLAG).sum())}, "
+          f"a gate / pool margin below {GATE:g} alone {int((out['gate50'] < GATE).sum())}")
     T, W = c50.shape
     fl = c50 > FLAG
-    print(f"{name}: {T} targets x {W} windows in {time.time() - t0:.0f} s; flagged 50-epoch windows (CPU vs CPU or 1-ulp sensitivity > 2e-6): {int(fl.sum())} of {T * W} "
+    print(f"{name}: {T} targets x {W} windows in {time.time() - t0:.0f} s; flagged 50-epoch windows (CPU vs CPU or 1-ulp sensitivity > 2e-6, or a gate margin < 5e-7): {int(fl.sum())} of {T * W} "
           f"({int((c50 > 1e-5).sum())} > 1e-5, max {c50.max():.2e}; per window {fl.sum(0).tolist()}); targets with a flagged window: "
           f"{int(fl.any(1).sum())}; their 10-epoch sub-windows: {int((c10 > FLAG).sum())} of {c10.size} > 2e-6, {int((c10 > 1e-5).sum())} > 1e-5 "
           f"(max {c10.max() if c10.size else 0:.2e})", flush=True)

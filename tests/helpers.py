@@ -158,7 +158,7 @@ class Windows:
         self.nsub = self.win // self.sub
         # conditioning of a window = max(CPU-vs-CPU deviation, deviation under a 1-ulp perturbation of its own start) - both measured on
         # the CPU by make_golden_windows.py before any implementation under test ran
-        self.cond50 = np.maximum(z["cond50"], z["sens50"]) if "sens50" in z.files else z["cond50"]
+        self.cond50 = self._conditioning(z["cond50"], z["sens50"], z["gate50"], float(z["gate"]))
         self.flagged = self.cond50 > WIN_FLAG                       # [T, W]
         self.fine_row = {(int(k), int(w)): i for i, (k, w) in enumerate(z["fine_tw"])}
 
@@ -190,8 +190,16 @@ class Windows:
             return self.boundary(w + 1, ks)
         return self.fine(w, s, ks)
 
+    @staticmethod
+    def _conditioning(cond, sens, gate, gate_thr):
+        """One number per window, all measured on the CPU by make_golden_windows.py before any implementation under test ran: the
+        larger of the CPU-vs-CPU deviation and the deviation under a 1-ulp perturbation of the window's own start, or 1.0 when a
+        decision that reaches the loss (ReLU gate / max-pool) comes within fp32 round-off (`gate`) of its boundary inside the window."""
+        c = np.maximum(cond, sens)
+        return np.where(gate < gate_thr, np.maximum(c, 1.0), c)
+
     def cond10(self, w, ks):
-        c = np.maximum(self.z["cond10"], self.z["sens10"]) if "sens10" in self.z.files else self.z["cond10"]
+        c = self._conditioning(self.z["cond10"], self.z["sens10"], self.z["gate10"], float(self.z["gate"]))
         return np.stack([c[self.fine_row[(int(k), int(w))]] for k in ks]) if len(ks) else np.zeros((0, self.nsub))
 
 
