@@ -8,19 +8,24 @@
 N = 1 (BASELINE.json configs[1], the configuration the metric is quoted on): syn1 BA-House, ALL 400 house-motif nodes
 (300..699) as ONE batched job, 300 mask-optimisation iterations, 3-hop sub-graphs, Adam lr 0.1, fp32.  The graph and the
 trained GCN come from tests/golden/syn1_ckpt.npz (minted by the reference's own train.py); initial masks follow the seed
-protocol torch.manual_seed(1000 + node).  A "step" = one pass of the hot path over the whole batch: the initial masks are
-re-spread from the resident RNG stream (gnnx_scatter_masks) and the 300 iterations run.  Inputs are resident in HBM
-before the timed region (`value`); the end-to-end rate of one batch - device-side k-hop + packing, host RNG, H2D,
-optimisation, edge-list D2H - is reported beside it as `pcie_inclusive`.
+protocol torch.manual_seed(1000 + node).  A "step" = one batch through the WHOLE hot path with only the graph resident in HBM
+(SURVEY.md section 8(d)): device k-hop, plan, device-side packing, routing, seeded host RNG, H2D + scatter, the 300 iterations,
+gather + D2H of the masks; consecutive batches overlap their stages (pipeline.BatchPipeline) and `value` = targets x K / wall time
+from the first submission to the last result.  The optimisation alone on resident inputs (what rounds 1-2 reported) is the
+secondary `loop_only`; `--workload config4` times BASELINE configs[3] (graph mode, 4337 molecule-like graphs) the same way.
 
 N > 1 (BASELINE.json configs[4], the north-star scaling curve): BA-House scaled to 100k nodes, ONE fixed set of 16384
 motif targets (seed-fixed) split over the ranks by longest-processing-time-first on parallel.target_cost(n); every
 rank optimises its shard as one batched job and the masks are gathered as edge entries through RCCL INSIDE the timed
 region.  Strong scaling: the total work is fixed, value = 16384 * K / max-over-ranks time.
 
-Every run checks parity in the same process: the GPU masks of all targets against the reference's own outputs
-(tests/golden/*_full_explain.npz, produced by running /root/reference) and - at N = 1 - against the CPU oracle on the
-CPU-baseline sample; the run FAILS if a well-conditioned target deviates by more than 1e-5.
+Every run checks parity in the same process: the GPU masks of all targets - the ones the TIMED end-to-end batches produced -
+against the reference's own outputs (tests/golden/*_full_explain.npz, produced by running /root/reference) and - at N = 1 - against
+the CPU oracle on the CPU-baseline sample.  The rule is helpers.parity_verdict: of the targets two CPU implementations agree on to
+2e-6 after 300 epochs, >= 99 % must lie within 1e-5 of an outcome of the reference and all of them within 5e-3 (the largest branch
+jump seen on the CPU); the run FAILS otherwise.  The chaotic targets (CPU-vs-CPU up to 0.97 on Tree-Grid) cannot be gated at the full
+horizon by any implementation; what pins them - every target, iterations 0..300 - is the windowed test against the reference's own
+optimiser state (tests/test_windowed_parity.py), not this gate.
 """
 import argparse
 import gc

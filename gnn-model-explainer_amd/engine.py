@@ -356,6 +356,11 @@ class MaskOptimJob:
         self.n = np.ascontiguousarray(neighbors.sizes, np.int32) if on_device else np.asarray([len(nb) for nb in neighbors], np.int32)
         if on_device and target_rows is None:
             target_rows = neighbors.rows
+        if np.any(np.asarray(target_rows) < 0):
+            # gnnx_khop reports -1 when a target is not in its own walk set (an isolated node, or a directed graph): the reference's
+            # node_idx_new = sum(row[:node_idx]) would silently explain whichever node sits there (explain.py:496)
+            bad = np.nonzero(np.asarray(target_rows) < 0)[0]
+            raise IndexError("targets %s are not in their own k-hop walk sets (isolated nodes?)" % bad[:8].tolist())
         self._create_plan(np.asarray(target_rows, np.int32), np.asarray(gt_labels, np.int32))
         self._alloc_device()
         if on_device:        # lists produced by khop_device: nothing crosses PCIe
@@ -383,6 +388,15 @@ class MaskOptimJob:
         self._enter()
         _check(self.lib, self.lib.gnnx_plan_analyze(self.handle, self.A.data_ptr(), self._stream()))
         self._leave()
+
+    def set_complete_graphs(self):
+        """Replace every target's packed adjacency by the complete graph on its n nodes, A = 1 - I (ExplainModule.forward with
+        unconstrained=True, explain.py:688-691: the masked adjacency is not multiplied by adj).  Re-run analyze() afterwards."""
+        A = np.zeros(self.Q, np.float32)
+        for v, n in zip(self._square_views(A), self.n):
+            v[:n, :n] = 1.0 - np.eye(int(n), dtype=np.float32)
+        self.A.copy_(torch.from_numpy(A))
+        self._eoff = None          # the edge layout belongs to the old adjacency
 
     def adjacency(self):
         """Per-target dense sub-adjacencies as packed on the device (host copies)."""
@@ -500,6 +514,8 @@ class MaskOptimJob:
         if raw.dtype != torch.float32 or raw.numel() != int(self.lib.gnnx_total_raw(self.handle)):
             raise ValueError("raw mask stream must hold sum(n^2) float32 values")
         self._raw = raw.to(self.device, non_blocking=True)
+        if self._raw.data_ptr() == raw.data_ptr():      # host "device" (the emulator): .to() made no copy and the caller may reuse its buffer
+            self._raw = raw.clone()
         c = _PIN_CACHE
         if c["buf"] is not None and raw.is_pinned() and raw.untyped_storage().data_ptr() == c["buf"].untyped_storage().data_ptr():
             c["event"] = torch.cuda.Event()           # the shared pinned buffer may be refilled once this copy is done
@@ -566,9 +582,12 @@ class MaskOptimJob:
     def auc(self, real, vals: Optional[torch.Tensor] = None):
         """ROC-AUC of the batch's edge scores against 0/1 ground truth `real` [E] (explain.py:325-328) from exact pair counts
         computed on the device (gnnx_auc_counts).  -> (auc, positives, negatives)"""
+        self._edge_layout()
         if vals is None:
             vals = self.gather_edges_device()
         E = int(self._eoff[-1])
+        if len(real) != E or vals.numel() < E:
+            raise ValueError("auc: `real` / `vals` must hold one entry per upper-triangle edge of the batch (%d)" % E)
         real_d = torch.from_numpy(np.ascontiguousarray(real, np.uint8)).to(self.device)
         scratch = torch.empty(max(E, 1), dtype=torch.float32, device=self.device)
         counts = torch.zeros(4, dtype=torch.int64, device=self.device)

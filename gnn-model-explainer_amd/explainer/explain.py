@@ -14,9 +14,10 @@ mask-optimisation path (`model="exp"`, `unconstrained=False`, sigmoid mask, Adam
 
 `--mask-bias` is accepted (the reference's bias mask provably stays exactly 0, see _check_supported); `mask_act="ReLU"` runs on
 the dense streaming kernels and reproduces the reference's NaN behaviour; `--bn` runs on the dense streaming kernels.
-Options the HIP path does not implement raise NotImplementedError (never a silent difference):
-`method="att"`, non-Adam optimisers / LR schedulers,
-`unconstrained=True`, `model="att"`, num_gc_layers != 3.  `model="grad"` (the gradient baseline, explain.py:125-133)
+`--opt sgd | rmsprop | adagrad`, `--opt-scheduler step | cos` and `unconstrained=True` run on the same kernels (round 3).
+Configurations the kernels do not implement - `method="att"`, `model="att"`, num_gc_layers != 3, encoders with add_self / dropout /
+a hidden head, a node explanation on a graph-mode Explainer - run on explainer/torch_route.py: the reference's algorithm as torch
+autograd on the HIP device through the caller's model, announced by a RuntimeWarning; never a silent difference.  `model="grad"` (the gradient baseline, explain.py:125-133)
 runs on the engine too (Explainer.explain_grad).
 Plotting / TensorBoard / alignment post-processing of the reference is out of scope.
 """
@@ -39,8 +40,6 @@ def _check_supported(args):
     # mask_act: "sigmoid", or "ReLU" (explain.py:669-670, 757-760) on the dense streaming kernels.  Like the reference, ReLU
     # yields NaN masks whenever an initial mask entry lies outside (0, 1] (its entropy term takes log(1 - relu(M))) - i.e.
     # always with the reference's own N(1, .) initialisation (tests/golden/flags_explain.npz: 100 % NaN).
-    if getattr(args, "mask_act", "sigmoid") not in ("sigmoid", "ReLU"):
-        raise NotImplementedError("mask_act=%r: 'sigmoid' and 'ReLU' are implemented" % args.mask_act)
     # --mask-bias (explain.py:657-661, 674-677) is accepted: the reference creates mask_bias = 0 and adds
     # sym(ReLU6(6 sym(mask_bias)) / 6) to the masked adjacency.  ReLU6 has zero gradient at 0 (torch: hardtanh backward is
     # strict), so mask_bias never receives a gradient, Adam leaves it at exactly 0 and the added term is exactly 0 in every
@@ -48,17 +47,107 @@ def _check_supported(args):
     # produced by running the reference with mask_bias=True).  The same kernels therefore serve both settings.
     # --bn (apply_bn, models.py:222-228, 241-253) runs on the dense streaming kernels (forward and backward through the row-wise
     # standardisation; pinned to the reference by tests/golden/flags_explain.npz)
+    # --opt adam | sgd | rmsprop | adagrad and --opt-scheduler none | step | cos (utils/train_utils.py:7-22) all run in the kernels'
+    # per-entry update (gnnx_hyper.opt, .lr_schedule); anything else makes the reference's build_optimizer fail too
+    if getattr(args, "opt", "adam") not in OPTIMIZER_EPS:
+        raise ValueError("opt=%r: the reference's build_optimizer knows adam, sgd, rmsprop, adagrad" % args.opt)
+    if (getattr(args, "opt_scheduler", "none") or "none") not in ("none", "step", "cos"):
+        raise ValueError("opt_scheduler=%r: the reference's build_optimizer knows none, step, cos" % args.opt_scheduler)
+
+
+OPTIMIZER_EPS = {"adam": 1e-8, "sgd": 0.0, "rmsprop": 1e-8, "adagrad": 1e-10}      # torch defaults of the optimisers train_utils.py:9-16 builds
+
+
+def _torch_optimizer(args, params):
+    """The optimiser / scheduler pair the reference's build_optimizer returns for `args` (utils/train_utils.py:7-22), built over
+    `params`: the `.optimizer` / `.scheduler` surface of ExplainModule, and the source of the per-epoch learning rates."""
+    import torch.optim as optim
+    lr = float(args.lr)
+    make = {"adam": lambda: optim.Adam(params, lr=lr, weight_decay=0.0), "sgd": lambda: optim.SGD(params, lr=lr, momentum=0.95, weight_decay=0.0),
+            "rmsprop": lambda: optim.RMSprop(params, lr=lr, weight_decay=0.0), "adagrad": lambda: optim.Adagrad(params, lr=lr, weight_decay=0.0)}
+    opt = make[getattr(args, "opt", "adam")]()
+    kind = getattr(args, "opt_scheduler", "none") or "none"
+    sched = None
+    if kind == "step":
+        sched = optim.lr_scheduler.StepLR(opt, step_size=args.opt_decay_step, gamma=args.opt_decay_rate)
+    elif kind == "cos":
+        sched = optim.lr_scheduler.CosineAnnealingLR(opt, T_max=args.opt_restart)
+    return sched, opt
+
+
+def _lr_schedule(args, num_iters):
+    """Learning rate of every epoch under --opt-scheduler: torch's own scheduler stepped on a one-parameter dummy, once after every
+    optimiser step as the reference's loop does (explain.py:144-146), so the doubles are the ones the reference's optimiser sees."""
+    if (getattr(args, "opt_scheduler", "none") or "none") == "none":
+        return None
+    import warnings
+    sched, opt = _torch_optimizer(args, [nn.Parameter(torch.zeros(1))])
+    lrs = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(int(num_iters)):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sched.step()
+    return np.asarray(lrs, np.float64)
+
+
+def _unmasked_features_state(job):
+    """ExplainModule.forward(unconstrained=True) does NOT apply the feature mask (explain.py:688-707: `x * feat_mask` sits in the other
+    branch): start the engine with feat_mask = 40 - sigmoid(40) == 1.0f exactly and its gradient factor phi (1 - phi) == 0, so the
+    features stay unmasked for the whole run."""
+    from ..engine import AdamState
+    f = torch.zeros(job.T, 3, FEAT_STRIDE, dtype=torch.float32)
+    f[:, 0, :job.D] = 40.0
+    return AdamState(0, None, None, f.to(job.device))
+
+
+def _regulariser_only_feat_mask(args, D, num_iters):
+    """What the reference's feat_mask parameter does in an unconstrained run: only the size term mean(sigmoid(f)) reaches it
+    (explain.py:763-766), a scalar recursion through the optimiser - evaluated with the very torch optimiser (host, D values)."""
+    f = nn.Parameter(torch.zeros(D))
+    sched, opt = _torch_optimizer(args, [f])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(int(num_iters)):
+            opt.zero_grad()
+            (COEFFS["feat_size"] * torch.mean(torch.sigmoid(f))).backward()
+            opt.step()
+            if sched is not None:
+                sched.step()
+    return f.detach().numpy()
+
+
+def _torch_route_reason(args, model, state_dict=None):
+    """None when the HIP kernels implement this configuration, else what makes it take explainer/torch_route.py (SURVEY.md section 8(b):
+    configurations the kernels do not cover run on a PyTorch-ROCm restatement of the reference path instead of silently differing)."""
     if getattr(args, "method", "base") != "base":
-        raise NotImplementedError("method=%r: only 'base' is implemented on the HIP path" % args.method)
-    if getattr(args, "opt", "adam") != "adam" or getattr(args, "opt_scheduler", "none") != "none":
-        raise NotImplementedError("only Adam without LR scheduler (utils/train_utils.py:9-10, 17-18) is implemented")
-    if getattr(args, "num_gc_layers", 3) != 3:
-        raise NotImplementedError("num_gc_layers=%r: the HIP path implements 3 layers" % args.num_gc_layers)
+        return "method=%r (models.py:62-68)" % args.method
+    if getattr(args, "mask_act", "sigmoid") not in ("sigmoid", "ReLU"):
+        return "mask_act=%r" % args.mask_act
+    sd = state_dict if state_dict is not None else model.state_dict()
+    extra = [k for k in sd if k.startswith("conv_block.") and not k.startswith("conv_block.0.")]
+    if extra or "conv_block.0.weight" not in sd:
+        return "an encoder with %d graph-convolution layers (the kernels implement 3)" % (2 + len({k.split(".")[1] for k in sd if k.startswith("conv_block.")}))
+    if any(k.endswith("self_weight") or k.endswith("att_weight") for k in sd):
+        return "an encoder with add_self / attention weights"
+    if "pred_model.weight" not in sd or "conv_first.bias" not in sd:
+        return "an encoder without bias or with a hidden prediction head"
+    if sd["pred_model.weight"].shape[1] != sd["conv_first.weight"].shape[1] + sd["conv_block.0.weight"].shape[1] + sd["conv_last.weight"].shape[1]:
+        return "an encoder without concatenated embeddings"
+    if max(sd["conv_first.weight"].shape + sd["conv_last.weight"].shape) > FEAT_STRIDE or sd["pred_model.weight"].shape[0] > 32:
+        return "feature / hidden / class widths beyond 32"
+    if any(getattr(m, "dropout", 0.0) and m.dropout > 0.001 for m in model.modules()):
+        return "dropout in the encoder (active during the optimisation: explain.py:135)"
+    return None
 
 
 def _hyper(args, **kw):
-    return Hyper(num_iters=int(args.num_epochs), lr=float(args.lr), c_size=COEFFS["size"], c_feat_size=COEFFS["feat_size"],
-                 c_ent=COEFFS["ent"], c_lap=COEFFS["lap"], **kw)
+    opt = getattr(args, "opt", "adam")
+    n = int(kw.pop("num_iters", args.num_epochs))
+    return Hyper(num_iters=n, lr=float(args.lr), eps=OPTIMIZER_EPS[opt], opt=opt, lr_schedule=_lr_schedule(args, n),
+                 c_size=COEFFS["size"], c_feat_size=COEFFS["feat_size"], c_ent=COEFFS["ent"], c_lap=COEFFS["lap"], **kw)
 
 
 def _np(a):
@@ -166,7 +255,8 @@ class Explainer:
                                                       _np(self.pred)[graph_idx], device=_ENGINE["device"])
         return self._dev_graph[graph_idx]
 
-    def explain_batch(self, node_indices=None, graph_indices=None, graph_idx=0, record_loss=False, use_graph=False, stats=False):
+    def explain_batch(self, node_indices=None, graph_indices=None, graph_idx=0, record_loss=False, use_graph=False, stats=False,
+                      unconstrained=False):
         """All targets as ONE job on the GPU. Returns list of float64 masked adjacencies (reference layout).
 
         Node mode runs device-side end to end: the k-hop walk sets (gnnx_khop), the dense sub-adjacencies, feature rows
@@ -174,9 +264,21 @@ class Explainer:
         initial masks (the caller's torch CPU generator, one normal_ per target in list order, like
         construct_edge_mask) and receives the masks as edge lists (gnnx_gather_edges).  With torch.distributed
         initialised (one process per GPU) the targets are sharded over the ranks by modelled GPU time (parallel.target_cost, parallel.run_sharded) and
-        every rank returns the full list."""
+        every rank returns the full list.
+
+        unconstrained=True (explain.py:688-691): the optimised masked adjacency is sym(sigmoid(mask)) * (1 - I) - not multiplied by
+        the sub-graph's adjacency - i.e. the same optimisation on the COMPLETE graph over the sub-graph's nodes; the result is still
+        multiplied by sub_adj (explain.py:209-211).  Runs on the same kernels with the packed adjacency replaced by 1 - I."""
         begin = time.time()
         lib, device = _ENGINE["lib"], _ENGINE["device"]
+        reason = _torch_route_reason(self.args, self.model)
+        if reason is None and self.graph_mode and graph_indices is None:
+            # --graph-idx N --explain-node K (explainer_main.py:257-258 with a graph-mode Explainer): the node head on a graph encoder
+            reason = "a node explanation on a graph-mode Explainer"
+        if reason is not None:
+            out = self._torch_route(node_indices, graph_indices, graph_idx, unconstrained, "exp", reason)
+            self.last_time = time.time() - begin
+            return out
         sd = self.model.state_dict()
         relu = getattr(self.args, "mask_act", "sigmoid") == "ReLU"
         bn = bool(getattr(self.args, "bn", False))
@@ -188,17 +290,20 @@ class Explainer:
             built = [self._graph_subgraph(g) for g in targets]
             subs = [b[0] for b in built]
             masks = [init_edge_mask(s.adj.shape[0]) for s in subs]     # same RNG stream as ExplainModule.__init__ per target
+            if unconstrained:
+                subs = [Subgraph(1.0 - np.eye(s.adj.shape[0], dtype=np.float32), s.feat, s.gt_label, 0, None, None) for s in subs]
             job = MaskOptimJob(subs, sd, graph_mode=True, device=device, lib=lib, mask_relu=relu, bn=bn)
-            res = job.run(masks, _hyper(self.args, record_loss=record_loss, use_graph=use_graph and len(targets) > 1))
+            hy = _hyper(self.args, record_loss=record_loss, use_graph=use_graph and len(targets) > 1)
+            job.set_masks(masks)
+            job.launch(hy, state=_unmasked_features_state(job) if unconstrained else None)
+            res = job.fetch(hy)
+            if unconstrained:
+                res.feat_mask[:] = _regulariser_only_feat_mask(self.args, job.D, hy.num_iters)
             job.close()
             self.last_time = time.time() - begin
             self.last_result = res
             # explain.py:209-211: float32 mask * float64 sub_adj -> float64
             return [ma.astype(np.float64) * np.asarray(b[1], np.float64) for ma, b in zip(res.masked_adj, built)]
-        if self.graph_mode:
-            # the reference's CLI allows --graph-idx N --explain-node K on a graph-mode Explainer (explain(node, graph_mode=False));
-            # that combination needs the node head on a graph encoder, which the HIP path does not implement
-            raise NotImplementedError("node explanations on a graph-mode Explainer are not implemented on the HIP path")
         targets = np.asarray([int(v) for v in node_indices], np.int64)
         graph = self._device_graph(graph_idx)
         dn = khop_device(graph, targets, self.n_hops, lib=lib)
@@ -219,14 +324,26 @@ class Explainer:
             else:
                 sub_dn = khop_device(graph, targets[idxs], self.n_hops, lib=lib)
                 sub_raw = torch.cat([raw[raw_off[i]:raw_off[i + 1]] for i in idxs])
-            job = MaskOptimJob.from_csr(graph, sub_dn, None, labels[idxs], sd, lib=lib, mask_relu=relu, bn=bn)
+            job = MaskOptimJob.from_csr(graph, sub_dn, None, labels[idxs], sd, lib=lib, mask_relu=relu, bn=bn, analyze=not unconstrained)
+            true_adj = None
+            if unconstrained:
+                true_adj = job.adjacency()                 # sub_adj of every target (explain.py:209-211 multiplies the result by it)
+                job.set_complete_graphs()                  # the optimisation sees 1 - I
+                job.analyze()
             job.set_masks_raw(sub_raw)
-            job.launch(hy)
-            if graph.binary:            # explain.py:209-211 multiplies by sub_adj: a no-op for a 0/1 adjacency
+            job.launch(hy, state=_unmasked_features_state(job) if unconstrained else None)
+            if unconstrained:
+                res = job.fetch(hy)
+                res.feat_mask[:] = _regulariser_only_feat_mask(self.args, job.D, hy.num_iters)
+                out = [ma.astype(np.float64) * a.astype(np.float64) for ma, a in zip(res.masked_adj, true_adj)]
+                last.update(feat_mask=res.feat_mask, loss=res.loss, edges=None, rows=sub_dn.rows)
+            elif graph.binary:            # explain.py:209-211 multiplies by sub_adj: a no-op for a 0/1 adjacency
                 em = job.fetch_edges()
                 out = [em.dense(k) for k in range(len(idxs))]
                 last.update(feat_mask=em.feat_mask, loss=job.loss.cpu().numpy() if record_loss else None, edges=em, rows=sub_dn.rows)
-                if stats and len(idxs) == len(targets):
+                # the device AUC scores EVERY upper-triangle edge; make_pred_real only the entries with masked_adj > 0 (explain.py:544):
+                # the two agree while every edge value is finite and positive - checked, else the host path below decides
+                if stats and len(idxs) == len(targets) and not relu and bool(np.isfinite(em.masked_adj).all() and (em.masked_adj > 0).all()):
                     # explain.py:306-351 on the device, on the edge lists: denoise_graph(threshold_num=20) per target and the
                     # ROC-AUC of all targets' edge scores against the motif ground truth
                     real = self._motif_truth(em, sub_dn.rows)
@@ -249,6 +366,38 @@ class Explainer:
         self.last_result = _Result(last.get("feat_mask"), last.get("loss"), last.get("edges"))
         self.last_result.denoised, self.last_result.auc = last.get("denoised"), last.get("auc")
         self.last_rows = dn.rows
+        return out
+
+    def _torch_route(self, node_indices, graph_indices, graph_idx, unconstrained, kind, reason):
+        """One target after the other through explainer/torch_route.py (torch autograd on the HIP device through self.model)."""
+        from . import torch_route
+        device = torch_route.device_for(_ENGINE["device"])
+        out, fms = [], []
+        if graph_indices is not None:
+            for g in graph_indices:
+                sub, sub_adj = self._graph_subgraph(g)
+                ma, fm = torch_route.explain_one(self.model, sub_adj, sub.feat, _np(self.label[g]), None, 0, self.args, dict(COEFFS), _torch_optimizer,
+                                                 init_edge_mask(sub.adj.shape[0]), self.graph_idx, True, unconstrained, kind, device, reason)
+                out.append(ma)
+                fms.append(fm)
+        else:
+            for v in node_indices:
+                if self.graph_mode:                       # explain(node, graph_idx=g) on a graph-mode Explainer: the whole graph g, node v
+                    new, sub_adj, nb = int(v), _np(self.adj[graph_idx]), np.arange(_np(self.adj[graph_idx]).shape[0])
+                    sub_feat, sub_label = _np(self.feat[graph_idx]), np.full(len(nb), int(_np(self.label[graph_idx])))
+                    pred_label = np.full(len(nb), int(np.argmax(_np(self.pred)[0][graph_idx])))
+                else:
+                    new, sub_adj, sub_feat, sub_label, nb = self.extract_neighborhood(int(v), graph_idx)
+                    if len(nb) == 0:
+                        raise IndexError("node %d has an empty %d-hop neighbourhood" % (v, self.n_hops))
+                    pred_label = np.argmax(_np(self.pred)[graph_idx][nb], axis=1)
+                ma, fm = torch_route.explain_one(self.model, sub_adj, sub_feat, sub_label, pred_label, int(new), self.args, dict(COEFFS),
+                                                 _torch_optimizer, init_edge_mask(len(nb)), self.graph_idx, False, unconstrained, kind, device, reason)
+                out.append(ma)
+                fms.append(fm)
+        self.last_result = _Result(None, None, None)
+        self.last_result.feat_mask_sigmoid = np.stack(fms)
+        self.last_rows = None
         return out
 
     def explain_grad(self, node_indices, graph_idx=0, graph_mode=False):
@@ -284,20 +433,23 @@ class Explainer:
     # -- reference API ---------------------------------------------------------------------------
     def explain(self, node_idx, graph_idx=0, graph_mode=False, unconstrained=False, model="exp"):
         """Explain a single node (or graph) prediction — explain.py:74-221."""
-        if unconstrained:
-            raise NotImplementedError("unconstrained=True is not implemented on the HIP path")
         if model == "grad":
             masked_adj = self.explain_grad([node_idx], graph_idx=graph_idx, graph_mode=graph_mode)[0]
             fname = self._save(masked_adj, node_idx)
             print("Saved adjacency matrix to ", fname)
             return masked_adj
-        if model != "exp":
-            raise NotImplementedError("model=%r: the mask optimisation ('exp') and the gradient baseline ('grad') are implemented" % model)
+        if model != "exp":                                     # explain.py:200-208: any other name is the attention baseline
+            targets = dict(graph_indices=[graph_idx], node_indices=None) if graph_mode else dict(node_indices=[node_idx], graph_indices=None)
+            masked_adj = self._torch_route(graph_idx=graph_idx, unconstrained=unconstrained, kind=model,
+                                           reason="model=%r (the attention baseline, explain.py:200-208)" % model, **targets)[0]
+            fname = self._save(masked_adj, node_idx)
+            print("Saved adjacency matrix to ", fname)
+            return masked_adj
         if graph_mode:
-            masked_adj = self.explain_batch(graph_indices=[graph_idx], record_loss=self.print_training)[0]
+            masked_adj = self.explain_batch(graph_indices=[graph_idx], record_loss=self.print_training, unconstrained=unconstrained)[0]
         else:
             masked_adj = self.explain_batch(node_indices=[node_idx], graph_idx=graph_idx,
-                                            record_loss=self.print_training)[0]
+                                            record_loss=self.print_training, unconstrained=unconstrained)[0]
         if self.print_training and self.last_result.loss is not None:
             tr = self.last_result.loss[0]
             for epoch in (0, len(tr) - 1):
@@ -421,7 +573,10 @@ class ExplainModule(nn.Module):
         self.mask_bias = nn.Parameter(torch.zeros(n, n)) if getattr(args, "mask_bias", False) else None
         self.diag_mask = torch.ones(n, n) - torch.eye(n)
         self.coeffs = dict(COEFFS)
-        self.scheduler = None
+        # explain.py:620-622: build_optimizer(args, params) - a real torch optimiser / scheduler over the mirror's parameters: same
+        # `.optimizer` / `.scheduler` attributes, param_groups and (after optimize()) state as the reference's
+        params = [self.mask, self.feat_mask] + ([self.mask_bias] if self.mask_bias is not None else [])
+        self.scheduler, self.optimizer = _torch_optimizer(args, params)
         self.masked_adj = None
         self._node_idx = int(node_idx)
         lab = _np(label)
@@ -466,9 +621,32 @@ class ExplainModule(nn.Module):
         hy = _hyper(self.args, record_loss=record_loss, use_resident=False)
         if num_epochs is not None:
             hy.num_iters = int(num_epochs)
-        res = self._job.run([self.mask.detach().numpy()], hy)
+        job = self._job
+        job.set_masks([self.mask.detach().numpy()])
+        job.launch(hy, keep_state=True)
+        res = job.fetch(hy)
         with torch.no_grad():
             self.mask.copy_(torch.from_numpy(res.mask[0]))
             self.feat_mask.copy_(torch.from_numpy(res.feat_mask[0]))
         self.masked_adj = torch.from_numpy(res.masked_adj[0])[None]
+        # the optimiser state the reference's torch optimiser would hold now (the engine's moments, dense: the streaming kernels keep
+        # every entry), and the learning rate its scheduler would have left
+        n = self._sub.adj.shape[0]
+        st = job.state_out
+        sq = lambda a: torch.from_numpy(job._square_views(a.cpu().numpy())[0][:n, :n].copy())
+        fs = st.feat.cpu().numpy()[0, :, :self.feat_mask.numel()]
+        steps = torch.tensor(float(hy.num_iters))
+        names = {"adam": ("exp_avg", "exp_avg_sq"), "sgd": ("momentum_buffer", None), "rmsprop": (None, "square_avg"),
+                 "adagrad": (None, "sum")}[hy.opt]
+        for prm, m, v in ((self.mask, sq(st.m), sq(st.v)), (self.feat_mask, torch.from_numpy(fs[1].copy()), torch.from_numpy(fs[2].copy()))):
+            state = self.optimizer.state[prm]
+            if hy.opt != "sgd":
+                state["step"] = steps.clone()
+            if names[0]:
+                state[names[0]] = m
+            if names[1]:
+                state[names[1]] = v
+        if hy.lr_schedule is not None:
+            for g in self.optimizer.param_groups:
+                g["lr"] = float(_lr_schedule(self.args, hy.num_iters + 1)[-1])
         return res

@@ -130,23 +130,25 @@ int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hyper, const gnnx_resume* r
                     const float* yhat, float* M, float* Abar, float* feat_mask, float* loss, void* workspace,
                     size_t workspace_bytes, void* stream);
 
-/* Inspect the packed adjacency A (DEVICE pointer, the layout of gnnx_get_layout) and choose the kernel of every target:
- * targets whose EDGE state fits a compute unit (n <= 512, <= 2048 undirected edges, rows of <= 256 entries, LDS
- * budget; node and graph mode) take the sparse on-chip-resident kernel in the smallest of its three size classes
- * that holds them (single-tile node-mode targets that fit none keep the dense on-chip-resident kernel); larger
- * node-mode targets (n <= 4095, < 32768 undirected edges, <= 512 row slots within two hops of the target) take its
- * large variant with the row arrays in the workspace; either way it
- * optimises only the mask entries on edges - the only ones that reach an output of the reference
- * (explain.py:665-678, 209-211; non-edge entries of M then keep their initial values); the rest streams.
- * Optional: without this call the plan uses the split described at gnnx_hyper.use_resident.  Synchronises `stream`.
- * Environment: GNNX_SPARSE_RESIDENT=0 disables the sparse kernels, GNNX_SPARSE_LARGE=0 / GNNX_TINY_SPARSE=0 the large
- * variant / the 64-thread class, GNNX_DEBUG_ROUTE=1 prints the analysis of every target that ends up streaming. */
+/* Inspect the packed adjacency A (DEVICE pointer, the layout of gnnx_get_layout) and choose the kernel of every target.  All sparse
+ * routes optimise only the mask entries on EDGES of the sub-graph - the only ones that reach an output of the reference
+ * (explain.py:665-678, 209-211; non-edge entries of M then keep their initial values):
+ *   - edge state fits one compute unit (n <= 512, <= 2048 undirected edges, rows of <= 256 entries, LDS budget; node and graph mode):
+ *     the sparse on-chip-resident kernel, in the smallest size class that holds the target - 64 threads (n <= 32), 256 (n <= 128),
+ *     512 (node mode: <= 256 row slots within two hops of the target), 1024; node-mode batches of 512-thread and single-tile targets
+ *     run as ONE mixed launch;
+ *   - larger node-mode targets (n <= 16383, <= 8192 rows and < 65535 directed entries within two hops of the target):
+ *     k_sparse_large - the entries of the rows within two hops in LDS, row arrays in the workspace, far edges as closed recursions;
+ *   - single-tile node-mode targets that fit no sparse class: the dense on-chip-resident kernel;  everything else streams.
+ * Optional: without this call the plan uses the dense resident kernels for batches of <= 3 row blocks per target and streams the rest.
+ * Synchronises `stream`.  Environment: GNNX_SPARSE_RESIDENT=0 disables the sparse kernels, GNNX_SPARSE_LARGE=0 / GNNX_TINY_SPARSE=0 /
+ * GNNX_SPARSE_512=0 / GNNX_SPARSE_MIXED=0 single classes, GNNX_KEEP_256=0|1 the class merge of saturated batches, GNNX_DEBUG_ROUTE=1 prints
+ * the analysis of every target that ends up streaming. */
 int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream);
 
-/* The kernel every target is routed to (host array of num_targets entries): 0 = dense streaming kernels,
- * 1..3 = dense on-chip-resident kernel of that many 32-row blocks, 4 / 5 / 6 = sparse on-chip-resident kernel in its
- * 1024- / 256- / 64-thread size class (n <= 512 / 128 / 32), 7 = sparse kernel for larger node-mode targets
- * (n <= 4095; edge state in LDS, row arrays in the workspace), 8 = sparse on-chip-resident kernel, 512-thread class
+/* The kernel every target is routed to (host array of num_targets entries): 0 = dense streaming kernels, 1..3 = dense
+ * on-chip-resident kernel of that many 32-row blocks, 4 / 5 / 6 = sparse on-chip-resident kernel in its 1024- / 256- / 64-thread size
+ * class (n <= 512 / 128 / 32), 7 = k_sparse_large (node mode, n <= 16383), 8 = sparse on-chip-resident kernel, 512-thread class
  * (node mode, n <= 512, at most 256 row slots within two hops of the target). */
 int gnnx_get_route(gnnx_handle h, int32_t* route);
 

@@ -11,6 +11,8 @@ options_explain.npz (syn1 checkpoint of make_golden.py, seed protocol torch.manu
                                                    lr = the learning rate the scheduler leaves in optimizer.param_groups[0]["lr"] per epoch
   unc:<t>:masked_adj_edges / :feat_sig             Explainer.explain(t, unconstrained=True) (explain.py:688-691: the masked adjacency is
                                                    sym(sigmoid(mask)) * (1 - I), NOT multiplied by adj; the result still is, :209-211)
+  route:att | l4:...                               method="att" and num_gc_layers=4 encoders trained by the reference's train.py: weights, predictions and
+                                                   the explanations of two targets (the configurations explainer/torch_route.py serves)
   auc:<dataset>:<model>                            ROC-AUC the reference's explain_nodes_gnn_stats(range(400, 700, 5)) writes to
                                                    log/pr/auc_<dataset>_<model>.txt (explain.py:295-353) for syn1 / syn4, model exp | grad,
                                                    100 epochs (the CLI default), torch.manual_seed(0) before the call;
@@ -25,6 +27,11 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import make_golden as mg  # noqa: E402
+
+
+def mg_adj(work, io_utils):
+    with mg.quiet():
+        return io_utils.load_ckpt(mg.explain_args("syn1", work, 1))["cg"]["adj"][0]
 
 
 def main():
@@ -99,6 +106,47 @@ def main():
         v, fs, _ = one(t, unconstrained=True)
         out[f"unc:{t}:masked_adj_edges"], out[f"unc:{t}:feat_sig"] = v, fs
         print(f"target {t} unconstrained: masked_adj in [{v.min():.4f}, {v.max():.4f}]")
+
+    # ---- configurations that take the PyTorch-ROCm route: method="att" (models.py:62-68) and a 4-layer encoder, each trained by the
+    # reference's own train.py (syn_task1, 1000 epochs, seed 0) and explained for 100 epochs ----
+    import random
+    import train
+    for tag, kw in (("att", dict(method="att")), ("l4", dict(num_gc_layers=4))):
+        work = os.path.join(a.work, "route_" + tag)
+        targs = mg.train_args("syn1", work)
+        for k, v in kw.items():
+            setattr(targs, k, v)
+        np.random.seed(0)
+        random.seed(0)
+        torch.manual_seed(0)
+        with mg.quiet():
+            train.syn_task1(targs)
+        eargs = mg.explain_args("syn1", work, 100)
+        for k, v in kw.items():
+            setattr(eargs, k, v)
+        os.makedirs(eargs.logdir, exist_ok=True)
+        with mg.quiet():
+            ckpt = io_utils.load_ckpt(eargs)
+        cg = ckpt["cg"]
+        model = models.GcnEncoderNode(input_dim=10, hidden_dim=20, embedding_dim=20, label_dim=4, num_layers=eargs.num_gc_layers, bn=False, args=eargs)
+        model.load_state_dict(ckpt["model_state"])
+        for k, v in ckpt["model_state"].items():
+            out[f"route:{tag}:w:{k}"] = v.detach().numpy().astype(np.float32)
+        out[f"route:{tag}:pred"] = cg["pred"][0].astype(np.float32)
+        assert np.array_equal(cg["adj"][0], mg_adj(a.work, io_utils)), "the graph of the route checkpoints must be syn1's"
+        with mg.quiet():
+            ex = explain.Explainer(model=model, adj=cg["adj"], feat=cg["feat"], label=cg["label"], pred=cg["pred"], train_idx=cg["train_idx"],
+                                   args=eargs, writer=None, print_training=False, graph_mode=False, graph_idx=-1)
+        for t in (302, 309):
+            with mg.quiet():
+                torch.manual_seed(1000 + t)
+                _, sub_adj, _, _, nb = ex.extract_neighborhood(t)
+                ma = ex.explain(t)
+            r, c = np.nonzero(np.triu(sub_adj, 1))
+            out[f"route:{tag}:{t}:neighbors"] = nb.astype(np.int32)
+            out[f"route:{tag}:{t}:masked_adj_edges"] = ma[r, c].astype(np.float32)
+            out[f"route:{tag}:{t}:feat_sig"] = torch.sigmoid(built[-1].feat_mask).detach().numpy()
+            print(f"route {tag} target {t}: n={len(nb)} masked_adj in [{ma[r, c].min():.4f}, {ma[r, c].max():.4f}]")
 
     # ---- the reference's own end-use metric (explain.py:295-353) ----
     cwd = os.getcwd()

@@ -86,15 +86,16 @@ def test_batched_list_api_equals_sequential_explains(tmp_path, emu_engine):
         assert np.array_equal(a, b)
 
 
-def test_unsupported_options_raise(tmp_path):
-    for kw in ({"mask_act": "tanh"}, {"method": "att"}, {"opt": "sgd"}, {"num_gc_layers": 4}):
-        with pytest.raises(NotImplementedError):
+def test_unknown_options_fail_like_the_reference(tmp_path):
+    """Every option the reference's CLI accepts runs (kernels, or explainer/torch_route.py: tests/test_options.py); names its
+    build_optimizer does not know fail at construction, as there (utils/train_utils.py:9-22 leaves `optimizer` unbound)."""
+    for kw in ({"opt": "lbfgs"}, {"opt_scheduler": "plateau"}):
+        with pytest.raises(ValueError):
             _explainer(tmp_path, 3, **kw)
-    ck, args, ex = _explainer(tmp_path, 3)
-    with pytest.raises(NotImplementedError):
-        ex.explain(302, unconstrained=True)
-    with pytest.raises(NotImplementedError):
-        ex.explain(302, model="att")
+    if not torch.cuda.is_available():
+        ck, args, ex = _explainer(tmp_path, 3)
+        with pytest.raises(RuntimeError, match="no CPU fallback"):      # the torch route needs the HIP device too
+            ex.explain(302, model="att")
 
 
 def test_grad_baseline_and_mask_bias_through_the_api_emulated(tmp_path, emu_engine):
@@ -162,10 +163,29 @@ def _explain_module_surface(tmp_path):
     ma0 = mod.masked_adj.detach().cpu().numpy()[0]
     want = float(ma0.sum() / (sub_adj != 0).sum())
     assert abs(float(mod.mask_density()) - want) < 1e-6 and 0 < want < 1
+    # .optimizer / .scheduler (explain.py:620-622): the torch objects build_optimizer returns, over the mirror's parameters
+    assert isinstance(mod.optimizer, torch.optim.Adam) and mod.scheduler is None
+    assert mod.optimizer.param_groups[0]["lr"] == args.lr and mod.optimizer.param_groups[0]["params"][0] is mod.mask
     mod.optimize(5)
     assert not np.array_equal(mod.mask.detach().numpy(), gx[f"{t}:mask0"])
     pred5, _ = mod.forward(new)
     assert float(mod.loss(pred5, pl, new, 5)) < loss0                         # five Adam steps lowered the loss
+    # ... and after the run its state is the state the reference's Adam holds after five steps (the oracle runs torch.optim.Adam)
+    from oracle import reference_restatement as rr
+    o = rr.MaskOptimOracle(torch.tensor(sub_adj, dtype=torch.float), torch.tensor(sub_feat, dtype=torch.float),
+                           {k: torch.tensor(v) for k, v in ck["sd"].items()}, int(sub_label[new]), pl, new, mask0=torch.tensor(gx[f"{t}:mask0"]))
+    o.run(5)
+    st, want = mod.optimizer.state[mod.mask], o.opt.state[o.mask]
+    assert float(st["step"]) == 5 and st["exp_avg"].shape == (len(nb), len(nb))
+    assert (st["exp_avg"] - want["exp_avg"]).abs().max() < 1e-6 and (st["exp_avg_sq"] - want["exp_avg_sq"]).abs().max() < 1e-7
+    assert (mod.optimizer.state[mod.feat_mask]["exp_avg"] - o.opt.state[o.feat_mask]["exp_avg"]).abs().max() < 1e-6
+    assert (mod.mask.detach() - o.mask.detach()).abs().max() < 1e-5
+    sgd = explain.ExplainModule(torch.tensor(sub_adj[None], dtype=torch.float), torch.tensor(sub_feat[None], dtype=torch.float), ex.model,
+                                torch.tensor(sub_label[None]), _args(tmp_path, 5, opt="sgd", opt_scheduler="step", opt_decay_step=2, opt_decay_rate=0.5),
+                                graph_idx=-1, node_idx=new, pred_label=pl)
+    assert isinstance(sgd.optimizer, torch.optim.SGD) and isinstance(sgd.scheduler, torch.optim.lr_scheduler.StepLR)
+    sgd.optimize(5)
+    assert "momentum_buffer" in sgd.optimizer.state[sgd.mask] and abs(sgd.optimizer.param_groups[0]["lr"] - 0.1 * 0.25) < 1e-12
 
 
 def test_explain_module_surface_emulated(tmp_path, emu_engine):
@@ -195,6 +215,26 @@ def test_explain_nodes_gnn_stats_auc_on_gpu(tmp_path, monkeypatch):
     out = ex.explain_nodes_gnn_stats(range(400, 700, 5), args)
     assert len(out) == 60 and ex.last_auc > 0.8
     assert os.path.exists("log/pr/auc_syn1_exp.txt")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,model", [("syn1", "exp"), ("syn1", "grad"), ("syn4", "exp"), ("syn4", "grad")])
+def test_auc_equals_the_number_the_reference_prints(tmp_path, monkeypatch, name, model):
+    """The reference's one quantitative output - the ROC-AUC explain_nodes_gnn_stats writes to log/pr/auc_<dataset>_<model>.txt
+    (explain.py:325-351) - for the CLI's node range at the CLI's 100 epochs, same global seed: tests/golden/options_explain.npz holds
+    the number the LIVE reference wrote (make_golden_options.py).  The masks come from the same RNG stream (one normal_ per target in
+    list order), so the device AUC must agree to 1e-3 (and the edge scores it is computed from, in sum, to 1e-3 relative)."""
+    monkeypatch.chdir(tmp_path)
+    z = np.load(helpers.GOLDEN + "/options_explain.npz")
+    ck, args, ex = _explainer(tmp_path, 100, name)
+    nodes = [int(v) for v in z[f"auc:{name}:{model}:nodes"]]
+    torch.manual_seed(0)
+    out = ex.explain_nodes_gnn_stats(nodes, args, model=model)
+    want = float(z[f"auc:{name}:{model}"])
+    print(f"{name} {model}: AUC {ex.last_auc:.6f}, the reference wrote {want:.6f}")
+    assert abs(ex.last_auc - want) <= 1e-3
+    got_sum = sum(float(m[np.triu(m) > 0].sum()) for m in out)
+    assert abs(got_sum - float(z[f"auc:{name}:{model}:pred_sum"])) <= 1e-3 * abs(float(z[f"auc:{name}:{model}:pred_sum"]))
 
 
 @pytest.mark.gpu
