@@ -7,8 +7,9 @@ the bit-pinned oracle (oracle/reference_restatement.py) runs with
   * a hand-written single-tensor Adam (the arithmetic of torch.optim.Adam, verified bit-identical to it without noise) whose
     denominator takes a random -1 / 0 / +1 ulp, and
   * F.normalize, torch.sigmoid, torch.softmax and torch.log results moved the same way,
-and prints how far the 300-epoch result moves from the unperturbed reference; `--append` stores the distinct outcomes as
-alternates of the target in tests/golden/<dataset>_branches.npz.  python tests/golden/reference_ulp_sampler.py syn5 767 24 [--append]"""
+and prints how far the 300-epoch result moves from the unperturbed reference.  A debugging aid only: it writes nothing (round 2's
+`--append`, which stored outcomes of targets an implementation under test had missed, is gone - the acceptance set of the parity
+tests comes from ONE pre-declared sampler, make_golden_branches.py).  python tests/golden/reference_ulp_sampler.py syn5 767 24"""
 import os, sys
 import numpy as np
 import torch
@@ -100,23 +101,3 @@ for s in range(trials):
 devs = np.asarray(devs)
 print("%s target %d: %d runs of the reference restatement with +-1 ulp in Adam's denominator, the normalisation, the sigmoid, the softmax and the logarithm: max %.2e, %d beyond 1e-5, %d beyond 1e-4"
       % (name, tt, trials, devs.max(), int((devs > 1e-5).sum()), int((devs > 1e-4).sum())))
-
-if "--append" in sys.argv:
-    # store the distinct outcomes as alternates of this target (300-epoch horizon) in tests/golden/<name>_branches.npz
-    bp = os.path.join(ROOT, "tests", "golden", name + "_branches.npz")
-    br = dict(np.load(bp))
-    have = [(br["alt_vals"][br["alt_off"][j]:br["alt_off"][j + 1]], br["alt_feat"][j]) for j in np.nonzero((br["alt_target"] == k) & (br["alt_early"] == 0))[0]]
-    new = [(v, fs) for v, fs in outcomes if not any(np.abs(v - hv).max() <= 1e-6 and np.abs(fs - hf).max() <= 1e-6 for hv, hf in have)]
-    at, ae = list(br["alt_target"]), list(br["alt_early"])
-    av = [br["alt_vals"][br["alt_off"][j]:br["alt_off"][j + 1]] for j in range(len(at))]
-    af = [br["alt_feat"][j] for j in range(len(at))]
-    for v, fs in new:
-        at.append(k); ae.append(0); av.append(v); af.append(fs)
-    order = np.argsort(np.asarray(at), kind="stable")
-    br["alt_target"] = np.asarray([at[i] for i in order], np.int32)
-    br["alt_early"] = np.asarray([ae[i] for i in order], np.int8)
-    br["alt_off"] = np.cumsum([0] + [len(av[i]) for i in order]).astype(np.int64)
-    br["alt_vals"] = np.concatenate([av[i] for i in order])
-    br["alt_feat"] = np.stack([af[i] for i in order]).astype(np.float32)
-    np.savez_compressed(bp, **br)
-    print("appended %d alternate outcome(s) of target %d to %s" % (len(new), tt, os.path.basename(bp)))

@@ -122,22 +122,50 @@ def test_sigmoid_saturation_bound_per_config():
     assert max(float(z[f"{t}:stats"][1]) for t in z["targets"]) < 12.0
 
 
-def test_config4_graph_mode_64_of_4337_graphs_vs_reference():
-    """BASELINE config 4: graph-level explanation; 64 graphs of the 4337-graph job (every 68th), reference
-    GcnEncoderGraph weights from the fixture, 300 and 50 epochs."""
-    z = _full("config4_explain.npz")
+def test_config4_graph_mode_512_of_4337_graphs_vs_reference():
+    """BASELINE config 4: graph-level explanation; 512 size-stratified graphs of the 4337-graph job (tests/golden/config4_windows.npz: the
+    LIVE reference's outputs with GcnEncoderGraph weights from the fixture), 300 epochs, on the edge-sparse graph-mode kernel AND - for every
+    eighth graph - on the dense streaming kernels, so that a defect of one route cannot hide behind max-pool ties.
+    Every full-horizon miss on a graph the two CPU implementations agree on must be EXPLAINED by the fixture's CPU-only window analysis: a
+    50-epoch window of that graph in which a max-pool margin / ReLU gate comes within fp32 round-off of its boundary (or a 1-ulp perturbation /
+    the other CPU implementation already diverges) - tests/golden/make_golden_windows.py; the windowed test (test_windowed_parity.py) shows
+    the kernels follow the reference through those windows at 10-epoch granularity."""
+    W = helpers.Windows("config4")
+    z = W.z
     sd = {k[2:]: z[k] for k in z.files if k.startswith("w:")}
     gids = z["graphs"]
     A, X, nn, y = synthetic.molecule_like_graphs(int(gids.max()) + 1, seed=0)
     subs = [Subgraph(A[g], X[g], int(y[g]), 0, None, helpers.seeded_mask0(g, A.shape[1]).numpy()) for g in gids]
-    for horizon, iters in (("full", int(z["epochs"])), ("early", int(z["early_epochs"]))):
-        job = MaskOptimJob(subs, sd, graph_mode=True)
-        job.set_masks([s.mask0 for s in subs])
-        job.launch(Hyper(num_iters=iters))
+    well = (z["cond_mask"] <= WELL) & (z["cond_feat"] <= WELL)
+    assert well.sum() >= 180, well.sum()
+
+    def run(sel, analyze, use_resident):
+        job = MaskOptimJob([subs[k] for k in sel], sd, graph_mode=True, analyze=analyze)
+        job.set_masks([subs[k].mask0 for k in sel])
+        job.launch(Hyper(num_iters=int(z["full_epochs"]), use_resident=use_resident))
         em = job.fetch_edges()
-        assert np.array_equal(em.eoff, z["eoff"])
-        rule = helpers.CONFIG4_FULL_RULE if horizon == "full" else helpers.CONFIG4_EARLY_RULE     # see helpers.py
-        _check(z, em.masked_adj, em.feat_mask, em.eoff, horizon, "config4", 20 if horizon == "full" else 60, helpers.load_branches("config4"), **rule)
+        assert np.array_equal(np.diff(em.eoff), np.diff(z["eoff"])[sel])
+        want = np.concatenate([z["vals"][z["eoff"][k]:z["eoff"][k + 1]] for k in sel])
+        err = _per_target_err(em.eoff, em.masked_adj, want)
+        ferr = np.abs(_sig(em.feat_mask) - z["feat_sig"][sel]).max(1)
+        return np.maximum(err, ferr), job.route()
+
+    allk = np.arange(len(gids))
+    e_sparse, route = run(allk, True, True)
+    assert set(route) <= {5, 6}, set(route)                      # the graph-mode classes of the sparse resident kernel
+    sub8 = allk[::8]
+    e_dense, route_d = run(sub8, False, False)
+    ok, msg = helpers.parity_verdict(e_sparse, e_sparse, well, **helpers.CONFIG4_FULL_RULE)
+    miss = np.nonzero(well & (e_sparse > TOL))[0]
+    unexplained = [int(gids[k]) for k in miss if not W.flagged[k].any()]
+    wd = well[sub8]
+    print(f"config4 [full, 512 graphs]: {msg}; misses {len(miss)}, of which {len(miss) - len(unexplained)} have a flagged window on the CPU, unexplained: "
+          f"{unexplained}; dense streaming route on {len(sub8)} graphs: {int((e_dense[wd] <= TOL).sum())} / {int(wd.sum())} non-chaotic within 1e-5 "
+          f"(sparse route on the same graphs: {int((e_sparse[sub8][wd] <= TOL).sum())})")
+    assert ok, msg
+    assert not unexplained, unexplained
+    # the two routes are independent implementations of the same mathematics: both must do comparably well against the reference
+    assert (e_dense[wd] <= TOL).sum() >= 0.6 * wd.sum()
 
 
 def test_config5_ba100k_route_stratified_targets_vs_reference():
