@@ -318,6 +318,7 @@ def main():
     ap.add_argument("--no-resident", action="store_true", help="streaming kernels for every target (no on-chip-resident path)")
     ap.add_argument("--no-parity-gate", action="store_true", help="measurement sessions: report parity but do not fail the run")
     ap.add_argument("--no-single-gpu-leg", action="store_true", help="N > 1: skip the same-workload single-GPU run on rank 0")
+    ap.add_argument("--no-calibration", action="store_true", help="N > 1: shard by the default cost table instead of measuring it on rank 0")
     ap.add_argument("--loop-only", action="store_true", help="N = 1: report the resident-input loop rate as `value` (rounds 1-2) instead of the end-to-end rate")
     args = ap.parse_args()
 
@@ -392,9 +393,33 @@ def main():
             timings.update(tm)
         return dn, job
 
+    cost_table = parallel.DEFAULT_COST_TABLE.copy()
     if world > 1:
         sizes = engine.khop_device(graph, wl.targets, 3).sizes.astype(np.float64)
-        shard = parallel.lpt_shards(parallel.target_cost(sizes), world)[rank]
+        if not args.no_calibration:
+            # the per-class constants of the cost model, measured on THIS workload and machine by rank 0 (one saturated batch per kernel
+            # class, outside the timed region) and broadcast, so that every rank cuts the same shards
+            if rank == 0:
+                def run_batch(idx):
+                    t_sub = wl.targets[np.asarray(idx, np.int64)]
+                    dn_c = engine.khop_device(graph, t_sub, 3)
+                    job_c = MaskOptimJob.from_csr(graph, dn_c, None, wl.label[t_sub], wl.ck["sd"])
+                    job_c.set_masks_raw(engine.init_edge_masks_raw(dn_c.sizes, seeds=1000 + t_sub, threads=engine.default_rng_threads()))
+                    job_c.launch(hy)
+                    torch.cuda.synchronize()
+                    t_c = time.perf_counter()
+                    job_c.set_masks_raw_resident()
+                    job_c.launch(hy)
+                    torch.cuda.synchronize()
+                    ms = (time.perf_counter() - t_c) * 1e3
+                    job_c.close()
+                    return ms
+                cost_table = parallel.calibrate_cost_table(sizes, run_batch)
+            tt = torch.tensor(cost_table, device=dev, dtype=torch.float64)
+            dist.broadcast(tt, 0)
+            cost_table = tt.cpu().numpy()
+            log(f"cost table (us per target, classes n <= 32 / 128 / 512 / 16383): {np.round(cost_table, 2).tolist()}")
+        shard = parallel.lpt_shards(parallel.target_cost(sizes, cost_table), world)[rank]
         my_targets = wl.targets[np.asarray(shard, np.int64)]
     else:
         shard, my_targets = list(range(len(wl.targets))), wl.targets
@@ -675,10 +700,12 @@ def main():
         loads = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(loads, torch.tensor([job.sum_n2], device=dev, dtype=torch.float64))
         costs = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(costs, torch.tensor([float(parallel.target_cost(job.n).sum())], device=dev, dtype=torch.float64))
+        dist.all_gather(costs, torch.tensor([float(parallel.target_cost(job.n, cost_table).sum())], device=dev, dtype=torch.float64))
         if rank == 0:
             out["config"]["sum_n2_per_rank"] = [float(x.item()) for x in loads]
             out["config"]["modelled_gpu_us_per_rank"] = [float(x.item()) for x in costs]
+            out["config"]["cost_table_us"] = {"classes": "n <= 32 / 128 / 512 / 16383", "measured_on_rank0": cost_table.tolist(),
+                                             "default": parallel.DEFAULT_COST_TABLE.tolist()}
             out["config"]["gathered_edge_entries_per_rank"] = gather_bufs["counts"]
         job.close()
         del job

@@ -14,17 +14,48 @@ from typing import Callable, Dict, List, Sequence
 import numpy as np
 
 
-def target_cost(sizes) -> np.ndarray:
-    """GPU time (microseconds) one target of n nodes adds to a batch that fills an MI355X, 300 iterations: the quantity the
-    shards must balance.  Measured by size class on the BA-House x100k target set (tools/probe_classes.py, round 2): the
-    edge-sparse kernels cost per workgroup slot, not per n^2 - 2.2-3.1 us for the one-wave class (n <= 32, six or seven
-    targets per CU), ~11 us for the 256-thread class (n <= 128, two per CU), 14-20 us for the 512-thread class (one per CU,
-    ~10-13 us per iteration whatever n), ~45 us for k_sparse_large (n ~ 900 on average; its iteration grows with the
-    entries of the rows within two hops).  Targets beyond its range stream dense n x n blocks: ~28 n^2 bytes per iteration
-    at ~4 TB/s."""
+# Size classes of the cost model = the kernel classes of the plan (gnnx_plan_analyze; csrc/gnnx_sparse.hpp): one-wave targets
+# (n <= 32), the 256-thread class (n <= 128), the 512- / 1024-thread classes (n <= 512), k_sparse_large (n <= 16383), dense streaming.
+CLASS_EDGES = (32, 128, 512, 16383)
+# GPU microseconds one target adds to a SATURATED batch of its class on one MI355X, 300 iterations.  For k_sparse_large and the
+# streaming class the cost grows with the target: a + b n (large) resp. the HBM time of 28 n^2 bytes per iteration at ~4 TB/s.
+# These defaults were measured on the BA-House x100k target set (tools/probe_classes.py); `calibrate_cost_table` re-measures them
+# on the workload and machine at hand (bench.py --gpus N does, on rank 0, and broadcasts the table), so the shards do not
+# depend on one dataset's fit.
+DEFAULT_COST_TABLE = np.asarray([2.5, 11.0, 17.0, 45.0], np.float64)
+
+
+def size_class(sizes) -> np.ndarray:
+    return np.searchsorted(np.asarray(CLASS_EDGES), np.asarray(sizes), side="left")
+
+
+def target_cost(sizes, table=None) -> np.ndarray:
+    """GPU time (microseconds) one target of n nodes adds to a batch that fills an MI355X, 300 iterations: the quantity the shards
+    must balance.  The edge-sparse kernels cost per workgroup slot, not per n^2 (every iteration is the same latency chain whatever
+    n), so the model is one constant per kernel class (`table`, default DEFAULT_COST_TABLE; within the two larger classes scaled
+    linearly with n around the class mean the table was measured at), and HBM time beyond k_sparse_large's range."""
     n = np.asarray(sizes, np.float64)
-    cost = np.where(n <= 32, 2.5, np.where(n <= 128, 11.0, np.where(n <= 512, 10.0 + 0.02 * n, 25.0 + 0.025 * n)))
-    return np.where(n > 16383, 300 * 28.0 * n * n / 4e6, cost)
+    t = DEFAULT_COST_TABLE if table is None else np.asarray(table, np.float64)
+    c = size_class(n)
+    cost = np.choose(np.minimum(c, 3), [t[0], t[1], t[2] * (0.6 + 0.4 * n / 320.0), t[3] * (0.55 + 0.45 * n / 900.0)])
+    return np.where(c >= 4, 300 * 28.0 * n * n / 4e6, cost)
+
+
+def calibrate_cost_table(sizes, run_batch, per_class=1024, min_members=64) -> np.ndarray:
+    """Measure the per-class constants of `target_cost` on this workload and machine.  `run_batch(indices) -> milliseconds` runs the
+    targets `indices` (positions in `sizes`) as one batched job for the full iteration count.  A class with fewer than `min_members`
+    targets cannot saturate the GPU and keeps its default.  Deterministic choice of the sample (the first `per_class` members)."""
+    sizes = np.asarray(sizes)
+    c = size_class(sizes)
+    table = DEFAULT_COST_TABLE.copy()
+    for k in range(4):
+        idx = np.nonzero(c == k)[0][:per_class]
+        if len(idx) < min_members:
+            continue
+        ms = float(run_batch(idx))
+        unit = target_cost(sizes[idx], np.where(np.arange(4) == k, 1.0, DEFAULT_COST_TABLE)).sum()     # the class constant's multiplier
+        table[k] = ms * 1e3 / unit
+    return table
 
 
 def lpt_shards(costs: Sequence[float], world_size: int) -> List[List[int]]:
@@ -52,28 +83,54 @@ def sparse_unpack(packed):
     return out
 
 
+def _gather_variable(t, group, device):
+    """all_gather of 1-D tensors of different lengths: sizes first, then the data padded to the longest (two collectives on the
+    group's device - RCCL over xGMI with the nccl backend; no pickling through the host as all_gather_object does)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=device)
+    ns = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(ns, n, group=group)
+    ns = [int(x.item()) for x in ns]
+    m = max(max(ns), 1)
+    buf = torch.zeros(m, dtype=t.dtype, device=device)
+    buf[:t.numel()] = t.to(device)
+    outs = [torch.empty(m, dtype=t.dtype, device=device) for _ in range(world)]
+    dist.all_gather(outs, buf, group=group)
+    return [o[:k].cpu() for o, k in zip(outs, ns)]
+
+
 def run_sharded(targets: Sequence, costs: Sequence[float], compute: Callable[[List], List[np.ndarray]],
                 group=None, gather_to_all: bool = True) -> Dict:
     """Every rank calls this with the SAME targets/costs.  `compute(list_of_targets)` runs this rank's shard
     (one batched GPU job) and returns one masked adjacency per target.  Returns {target: masked_adj} on every
-    rank (or on rank 0 only when gather_to_all is False)."""
+    rank.  The masks travel as their non-zero entries in two padded tensor all-gathers (indices, values)."""
+    import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return dict(zip(targets, compute(list(targets))))
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     mine = lpt_shards(costs, world)[rank]
     results = compute([targets[i] for i in mine]) if mine else []
-    payload = [(i, sparse_pack(np.asarray(m))) for i, m in zip(mine, results)]
-    if gather_to_all:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, payload, group=group)
-    else:
-        gathered = [None] * world if rank == 0 else None
-        dist.gather_object(payload, gathered, dst=0, group=group)
-        if rank != 0:
-            return {}
+    device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    packed = [sparse_pack(np.asarray(m)) for m in results]
+    dtype = packed[0][3].dtype if packed else np.float64
+    # int32 stream: [k, then per target (index, n, nnz)], then all rows, then all columns; value stream: all values (as float64 bits)
+    head = np.asarray([len(mine)] + [x for i, pk in zip(mine, packed) for x in (i, pk[0], len(pk[1]))], np.int32)
+    ints = np.concatenate([head] + [pk[1] for pk in packed] + [pk[2] for pk in packed]).astype(np.int32)
+    vals = np.concatenate([pk[3].astype(np.float64) for pk in packed]) if packed else np.zeros(0, np.float64)
+    all_ints = _gather_variable(torch.from_numpy(ints), group, device)
+    all_vals = _gather_variable(torch.from_numpy(vals), group, device)
     out = {}
-    for part in gathered:
-        for i, packed in part:
-            out[targets[i]] = sparse_unpack(packed)
+    for it, vt in zip(all_ints, all_vals):
+        it, vt = it.numpy(), vt.numpy()
+        k = int(it[0])
+        meta = it[1:1 + 3 * k].reshape(k, 3)
+        nnz = meta[:, 2].astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(nnz)])
+        rows, cols = it[1 + 3 * k:1 + 3 * k + off[-1]], it[1 + 3 * k + off[-1]:1 + 3 * k + 2 * off[-1]]
+        for j in range(k):
+            a, b = off[j], off[j + 1]
+            out[targets[int(meta[j, 0])]] = sparse_unpack((int(meta[j, 1]), rows[a:b], cols[a:b], vt[a:b].astype(dtype)))
     return out

@@ -1,0 +1,61 @@
+"""The cost model the multi-GPU shards are cut by (parallel.target_cost / calibrate_cost_table / lpt_shards): shards of equal modelled
+cost must take equal GPU time.  One GPU stands in for N: the shards of a 4-way split run one after the other."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from gnn_model_explainer_amd import engine, parallel
+from gnn_model_explainer_amd.engine import Hyper, MaskOptimJob
+from gnn_model_explainer_amd.utils import synthetic
+from gnn_model_explainer_amd.utils.graph_utils import KHopIndex
+
+
+def test_calibration_recovers_the_class_constants():
+    """CPU: a synthetic machine whose batches cost exactly the model with another table -> the calibration returns that table."""
+    rng = np.random.default_rng(0)
+    sizes = np.concatenate([rng.integers(4, 33, 3000), rng.integers(33, 129, 500), rng.integers(129, 513, 400), rng.integers(513, 4000, 200)])
+    truth = np.asarray([3.1, 9.0, 21.0, 60.0])
+    got = parallel.calibrate_cost_table(sizes, lambda idx: parallel.target_cost(sizes[idx], truth).sum() / 1e3)
+    assert np.allclose(got, truth, rtol=1e-9)
+    # a class too small to saturate the GPU keeps its default
+    got = parallel.calibrate_cost_table(sizes[:3000], lambda idx: 1.0)
+    assert np.array_equal(got[1:], parallel.DEFAULT_COST_TABLE[1:])
+
+
+@pytest.mark.gpu
+def test_lpt_shards_by_calibrated_cost_take_equal_gpu_time():
+    ck = helpers.load_ckpt("syn1")
+    N, edges, label = synthetic.ba_house(42857, 11428, seed=0)
+    csr = synthetic.csr_from_edges(N, edges)
+    feat = np.ones((N, 10), np.float32)
+    pred = synthetic.sparse_gcn_predict(csr, feat, ck["sd"])
+    graph = engine.device_graph(csr, feat, pred)
+    targets = np.sort(np.random.default_rng(1234).choice(np.arange(42857, N), 8192, replace=False))
+    sizes = engine.khop_device(graph, targets, 3).sizes
+    hy = Hyper(num_iters=100)
+
+    def run_batch(idx):
+        t_sub = targets[np.asarray(idx, np.int64)]
+        dn = engine.khop_device(graph, t_sub, 3)
+        job = MaskOptimJob.from_csr(graph, dn, None, label[t_sub], ck["sd"])
+        job.set_masks_raw(engine.init_edge_masks_raw(dn.sizes, seeds=1000 + t_sub, threads=8))
+        job.launch(hy)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        job.set_masks_raw_resident()
+        job.launch(hy)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        job.close()
+        return ms
+
+    table = parallel.calibrate_cost_table(sizes, run_batch)
+    shards = parallel.lpt_shards(parallel.target_cost(sizes, table), 4)
+    model = [float(parallel.target_cost(sizes[s], table).sum()) for s in shards]
+    times = [run_batch(s) for s in shards]
+    print(f"cost table (100 iterations) {np.round(table, 2).tolist()}; modelled shard cost {np.round(model, 0).tolist()} us; measured {np.round(times, 2).tolist()} ms")
+    assert max(model) / min(model) < 1.01
+    assert max(times) / min(times) <= 1.15, times
