@@ -548,6 +548,7 @@ static Params make_params(gnnx_handle h, const gnnx_hyper* hy, const float* A, c
     if (hy) {
         p.num_iters = hy->num_iters;
         p.opt = hy->opt;
+        p.edge_only = hy->edge_results_only;
         p.lr = (float)hy->lr;
         p.beta2 = (float)(hy->opt == 2 ? hy->alpha : hy->beta2);
         p.omb1 = (float)(1.0 - hy->beta1);

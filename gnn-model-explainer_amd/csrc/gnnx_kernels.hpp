@@ -99,6 +99,7 @@ struct Params {
     int32_t graph_mode;
     int32_t num_iters;
     int32_t opt;        // 0 Adam, 1 SGD with momentum, 2 RMSprop, 3 Adagrad (gnnx_hyper.opt)
+    int32_t edge_only;  // gnnx_hyper.edge_results_only: the edge-sparse kernels write Abar on the edges only
     float lr, beta2, eps;   // beta2: Adam's second-moment decay, or RMSprop's alpha
     float omb1, omb2;   // (float)(1 - beta1), (float)(1 - beta2) with the subtraction in DOUBLE, as torch passes them to lerp_ / addcmul_
     float c_size, c_feat_size, c_ent, c_lap;

@@ -1321,7 +1321,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     // ---------------- results: dense Abar block (zero off the edges), M on the edges, feature mask ----------------
     {
         f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int e = tid * 4; e < ld * ld; e += 4 * NT) *reinterpret_cast<f32x4*>(p.Abar + tm.offQ + e) = z4;
+        if (!p.edge_only)   // (gnnx_hyper.edge_results_only: the caller reads Abar on the edges only - skip the ld^2 zero-fill)
+            for (int e = tid * 4; e < ld * ld; e += 4 * NT) *reinterpret_cast<f32x4*>(p.Abar + tm.offQ + e) = z4;
     }
     __threadfence_block();
     SYNC();

@@ -973,7 +973,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     // stream and delays this one by more than the 0.2-0.8 ms the fill costs here)
     {
         f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (size_t e = (size_t)tid * 4; e < (size_t)ld * ld; e += 4 * NT) *reinterpret_cast<f32x4*>(p.Abar + tm.offQ + e) = z4;
+        if (!p.edge_only)   // (gnnx_hyper.edge_results_only: the caller reads Abar on the edges only - skip the ld^2 zero-fill)
+            for (size_t e = (size_t)tid * 4; e < (size_t)ld * ld; e += 4 * NT) *reinterpret_cast<f32x4*>(p.Abar + tm.offQ + e) = z4;
     }
     __threadfence_block();
     __syncthreads();

@@ -57,7 +57,7 @@ class _Hyper(ctypes.Structure):
     _fields_ = [("lr", ctypes.c_double), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double),
                 ("c_size", ctypes.c_float), ("c_feat_size", ctypes.c_float), ("c_ent", ctypes.c_float),
                 ("c_lap", ctypes.c_float), ("num_iters", ctypes.c_int32), ("record_loss", ctypes.c_int32),
-                ("use_graph", ctypes.c_int32), ("use_resident", ctypes.c_int32), ("opt", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("use_graph", ctypes.c_int32), ("use_resident", ctypes.c_int32), ("opt", ctypes.c_int32), ("edge_results_only", ctypes.c_int32),
                 ("momentum", ctypes.c_double), ("alpha", ctypes.c_double), ("lr_schedule", ctypes.POINTER(ctypes.c_double))]
 
 
@@ -98,11 +98,12 @@ class Hyper:
     momentum: float = 0.95        # train_utils.py:12
     alpha: float = 0.99           # torch.optim.RMSprop default
     lr_schedule: Optional[np.ndarray] = None   # [num_iters] learning rate of every iteration (an LR scheduler's trace), None = constant
+    edge_results_only: bool = False   # the result is fetched as edge lists only (fetch_edges / gather_edges_device): no dense Abar blocks
 
     def c(self):
         hy = _Hyper(self.lr, self.beta1, self.beta2, self.eps, self.c_size, self.c_feat_size, self.c_ent,
                     self.c_lap, int(self.num_iters), int(self.record_loss), int(self.use_graph), int(self.use_resident),
-                    OPTIMIZERS[self.opt], 0, self.momentum, self.alpha, None)
+                    OPTIMIZERS[self.opt], int(self.edge_results_only), self.momentum, self.alpha, None)
         if self.lr_schedule is not None:
             sch = np.ascontiguousarray(self.lr_schedule, np.float64)
             if sch.shape != (int(self.num_iters),):
@@ -685,6 +686,8 @@ class MaskOptimJob:
         return g(self.M), g(st.m), g(st.v), st.feat[:, :, :self.D].cpu().numpy()
 
     def fetch(self, hyper: Hyper) -> JobResult:
+        if hyper.edge_results_only:
+            raise ValueError("this run wrote its result on the edges only (Hyper.edge_results_only): use fetch_edges()")
         if self.device.type == _DEVICE_TYPE:
             torch.cuda.synchronize(self.device)
         Abar = self.Abar.cpu().numpy()

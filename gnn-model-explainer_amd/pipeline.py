@@ -34,6 +34,8 @@ class BatchPipeline:
         """graph: engine.DeviceGraph (resident); labels [N]: the label the prediction loss uses (explain.py:750-753); the initial
         mask of target v is drawn from a generator seeded with seed_base + v (the seed protocol of the golden runs)."""
         self.graph, self.sd, self.labels, self.hyper = graph, state_dict, np.asarray(labels), hyper
+        import dataclasses
+        self._edge_hyper = dataclasses.replace(hyper, edge_results_only=True)      # results leave as edge lists: no dense Abar blocks
         self.n_hops, self.seed_base = int(n_hops), int(seed_base)
         self.rng_threads = int(rng_threads) if rng_threads else engine.default_rng_threads()
         self.depth = max(1, int(depth))
@@ -152,7 +154,7 @@ class BatchPipeline:
         with torch.cuda.stream(self.s_loop):
             self.s_loop.wait_event(p.ready)
             job.use_stream(self.s_loop)
-            job.launch(self.hyper)
+            job.launch(self._edge_hyper)
             done = torch.cuda.Event()
             done.record(self.s_loop)
         with torch.cuda.stream(self.s_fetch):

@@ -76,7 +76,9 @@ typedef struct {
      *                (StepLR / CosineAnnealingLR, stepped after every optimiser step: explain.py:144-146) leaves it in
      *                optimizer.param_groups[0]["lr"]; NULL = constant lr. */
     int32_t opt;
-    int32_t reserved;
+    int32_t edge_results_only; /* 1: the caller reads the result as edge lists (gnnx_gather_values / gnnx_gather_edges): on the edge-sparse
+                                * routes Abar is then DEFINED ONLY ON THE EDGES of the sub-graphs - the kernels skip the ld^2 zero-fill of
+                                * every target's block (28 GB per launch on the 16 384-target BA-House x100k set); 0: dense Abar blocks */
     double momentum, alpha;
     const double* lr_schedule;
 } gnnx_hyper;

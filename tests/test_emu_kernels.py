@@ -758,3 +758,26 @@ def test_batch_norm_vs_reference_golden(be):
         r, c = np.nonzero(np.triu(s.adj, 1))
         assert np.abs(ma[r, c] - z[f"bn:{t}:masked_adj_edges"]).max() <= 1e-5
         assert np.abs(1 / (1 + np.exp(-fm.astype(np.float64))) - z[f"bn:{t}:feat_sig"]).max() <= 1e-5
+
+
+def test_edge_only_results_equal_dense_results(be):
+    """Hyper.edge_results_only (gnnx_hyper.edge_results_only): the edge-sparse kernels skip the ld^2 zero-fill of every target's Abar block
+    and write it on the edges only; the edge lists must be bit-identical to those of a dense-result run (and fetch() refuses)."""
+    ck = helpers.load_ckpt("syn1")
+    subs = [_node_case("syn1", t)[2] for t in (302, 309, 330)]
+    outs = []
+    for eo in (False, True):
+        job = be.job(subs, ck["sd"])
+        job.set_masks([s.mask0 for s in subs])
+        job.Abar.fill_(float("nan"))                  # whatever the kernels do not write stays NaN
+        hy = Hyper(num_iters=7, edge_results_only=eo)
+        job.launch(hy)
+        em = job.fetch_edges(with_mask=True)
+        outs.append(em)
+        if eo:
+            with pytest.raises(ValueError, match="edges only"):
+                job.fetch(hy)
+        else:
+            assert np.isfinite(job.fetch(hy).masked_adj[0]).all()
+    assert np.array_equal(outs[0].masked_adj, outs[1].masked_adj) and np.array_equal(outs[0].mask_rc, outs[1].mask_rc)
+    assert np.array_equal(outs[0].feat_mask, outs[1].feat_mask) and np.isfinite(outs[1].masked_adj).all()

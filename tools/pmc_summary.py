@@ -41,6 +41,23 @@ def main():
     for k, cs in summary["counters_mean_per_launch"].items():
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             summary["hbm_bytes_per_launch"][k] = (2.0 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024.0
+    # normalised utilisations: SQ_VALU_MFMA_BUSY_CYCLES counts shader cycles summed over the SIMDs that issue
+    # MFMA, GRBM_GUI_ACTIVE the shader cycles of the launch; 256 CUs x 4 SIMDs can be busy at once.  SQ_WAIT_ANY / SQ_WAVE_CYCLES
+    # are both in quad-cycles, so their ratio needs no unit.
+    NUM_SIMDS = 256 * 4
+    summary["normalised"] = {}
+    for k, cs in summary["counters_mean_per_launch"].items():
+        nrm = {}
+        if cs.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in cs:
+            nrm["mfma_busy_frac_of_all_simds"] = cs["SQ_VALU_MFMA_BUSY_CYCLES"] / (cs["GRBM_GUI_ACTIVE"] * NUM_SIMDS)
+        if cs.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in cs:
+            nrm["waves_waiting_frac"] = cs["SQ_WAIT_ANY"] / cs["SQ_WAVE_CYCLES"]
+        if cs.get("SQ_WAVE_CYCLES") and "SQ_ACTIVE_INST_ANY" in cs:
+            nrm["waves_issuing_frac"] = cs["SQ_ACTIVE_INST_ANY"] / cs["SQ_WAVE_CYCLES"]
+        if cs.get("SQ_LDS_IDX_ACTIVE") and "SQ_LDS_BANK_CONFLICT" in cs:
+            nrm["lds_bank_conflict_frac_of_lds_active"] = cs["SQ_LDS_BANK_CONFLICT"] / cs["SQ_LDS_IDX_ACTIVE"]
+        if nrm:
+            summary["normalised"][k] = nrm
     summary["note"] = ("rocprofv3 --pmc, separate passes per counter group; HBM bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB "
                        "(gfx950: FETCH_SIZE tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section)")
     json.dump(summary, open(out_json, "w"), indent=1)
