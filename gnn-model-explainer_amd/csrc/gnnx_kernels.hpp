@@ -142,9 +142,13 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // omb2 = (float)(1 - 0.999) - NOT 1.0f - (float)0.999, which is 1.3e-5 smaller and made every step 6e-6 too long (found by the
 // windowed parity test against the reference's own optimiser state, tests/test_windowed_parity.py).
 // step_size = lr / (1 - beta1^k), bc2s = sqrt(1 - beta2^k), both evaluated in double on the host.
+// ADAM_ONLY: the caller has already branched on the optimiser around a whole loop of updates - inside an unrolled loop the uniform
+// test below would put every update in its own basic block, and the independent sqrt -> rcp chains of a thread's 8 mask entries
+// would run one after the other instead of interleaved (measured: the edge phase of the sparse resident kernel 0.76 -> 1.28 us).
+template <bool ADAM_ONLY = false>
 __device__ __forceinline__ void adam_update(float& theta, float& m, float& v, float g, float omb1, float beta2, float omb2,
                                             float eps, float step_size, float bc2s, int opt = 0) {
-    if (opt == 0) {   // Adam (uniform branch: the optimiser is a property of the whole job)
+    if (ADAM_ONLY || opt == 0) {   // Adam (uniform branch: the optimiser is a property of the whole job)
         m = m + (g - m) * omb1;
         v = v * beta2 + omb2 * g * g;
 #ifndef GNNX_IEEE_MATH
@@ -159,12 +163,14 @@ __device__ __forceinline__ void adam_update(float& theta, float& m, float& v, fl
     //   opt 1  SGD(momentum=0.95): buf = g at the first step, else buf * 0.95 + g; p += -lr * buf               (torch/optim/sgd.py)
     //   opt 2  RMSprop(alpha=0.99, eps): sq = sq * alpha + (1 - alpha) g g; p += (-lr * g) / (sqrt(sq) + eps)   (rmsprop.py)
     //   opt 3  Adagrad(eps=1e-10): sum += g g; p += (-lr * g) / (sqrt(sum) + eps)                               (adagrad.py)
+    // (hardware reciprocal / square root like the Adam path: after inlining the compiler may evaluate both sides of this uniform
+    // branch and select - with IEEE divisions here the edge phase of the sparse resident kernel took 1.28 instead of 0.76 us)
     if (opt == 1) {
         m = m * bc2s + g;
         theta = theta + (-step_size) * m;
     } else {
         v = (opt == 2) ? v * beta2 + omb2 * g * g : v + g * g;
-        theta = theta + (-step_size * g) / (sqrtf(v) + eps);
+        theta = theta + (-step_size * g) * rcp_(sqrt_(v) + eps);
     }
 }
 

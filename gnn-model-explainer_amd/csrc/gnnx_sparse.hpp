@@ -644,7 +644,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     // owned undirected edges: k = tid + NT q; mask entries and Adam moments stay in registers
     float Mij[SP_QMAX], Mji[SP_QMAX], mij[SP_QMAX], mji[SP_QMAX], vij[SP_QMAX], vji[SP_QMAX], wgt[SP_QMAX];
     float Sij[SP_QMAX], Sji[SP_QMAX];  // sigma(M) of the current iterate (computed when the masked adjacency is published)
-    int eij[SP_QMAX], eji[SP_QMAX], ni[SP_QMAX], nj[SP_QMAX];
+    unsigned epk[SP_QMAX], npk[SP_QMAX];   // (eij | eji << 16), (i | j << 16): rows and directed entries are < 65536 (sparse_fits) - two registers per edge instead of four
     int eflag[SP_QMAX];   // bit 0 / 1: row i / j lies within two hops of t (dZ1 can be non-zero there); bit 2 / 3: row i / j is t
                           // or a neighbour of t (dZ2 can be non-zero there); graph mode: all set
     {
@@ -654,7 +654,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             const int k = tid + NT * q;
             Mij[q] = Mji[q] = mij[q] = mji[q] = vij[q] = vji[q] = wgt[q] = 0.0f;
             Sij[q] = Sji[q] = 0.5f;
-            eij[q] = eji[q] = ni[q] = nj[q] = 0;
+            epk[q] = npk[q] = 0u;
             eflag[q] = 0;
             if (k < eup) {
                 int lo = 0, hi = ld;  // largest row i with upptr[i] <= k
@@ -667,10 +667,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 const int j = scol[e];
                 const int em = lower_bound_u16(scol, rowptr[j], rowptr[j + 1], i);
                 if (em >= rowptr[j + 1] || (int)scol[em] != i) asym = true;
-                ni[q] = i;
-                nj[q] = j;
-                eij[q] = e;
-                eji[q] = asym ? e : em;
+                npk[q] = (unsigned)i | ((unsigned)j << 16);
+                epk[q] = (unsigned)e | ((unsigned)(asym ? e : em) << 16);
                 wgt[q] = Ag[(size_t)i * ld + j];
                 if (Ag[(size_t)j * ld + i] != wgt[q]) asym = true;
                 Mij[q] = Mg[(size_t)i * ld + j];
@@ -743,11 +741,11 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 Sij[q] = sigmoidf_(Mij[q]);   // kept for the next update: sigma'(M) = S (1 - S)
                 Sji[q] = sigmoidf_(Mji[q]);
                 const float a = wgt[q] * (0.5f * (Sij[q] + Sji[q]));
-                sAb[eij[q]] = a;
-                sAb[eji[q]] = a;
+                sAb[epk[q] & 0xffffu] = a;
+                sAb[epk[q] >> 16] = a;
                 if (!GRAPH) {
-                    if (ni[q] == tr) sArt[nj[q]] = a;
-                    if (nj[q] == tr) sArt[ni[q]] = a;
+                    if ((int)(npk[q] & 0xffffu) == tr) sArt[npk[q] >> 16] = a;
+                    if ((int)(npk[q] >> 16) == tr) sArt[npk[q] & 0xffffu] = a;
                 }
             }
         SYNC();
@@ -1239,16 +1237,18 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             sh.dfp[tid] = s;
         }
         // ======== per owned edge: G_ij + G_ji, regulariser gradients, Adam on both directed entries ========
+        auto edge_phase = [&](auto ADAMc) {
+        constexpr bool ADAM = decltype(ADAMc)::value;
 #pragma unroll
         for (int q = 0; q < SP_QMAX; ++q)
             if (tid + NT * q < eup) {
-                const int i = ni[q], j = nj[q];
+                const int i = (int)(npk[q] & 0xffffu), j = (int)(npk[q] >> 16);
                 // compile-time trip counts: all loads of an edge are issued before the first use; columns beyond
                 // D / H are read from the row padding / the next row and dropped by the select
                 float G0 = 0.0f, G1 = 0.0f;
                 if constexpr (!GRAPH) {
-                    G0 = sGe[eij[q]];   // row-side products of both directions, formed by the layer-1 backward
-                    G1 = sGe[eji[q]];
+                    G0 = sGe[epk[q] & 0xffffu];   // row-side products of both directions, formed by the layer-1 backward
+                    G1 = sGe[epk[q] >> 16];
                 } else {
                 const int fl = eflag[q];
                 // columns per load group (one LDS round trip each): the reference's widths take the whole dZ1 . X product in one
@@ -1296,14 +1296,16 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 {
                     const float S = Sij[q];
                     const float g = (gc + p.c_size - p.c_ent * Mij[q] * inv_n2) * S * (1.0f - S);
-                    adam_update(Mij[q], mij[q], vij[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
+                    adam_update<ADAM>(Mij[q], mij[q], vij[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
                 }
                 {
                     const float S = Sji[q];
                     const float g = (gc + p.c_size - p.c_ent * Mji[q] * inv_n2) * S * (1.0f - S);
-                    adam_update(Mji[q], mji[q], vji[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
+                    adam_update<ADAM>(Mji[q], mji[q], vji[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
                 }
             }
+        };
+        if (p.opt == 0) edge_phase(std::true_type{}); else edge_phase(std::false_type{});   // one branch around the loop, not one per update
         SYNC();  // dfp complete; every reader of sAb / sArt of this iteration is done
         if (tid < D) {  // feature mask
             const float ph = sh.phi[tid];
@@ -1329,8 +1331,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
 #pragma unroll
     for (int q = 0; q < SP_QMAX; ++q)
         if (tid + NT * q < eup) {
-            const int i = ni[q], j = nj[q];
-            const float a = sAb[eij[q]];
+            const int i = (int)(npk[q] & 0xffffu), j = (int)(npk[q] >> 16);
+            const float a = sAb[epk[q] & 0xffffu];
             p.Abar[tm.offQ + (size_t)i * ld + j] = a;
             p.Abar[tm.offQ + (size_t)j * ld + i] = a;
             Mg[(size_t)i * ld + j] = Mij[q];

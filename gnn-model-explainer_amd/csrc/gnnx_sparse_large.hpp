@@ -22,6 +22,7 @@
 //   * rows of up to 1024 entries are split into slots of 64 (the BA-House x100k hubs), loops run over rows / edges
 //     instead of one item per thread.
 #pragma once
+#include <type_traits>
 #include "gnnx_sparse.hpp"
 
 namespace gnnx {
@@ -926,20 +927,24 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 G[u] += (cij[u] < degT) ? sG3[cij[u]] : 0.0f;        // i == t: the layer-3 part of row t of G (row t's entries come first)
                 G[u] += (cji[u] < degT) ? sG3[cji[u]] : 0.0f;
             }
+            auto update = [&](auto ADAMc) {      // one optimiser branch around the unrolled updates (see adam_update)
+                constexpr bool ADAM = decltype(ADAMc)::value;
 #pragma unroll
-            for (int u = 0; u < EU; ++u) {
-                const float gc = (0.5f * G[u] + lap[u]) * w[u];
-                {
-                    const float S = sigmoidf_(Mij[u]);
-                    const float g = (gc + p.c_size - p.c_ent * Mij[u] * inv_n2) * S * (1.0f - S);
-                    adam_update(Mij[u], mij[u], vij[u], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
+                for (int u = 0; u < EU; ++u) {
+                    const float gc = (0.5f * G[u] + lap[u]) * w[u];
+                    {
+                        const float S = sigmoidf_(Mij[u]);
+                        const float g = (gc + p.c_size - p.c_ent * Mij[u] * inv_n2) * S * (1.0f - S);
+                        adam_update<ADAM>(Mij[u], mij[u], vij[u], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
+                    }
+                    {
+                        const float S = sigmoidf_(Mji[u]);
+                        const float g = (gc + p.c_size - p.c_ent * Mji[u] * inv_n2) * S * (1.0f - S);
+                        adam_update<ADAM>(Mji[u], mji[u], vji[u], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
+                    }
                 }
-                {
-                    const float S = sigmoidf_(Mji[u]);
-                    const float g = (gc + p.c_size - p.c_ent * Mji[u] * inv_n2) * S * (1.0f - S);
-                    adam_update(Mji[u], mji[u], vji[u], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
-                }
-            }
+            };
+            if (p.opt == 0) update(std::true_type{}); else update(std::false_type{});
 #pragma unroll
             for (int u = 0; u < EU; ++u) {
                 if (!on[u]) continue;

@@ -79,6 +79,11 @@ def _check(z, em_vals, em_feat, eoff, horizon, what, min_well, br=None, min_frac
     well = (cm <= WELL) & (cf <= WELL)
     assert well.sum() >= min_well, f"{what}: only {well.sum()} non-chaotic targets in the fixture"
     ok, msg = helpers.parity_verdict(err, ferr, well, min_frac, jump_max)
+    s_err, s_ferr, _ = helpers.branch_errors(z, None, eoff, em_vals, _sig(em_feat), early)        # strict: the reference's one output, no alternates
+    strict = (s_err <= TOL) & (s_ferr <= TOL)
+    print(f"{what} [{horizon}] three numbers: strict vs the reference's output {int((strict & well).sum())} / {int(well.sum())} non-chaotic "
+          f"({int(strict.sum())} / {len(strict)} of all targets); with the pre-declared alternates {int((well & (err <= TOL) & (ferr <= TOL)).sum())} / {int(well.sum())}; "
+          f"ungated chaotic targets {int((~well).sum())}, {int((strict & ~well).sum())} of them within 1e-5 anyway")
     bad = np.nonzero(well & ((err > TOL) | (ferr > TOL)))[0]
     ids = z["targets"] if "targets" in z.files else z["graphs"]
     print(f"{what} [{horizon}]: {msg}; {int((matched[well] >= 0).sum())} on an alternate branch; beyond 1e-5: "
