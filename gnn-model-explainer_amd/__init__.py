@@ -9,4 +9,4 @@ import os as _os
 # k-hop / packing kernels of the next batch queued behind it on another stream (measured: 4.1 ms instead of 0.3 ms for the k-hop
 # pass of pipeline.BatchPipeline).  The engine uses up to eight streams per device (three launch lanes, prepare / optimise / fetch,
 # the per-device engine stream, the caller's), so ask for eight queues - effective when set before the first HIP call.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # (the runtime's upper limit)

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -165,6 +166,14 @@ static hipStream_t lane_stream(int i) {
     hipStream_t& st = g_lane[dev][i % N_LANES];
     if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
     return st;
+}
+// a stream restricted to the compute units whose bits are set in `mask` (bit c of word c / 32 = CU c): pipeline.BatchPipeline keeps a few
+// CUs for the kernels of its prepare / fetch stages so that they do not wait for a CU behind the optimisations of the batches in flight
+// (every workgroup of a resident launch holds its CU for milliseconds; there is no preemption).  NULL on failure.
+extern "C" void* gnnx_stream_create_cu_mask(const uint32_t* mask, int32_t words) {
+    hipStream_t st = nullptr;
+    if (!mask || words < 1 || hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask) != hipSuccess) return nullptr;
+    return (void*)st;
 }
 extern "C" void* gnnx_lane_stream(int32_t i) { return (i >= 0 && i < N_LANES) ? (void*)lane_stream(i) : nullptr; }
 extern "C" int gnnx_debug_spin(void* stream, int32_t micros) {
@@ -770,13 +779,25 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
         // another group, and a 40-200 us delay kernel in front of the small launches changed nothing - measured, not
         // used; see gnnx_plan_analyze for which groups are allowed to meet.)
         // every group of this run takes the next lane (lane_stream above); a fourth group shares the first one's
-        int next_lane = 0;
+        // consecutive runs start on consecutive lanes, so that the launches of two batches in flight (pipeline.BatchPipeline keeps up to
+        // three optimisations going: a syn1 batch fills 141 of 256 CUs and lasts as long as its slowest workgroup) do not queue behind each
+        // other on one stream; a run with several groups still takes consecutive lanes from there
+        // node-mode batches of 512-thread and single-tile (64-thread class) targets: ONE launch (k_sparse_resident_mixed)
+        const bool mixed = !h->prob.graph_mode && h->n_sp[SPC_512] > 0 && h->n_sp[2] > 0;
+        // A run whose targets all sit in ONE launch group (syn1 / syn4 / syn5: the mixed launch; config 4: the 256-thread class) needs no
+        // side lane at all - nothing has to overlap inside the run: it goes to the caller's stream.  Fewer busy streams = fewer
+        // hardware queues (HIP has eight at most) for the streams of a pipelined job to collide with.
+        int n_groups = 0;
+        for (int k = 0; k < N_SPC; ++k) n_groups += (h->n_sp[k] > 0 && !(mixed && k == 2));
+        for (int nb = 1; nb <= RES_NBMAX; ++nb) n_groups += h->res_count[nb] > 0;
+        const bool single_group = n_groups == 1 && !streaming;
+        static std::atomic<unsigned> g_lane_base{0};
+        int next_lane = single_group ? 0 : (int)(g_lane_base.fetch_add(1) % N_LANES);
         auto group_stream = [&](int) -> hipStream_t {
+            if (single_group) return s;
             hipStream_t st = lane_stream(next_lane++);
             return st ? st : s;
         };
-        // node-mode batches of 512-thread and single-tile (64-thread class) targets: ONE launch (k_sparse_resident_mixed)
-        const bool mixed = !h->prob.graph_mode && h->n_sp[SPC_512] > 0 && h->n_sp[2] > 0;
         const int launch_order[N_SPC] = {SPC_LARGE, 0, SPC_512, 1, 2};   // the longest workgroups first, then the other whole-CU ones
         for (int ko = 0; ko < N_SPC; ++ko) {
             const int k = launch_order[ko];

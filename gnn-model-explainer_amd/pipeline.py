@@ -30,7 +30,7 @@ class _Prepared:
 
 
 class BatchPipeline:
-    def __init__(self, graph, state_dict, labels, hyper, n_hops=3, seed_base=1000, rng_threads=None, depth=2, lib=None):
+    def __init__(self, graph, state_dict, labels, hyper, n_hops=3, seed_base=1000, rng_threads=None, depth=3, prepare_workers=2, reserve_cus=0, lib=None):
         """graph: engine.DeviceGraph (resident); labels [N]: the label the prediction loss uses (explain.py:750-753); the initial
         mask of target v is drawn from a generator seeded with seed_base + v (the seed protocol of the golden runs)."""
         self.graph, self.sd, self.labels, self.hyper = graph, state_dict, np.asarray(labels), hyper
@@ -38,45 +38,80 @@ class BatchPipeline:
         self._edge_hyper = dataclasses.replace(hyper, edge_results_only=True)      # results leave as edge lists: no dense Abar blocks
         self.n_hops, self.seed_base = int(n_hops), int(seed_base)
         self.rng_threads = int(rng_threads) if rng_threads else engine.default_rng_threads()
+        import os
+        depth = int(os.environ.get("GNNX_PIPE_DEPTH", depth))                        # (measurement knobs)
+        prepare_workers = int(os.environ.get("GNNX_PIPE_WORKERS", prepare_workers))
         self.depth = max(1, int(depth))
         self.lib = lib if lib is not None else engine.get_library()
         dev = graph.feat.device
         self.device = dev
-        self.s_loop = torch.cuda.Stream(dev)
+        # `depth` optimisations in flight, each on its own optimise stream (the library rotates its launch lanes from run to run): a
+        # batch that fills half the GPU for the 3.75 ms of its slowest workgroup leaves room for the next one to start beside it
+        # (reserve_cus > 0 keeps that many compute units out of the optimise streams' CU masks for the prepare / fetch kernels -
+        # measured on syn1: 16 reserved CUs made the prepare stage 11 instead of 2.3 ms, its kernels crawl on 16 CUs: off by default)
+        self._masks = self._cu_masks(reserve_cus)
+        self.s_loops = [self._new_stream("loop") for _ in range(self.depth)]
+        self.s_loop = self.s_loops[0]
         self._rejected = []        # streams that share a hardware queue with a launch lane (kept alive: their queue slot stays taken)
-        self.s_prep = self._free_stream()
+        self.prepare_workers = max(1, int(prepare_workers))
+        self.s_preps = [self._free_stream() for _ in range(self.prepare_workers)]
+        self.s_prep = self.s_preps[0]
         self.s_fetch = self._free_stream()
-        self._pinned = {}          # name -> grow-only pinned host buffers (ring of `depth + 1` each)
+        self._pinned = {}          # (name, slot) -> grow-only pinned host buffers
+        self._raw_done = {}        # raw slot -> event behind the H2D copy that read it
         self._ring = 0
         self.stats = []            # per batch: host milliseconds of the stages (measurement)
 
+    def _cu_masks(self, reserve, num_cus=256):
+        """(mask of the optimise streams, mask of the prepare / fetch streams): `reserve` CUs spread evenly over the chip for the latter."""
+        if not reserve:
+            return None
+        aux = np.zeros(num_cus, bool)
+        aux[::max(1, num_cus // reserve)][:reserve] = True
+        words = lambda bits: np.packbits(bits.reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).ravel()
+        return words(~aux), words(aux)
+
+    def _new_stream(self, kind):
+        import ctypes
+        if self._masks is not None:
+            m = np.ascontiguousarray(self._masks[0 if kind == "loop" else 1])
+            ptr = self.lib.gnnx_stream_create_cu_mask(m.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), len(m))
+            if ptr:
+                return torch.cuda.ExternalStream(ptr, device=self.device)
+        # prepare / fetch streams at high priority: with the batches in flight filling the chip, their short kernels take the next
+        # compute unit a finishing optimisation workgroup frees instead of queueing behind the pending workgroups of the next batch
+        return torch.cuda.Stream(self.device, priority=-1 if kind == "aux" else 0)
+
     # -- streams -------------------------------------------------------------------------------------------------------------
-    def _free_stream(self, tries=16, spin_us=3000):
-        """A new stream whose hardware queue is not the queue of a launch lane nor of the optimise stream.  HIP binds a stream to
-        one of GPU_MAX_HW_QUEUES queues when it is created and executes the packets of one queue in order, so a prepare / fetch
-        stream that lands on the queue of the lane running a 4 ms optimisation (or on the queue where the optimise stream's barrier
-        packet waits for it) makes the next batch's k-hop kernels wait for that launch - the stages would not overlap.  Found by
-        trial: keep the lanes and the optimise stream busy for 3 ms (gnnx_debug_spin), time a trivial operation on the candidate."""
+    def _free_stream(self, tries=12, spin_us=3000):
+        """A new stream whose hardware queue is not the queue of an optimise stream nor (if possible) of a launch lane.  HIP binds a
+        stream to one of GPU_MAX_HW_QUEUES (<= 8) queues when it is created and executes the packets of one queue in order, so a
+        prepare / fetch stream that lands on the queue where a 4 ms optimisation runs - or where a barrier packet waits for it - makes the
+        next batch's k-hop kernels wait for that launch: the stages would not overlap.  Found by trial: keep those streams busy for
+        3 ms (gnnx_debug_spin), time a trivial operation on the candidate.  Runs whose targets share one launch group execute on the
+        optimise stream itself, so the lanes only matter for multi-group batches: they are avoided first, given up second."""
         dev = self.device
         lanes = [self.lib.gnnx_lane_stream(i) for i in range(3)]
         probe = torch.zeros(64, dtype=torch.int32, device=dev)
-        for _ in range(tries):
-            cand = torch.cuda.Stream(dev)
-            torch.cuda.synchronize(dev)
-            for ln in lanes:
-                if ln:
-                    self.lib.gnnx_debug_spin(ln, spin_us)
-            self.lib.gnnx_debug_spin(self.s_loop.cuda_stream, spin_us)
-            t0 = time.perf_counter()
-            with torch.cuda.stream(cand):
-                probe.add_(1)
-            cand.synchronize()
-            waited = time.perf_counter() - t0
-            torch.cuda.synchronize(dev)
-            if waited < 0.3 * spin_us * 1e-6:
-                return cand
-            self._rejected.append(cand)
-        return torch.cuda.Stream(dev)      # no free queue found (GPU_MAX_HW_QUEUES too small): the stages then serialise, correctly but slower
+        for with_lanes in (True, False):
+            for _ in range(tries):
+                cand = self._new_stream("aux")
+                torch.cuda.synchronize(dev)
+                for ln in (lanes if with_lanes else []):
+                    if ln:
+                        self.lib.gnnx_debug_spin(ln, spin_us)
+                for sl in self.s_loops:
+                    self.lib.gnnx_debug_spin(sl.cuda_stream, spin_us)
+                t0 = time.perf_counter()
+                with torch.cuda.stream(cand):
+                    probe.add_(1)
+                cand.synchronize()
+                waited = time.perf_counter() - t0
+                torch.cuda.synchronize(dev)
+                if waited < 0.3 * spin_us * 1e-6:
+                    return cand
+                self._rejected.append(cand)
+        return self._new_stream("aux")      # no free queue found: the stages then serialise, correctly but slower
 
     # -- pinned staging ----------------------------------------------------------------------------------------------------
     def _pin(self, name, numel, dtype, slot):
@@ -88,11 +123,17 @@ class BatchPipeline:
         return buf[:numel]
 
     # -- stage 1 -----------------------------------------------------------------------------------------------------------
-    def _prepare(self, targets, slot):
+    def _prepare(self, targets, k, s_prep):
         p = _Prepared()
         p.targets, p.error, p.times = targets, None, {}
         t0 = time.perf_counter()
-        with torch.cuda.stream(self.s_prep):
+        self.lib.gnnx_set_service_stream(s_prep.cuda_stream)    # this thread's plan-table uploads: not the null stream
+        slot = k % 16                                          # small host buffers (edge ids): one of 16, more than the batches in flight
+        raw_slot = k % (self.prepare_workers + 1)              # the RNG stream (n^2 floats per target): as few as the preparations in flight;
+        ev = self._raw_done.get(raw_slot)                      # it is free again once its H2D copy has finished
+        if ev is not None:
+            ev.synchronize()
+        with torch.cuda.stream(s_prep):
             dn = engine.khop_device(self.graph, targets, self.n_hops, lib=self.lib)
             p.times["khop_ms"] = (time.perf_counter() - t0) * 1e3
             if (dn.rows < 0).any():
@@ -105,7 +146,7 @@ class BatchPipeline:
                 total = int((dn.sizes.astype(np.int64) ** 2).sum())
                 try:
                     box["raw"] = engine.init_edge_masks_raw(dn.sizes, seeds=self.seed_base + targets, threads=self.rng_threads,
-                                                            out=self._pin("raw", total, torch.float32, slot))
+                                                            out=self._pin("raw", total, torch.float32, raw_slot))
                 except Exception as e:      # noqa: BLE001 - re-raised on the preparing thread
                     box["err"] = e
                 box["ms"] = (time.perf_counter() - t_r) * 1e3
@@ -125,38 +166,54 @@ class BatchPipeline:
             t2 = time.perf_counter()
             job.set_masks_raw(box["raw"])
             p.ready = torch.cuda.Event()
-            p.ready.record(self.s_prep)
+            p.ready.record(s_prep)
+            self._raw_done[raw_slot] = p.ready
             p.times["h2d_scatter_enqueue_ms"] = (time.perf_counter() - t2) * 1e3
         p.job, p.dn, p.rc, p.eoff, p.E = job, dn, rc_host, job._eoff, E
         p.times["prepare_ms"] = (time.perf_counter() - t0) * 1e3
         return p
 
     def _worker(self, batches, out_q):
-        slot = 0
-        self.lib.gnnx_set_service_stream(self.s_prep.cuda_stream)    # this thread's plan-table uploads: not the null stream
+        """Feeds out_q with prepared batches IN ORDER; the preparation itself runs on `prepare_workers` threads, each with its own
+        stream (a batch's plan + pack + layout is ~2 ms of host and device work; the optimise stage takes a new batch every ~1.9 ms)."""
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(self.prepare_workers)
+        pending = deque()
         try:
-            for targets in batches:
+            for k, targets in enumerate(batches):
                 targets = np.ascontiguousarray(targets, np.int64)
-                try:
-                    out_q.put(self._prepare(targets, slot))
-                except Exception as e:      # noqa: BLE001 - handed to the consumer
-                    p = _Prepared()
-                    p.error = e
-                    out_q.put(p)
+                pending.append(pool.submit(self._prepare, targets, k, self.s_preps[k % self.prepare_workers]))
+                while len(pending) >= self.prepare_workers + 1:
+                    if not self._emit(pending.popleft(), out_q):
+                        return
+            while pending:
+                if not self._emit(pending.popleft(), out_q):
                     return
-                slot = (slot + 1) % (self.depth + 2)
         finally:
+            pool.shutdown(wait=False)
             out_q.put(None)
+
+    @staticmethod
+    def _emit(fut, out_q):
+        try:
+            out_q.put(fut.result())
+            return True
+        except Exception as e:      # noqa: BLE001 - handed to the consumer
+            p = _Prepared()
+            p.error = e
+            out_q.put(p)
+            return False
 
     # -- stages 2 + 3 ------------------------------------------------------------------------------------------------------
     def _launch(self, p, slot):
         job = p.job
-        with torch.cuda.stream(self.s_loop):
-            self.s_loop.wait_event(p.ready)
-            job.use_stream(self.s_loop)
+        s_loop = self.s_loops[slot % len(self.s_loops)]
+        with torch.cuda.stream(s_loop):
+            s_loop.wait_event(p.ready)
+            job.use_stream(s_loop)
             job.launch(self._edge_hyper)
             done = torch.cuda.Event()
-            done.record(self.s_loop)
+            done.record(s_loop)
         with torch.cuda.stream(self.s_fetch):
             self.s_fetch.wait_event(done)
             job.use_stream(self.s_fetch)
@@ -171,7 +228,7 @@ class BatchPipeline:
 
     def run(self, batches):
         """batches: iterable of int arrays of target node ids.  Yields one engine.EdgeMasks per batch, in order."""
-        q = queue.Queue(maxsize=self.depth)
+        q = queue.Queue(maxsize=self.depth + 1)
         th = threading.Thread(target=self._worker, args=(iter(batches), q), daemon=True)
         th.start()
         pending = deque()
@@ -194,7 +251,7 @@ class BatchPipeline:
             if p.error is not None:
                 raise p.error
             pending.append((p,) + self._launch(p, slot))
-            slot = (slot + 1) % (self.depth + 2)
+            slot = (slot + 1) % (self.depth * 8)      # (a multiple of the optimise streams: launch k goes to stream k mod depth)
             while len(pending) > self.depth:
                 yield finish(pending.popleft())
         while pending:

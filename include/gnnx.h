@@ -252,6 +252,9 @@ int gnnx_auc_counts(const float* vals, const uint8_t* real, int64_t num_edges, f
  * last two exist so that a caller can check which of ITS streams share a hardware queue with a lane (HIP binds streams to
  * GPU_MAX_HW_QUEUES queues round-robin; streams on one queue execute in order). */
 int gnnx_set_service_stream(void* stream);
+/* a hipStream_t restricted to the compute units set in `mask` (bit c of word c / 32 = CU c; hipExtStreamCreateWithCUMask): a pipelined job
+ * reserves a few CUs for its prepare / fetch kernels - the workgroups of a resident launch hold their CUs for milliseconds.  NULL on failure. */
+void* gnnx_stream_create_cu_mask(const uint32_t* mask, int32_t words);
 void* gnnx_lane_stream(int32_t i);
 int gnnx_debug_spin(void* stream, int32_t micros);
 
