@@ -40,6 +40,7 @@ class BatchPipeline:
         self.rng_threads = int(rng_threads) if rng_threads else engine.default_rng_threads()
         import os
         depth = int(os.environ.get("GNNX_PIPE_DEPTH", depth))                        # (measurement knobs)
+        reserve_cus = int(os.environ.get("GNNX_PIPE_RESERVE", reserve_cus))
         prepare_workers = int(os.environ.get("GNNX_PIPE_WORKERS", prepare_workers))
         self.depth = max(1, int(depth))
         self.lib = lib if lib is not None else engine.get_library()
@@ -50,13 +51,14 @@ class BatchPipeline:
         # (reserve_cus > 0 keeps that many compute units out of the optimise streams' CU masks for the prepare / fetch kernels -
         # measured on syn1: 16 reserved CUs made the prepare stage 11 instead of 2.3 ms, its kernels crawl on 16 CUs: off by default)
         self._masks = self._cu_masks(reserve_cus)
-        self.s_loops = [self._new_stream("loop") for _ in range(self.depth)]
-        self.s_loop = self.s_loops[0]
-        self._rejected = []        # streams that share a hardware queue with a launch lane (kept alive: their queue slot stays taken)
+        self._rejected = []        # streams that share a hardware queue with one already chosen (kept alive: their queue slot stays taken)
+        self._chosen = []
         self.prepare_workers = max(1, int(prepare_workers))
-        self.s_preps = [self._free_stream() for _ in range(self.prepare_workers)]
+        self.s_loops = [self._distinct_stream("loop") for _ in range(self.depth)]
+        self.s_loop = self.s_loops[0]
+        self.s_preps = [self._distinct_stream("aux") for _ in range(self.prepare_workers)]
         self.s_prep = self.s_preps[0]
-        self.s_fetch = self._free_stream()
+        self.s_fetch = self._distinct_stream("aux")
         self._pinned = {}          # (name, slot) -> grow-only pinned host buffers
         self._raw_done = {}        # raw slot -> event behind the H2D copy that read it
         self._ring = 0
@@ -73,8 +75,8 @@ class BatchPipeline:
 
     def _new_stream(self, kind):
         import ctypes
-        if self._masks is not None:
-            m = np.ascontiguousarray(self._masks[0 if kind == "loop" else 1])
+        if self._masks is not None and kind == "loop":      # only the optimise streams are restricted; prepare / fetch kernels may use every CU
+            m = np.ascontiguousarray(self._masks[0])
             ptr = self.lib.gnnx_stream_create_cu_mask(m.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), len(m))
             if ptr:
                 return torch.cuda.ExternalStream(ptr, device=self.device)
@@ -83,35 +85,36 @@ class BatchPipeline:
         return torch.cuda.Stream(self.device, priority=-1 if kind == "aux" else 0)
 
     # -- streams -------------------------------------------------------------------------------------------------------------
-    def _free_stream(self, tries=12, spin_us=3000):
-        """A new stream whose hardware queue is not the queue of an optimise stream nor (if possible) of a launch lane.  HIP binds a
-        stream to one of GPU_MAX_HW_QUEUES (<= 8) queues when it is created and executes the packets of one queue in order, so a
-        prepare / fetch stream that lands on the queue where a 4 ms optimisation runs - or where a barrier packet waits for it - makes the
-        next batch's k-hop kernels wait for that launch: the stages would not overlap.  Found by trial: keep those streams busy for
-        3 ms (gnnx_debug_spin), time a trivial operation on the candidate.  Runs whose targets share one launch group execute on the
-        optimise stream itself, so the lanes only matter for multi-group batches: they are avoided first, given up second."""
+    def _distinct_stream(self, kind, tries=16, spin_us=2000):
+        """A new stream on a hardware queue none of the pipeline's other streams uses.  HIP binds a stream to one of GPU_MAX_HW_QUEUES
+        (<= 8) queues when it is created and executes the packets of one queue in order, so two optimise streams on one queue would run
+        their batches one after the other, and a prepare / fetch stream that lands on the queue where a 4 ms optimisation runs makes the
+        next batch's k-hop kernels wait for that launch - the stages would not overlap (measured: 4.1 instead of 0.3 ms for the k-hop pass,
+        and end-to-end rates between 119 k and 152 k nodes/s from run to run before the streams were checked against each other).  Found
+        by trial: keep the streams already chosen busy for 2 ms each (gnnx_debug_spin), time a trivial operation on the candidate."""
         dev = self.device
-        lanes = [self.lib.gnnx_lane_stream(i) for i in range(3)]
         probe = torch.zeros(64, dtype=torch.int32, device=dev)
-        for with_lanes in (True, False):
-            for _ in range(tries):
-                cand = self._new_stream("aux")
-                torch.cuda.synchronize(dev)
-                for ln in (lanes if with_lanes else []):
-                    if ln:
-                        self.lib.gnnx_debug_spin(ln, spin_us)
-                for sl in self.s_loops:
-                    self.lib.gnnx_debug_spin(sl.cuda_stream, spin_us)
-                t0 = time.perf_counter()
-                with torch.cuda.stream(cand):
-                    probe.add_(1)
-                cand.synchronize()
-                waited = time.perf_counter() - t0
-                torch.cuda.synchronize(dev)
-                if waited < 0.3 * spin_us * 1e-6:
-                    return cand
-                self._rejected.append(cand)
-        return self._new_stream("aux")      # no free queue found: the stages then serialise, correctly but slower
+        for _ in range(tries):
+            cand = self._new_stream(kind)
+            if not self._chosen:
+                self._chosen.append(cand)
+                return cand
+            torch.cuda.synchronize(dev)
+            for st in self._chosen:
+                self.lib.gnnx_debug_spin(st.cuda_stream, spin_us)
+            t0 = time.perf_counter()
+            with torch.cuda.stream(cand):
+                probe.add_(1)
+            cand.synchronize()
+            waited = time.perf_counter() - t0
+            torch.cuda.synchronize(dev)
+            if waited < 0.3 * spin_us * 1e-6:
+                self._chosen.append(cand)
+                return cand
+            self._rejected.append(cand)
+        cand = self._new_stream(kind)      # no free queue found: some stages then serialise, correctly but slower
+        self._chosen.append(cand)
+        return cand
 
     # -- pinned staging ----------------------------------------------------------------------------------------------------
     def _pin(self, name, numel, dtype, slot):
@@ -154,12 +157,17 @@ class BatchPipeline:
             th.start()
             t1 = time.perf_counter()
             job = engine.MaskOptimJob.from_csr(self.graph, dn, None, self.labels[targets], self.sd, lib=self.lib)
+            p.times["plan_pack_route_ms"] = (time.perf_counter() - t1) * 1e3
+            t1b = time.perf_counter()
             job._edge_layout()
             E = int(job._eoff[-1])
             rc_host = self._pin("rc", 2 * max(E, 1), torch.int32, slot).view(-1, 2)
             rc_host[:E].copy_(job._rc[:E], non_blocking=True)
+            p.times["edge_layout_ms"] = (time.perf_counter() - t1b) * 1e3
             p.times["plan_pack_route_layout_ms"] = (time.perf_counter() - t1) * 1e3
+            t1c = time.perf_counter()
             th.join()
+            p.times["wait_for_rng_ms"] = (time.perf_counter() - t1c) * 1e3
             if "err" in box:
                 raise box["err"]
             p.times["host_rng_ms"] = box["ms"]
