@@ -200,6 +200,14 @@ struct gnnx_plan_s {
     int32_t* d_big = nullptr;        // target ids of the streaming set
     ConvTile* d_conv_big = nullptr;
     MaskTile* d_mask_big = nullptr;
+    // work units of k_conv (groups of adjacent row blocks, largest targets first) for the two tile tables
+    ConvUnit* d_unit = nullptr;
+    ConvUnit* d_unit_big = nullptr;
+    ConvJoin* d_join = nullptr;
+    ConvJoin* d_join_big = nullptr;
+    int n_unit = 0, n_unit_big = 0, n_join = 0, n_join_big = 0;
+    float* d_cpart = nullptr;        // slabs of the K slices (shared by the two tables: one of them runs at a time)
+    size_t cap_slabs = 0;
     // the resident kernels run beside the streaming launches, each group on its own stream:
     // [0..RES_NBMAX) dense resident kernels by row blocks, [RES_NBMAX + k] sparse resident kernel of size class k
     hipEvent_t ev_in = nullptr, ev_out[N_SIDE] = {};
@@ -237,6 +245,80 @@ struct gnnx_plan_s {
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Units of k_conv for a tile table (row blocks of a target are adjacent in it), longest K range first, and the row blocks whose
+// slices k_conv_reduce joins.  Both knobs are OFF by default - measured on the BA-House x100k streaming set (243 targets, ld up
+// to 4992; tools/probe_conv.py, profiles/r03_conv_*): with the ring K loop one row block per workgroup over whole rows runs at
+// 82-90 us per launch, K slices of 2048 / 1024 / 512 rows at 95 / 97 / 109, groups of 2 / 4 row blocks at 90 / 105.
+//   GNNX_CONV_KU   = K rows per slice (0 = whole rows; a target of ld >= 1.5 KU is cut into round(ld / KU) slices whose
+//                    partial tiles meet in slabs; k_conv_reduce joins them in the next launch - an in-launch join with agent-scope
+//                    release / acquire fences was measured too: 166 -> 530 us as the slices get shorter, the L2 write-back of
+//                    the release dominates)
+//   GNNX_CONV_WIDE = row blocks per workgroup for ld >= 256 (1, 2 or 4)
+struct UnitTables {
+    std::vector<ConvUnit> units;
+    std::vector<ConvJoin> joins;
+    int slabs = 0;
+};
+static UnitTables make_units(const std::vector<ConvTile>& tiles) {
+    UnitTables o;
+    o.units.reserve(tiles.size());
+    const char* e_wide = getenv("GNNX_CONV_WIDE");
+    const char* e_ku = getenv("GNNX_CONV_KU");
+    const int wide = e_wide ? atoi(e_wide) : 1;
+    const int ku = e_ku ? atoi(e_ku) : 0;
+    for (size_t i = 0; i < tiles.size();) {
+        const ConvTile& tl = tiles[i];
+        const int ld = tl.tm.ld, nb = ld / TILE;
+        int nrb = 1;
+        if (ld >= 256 && wide > 1) {
+            const int left = nb - tl.rb;
+            nrb = (left >= 4 && wide >= 4) ? 4 : (left >= 2) ? 2 : 1;
+        }
+        int nks = (ku >= TILE && ld >= ku + ku / 2) ? (ld + ku / 2) / ku : 1;
+        if (nks > nb) nks = nb;
+        for (int ks = 0; ks < nks; ++ks) {
+            const int b0 = (int)((int64_t)nb * ks / nks), b1 = (int)((int64_t)nb * (ks + 1) / nks);
+            o.units.push_back({tl.t, tl.rb, nrb, b0 * TILE, b1 * TILE, ks, nks, nks > 1 ? o.slabs : 0, tl.tm});
+        }
+        if (nks > 1) {
+            for (int j = 0; j < nrb; ++j) o.joins.push_back({tl.t, tl.rb + j, nks, o.slabs + j * nks, tl.tm});
+            o.slabs += nrb * nks;
+        }
+        i += nrb;
+    }
+    std::stable_sort(o.units.begin(), o.units.end(), [](const ConvUnit& a, const ConvUnit& b) { return a.ke - a.kb > b.ke - b.kb; });
+    return o;
+}
+
+static hipError_t upload_units(gnnx_handle h, const std::vector<ConvTile>& tiles, ConvUnit*& d_units, int& n_units, ConvJoin*& d_joins,
+                                int& n_joins) {
+    const UnitTables ut = make_units(tiles);
+    if (d_units) (void)pool_free(d_units);
+    if (d_joins) (void)pool_free(d_joins);
+    d_units = nullptr;
+    d_joins = nullptr;
+    n_units = (int)ut.units.size();
+    n_joins = (int)ut.joins.size();
+    hipError_t e;
+    if (n_units) {
+        if ((e = pool_malloc(&d_units, sizeof(ConvUnit) * ut.units.size())) != hipSuccess) return e;
+        if ((e = upload_sync(d_units, ut.units.data(), sizeof(ConvUnit) * ut.units.size())) != hipSuccess) return e;
+    }
+    if (n_joins) {
+        if ((e = pool_malloc(&d_joins, sizeof(ConvJoin) * ut.joins.size())) != hipSuccess) return e;
+        if ((e = upload_sync(d_joins, ut.joins.data(), sizeof(ConvJoin) * ut.joins.size())) != hipSuccess) return e;
+    }
+    if ((size_t)ut.slabs > h->cap_slabs) {
+        if (h->d_cpart) (void)pool_free(h->d_cpart);
+        h->d_cpart = nullptr;
+        h->cap_slabs = 0;
+        if ((e = pool_malloc(&h->d_cpart, sizeof(float) * TILE * FS * (size_t)ut.slabs)) != hipSuccess) return e;
+        h->cap_slabs = ut.slabs;
+    }
+    return hipSuccess;
+}
+
 // (Re)build the hybrid split from h->cat: id lists of the resident kernels, tile tables of the streaming remainder,
 // side streams.  Invalidates a captured graph.
 static int build_split(gnnx_handle h) {
@@ -292,6 +374,7 @@ static int build_split(gnnx_handle h) {
     if (any_resident && h->n_big) {
         SPLITCK(upload(h->d_big, big_ids));
         SPLITCK(upload(h->d_conv_big, conv_big));
+        SPLITCK(upload_units(h, conv_big, h->d_unit_big, h->n_unit_big, h->d_join_big, h->n_join_big));
         SPLITCK(upload(h->d_mask_big, mask_big));
     }
     if (any_resident && !h->ev_in) SPLITCK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
@@ -409,6 +492,7 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
     PLANCK(pool_malloc(&h->d_wts, sizeof(float) * WT_TOTAL));
     PLANCK(upload_sync(h->d_meta, h->meta.data(), sizeof(TargetMeta) * T));
     PLANCK(upload_sync(h->d_conv, conv.data(), sizeof(ConvTile) * conv.size()));
+    PLANCK(upload_units(h, conv, h->d_unit, h->n_unit, h->d_join, h->n_join));
     PLANCK(upload_sync(h->d_mask, mask.data(), sizeof(MaskTile) * mask.size()));
     PLANCK(upload_sync(h->d_wts, w.data(), sizeof(float) * WT_TOTAL));
     {
@@ -490,6 +574,11 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
     if (h->d_conv_big) (void)pool_free(h->d_conv_big);
     if (h->d_mask_big) (void)pool_free(h->d_mask_big);
     if (h->d_conv) (void)pool_free(h->d_conv);
+    if (h->d_unit) (void)pool_free(h->d_unit);
+    if (h->d_unit_big) (void)pool_free(h->d_unit_big);
+    if (h->d_join) (void)pool_free(h->d_join);
+    if (h->d_join_big) (void)pool_free(h->d_join_big);
+    if (h->d_cpart) (void)pool_free(h->d_cpart);
     if (h->d_mask) (void)pool_free(h->d_mask);
     if (h->d_wts) (void)pool_free(h->d_wts);
     delete h;
@@ -526,6 +615,7 @@ static Params make_params(gnnx_handle h, const gnnx_hyper* hy, const float* A, c
     p.Zraw = reinterpret_cast<float*>(w + h->o_Zraw);
     p.g3 = reinterpret_cast<float*>(w + h->o_g3);
     p.z3p = reinterpret_cast<float*>(w + h->o_z3p);
+    p.cpart = h->d_cpart;
     for (int l = 0; l < 3; ++l) {
         p.U[l] = reinterpret_cast<float*>(w + h->o_U[l]);
         p.UT[l] = reinterpret_cast<float*>(w + h->o_UT[l]);
@@ -588,6 +678,10 @@ static void adam_scalars(const gnnx_hyper* hy, int it, float* step_size, float* 
 
 // which tile tables a launch sequence walks: all targets, or only the streaming ("big") set of a hybrid run
 struct Tables {
+    const ConvUnit* unit;  // k_conv: groups of adjacent row blocks x K slice
+    int n_unit;
+    const ConvJoin* join;  // k_conv_reduce: the row blocks cut into slices
+    int n_join;
     const ConvTile* conv;
     int n_conv;
     const MaskTile* mask;
@@ -595,12 +689,13 @@ struct Tables {
     const int32_t* ids;  // target ids for per-target kernels (null = 0..T-1)
     int n_targets;
 };
-static Tables tables_all(gnnx_handle h) { return {h->d_conv, h->n_conv, h->d_mask, h->n_mask, nullptr, h->prob.num_targets}; }
-static Tables tables_big(gnnx_handle h) { return {h->d_conv_big, h->n_conv_big, h->d_mask_big, h->n_mask_big, h->d_big, h->n_big}; }
+static Tables tables_all(gnnx_handle h) { return {h->d_unit, h->n_unit, h->d_join, h->n_join, h->d_conv, h->n_conv, h->d_mask, h->n_mask, nullptr, h->prob.num_targets}; }
+static Tables tables_big(gnnx_handle h) { return {h->d_unit_big, h->n_unit_big, h->d_join_big, h->n_join_big, h->d_conv_big, h->n_conv_big, h->d_mask_big, h->n_mask_big, h->d_big, h->n_big}; }
 
 template <int MODE>
 static void launch_conv(const Tables& tb, const Params& p, int it, hipStream_t s) {
-    hipLaunchKernelGGL((k_conv<MODE>), dim3(tb.n_conv), dim3(256), 0, s, p, tb.conv, it);
+    hipLaunchKernelGGL((k_conv<MODE>), dim3(tb.n_unit), dim3(256), 0, s, p, tb.unit, it);
+    if (MODE != BWD3 && tb.n_join) hipLaunchKernelGGL((k_conv_reduce<MODE>), dim3(tb.n_join), dim3(256), 0, s, p, tb.join, it);
 }
 
 template <bool UPDATE, bool WRITE_ABAR>

@@ -52,6 +52,13 @@ struct TargetMeta {
 // tile-table entries carry a copy of the target's meta: one dependent load per workgroup instead of two
 struct ConvTile { int32_t t, rb; TargetMeta tm; };               // target, 32-row block
 struct MaskTile { int32_t t, I, J; int32_t pad; TargetMeta tm; };  // target, tile pair I <= J
+// Work unit of the masked-adjacency contraction: nrb in {1, 2, 4} adjacent 32-row blocks of one target from row block rb, over
+// the K range [kb, ke).  Rows of large targets are cut into nks such slices (this is slice ks); each slice leaves its partial
+// tile of row block rb + j in slab part + j * nks + ks and k_conv_reduce (the next launch: no in-kernel fences) sums the
+// slabs in slice order and runs the row-local epilogue.  nks = 1: the unit runs the epilogue itself.
+struct ConvUnit { int32_t t, rb, nrb, kb, ke, ks, nks, part; TargetMeta tm; };
+// a row block whose slices meet in slabs part .. part + nks - 1
+struct ConvJoin { int32_t t, rb, nks, part; TargetMeta tm; };
 
 struct Params {
     const TargetMeta* meta;
@@ -70,6 +77,7 @@ struct Params {
     float* dZ[3];       // gradients w.r.t. the aggregated inputs, row-major [R][32]
     float* dZT[3];      // same, column-major
     float* g3;          // node mode: layer-3 part of row t of G, one float per row [R]
+    float* cpart;       // partial tiles of the K slices of k_conv, 32 x 32 floats each
     float* z3p;         // node mode: per row block partial of row t of Abar . relu(U2)  [R/32][32]
     float* dE;          // direct gradient of the concatenated embedding [T][3][32]
     int32_t* argrow;    // row that receives dE[l][c]  [T][3][32]
@@ -250,6 +258,7 @@ struct ConvShared {
     float wl[32 * 33];         // layer weight, padded rows
     float zs[TILE * 33];       // reduced Z rows, then dY staging
     float phis[32];
+    float part[4 * 32];  // per-wave partials of the row-set reductions (red holds the tiles of the other row blocks)
 };
 
 // Fused row-local epilogue for 32 rows: thread (row = tid/8, cg = 4 (tid%8)) holds z4 = the reduced contraction of
@@ -333,12 +342,12 @@ __device__ __forceinline__ void conv_epilogue(const Params& p, const ConvTile& t
             __syncthreads();
             if (lane < 8) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sh.red[wave * 32 + cg + j] = part[j];
+                for (int j = 0; j < 4; ++j) sh.part[wave * 32 + cg + j] = part[j];
             }
             __syncthreads();
             if (tid < 32)
                 p.z3p[((size_t)(tm.offR >> 5) + slot) * FS + tid] =
-                    sh.red[tid] + sh.red[32 + tid] + sh.red[64 + tid] + sh.red[96 + tid];
+                    sh.part[tid] + sh.part[32 + tid] + sh.part[64 + tid] + sh.part[96 + tid];
         }
     } else {
         // BWD3 / BWD2 / BWD1: dX (+ direct part) -> dZ_layer
@@ -383,12 +392,12 @@ __device__ __forceinline__ void conv_epilogue(const Params& p, const ConvTile& t
             __syncthreads();
             if (lane < 8) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sh.red[wave * 32 + cg + j] = part[j];
+                for (int j = 0; j < 4; ++j) sh.part[wave * 32 + cg + j] = part[j];
             }
             __syncthreads();
             if (tid < 32)  // one partial per row set, summed in a fixed order by k_mask (deterministic)
                 p.df[((size_t)(tm.offR >> 5) + slot) * FS + tid] =
-                    sh.red[tid] + sh.red[32 + tid] + sh.red[64 + tid] + sh.red[96 + tid];
+                    sh.part[tid] + sh.part[32 + tid] + sh.part[64 + tid] + sh.part[96 + tid];
         }
     }
 }
@@ -434,24 +443,23 @@ __device__ __forceinline__ const float* conv_b_source(const Params& p) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, int iter) {
+__global__ __launch_bounds__(256) void k_conv(Params p, const ConvUnit* units, int iter) {
     __shared__ ConvShared sh;
-    const ConvTile tl = tiles[blockIdx.x];
-    const TargetMeta tm = tl.tm;
+    const ConvUnit cu = units[blockIdx.x];
+    if (MODE == BWD3 && cu.ks) return;  // no contraction in BWD3: the first slice does the row blocks
+    const TargetMeta tm = cu.tm;
     const int ld = tm.ld;
-    const int row0 = tl.rb * TILE;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    // nrb in {1, 2, 4} adjacent row blocks per workgroup, the K range cut into 4 / nrb slices: wave w contracts row block
+    // rb + w % nrb over slice w / nrb.  Waves of one slice read ADJACENT 128-B segments of the same rows of Abar (512 B
+    // contiguous for nrb = 4) and the same rows of the B operand.
+    const int nrb = cu.nrb, ksplit = 4 / nrb;
+    const int wj = wave % nrb, ws = wave / nrb;
+    const int row0 = (cu.rb + wj) * TILE;
+    const ConvTile tl = {cu.t, cu.rb, cu.tm};
     conv_stage_weights<MODE>(p, tl, sh, iter);
-
-    // epilogue operands, loaded BEFORE the contraction so their latency hides under it
     const int row = tid >> 3, cg = (tid & 7) * 4;
-    const int irow = row0 + row;
-    f32x4 pre_a = {0.0f, 0.0f, 0.0f, 0.0f}, pre_b = pre_a, pre_c = pre_a;
-    int pre_ar[4] = {-1, -1, -1, -1};
-    float pre_rn = 1.0f, pre_rs = 1.0f;
-    f32x4 pre_x = pre_a;
-    conv_epilogue_operands<MODE>(p, tl, tm, irow, cg, pre_a, pre_b, pre_c, pre_ar, pre_rn, pre_x, pre_rs);
 
     f32x16 acc;
 #pragma unroll
@@ -459,14 +467,14 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
     if (MODE != BWD3) {
         const float* Bsrc = conv_b_source<MODE>(p) + tm.offR * FS + li;
         const bool relu_b = (MODE == FWD2 || MODE == FWD3) && !p.bn;
-        const int kchunk = ld >> 2;  // multiple of 8
+        const int kchunk = (cu.ke - cu.kb) / ksplit;  // per wave; a multiple of 8
         if (ld < 256) {
-            // small targets (latency-bound): lane (i = li, half h) reads 16 B of row row0+i,
+            // small targets (latency-bound; nrb = 1): lane (i = li, half h) reads 16 B of row row0+i,
             // Abar[row0+i][k0 + 8u + 4h .. +3].  The MFMA k index is a free permutation as long as A and B agree,
             // so step e of a batch uses k = k0 + 8u + 4h + e: one 16-B load feeds 4 MFMAs.  Measured on syn1:
             // 9.5-10.8 us per launch vs 11.0-11.5 us for the 4-B form below.
             const float* Ab = p.Abar + tm.offQ + (size_t)(row0 + li) * ld + 4 * h;
-            const int k0 = wave * kchunk;
+            const int k0 = cu.kb + ws * kchunk;
             constexpr int NB = 4;  // batches of 8 k values in flight per wave
             f32x4 a[NB];
             float b[NB][4];
@@ -497,52 +505,95 @@ __global__ __launch_bounds__(256) void k_conv(Params p, const ConvTile* tiles, i
             // 128-B fully coalesced segments straight into the MFMA A layout.  The row form above touches 32
             // cache lines per wave instruction and was 12 % slower here (BA-House x100k: 152-162 vs 171-181 us).
             const float* Ab = p.Abar + tm.offQ + row0 + li;
-            const int k0 = wave * kchunk + h;
-            // the launch ends with the workgroups of the largest target, and their K loop is a chain of dependent round
-            // trips to HBM: KB k pairs per batch, two batches in flight per wave (KB = 8: 39 round trips for ld = 2464)
-            constexpr int KB = 16;
-            float a0[KB], b0[KB], a1[KB], b1[KB];
-            auto loadb = [&](float (&a)[KB], float (&b)[KB], int s0) {
-#pragma unroll
-                for (int u = 0; u < KB; ++u) {
-                    const bool on = (s0 + 2 * u) < kchunk;  // a batch spans 2 KB k values, kchunk is a multiple of 8
-                    const int k = k0 + s0 + 2 * u;
-                    a[u] = on ? Ab[(size_t)k * ld] : 0.0f;
-                    b[u] = on ? Bsrc[(size_t)k * FS] : 0.0f;
-                }
+            const int k0 = cu.kb + ws * kchunk + h;
+            // A ring of RING k pairs in flight per wave: step j feeds pair j to the MFMA and at once re-issues that slot's
+            // loads for pair j + RING, so the loads stay RING deep WHILE the MFMAs run.  (Round 2 ran batches - 16 MFMAs, then
+            // the 32 loads of the batch after next - with predicated loads that compiled to a branch and a wait per load.)
+            // Straight-line code: a load past the end of the slice reads the slice's last pair again (an L1 hit) and the
+            // select that zeroes it sits at the USE.  Measured on the BA-House x100k streaming set (tools/probe_conv.py,
+            // one box): batches 119 us per launch; ring 32 (4 waves per SIMD) 90; rings 8 / 12 / 16 / 24 (5 waves) 82-85.
+            // tools/micro/stream_pattern.hip puts the ceiling of "one 32x32x2 MFMA + one B row pair per A row pair" at
+            // 3.6 TB/s of Abar against 6.4 for the bare stream - the MFMA step and the B loads cost 2.3 and 1.4 TB/s.
+#ifndef GNNX_CONV_RING  // (measurement knob, tools/probe_conv.py)
+#define GNNX_CONV_RING 16
+#endif
+            constexpr int RING = GNNX_CONV_RING;
+            float ra[RING], rb[RING];
+            const int klast = kchunk - 2;
+            auto fetch = [&](int slot, int ks) {  // ks = k offset of the pair inside the slice (even); kchunk is a multiple of 8
+                const int k = k0 + (ks < klast ? ks : klast);
+                ra[slot] = Ab[(size_t)k * ld];
+                rb[slot] = Bsrc[(size_t)k * FS];
             };
-            auto mmab = [&](const float (&a)[KB], const float (&b)[KB]) {
 #pragma unroll
-                for (int u = 0; u < KB; ++u) {
-                    float bb = b[u];
+            for (int u = 0; u < RING; ++u) fetch(u, 2 * u);
+            __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks the loads next to their uses: 3-5 in flight)
+            for (int s0 = 0; s0 < kchunk; s0 += 2 * RING) {
+#pragma unroll
+                for (int u = 0; u < RING; ++u) {
+                    const bool on = s0 + 2 * u < kchunk;  // (the select sits at the USE: next to the load it would wait for it)
+                    float bb = on ? rb[u] : 0.0f;
                     if (relu_b) bb = fmaxf(bb, 0.0f);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bb, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(on ? ra[u] : 0.0f, bb, acc, 0, 0, 0);
+                    fetch(u, s0 + 2 * RING + 2 * u);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            };
-            loadb(a0, b0, 0);
-            for (int s0 = 0; s0 < kchunk; s0 += 4 * KB) {
-                const bool more1 = s0 + 2 * KB < kchunk;
-                if (more1) loadb(a1, b1, s0 + 2 * KB);
-                mmab(a0, b0);
-                const bool more0 = s0 + 4 * KB < kchunk;
-                if (more0) loadb(a0, b0, s0 + 4 * KB);
-                if (more1) mmab(a1, b1);
             }
         }
     }
-    // split-K reduction through LDS
+    // the wave tiles meet in LDS: tile w = row block w % nrb, K slice w / nrb
 #pragma unroll
     for (int r = 0; r < 16; ++r) sh.red[(wave * TILE + acc_row(r, h)) * 33 + li] = acc[r];
-    __syncthreads();
-    float z4[4];
+    for (int j = 0; j < nrb; ++j) {
+        __syncthreads();  // tiles complete / the previous row block's epilogue is done with zs
+        const int irow = (cu.rb + j) * TILE + row;
+        float z4[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float s = 0.0f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) s += sh.red[(w * TILE + row) * 33 + cg + j];
-        z4[j] = s;
+        for (int q = 0; q < 4; ++q) {
+            float s = 0.0f;
+            for (int w = j; w < 4; w += nrb) s += sh.red[(w * TILE + row) * 33 + cg + q];
+            z4[q] = s;
+        }
+        if (MODE != BWD3 && cu.nks > 1) {  // one K slice of several: the partial tile goes to its slab
+            *reinterpret_cast<f32x4*>(p.cpart + ((size_t)cu.part + j * cu.nks + cu.ks) * (TILE * FS) + row * FS + cg) =
+                f32x4{z4[0], z4[1], z4[2], z4[3]};
+            continue;
+        }
+        f32x4 pre_a = {0.0f, 0.0f, 0.0f, 0.0f}, pre_b = pre_a, pre_c = pre_a;
+        int pre_ar[4] = {-1, -1, -1, -1};
+        float pre_rn = 1.0f, pre_rs = 1.0f;
+        f32x4 pre_x = pre_a;
+        conv_epilogue_operands<MODE>(p, tl, tm, irow, cg, pre_a, pre_b, pre_c, pre_ar, pre_rn, pre_x, pre_rs);
+        conv_epilogue<MODE>(p, tl, tm, sh, z4, irow, cu.rb + j, pre_a, pre_b, pre_c, pre_ar, pre_rn, pre_x, pre_rs);
     }
-    conv_epilogue<MODE>(p, tl, tm, sh, z4, irow, tl.rb, pre_a, pre_b, pre_c, pre_ar, pre_rn, pre_x, pre_rs);
+}
+
+// The row blocks whose K range was cut: sum the slabs in slice order (deterministic), then the same epilogue.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_conv_reduce(Params p, const ConvJoin* joins, int iter) {
+    __shared__ ConvShared sh;
+    const ConvJoin jn = joins[blockIdx.x];
+    const TargetMeta tm = jn.tm;
+    const ConvTile tl = {jn.t, jn.rb, jn.tm};
+    const int tid = threadIdx.x;
+    const int row = tid >> 3, cg = (tid & 7) * 4;
+    const int irow = jn.rb * TILE + row;
+    conv_stage_weights<MODE>(p, tl, sh, iter);
+    f32x4 pre_a = {0.0f, 0.0f, 0.0f, 0.0f}, pre_b = pre_a, pre_c = pre_a;
+    int pre_ar[4] = {-1, -1, -1, -1};
+    float pre_rn = 1.0f, pre_rs = 1.0f;
+    f32x4 pre_x = pre_a;
+    conv_epilogue_operands<MODE>(p, tl, tm, irow, cg, pre_a, pre_b, pre_c, pre_ar, pre_rn, pre_x, pre_rs);
+    const f32x4* slab = reinterpret_cast<const f32x4*>(p.cpart + (size_t)jn.part * (TILE * FS) + row * FS + cg);
+    f32x4 acc = slab[0];
+    for (int q = 1; q < jn.nks; ++q) {
+        const f32x4 v = slab[(size_t)q * (TILE * FS / 4)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += v[j];
+    }
+    float z4[4] = {acc[0], acc[1], acc[2], acc[3]};
+    __syncthreads();  // weights staged
+    conv_epilogue<MODE>(p, tl, tm, sh, z4, irow, jn.rb, pre_a, pre_b, pre_c, pre_ar, pre_rn, pre_x, pre_rs);
 }
 
 // softmax head shared by both modes: e[96] (concatenated embedding) -> probs, g = p - onehot, dE = Wp^T g.

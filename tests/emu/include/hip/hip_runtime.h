@@ -63,6 +63,7 @@ inline unsigned long long __ballot(bool pred) { return emu::ballot(pred); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline void __threadfence_block() {}
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_wave_barrier() emu::wave_sync()
 #define __builtin_amdgcn_readfirstlane(v) emu::shfl_i((v), 0)
 #define __builtin_amdgcn_readlane(v, k) emu::shfl_i((v), (k))

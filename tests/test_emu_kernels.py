@@ -129,6 +129,37 @@ def test_large_target_many_row_blocks(be, sparse):
         assert np.abs(res.mask[0] - o.M).max() < 2e-5
 
 
+@pytest.mark.parametrize("graph_mode,wide,ku", [(False, "1", "64"), (True, "1", "96"), (False, "4", "0"), (True, "4", "64"), (False, "2", "128")])
+def test_contraction_units_slices_and_row_block_groups(be, graph_mode, wide, ku, monkeypatch):
+    """k_conv cuts the K range of long rows into slices (GNNX_CONV_KU; partial tiles in slabs, k_conv_reduce joins them in slice
+    order in the next launch) and can run groups of 4 / 2 / 1 adjacent row blocks per workgroup (GNNX_CONV_WIDE).  n = 310
+    (ld = 320, 10 row blocks: groups 4 + 4 + 2, 5 / 3 / 2 slices) and n = 275 (ld = 288, 9 row blocks: 4 + 4 + 1).  Every
+    combination has to agree with whole rows / one row block per workgroup to summation-order noise and with the closed form."""
+    ck, gx, sg = _node_case("syn1", 300)
+    keep = np.unique(np.r_[np.arange(274), sg.target_row])[:275]
+    if sg.target_row not in keep:
+        keep[-1] = sg.target_row
+        keep = np.sort(keep)
+    row = int(np.searchsorted(keep, sg.target_row))
+    cases = [sg, Subgraph(sg.adj[np.ix_(keep, keep)], sg.feat[keep], sg.gt_label, row, sg.pred_label[keep], sg.mask0[np.ix_(keep, keep)])]
+    if graph_mode:
+        cases = [Subgraph(c.adj, c.feat, c.gt_label, 0, None, c.mask0) for c in cases]
+    hy = Hyper(num_iters=3, record_loss=True)
+    runs = {}
+    for key, (w, k) in {"plain": ("1", "0"), "cut": (wide, ku)}.items():
+        monkeypatch.setenv("GNNX_CONV_WIDE", w)
+        monkeypatch.setenv("GNNX_CONV_KU", k)
+        job = be.job(cases, ck["sd"], graph_mode=graph_mode, analyze=False)
+        runs[key] = job.run([c.mask0 for c in cases], hy)
+    for k, c in enumerate(cases):
+        o = closed_form.ClosedFormOracle(c.adj, c.feat, ck["sd"], c.gt_label, c.pred_label, c.target_row, c.mask0, graph_mode=graph_mode)
+        want = o.run(3)
+        assert np.abs(runs["cut"].masked_adj[k] - want).max() < 2e-6
+        assert np.abs(runs["cut"].feat_mask[k] - o.f).max() < 2e-5
+        assert np.abs(runs["cut"].masked_adj[k] - runs["plain"].masked_adj[k]).max() < 1e-6
+        assert np.allclose(runs["cut"].loss[k], runs["plain"].loss[k], rtol=1e-5, atol=1e-7)
+
+
 @pytest.mark.parametrize("analyze", [False, True])
 def test_resident_kernel_matches_streaming_and_reference(be, analyze):
     """Single-tile targets (n <= 32) run on chip: in the dense resident kernel k_resident<1> (plan not analysed) or in the
