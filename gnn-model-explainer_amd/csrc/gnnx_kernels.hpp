@@ -877,33 +877,21 @@ __global__ __launch_bounds__(256, 4) void k_mask(Params p, const MaskTile* tiles
     const size_t own = tm.offQ + (size_t)gi * ld + J0 + c4;        // my 4 entries of tile (I,J)
     const size_t par = tm.offQ + (size_t)(J0 + i) * ld + I0 + c4;  // my row segment of tile (J,I) (staging only)
 
-    // ---- every global load is issued here ----
-    f32x4 Mo = *reinterpret_cast<const f32x4*>(p.M + own);
-    const f32x4 Ao = *reinterpret_cast<const f32x4*>(p.A + own);
-    const f32x4 Mp = *reinterpret_cast<const f32x4*>(p.M + par);
-    f32x4 mo, vo, mp, vp;
+    // ---- every global load is issued here, back to back, and NOTHING is computed on a loaded value before the last one is out:
+    // an operation next to its load makes the compiler wait for it right there (round 2 had sigmoid(f[k]) * x and relu(x) inside
+    // the load loop: s_waitcnt vmcnt(0) after every k step, ~8 serialised L2 round trips per workgroup - the kernel ran at the
+    // rate of that chain, 4.1-4.6 TB/s, not of HBM).  The G operands (L2-resident rows, they return first) go out before the
+    // seven HBM streams of the two tiles.
+    float zi[3][4], zj[3][4], xi[3][4], xj[3][4], fk[4];
     f32x4 yj4 = {0.0f, 0.0f, 0.0f, 0.0f}, g3j4 = {0.0f, 0.0f, 0.0f, 0.0f};
     float yi = 0.0f, g3i = 0.0f;
     // G operands: k-step s (columns 2s, 2s+1) of a layer goes to wave s % 4 -> at most 4 steps per wave per layer
-    float zi[3][4], zj[3][4], xi[3][4], xj[3][4];
     constexpr int NL = NODE ? 2 : 3;
     if (UPDATE) {
-        mo = *reinterpret_cast<const f32x4*>(p.mM + own);
-        vo = *reinterpret_cast<const f32x4*>(p.vM + own);
-        if (!diag) {
-            mp = *reinterpret_cast<const f32x4*>(p.mM + par);
-            vp = *reinterpret_cast<const f32x4*>(p.vM + par);
-        }
-        if (!p.graph_mode) {
-            yj4 = *reinterpret_cast<const f32x4*>(p.yhat + tm.offR + J0 + c4);
-            yi = p.yhat[tm.offR + gi];
-        }
-        if (NODE) {
-            g3j4 = *reinterpret_cast<const f32x4*>(p.g3 + tm.offR + J0 + c4);
-            g3i = p.g3[tm.offR + gi];
-        }
         const size_t ro = (size_t)tm.offR * FS;
         const float* fcur = p.f[iter & 1] + tl.t * FS;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fk[u] = fcur[2 * (wave + 4 * u) + h];  // (first: whatever the compiler hoists onto them waits for nothing else)
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             const int d = (l == 0) ? p.D : p.H;
@@ -919,26 +907,34 @@ __global__ __launch_bounds__(256, 4) void k_mask(Params p, const MaskTile* tiles
                     b = zT[(size_t)k * ld + J0 + li];
                     c = xT[(size_t)k * ld + I0 + li];
                     e = xT[(size_t)k * ld + J0 + li];
-                    if (l == 0) {
-                        const float phi = (k < p.D) ? sigmoidf_(fcur[k]) : 0.0f;
-                        c *= phi;
-                        e *= phi;
-                    } else if (!p.bn) {   // --bn: the standardised activations are the layer inputs as they are
-                        c = fmaxf(c, 0.0f);
-                        e = fmaxf(e, 0.0f);
-                    }
                 }
                 zi[l][u] = a; zj[l][u] = b; xi[l][u] = c; xj[l][u] = e;
             }
         }
+        if (!p.graph_mode) {
+            yj4 = *reinterpret_cast<const f32x4*>(p.yhat + tm.offR + J0 + c4);
+            yi = p.yhat[tm.offR + gi];
+        }
+        if (NODE) {
+            g3j4 = *reinterpret_cast<const f32x4*>(p.g3 + tm.offR + J0 + c4);
+            g3i = p.g3[tm.offR + gi];
+        }
     }
-    // mirror tile -> LDS in its natural orientation [j][i]; read back transposed below
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        sPM[i * LS + c4 + e] = Mp[e];
-        if (UPDATE && !diag) { sPm[i * LS + c4 + e] = mp[e]; sPv[i * LS + c4 + e] = vp[e]; }
-    }
+    f32x4 Mo = *reinterpret_cast<const f32x4*>(p.M + own);
+    const f32x4 Ao = *reinterpret_cast<const f32x4*>(p.A + own);
+    const f32x4 Mp = *reinterpret_cast<const f32x4*>(p.M + par);
+    f32x4 mo, vo, mp, vp;
     if (UPDATE) {
+        mo = *reinterpret_cast<const f32x4*>(p.mM + own);
+        vo = *reinterpret_cast<const f32x4*>(p.vM + own);
+        if (!diag) {
+            mp = *reinterpret_cast<const f32x4*>(p.mM + par);
+            vp = *reinterpret_cast<const f32x4*>(p.vM + par);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (keeps the loads above together, ahead of everything below)
+    if (UPDATE) {
+        // the G tiles first: their operands are back long before the HBM streams
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -948,14 +944,30 @@ __global__ __launch_bounds__(256, 4) void k_mask(Params p, const MaskTile* tiles
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (2 * (wave + 4 * u) < d) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zi[l][u], xj[l][u], acc, 0, 0, 0);  // G[i][j]
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xi[l][u], zj[l][u], acc, 0, 0, 0);  // G[j][i]
+                    float c = xi[l][u], e = xj[l][u];
+                    if (l == 0) {  // the masked features: X * sigma(feat_mask)
+                        const int k = 2 * (wave + 4 * u) + h;
+                        const float phi = (k < p.D) ? sigmoidf_(fk[u]) : 0.0f;
+                        c *= phi;
+                        e *= phi;
+                    } else if (!p.bn) {   // --bn: the standardised activations are the layer inputs as they are
+                        c = fmaxf(c, 0.0f);
+                        e = fmaxf(e, 0.0f);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zi[l][u], e, acc, 0, 0, 0);  // G[i][j]
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c, zj[l][u], acc, 0, 0, 0);  // G[j][i]
                 }
             }
         }
         // accumulator (C layout: row acc_row(r,h), column li) -> this wave's partial tile in LDS
 #pragma unroll
         for (int r = 0; r < 16; ++r) sGp[(wave * TILE + acc_row(r, h)) * LS + li] = acc[r];
+    }
+    // mirror tile -> LDS in its natural orientation [j][i]; read back transposed below
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sPM[i * LS + c4 + e] = Mp[e];
+        if (UPDATE && !diag) { sPm[i * LS + c4 + e] = mp[e]; sPv[i * LS + c4 + e] = vp[e]; }
     }
     __syncthreads();
 
