@@ -1,0 +1,379 @@
+// gnnx_att.hpp — method="att": the attention GraphConv of the reference (models.py:36-37 weights, :62-68 forward)
+//
+//     x_att = x W_att;  att = x_att x_att^T;  adj' = adj * att;  y = normalize((adj' x) W + b)
+//
+// in all three layers of the encoder, and the whole mask optimisation through it (explain.py:685-715, 740-808, 137-146): one
+// workgroup per target, every iteration inside one launch.  Only entries ON EDGES are live (adj' = 0 elsewhere and a mask entry
+// off the edges never reaches masked_adj * sub_adj), so the state is a CSR of the target's sub-graph built at the start of the
+// launch: w_e = Abar on the edge, s_e^l = att of layer l on the edge, and per layer
+//
+//   forward    u = Xin W_att;   s_e = u_i . u_k;   Z_i = sum_e w_e s_e Xin_k;   Y = Z W + b;   U = Y / max(|Y|, 1e-12)
+//   backward   dZ = rowlocal(dU);  g_e = dZ_i . Xin_k  (= dL/dadj'_ik);  dAbar_e += g_e s_e;  q_e = g_e w_e  (= dL/datt_ik)
+//              dXin_i = sum_e w_e s_e dZ_k                       (adj' is symmetric: Abar and att both are)
+//                     + (sum_e (q_e + q_mirror(e)) u_k) W_att^T  (att_ik = u_i . u_k: u_i sits on both sides)
+//
+// followed by the same regularisers, symmetrisation and Adam step as k_mask (gnnx_kernels.hpp), edge by edge.  Rows are worked
+// on by half-waves (lane = feature column; the two halves of a wave take two rows in lockstep, padded to the longer one), the
+// per-edge dot products are 32-lane butterflies; every sum has a fixed order (deterministic, batch-invariant).  This is a
+// correct, parallel-over-targets kernel for a flag the reference's experiments rarely use, not a roofline kernel: its time is
+// the chain of dependent row gathers of the busiest row pair.
+#pragma once
+#include "gnnx_kernels.hpp"
+
+namespace gnnx {
+
+struct AttScratch {
+    const float* watt;       // [3][32][32] zero padded, W_att of layer l at l * 1024 + b * 32 + a  (b = input column)
+    const long long* eoff;   // [T + 1] first directed edge of target t in the edge arrays
+    int32_t* rowptr;         // [R + T]: the n + 1 row pointers of target t start at offR + t (relative to eoff[t])
+    int32_t *col, *mir;      // [E] column of the entry, position of the mirror entry (k, i) (relative to eoff[t])
+    float *w, *s[3], *q, *dA;  // [E]
+    float *xin[3], *u[3], *U[3], *dZ, *dX;  // [R][32]
+    float* rn[3];            // [R]
+};
+
+__device__ __forceinline__ float att_sum32(float v) {  // over the 32 lanes of a half-wave
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+
+constexpr int ATT_THREADS = 512;
+
+__global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, const float* __restrict__ adam) {
+    constexpr int NWV = ATT_THREADS / 64;
+    __shared__ float sW[3][32 * 33], sWa[3][32 * 33], sb[3][32];
+    __shared__ float sWp[CMAX * 96 + CMAX];
+    __shared__ float fcur[32], mf[32], vf[32], phi[32];
+    __shared__ float emb[96], gcls[CMAX], dEs[96];
+    __shared__ float part[2 * NWV][32];
+    const int t = blockIdx.x;
+    const TargetMeta tm = p.meta[t];
+    const int n = tm.n, ld = tm.ld, tr = tm.t;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ln = lane & 31, hf = lane >> 5, hbase = lane & 32;
+    const int D = p.D, H = p.H;
+    const long long eb = a.eoff[t];
+    const int nnz = (int)(a.eoff[t + 1] - eb);
+    int32_t* rowptr = a.rowptr + tm.offR + t;
+    int32_t* col = a.col + eb;
+    int32_t* mir = a.mir + eb;
+    float* w = a.w + eb;
+    float* q = a.q + eb;
+    float* dA = a.dA + eb;
+    const size_t ro = (size_t)tm.offR * FS;
+    const float* X = p.X + ro;
+    const float* Ad = p.A + tm.offQ;
+    float* Md = p.M + tm.offQ;
+    float* md = p.mM + tm.offQ;
+    float* vd = p.vM + tm.offQ;
+    const float* yh = p.yhat + tm.offR;
+
+    // ---------------- set-up: model, feature-mask state, CSR of the sub-graph ----------------
+    for (int l = 0; l < 3; ++l)
+        for (int e = tid; e < 1024; e += ATT_THREADS) {
+            sW[l][(e >> 5) * 33 + (e & 31)] = p.wts[WT_W + l * 1024 + e];
+            sWa[l][(e >> 5) * 33 + (e & 31)] = a.watt[l * 1024 + e];
+        }
+    if (tid < 96) sb[tid >> 5][tid & 31] = p.wts[WT_B + tid];
+    stage_head_weights(p, sWp);
+    if (tid < 32) {
+        const float* fs = p.fs_in ? p.fs_in + (size_t)t * 3 * FS + tid : nullptr;  // gnnx_run_resume
+        fcur[tid] = (fs && tid < D) ? fs[0] : 0.0f;  // construct_feat_mask: constant 0 (explain.py:639-641)
+        mf[tid] = (fs && tid < D) ? fs[FS] : 0.0f;
+        vf[tid] = (fs && tid < D) ? fs[2 * FS] : 0.0f;
+    }
+    if (!p.edge_only)
+        for (size_t e = tid; e < (size_t)ld * ld; e += ATT_THREADS) p.Abar[tm.offQ + e] = 0.0f;
+    // row degrees (off the diagonal), one wave per row
+    for (int i = wave; i < n; i += NWV) {
+        int c = 0;
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int k = k0 + lane;
+            c += __popcll(__ballot(k < n && k != i && Ad[(size_t)i * ld + k] != 0.0f));
+        }
+        if (lane == 0) rowptr[i + 1] = c;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int s = 0;
+        rowptr[0] = 0;
+        for (int i = 0; i < n; ++i) {
+            s += rowptr[i + 1];
+            rowptr[i + 1] = s;
+        }
+    }
+    __syncthreads();
+    for (int i = wave; i < n; i += NWV) {
+        int pos = rowptr[i];
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int k = k0 + lane;
+            const bool on = k < n && k != i && Ad[(size_t)i * ld + k] != 0.0f;
+            const unsigned long long bal = __ballot(on);
+            if (on) col[pos + __popcll(bal & ((1ull << lane) - 1ull))] = k;
+            pos += __popcll(bal);
+        }
+    }
+    __syncthreads();
+    // mirror positions, Adam moments of the live entries, the first masked adjacency
+    for (int i = wave; i < n; i += NWV) {
+        for (int e = rowptr[i] + lane; e < rowptr[i + 1]; e += 64) {
+            const int k = col[e];
+            int lo = rowptr[k], hi = rowptr[k + 1] - 1, at = -1;
+            while (lo <= hi) {  // the pattern of A is symmetric (the reference's sub_adj is): (k, i) exists
+                const int mid = (lo + hi) >> 1, c = col[mid];
+                if (c == i) { at = mid; break; }
+                if (c < i) lo = mid + 1; else hi = mid - 1;
+            }
+            mir[e] = at < 0 ? e : at;
+            const size_t idx = (size_t)i * ld + k;
+            md[idx] = p.m_in ? p.m_in[tm.offQ + idx] : 0.0f;
+            vd[idx] = p.v_in ? p.v_in[tm.offQ + idx] : 0.0f;
+            w[e] = Ad[idx] * (0.5f * (sigmoidf_(Md[idx]) + sigmoidf_(Md[(size_t)k * ld + i])));
+        }
+    }
+    __syncthreads();
+    const float inv_n2 = 1.0f / ((float)n * (float)n);
+
+    for (int iter = 0; iter < p.num_iters; ++iter) {
+        // ======== forward ========
+        if (tid < 32) phi[tid] = (tid < D) ? sigmoidf_(fcur[tid]) : 0.0f;
+        __syncthreads();
+        // masked features and their attention projection (row-local)
+        for (int i0 = 2 * wave; i0 < n; i0 += 2 * NWV) {
+            const int i = i0 + hf;
+            const bool on = i < n;
+            const float x = on ? X[(size_t)i * FS + ln] * phi[ln] : 0.0f;
+            float uu = 0.0f;
+            for (int b = 0; b < D; ++b) uu = fmaf(__shfl(x, hbase | b), sWa[0][b * 33 + ln], uu);
+            if (on) {
+                a.xin[0][ro + (size_t)i * FS + ln] = x;
+                a.u[0][ro + (size_t)i * FS + ln] = uu;
+            }
+        }
+        __syncthreads();
+        for (int l = 0; l < 3; ++l) {
+            const int din = (l == 0) ? D : H, dout = (l == 2) ? p.O : H;
+            const float* xin = a.xin[l] + ro;
+            const float* ul = a.u[l] + ro;
+            float* sl = a.s[l] + eb;
+            for (int i0 = 2 * wave; i0 < n; i0 += 2 * NWV) {
+                const int i = i0 + hf;
+                const bool ron = i < n;
+                const int e0 = ron ? rowptr[i] : 0, deg = ron ? rowptr[i + 1] - e0 : 0;
+                const int odeg = __shfl_xor(deg, 32), trip = deg > odeg ? deg : odeg;
+                const float ui = ron ? ul[(size_t)i * FS + ln] : 0.0f;
+                float acc = 0.0f;
+                for (int j0 = 0; j0 < trip; j0 += 32) {
+                    // this chunk's edge records, one per lane (coalesced), handed out by shuffles: the gathers of successive
+                    // edges do not wait for an index load each
+                    const int je = j0 + ln;
+                    const bool eon = je < deg;
+                    const int ck = eon ? col[e0 + je] : 0;
+                    const float cw = eon ? w[e0 + je] : 0.0f;
+                    float cs = 0.0f;
+                    const int cnt = (trip - j0 < 32) ? trip - j0 : 32;
+                    for (int jj = 0; jj < cnt; ++jj) {
+                        const int k = __shfl(ck, hbase | jj);
+                        const float se = att_sum32(ui * ul[(size_t)k * FS + ln]);
+                        acc = fmaf(__shfl(cw, hbase | jj) * se, xin[(size_t)k * FS + ln], acc);
+                        cs = (jj == ln) ? se : cs;
+                    }
+                    if (eon) sl[e0 + je] = cs;
+                }
+                // row-local: Y = Z W + b, U = Y / max(|Y|, 1e-12), the next layer's input and its attention projection
+                float y = 0.0f;
+                for (int b = 0; b < din; ++b) y = fmaf(__shfl(acc, hbase | b), sW[l][b * 33 + ln], y);
+                y = (ln < dout) ? y + sb[l][ln] : 0.0f;
+                const float rnorm = fmaxf(sqrtf(att_sum32(y * y)), 1e-12f);
+                const float un = y / rnorm;
+                const float xn = fmaxf(un, 0.0f);
+                float uu = 0.0f;
+                if (l < 2)
+                    for (int b = 0; b < dout; ++b) uu = fmaf(__shfl(xn, hbase | b), sWa[l + 1][b * 33 + ln], uu);
+                if (ron) {
+                    a.U[l][ro + (size_t)i * FS + ln] = un;
+                    if (ln == 0) a.rn[l][tm.offR + i] = rnorm;
+                    if (l < 2) {
+                        a.xin[l + 1][ro + (size_t)i * FS + ln] = xn;
+                        a.u[l + 1][ro + (size_t)i * FS + ln] = uu;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // head on row t of the three layers (explain.py:713, models.py:372-380)
+        if (tid < 96) {
+            const int l = tid >> 5, c = tid & 31;
+            const float v = a.U[l][ro + (size_t)tr * FS + c];
+            emb[tid] = (l < 2) ? fmaxf(v, 0.0f) : v;
+        }
+        __syncthreads();
+        head_softmax(p, tm, t, iter, true, sWp, emb, gcls, dEs);
+
+        // ======== backward ========
+        for (int l = 2; l >= 0; --l) {
+            const int din = (l == 0) ? D : H, dout = (l == 2) ? p.O : H;
+            const float* xin = a.xin[l] + ro;
+            const float* ul = a.u[l] + ro;
+            const float* sl = a.s[l] + eb;
+            float* dZ = a.dZ + ro;
+            float* dX = a.dX + ro;
+            // row-local: gradient of the layer's output -> dZ
+            for (int i0 = 2 * wave; i0 < n; i0 += 2 * NWV) {
+                const int i = i0 + hf;
+                const bool ron = i < n;
+                const size_t r = (size_t)(ron ? i : 0) * FS + ln;
+                float dx = (l < 2) ? dX[r] : 0.0f;
+                if (i == tr) dx += dEs[l * 32 + ln];
+                const float un = a.U[l][ro + r];
+                float du = (ln < dout) ? dx : 0.0f;
+                if (l < 2) du = (un > 0.0f) ? du : 0.0f;
+                const float sd = att_sum32(du * un);
+                const float dy = (du - un * sd) / a.rn[l][tm.offR + (ron ? i : 0)];
+                float dz = 0.0f;
+                for (int c = 0; c < dout; ++c) dz = fmaf(__shfl(dy, hbase | c), sW[l][ln * 33 + c], dz);
+                if (ron) dZ[r] = (ln < din) ? dz : 0.0f;
+            }
+            __syncthreads();
+            // edges: dL/dadj' -> dAbar, dL/datt, and the adj'-path of dXin
+            for (int i0 = 2 * wave; i0 < n; i0 += 2 * NWV) {
+                const int i = i0 + hf;
+                const bool ron = i < n;
+                const int e0 = ron ? rowptr[i] : 0, deg = ron ? rowptr[i + 1] - e0 : 0;
+                const int odeg = __shfl_xor(deg, 32), trip = deg > odeg ? deg : odeg;
+                const float dzi = ron ? dZ[(size_t)i * FS + ln] : 0.0f;
+                float acc = 0.0f;
+                for (int j0 = 0; j0 < trip; j0 += 32) {
+                    const int je = j0 + ln;
+                    const bool eon = je < deg;
+                    const int ck = eon ? col[e0 + je] : 0;
+                    const float cw = eon ? w[e0 + je] : 0.0f, cs = eon ? sl[e0 + je] : 0.0f;
+                    const float cc = cw * cs;
+                    float cg = 0.0f;
+                    const int cnt = (trip - j0 < 32) ? trip - j0 : 32;
+                    for (int jj = 0; jj < cnt; ++jj) {
+                        const int k = __shfl(ck, hbase | jj);
+                        const float g = att_sum32(dzi * xin[(size_t)k * FS + ln]);
+                        acc = fmaf(__shfl(cc, hbase | jj), dZ[(size_t)k * FS + ln], acc);
+                        cg = (jj == ln) ? g : cg;
+                    }
+                    if (eon) {
+                        dA[e0 + je] = (l == 2) ? cg * cs : dA[e0 + je] + cg * cs;
+                        q[e0 + je] = cg * cw;
+                    }
+                }
+                if (ron) dX[(size_t)i * FS + ln] = acc;
+            }
+            __syncthreads();
+            // edges: the attention path, then dXin complete (+ the feature-mask partials in layer 1)
+            float fp = 0.0f;
+            for (int i0 = 2 * wave; i0 < n; i0 += 2 * NWV) {
+                const int i = i0 + hf;
+                const bool ron = i < n;
+                const int e0 = ron ? rowptr[i] : 0, deg = ron ? rowptr[i + 1] - e0 : 0;
+                const int odeg = __shfl_xor(deg, 32), trip = deg > odeg ? deg : odeg;
+                float du = 0.0f;
+                for (int j0 = 0; j0 < trip; j0 += 32) {
+                    const int je = j0 + ln;
+                    const bool eon = je < deg;
+                    const int ck = eon ? col[e0 + je] : 0;
+                    const float cq = eon ? q[e0 + je] + q[mir[e0 + je]] : 0.0f;
+                    const int cnt = (trip - j0 < 32) ? trip - j0 : 32;
+                    for (int jj = 0; jj < cnt; ++jj)
+                        du = fmaf(__shfl(cq, hbase | jj), ul[(size_t)__shfl(ck, hbase | jj) * FS + ln], du);
+                }
+                float dxa = 0.0f;
+                for (int c = 0; c < din; ++c) dxa = fmaf(__shfl(du, hbase | c), sWa[l][ln * 33 + c], dxa);
+                if (ron) {
+                    const size_t r = (size_t)i * FS + ln;
+                    const float dxi = (ln < din) ? dX[r] + dxa : 0.0f;
+                    dX[r] = dxi;
+                    if (l == 0) fp = fmaf(dxi, X[r], fp);
+                }
+            }
+            if (l == 0) part[2 * wave + hf][ln] = fp;
+            __syncthreads();
+        }
+
+        // ======== mask entries on the edges: regularisers, symmetrisation, Adam (as k_mask) ========
+        const float step_size = adam[2 * iter], bc2s = adam[2 * iter + 1];
+        for (int i = wave; i < n; i += NWV) {
+            const float yi = yh[i];
+            for (int e = rowptr[i] + lane; e < rowptr[i + 1]; e += 64) {
+                const int k = col[e];
+                const size_t idx = (size_t)i * ld + k;
+                float Gs = 0.5f * (dA[e] + dA[mir[e]]);
+                if (!p.graph_mode) {
+                    const float dy = yi - yh[k];
+                    Gs += p.c_lap * 0.5f * dy * dy * inv_n2;
+                }
+                float Mij = Md[idx], mij = md[idx], vij = vd[idx];
+                const float Sij = sigmoidf_(Mij);
+                const float gij = (Gs * Ad[idx] + p.c_size + p.c_ent * (-Mij) * inv_n2) * (Sij * (1.0f - Sij));
+                adam_update(Mij, mij, vij, gij, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
+                Md[idx] = Mij;
+                md[idx] = mij;
+                vd[idx] = vij;
+            }
+        }
+        if (tid < D) {  // feature mask
+            float dsum = 0.0f;
+            for (int r = 0; r < 2 * NWV; ++r) dsum += part[r][tid];
+            const float ph = phi[tid];
+            const float gf = (dsum + p.c_feat_size / (float)D) * ph * (1.0f - ph);
+            float fn = fcur[tid], m = mf[tid], v = vf[tid];
+            adam_update(fn, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
+            fcur[tid] = fn;
+            mf[tid] = m;
+            vf[tid] = v;
+        }
+        __syncthreads();
+        if (iter + 1 < p.num_iters) {  // the result is the masked adjacency of the LAST forward (explain.py:209-211)
+            for (int i = wave; i < n; i += NWV)
+                for (int e = rowptr[i] + lane; e < rowptr[i + 1]; e += 64) {
+                    const int k = col[e];
+                    const size_t idx = (size_t)i * ld + k;
+                    w[e] = Ad[idx] * (0.5f * (sigmoidf_(Md[idx]) + sigmoidf_(Md[(size_t)k * ld + i])));
+                }
+            __syncthreads();
+        }
+    }
+
+    // ---------------- results ----------------
+    for (int i = wave; i < n; i += NWV)
+        for (int e = rowptr[i] + lane; e < rowptr[i + 1]; e += 64) {
+            const size_t idx = (size_t)i * ld + col[e];
+            p.Abar[tm.offQ + idx] = w[e];
+            if (p.m_out) p.m_out[tm.offQ + idx] = md[idx];
+            if (p.v_out) p.v_out[tm.offQ + idx] = vd[idx];
+        }
+    if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = (tid < D) ? fcur[tid] : 0.0f;
+    if (p.fs_out && tid < FS) {
+        float* fs = p.fs_out + (size_t)t * 3 * FS + tid;
+        fs[0] = (tid < D) ? fcur[tid] : 0.0f;
+        fs[FS] = (tid < D) ? mf[tid] : 0.0f;
+        fs[2 * FS] = (tid < D) ? vf[tid] : 0.0f;
+    }
+    (void)nnz;
+}
+
+// directed off-diagonal entries of every target (the host sizes the edge arrays from them)
+__global__ __launch_bounds__(256) void k_att_count(const TargetMeta* meta, const float* A, int32_t* cnt) {
+    __shared__ int red[4];
+    const TargetMeta tm = meta[blockIdx.x];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int c = 0;
+    for (int i = wave; i < tm.n; i += 4)
+        for (int k0 = 0; k0 < tm.n; k0 += 64) {
+            const int k = k0 + lane;
+            c += __popcll(__ballot(k < tm.n && k != i && A[tm.offQ + (size_t)i * tm.ld + k] != 0.0f));
+        }
+    if (lane == 0) red[wave] = c;
+    __syncthreads();
+    if (tid == 0) cnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+}  // namespace gnnx

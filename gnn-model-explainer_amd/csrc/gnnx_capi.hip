@@ -22,6 +22,7 @@ constexpr int MAX_DEVICES_POOL = 16;
 #include "gnnx_sparse.hpp"
 #include "gnnx_sparse_large.hpp"
 #include "gnnx_graph.hpp"
+#include "gnnx_att.hpp"
 
 using namespace gnnx;
 
@@ -208,6 +209,7 @@ struct gnnx_plan_s {
     int n_unit = 0, n_unit_big = 0, n_join = 0, n_join_big = 0;
     float* d_cpart = nullptr;        // slabs of the K slices (shared by the two tables: one of them runs at a time)
     size_t cap_slabs = 0;
+    float* d_watt = nullptr;         // method="att": attention weights of the three layers (gnnx_set_att_weights); every run takes k_att
     // the resident kernels run beside the streaming launches, each group on its own stream:
     // [0..RES_NBMAX) dense resident kernels by row blocks, [RES_NBMAX + k] sparse resident kernel of size class k
     hipEvent_t ev_in = nullptr, ev_out[N_SIDE] = {};
@@ -311,6 +313,7 @@ static hipError_t upload_units(gnnx_handle h, const std::vector<ConvTile>& tiles
     }
     if ((size_t)ut.slabs > h->cap_slabs) {
         if (h->d_cpart) (void)pool_free(h->d_cpart);
+    if (h->d_watt) (void)pool_free(h->d_watt);
         h->d_cpart = nullptr;
         h->cap_slabs = 0;
         if ((e = pool_malloc(&h->d_cpart, sizeof(float) * TILE * FS * (size_t)ut.slabs)) != hipSuccess) return e;
@@ -811,6 +814,85 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
     return gnnx_run_resume(h, hy, nullptr, A, X, yhat, M, Abar, feat_mask, loss, workspace, workspace_bytes, stream);
 }
 
+extern "C" int gnnx_set_att_weights(gnnx_handle h, const float* att_weights) {
+    if (!h || !att_weights) return fail("null argument");
+    if (h->prob.graph_mode) return fail("method=att runs on the kernels in node mode only");
+    if (h->prob.bn || h->prob.mask_relu) return fail("method=att is not implemented together with --bn / mask_act=ReLU");
+    if (!h->d_watt) HIPCK(pool_malloc(&h->d_watt, sizeof(float) * 3 * 1024));
+    HIPCK(upload_sync(h->d_watt, att_weights, sizeof(float) * 3 * 1024));
+    return 0;
+}
+
+// method="att": every target in k_att (gnnx_att.hpp).  The edge arrays are sized from a count of the batch's directed entries, so this
+// path synchronises with the host once before and once after the launch - it is the complete path for a rarely used flag, not a
+// pipelined one.
+static int run_att(gnnx_handle h, const gnnx_hyper* hy, const gnnx_resume& rs, Params p, const float* A, float* feat_mask, hipStream_t s) {
+    const int T = h->prob.num_targets;
+    if (p.loss) return fail("loss logging is not implemented for method=att");
+    int32_t* d_cnt = nullptr;
+    HIPCK(pool_malloc(&d_cnt, sizeof(int32_t) * T));
+    hipLaunchKernelGGL(k_att_count, dim3(T), dim3(256), 0, s, h->d_meta, A, d_cnt);
+    std::vector<int32_t> cnt(T);
+    HIPCK(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int32_t) * T, hipMemcpyDeviceToHost, s));
+    HIPCK(hipStreamSynchronize(s));
+    (void)pool_free(d_cnt);
+    std::vector<long long> eoff(T + 1, 0);
+    for (int t = 0; t < T; ++t) eoff[t + 1] = eoff[t] + cnt[t];
+    const size_t E = (size_t)std::max<long long>(eoff[T], 1), R = (size_t)h->R;
+    // one allocation, carved: edge arrays (col, mir, w, s[3], q, dA), row arrays (xin[3], u[3], U[3], dZ, dX, rn[3]), offsets, row pointers
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t r = o;
+        o = align_up(o + bytes, 256);
+        return r;
+    };
+    const size_t o_eoff = take(sizeof(long long) * (T + 1)), o_rowptr = take(sizeof(int32_t) * (R + T)), o_col = take(4 * E), o_mir = take(4 * E);
+    size_t o_e[6], o_r[11], o_rn[3];
+    for (auto& x : o_e) x = take(4 * E);
+    for (auto& x : o_r) x = take(4 * R * FS);
+    for (auto& x : o_rn) x = take(4 * R);
+    char* d = nullptr;
+    HIPCK(pool_malloc(&d, o));
+    float* d_tab = nullptr;
+    std::vector<float> tab(2 * (size_t)hy->num_iters);
+    for (int it = 0; it < hy->num_iters; ++it) adam_scalars(hy, rs.first_iter + it, &tab[2 * it], &tab[2 * it + 1], it);
+    hipError_t e = pool_malloc(&d_tab, sizeof(float) * tab.size());
+    if (e == hipSuccess) e = upload_sync(d_tab, tab.data(), sizeof(float) * tab.size());
+    if (e == hipSuccess) e = upload_sync(d + o_eoff, eoff.data(), sizeof(long long) * (T + 1));
+    if (e != hipSuccess) {
+        (void)pool_free(d);
+        if (d_tab) (void)pool_free(d_tab);
+        return fail(std::string("method=att set-up: ") + hipGetErrorString(e));
+    }
+    AttScratch a{};
+    a.watt = h->d_watt;
+    a.eoff = reinterpret_cast<const long long*>(d + o_eoff);
+    a.rowptr = reinterpret_cast<int32_t*>(d + o_rowptr);
+    a.col = reinterpret_cast<int32_t*>(d + o_col);
+    a.mir = reinterpret_cast<int32_t*>(d + o_mir);
+    a.w = reinterpret_cast<float*>(d + o_e[0]);
+    for (int l = 0; l < 3; ++l) a.s[l] = reinterpret_cast<float*>(d + o_e[1 + l]);
+    a.q = reinterpret_cast<float*>(d + o_e[4]);
+    a.dA = reinterpret_cast<float*>(d + o_e[5]);
+    for (int l = 0; l < 3; ++l) {
+        a.xin[l] = reinterpret_cast<float*>(d + o_r[l]);
+        a.u[l] = reinterpret_cast<float*>(d + o_r[3 + l]);
+        a.U[l] = reinterpret_cast<float*>(d + o_r[6 + l]);
+        a.rn[l] = reinterpret_cast<float*>(d + o_rn[l]);
+    }
+    a.dZ = reinterpret_cast<float*>(d + o_r[9]);
+    a.dX = reinterpret_cast<float*>(d + o_r[10]);
+    hipLaunchKernelGGL(k_att, dim3(T), dim3(ATT_THREADS), 0, s, p, a, d_tab);
+    if (feat_mask)
+        (void)hipMemcpyAsync(feat_mask, p.f[hy->num_iters & 1], sizeof(float) * T * FS, hipMemcpyDeviceToDevice, s);
+    e = hipStreamSynchronize(s);
+    (void)pool_free(d);
+    (void)pool_free(d_tab);
+    if (e != hipSuccess) return fail(std::string("method=att run: ") + hipGetErrorString(e));
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_resume* resume, const float* A, const float* X,
                                const float* yhat, float* M, float* Abar, float* feat_mask, float* loss, void* workspace,
                                size_t workspace_bytes, void* stream) {
@@ -843,6 +925,7 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
     p.m_out = rs.m_out;
     p.v_out = rs.v_out;
     p.fs_out = rs.feat_out;
+    if (h->d_watt) return run_att(h, hy, rs, p, A, feat_mask, s);
     if (rs.m_out) p.mM = rs.m_out;   // the streaming kernels keep their moments in the caller's arrays when it wants them back
     if (rs.v_out) p.vM = rs.v_out;
     // hybrid split: small targets (<= res_nbmax row blocks) -> on-chip-resident kernels on side streams (overlap with the

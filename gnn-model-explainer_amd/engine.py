@@ -130,6 +130,7 @@ def _load_hip_library():
 
 _API = {
     "gnnx_plan_create": (ctypes.c_int, [ctypes.POINTER(_Problem), ctypes.POINTER(_Model), ctypes.POINTER(ctypes.c_void_p)]),
+    "gnnx_set_att_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
     "gnnx_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "gnnx_total_q": (ctypes.c_int64, [ctypes.c_void_p]),
     "gnnx_total_rows": (ctypes.c_int64, [ctypes.c_void_p]),
@@ -443,6 +444,19 @@ class MaskOptimJob:
             raise NotImplementedError("unexpected encoder shapes")
         if self.w["pred_model.weight"].shape[1] != 2 * self.H + self.O:
             raise NotImplementedError("only concat=True prediction heads are supported")
+        # method="att" (models.py:36-37, 62-68): the three att_weight matrices, zero padded to [3][32][32] -> every run takes k_att
+        self.att = None
+        att_keys = [k + ".att_weight" for k in ("conv_first", "conv_block.0", "conv_last")]
+        if any(k in state_dict for k in att_keys):
+            if not all(k in state_dict for k in att_keys):
+                raise NotImplementedError("an encoder with attention weights in some layers only")
+            self.att = np.zeros((3, FEAT_STRIDE, FEAT_STRIDE), np.float32)
+            for l, (k, d) in enumerate(zip(att_keys, (self.D, self.H, self.H))):
+                v = state_dict[k]
+                v = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+                if v.shape != (d, d):
+                    raise NotImplementedError(f"{k}: expected [{d}, {d}], got {list(v.shape)}")
+                self.att[l, :d, :d] = v
 
     def _create_plan(self, rows, labels):
         prob = _Problem(self.T, self.n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
@@ -457,6 +471,8 @@ class MaskOptimJob:
         mdl.bp = _fptr(self.w["pred_model.bias"])
         self.handle = ctypes.c_void_p()
         _check(self.lib, self.lib.gnnx_plan_create(ctypes.byref(prob), ctypes.byref(mdl), ctypes.byref(self.handle)))
+        if getattr(self, "att", None) is not None:
+            _check(self.lib, self.lib.gnnx_set_att_weights(self.handle, _fptr(self.att)))
         self.Q = int(self.lib.gnnx_total_q(self.handle))
         self.R = int(self.lib.gnnx_total_rows(self.handle))
         self.ld = np.zeros(self.T, np.int32)

@@ -119,19 +119,29 @@ def _regulariser_only_feat_mask(args, D, num_iters):
     return f.detach().numpy()
 
 
-def _torch_route_reason(args, model, state_dict=None):
+def _torch_route_reason(args, model, state_dict=None, graph_mode=False, record_loss=False, unconstrained=False):
     """None when the HIP kernels implement this configuration, else what makes it take explainer/torch_route.py (SURVEY.md section 8(b):
-    configurations the kernels do not cover run on a PyTorch-ROCm restatement of the reference path instead of silently differing)."""
-    if getattr(args, "method", "base") != "base":
-        return "method=%r (models.py:62-68)" % args.method
+    configurations the kernels do not cover run on a PyTorch-ROCm restatement of the reference path instead of silently differing).
+    method="att" (models.py:62-68) runs on k_att (csrc/gnnx_att.hpp) in node mode with the sigmoid mask; its other combinations
+    (graph mode, --bn, mask_act=ReLU, loss logging, unconstrained) take the PyTorch-ROCm route."""
+    method = getattr(args, "method", "base")
+    if method not in ("base", "att"):
+        return "method=%r" % method
     if getattr(args, "mask_act", "sigmoid") not in ("sigmoid", "ReLU"):
         return "mask_act=%r" % args.mask_act
     sd = state_dict if state_dict is not None else model.state_dict()
+    att = any(k.endswith("att_weight") for k in sd)
+    if att or method == "att":
+        for what, on in (("graph mode", graph_mode), ("--bn", bool(getattr(args, "bn", False))), ("loss logging", record_loss),
+                         ("mask_act=ReLU", getattr(args, "mask_act", "sigmoid") == "ReLU"), ("unconstrained", unconstrained),
+                         ("attention weights in some layers only", not all(k + ".att_weight" in sd for k in ("conv_first", "conv_block.0", "conv_last")))):
+            if on:
+                return "method='att' (models.py:62-68) with %s" % what
     extra = [k for k in sd if k.startswith("conv_block.") and not k.startswith("conv_block.0.")]
     if extra or "conv_block.0.weight" not in sd:
         return "an encoder with %d graph-convolution layers (the kernels implement 3)" % (2 + len({k.split(".")[1] for k in sd if k.startswith("conv_block.")}))
-    if any(k.endswith("self_weight") or k.endswith("att_weight") for k in sd):
-        return "an encoder with add_self / attention weights"
+    if any(k.endswith("self_weight") for k in sd):
+        return "an encoder with add_self"
     if "pred_model.weight" not in sd or "conv_first.bias" not in sd:
         return "an encoder without bias or with a hidden prediction head"
     if sd["pred_model.weight"].shape[1] != sd["conv_first.weight"].shape[1] + sd["conv_block.0.weight"].shape[1] + sd["conv_last.weight"].shape[1]:
@@ -271,7 +281,8 @@ class Explainer:
         multiplied by sub_adj (explain.py:209-211).  Runs on the same kernels with the packed adjacency replaced by 1 - I."""
         begin = time.time()
         lib, device = _ENGINE["lib"], _ENGINE["device"]
-        reason = _torch_route_reason(self.args, self.model)
+        reason = _torch_route_reason(self.args, self.model, graph_mode=graph_indices is not None, record_loss=record_loss,
+                                     unconstrained=unconstrained)
         if reason is None and self.graph_mode and graph_indices is None:
             # --graph-idx N --explain-node K (explainer_main.py:257-258 with a graph-mode Explainer): the node head on a graph encoder
             reason = "a node explanation on a graph-mode Explainer"
@@ -563,6 +574,9 @@ class ExplainModule(nn.Module):
         _check_supported(args)
         if not use_sigmoid:
             raise NotImplementedError("use_sigmoid=False is not implemented on the HIP path")
+        if any(k.endswith("att_weight") for k in model.state_dict()):
+            raise NotImplementedError("the ExplainModule mirror steps the base encoder only: explain an attention encoder (method='att') "
+                                      "through Explainer.explain / explain_nodes, which run it on k_att")
         self.adj, self.x, self.model, self.label = adj, x, model, label
         self.graph_idx, self.args, self.writer, self.graph_mode = graph_idx, args, writer, graph_mode
         self.mask_act = args.mask_act

@@ -132,6 +132,15 @@ int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hyper, const gnnx_resume* r
                     const float* yhat, float* M, float* Abar, float* feat_mask, float* loss, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* method="att" - the attention GraphConv of the reference (/root/reference/models.py:36-37 the att_weight parameters, :62-68
+ * `x_att = x W_att; att = x_att x_att^T; adj = adj * att` in every layer).  att_weights: HOST pointer, [3][32][32] floats, zero
+ * padded, W_att of layer l at l * 1024 + b * 32 + a (b = input column, as the reference stores it).  Once set, every gnnx_run /
+ * gnnx_run_resume of the plan optimises all targets in k_att (gnnx_att.hpp: one workgroup per target, edge-list state, all
+ * iterations in one launch, forward and backward through the attention products).  Node mode, sigmoid mask, no --bn, no loss
+ * logging (other combinations return an error: the Python mirror sends them to its PyTorch-ROCm route).  The call synchronises
+ * with the host (the edge arrays are sized from a device count). */
+int gnnx_set_att_weights(gnnx_handle h, const float* att_weights);
+
 /* Inspect the packed adjacency A (DEVICE pointer, the layout of gnnx_get_layout) and choose the kernel of every target.  All sparse
  * routes optimise only the mask entries on EDGES of the sub-graph - the only ones that reach an output of the reference
  * (explain.py:665-678, 209-211; non-edge entries of M then keep their initial values):

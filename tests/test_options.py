@@ -90,6 +90,69 @@ def test_unconstrained_vs_reference(be, t):
     _check(be, t, f"unc:{t}", explain._hyper(_args()), unconstrained=True)
 
 
+# ---------------------------------------------------------------- method="att" on k_att (csrc/gnnx_att.hpp) ----------------------------------------------------------------
+def _att_case(t):
+    """syn1 target t with the attention encoder the reference's train.py produced (tests/golden/make_golden_options.py)."""
+    ck = helpers.load_ckpt("syn1")
+    sd = {k[len("route:att:w:"):]: Z[k] for k in Z.files if k.startswith("route:att:w:")}
+    nb = Z[f"route:att:{t}:neighbors"]
+    A = ck["adj"][np.ix_(nb, nb)].astype(np.float32)
+    X = ck["feat"][nb].astype(np.float32)
+    new = int(np.searchsorted(nb, t))
+    yhat = np.argmax(Z["route:att:pred"][nb], 1)
+    m0 = helpers.seeded_mask0(t, len(nb)).numpy()
+    return ck, sd, Subgraph(A, X, int(ck["label"][t]), new, yhat, m0)
+
+
+@pytest.mark.parametrize("t", [302, 309])
+def test_method_att_kernel_vs_reference(be, t):
+    """method="att" (models.py:62-68) - adj * (x W_att)(x W_att)^T in every layer, forward and backward through the attention
+    products - on k_att against the LIVE reference's output for an encoder its own train.py trained with --method att
+    (100 epochs, as the fixture was made).  Same tolerance as the PyTorch-ROCm route had (1e-4: the attention products square the
+    activations' round-off)."""
+    ck, sd, sg = _att_case(t)
+    job = be.job([sg], sd)
+    assert job.att is not None
+    res = job.run([sg.mask0], explain._hyper(_args()))
+    r, c = np.nonzero(np.triu(sg.adj, 1))
+    em = np.abs(res.masked_adj[0][r, c].astype(np.float64) - Z[f"route:att:{t}:masked_adj_edges"]).max()
+    ef = np.abs(1 / (1 + np.exp(-res.feat_mask[0].astype(np.float64))) - Z[f"route:att:{t}:feat_sig"]).max()
+    print(f"method=att target {t}: n={len(sg.adj)} mask {em:.2e} feat {ef:.2e}")
+    assert em <= 1e-4 and ef <= 1e-4
+    ma = res.masked_adj[0]
+    assert np.array_equal(ma, ma.T) and np.all(ma[sg.adj == 0] == 0)
+
+
+def test_method_att_one_step_equals_autograd(be):
+    """One Adam step of k_att against torch autograd through the mirror encoder (models.GcnEncoderNode with method="att") on the
+    same inputs: the updated mask entries on the edges, the feature mask, and two targets in one batch == alone."""
+    from gnn_model_explainer_amd import models
+    from gnn_model_explainer_amd.explainer import torch_route
+    ck, sd, sg = _att_case(309)
+    _, _, sg2 = _att_case(302)
+    args = argparse.Namespace(method="att", bias=True, num_gc_layers=3, mask_act="sigmoid", num_epochs=2, lr=0.1, opt="adam", opt_scheduler="none")
+    model = models.GcnEncoderNode(10, 20, 20, 4, 3, bn=False, args=args)
+    model.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    hy = explain._hyper(args)
+    res = be.job([sg, sg2], sd).run([sg.mask0, sg2.mask0], hy)
+    alone = be.job([sg], sd).run([sg.mask0], hy)
+    assert np.array_equal(res.masked_adj[0], alone.masked_adj[0]) and np.array_equal(res.mask[0], alone.mask[0])
+    for k, s in enumerate((sg, sg2)):
+        mod = torch_route.TorchExplainModule(torch.tensor(s.adj[None]), torch.tensor(s.feat[None]), model, torch.tensor([[0] * s.target_row + [s.gt_label]]),
+                                             args, explain.COEFFS, s.mask0, device="cpu")
+        opt = torch.optim.Adam([mod.mask, mod.feat_mask], lr=0.1)
+        model.eval()
+        for _ in range(2):
+            opt.zero_grad()
+            pred, _ = mod(s.target_row)
+            mod.loss(pred, s.pred_label, s.target_row).backward()
+            opt.step()
+        e = s.adj != 0
+        assert np.abs(res.masked_adj[k] - mod.masked_adj[0].detach().numpy())[e].max() < 2e-6     # the second forward
+        assert np.abs(res.mask[k] - mod.mask.detach().numpy())[e].max() < 2e-5                     # two steps of 0.1
+        assert np.abs(res.feat_mask[k][:10] - mod.feat_mask.detach().numpy()).max() < 2e-5
+
+
 # ---------------------------------------------------------------- the PyTorch-ROCm route (explainer/torch_route.py) ----------------------------------------------------------------
 def _route_explainer(tmp, tag, **kw):
     from gnn_model_explainer_amd import models
@@ -105,18 +168,20 @@ def _route_explainer(tmp, tag, **kw):
     return ck, ex
 
 
-def _route_case(tmp_path, tag, kw):
+def _route_case(tmp_path, tag, kw, on_kernels=False):
     ck, ex = _route_explainer(tmp_path, tag, **kw)
-    assert explain._torch_route_reason(ex.args, ex.model) is not None
+    assert (explain._torch_route_reason(ex.args, ex.model) is None) == on_kernels
     for t in (302, 309):
         torch.manual_seed(1000 + t)
-        with pytest.warns(RuntimeWarning, match="PyTorch-ROCm route") if not _already_warned(ex) else _nullcontext():
+        with pytest.warns(RuntimeWarning, match="PyTorch-ROCm route") if not (on_kernels or _already_warned(ex)) else _nullcontext():
             ma = ex.explain(t)
         nb = Z[f"route:{tag}:{t}:neighbors"]
         assert ma.dtype == np.float64 and ma.shape == (len(nb), len(nb))
         r, c = np.nonzero(np.triu(ck["adj"][np.ix_(nb, nb)], 1))
         em = np.abs(ma[r, c] - Z[f"route:{tag}:{t}:masked_adj_edges"]).max()
-        ef = np.abs(ex.last_result.feat_mask_sigmoid[0] - Z[f"route:{tag}:{t}:feat_sig"]).max()
+        lr = ex.last_result
+        fsig = lr.feat_mask_sigmoid[0] if hasattr(lr, "feat_mask_sigmoid") else 1 / (1 + np.exp(-np.asarray(lr.feat_mask, np.float64)[0][:10]))
+        ef = np.abs(fsig - Z[f"route:{tag}:{t}:feat_sig"]).max()
         print(f"route {tag} target {t}: n={len(nb)} mask {em:.2e} feat {ef:.2e}")
         assert em <= 1e-4 and ef <= 1e-4          # torch ops in another order on another device; the reference run here is CPU
 
@@ -134,24 +199,50 @@ def _already_warned(ex):
     return explain._torch_route_reason(ex.args, ex.model) in torch_route._warned
 
 
-@pytest.mark.parametrize("tag,kw", [("att", dict(method="att")), ("l4", dict(num_gc_layers=4))])
+@pytest.mark.parametrize("tag,kw", [("att+bn", dict(method="att")), ("l4", dict(num_gc_layers=4))])
 def test_torch_route_vs_reference_on_the_cpu_hook(tmp_path, monkeypatch, tag, kw):
-    """method="att" / a 4-layer encoder (trained by the reference's train.py) through the drop-in API: the mirror models load the
-    reference's state_dict, the explanation runs on explainer/torch_route.py (here on the CPU through the test hook) and matches
-    the reference's own output."""
+    """A 4-layer encoder (trained by the reference's train.py) through the drop-in API: the mirror models load the reference's
+    state_dict, the explanation runs on explainer/torch_route.py (here on the CPU through the test hook) and matches the
+    reference's own output.  method="att" runs on k_att; what k_att does not implement (loss logging here: print_training) still
+    takes this route and gives the same numbers."""
     monkeypatch.setitem(explain._ENGINE, "device", "cpu")
+    if tag == "att+bn":
+        ck, ex = _route_explainer(tmp_path, "att", **kw)
+        ex.print_training = True
+        assert "loss logging" in explain._torch_route_reason(ex.args, ex.model, record_loss=True)
+        torch.manual_seed(1000 + 309)
+        with pytest.warns(RuntimeWarning, match="PyTorch-ROCm route"):
+            ma = ex.explain(309)
+        nb = Z["route:att:309:neighbors"]
+        r, c = np.nonzero(np.triu(ck["adj"][np.ix_(nb, nb)], 1))
+        assert np.abs(ma[r, c] - Z["route:att:309:masked_adj_edges"]).max() <= 1e-4
+        return
     _route_case(tmp_path, tag, kw)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag,kw", [("att", dict(method="att")), ("l4", dict(num_gc_layers=4))])
+@pytest.mark.parametrize("tag,kw", [("l4", dict(num_gc_layers=4))])
 def test_torch_route_vs_reference_on_gpu(tmp_path, tag, kw):
     _route_case(tmp_path, tag, kw)
+
+
+def test_method_att_through_the_explainer_api_on_the_emulator(tmp_path, monkeypatch):
+    """`--method att` through Explainer.explain: the kernels (k_att), not the PyTorch-ROCm route - the emulator build of the
+    same sources stands in for the GPU here."""
+    from emu.emu_engine import emu_library
+    monkeypatch.setitem(explain._ENGINE, "lib", emu_library())
+    monkeypatch.setitem(explain._ENGINE, "device", "cpu")
+    _route_case(tmp_path, "att", dict(method="att"), on_kernels=True)
+
+
+@pytest.mark.gpu
+def test_method_att_through_the_explainer_api_on_gpu(tmp_path):
+    _route_case(tmp_path, "att", dict(method="att"), on_kernels=True)
 
 
 def test_torch_route_refuses_a_cpu_only_host(tmp_path):
     if torch.cuda.is_available():
         pytest.skip("GPU present")
-    ck, ex = _route_explainer(tmp_path, "att", method="att")
+    ck, ex = _route_explainer(tmp_path, "l4", num_gc_layers=4)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ex.explain(302)
