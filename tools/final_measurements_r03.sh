@@ -20,6 +20,12 @@ find $O/prof_syn1 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/r03_
 rm -rf $O/prof_syn1
 timeout 300 python tools/probe_sparse.py 0 2>/dev/null | grep -v amdgpu > $O/r03_timeline_sparse_resident_syn1_n310.txt
 timeout 300 python tools/probe_sparse.py 150 2>/dev/null | grep -v amdgpu > $O/r03_timeline_sparse_resident_syn1_one_wave.txt
+# the dense streaming pair (k_conv / k_mask) on the BA-House x100k streaming set, the access-pattern micro-benchmark, method=att
+GNNX_SPARSE_RESIDENT=0 timeout 300 python tools/probe_conv.py 1024 1:0,1:1024,2:0 2>/dev/null | grep WIDE > $O/r03_conv_streaming_set.txt
+GNNX_SPARSE_RESIDENT=0 timeout 300 python tools/probe_conv_timeline.py 2>/dev/null | grep -v amdgpu > $O/r03_timeline_k_conv_ba100k.txt
+(cd tools/micro && for a in "4992 3" "1056 64" "4992 1"; do timeout 60 ./stream_pattern $a; done) > $O/r03_micro_stream_pattern.txt 2>&1
+timeout 300 python tools/probe_att.py 2>/dev/null | grep -v Warning > $O/r03_method_att_syn1_400targets.txt
+bash tools/gpu_pmc_stream.sh ${1:-final_r03}/pmc_stream > /dev/null 2>&1
 bash tools/gpu_pmc.sh ${1:-final_r03}/pmc_syn1 syn1 > /dev/null 2>&1
 bash tools/gpu_pmc.sh ${1:-final_r03}/pmc_ba100k ba100k > /dev/null 2>&1
 cat $O/pytest_gpu_tail.txt
