@@ -44,13 +44,15 @@ def test_lpt_shards_by_calibrated_cost_take_equal_gpu_time():
         job.set_masks_raw(engine.init_edge_masks_raw(dn.sizes, seeds=1000 + t_sub, threads=8))
         job.launch(hy)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        job.set_masks_raw_resident()
-        job.launch(hy)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) * 1e3
+        ms = []
+        for _ in range(3):          # the best of three: a wall-clock comparison at the 15 % level (one run in the round-3 session lost 1.3 ms to the host)
+            t0 = time.perf_counter()
+            job.set_masks_raw_resident()
+            job.launch(hy)
+            torch.cuda.synchronize()
+            ms.append((time.perf_counter() - t0) * 1e3)
         job.close()
-        return ms
+        return min(ms)
 
     table = parallel.calibrate_cost_table(sizes, run_batch)
     shards = parallel.lpt_shards(parallel.target_cost(sizes, table), 4)
