@@ -209,6 +209,8 @@ struct gnnx_plan_s {
     int n_unit = 0, n_unit_big = 0, n_join = 0, n_join_big = 0;
     float* d_cpart = nullptr;        // slabs of the K slices (shared by the two tables: one of them runs at a time)
     size_t cap_slabs = 0;
+    void* create_block = nullptr;    // d_meta, d_conv, d_mask, d_wts, d_raw_off, d_unit, d_join live in it (one upload)
+    void* split_block = nullptr;     // d_res, d_sp[], d_big, d_conv_big, d_mask_big, d_unit_big, d_join_big (one upload per split)
     float* d_watt = nullptr;         // method="att": attention weights of the three layers (gnnx_set_att_weights); every run takes k_att
     // the resident kernels run beside the streaming launches, each group on its own stream:
     // [0..RES_NBMAX) dense resident kernels by row blocks, [RES_NBMAX + k] sparse resident kernel of size class k
@@ -293,30 +295,50 @@ static UnitTables make_units(const std::vector<ConvTile>& tiles) {
     return o;
 }
 
-static hipError_t upload_units(gnnx_handle h, const std::vector<ConvTile>& tiles, ConvUnit*& d_units, int& n_units, ConvJoin*& d_joins,
-                                int& n_joins) {
+// The tables of a plan travel as ONE block: every upload is a host-blocking round trip through a stream whose small copy kernel has
+// to find a free compute unit - in a pipelined job (pipeline.BatchPipeline) the chip is full of the optimisations of the batches
+// ahead, and six uploads per plan + three per split cost the preparing thread nine such waits.  The builder packs the host arrays
+// (256-B aligned), uploads once and points the plan's table pointers into the block.
+struct BlockBuilder {
+    std::vector<char> host;
+    std::vector<std::pair<void**, size_t>> fix;
+    template <class T>
+    void add(T*& slot, const T* data, size_t count) {
+        slot = nullptr;
+        if (!count) return;
+        const size_t off = (host.size() + 255) / 256 * 256;
+        host.resize(off + sizeof(T) * count);
+        std::memcpy(host.data() + off, data, sizeof(T) * count);
+        fix.push_back({reinterpret_cast<void**>(&slot), off});
+    }
+    template <class T>
+    void add(T*& slot, const std::vector<T>& v) { add(slot, v.data(), v.size()); }
+    hipError_t commit(void*& block) {
+        if (block) (void)pool_free(block);
+        block = nullptr;
+        if (host.empty()) return hipSuccess;
+        hipError_t e = pool_malloc(&block, host.size());
+        if (e != hipSuccess) return e;
+        e = upload_sync(block, host.data(), host.size());
+        if (e != hipSuccess) return e;
+        for (auto& f : fix) *f.first = static_cast<char*>(block) + f.second;
+        return hipSuccess;
+    }
+};
+
+static hipError_t add_units(gnnx_handle h, BlockBuilder& bb, const std::vector<ConvTile>& tiles, ConvUnit*& d_units, int& n_units,
+                            ConvJoin*& d_joins, int& n_joins) {
     const UnitTables ut = make_units(tiles);
-    if (d_units) (void)pool_free(d_units);
-    if (d_joins) (void)pool_free(d_joins);
-    d_units = nullptr;
-    d_joins = nullptr;
     n_units = (int)ut.units.size();
     n_joins = (int)ut.joins.size();
-    hipError_t e;
-    if (n_units) {
-        if ((e = pool_malloc(&d_units, sizeof(ConvUnit) * ut.units.size())) != hipSuccess) return e;
-        if ((e = upload_sync(d_units, ut.units.data(), sizeof(ConvUnit) * ut.units.size())) != hipSuccess) return e;
-    }
-    if (n_joins) {
-        if ((e = pool_malloc(&d_joins, sizeof(ConvJoin) * ut.joins.size())) != hipSuccess) return e;
-        if ((e = upload_sync(d_joins, ut.joins.data(), sizeof(ConvJoin) * ut.joins.size())) != hipSuccess) return e;
-    }
+    bb.add(d_units, ut.units);
+    bb.add(d_joins, ut.joins);
     if ((size_t)ut.slabs > h->cap_slabs) {
         if (h->d_cpart) (void)pool_free(h->d_cpart);
-    if (h->d_watt) (void)pool_free(h->d_watt);
         h->d_cpart = nullptr;
         h->cap_slabs = 0;
-        if ((e = pool_malloc(&h->d_cpart, sizeof(float) * TILE * FS * (size_t)ut.slabs)) != hipSuccess) return e;
+        hipError_t e = pool_malloc(&h->d_cpart, sizeof(float) * TILE * FS * (size_t)ut.slabs);
+        if (e != hipSuccess) return e;
         h->cap_slabs = ut.slabs;
     }
     return hipSuccess;
@@ -334,13 +356,13 @@ static int build_split(gnnx_handle h) {
         (void)hipGraphExecDestroy(h->gexec);
         h->gexec = nullptr;
     }
-    for (void* ptr : {(void*)h->d_res, (void*)h->d_sp[0], (void*)h->d_sp[1], (void*)h->d_sp[2], (void*)h->d_sp[3], (void*)h->d_sp[4],
-                      (void*)h->d_big, (void*)h->d_conv_big, (void*)h->d_mask_big})
-        if (ptr) (void)pool_free(ptr);
-    h->d_res = h->d_big = nullptr;
+    h->d_res = h->d_big = nullptr;   // (they point into split_block, which the commit below replaces)
     for (int k = 0; k < N_SPC; ++k) h->d_sp[k] = nullptr;
     h->d_conv_big = nullptr;
     h->d_mask_big = nullptr;
+    h->d_unit_big = nullptr;
+    h->d_join_big = nullptr;
+    h->n_unit_big = h->n_join_big = 0;
     std::vector<ConvTile> conv_big;
     std::vector<MaskTile> mask_big;
     std::vector<int32_t> res_ids, sp_ids[N_SPC], big_ids;
@@ -364,22 +386,17 @@ static int build_split(gnnx_handle h) {
     h->n_big = (int)big_ids.size();
     h->n_conv_big = (int)conv_big.size();
     h->n_mask_big = (int)mask_big.size();
-    auto upload = [&](auto*& dst, const auto& v) -> hipError_t {
-        using E = typename std::remove_reference<decltype(v)>::type::value_type;
-        if (v.empty()) return hipSuccess;
-        hipError_t e = pool_malloc(&dst, sizeof(E) * v.size());
-        if (e != hipSuccess) return e;
-        return upload_sync(dst, v.data(), sizeof(E) * v.size());
-    };
-    SPLITCK(upload(h->d_res, res_ids));
-    for (int k = 0; k < N_SPC; ++k) SPLITCK(upload(h->d_sp[k], sp_ids[k]));
+    BlockBuilder bb;
+    bb.add(h->d_res, res_ids);
+    for (int k = 0; k < N_SPC; ++k) bb.add(h->d_sp[k], sp_ids[k]);
     const bool any_resident = h->n_res || h->n_sparse();
     if (any_resident && h->n_big) {
-        SPLITCK(upload(h->d_big, big_ids));
-        SPLITCK(upload(h->d_conv_big, conv_big));
-        SPLITCK(upload_units(h, conv_big, h->d_unit_big, h->n_unit_big, h->d_join_big, h->n_join_big));
-        SPLITCK(upload(h->d_mask_big, mask_big));
+        bb.add(h->d_big, big_ids);
+        bb.add(h->d_conv_big, conv_big);
+        SPLITCK(add_units(h, bb, conv_big, h->d_unit_big, h->n_unit_big, h->d_join_big, h->n_join_big));
+        bb.add(h->d_mask_big, mask_big);
     }
+    SPLITCK(bb.commit(h->split_block));
     if (any_resident && !h->ev_in) SPLITCK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     // (Disjoint compute-unit masks for the sparse and the single-tile dense launch - hipExtStreamCreateWithCUMask - were
     // measured on syn1 and made the sparse launch slower, 9.7 vs 6.4 ms in situ: not used.)
@@ -489,23 +506,20 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
             return fail(std::string(#x) + ": " + hipGetErrorString(e_));                               \
         }                                                                                              \
     } while (0)
-    PLANCK(pool_malloc(&h->d_meta, sizeof(TargetMeta) * T));
-    PLANCK(pool_malloc(&h->d_conv, sizeof(ConvTile) * conv.size()));
-    PLANCK(pool_malloc(&h->d_mask, sizeof(MaskTile) * mask.size()));
-    PLANCK(pool_malloc(&h->d_wts, sizeof(float) * WT_TOTAL));
-    PLANCK(upload_sync(h->d_meta, h->meta.data(), sizeof(TargetMeta) * T));
-    PLANCK(upload_sync(h->d_conv, conv.data(), sizeof(ConvTile) * conv.size()));
-    PLANCK(upload_units(h, conv, h->d_unit, h->n_unit, h->d_join, h->n_join));
-    PLANCK(upload_sync(h->d_mask, mask.data(), sizeof(MaskTile) * mask.size()));
-    PLANCK(upload_sync(h->d_wts, w.data(), sizeof(float) * WT_TOTAL));
     {
         std::vector<int64_t> ro(T);
         for (int t = 0; t < T; ++t) {
             ro[t] = h->total_raw;
             h->total_raw += (int64_t)h->meta[t].n * h->meta[t].n;
         }
-        PLANCK(pool_malloc(&h->d_raw_off, sizeof(int64_t) * T));
-        PLANCK(upload_sync(h->d_raw_off, ro.data(), sizeof(int64_t) * T));
+        BlockBuilder bb;
+        bb.add(h->d_meta, h->meta);
+        bb.add(h->d_conv, conv);
+        PLANCK(add_units(h, bb, conv, h->d_unit, h->n_unit, h->d_join, h->n_join));
+        bb.add(h->d_mask, mask);
+        bb.add(h->d_wts, w);
+        bb.add(h->d_raw_off, ro);
+        PLANCK(bb.commit(h->create_block));
     }
 #undef PLANCK
     if (int rc = build_split(h)) {
@@ -555,15 +569,11 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
 extern "C" int gnnx_destroy(gnnx_handle h) {
     if (!h) return 0;
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
-    if (h->d_meta) (void)pool_free(h->d_meta);
     for (int k = 0; k < N_SIDE; ++k) {
         if (h->ev_out[k]) (void)hipEventDestroy(h->ev_out[k]);
         if (h->ev_t0[k]) (void)hipEventDestroy(h->ev_t0[k]);
     }
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
-    if (h->d_res) (void)pool_free(h->d_res);
-    for (int k = 0; k < N_SPC; ++k)
-        if (h->d_sp[k]) (void)pool_free(h->d_sp[k]);
     if (h->d_nnz) (void)pool_free(h->d_nnz);
     if (h->d_rowdeg) (void)pool_free(h->d_rowdeg);
     if (h->d_csr_rowptr) (void)pool_free(h->d_csr_rowptr);
@@ -571,19 +581,11 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
     if (h->d_csr_row) (void)pool_free(h->d_csr_row);
     if (h->d_csr_off) (void)pool_free(h->d_csr_off);
     if (h->d_adam) (void)pool_free(h->d_adam);
-    if (h->d_raw_off) (void)pool_free(h->d_raw_off);
     if (h->d_rowcnt) (void)pool_free(h->d_rowcnt);
-    if (h->d_big) (void)pool_free(h->d_big);
-    if (h->d_conv_big) (void)pool_free(h->d_conv_big);
-    if (h->d_mask_big) (void)pool_free(h->d_mask_big);
-    if (h->d_conv) (void)pool_free(h->d_conv);
-    if (h->d_unit) (void)pool_free(h->d_unit);
-    if (h->d_unit_big) (void)pool_free(h->d_unit_big);
-    if (h->d_join) (void)pool_free(h->d_join);
-    if (h->d_join_big) (void)pool_free(h->d_join_big);
     if (h->d_cpart) (void)pool_free(h->d_cpart);
-    if (h->d_mask) (void)pool_free(h->d_mask);
-    if (h->d_wts) (void)pool_free(h->d_wts);
+    if (h->d_watt) (void)pool_free(h->d_watt);
+    if (h->create_block) (void)pool_free(h->create_block);
+    if (h->split_block) (void)pool_free(h->split_block);
     delete h;
     return 0;
 }
