@@ -49,6 +49,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
     __shared__ float sWp[CMAX * 96 + CMAX];
     __shared__ float fcur[32], mf[32], vf[32], phi[32];
     __shared__ float emb[96], gcls[CMAX], dEs[96];
+    __shared__ int erow[96];
     __shared__ float part[2 * NWV][32];
     const int t = blockIdx.x;
     const TargetMeta tm = p.meta[t];
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
     float* Md = p.M + tm.offQ;
     float* md = p.mM + tm.offQ;
     float* vd = p.vM + tm.offQ;
-    const float* yh = p.yhat + tm.offR;
+    const float* yh = p.graph_mode ? nullptr : p.yhat + tm.offR;   // graph mode has no Laplacian term (explain.py:780)
 
     // ---------------- set-up: model, feature-mask state, CSR of the sub-graph ----------------
     for (int l = 0; l < 3; ++l)
@@ -204,11 +205,29 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
             }
             __syncthreads();
         }
-        // head on row t of the three layers (explain.py:713, models.py:372-380)
+        // head: row t of the three layers in node mode (explain.py:713, models.py:372-380); in graph mode the column-wise max over
+        // ALL n rows of every layer (models.py:283, 291, 300; the first maximal row wins, as torch.max)
         if (tid < 96) {
             const int l = tid >> 5, c = tid & 31;
-            const float v = a.U[l][ro + (size_t)tr * FS + c];
-            emb[tid] = (l < 2) ? fmaxf(v, 0.0f) : v;
+            if (p.graph_mode) {
+                const int dl = (l == 2) ? p.O : H;
+                float best = 0.0f;
+                int arg = 0;
+                if (c < dl) {
+                    best = -3.0e38f;
+                    for (int i = 0; i < n; ++i) {
+                        float v = a.U[l][ro + (size_t)i * FS + c];
+                        if (l < 2) v = fmaxf(v, 0.0f);
+                        if (v > best) { best = v; arg = i; }
+                    }
+                }
+                emb[tid] = best;
+                erow[tid] = arg;
+            } else {
+                const float v = a.U[l][ro + (size_t)tr * FS + c];
+                emb[tid] = (l < 2) ? fmaxf(v, 0.0f) : v;
+                erow[tid] = tr;
+            }
         }
         __syncthreads();
         head_softmax(p, tm, t, iter, true, sWp, emb, gcls, dEs);
@@ -227,7 +246,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
                 const bool ron = i < n;
                 const size_t r = (size_t)(ron ? i : 0) * FS + ln;
                 float dx = (l < 2) ? dX[r] : 0.0f;
-                if (i == tr) dx += dEs[l * 32 + ln];
+                if (ron && erow[l * 32 + ln] == i) dx += dEs[l * 32 + ln];   // the direct part lands on row t / on the arg-max row of the column
                 const float un = a.U[l][ro + r];
                 float du = (ln < dout) ? dx : 0.0f;
                 if (l < 2) du = (un > 0.0f) ? du : 0.0f;
@@ -301,7 +320,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
         // ======== mask entries on the edges: regularisers, symmetrisation, Adam (as k_mask) ========
         const float step_size = adam[2 * iter], bc2s = adam[2 * iter + 1];
         for (int i = wave; i < n; i += NWV) {
-            const float yi = yh[i];
+            const float yi = p.graph_mode ? 0.0f : yh[i];
             for (int e = rowptr[i] + lane; e < rowptr[i + 1]; e += 64) {
                 const int k = col[e];
                 const size_t idx = (size_t)i * ld + k;

@@ -818,7 +818,6 @@ extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, con
 
 extern "C" int gnnx_set_att_weights(gnnx_handle h, const float* att_weights) {
     if (!h || !att_weights) return fail("null argument");
-    if (h->prob.graph_mode) return fail("method=att runs on the kernels in node mode only");
     if (h->prob.bn || h->prob.mask_relu) return fail("method=att is not implemented together with --bn / mask_act=ReLU");
     if (!h->d_watt) HIPCK(pool_malloc(&h->d_watt, sizeof(float) * 3 * 1024));
     HIPCK(upload_sync(h->d_watt, att_weights, sizeof(float) * 3 * 1024));

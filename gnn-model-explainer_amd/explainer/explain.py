@@ -122,8 +122,8 @@ def _regulariser_only_feat_mask(args, D, num_iters):
 def _torch_route_reason(args, model, state_dict=None, graph_mode=False, record_loss=False, unconstrained=False):
     """None when the HIP kernels implement this configuration, else what makes it take explainer/torch_route.py (SURVEY.md section 8(b):
     configurations the kernels do not cover run on a PyTorch-ROCm restatement of the reference path instead of silently differing).
-    method="att" (models.py:62-68) runs on k_att (csrc/gnnx_att.hpp) in node mode with the sigmoid mask; its other combinations
-    (graph mode, --bn, mask_act=ReLU, loss logging, unconstrained) take the PyTorch-ROCm route."""
+    method="att" (models.py:62-68) runs on k_att (csrc/gnnx_att.hpp), node and graph mode, with the sigmoid mask; its other
+    combinations (--bn, mask_act=ReLU, loss logging, unconstrained) take the PyTorch-ROCm route."""
     method = getattr(args, "method", "base")
     if method not in ("base", "att"):
         return "method=%r" % method
@@ -132,7 +132,7 @@ def _torch_route_reason(args, model, state_dict=None, graph_mode=False, record_l
     sd = state_dict if state_dict is not None else model.state_dict()
     att = any(k.endswith("att_weight") for k in sd)
     if att or method == "att":
-        for what, on in (("graph mode", graph_mode), ("--bn", bool(getattr(args, "bn", False))), ("loss logging", record_loss),
+        for what, on in (("--bn", bool(getattr(args, "bn", False))), ("loss logging", record_loss),
                          ("mask_act=ReLU", getattr(args, "mask_act", "sigmoid") == "ReLU"), ("unconstrained", unconstrained),
                          ("attention weights in some layers only", not all(k + ".att_weight" in sd for k in ("conv_first", "conv_block.0", "conv_last")))):
             if on:

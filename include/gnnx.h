@@ -136,8 +136,9 @@ int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hyper, const gnnx_resume* r
  * `x_att = x W_att; att = x_att x_att^T; adj = adj * att` in every layer).  att_weights: HOST pointer, [3][32][32] floats, zero
  * padded, W_att of layer l at l * 1024 + b * 32 + a (b = input column, as the reference stores it).  Once set, every gnnx_run /
  * gnnx_run_resume of the plan optimises all targets in k_att (gnnx_att.hpp: one workgroup per target, edge-list state, all
- * iterations in one launch, forward and backward through the attention products).  Node mode, sigmoid mask, no --bn, no loss
- * logging (other combinations return an error: the Python mirror sends them to its PyTorch-ROCm route).  The call synchronises
+ * iterations in one launch, forward and backward through the attention products).  Node and graph mode (GcnEncoderNode /
+ * GcnEncoderGraph heads), sigmoid mask, no --bn, no loss logging (other combinations return an error: the Python mirror sends
+ * them to its PyTorch-ROCm route).  The call synchronises
  * with the host (the edge arrays are sized from a device count). */
 int gnnx_set_att_weights(gnnx_handle h, const float* att_weights);
 
