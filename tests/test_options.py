@@ -109,6 +109,8 @@ def test_method_att_kernel_vs_reference(be, t):
     """method="att" (models.py:62-68) - adj * (x W_att)(x W_att)^T in every layer, forward and backward through the attention
     products - on k_att against the LIVE reference's output for an encoder its own train.py trained with --method att
     (100 epochs, as the fixture was made), at the 1e-5 of every other parity test (measured: 6e-8 on the GPU)."""
+    if be.name == "emu" and t == 309:
+        pytest.skip("n = 48 x 100 epochs takes the emulator 80 s: the GPU twin runs it; the emulator covers n = 6, the graph-mode fixture and the autograd check on n = 48")
     ck, sd, sg = _att_case(t)
     job = be.job([sg], sd)
     assert job.att is not None
@@ -130,7 +132,7 @@ def test_method_att_graph_mode_kernel_vs_reference(be):
     k_att against the LIVE reference (tests/golden/make_golden_att_graph.py: its GcnEncoderGraph with args.method = "att", four padded
     molecule-like graphs of 10-39 nodes, 60 epochs), all four graphs as one batch."""
     sd = {k[2:]: ZG[k] for k in ZG.files if k.startswith("w:")}
-    graphs = [1, 2] if be.name == "emu" else list(range(len(ZG["label"])))     # (the emulator steps a 40-row graph for 40 s)
+    graphs = [2, 3] if be.name == "emu" else list(range(len(ZG["label"])))     # (the emulator steps a 40-row graph for 40 s)
     subs = [Subgraph(ZG["adj"][g], ZG["feat"][g], int(ZG["label"][g]), 0, None, helpers.seeded_mask0(g, ZG["adj"][g].shape[0]).numpy()) for g in graphs]
     job = be.job(subs, sd, graph_mode=True)
     assert job.att is not None
