@@ -14,9 +14,11 @@ mask-optimisation path (`model="exp"`, `unconstrained=False`, sigmoid mask, Adam
 
 `--mask-bias` is accepted (the reference's bias mask provably stays exactly 0, see _check_supported); `mask_act="ReLU"` runs on
 the dense streaming kernels and reproduces the reference's NaN behaviour; `--bn` runs on the dense streaming kernels.
-`--opt sgd | rmsprop | adagrad`, `--opt-scheduler step | cos` and `unconstrained=True` run on the same kernels (round 3).
-Configurations the kernels do not implement - `method="att"`, `model="att"`, num_gc_layers != 3, encoders with add_self / dropout /
-a hidden head, a node explanation on a graph-mode Explainer - run on explainer/torch_route.py: the reference's algorithm as torch
+`--opt sgd | rmsprop | adagrad`, `--opt-scheduler step | cos` and `unconstrained=True` run on the same kernels (round 3);
+`--method att` (the attention encoder, models.py:62-68) runs on k_att (csrc/gnnx_att.hpp), node and graph mode.
+Configurations the kernels do not implement - `model="att"` (the attention baseline), num_gc_layers != 3, encoders with add_self /
+dropout / a hidden head, a node explanation on a graph-mode Explainer, `--method att` together with --bn / loss logging - run on
+explainer/torch_route.py: the reference's algorithm as torch
 autograd on the HIP device through the caller's model, announced by a RuntimeWarning; never a silent difference.  `model="grad"` (the gradient baseline, explain.py:125-133)
 runs on the engine too (Explainer.explain_grad).
 Plotting / TensorBoard / alignment post-processing of the reference is out of scope.

@@ -1,6 +1,7 @@
 """The PyTorch-ROCm route for the configurations the HIP kernels do not implement ("fall back to a
-PyTorch-ROCm restatement of the reference path rather than silently differ"): `method="att"`, `model="att"`, `num_gc_layers != 3`,
-encoders with `add_self` / dropout / a hidden prediction head, node explanations on a graph-mode Explainer, and
+PyTorch-ROCm restatement of the reference path rather than silently differ"): `model="att"` (the attention baseline),
+`num_gc_layers != 3`, encoders with `add_self` / dropout / a hidden prediction head, node explanations on a graph-mode Explainer,
+`method="att"` together with `--bn` / a ReLU mask / loss logging / unconstrained (`method="att"` itself runs on k_att), and
 `ExplainModule.forward(marginalize=True / mask_features=False)`.
 
 It is the reference's algorithm - ExplainModule (explainer/explain.py:582-820) and the loop of Explainer.explain (:137-146,
