@@ -41,7 +41,7 @@ __device__ __forceinline__ float att_sum32(float v) {  // over the 32 lanes of a
     return v;
 }
 
-constexpr int ATT_THREADS = 512;
+constexpr int ATT_THREADS = 1024;
 
 __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, const float* __restrict__ adam) {
     constexpr int NWV = ATT_THREADS / 64;
