@@ -37,6 +37,7 @@ import threading
 import time
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the first HIP call: see gnn-model-explainer_amd/__init__.py
+os.environ.setdefault("GPU_FORCE_BLIT_COPY_SIZE", "1024")   # (KB) table uploads / result downloads as blit kernels, not SDMA: ibid.
 
 import numpy as np
 import torch

@@ -1237,9 +1237,7 @@ extern "C" int gnnx_pack_csr(gnnx_handle h, const int64_t* indptr, const int32_t
     if (!h || !indptr || !indices || !feat || !nb || !nb_off || !A || !X) return fail("null argument");
     if (!h->prob.graph_mode && (!pred_label || !yhat)) return fail("pred_label / yhat are required in node mode");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    HIPCK(hipMemsetAsync(A, 0, sizeof(float) * (size_t)h->Q, s));
-    HIPCK(hipMemsetAsync(X, 0, sizeof(float) * (size_t)h->R * FS, s));
-    if (yhat) HIPCK(hipMemsetAsync(yhat, 0, sizeof(float) * (size_t)h->R, s));
+    // (k_pack zeroes its own 32-row blocks of A, X and yhat first: every block of the batch belongs to one workgroup)
     PackArgs a{indptr, indices, weights, feat, feat_stride, pred_label, nb, nb_off, A, X, yhat, h->prob.D};
     hipLaunchKernelGGL(k_pack, dim3(h->n_conv), dim3(256), 0, s, a, h->d_conv);
     HIPCK(hipGetLastError());

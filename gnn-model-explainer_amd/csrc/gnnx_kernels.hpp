@@ -1244,6 +1244,16 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a, const ConvTile* tiles)
     const TargetMeta tm = tl.tm;
     const int row = threadIdx.x >> 3, part = threadIdx.x & 7;
     const int i = tl.rb * TILE + row;
+    // the block's 32 rows of A (ld wide, contiguous), of X and of yhat start as zeros (padding rows and columns stay zero): done
+    // here instead of three memsets over the whole batch - three launches fewer for a pipeline whose short kernels queue for CUs
+    {
+        f32x4* Ab = reinterpret_cast<f32x4*>(a.A + tm.offQ + (size_t)tl.rb * TILE * tm.ld);
+        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int e = threadIdx.x; e < TILE * tm.ld / 4; e += 256) Ab[e] = z;
+        reinterpret_cast<f32x4*>(a.X + ((size_t)tm.offR + tl.rb * TILE) * FS)[threadIdx.x] = z;   // 32 rows x 32 floats = 256 x 16 B
+        if (a.yhat && threadIdx.x < TILE) a.yhat[tm.offR + tl.rb * TILE + threadIdx.x] = 0.0f;
+    }
+    __syncthreads();
     if (i >= tm.n) return;
     const int32_t* nb = a.nb + a.nb_off[tl.t];
     const int u = nb[i];
