@@ -224,6 +224,15 @@ def test_device_side_packing_equals_host_packing(be):
     assert torch.equal(dev.A.cpu(), host.A.cpu()) and torch.equal(dev.X.cpu(), host.X.cpu()) and torch.equal(dev.yhat.cpu(), host.yhat.cpu())
     for a, s in zip(dev.adjacency(), subs):
         assert np.array_equal(a, s.adj)
+    # the pack kernel zeroes its own row blocks (no memset ahead of it): poisoned buffers come out identical
+    nb_flat, nb_off_d, g = dev._keepalive
+    dev.A.fill_(float("nan")); dev.X.fill_(7.0); dev.yhat.fill_(-3.0)
+    dev._enter()
+    engine._check(dev.lib, dev.lib.gnnx_pack_csr(dev.handle, g.indptr.data_ptr(), g.indices.data_ptr(), None, g.feat.data_ptr(), g.feat.shape[1],
+                                                 g.pred_label.data_ptr(), nb_flat.data_ptr(), nb_off_d.data_ptr(), dev.A.data_ptr(), dev.X.data_ptr(),
+                                                 dev.yhat.data_ptr(), dev._stream()))
+    dev._leave()
+    assert torch.equal(dev.A.cpu(), host.A.cpu()) and torch.equal(dev.X.cpu(), host.X.cpu()) and torch.equal(dev.yhat.cpu(), host.yhat.cpu())
 
 
 @pytest.mark.parametrize("D,H,O,C,n,graph_mode,path", [
