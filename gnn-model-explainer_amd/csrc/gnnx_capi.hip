@@ -1364,6 +1364,7 @@ extern "C" int gnnx_auc_counts(const float* vals, const uint8_t* real, int64_t n
 
 extern "C" int gnnx_forward(gnnx_handle h, const float* A, const float* X, const float* M, const float* feat_mask_in,
                             float* Abar, float* probs, void* workspace, size_t workspace_bytes, void* stream) {
+    if (h && h->d_watt) return fail("gnnx_forward is not implemented for a method=att plan (gnnx_set_att_weights): only gnnx_run / gnnx_run_resume are");
     if (!h || !A || !X || !M || !Abar || !probs || !workspace) return fail("null argument");
     if (workspace_bytes < h->ws_bytes) return fail("workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1380,6 +1381,7 @@ extern "C" int gnnx_forward(gnnx_handle h, const float* A, const float* X, const
 
 extern "C" int gnnx_grad_baseline(gnnx_handle h, const float* A, const float* X, float* out, void* workspace, size_t workspace_bytes,
                                   void* stream) {
+    if (h && h->d_watt) return fail("gnnx_grad_baseline is not implemented for a method=att plan (gnnx_set_att_weights): only gnnx_run / gnnx_run_resume are");
     if (!h || !A || !X || !out || !workspace) return fail("null argument");
     if (h->prob.graph_mode) return fail("the gradient baseline is a node-mode path (the reference indexes pred_label[node_idx], explain.py:130)");
     if (h->prob.bn) return fail("the gradient baseline with --bn is not implemented");
@@ -1407,6 +1409,7 @@ extern "C" int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hy, int32_t kin
                                 const float* X, const float* yhat, float* M, float* Abar, void* workspace,
                                 size_t workspace_bytes, void* stream, float* ms_avg, double* alg_bytes,
                                 double* alg_flops) {
+    if (h && h->d_watt) return fail("gnnx_time_kernel is not implemented for a method=att plan (gnnx_set_att_weights): only gnnx_run / gnnx_run_resume are");
     if (!h || !hy || !ms_avg || reps < 1) return fail("bad argument");
     if (workspace_bytes < h->ws_bytes) return fail("workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);

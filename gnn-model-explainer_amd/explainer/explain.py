@@ -423,6 +423,10 @@ class Explainer:
             raise NotImplementedError("the gradient baseline is a node-mode path")
         if getattr(self.args, "bn", False):
             raise NotImplementedError("the gradient baseline with --bn is not implemented on the HIP path")
+        sd = self.model.state_dict()
+        if any(k.endswith("att_weight") for k in sd) or _torch_route_reason(self.args, self.model, state_dict=sd) is not None:
+            raise NotImplementedError("the gradient baseline (gnnx_grad_baseline) implements the base 3-layer encoder only: %s" %
+                                      (_torch_route_reason(self.args, self.model, state_dict=sd) or "an attention encoder (method='att')"))
         lib = _ENGINE["lib"]
         targets = np.asarray([int(v) for v in node_indices], np.int64)
         graph = self._device_graph(graph_idx)

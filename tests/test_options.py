@@ -168,6 +168,21 @@ def test_method_att_graph_mode_through_the_explainer_api_on_gpu(tmp_path):
             assert np.abs(ma - ZG[f"{g}:masked_adj"])[e].max() <= TOL
 
 
+def test_method_att_plans_refuse_the_base_encoder_entry_points(be, tmp_path):
+    """gnnx_forward / gnnx_grad_baseline run the base encoder: on a plan with attention weights they fail instead of silently ignoring them;
+    the mirror's gradient baseline says so before it gets there."""
+    ck, sd, sg = _att_case(302)
+    job = be.job([sg], sd)
+    with pytest.raises(RuntimeError, match="method=att"):
+        job.grad_baseline()
+    with pytest.raises(RuntimeError, match="method=att"):
+        job.forward([sg.mask0])
+    if be.name == "emu":
+        ck, ex = _route_explainer(tmp_path, "att", method="att")
+        with pytest.raises(NotImplementedError, match="attention encoder"):
+            ex.explain(302, model="grad")
+
+
 def test_method_att_one_step_equals_autograd(be):
     """One Adam step of k_att against torch autograd through the mirror encoder (models.GcnEncoderNode with method="att") on the
     same inputs: the updated mask entries on the edges, the feature mask, and two targets in one batch == alone."""
