@@ -138,7 +138,8 @@ int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hyper, const gnnx_resume* r
  * gnnx_run_resume of the plan optimises all targets in k_att (gnnx_att.hpp: one workgroup per target, edge-list state, all
  * iterations in one launch, forward and backward through the attention products).  Node and graph mode (GcnEncoderNode /
  * GcnEncoderGraph heads), sigmoid mask, no --bn, no loss logging (other combinations return an error: the Python mirror sends
- * them to its PyTorch-ROCm route).  The call synchronises
+ * them to its PyTorch-ROCm route); gnnx_forward, gnnx_grad_baseline and gnnx_time_kernel implement the base encoder and return
+ * an error on such a plan.  The call synchronises
  * with the host (the edge arrays are sized from a device count). */
 int gnnx_set_att_weights(gnnx_handle h, const float* att_weights);
 
