@@ -1263,7 +1263,12 @@ extern "C" int gnnx_khop(const int64_t* indptr, const int32_t* indices, int32_t 
     hipStream_t s = static_cast<hipStream_t>(stream);
     KhopArgs a{indptr, indices, num_nodes, n_hops, targets, num_targets, sizes, nb_off, nb, target_row,
                static_cast<uint32_t*>(scratch), words};
-    const dim3 grid(in_lds ? num_targets : std::min(num_targets, 1024)), block(KH_THREADS);
+    // workgroups loop over targets: GNNX_KHOP_GRID caps their number (measurement knob; a pipelined job's k-hop pass queues for
+    // compute units behind the optimisations of the batches ahead; 32 / 64 / 128 workgroups instead of one per target: k-hop stage
+    // 1.6-2.3 ms against 1.7 - no gain, default unchanged)
+    const char* e_grid = getenv("GNNX_KHOP_GRID");
+    const int cap = e_grid ? std::max(1, atoi(e_grid)) : (in_lds ? num_targets : 1024);
+    const dim3 grid(std::min(num_targets, in_lds ? cap : std::min(cap, 1024))), block(KH_THREADS);
     if (emit) {
         if (in_lds) hipLaunchKernelGGL((k_khop<true, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((k_khop<true, false>), grid, block, 0, s, a);
