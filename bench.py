@@ -525,6 +525,8 @@ def main():
         keys = sorted({k for st in pipe.stats for k in st})
         e2e_stats = {k: float(np.mean([st[k] for st in pipe.stats if k in st])) for k in keys}
         e2e_stats["rng_threads"] = pipe.rng_threads
+        e2e_stats["stream_candidates_rejected"] = len(pipe._rejected)          # (hardware-queue calibration of the pipeline's six streams)
+        e2e_stats["streams_without_own_queue"] = getattr(pipe, "queue_fallbacks", 0)
         log(f"end-to-end pipelined region done: {dt:.3f} s for {args.steps} batches")
 
     # ---------------------------------------------------------------- parity gate (same run) ----------------------------------

@@ -114,6 +114,7 @@ class BatchPipeline:
             self._rejected.append(cand)
         cand = self._new_stream(kind)      # no free queue found: some stages then serialise, correctly but slower
         self._chosen.append(cand)
+        self.queue_fallbacks = getattr(self, "queue_fallbacks", 0) + 1
         return cand
 
     # -- pinned staging ----------------------------------------------------------------------------------------------------
