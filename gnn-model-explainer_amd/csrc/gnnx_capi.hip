@@ -219,6 +219,7 @@ struct gnnx_plan_s {
     bool launched[N_SIDE] = {};
     std::vector<int> order;          // targets, largest first
     std::vector<int> cat;            // per target: 0 streaming, 1..RES_NBMAX dense resident kernel of that many row blocks, CAT_SPARSE
+    bool xconst = false;             // every target of the sparse resident classes has constant feature rows (gnnx_plan_analyze_features)
     std::vector<int32_t> nnz;        // per target (directed edge entries, row slots) from gnnx_plan_analyze, empty before
     int n_sp[N_SPC] = {};            // targets of the sparse resident kernel, per size class (1024 / 256 / 64 threads)
     int32_t* d_sp[N_SPC] = {};
@@ -789,7 +790,8 @@ static void launch_sparse_nt(gnnx_handle h, const Params& p, const int32_t* ids,
         if (exact_shape(h, 14)) hipLaunchKernelGGL((k_sparse_resident<7, 10, true, NT>), grid, block, 0, s, p, ids, adam_tab);
         else hipLaunchKernelGGL((k_sparse_resident<16, 16, true, NT>), grid, block, 0, s, p, ids, adam_tab);
     } else {
-        if (exact_shape(h, 10)) hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT>), grid, block, 0, s, p, ids, adam_tab);
+        if (exact_shape(h, 10) && h->xconst) hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT, true>), grid, block, 0, s, p, ids, adam_tab);
+        else if (exact_shape(h, 10)) hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT>), grid, block, 0, s, p, ids, adam_tab);
         else hipLaunchKernelGGL((k_sparse_resident<16, 16, false, NT>), grid, block, 0, s, p, ids, adam_tab);
     }
 }
@@ -989,7 +991,10 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
             if (mixed && k == SPC_512) {
                 const int per_wg = sp_mix_tiny(h->prob.D, h->prob.H, h->prob.C);   // single-tile targets per workgroup
                 const dim3 grid(h->n_sp[SPC_512] + (h->n_sp[2] + per_wg - 1) / per_wg), block(512);
-                if (exact_shape(h, 10))
+                if (exact_shape(h, 10) && h->xconst)
+                    hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, true>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
+                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C));
+                else if (exact_shape(h, 10))
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
                                        h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C));
                 else
@@ -1075,12 +1080,16 @@ extern "C" int gnnx_get_route(gnnx_handle h, int32_t* route) {
     return 0;
 }
 
-extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
+extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) { return gnnx_plan_analyze_features(h, A, nullptr, stream); }
+
+extern "C" int gnnx_plan_analyze_features(gnnx_handle h, const float* A, const float* X, void* stream) {
     if (!h || !A) return fail("null argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int T = h->prob.num_targets;
-    if (!h->d_nnz) HIPCK(pool_malloc(&h->d_nnz, sizeof(int32_t) * (2 + SPL_COUNTS) * T));
-    hipLaunchKernelGGL(k_count_edges, dim3(T), dim3(256), 0, s, h->d_meta, A, h->d_nnz);
+    const bool look_at_x = X && !h->prob.graph_mode;   // constant feature rows: node mode (the form exists for the node encoder's shapes)
+    if (!h->d_nnz) HIPCK(pool_malloc(&h->d_nnz, sizeof(int32_t) * (3 + SPL_COUNTS) * T));
+    hipLaunchKernelGGL(k_count_edges, dim3(T), dim3(256), 0, s, h->d_meta, A, h->d_nnz, look_at_x ? X : nullptr,
+                       look_at_x ? h->d_nnz + (2 + SPL_COUNTS) * (size_t)T : nullptr);
     if (!h->prob.graph_mode) {
         int nmax = 0;
         for (int t = 0; t < T; ++t) nmax = std::max(nmax, h->meta[t].n);
@@ -1093,9 +1102,10 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
     }
     HIPCK(hipGetLastError());
     // per target: (directed entries, row slots over all rows); then k_count_edges_large's SPL_COUNTS figures
-    h->nnz.assign((2 + SPL_COUNTS) * (size_t)T, -1);
-    HIPCK(hipMemcpyAsync(h->nnz.data(), h->d_nnz, sizeof(int32_t) * (h->prob.graph_mode ? 2 : 2 + SPL_COUNTS) * T, hipMemcpyDeviceToHost, s));
+    h->nnz.assign((3 + SPL_COUNTS) * (size_t)T, -1);   // ..., then one flag per target: constant feature rows (0 when X was not given)
+    HIPCK(hipMemcpyAsync(h->nnz.data(), h->d_nnz, sizeof(int32_t) * (h->prob.graph_mode ? 2 : (look_at_x ? 3 : 2) + SPL_COUNTS) * T, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
+    h->xconst = false;
     const bool graph = h->prob.graph_mode != 0;
     if (h->prob.C > RES_CMAX || h->prob.mask_relu || h->prob.bn) return 0;   // mask_act = "ReLU" and --bn run on the dense streaming kernels only
     int sparse_on = 1;
@@ -1196,6 +1206,20 @@ extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) {
     for (int t = 0; t < T; ++t) {
         changed |= (new_cat[t] != h->cat[t]);
         h->cat[t] = new_cat[t];
+    }
+    // constant-feature form of the sparse resident kernel: when EVERY target it takes has constant feature rows (one launch = one form)
+    if (look_at_x) {
+        bool all = true, any = false;
+        for (int t = 0; t < T; ++t) {
+            const int c = h->cat[t];
+            if (c == CAT_SPARSE || c == CAT_SPARSE + 1 || c == CAT_SPARSE + 2 || c == CAT_SPARSE + SPC_512) {
+                any = true;
+                all &= h->nnz[(2 + SPL_COUNTS) * (size_t)T + t] == 1;
+            }
+        }
+        int xc_on = 1;
+        if (const char* env = std::getenv("GNNX_XCONST")) xc_on = std::atoi(env);
+        h->xconst = any && all && xc_on && exact_shape(h, 10);
     }
     if (changed)
         if (int rc = build_split(h)) return rc;

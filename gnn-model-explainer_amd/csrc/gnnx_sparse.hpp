@@ -112,6 +112,7 @@ struct SparseFixed {
     float z3[32], y3[32], dz3[32], e[96], g[CMAX], dEs[96], dfp[32], dfw[SP_THREADS / 64][32];
     float sr3;
     int nnz, eup, bad;
+    int xconst;  // node mode: every feature row of the sub-graph equals row 0 bit for bit (constant / featureless inputs)
     int set_rows[2], set_slots[2];
     int set_chunk[2];  // entries per row slot of the set: the smallest of {4, 8, 16} (8, 16 for set A) whose slots fit the class
     int erow[96];  // graph mode: arg-max row of every pooled column
@@ -209,6 +210,29 @@ __device__ __forceinline__ void sparse_gather(const float* sAb, const unsigned s
         sparse_gather_impl<RELU, NQ, true, UN>(sAb, scol, B, stride, W, e0, e1, half, acc);
     else
         sparse_gather_impl<RELU, NQ, false, UN>(sAb, scol, B, stride, W, e0, e1, half, acc);
+}
+
+// Constant feature rows (every X[j] == X[0] bit for bit: the reference's synthetic datasets use ConstFeatureGen, gengraph.py:60-61,
+// and featureless graphs get constant inputs): Abar . X needs neither the column of an entry nor the row it points at - the lane
+// keeps its NQ columns of the one row in registers and the entry loop is a stream of independent loads of Abar alone.  Same
+// products in the same order as sparse_gather (fmaf(Abar_e, X[col_e][c], acc) with X[col_e][c] == xq), so the results are
+// bit-identical to the general path.
+template <int NQ, int UN = 4>
+__device__ __forceinline__ void sparse_gather_const(const float* sAb, const float (&xq)[NQ], int e0, int e1, float (&acc)[NQ]) {
+#pragma unroll 1
+    for (int e = e0; e < e1; e += UN) {
+        float a[UN];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const bool in = e + j < e1;
+            const float v = sAb[in ? e + j : e0];
+            a[j] = in ? v : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int j = 0; j < UN; ++j) acc[q] = fmaf(a[j], xq[q], acc[q]);
+    }
 }
 
 // forward row-local part for the lane's row: Y^T[c][r] = sum_k W[k][c] Z[r][k] on MFMA (the lane's registers zq[u] =
@@ -359,7 +383,10 @@ __device__ __forceinline__ void sparse_combine(float (&acc)[NQ], int rem, int ws
 // The body works on NT consecutive threads tid = 0 .. NT-1 with their own LDS pool and SparseFixed: a whole workgroup
 // (k_sparse_resident) or, for NT = 64, one wave of a larger workgroup (k_sparse_resident_mixed) - a single wave
 // synchronises with itself, so its barriers are wave-level.
-template <int DQ, int HQ, bool GRAPH, int NT>
+// XC: every feature row of the target equals its row 0 bit for bit (decided per plan by gnnx_plan_analyze_features, verified here):
+// layer 1 and the X part of dL/dAbar then need no gathers (sparse_gather_const); a compile-time form because a run-time test inside
+// the phases keeps the operands of both forms alive across them (the 512-thread class sits at 256 VGPRs).  Node mode, exact shapes.
+template <int DQ, int HQ, bool GRAPH, int NT, bool XC = false>
 __device__ __forceinline__ void sparse_resident_body(const Params p, int t, const float* adam_tab, float* pool, SparseFixed& sh,
                                                      int tid, float* shared_w = nullptr) {
     constexpr int SCAN = (sp_ld_max(NT) + 63) / 64;  // rows per lane in the setup prefix scans
@@ -428,7 +455,10 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     int* rowptr = reinterpret_cast<int*>(pool + L.oRowptr);
     if (tid < ld) rowptr[tid] = rp_keep;
     if (tid == 0) rowptr[ld] = nnz;
-    if (tid == 0) sh.bad = 0;
+    if (tid == 0) {
+        sh.bad = 0;
+        sh.xconst = 1;
+    }
     SYNC();
     float* sX = pool + L.oX;
     float* sU1 = pool + L.oU1;
@@ -734,6 +764,14 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     if (tid < 32)   // sigmoid of the initial feature mask (0), or of the resumed one
         sh.phi[tid] = (tid < D) ? (p.fs_in ? sigmoidf_(p.fs_in[(size_t)t * 3 * FS + tid]) : 0.5f) : 0.0f;
     SYNC();
+    if constexpr (XC) {   // constant feature rows?  (benign race: every writer stores 0; visible after publish_abar's barrier)
+        bool same = true;
+        for (int e = tid; e < n * D; e += NT) {
+            const int r = e / D, c = e - r * D;
+            same &= __float_as_uint(sX[r * sD + c]) == __float_as_uint(sX[c]);
+        }
+        if (!same) sh.xconst = 0;
+    }
     auto publish_abar = [&]() {
 #pragma unroll
         for (int q = 0; q < SP_QMAX; ++q)
@@ -751,7 +789,14 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         SYNC();
     };
     publish_abar();
-
+    if constexpr (XC) {   // the plan promised constant feature rows for THIS X (gnnx_plan_analyze_features): anything else must fail loudly
+        if (sh.xconst == 0) {
+            const float qnan = __builtin_nanf("");
+            for (int e = tid; e < ld * ld; e += NT) p.Abar[tm.offQ + e] = qnan;
+            if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = qnan;
+            return;
+        }
+    }
     for (int iter = 0; iter < p.num_iters; ++iter) {
         const float step_size = adam_tab[2 * iter], bc2s = adam_tab[2 * iter + 1];
 
@@ -762,7 +807,17 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             float acc[DQ];
 #pragma unroll
             for (int q = 0; q < DQ; ++q) acc[q] = 0.0f;
-            sparse_gather<false, DQ>(sAb, scol, sX, sD, D, re0, re1, h, acc);
+            if constexpr (XC) {
+                float xq[DQ];
+#pragma unroll
+                for (int q = 0; q < DQ; ++q) {
+                    const float xv = sX[(EXACT || 2 * q + h < D) ? 2 * q + h : 0];   // row 0 = every row
+                    xq[q] = (EXACT || 2 * q + h < D) ? xv : 0.0f;
+                }
+                sparse_gather_const<DQ>(sAb, xq, re0, re1, acc);
+            } else {
+                sparse_gather<false, DQ>(sAb, scol, sX, sD, D, re0, re1, h, acc);
+            }
             sparse_combine<DQ>(acc, SA.rem, wsplit);
 #pragma unroll
             for (int q = 0; q < DQ; ++q) {
@@ -1184,6 +1239,38 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                             const float dl = (EXACT || (inB && c < H)) ? sdZ2[ri * sH + c] : 0.0f;
                             d2[c] = (inB && c < H) ? dl : 0.0f;
                         }
+                        if constexpr (XC) {
+                            // constant feature rows: dZ1[i] . (X[j] * phi) is the same number for every entry of the row - formed once,
+                            // with the accumulation order of the general path (bit-identical); entries of rows beyond t's neighbours
+                            // (no dZ2 part) are a stream of stores, the others continue the two sums with the dZ2 . relu(U1[j]) terms
+                            float c0 = 0.0f, c1 = 0.0f;
+#pragma unroll
+                            for (int c = 0; c < 2 * DQ; c += 2) {
+                                c0 = fmaf(dz[c], sX[c], c0);
+                                c1 = fmaf(dz[c + 1], sX[c + 1], c1);
+                            }
+                            if (!inB) {
+                                const float g = c0 + c1;
+                                for (int e = re0 + h; e < re1; e += 2) sGe[e] = g;
+                            } else {
+                                for (int e = re0 + h; e < re1; e += 4) {
+                                    const bool two = e + 2 < re1;
+                                    const int j0 = scol[e], j1 = scol[two ? e + 2 : e];
+                                    const float* u0 = sU1 + j0 * sH;
+                                    const float* u1 = sU1 + j1 * sH;
+                                    float a0 = c0, a1 = c1, b0 = c0, b1 = c1;
+#pragma unroll
+                                    for (int c = 0; c < 2 * HQ; c += 2) {
+                                        a0 = fmaf(d2[c], relu_(u0[c]), a0);
+                                        a1 = fmaf(d2[c + 1], relu_(u0[c + 1]), a1);
+                                        b0 = fmaf(d2[c], relu_(u1[c]), b0);
+                                        b1 = fmaf(d2[c + 1], relu_(u1[c + 1]), b1);
+                                    }
+                                    sGe[e] = a0 + a1;
+                                    if (two) sGe[e + 2] = b0 + b1;
+                                }
+                            }
+                        } else
                         // two entries per trip (e, e + 2: this half-lane's next two), two accumulators per entry: the loads of
                         // both entries are in flight together and no FMA chain is longer than half a row
                         for (int e = re0 + h; e < re1; e += 4) {
@@ -1358,11 +1445,12 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
 
 // second launch bound = waves per SIMD the register allocation must leave room for: two 256-thread workgroups (or six
 // 64-thread ones) per CU need 2; without it the 256-thread graph-mode build took 266 registers and ran one per CU
-template <int DQ, int HQ, bool GRAPH, int NT>
+template <int DQ, int HQ, bool GRAPH, int NT, bool XC = false>
 __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : 2) void k_sparse_resident(Params p, const int32_t* targets, const float* adam_tab) {
+    static_assert(!(XC && GRAPH), "constant-feature form: node mode only");
     __shared__ float pool[sp_pool_floats(NT)];
     __shared__ SparseFixed sh;
-    sparse_resident_body<DQ, HQ, GRAPH, NT>(p, targets[blockIdx.x], adam_tab, pool, sh, (int)threadIdx.x);
+    sparse_resident_body<DQ, HQ, GRAPH, NT, XC>(p, targets[blockIdx.x], adam_tab, pool, sh, (int)threadIdx.x);
 }
 
 // One launch for a node-mode batch of larger targets (512-thread class) and single-tile targets (64-thread code path):
@@ -1378,7 +1466,7 @@ __host__ __device__ inline int sp_mix_tiny(int D, int H, int C) {
     const int wsz = sp_model_floats(D, H, C);
     return wsz + 8 * (sp_pool_floats(64) - wsz) + 8 * sp_fixed_floats() <= sp_pool_floats(512) ? 8 : 6;
 }
-template <int DQ, int HQ>
+template <int DQ, int HQ, bool XC = false>
 __global__ __launch_bounds__(512) void k_sparse_resident_mixed(Params p, const int32_t* big_ids, int n_big, const int32_t* tiny_ids,
                                                                int n_tiny, const float* adam_tab, int per_wg, int wsz) {
     __shared__ float pool[sp_pool_floats(512)];
@@ -1386,7 +1474,7 @@ __global__ __launch_bounds__(512) void k_sparse_resident_mixed(Params p, const i
     static_assert(6 * sp_pool_floats(64) + 6 * (int)((sizeof(SparseFixed) + 3) / 4) <= sp_pool_floats(512),
                   "six single-tile slices and their SparseFixed blocks must fit the 512-thread pool whatever the model");
     if ((int)blockIdx.x < n_big) {
-        sparse_resident_body<DQ, HQ, false, 512>(p, big_ids[blockIdx.x], adam_tab, pool, sh_big, (int)threadIdx.x);
+        sparse_resident_body<DQ, HQ, false, 512, XC>(p, big_ids[blockIdx.x], adam_tab, pool, sh_big, (int)threadIdx.x);
         return;
     }
     // per_wg = sp_mix_tiny(D, H, C), wsz = sp_model_floats(D, H, C) from the host (reading a field of p here makes the compiler
@@ -1396,14 +1484,18 @@ __global__ __launch_bounds__(512) void k_sparse_resident_mixed(Params p, const i
     const int idx = ((int)blockIdx.x - n_big) * per_wg + wave;
     if (wave >= per_wg || idx >= n_tiny) return;  // whole waves leave: the 64-thread body has no workgroup barrier
     SparseFixed* shp = reinterpret_cast<SparseFixed*>(pool + wsz + per_wg * slice) + wave;
-    sparse_resident_body<DQ, HQ, false, 64>(p, tiny_ids[idx], adam_tab, pool + wsz + wave * slice, *shp, lane, pool);
+    sparse_resident_body<DQ, HQ, false, 64, XC>(p, tiny_ids[idx], adam_tab, pool + wsz + wave * slice, *shp, lane, pool);
 }
 
 // per target: directed off-diagonal non-zeros of its block of the packed adjacency and the row slots the sparse
 // resident kernel would need (-1: more than SP_LD_MAX rows) -> out[2 t], out[2 t + 1]   (gnnx_plan_analyze)
-__global__ __launch_bounds__(256) void k_count_edges(const TargetMeta* meta, const float* A, int32_t* out) {
+// X (may be null) -> xconst[t] = 1 when every feature row of the target equals its first row bit for bit (all FS columns: the
+// padding columns are zero in every row), else 0   (gnnx_plan_analyze_features: selects the constant-feature form of the kernel)
+__global__ __launch_bounds__(256) void k_count_edges(const TargetMeta* meta, const float* A, int32_t* out, const float* X = nullptr,
+                                                     int32_t* xconst = nullptr) {
     __shared__ int deg[SP_LD_MAX];
     __shared__ int part[4];
+    __shared__ int differs;
     const TargetMeta tm = meta[blockIdx.x];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool small = tm.ld <= SP_LD_MAX;
@@ -1411,8 +1503,20 @@ __global__ __launch_bounds__(256) void k_count_edges(const TargetMeta* meta, con
         if (tid == 0) {
             out[2 * blockIdx.x] = -1;
             out[2 * blockIdx.x + 1] = -1;
+            if (xconst) xconst[blockIdx.x] = 0;
         }
         return;
+    }
+    if (xconst) {
+        if (tid == 0) differs = 0;
+        __syncthreads();
+        bool same = X != nullptr;
+        if (X)
+            for (int e = tid; e < tm.n * FS; e += 256)
+                same &= __float_as_uint(X[(size_t)tm.offR * FS + e]) == __float_as_uint(X[(size_t)tm.offR * FS + (e & (FS - 1))]);
+        if (!same) differs = 1;  // benign race: every writer stores 1
+        __syncthreads();
+        if (tid == 0) xconst[blockIdx.x] = differs ? 0 : 1;
     }
     int cnt = 0;
     for (int r = wave; r < tm.n; r += 4) {

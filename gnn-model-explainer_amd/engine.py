@@ -142,6 +142,7 @@ _API = {
     "gnnx_run_resume": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper), ctypes.POINTER(_Resume)] + [ctypes.c_void_p] * 8 +
                         [ctypes.c_size_t, ctypes.c_void_p]),
     "gnnx_plan_analyze": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "gnnx_plan_analyze_features": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "gnnx_get_route": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
     "gnnx_resident_times": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
     "gnnx_pack_csr": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int32] + [ctypes.c_void_p] * 7),
@@ -389,7 +390,7 @@ class MaskOptimJob:
         """Let the plan look at the packed adjacency and route every target to the best kernel (gnnx_plan_analyze):
         the sparse on-chip-resident kernel for targets whose edge state fits one compute unit."""
         self._enter()
-        _check(self.lib, self.lib.gnnx_plan_analyze(self.handle, self.A.data_ptr(), self._stream()))
+        _check(self.lib, self.lib.gnnx_plan_analyze_features(self.handle, self.A.data_ptr(), self.X.data_ptr(), self._stream()))
         self._leave()
 
     def set_complete_graphs(self):

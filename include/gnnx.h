@@ -159,6 +159,15 @@ int gnnx_set_att_weights(gnnx_handle h, const float* att_weights);
  * the analysis of every target that ends up streaming. */
 int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream);
 
+/* gnnx_plan_analyze that also looks at the packed features X (DEVICE pointer, [R][32] rows as gnnx_run takes them; null = do not look).
+ * Node mode, the reference's encoder widths (D = 10, H = O = 20): when every target the sparse on-chip-resident kernel takes has
+ * CONSTANT feature rows (X[j] == X[0] bit for bit inside the target - ConstFeatureGen, gengraph.py:60-61, i.e. every synthetic dataset
+ * of the reference; featureless graphs in general), its launches use the constant-feature form: Abar . X (models.py:70) and the X part of
+ * dL/dAbar need no gathers.  Same products in the same order as the general form: results are bit-identical.  The form checks the X
+ * handed to gnnx_run / gnnx_run_resume again; a target whose rows are not constant there comes back NaN (it fails loudly).
+ * GNNX_XCONST=0 keeps the general form. */
+int gnnx_plan_analyze_features(gnnx_handle h, const float* A, const float* X, void* stream);
+
 /* The kernel every target is routed to (host array of num_targets entries): 0 = dense streaming kernels, 1..3 = dense
  * on-chip-resident kernel of that many 32-row blocks, 4 / 5 / 6 = sparse on-chip-resident kernel in its 1024- / 256- / 64-thread size
  * class (n <= 512 / 128 / 32), 7 = k_sparse_large (node mode, n <= 16383), 8 = sparse on-chip-resident kernel, 512-thread class
