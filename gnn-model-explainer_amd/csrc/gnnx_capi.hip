@@ -231,6 +231,10 @@ struct gnnx_plan_s {
     unsigned short* d_csr_row = nullptr;   // row of every directed entry
     long long* d_csr_off = nullptr;    // [2 T]: offsets of target t into the two arrays
     float* d_adam = nullptr;         // per-iteration Adam scalars for the resident kernel
+    DeadBlock* d_dead = nullptr;     // work list of k_dead_entries (loss logging on the edge-sparse kernels); rebuilt after a new split
+    int n_dead = 0;
+    uint32_t* trace_gates = nullptr; // gnnx_set_trace: caller's device buffers, filled by the runs that follow (null: no trace)
+    int32_t* trace_pool = nullptr;
     int32_t* d_rowcnt = nullptr;     // [R] scratch of gnnx_edge_counts
     int64_t* d_raw_off = nullptr;    // [T] float offset of target t's n x n block in the unpadded RNG stream (gnnx_scatter_masks)
     int64_t total_raw = 0;
@@ -358,6 +362,11 @@ static int build_split(gnnx_handle h) {
         h->gexec = nullptr;
     }
     h->d_res = h->d_big = nullptr;   // (they point into split_block, which the commit below replaces)
+    if (h->d_dead) {
+        (void)pool_free(h->d_dead);
+        h->d_dead = nullptr;
+        h->n_dead = 0;
+    }
     for (int k = 0; k < N_SPC; ++k) h->d_sp[k] = nullptr;
     h->d_conv_big = nullptr;
     h->d_mask_big = nullptr;
@@ -576,6 +585,7 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
     }
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->d_nnz) (void)pool_free(h->d_nnz);
+    if (h->d_dead) (void)pool_free(h->d_dead);
     if (h->d_rowdeg) (void)pool_free(h->d_rowdeg);
     if (h->d_csr_rowptr) (void)pool_free(h->d_csr_rowptr);
     if (h->d_csr_col) (void)pool_free(h->d_csr_col);
@@ -784,8 +794,13 @@ static int init_stream_state(gnnx_handle h, const Params& p, hipStream_t s) {
 static bool exact_shape(gnnx_handle h, int D) { return h->prob.D == D && h->prob.H == 20 && h->prob.O == 20; }
 
 template <int NT>
-static void launch_sparse_nt(gnnx_handle h, const Params& p, const int32_t* ids, int cnt, const float* adam_tab, hipStream_t s) {
+static void launch_sparse_nt(gnnx_handle h, const Params& p, const int32_t* ids, int cnt, const float* adam_tab, hipStream_t s, bool log) {
     const dim3 grid(cnt), block(NT);
+    if (log) {   // the logging form (loss scalars + decision trace): exact shapes only, checked by the caller
+        if (h->prob.graph_mode) hipLaunchKernelGGL((k_sparse_resident<7, 10, true, NT, false, true>), grid, block, 0, s, p, ids, adam_tab);
+        else hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT, false, true>), grid, block, 0, s, p, ids, adam_tab);
+        return;
+    }
     if (h->prob.graph_mode) {
         if (exact_shape(h, 14)) hipLaunchKernelGGL((k_sparse_resident<7, 10, true, NT>), grid, block, 0, s, p, ids, adam_tab);
         else hipLaunchKernelGGL((k_sparse_resident<16, 16, true, NT>), grid, block, 0, s, p, ids, adam_tab);
@@ -795,7 +810,7 @@ static void launch_sparse_nt(gnnx_handle h, const Params& p, const int32_t* ids,
         else hipLaunchKernelGGL((k_sparse_resident<16, 16, false, NT>), grid, block, 0, s, p, ids, adam_tab);
     }
 }
-static void launch_sparse(gnnx_handle h, const Params& p, int cls, const float* adam_tab, hipStream_t s) {
+static void launch_sparse(gnnx_handle h, const Params& p, int cls, const float* adam_tab, hipStream_t s, bool log = false) {
     if (cls == SPC_LARGE) {  // node-mode targets beyond the LDS-resident classes: row arrays in HBM / L2 (gnnx_sparse_large.hpp)
         const dim3 grid(h->n_sp[cls]), block(SPL_THREADS);
         if (exact_shape(h, 10))
@@ -806,10 +821,35 @@ static void launch_sparse(gnnx_handle h, const Params& p, int cls, const float* 
                                h->d_csr_col, h->d_csr_row, h->d_csr_off, h->d_nnz + 2 * h->prob.num_targets);
         return;
     }
-    if (cls == SPC_512) launch_sparse_nt<512>(h, p, h->d_sp[cls], h->n_sp[cls], adam_tab, s);
-    else if (cls == 0) launch_sparse_nt<1024>(h, p, h->d_sp[0], h->n_sp[0], adam_tab, s);
-    else if (cls == 1) launch_sparse_nt<256>(h, p, h->d_sp[1], h->n_sp[1], adam_tab, s);
-    else launch_sparse_nt<64>(h, p, h->d_sp[2], h->n_sp[2], adam_tab, s);
+    if (cls == SPC_512) launch_sparse_nt<512>(h, p, h->d_sp[cls], h->n_sp[cls], adam_tab, s, log);
+    else if (cls == 0) launch_sparse_nt<1024>(h, p, h->d_sp[0], h->n_sp[0], adam_tab, s, log);
+    else if (cls == 1) launch_sparse_nt<256>(h, p, h->d_sp[1], h->n_sp[1], adam_tab, s, log);
+    else launch_sparse_nt<64>(h, p, h->d_sp[2], h->n_sp[2], adam_tab, s, log);
+}
+
+extern "C" int gnnx_set_trace(gnnx_handle h, uint32_t* gates, int32_t* pool_rows) {
+    if (!h) return fail("null argument");
+    h->trace_gates = gates;
+    h->trace_pool = pool_rows;
+    return 0;
+}
+
+// work list of k_dead_entries: every ld x ld block of the edge-sparse resident targets, DEAD_THREADS x DEAD_Q entries per workgroup
+static int build_dead_list(gnnx_handle h) {
+    if (h->d_dead) return 0;
+    std::vector<DeadBlock> blocks;
+    const long long per = (long long)DEAD_THREADS * DEAD_Q;
+    for (int t = 0; t < h->prob.num_targets; ++t) {
+        const int c = h->cat[t];
+        if (!(c == CAT_SPARSE || c == CAT_SPARSE + 1 || c == CAT_SPARSE + 2 || c == CAT_SPARSE + SPC_512)) continue;
+        const long long q = (long long)h->meta[t].ld * h->meta[t].ld;
+        for (long long f = 0; f < q; f += per) blocks.push_back(DeadBlock{t, 0, f});
+    }
+    h->n_dead = (int)blocks.size();
+    if (!h->n_dead) return 0;
+    HIPCK(pool_malloc(&h->d_dead, sizeof(DeadBlock) * blocks.size()));
+    HIPCK(upload_sync(h->d_dead, blocks.data(), sizeof(DeadBlock) * blocks.size()));
+    return 0;
 }
 
 extern "C" int gnnx_run(gnnx_handle h, const gnnx_hyper* hy, const float* A, const float* X, const float* yhat,
@@ -933,13 +973,24 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
     if (rs.v_out) p.vM = rs.v_out;
     // hybrid split: small targets (<= res_nbmax row blocks) -> on-chip-resident kernels on side streams (overlap with the
     // streaming launches of the other targets); loss logging is a streaming-path feature
-    const bool resident = hy->use_resident && (h->n_res > 0 || h->n_sparse() > 0) && !lossp;
+    // Logging runs (loss scalars, decision trace) stay on the edge-sparse resident kernel - its LOG form plus k_dead_entries for the
+    // entries off the edges - when EVERY target of the plan is routed there and the encoder has the reference's widths (the usual case:
+    // explainer_main.py --explain-node / the default node list, explain.py:149-159); any other plan logs on the dense streaming kernels.
+    const bool want_trace = h->trace_gates || h->trace_pool;
+    const bool log_resident = (lossp || want_trace) && hy->use_resident && h->n_res == 0 && h->n_big == 0 && h->n_sp[SPC_LARGE] == 0 &&
+                              h->n_sparse() > 0 && exact_shape(h, h->prob.graph_mode ? 14 : 10);
+    if (want_trace && !log_resident)
+        return fail("gnnx_set_trace: the decision trace is recorded by the sparse on-chip-resident kernel only (every target routed there, "
+                    "D = 10 / 14, H = O = 20, use_resident = 1)");
+    p.trace_gates = h->trace_gates;
+    p.trace_pool = h->trace_pool;
+    p.trace_rows = h->R;
+    const bool resident = hy->use_resident && (h->n_res > 0 || h->n_sparse() > 0) && (!lossp || log_resident);
     const Tables tb = (resident && h->n_big > 0) ? tables_big(h) : tables_all(h);
     const bool streaming = !resident || h->n_big > 0;
     if (streaming)
         if (int rc = init_stream_state(h, p, s)) return rc;
     if (resident) {
-        HIPCK(hipEventRecord(h->ev_in, s));
         if (!h->d_adam || hy->lr_schedule || h->adam_first != rs.first_iter || std::memcmp(&h->adam_for, hy, sizeof(gnnx_hyper)) != 0) {
             if (h->d_adam) {
                 HIPCK(hipStreamSynchronize(s));   // an earlier run of this plan may still be reading the table (its side lanes join `s`)
@@ -953,6 +1004,17 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
             h->adam_for = *hy;
             h->adam_first = rs.first_iter;
         }
+        if (log_resident) {
+            const size_t T = (size_t)h->prob.num_targets;
+            if (p.trace_gates) HIPCK(hipMemsetAsync(p.trace_gates, 0, sizeof(uint32_t) * 2 * (size_t)h->R * hy->num_iters, s));
+            if (p.trace_pool) HIPCK(hipMemsetAsync(p.trace_pool, 0xff, sizeof(int32_t) * 96 * T * hy->num_iters, s));
+            if (lossp) {   // the entries off the edges first (they add to the size / entropy columns; the resident launch completes the rows)
+                HIPCK(hipMemsetAsync(lossp, 0, sizeof(float) * T * hy->num_iters * NLOSS, s));
+                if (int rc = build_dead_list(h)) return rc;
+                if (h->n_dead) hipLaunchKernelGGL(k_dead_entries, dim3(h->n_dead), dim3(DEAD_THREADS), 0, s, p, h->d_dead, h->d_adam);
+            }
+        }
+        HIPCK(hipEventRecord(h->ev_in, s));
         // Launch order: sparse resident kernel (gnnx_plan_analyze), largest size class FIRST - its workgroups need a whole
         // CU (1024 threads x 128 VGPRs), so they must be placed before the small workgroups of the other launches spread
         // over every CU (measured on syn1: 21.5 -> 13.4 ms) - then the dense resident kernels.  Every group has its own
@@ -991,7 +1053,10 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
             if (mixed && k == SPC_512) {
                 const int per_wg = sp_mix_tiny(h->prob.D, h->prob.H, h->prob.C);   // single-tile targets per workgroup
                 const dim3 grid(h->n_sp[SPC_512] + (h->n_sp[2] + per_wg - 1) / per_wg), block(512);
-                if (exact_shape(h, 10) && h->xconst)
+                if (log_resident)
+                    hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, false, true>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
+                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C));
+                else if (exact_shape(h, 10) && h->xconst)
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, true>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
                                        h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C));
                 else if (exact_shape(h, 10))
@@ -1001,7 +1066,7 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
                     hipLaunchKernelGGL((k_sparse_resident_mixed<16, 16>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
                                        h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C));
             } else {
-                launch_sparse(h, p, k, h->d_adam, ss);
+                launch_sparse(h, p, k, h->d_adam, ss, log_resident);
             }
             HIPCK(hipEventRecord(h->ev_out[g], ss));
         }

@@ -102,6 +102,11 @@ struct Params {
     float* m_out;
     float* v_out;
     float* fs_out;
+    // decision trace (gnnx_set_trace; the LOG form of the sparse resident kernel): which side of every ReLU gate that reaches the loss
+    // each iteration's forward took, and the rows the graph-mode max-pools picked.  Null = not recorded.
+    uint32_t* trace_gates;  // [num_iters][R][2]: bit c of word (iter, row, l) = U_{l+1}[row][c] > 0 (models.py:241, 251); rows outside the layer's row set: 0
+    int32_t* trace_pool;    // graph mode [T][num_iters][96]: arg-max row of pooled column (layer, c) (models.py:283, 291, 300)
+    int64_t trace_rows;     // R
     int32_t bn;
     int32_t D, H, O, C;
     int32_t graph_mode;

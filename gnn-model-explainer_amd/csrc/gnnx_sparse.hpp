@@ -116,6 +116,7 @@ struct SparseFixed {
     int set_rows[2], set_slots[2];
     int set_chunk[2];  // entries per row slot of the set: the smallest of {4, 8, 16} (8, 16 for set A) whose slots fit the class
     int erow[96];  // graph mode: arg-max row of every pooled column
+    float lsum[SP_THREADS / 64][4];  // LOG form: per-wave partial sums of the logged size / entropy / Laplacian terms over the owned edges
 };
 
 // every lane of a wave has finished its LDS accesses before any lane continues (LDS operations of one wave
@@ -386,7 +387,10 @@ __device__ __forceinline__ void sparse_combine(float (&acc)[NQ], int rem, int ws
 // XC: every feature row of the target equals its row 0 bit for bit (decided per plan by gnnx_plan_analyze_features, verified here):
 // layer 1 and the X part of dL/dAbar then need no gathers (sparse_gather_const); a compile-time form because a run-time test inside
 // the phases keeps the operands of both forms alive across them (the 512-thread class sits at 256 VGPRs).  Node mode, exact shapes.
-template <int DQ, int HQ, bool GRAPH, int NT, bool XC = false>
+// LOG: the logging form - per iteration the loss scalars of explain.py:808-819 (prediction, and the size / entropy / Laplacian sums
+// over the entries on EDGES; the entries off the edges follow a closed scalar recursion each and are added by k_dead_entries) and the
+// decision trace (Params::trace_gates / trace_pool).  A separate instantiation: the hot form carries none of it.
+template <int DQ, int HQ, bool GRAPH, int NT, bool XC = false, bool LOG = false>
 __device__ __forceinline__ void sparse_resident_body(const Params p, int t, const float* adam_tab, float* pool, SparseFixed& sh,
                                                      int tid, float* shared_w = nullptr) {
     constexpr int SCAN = (sp_ld_max(NT) + 63) / 64;  // rows per lane in the setup prefix scans
@@ -797,8 +801,16 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             return;
         }
     }
+    // LOG form: sign bits of a row of normalised pre-activations (the ReLU gates, models.py:241, 251) -> trace word (iter, row, layer)
+    auto trace_row = [&](int iter, int layer, int r, const float* urow) {
+        unsigned bits = 0u;
+        for (int c = 0; c < H; ++c) bits |= (urow[c] > 0.0f ? 1u : 0u) << c;
+        p.trace_gates[((size_t)iter * (size_t)p.trace_rows + (size_t)(tm.offR + r)) * 2 + layer] = bits;
+    };
+    float* Lrow = nullptr;   // LOG form: this target's row of the loss array for the current iteration
     for (int iter = 0; iter < p.num_iters; ++iter) {
         const float step_size = adam_tab[2 * iter], bc2s = adam_tab[2 * iter + 1];
+        if constexpr (LOG) Lrow = p.loss ? p.loss + ((size_t)t * p.num_iters + iter) * NLOSS : nullptr;
 
         // ======== layer 1: Zraw = Abar . X (kept in registers for the feature-mask gradient), U1 ========
         if (SA.wave_active) {
@@ -828,6 +840,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             sparse_forward_rowlocal<DQ>(acc, sW1, sh.bias[0], D, H, li, h, first, sU1 + r * sH, sRn1 + r);
         }
         SYNC();
+        if constexpr (LOG)
+            if (p.trace_gates && SA.wave_active && SA.first && h == 0) trace_row(iter, 0, SA.row, sU1 + SA.row * sH);
         // ======== layer 2: U2 ========
         if (SB.wave_active) {
             const bool first = SB.first;
@@ -842,6 +856,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             sparse_forward_rowlocal<HQ>(acc, sW2, sh.bias[1], H, H, li, h, first, sU2 + r * sH, sRn2 + r);
         }
         SYNC_B();
+        if constexpr (LOG)   // (node mode with the fused wave-0 chain: the rows of set B all sit in wave 0, which has just synchronised)
+            if (p.trace_gates && SB.wave_active && SB.first && h == 0) trace_row(iter, 1, SB.row, sU2 + SB.row * sH);
         if constexpr (GRAPH) {
         // ======== graph mode: layer 3 in full (no ReLU), U3 ========
         if (SA.wave_active) {
@@ -879,6 +895,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 }
                 sh.e[col] = best;
                 sh.erow[col] = barg;
+                if constexpr (LOG)
+                    if (p.trace_pool) p.trace_pool[((size_t)t * p.num_iters + iter) * 96 + col] = (c < ((l == 2) ? O : H)) ? barg : -1;
             }
         }
         SYNC();
@@ -905,6 +923,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 sum += row_shl<1>(sum);
                 sum = bcast_first(sum);
                 if (lane < CMAX) sh.g[lane] = (lane < C) ? ex / sum - ((lane == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
+                if constexpr (LOG)
+                    if (Lrow && lane == tm.y_gt) Lrow[0] = -logf(ex / sum);   // explain.py:750-753
             }
             wave_sync();
 #pragma unroll
@@ -1027,6 +1047,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
 #pragma unroll
                 for (int cc = 0; cc < CH; ++cc) {
                     const float g = (cc < C) ? zl[cc] / sum - ((cc == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
+                    if constexpr (LOG)
+                        if (Lrow && lane == 0 && cc == tm.y_gt) Lrow[0] = -logf(zl[cc] / sum);   // explain.py:750-753
                     dE1 = fmaf(wp[0][cc], g, dE1);
                     dE2 = fmaf(wp[1][cc], g, dE2);
                     dE3 = fmaf(wp[2][cc], g, dE3);
@@ -1117,6 +1139,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 sum += row_shl<1>(sum);
                 sum = bcast_first(sum);
                 if (lane < CMAX) sh.g[lane] = (lane < C) ? ex / sum - ((lane == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
+                if constexpr (LOG)
+                    if (Lrow && lane == tm.y_gt) Lrow[0] = -logf(ex / sum);   // explain.py:750-753
             }
             wave_sync();
 #pragma unroll
@@ -1324,12 +1348,20 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             sh.dfp[tid] = s;
         }
         // ======== per owned edge: G_ij + G_ji, regulariser gradients, Adam on both directed entries ========
+        float ls_size = 0.0f, ls_ent = 0.0f, ls_lap = 0.0f;   // LOG form: this thread's part of the logged sums (its owned edges, both directions)
         auto edge_phase = [&](auto ADAMc) {
         constexpr bool ADAM = decltype(ADAMc)::value;
 #pragma unroll
         for (int q = 0; q < SP_QMAX; ++q)
             if (tid + NT * q < eup) {
                 const int i = (int)(npk[q] & 0xffffu), j = (int)(npk[q] >> 16);
+                if constexpr (LOG) {   // explain.py:755-770, 780-793 on the current iterate (before its update)
+                    const float Sa = Sij[q], Sb = Sji[q];
+                    ls_size += Sa + Sb;
+                    ls_ent += (-Sa * logf(Sa) - (1.0f - Sa) * logf(1.0f - Sa)) + (-Sb * logf(Sb) - (1.0f - Sb) * logf(1.0f - Sb));
+                    const float dyl = sYhat[i] - sYhat[j];
+                    ls_lap += wgt[q] * (0.5f * (Sa + Sb)) * dyl * dyl;   // yhat^T (D - Abar) yhat = sum over undirected edges of Abar_ij (yhat_i - yhat_j)^2
+                }
                 // compile-time trip counts: all loads of an edge are issued before the first use; columns beyond
                 // D / H are read from the row padding / the next row and dropped by the select
                 float G0 = 0.0f, G1 = 0.0f;
@@ -1393,7 +1425,38 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             }
         };
         if (p.opt == 0) edge_phase(std::true_type{}); else edge_phase(std::false_type{});   // one branch around the loop, not one per update
+        if constexpr (LOG) {   // wave sums in lane order, then (after the barrier) the waves in order: a fixed summation order
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                ls_size += __shfl_xor(ls_size, o);
+                ls_ent += __shfl_xor(ls_ent, o);
+                ls_lap += __shfl_xor(ls_lap, o);
+            }
+            if (lane == 0) {
+                sh.lsum[wave][0] = ls_size;
+                sh.lsum[wave][1] = ls_ent;
+                sh.lsum[wave][2] = ls_lap;
+            }
+        }
         SYNC();  // dfp complete; every reader of sAb / sArt of this iteration is done
+        if constexpr (LOG) {
+            if (Lrow && wave == 0) {   // the entries off the edges were added to [1] and [3] by k_dead_entries before this launch
+                const float phs = sum_lanes_0_31((lane < D) ? sh.phi[lane] : 0.0f);   // (phi of this iteration: its update below is behind the wave sync)
+                float a = 0.0f, b = 0.0f, c = 0.0f;
+                for (int w = 0; w < NW; ++w) {
+                    a += sh.lsum[w][0];
+                    b += sh.lsum[w][1];
+                    c += sh.lsum[w][2];
+                }
+                if (lane == 0) {
+                    Lrow[1] += p.c_size * a;
+                    Lrow[2] = GRAPH ? 0.0f : p.c_lap * c * inv_n2;
+                    Lrow[3] += p.c_ent * b * inv_n2;
+                    Lrow[4] = p.c_feat_size * phs / (float)D;
+                }
+                wave_sync();
+            }
+        }
         if (tid < D) {  // feature mask
             const float ph = sh.phi[tid];
             const float gf = (sh.dfp[tid] + p.c_feat_size / (float)D) * ph * (1.0f - ph);
@@ -1445,12 +1508,12 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
 
 // second launch bound = waves per SIMD the register allocation must leave room for: two 256-thread workgroups (or six
 // 64-thread ones) per CU need 2; without it the 256-thread graph-mode build took 266 registers and ran one per CU
-template <int DQ, int HQ, bool GRAPH, int NT, bool XC = false>
+template <int DQ, int HQ, bool GRAPH, int NT, bool XC = false, bool LOG = false>
 __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : 2) void k_sparse_resident(Params p, const int32_t* targets, const float* adam_tab) {
     static_assert(!(XC && GRAPH), "constant-feature form: node mode only");
     __shared__ float pool[sp_pool_floats(NT)];
     __shared__ SparseFixed sh;
-    sparse_resident_body<DQ, HQ, GRAPH, NT, XC>(p, targets[blockIdx.x], adam_tab, pool, sh, (int)threadIdx.x);
+    sparse_resident_body<DQ, HQ, GRAPH, NT, XC, LOG>(p, targets[blockIdx.x], adam_tab, pool, sh, (int)threadIdx.x);
 }
 
 // One launch for a node-mode batch of larger targets (512-thread class) and single-tile targets (64-thread code path):
@@ -1466,7 +1529,7 @@ __host__ __device__ inline int sp_mix_tiny(int D, int H, int C) {
     const int wsz = sp_model_floats(D, H, C);
     return wsz + 8 * (sp_pool_floats(64) - wsz) + 8 * sp_fixed_floats() <= sp_pool_floats(512) ? 8 : 6;
 }
-template <int DQ, int HQ, bool XC = false>
+template <int DQ, int HQ, bool XC = false, bool LOG = false>
 __global__ __launch_bounds__(512) void k_sparse_resident_mixed(Params p, const int32_t* big_ids, int n_big, const int32_t* tiny_ids,
                                                                int n_tiny, const float* adam_tab, int per_wg, int wsz) {
     __shared__ float pool[sp_pool_floats(512)];
@@ -1474,7 +1537,7 @@ __global__ __launch_bounds__(512) void k_sparse_resident_mixed(Params p, const i
     static_assert(6 * sp_pool_floats(64) + 6 * (int)((sizeof(SparseFixed) + 3) / 4) <= sp_pool_floats(512),
                   "six single-tile slices and their SparseFixed blocks must fit the 512-thread pool whatever the model");
     if ((int)blockIdx.x < n_big) {
-        sparse_resident_body<DQ, HQ, false, 512, XC>(p, big_ids[blockIdx.x], adam_tab, pool, sh_big, (int)threadIdx.x);
+        sparse_resident_body<DQ, HQ, false, 512, XC, LOG>(p, big_ids[blockIdx.x], adam_tab, pool, sh_big, (int)threadIdx.x);
         return;
     }
     // per_wg = sp_mix_tiny(D, H, C), wsz = sp_model_floats(D, H, C) from the host (reading a field of p here makes the compiler
@@ -1484,7 +1547,7 @@ __global__ __launch_bounds__(512) void k_sparse_resident_mixed(Params p, const i
     const int idx = ((int)blockIdx.x - n_big) * per_wg + wave;
     if (wave >= per_wg || idx >= n_tiny) return;  // whole waves leave: the 64-thread body has no workgroup barrier
     SparseFixed* shp = reinterpret_cast<SparseFixed*>(pool + wsz + per_wg * slice) + wave;
-    sparse_resident_body<DQ, HQ, false, 64, XC>(p, tiny_ids[idx], adam_tab, pool + wsz + wave * slice, *shp, lane, pool);
+    sparse_resident_body<DQ, HQ, false, 64, XC, LOG>(p, tiny_ids[idx], adam_tab, pool + wsz + wave * slice, *shp, lane, pool);
 }
 
 // per target: directed off-diagonal non-zeros of its block of the packed adjacency and the row slots the sparse
@@ -1551,6 +1614,81 @@ __global__ __launch_bounds__(256) void k_count_edges(const TargetMeta* meta, con
         out[2 * blockIdx.x] = part[0] + part[1] + part[2] + part[3];
         out[2 * blockIdx.x + 1] = pos;
     }
+}
+
+// The mask entries OFF the edges of a target (the diagonal included; explain.py:645-663 initialises all n x n of them) reach no output of
+// the reference - Abar = A (.) sym(sigma(M)) is zero there - but its LOGGED size and entropy terms sum over all n^2 entries
+// (explain.py:755-770), and torch.optim keeps updating them.  Each follows a closed scalar recursion through the optimiser:
+//     g = (c_size - c_ent M / n^2) sigma'(M)          (no prediction, Laplacian or feature term reaches it).
+// This kernel runs those recursions for the targets of the edge-sparse kernels when the loss is logged (gnnx_hyper.record_loss): one
+// thread per DEAD_Q entries, state in registers for all iterations, per iteration the workgroup's sums of sigma(M) and of the entropy are
+// added to loss[t][iter][1] and [3] (float atomics: logging only, like k_mask's), and at the end M (and the moments, if the caller
+// wants the optimiser state back) is written for these entries - so M, like the loss, is what the dense kernels would have produced.
+// grid: dead_blocks[k] = (target, first entry of its ld x ld block), DEAD_THREADS x DEAD_Q entries per workgroup.
+constexpr int DEAD_THREADS = 256, DEAD_Q = 8;
+struct DeadBlock { int32_t t; int32_t pad; int64_t first; };
+__global__ __launch_bounds__(DEAD_THREADS) void k_dead_entries(Params p, const DeadBlock* blocks, const float* adam_tab) {
+    __shared__ float part[DEAD_THREADS / 64][2];
+    const DeadBlock db = blocks[blockIdx.x];
+    const TargetMeta tm = p.meta[db.t];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n = tm.n, ld = tm.ld;
+    const float inv_n2 = 1.0f / ((float)n * (float)n);
+    float M[DEAD_Q], m[DEAD_Q], v[DEAD_Q];
+    bool dead[DEAD_Q];
+    size_t at[DEAD_Q];
+#pragma unroll
+    for (int q = 0; q < DEAD_Q; ++q) {
+        const long long e = db.first + (long long)q * DEAD_THREADS + tid;
+        const int r = (int)(e / ld), c = (int)(e - (long long)r * ld);
+        at[q] = (size_t)tm.offQ + (size_t)(e < (long long)ld * ld ? e : 0);
+        dead[q] = e < (long long)ld * ld && r < n && c < n && (r == c || p.A[at[q]] == 0.0f);
+        M[q] = dead[q] ? p.M[at[q]] : 0.0f;
+        m[q] = (dead[q] && p.m_in) ? p.m_in[at[q]] : 0.0f;
+        v[q] = (dead[q] && p.v_in) ? p.v_in[at[q]] : 0.0f;
+    }
+    for (int iter = 0; iter < p.num_iters; ++iter) {
+        const float step_size = adam_tab[2 * iter], bc2s = adam_tab[2 * iter + 1];
+        float s_size = 0.0f, s_ent = 0.0f;
+#pragma unroll
+        for (int q = 0; q < DEAD_Q; ++q) {
+            const float S = sigmoidf_(M[q]);
+            s_size += dead[q] ? S : 0.0f;
+            s_ent += dead[q] ? -S * logf(S) - (1.0f - S) * logf(1.0f - S) : 0.0f;
+            const float g = (p.c_size - p.c_ent * M[q] * inv_n2) * S * (1.0f - S);
+            adam_update(M[q], m[q], v[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
+        }
+        if (p.loss) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                s_size += __shfl_xor(s_size, o);
+                s_ent += __shfl_xor(s_ent, o);
+            }
+            if (lane == 0) {
+                part[wave][0] = s_size;
+                part[wave][1] = s_ent;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                float a = 0.0f, b = 0.0f;
+                for (int w = 0; w < DEAD_THREADS / 64; ++w) {
+                    a += part[w][0];
+                    b += part[w][1];
+                }
+                float* L = p.loss + ((size_t)db.t * p.num_iters + iter) * NLOSS;
+                atomicAdd(&L[1], p.c_size * a);
+                atomicAdd(&L[3], p.c_ent * b * inv_n2);
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < DEAD_Q; ++q)
+        if (dead[q]) {
+            p.M[at[q]] = M[q];
+            if (p.m_out) p.m_out[at[q]] = m[q];
+            if (p.v_out) p.v_out[at[q]] = v[q];
+        }
 }
 
 }  // namespace gnnx

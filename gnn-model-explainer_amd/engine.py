@@ -145,6 +145,7 @@ _API = {
     "gnnx_plan_analyze_features": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "gnnx_get_route": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
     "gnnx_resident_times": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
+    "gnnx_set_trace": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "gnnx_pack_csr": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int32] + [ctypes.c_void_p] * 7),
     "gnnx_forward": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_void_p] * 7 + [ctypes.c_size_t, ctypes.c_void_p]),
     "gnnx_time_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper), ctypes.c_int32, ctypes.c_int32] +
@@ -645,10 +646,17 @@ class MaskOptimJob:
                 cur.wait_stream(self.stream)
 
     # -- the hot loop --------------------------------------------------------------------------
-    def launch(self, hyper: Hyper, state: Optional[AdamState] = None, keep_state=False):
+    def launch(self, hyper: Hyper, state: Optional[AdamState] = None, keep_state=False, trace=False):
         """Enqueue the whole optimisation on the current stream (asynchronous).  `state`: continue from an optimiser state
         (gnnx_run_resume: self.M holds the mask after state.first_iter steps); `keep_state`: also hand the state after the run
-        back (self.state_out, an AdamState whose first_iter counts the steps taken so far)."""
+        back (self.state_out, an AdamState whose first_iter counts the steps taken so far); `trace`: record the decision trace of
+        every iteration (gnnx_set_trace; fetch_trace())."""
+        if trace:
+            i32 = dict(dtype=torch.int32, device=self.device)
+            self.trace_gates = torch.empty(hyper.num_iters, self.R, 2, **i32)
+            self.trace_pool = torch.empty(self.T, hyper.num_iters, 96, **i32) if self.graph_mode else None
+            _check(self.lib, self.lib.gnnx_set_trace(self.handle, self.trace_gates.data_ptr(),
+                                                     None if self.trace_pool is None else self.trace_pool.data_ptr()))
         if hyper.record_loss and (self.loss is None or self.loss.shape[1] != hyper.num_iters):
             self.loss = torch.empty(self.T, hyper.num_iters, LOSS_TERMS, dtype=torch.float32, device=self.device)
         hy = hyper.c()
@@ -671,6 +679,20 @@ class MaskOptimJob:
                                                   self.Abar.data_ptr(), self.fmask.data_ptr(), loss_ptr, self.ws.data_ptr(),
                                                   self.ws_bytes, self._stream()))
         self._leave()
+        if trace:
+            _check(self.lib, self.lib.gnnx_set_trace(self.handle, None, None))
+
+    def fetch_trace(self):
+        """The decision trace of the last launch(trace=True): (gates, pool).  gates[k] = uint32 [iters, n_k, 2] for target k - bit c of
+        word (iter, row, l) says that the forward of that iteration found U_{l+1}[row][c] > 0 (the ReLU gates of models.py:241, 251;
+        rows outside the layer's row set - beyond two hops / one hop of the target in node mode - read 0); pool = int32
+        [T, iters, 3, 32]: the row every graph-mode max-pool picked (models.py:283, 291, 300; -1 = no such column), or None."""
+        if self.device.type == _DEVICE_TYPE:
+            torch.cuda.synchronize(self.device)
+        g = self.trace_gates.cpu().numpy().view(np.uint32)
+        gates = [g[:, o:o + n, :].copy() for o, n in zip(self.offR, self.n)]
+        pool = None if self.trace_pool is None else self.trace_pool.cpu().numpy().reshape(self.T, -1, 3, 32)
+        return gates, pool
 
     def set_state_edges(self, first_iter, mask_rc, m_rc, v_rc, feat=None, feat_m=None, feat_v=None) -> AdamState:
         """Load an optimiser state given on the EDGES of the batch (the layout of fetch_edges: [E, 2] = entry (r, c), entry (c, r)

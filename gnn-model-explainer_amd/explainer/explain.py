@@ -468,9 +468,9 @@ class Explainer:
             masked_adj = self.explain_batch(node_indices=[node_idx], graph_idx=graph_idx,
                                             record_loss=self.print_training, unconstrained=unconstrained)[0]
         if self.print_training and self.last_result.loss is not None:
-            tr = self.last_result.loss[0]
-            for epoch in (0, len(tr) - 1):
-                print("epoch: ", epoch, "; loss: ", float(tr[epoch, :5].sum()))
+            tr = self.last_result.loss[0]        # logged by the kernel the optimisation ran on (the resident kernel's logging form)
+            for epoch in range(len(tr)):          # explain.py:149-159 prints every epoch
+                print("epoch: ", epoch, "; loss: ", float(tr[epoch, :5].sum()), "; pred loss: ", float(tr[epoch, 0]))
         print("finished training in ", self.last_time)
         fname = self._save(masked_adj, node_idx)
         print("Saved adjacency matrix to ", fname)

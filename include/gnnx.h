@@ -68,7 +68,9 @@ typedef struct {
     int32_t record_loss; /* 1: fill loss[T][num_iters][GNNX_LOSS_TERMS] (explain.py:808-819 scalars) */
     int32_t use_graph;   /* 1: capture the launch sequence once into a hipGraph and replay it */
     int32_t use_resident; /* 1: targets may take the on-chip-resident kernels gnnx_plan_analyze routed them to (gnnx_get_route);
-                           * 0: every target runs on the dense streaming kernels.  Ignored (= 0) with record_loss. */
+                           * 0: every target runs on the dense streaming kernels.  With record_loss the resident path is taken only when
+                           * EVERY target is routed to the sparse on-chip-resident kernel and the encoder has the reference's widths
+                           * (its logging form + k_dead_entries for the entries off the edges); other plans log on the streaming kernels. */
     /* The other optimisers / LR schedulers the reference's build_optimizer can return (utils/train_utils.py:7-22):
      *   opt          0 = Adam (lr, beta1, beta2, eps above), 1 = SGD(momentum), 2 = RMSprop(alpha, eps), 3 = Adagrad(eps) - torch
      *                defaults otherwise (no weight decay, dampening 0, not centered, lr_decay 0);
@@ -173,6 +175,20 @@ int gnnx_plan_analyze_features(gnnx_handle h, const float* A, const float* X, vo
  * class (n <= 512 / 128 / 32), 7 = k_sparse_large (node mode, n <= 16383), 8 = sparse on-chip-resident kernel, 512-thread class
  * (node mode, n <= 512, at most 256 row slots within two hops of the target). */
 int gnnx_get_route(gnnx_handle h, int32_t* route);
+
+/* Decision trace (parity instrumentation of the boundary; tests/test_decision_parity.py): device buffers the runs that follow fill, or
+ * null / null to switch it off.  The reference's trajectory is piecewise smooth: between two iterations at which a ReLU gate
+ * (models.py:241, 251) or a max-pool (models.py:283-300) changes sides it is a continuous function of its state, and an implementation
+ * that takes the SAME side of every gate stays within round-off of it.  The trace records the side taken:
+ *   gates     [num_iters][R][2] uint32, R = rows of the row arrays (gnnx_get_layout: target t owns rows offR[t] .. offR[t] + n_t):
+ *             bit c of word (iter, row, l) = U_{l+1}[row][c] > 0 in the forward of that iteration; rows outside the row set of the
+ *             layer (node mode: beyond two hops of the target for l = 0, beyond its neighbours for l = 1 - their activations reach
+ *             no output) read 0;
+ *   pool_rows [T][num_iters][96] int32 (graph mode, else null): the row the max-pool of pooled column (layer, c) picked, -1 where the
+ *             column does not exist.
+ * Recorded by the sparse on-chip-resident kernel in its logging form: every target of the plan routed there, D = 10 (node) / 14
+ * (graph), H = O = 20, use_resident = 1 - a run on any other plan returns an error while a trace is set. */
+int gnnx_set_trace(gnnx_handle h, uint32_t* gates, int32_t* pool_rows);
 
 /* Measurement hook: device time (ms, HIP events on the side streams the kernels run on) of the on-chip-resident
  * launches of the LAST gnnx_run, in situ (i.e. while the other kernels of that run were executing):

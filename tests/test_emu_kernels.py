@@ -55,11 +55,15 @@ def test_forward_probs_and_masked_adj(be, name, t):
     assert np.abs(probs[0] - o.stages["p"]).max() < 1e-5
 
 
+@pytest.mark.parametrize("use_resident", [True, False])
 @pytest.mark.parametrize("name,t,iters", [("syn1", 302, 12), ("syn4", 511, 12), ("syn1", 309, 6)])
-def test_short_run_matches_closed_form(be, name, t, iters):
+def test_short_run_matches_closed_form(be, name, t, iters, use_resident):
+    """Masks, ALL n x n mask parameters and the logged loss terms (explain.py:808-819) after a short run - on the edge-sparse resident
+    kernel in its logging form (+ k_dead_entries for the entries off the edges) and on the dense streaming kernels."""
     ck, gx, sg = _node_case(name, t)
     job = be.job([sg], ck["sd"])
-    hy = Hyper(num_iters=iters, record_loss=True)
+    assert set(job.route()) <= {4, 5, 6, 8}
+    hy = Hyper(num_iters=iters, record_loss=True, use_resident=use_resident)
     res = job.run([sg.mask0], hy)
     o = closed_form.ClosedFormOracle(sg.adj, sg.feat, ck["sd"], sg.gt_label, sg.pred_label, sg.target_row, sg.mask0)
     want = o.run(iters)
