@@ -200,7 +200,8 @@ struct gnnx_plan_s {
     int32_t* d_res = nullptr;        // target ids of the resident set (grouped by nb, largest first)
     int32_t* d_big = nullptr;        // target ids of the streaming set
     ConvTile* d_conv_big = nullptr;
-    MaskTile* d_mask_big = nullptr;
+    MaskTile* d_mask_big = nullptr;  // tile pairs of the streaming set: its own pool block, built on first use (ensure_mask_big)
+    std::vector<int32_t> big_ids;    // the streaming set on the host (largest first)
     // work units of k_conv (groups of adjacent row blocks, largest targets first) for the two tile tables
     ConvUnit* d_unit = nullptr;
     ConvUnit* d_unit_big = nullptr;
@@ -243,7 +244,7 @@ struct gnnx_plan_s {
     int adam_first = 0;              // first_iter the table was built for (gnnx_run_resume)
     TargetMeta* d_meta = nullptr;
     ConvTile* d_conv = nullptr;   // every 32-row block of every target
-    MaskTile* d_mask = nullptr;
+    MaskTile* d_mask = nullptr;   // tile pairs of ALL targets: built on first use (ensure_mask_all)
     float* d_wts = nullptr;
     double sum_n2 = 0;
     // workspace offsets in bytes
@@ -251,7 +252,31 @@ struct gnnx_plan_s {
         o_probs, o_Xn[2], o_XnT[2], o_bnr[2], ws_bytes;
     hipGraphExec_t gexec = nullptr;
     GraphKey gkey{};
+    // streams that may still be executing work that reads this plan's device tables, each with the event recorded behind the last such
+    // call: the tables go back to the recycling pool (pool_free does not synchronise, unlike the hipFree it replaced) only after these
+    // events completed - gnnx_destroy of a job whose kernels still run, a new split under a running job
+    std::vector<std::pair<hipStream_t, hipEvent_t>> busy;
 };
+
+// the call that just enqueued work on `s` reads the plan's tables: remember where that work ends
+static void mark_busy(gnnx_handle h, hipStream_t s) {
+    for (auto& b : h->busy)
+        if (b.first == s) {
+            (void)hipEventRecord(b.second, s);
+            return;
+        }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamSynchronize(s);   // no event to remember it by: wait now
+        return;
+    }
+    (void)hipEventRecord(e, s);
+    h->busy.push_back({s, e});
+}
+// every piece of enqueued work that reads the plan's tables has finished (cheap when it already has)
+static void wait_idle(gnnx_handle h) {
+    for (auto& b : h->busy) (void)hipEventSynchronize(b.second);
+}
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -357,6 +382,7 @@ static int build_split(gnnx_handle h) {
         hipError_t e_ = (x);                                                       \
         if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); \
     } while (0)
+    wait_idle(h);   // the split block (and the slabs) it replaces may still be read by an earlier run of this plan
     if (h->gexec) {
         (void)hipGraphExecDestroy(h->gexec);
         h->gexec = nullptr;
@@ -369,12 +395,13 @@ static int build_split(gnnx_handle h) {
     }
     for (int k = 0; k < N_SPC; ++k) h->d_sp[k] = nullptr;
     h->d_conv_big = nullptr;
+    if (h->d_mask_big) (void)pool_free(h->d_mask_big);
     h->d_mask_big = nullptr;
     h->d_unit_big = nullptr;
     h->d_join_big = nullptr;
     h->n_unit_big = h->n_join_big = 0;
     std::vector<ConvTile> conv_big;
-    std::vector<MaskTile> mask_big;
+    long long n_mask_big = 0;
     std::vector<int32_t> res_ids, sp_ids[N_SPC], big_ids;
     for (int k = 0; k <= RES_NBMAX; ++k) h->res_count[k] = h->res_first[k] = 0;
     for (int t : h->order) {  // sorted by ld: the dense resident groups are contiguous
@@ -387,15 +414,15 @@ static int build_split(gnnx_handle h) {
         } else {
             big_ids.push_back(t);
             for (int rb = 0; rb < nb; ++rb) conv_big.push_back({t, rb, h->meta[t]});
-            for (int I = 0; I < nb; ++I)
-                for (int J = I; J < nb; ++J) mask_big.push_back({t, I, J, 0, h->meta[t]});
+            n_mask_big += (long long)nb * (nb + 1) / 2;   // the tile pairs themselves: on first use (ensure_mask_big)
         }
     }
+    h->big_ids = big_ids;
     h->n_res = (int)res_ids.size();
     for (int k = 0; k < N_SPC; ++k) h->n_sp[k] = (int)sp_ids[k].size();
     h->n_big = (int)big_ids.size();
     h->n_conv_big = (int)conv_big.size();
-    h->n_mask_big = (int)mask_big.size();
+    h->n_mask_big = (int)n_mask_big;
     BlockBuilder bb;
     bb.add(h->d_res, res_ids);
     for (int k = 0; k < N_SPC; ++k) bb.add(h->d_sp[k], sp_ids[k]);
@@ -404,7 +431,6 @@ static int build_split(gnnx_handle h) {
         bb.add(h->d_big, big_ids);
         bb.add(h->d_conv_big, conv_big);
         SPLITCK(add_units(h, bb, conv_big, h->d_unit_big, h->n_unit_big, h->d_join_big, h->n_join_big));
-        bb.add(h->d_mask_big, mask_big);
     }
     SPLITCK(bb.commit(h->split_block));
     if (any_resident && !h->ev_in) SPLITCK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
@@ -435,7 +461,7 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
     const int T = prob->num_targets;
     h->meta.resize(T);
     std::vector<ConvTile> conv;
-    std::vector<MaskTile> mask;
+    long long n_mask_all = 0;
     for (int t = 0; t < T; ++t) {
         const int n = prob->n[t];
         if (n < 1) {
@@ -486,11 +512,17 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
         const int nb = h->meta[t].ld / TILE;
         if (resident_ok && nb <= h->res_nbmax) h->cat[t] = nb;
         for (int rb = 0; rb < nb; ++rb) conv.push_back({t, rb, h->meta[t]});
-        for (int I = 0; I < nb; ++I)
-            for (int J = I; J < nb; ++J) mask.push_back({t, I, J, 0, h->meta[t]});
+        n_mask_all += (long long)nb * (nb + 1) / 2;
+    }
+    // The tile-pair table of k_mask over ALL targets (sum of nb (nb + 1) / 2 entries: 3.4 M entries = 164 MB for the 16 384-target
+    // BA-House x100k set, 0.28 s of host loops + upload per plan) is built on first use (ensure_mask_all): a plan whose targets the
+    // analysis routes to the edge-sparse kernels never needs it.
+    if (n_mask_all > 0x7fffffffLL) {
+        delete h;
+        return fail("too many tile pairs in one plan");
     }
     h->n_conv = (int)conv.size();
-    h->n_mask = (int)mask.size();
+    h->n_mask = (int)n_mask_all;
 
     // packed, zero padded model block
     std::vector<float> w(WT_TOTAL, 0.0f);
@@ -526,7 +558,6 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
         bb.add(h->d_meta, h->meta);
         bb.add(h->d_conv, conv);
         PLANCK(add_units(h, bb, conv, h->d_unit, h->n_unit, h->d_join, h->n_join));
-        bb.add(h->d_mask, mask);
         bb.add(h->d_wts, w);
         bb.add(h->d_raw_off, ro);
         PLANCK(bb.commit(h->create_block));
@@ -578,6 +609,9 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
 
 extern "C" int gnnx_destroy(gnnx_handle h) {
     if (!h) return 0;
+    wait_idle(h);   // a job dropped while its kernels run (an abandoned pipeline, an exception between launch and fetch) must not hand
+                    // its tables to the next plan under them
+    for (auto& b : h->busy) (void)hipEventDestroy(b.second);
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     for (int k = 0; k < N_SIDE; ++k) {
         if (h->ev_out[k]) (void)hipEventDestroy(h->ev_out[k]);
@@ -586,6 +620,8 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->d_nnz) (void)pool_free(h->d_nnz);
     if (h->d_dead) (void)pool_free(h->d_dead);
+    if (h->d_mask) (void)pool_free(h->d_mask);
+    if (h->d_mask_big) (void)pool_free(h->d_mask_big);
     if (h->d_rowdeg) (void)pool_free(h->d_rowdeg);
     if (h->d_csr_rowptr) (void)pool_free(h->d_csr_rowptr);
     if (h->d_csr_col) (void)pool_free(h->d_csr_col);
@@ -705,6 +741,33 @@ struct Tables {
     const int32_t* ids;  // target ids for per-target kernels (null = 0..T-1)
     int n_targets;
 };
+// the tile-pair table of k_mask / k_grad_edges over all targets, largest targets first (the order of the conv table)
+static int ensure_mask_all(gnnx_handle h) {
+    if (h->d_mask || !h->n_mask) return 0;
+    std::vector<MaskTile> mask;
+    mask.reserve((size_t)h->n_mask);
+    for (int t : h->order) {
+        const int nb = h->meta[t].ld / TILE;
+        for (int I = 0; I < nb; ++I)
+            for (int J = I; J < nb; ++J) mask.push_back({t, I, J, 0, h->meta[t]});
+    }
+    HIPCK(pool_malloc(&h->d_mask, sizeof(MaskTile) * mask.size()));
+    HIPCK(upload_sync(h->d_mask, mask.data(), sizeof(MaskTile) * mask.size()));
+    return 0;
+}
+static int ensure_mask_big(gnnx_handle h) {
+    if (h->d_mask_big || !h->n_mask_big) return 0;
+    std::vector<MaskTile> mask;
+    mask.reserve((size_t)h->n_mask_big);
+    for (int t : h->big_ids) {
+        const int nb = h->meta[t].ld / TILE;
+        for (int I = 0; I < nb; ++I)
+            for (int J = I; J < nb; ++J) mask.push_back({t, I, J, 0, h->meta[t]});
+    }
+    HIPCK(pool_malloc(&h->d_mask_big, sizeof(MaskTile) * mask.size()));
+    HIPCK(upload_sync(h->d_mask_big, mask.data(), sizeof(MaskTile) * mask.size()));
+    return 0;
+}
 static Tables tables_all(gnnx_handle h) { return {h->d_unit, h->n_unit, h->d_join, h->n_join, h->d_conv, h->n_conv, h->d_mask, h->n_mask, nullptr, h->prob.num_targets}; }
 static Tables tables_big(gnnx_handle h) { return {h->d_unit_big, h->n_unit_big, h->d_join_big, h->n_join_big, h->d_conv_big, h->n_conv_big, h->d_mask_big, h->n_mask_big, h->d_big, h->n_big}; }
 
@@ -986,8 +1049,10 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
     p.trace_pool = h->trace_pool;
     p.trace_rows = h->R;
     const bool resident = hy->use_resident && (h->n_res > 0 || h->n_sparse() > 0) && (!lossp || log_resident);
-    const Tables tb = (resident && h->n_big > 0) ? tables_big(h) : tables_all(h);
     const bool streaming = !resident || h->n_big > 0;
+    if (streaming)
+        if (int rc = (resident && h->n_big > 0) ? ensure_mask_big(h) : ensure_mask_all(h)) return rc;
+    const Tables tb = (resident && h->n_big > 0) ? tables_big(h) : tables_all(h);
     if (streaming)
         if (int rc = init_stream_state(h, p, s)) return rc;
     if (resident) {
@@ -1125,6 +1190,7 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
         HIPCK(hipMemcpyAsync(feat_mask, p.f[hy->num_iters & 1], sizeof(float) * h->prob.num_targets * FS,
                              hipMemcpyDeviceToDevice, s));
     HIPCK(hipGetLastError());
+    mark_busy(h, s);
     return 0;
 }
 
@@ -1317,6 +1383,7 @@ extern "C" int gnnx_plan_analyze_features(gnnx_handle h, const float* A, const f
         HIPCK(hipGetLastError());
         HIPCK(hipStreamSynchronize(s));
     }
+    mark_busy(h, s);
     return 0;
 }
 
@@ -1330,6 +1397,7 @@ extern "C" int gnnx_pack_csr(gnnx_handle h, const int64_t* indptr, const int32_t
     PackArgs a{indptr, indices, weights, feat, feat_stride, pred_label, nb, nb_off, A, X, yhat, h->prob.D};
     hipLaunchKernelGGL(k_pack, dim3(h->n_conv), dim3(256), 0, s, a, h->d_conv);
     HIPCK(hipGetLastError());
+    mark_busy(h, s);
     return 0;
 }
 
@@ -1375,6 +1443,7 @@ extern "C" int gnnx_scatter_masks(gnnx_handle h, const float* raw, float* M, voi
     if (!h || !raw || !M) return fail("null argument");
     hipLaunchKernelGGL(k_scatter_masks, dim3(h->n_conv), dim3(256), 0, static_cast<hipStream_t>(stream), raw, h->d_raw_off, M, h->d_conv);
     HIPCK(hipGetLastError());
+    mark_busy(h, static_cast<hipStream_t>(stream));
     return 0;
 }
 
@@ -1393,6 +1462,7 @@ extern "C" int gnnx_edge_counts(gnnx_handle h, const float* A, int64_t* counts, 
     if (!h->d_rowcnt) HIPCK(pool_malloc(&h->d_rowcnt, sizeof(int32_t) * (size_t)h->R));
     edge_rows(h, A, h->d_rowcnt, counts, s);
     HIPCK(hipGetLastError());
+    mark_busy(h, s);
     return 0;
 }
 
@@ -1406,6 +1476,7 @@ extern "C" int gnnx_gather_edges(gnnx_handle h, const float* A, const float* Aba
     edge_rows(h, A, o.rowcnt, nullptr, s);
     hipLaunchKernelGGL(k_edge_emit, dim3(h->n_conv), dim3(256), 0, s, A, Abar, M, h->d_conv, o);
     HIPCK(hipGetLastError());
+    mark_busy(h, s);
     return 0;
 }
 
@@ -1418,6 +1489,7 @@ extern "C" int gnnx_edge_positions(gnnx_handle h, const float* A, const int64_t*
     edge_rows(h, A, o.rowcnt, nullptr, s);
     hipLaunchKernelGGL(k_edge_emit, dim3(h->n_conv), dim3(256), 0, s, A, (const float*)nullptr, (const float*)nullptr, h->d_conv, o);
     HIPCK(hipGetLastError());
+    mark_busy(h, s);
     return 0;
 }
 
@@ -1441,6 +1513,7 @@ extern "C" int gnnx_denoise_edges(gnnx_handle h, const int64_t* eoff, const int3
                   reinterpret_cast<int32_t*>(w + h->o_z3p)};
     hipLaunchKernelGGL(k_denoise, dim3(h->prob.num_targets), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     HIPCK(hipGetLastError());
+    mark_busy(h, static_cast<hipStream_t>(stream));
     return 0;
 }
 
@@ -1464,12 +1537,14 @@ extern "C" int gnnx_forward(gnnx_handle h, const float* A, const float* X, const
     hipStream_t s = static_cast<hipStream_t>(stream);
     Params p = make_params(h, nullptr, A, X, nullptr, const_cast<float*>(M), Abar, nullptr, workspace);
     p.num_iters = 1;
+    if (int rc = ensure_mask_all(h)) return rc;
     const Tables tb = tables_all(h);
     hipLaunchKernelGGL(k_prep, dim3(h->prob.num_targets), dim3(256), 0, s, p, feat_mask_in, (const int32_t*)nullptr);
     launch_mask<false, true>(h, tb, p, 0, 0.0f, 1.0f, s);
     launch_forward(h, tb, p, 0, s);
     HIPCK(hipMemcpyAsync(probs, p.probs, sizeof(float) * h->prob.num_targets * CMAX, hipMemcpyDeviceToDevice, s));
     HIPCK(hipGetLastError());
+    mark_busy(h, s);
     return 0;
 }
 
@@ -1484,6 +1559,7 @@ extern "C" int gnnx_grad_baseline(gnnx_handle h, const float* A, const float* X,
     // the streaming forward / backward with Abar := A (unmasked adjacency, diagonal included as the reference's model(x, adj))
     Params p = make_params(h, nullptr, A, X, nullptr, nullptr, const_cast<float*>(A), nullptr, workspace);
     p.num_iters = 1;
+    if (int rc = ensure_mask_all(h)) return rc;
     const Tables tb = tables_all(h);
     // phi := 1: a feature-mask parameter of 40 (sigmoid(40) == 1.0f), staged in the (yet unused) df array
     const size_t nf = (size_t)h->prob.num_targets * FS;
@@ -1496,6 +1572,7 @@ extern "C" int gnnx_grad_baseline(gnnx_handle h, const float* A, const float* X,
     launch_backward(h, tb, p, 0, s);
     hipLaunchKernelGGL(k_grad_edges, dim3(tb.n_mask), dim3(256), 0, s, p, tb.mask, out);
     HIPCK(hipGetLastError());
+    mark_busy(h, s);
     return 0;
 }
 
@@ -1556,6 +1633,7 @@ extern "C" int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hy, int32_t kin
     adam_scalars(hy, 0, &ss, &b2);
     // the tables gnnx_run would walk: only the streaming remainder when resident kernels take part of the batch
     const bool hybrid = hy->use_resident && (h->n_res > 0 || h->n_sparse() > 0) && h->n_big > 0;
+    if (int rc = hybrid ? ensure_mask_big(h) : ensure_mask_all(h)) return rc;
     const Tables tb = hybrid ? tables_big(h) : tables_all(h);
     double sum_n2 = h->sum_n2;
     if (hybrid) {

@@ -638,12 +638,18 @@ class ExplainModule(nn.Module):
         """The hot loop (explain.py:137-146) on the GPU; updates mask / feat_mask / masked_adj in place."""
         # the streaming kernels keep EVERY entry of the dense mask up to date (the edge-sparse resident kernels only the
         # entries on edges), so `self.mask` - and a later `loss()` over all n^2 entries - match the reference's parameter
-        hy = _hyper(self.args, record_loss=record_loss, use_resident=False)
-        if num_epochs is not None:
-            hy.num_iters = int(num_epochs)
+        # A second call continues where the first stopped - moments, step count for the bias corrections and position in the learning-rate
+        # schedule - like the torch optimiser / scheduler the reference keeps in the module (explain.py:620-622).
+        n = int(num_epochs) if num_epochs is not None else int(self.args.num_epochs)
+        prev = getattr(self, "_state", None)
+        first = 0 if prev is None else int(prev.first_iter)
+        hy = _hyper(self.args, num_iters=n, record_loss=record_loss, use_resident=False)
+        if hy.lr_schedule is not None:
+            hy.lr_schedule = _lr_schedule(self.args, first + n)[first:]
         job = self._job
         job.set_masks([self.mask.detach().numpy()])
-        job.launch(hy, keep_state=True)
+        job.launch(hy, state=prev, keep_state=True)
+        self._state = job.state_out
         res = job.fetch(hy)
         with torch.no_grad():
             self.mask.copy_(torch.from_numpy(res.mask[0]))
@@ -655,7 +661,7 @@ class ExplainModule(nn.Module):
         st = job.state_out
         sq = lambda a: torch.from_numpy(job._square_views(a.cpu().numpy())[0][:n, :n].copy())
         fs = st.feat.cpu().numpy()[0, :, :self.feat_mask.numel()]
-        steps = torch.tensor(float(hy.num_iters))
+        steps = torch.tensor(float(first + hy.num_iters))
         names = {"adam": ("exp_avg", "exp_avg_sq"), "sgd": ("momentum_buffer", None), "rmsprop": (None, "square_avg"),
                  "adagrad": (None, "sum")}[hy.opt]
         for prm, m, v in ((self.mask, sq(st.m), sq(st.v)), (self.feat_mask, torch.from_numpy(fs[1].copy()), torch.from_numpy(fs[2].copy()))):
@@ -668,5 +674,5 @@ class ExplainModule(nn.Module):
                 state[names[1]] = v
         if hy.lr_schedule is not None:
             for g in self.optimizer.param_groups:
-                g["lr"] = float(_lr_schedule(self.args, hy.num_iters + 1)[-1])
+                g["lr"] = float(_lr_schedule(self.args, first + hy.num_iters + 1)[-1])
         return res

@@ -62,6 +62,9 @@ class BatchPipeline:
         self._pinned = {}          # (name, slot) -> grow-only pinned host buffers
         self._raw_done = {}        # raw slot -> event behind the H2D copy that read it
         self._ring = 0
+        # pinned staging slots of the small per-batch host buffers (edge ids): a slot is reused by batch k + slots, so it must outnumber
+        # the batches whose buffer finish() has not copied yet: those being prepared + those optimising + those queued for / in fetch
+        self._rc_slots = self.prepare_workers + 2 * self.depth + 4
         self.stats = []            # per batch: host milliseconds of the stages (measurement)
 
     def _cu_masks(self, reserve, num_cus=256):
@@ -132,7 +135,7 @@ class BatchPipeline:
         p.targets, p.error, p.times = targets, None, {}
         t0 = time.perf_counter()
         self.lib.gnnx_set_service_stream(s_prep.cuda_stream)    # this thread's plan-table uploads: not the null stream
-        slot = k % 16                                          # small host buffers (edge ids): one of 16, more than the batches in flight
+        slot = k % self._rc_slots                              # small host buffers (edge ids): more slots than batches in flight (see __init__)
         raw_slot = k % (self.prepare_workers + 1)              # the RNG stream (n^2 floats per target): as few as the preparations in flight;
         ev = self._raw_done.get(raw_slot)                      # it is free again once its H2D copy has finished
         if ev is not None:

@@ -208,15 +208,19 @@ class Windows:
         return np.stack([c[self.fine_row[(int(k), int(w))]] for k in ks]) if len(ks) else np.zeros((0, self.nsub))
 
 
-def run_window(job, start, iters):
+def run_window(job, start, iters, trace=False):
     """Start `job` (its M holding the seeded initial masks) from a fixture state (Windows.boundary / .fine; None = the initial
-    state) and run `iters` iterations.  -> (mask_rc [E, 2], feat_mask [T, D]) after them."""
+    state) and run `iters` iterations.  -> (mask_rc [E, 2], feat_mask [T, D]) after them; with trace=True also the decision
+    trace of those iterations (MaskOptimJob.fetch_trace: gates per target, pool rows or None)."""
     from gnn_model_explainer_amd.engine import Hyper
     st = None
     if start is not None:
         st = job.set_state_edges(*start)
-    job.launch(Hyper(num_iters=int(iters)), state=st, keep_state=True)
+    job.launch(Hyper(num_iters=int(iters)), state=st, keep_state=True, trace=trace)
     mask_rc, _, _, fs = job.fetch_state_edges()
+    if trace:
+        gates, pool = job.fetch_trace()
+        return mask_rc, fs[:, 0, :], gates, pool
     return mask_rc, fs[:, 0, :]
 
 
@@ -226,3 +230,95 @@ def window_errors(eoff, mask_rc, feat, want):
     em = np.asarray([d[a:b].max() if b > a else 0.0 for a, b in zip(eoff[:-1], eoff[1:])])
     ef = np.abs(_sig64(feat) - _sig64(want[4])).max(1)
     return em, ef
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Decision parity: tests/golden/<name>_decisions.npz (make_golden_decisions.py) holds the side of every discrete decision of the
+# LIVE reference's forward - ReLU gates that reach the loss, graph-mode max-pool rows - at every epoch of every target, plus the
+# NEAR list (gates with |U| < 1e-5, pools whose winner leads by < 1e-5).  The engine's own decisions come from gnnx_set_trace.
+# ---------------------------------------------------------------------------------------------------------------------------
+class Decisions:
+    def __init__(self, name):
+        self.z = z = np.load(os.path.join(GOLDEN, name + "_decisions.npz"))
+        self.ids = z["targets"] if "targets" in z.files else z["graphs"]
+        self.T = len(self.ids)
+        self.graph_mode = "pool0" in z.files
+        self.near_tol = float(z["near"])
+
+    def gate_words(self, k, e0, e1):
+        """uint32 [e1 - e0, n_k, 2]: the reference's sign words at epochs e0 .. e1 - 1 of target k (fixture index)"""
+        z = self.z
+        a, b = int(z["row_off"][k]), int(z["row_off"][k + 1])
+        cur = z["gates0"][a:b].copy()
+        ev = z["ev"][int(z["ev_off"][k]):int(z["ev_off"][k + 1])]
+        out = np.empty((e1 - e0, b - a, 2), np.uint32)
+        j = 0
+        for e in range(e1):
+            while j < len(ev) and ev[j, 0] == e:
+                cur[ev[j, 1], ev[j, 2]] = np.int32(ev[j, 3]).view(np.uint32)
+                j += 1
+            if e >= e0:
+                out[e - e0] = cur
+        return out
+
+    def pool_rows(self, k, e0, e1):
+        z = self.z
+        cur = z["pool0"][k].astype(np.int32).copy()
+        ev = z["pev"][int(z["pev_off"][k]):int(z["pev_off"][k + 1])]
+        out = np.empty((e1 - e0, 3, 20), np.int32)
+        j = 0
+        for e in range(e1):
+            while j < len(ev) and ev[j, 0] == e:
+                cur[ev[j, 1], ev[j, 2]] = ev[j, 3]
+                j += 1
+            if e >= e0:
+                out[e - e0] = cur
+        return out
+
+    def near_gates(self, k):
+        """{(epoch, layer, row, column): U} of the gates of target k whose |U| < NEAR in the reference"""
+        z = self.z
+        a, b = int(z["near_off"][k]), int(z["near_off"][k + 1])
+        return {tuple(int(x) for x in ev): float(v) for ev, v in zip(z["near_ev"][a:b], z["near_val"][a:b])}
+
+    def near_pools(self, k):
+        z = self.z
+        a, b = int(z["pnear_off"][k]), int(z["pnear_off"][k + 1])
+        return {tuple(int(x) for x in ev): float(v) for ev, v in zip(z["pnear_ev"][a:b], z["pnear_val"][a:b])}
+
+    def first_disagreement(self, k, e0, gates, pool=None):
+        """Engine trace of target k for epochs e0 .. e0 + len(gates) - 1 (gates uint32 [iters, n, 2], pool int32 [iters, 3, 32] or None)
+        against the reference's decisions.  -> None when every decision of every epoch agrees, else
+        (epoch, what, margin): the first epoch with a difference, a description of the differing decisions, and the LARGEST |U| /
+        pool margin the reference has on any of them (inf when one of them is not on its NEAR list: not a tie)."""
+        iters = gates.shape[0]
+        want = self.gate_words(k, e0, e0 + iters)
+        dg = (want != gates).reshape(iters, -1).any(1)
+        dp = np.zeros(iters, bool)
+        if pool is not None:
+            wp = self.pool_rows(k, e0, e0 + iters)
+            dp = (wp != pool[:, :, :20]).reshape(iters, -1).any(1)
+        bad = np.nonzero(dg | dp)[0]
+        if not len(bad):
+            return None
+        i = int(bad[0])
+        e = e0 + i
+        margin, what = 0.0, []
+        if dg[i]:
+            near = self.near_gates(k)
+            r, l = np.nonzero(want[i] != gates[i])
+            for rr, ll in zip(r, l):
+                x = int(want[i][rr, ll] ^ gates[i][rr, ll])
+                for c in range(20):
+                    if x >> c & 1:
+                        v = near.get((e, int(ll), int(rr), c))
+                        margin = max(margin, abs(v) if v is not None else np.inf)
+                        what.append(("gate", int(ll), int(rr), c, v))
+        if dp[i]:
+            near = self.near_pools(k)
+            l, c = np.nonzero(wp[i] != pool[i][:, :20])
+            for ll, cc in zip(l, c):
+                v = near.get((e, int(ll), int(cc)))
+                margin = max(margin, abs(v) if v is not None else np.inf)
+                what.append(("pool", int(ll), int(cc), int(wp[i][ll, cc]), int(pool[i][ll, cc]), v))
+        return e, what, margin

@@ -180,12 +180,21 @@ def _explain_module_surface(tmp_path):
     assert (st["exp_avg"] - want["exp_avg"]).abs().max() < 1e-6 and (st["exp_avg_sq"] - want["exp_avg_sq"]).abs().max() < 1e-7
     assert (mod.optimizer.state[mod.feat_mask]["exp_avg"] - o.opt.state[o.feat_mask]["exp_avg"]).abs().max() < 1e-6
     assert (mod.mask.detach() - o.mask.detach()).abs().max() < 1e-5
+    # a second call (k != args.num_epochs) continues: moments, step count of the bias corrections - like the reference's optimiser
+    mod.optimize(3)
+    o.run(3)
+    st, want = mod.optimizer.state[mod.mask], o.opt.state[o.mask]
+    assert float(st["step"]) == 8
+    assert (st["exp_avg"] - want["exp_avg"]).abs().max() < 1e-6 and (st["exp_avg_sq"] - want["exp_avg_sq"]).abs().max() < 1e-7
+    assert (mod.mask.detach() - o.mask.detach()).abs().max() < 1e-5
     sgd = explain.ExplainModule(torch.tensor(sub_adj[None], dtype=torch.float), torch.tensor(sub_feat[None], dtype=torch.float), ex.model,
                                 torch.tensor(sub_label[None]), _args(tmp_path, 5, opt="sgd", opt_scheduler="step", opt_decay_step=2, opt_decay_rate=0.5),
                                 graph_idx=-1, node_idx=new, pred_label=pl)
     assert isinstance(sgd.optimizer, torch.optim.SGD) and isinstance(sgd.scheduler, torch.optim.lr_scheduler.StepLR)
     sgd.optimize(5)
     assert "momentum_buffer" in sgd.optimizer.state[sgd.mask] and abs(sgd.optimizer.param_groups[0]["lr"] - 0.1 * 0.25) < 1e-12
+    sgd.optimize(3)        # the schedule continues at step 5: lr 0.1 * 0.5 ** (8 // 2) afterwards
+    assert abs(sgd.optimizer.param_groups[0]["lr"] - 0.1 * 0.5 ** 4) < 1e-12
 
 
 def test_explain_module_surface_emulated(tmp_path, emu_engine):
