@@ -220,7 +220,8 @@ struct gnnx_plan_s {
     bool launched[N_SIDE] = {};
     std::vector<int> order;          // targets, largest first
     std::vector<int> cat;            // per target: 0 streaming, 1..RES_NBMAX dense resident kernel of that many row blocks, CAT_SPARSE
-    bool xconst = false;             // every target of the sparse resident classes has constant feature rows (gnnx_plan_analyze_features)
+    int xconst = 0;                  // every target of the sparse resident classes has constant feature rows (gnnx_plan_analyze_features):
+                                     // 0 general form, 1 the general form's products without the gathers (bit-identical), 2 the algebraic form
     std::vector<int32_t> nnz;        // per target (directed edge entries, row slots) from gnnx_plan_analyze, empty before
     int n_sp[N_SPC] = {};            // targets of the sparse resident kernel, per size class (1024 / 256 / 64 threads)
     int32_t* d_sp[N_SPC] = {};
@@ -860,15 +861,16 @@ template <int NT>
 static void launch_sparse_nt(gnnx_handle h, const Params& p, const int32_t* ids, int cnt, const float* adam_tab, hipStream_t s, bool log) {
     const dim3 grid(cnt), block(NT);
     if (log) {   // the logging form (loss scalars + decision trace): exact shapes only, checked by the caller
-        if (h->prob.graph_mode) hipLaunchKernelGGL((k_sparse_resident<7, 10, true, NT, false, true>), grid, block, 0, s, p, ids, adam_tab);
-        else hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT, false, true>), grid, block, 0, s, p, ids, adam_tab);
+        if (h->prob.graph_mode) hipLaunchKernelGGL((k_sparse_resident<7, 10, true, NT, 0, true>), grid, block, 0, s, p, ids, adam_tab);
+        else hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT, 0, true>), grid, block, 0, s, p, ids, adam_tab);
         return;
     }
     if (h->prob.graph_mode) {
         if (exact_shape(h, 14)) hipLaunchKernelGGL((k_sparse_resident<7, 10, true, NT>), grid, block, 0, s, p, ids, adam_tab);
         else hipLaunchKernelGGL((k_sparse_resident<16, 16, true, NT>), grid, block, 0, s, p, ids, adam_tab);
     } else {
-        if (exact_shape(h, 10) && h->xconst) hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT, true>), grid, block, 0, s, p, ids, adam_tab);
+        if (exact_shape(h, 10) && h->xconst == 2) hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT, 2>), grid, block, 0, s, p, ids, adam_tab);
+        else if (exact_shape(h, 10) && h->xconst == 1) hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT, 1>), grid, block, 0, s, p, ids, adam_tab);
         else if (exact_shape(h, 10)) hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT>), grid, block, 0, s, p, ids, adam_tab);
         else hipLaunchKernelGGL((k_sparse_resident<16, 16, false, NT>), grid, block, 0, s, p, ids, adam_tab);
     }
@@ -1119,10 +1121,13 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
                 const int per_wg = sp_mix_tiny(h->prob.D, h->prob.H, h->prob.C);   // single-tile targets per workgroup
                 const dim3 grid(h->n_sp[SPC_512] + (h->n_sp[2] + per_wg - 1) / per_wg), block(512);
                 if (log_resident)
-                    hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, false, true>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
+                    hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, 0, true>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
                                        h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C));
-                else if (exact_shape(h, 10) && h->xconst)
-                    hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, true>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
+                else if (exact_shape(h, 10) && h->xconst == 2)
+                    hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, 2>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
+                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C));
+                else if (exact_shape(h, 10) && h->xconst == 1)
+                    hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, 1>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
                                        h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C));
                 else if (exact_shape(h, 10))
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
@@ -1236,7 +1241,7 @@ extern "C" int gnnx_plan_analyze_features(gnnx_handle h, const float* A, const f
     h->nnz.assign((3 + SPL_COUNTS) * (size_t)T, -1);   // ..., then one flag per target: constant feature rows (0 when X was not given)
     HIPCK(hipMemcpyAsync(h->nnz.data(), h->d_nnz, sizeof(int32_t) * (h->prob.graph_mode ? 2 : (look_at_x ? 3 : 2) + SPL_COUNTS) * T, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
-    h->xconst = false;
+    h->xconst = 0;
     const bool graph = h->prob.graph_mode != 0;
     if (h->prob.C > RES_CMAX || h->prob.mask_relu || h->prob.bn) return 0;   // mask_act = "ReLU" and --bn run on the dense streaming kernels only
     int sparse_on = 1;
@@ -1348,9 +1353,9 @@ extern "C" int gnnx_plan_analyze_features(gnnx_handle h, const float* A, const f
                 all &= h->nnz[(2 + SPL_COUNTS) * (size_t)T + t] == 1;
             }
         }
-        int xc_on = 1;
-        if (const char* env = std::getenv("GNNX_XCONST")) xc_on = std::atoi(env);
-        h->xconst = any && all && xc_on && exact_shape(h, 10);
+        int xc_form = 2;   // GNNX_XCONST = 0 / 1 / 2: general form / bit-identical constant-feature form / algebraic form (default)
+        if (const char* env = std::getenv("GNNX_XCONST")) xc_form = std::max(0, std::min(2, std::atoi(env)));
+        h->xconst = (any && all && exact_shape(h, 10)) ? xc_form : 0;
     }
     if (changed)
         if (int rc = build_split(h)) return rc;

@@ -73,50 +73,146 @@ std::mutex g_pool_mu;
 
 extern "C" const char* gnnx_host_last_error(void) { return g_err.c_str(); }
 
+// One target's n x n values are ONE normal_ call of the reference (explain.py:645-652), i.e. one sequential pass over one mt19937
+// stream: the largest target of a batch (BA-House x100k: n = 5600, 31 M values = 0.3 s on one thread) used to bound the whole draw.
+// ATen's CPU normal_ on a contiguous float tensor of >= 16 values (normal_fill, aten/src/ATen/native/cpu/DistributionTemplates.h) first
+// fills the tensor with ONE 32-bit engine draw per value, then transforms 16 values at a time (Box-Muller on values i .. i + 7 and
+// i + 8 .. i + 15), and if the size is not a multiple of 16 redraws the last 16 values from 16 further engine draws.  So values
+// [a, b) of the tensor, a and b multiples of 16, are exactly normal_ of b - a values from the engine state after `a` draws, and a last
+// slice [a, N) is normal_ of N - a values from that state (its tail redraw consumes the draws that follow the N fill draws, as in the
+// whole tensor).  A "walker" steps the raw engine (about 2 ns per draw instead of the ~10 ns of a full normal) and leaves a copy of
+// its state at every slice boundary; the slices are then drawn by ATen itself, in parallel.  Bit-identical to the one-call draw (test).
+namespace {
+struct Slice { int k; int64_t a, b; at::mt19937 eng; };
+
+// Stepping at::mt19937 without producing outputs: its state after d draws is the seeded state after ceil(d / 624) block updates (the
+// recurrence of MT19937RNGEngine.h's next_state, the standard MT19937 one) with next_ = r, left_ = 625 - r, r = (d - 1) % 624 + 1 draws
+// taken from the current block.  The block update alone is a short vectorisable loop (0.3 ns per skipped draw instead of the 2-3 ns of
+// operator(), which also tempers every output).
+inline void mt_block_update(uint32_t* st) {
+    constexpr int N = 624, M = 397;
+    constexpr uint32_t A = 0x9908b0dfu, UM = 0x80000000u, LM = 0x7fffffffu;
+    auto tw = [](uint32_t u, uint32_t v) { return (((u & UM) | (v & LM)) >> 1) ^ ((v & 1u) ? A : 0u); };
+    const uint32_t first = st[0];
+    for (int k = 0; k < N - M; ++k) st[k] = st[k + M] ^ tw(st[k], st[k + 1]);
+    for (int k = N - M; k < N - 1; ++k) st[k] = st[k + M - N] ^ tw(st[k], st[k + 1]);
+    (void)first;
+    st[N - 1] = st[M - 1] ^ tw(st[N - 1], st[0]);   // (st[0] is already the new one, as in next_state)
+}
+// engine seeded with `seed`, positioned after `before` draws -> positioned after `after` >= before draws
+inline void mt_advance(at::mt19937& eng, int64_t before, int64_t after) {
+    if (after == before) return;
+    at::mt19937_data_pod pod = eng.data();
+    const int64_t blocks = (after + 623) / 624 - (before + 623) / 624;
+    for (int64_t b = 0; b < blocks; ++b) mt_block_update(pod.state_.data());
+    const int r = (int)((after - 1) % 624) + 1;
+    pod.next_ = (uint32_t)r;
+    pod.left_ = 625 - r;
+    eng.set_data(pod);
+}
+}
+
 extern "C" int gnnx_host_draw_masks(int32_t T, const int32_t* n, const int64_t* seeds, const int64_t* off, float* out, int32_t threads) {
+    return gnnx_host_draw_masks_sliced(T, n, seeds, off, out, threads, (int64_t)1 << 21);
+}
+
+extern "C" int gnnx_host_draw_masks_sliced(int32_t T, const int32_t* n, const int64_t* seeds, const int64_t* off, float* out, int32_t threads,
+                                           int64_t slice_values) {
     if (T < 0 || (T > 0 && (!n || !seeds || !off || !out))) {
         g_err = "null argument";
         return 1;
     }
     if (T == 0) return 0;
-    threads = std::max(1, std::min<int32_t>(threads, 64));
-    // equal shares of the VALUES (not of the targets): cut points in the prefix sums
-    const int64_t total = off[T - 1] + (int64_t)n[T - 1] * n[T - 1];
-    const int parts = (int)std::min<int64_t>(threads, T);
-    std::vector<int> cut(parts + 1, T);
-    cut[0] = 0;
-    for (int i = 1; i < parts; ++i) {
-        const int64_t want = total * i / parts;
-        cut[i] = (int)(std::lower_bound(off, off + T, want) - off);
+    threads = std::max(1, std::min<int32_t>(threads, 128));
+    slice_values = std::max<int64_t>(16, slice_values / 16 * 16);
+    // targets of more than two slices are cut; the others are dealt in equal shares of the VALUES (cut points in their prefix sums)
+    std::vector<int> big, small;
+    std::vector<int64_t> small_off(1, 0);
+    for (int k = 0; k < T; ++k) {
+        const int64_t nn = (int64_t)n[k] * n[k];
+        if (threads > 1 && nn > 2 * slice_values) {
+            big.push_back(k);
+        } else {
+            small.push_back(k);
+            small_off.push_back(small_off.back() + nn);
+        }
     }
+    const int S = (int)small.size();
+    const int small_parts = S ? (int)std::min<int64_t>(threads, S) : 0;
+    std::vector<int> cut(small_parts + 1, S);
+    if (small_parts) cut[0] = 0;
+    for (int i = 1; i < small_parts; ++i) {
+        const int64_t want = small_off[S] * i / small_parts;
+        cut[i] = (int)(std::lower_bound(small_off.begin(), small_off.begin() + S, want) - small_off.begin());
+    }
+    std::vector<std::vector<Slice>> slices(big.size());
     std::atomic<bool> failed{false};
     std::string err;
     std::mutex err_mu;
-    auto work = [&](int part) {
+    auto fail = [&](const std::exception& e) {
+        std::lock_guard<std::mutex> lk(err_mu);
+        failed = true;
+        err = e.what();
+    };
+    auto std_of = [&](int k) {   // nn.init.calculate_gain("relu") * math.sqrt(2.0 / (n + n)), evaluated in double like the Python expression
+        return std::sqrt(2.0) * std::sqrt(2.0 / ((double)n[k] + (double)n[k]));
+    };
+    // phase 1: the walkers of the big targets (first: they are the long poles) and the small targets
+    auto phase1 = [&](int part) {
         try {
             c10::InferenceMode ng;
+            if (part < (int)big.size()) {
+                const int k = big[part];
+                const int64_t nn = (int64_t)n[k] * n[k];
+                at::mt19937 eng((uint64_t)seeds[k]);    // == CPUGeneratorImpl::set_current_seed(seed)
+                std::vector<Slice>& sl = slices[part];
+                for (int64_t a = 0; a < nn; a += slice_values) {
+                    const int64_t b = (nn - a < slice_values + 16) ? nn : a + slice_values;   // no last slice shorter than 16 values
+                    sl.push_back(Slice{k, a, b, eng});
+                    if (b == nn) break;
+                    mt_advance(eng, a, b);
+                }
+                return;
+            }
+            const int sp = part - (int)big.size();
             at::Generator gen = at::detail::createCPUGenerator(0);
-            for (int k = cut[part]; k < cut[part + 1]; ++k) {
+            for (int q = cut[sp]; q < cut[sp + 1]; ++q) {
+                const int k = small[q];
                 const int64_t nn = (int64_t)n[k] * n[k];
                 if (nn == 0) continue;
                 gen.set_current_seed((uint64_t)seeds[k]);   // == torch.manual_seed(seed) on the default generator: fresh mt19937, no cached normal
-                // nn.init.calculate_gain("relu") * math.sqrt(2.0 / (n + n)), evaluated in double like the Python expression
-                const double std_ = std::sqrt(2.0) * std::sqrt(2.0 / ((double)n[k] + (double)n[k]));
                 at::Tensor view = at::from_blob(out + off[k], {nn}, at::TensorOptions().dtype(at::kFloat));
-                view.normal_(1.0, std_, gen);
+                view.normal_(1.0, std_of(k), gen);
             }
         } catch (const std::exception& e) {
-            std::lock_guard<std::mutex> lk(err_mu);
-            failed = true;
-            err = e.what();
+            fail(e);
         }
     };
-    if (parts == 1) {
-        work(0);
+    std::vector<const Slice*> all;
+    auto phase2 = [&](int part) {
+        try {
+            c10::InferenceMode ng;
+            const Slice& s = *all[part];
+            at::Generator gen = at::detail::createCPUGenerator(0);
+            auto* impl = at::check_generator<at::CPUGeneratorImpl>(gen);
+            impl->set_engine(s.eng);
+            impl->set_next_float_normal_sample(std::optional<float>());
+            at::Tensor view = at::from_blob(out + off[s.k] + s.a, {s.b - s.a}, at::TensorOptions().dtype(at::kFloat));
+            view.normal_(1.0, std_of(s.k), gen);
+        } catch (const std::exception& e) {
+            fail(e);
+        }
+    };
+    const int parts1 = (int)big.size() + small_parts;
+    if (parts1 == 1 && big.empty()) {
+        phase1(0);
     } else {
         std::lock_guard<std::mutex> lk(g_pool_mu);   // one batch at a time draws on the pool
-        if (!g_pool || g_pool->size() < parts) g_pool = new Pool(std::max(parts, 16));   // (an outgrown pool is leaked on purpose: its threads sleep)
-        g_pool->run(parts, work);
+        if (!g_pool || g_pool->size() < threads) g_pool = new Pool(std::max<int>(threads, 16));   // (an outgrown pool is leaked on purpose: its threads sleep)
+        if (parts1) g_pool->run(parts1, phase1);
+        for (auto& sl : slices)
+            for (auto& x : sl) all.push_back(&x);
+        if (!failed && !all.empty()) g_pool->run((int)all.size(), phase2);
     }
     if (failed) {
         g_err = err;

@@ -116,6 +116,7 @@ struct SparseFixed {
     int set_rows[2], set_slots[2];
     int set_chunk[2];  // entries per row slot of the set: the smallest of {4, 8, 16} (8, 16 for set A) whose slots fit the class
     int erow[96];  // graph mode: arg-max row of every pooled column
+    float wt[32], vsum[32];  // algebraic constant-feature form: (x (.) phi) W1, and sum over the rows of s_r dY1[r]
     float lsum[SP_THREADS / 64][4];  // LOG form: per-wave partial sums of the logged size / entropy / Laplacian terms over the owned edges
 };
 
@@ -384,13 +385,20 @@ __device__ __forceinline__ void sparse_combine(float (&acc)[NQ], int rem, int ws
 // The body works on NT consecutive threads tid = 0 .. NT-1 with their own LDS pool and SparseFixed: a whole workgroup
 // (k_sparse_resident) or, for NT = 64, one wave of a larger workgroup (k_sparse_resident_mixed) - a single wave
 // synchronises with itself, so its barriers are wave-level.
-// XC: every feature row of the target equals its row 0 bit for bit (decided per plan by gnnx_plan_analyze_features, verified here):
-// layer 1 and the X part of dL/dAbar then need no gathers (sparse_gather_const); a compile-time form because a run-time test inside
-// the phases keeps the operands of both forms alive across them (the 512-thread class sits at 256 VGPRs).  Node mode, exact shapes.
+// XC != 0: every feature row of the target equals its row 0 bit for bit (decided per plan by gnnx_plan_analyze_features, verified here):
+// layer 1 and the X part of dL/dAbar then need no gathers; a compile-time form because a run-time test inside the phases keeps the
+// operands of both forms alive across them (the 512-thread class sits at 256 VGPRs).  Node mode, exact shapes.
+//   XC = 1: the general form's products in the general form's order (sparse_gather_const): bit-identical results;
+//   XC = 2: the algebraic form.  With X[j] = x for every j, row r of layer 1 depends on ONE scalar, s_r = sum_e Abar_e:
+//           Y1[r] = s_r wt + b1, wt = (x (.) phi) W1 (a 20-vector, refreshed when phi changes), so the forward needs neither the D-wide
+//           gather nor its MFMA chain; backward, with dY1[r] = (dU - U (dU . U)) / r in the lane's registers,
+//             dL/dAbar[r][j] (layer-1 part) = dZ1[r] . (x (.) phi) = dY1[r] . wt           (one 20-term dot per row, no dZ1 at all),
+//             dL/dphi[k] = sum_r dZ1[r][k] (Abar X)[r][k] = x_k W1[k] . (sum_r s_r dY1[r])   (one 20-vector reduced over the rows).
+//           Same mathematics, other rounding: within round-off of XC = 1 (tests: closed form, decision parity), not bit-identical.
 // LOG: the logging form - per iteration the loss scalars of explain.py:808-819 (prediction, and the size / entropy / Laplacian sums
 // over the entries on EDGES; the entries off the edges follow a closed scalar recursion each and are added by k_dead_entries) and the
 // decision trace (Params::trace_gates / trace_pool).  A separate instantiation: the hot form carries none of it.
-template <int DQ, int HQ, bool GRAPH, int NT, bool XC = false, bool LOG = false>
+template <int DQ, int HQ, bool GRAPH, int NT, int XC = 0, bool LOG = false>
 __device__ __forceinline__ void sparse_resident_body(const Params p, int t, const float* adam_tab, float* pool, SparseFixed& sh,
                                                      int tid, float* shared_w = nullptr) {
     constexpr int SCAN = (sp_ld_max(NT) + 63) / 64;  // rows per lane in the setup prefix scans
@@ -760,6 +768,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     const int rt0 = rowptr[tr], rt1 = rowptr[tr + 1];
     // this lane's row (waves beyond the target's row blocks idle through the row phases)
     float zraw[DQ];
+    float sraw = 0.0f;   // algebraic constant-feature form: s_r = sum of the row's masked adjacency (what Zraw collapses to)
 
     // sigma(M) -> symmetrised masked adjacency, one float per directed entry
     // sArt = Abar[t][.] as a dense row (rank-1 layer-3 backward): zero except on t's neighbours, whose entries the owners of
@@ -792,6 +801,16 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             }
         SYNC();
     };
+    // algebraic constant-feature form: wt = (x (.) phi) W1, by wave 0 (its lanes c < H), whenever phi has changed
+    auto update_wt = [&]() {
+        if (wave == 0 && h == 0 && li < H) {
+            float a = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 2 * DQ; ++k) a = fmaf(sX[k] * sh.phi[k], sW1[k * 33 + li], a);
+            sh.wt[li] = a;
+        }
+    };
+    if constexpr (XC == 2) update_wt();   // (sX, the model block and phi are in place since the barrier above; publish_abar's barrier publishes wt)
     publish_abar();
     if constexpr (XC) {   // the plan promised constant feature rows for THIS X (gnnx_plan_analyze_features): anything else must fail loudly
         if (sh.xconst == 0) {
@@ -816,6 +835,28 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         if (SA.wave_active) {
             const bool first = SA.first;
             const int r = first ? SA.row : 0, re0 = SA.e0, re1 = SA.e1, nsplit = SA.nsplit, wsplit = SA.wsplit;
+            if constexpr (XC == 2) {
+                float a1[1] = {0.0f};
+                const float one[1] = {1.0f};
+                sparse_gather_const<1>(sAb, one, re0, re1, a1);
+                sparse_combine<1>(a1, SA.rem, wsplit);
+                sraw = first ? a1[0] : 0.0f;
+                float y[HQ];
+                float sp[2] = {0.0f, 0.0f};
+#pragma unroll
+                for (int q = 0; q < HQ; ++q) {
+                    y[q] = fmaf(sraw, sh.wt[2 * q + h], sh.bias[0][2 * q + h]);
+                    sp[q & 1] = fmaf(y[q], y[q], sp[q & 1]);
+                }
+                const float ss = xor32_sum(sp[0] + sp[1]);
+                const float rnorm = fmaxf(sqrt_(ss), 1e-12f);
+                const float rinv = rcp_(rnorm);
+                if (first) {
+#pragma unroll
+                    for (int q = 0; q < HQ; ++q) sU1[r * sH + 2 * q + h] = y[q] * rinv;
+                    if (h == 0) sRn1[r] = rnorm;
+                }
+            } else {
             float acc[DQ];
 #pragma unroll
             for (int q = 0; q < DQ; ++q) acc[q] = 0.0f;
@@ -838,6 +879,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 acc[q] = (first && 2 * q + h < D) ? acc[q] * ph : 0.0f;
             }
             sparse_forward_rowlocal<DQ>(acc, sW1, sh.bias[0], D, H, li, h, first, sU1 + r * sH, sRn1 + r);
+            }
         }
         SYNC();
         if constexpr (LOG)
@@ -1205,8 +1247,11 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         // ======== dX1 = Abar . dZ2 (+ dE1 on row t) -> dZ1 ; feature-mask gradient partials ========
         {
             float dfq[DQ];
+            float dvq[HQ];   // algebraic constant-feature form: this lane's share of sum_r s_r dY1[r]
 #pragma unroll
             for (int q = 0; q < DQ; ++q) dfq[q] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) dvq[q] = 0.0f;
             if (SA.wave_active) {
                 const bool first = SA.first;
                 const int r = first ? SA.row : 0, re0 = SA.e0, re1 = SA.e1, nsplit = SA.nsplit, wsplit = SA.wsplit;
@@ -1238,6 +1283,55 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                     acc[q] = (u > 0.0f) ? dx : 0.0f;
                     uu[q] = u;
                 }
+                if constexpr (XC == 2) {
+                    // dY1 of the row stays in the lane's registers (columns 2q + h); the layer-1 part of dL/dAbar is ONE number per row,
+                    // ci = dY1 . wt, handed to the row's other slots through its slot in the (otherwise unused) dZ1 array; the feature-mask
+                    // gradient needs sum_r s_r dY1[r]: this row's share goes into the reduction below
+                    float sd2[2] = {0.0f, 0.0f};
+#pragma unroll
+                    for (int q = 0; q < HQ; ++q) sd2[q & 1] = fmaf(acc[q], uu[q], sd2[q & 1]);
+                    const float sdot = xor32_sum(sd2[0] + sd2[1]);
+                    const float rinv = rcp_(first ? sRn1[r] : 1.0f);
+                    float cp[2] = {0.0f, 0.0f};
+#pragma unroll
+                    for (int q = 0; q < HQ; ++q) {
+                        const float dy = (acc[q] - uu[q] * sdot) * rinv;
+                        cp[q & 1] = fmaf(dy, sh.wt[2 * q + h], cp[q & 1]);
+                        dvq[q] = sraw * dy;     // (sraw is zero on lanes that own no row)
+                    }
+                    const float ci = xor32_sum(cp[0] + cp[1]);
+                    float* sCi = sdZ1;          // one float per row
+                    if (first && h == 0) sCi[r] = ci;
+                    wave_sync();
+                    const int ri = SA.row;
+                    if (re0 < re1) {
+                        const bool inB = SA.inB;
+                        const float cr = sCi[ri];
+                        if (!inB) {
+                            for (int e = re0 + h; e < re1; e += 2) sGe[e] = cr;
+                        } else {
+                            float d2[2 * HQ];
+#pragma unroll
+                            for (int c = 0; c < 2 * HQ; ++c) d2[c] = sdZ2[ri * sH + c];
+                            for (int e = re0 + h; e < re1; e += 4) {
+                                const bool two = e + 2 < re1;
+                                const int j0 = scol[e], j1 = scol[two ? e + 2 : e];
+                                const float* u0 = sU1 + j0 * sH;
+                                const float* u1 = sU1 + j1 * sH;
+                                float a0 = cr, a1 = 0.0f, b0 = cr, b1 = 0.0f;
+#pragma unroll
+                                for (int c = 0; c < 2 * HQ; c += 2) {
+                                    a0 = fmaf(d2[c], relu_(u0[c]), a0);
+                                    a1 = fmaf(d2[c + 1], relu_(u0[c + 1]), a1);
+                                    b0 = fmaf(d2[c], relu_(u1[c]), b0);
+                                    b1 = fmaf(d2[c + 1], relu_(u1[c + 1]), b1);
+                                }
+                                sGe[e] = a0 + a1;
+                                if (two) sGe[e + 2] = b0 + b1;
+                            }
+                        }
+                    }
+                } else {
                 const f32x16 c16 = sparse_backward_rowlocal<HQ, EXACT>(acc, uu, first ? sRn1[r] : 1.0f, sW1, D, H, li, h);
                 sparse_store_cols(c16, sdZ1 + r * sD, D, first, h);
                 wave_sync();  // the other half-lane of this row wrote the columns this lane reads next
@@ -1326,9 +1420,22 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                         }
                     }
                 }
+                }
             }
             // colsum(dZ1 * Zraw): over the 16 lanes of a DPP row (row shifts), the two rows of a half (one shuffle), then
-            // over the waves in fixed order
+            // over the waves in fixed order   (algebraic form: sum over the rows of s_r dY1[r], H columns instead of D)
+            if constexpr (XC == 2) {
+#pragma unroll
+                for (int q = 0; q < HQ; ++q) {
+                    float v = dvq[q];
+                    v += row_shl<8>(v);
+                    v += row_shl<4>(v);
+                    v += row_shl<2>(v);
+                    v += row_shl<1>(v);
+                    v = xor16_sum(v);
+                    if (li == 0) sh.dfw[wave][2 * q + h] = v;
+                }
+            } else
 #pragma unroll
             for (int q = 0; q < DQ; ++q) {
                 float v = dfq[q];
@@ -1341,6 +1448,21 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             }
         }
         SYNC();
+        if constexpr (XC == 2) {
+            if (wave == 0) {   // dL/dphi[k] = x_k W1[k] . vsum, vsum = the waves' partial sums in wave order
+                float v = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) v += sh.dfw[w][li];
+                if (h == 0) sh.vsum[li] = (li < H) ? v : 0.0f;
+                wave_sync();
+                if (tid < D) {
+                    float a = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 2 * HQ; ++c) a = fmaf(sW1[tid * 33 + c], sh.vsum[c], a);
+                    sh.dfp[tid] = sX[tid] * a;
+                }
+            }
+        } else
         if (tid < D) {
             float s = 0.0f;
 #pragma unroll
@@ -1467,6 +1589,10 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             sh.vf[tid] = v;
             sh.phi[tid] = sigmoidf_(fn);  // for the next iteration's layer 1 / edge phase (this iteration's readers are done)
         }
+        if constexpr (XC == 2) {
+            if (wave == 0) wave_sync();   // phi of all D columns (threads of wave 0) before wt is refreshed; publish_abar's barrier publishes wt
+            update_wt();
+        }
         if (iter + 1 < p.num_iters) publish_abar();  // the returned mask is the one of the LAST forward (explain.py:209-211)
     }
     SYNC();
@@ -1508,9 +1634,9 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
 
 // second launch bound = waves per SIMD the register allocation must leave room for: two 256-thread workgroups (or six
 // 64-thread ones) per CU need 2; without it the 256-thread graph-mode build took 266 registers and ran one per CU
-template <int DQ, int HQ, bool GRAPH, int NT, bool XC = false, bool LOG = false>
+template <int DQ, int HQ, bool GRAPH, int NT, int XC = 0, bool LOG = false>
 __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : 2) void k_sparse_resident(Params p, const int32_t* targets, const float* adam_tab) {
-    static_assert(!(XC && GRAPH), "constant-feature form: node mode only");
+    static_assert(!(XC && GRAPH) && !(XC == 2 && LOG), "constant-feature forms: node mode only; the logging form is the general one");
     __shared__ float pool[sp_pool_floats(NT)];
     __shared__ SparseFixed sh;
     sparse_resident_body<DQ, HQ, GRAPH, NT, XC, LOG>(p, targets[blockIdx.x], adam_tab, pool, sh, (int)threadIdx.x);
@@ -1529,7 +1655,7 @@ __host__ __device__ inline int sp_mix_tiny(int D, int H, int C) {
     const int wsz = sp_model_floats(D, H, C);
     return wsz + 8 * (sp_pool_floats(64) - wsz) + 8 * sp_fixed_floats() <= sp_pool_floats(512) ? 8 : 6;
 }
-template <int DQ, int HQ, bool XC = false, bool LOG = false>
+template <int DQ, int HQ, int XC = 0, bool LOG = false>
 __global__ __launch_bounds__(512) void k_sparse_resident_mixed(Params p, const int32_t* big_ids, int n_big, const int32_t* tiny_ids,
                                                                int n_tiny, const float* adam_tab, int per_wg, int wsz) {
     __shared__ float pool[sp_pool_floats(512)];

@@ -859,6 +859,8 @@ def host_library():
             lib = ctypes.CDLL(path)
             lib.gnnx_host_draw_masks.restype = ctypes.c_int
             lib.gnnx_host_draw_masks.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
+            lib.gnnx_host_draw_masks_sliced.restype = ctypes.c_int
+            lib.gnnx_host_draw_masks_sliced.argtypes = lib.gnnx_host_draw_masks.argtypes + [ctypes.c_int64]
             lib.gnnx_host_last_error.restype = ctypes.c_char_p
         _host_lib_cache.append(lib)
     return _host_lib_cache[0]
@@ -870,14 +872,14 @@ def default_rng_threads():
     return max(1, min(32, (os.cpu_count() or 2) // 2))
 
 
-def init_edge_masks_raw(sizes, generator=None, seeds=None, pin=False, threads=1, out=None):
+def init_edge_masks_raw(sizes, generator=None, seeds=None, pin=False, threads=1, out=None, slice_values=None):
     """The initial edge masks of a whole batch as ONE host buffer: target after target the n x n values of the single
     normal_(1, std) draw construct_edge_mask makes (explain.py:645-652), generated in place (a draw into a contiguous
     slice consumes the generator exactly like a draw into a fresh [n, n] tensor).  `seeds`: re-seed a PRIVATE generator
     before every target (the seed protocol of the golden runs) instead of consuming the caller's global stream; the
     targets are then independent and `threads` > 1 draws them on several host threads (normal_ releases the GIL).
     `pin`: the result is a view of ONE process-wide pinned buffer - upload it (set_masks_raw) before the next pinned call;
-    `out`: draw into the caller's buffer instead."""
+    `out`: draw into the caller's buffer instead; `slice_values`: slice length for large targets (gnnx_host_draw_masks_sliced; default 2^21)."""
     sizes = [int(n) for n in sizes]
     off = np.zeros(len(sizes) + 1, np.int64)
     np.cumsum(np.asarray(sizes, np.int64) ** 2, out=off[1:])
@@ -899,7 +901,8 @@ def init_edge_masks_raw(sizes, generator=None, seeds=None, pin=False, threads=1,
     if hl is not None and len(sizes):       # the seed protocol makes targets independent: C++ threads, no GIL (gnnx_host_draw_masks)
         n32 = np.ascontiguousarray(sizes, np.int32)
         sd = np.ascontiguousarray(np.asarray(seeds).astype(np.int64))
-        if hl.gnnx_host_draw_masks(len(sizes), n32.ctypes.data, sd.ctypes.data, off.ctypes.data, buf.data_ptr(), int(max(1, threads))) != 0:
+        if hl.gnnx_host_draw_masks_sliced(len(sizes), n32.ctypes.data, sd.ctypes.data, off.ctypes.data, buf.data_ptr(), int(max(1, threads)),
+                                          int(slice_values) if slice_values else 1 << 21) != 0:
             raise GnnxError(hl.gnnx_host_last_error().decode())
         return buf
     if seeds is None or threads <= 1 or len(sizes) < 2 * threads:

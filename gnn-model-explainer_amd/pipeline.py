@@ -14,6 +14,7 @@ adjacency handed back (:208-221).  Here a batch runs as three stages on three HI
 Batch k + 1 is prepared and batch k - 1 fetched while batch k optimises, so a long job costs max(stage) per batch instead of
 their sum; nothing is shared between batches but the resident graph.  Results come back in order as engine.EdgeMasks.
 """
+import os
 import queue
 import threading
 import time
@@ -30,7 +31,8 @@ class _Prepared:
 
 
 class BatchPipeline:
-    def __init__(self, graph, state_dict, labels, hyper, n_hops=3, seed_base=1000, rng_threads=None, depth=3, prepare_workers=2, reserve_cus=0, lib=None):
+    def __init__(self, graph, state_dict, labels, hyper, n_hops=3, seed_base=1000, rng_threads=None, depth=3, prepare_workers=2, reserve_cus=0, lib=None,
+                 device_hook=None, rng_threads_big=None):
         """graph: engine.DeviceGraph (resident); labels [N]: the label the prediction loss uses (explain.py:750-753); the initial
         mask of target v is drawn from a generator seeded with seed_base + v (the seed protocol of the golden runs)."""
         self.graph, self.sd, self.labels, self.hyper = graph, state_dict, np.asarray(labels), hyper
@@ -38,7 +40,12 @@ class BatchPipeline:
         self._edge_hyper = dataclasses.replace(hyper, edge_results_only=True)      # results leave as edge lists: no dense Abar blocks
         self.n_hops, self.seed_base = int(n_hops), int(seed_base)
         self.rng_threads = int(rng_threads) if rng_threads else engine.default_rng_threads()
-        import os
+        # batches of more than 2e7 normals (BA-House x100k: 1e9 per 16 384 targets) are bound by the draw itself: up to half the host's cores,
+        # the largest targets cut into slices (gnnx_host_draw_masks_sliced); small batches lose to the hand-off beyond ~32 threads
+        self.rng_threads_big = int(rng_threads_big) if rng_threads_big else max(self.rng_threads, min(96, (os.cpu_count() or 2) // 2))
+        # device_hook(values [E] on the device, job): called on the fetch stream once a batch's edge values are gathered, before their D2H
+        # copy - the sharded job all-gathers the masks of every rank there (RCCL over xGMI; bench.py --gpus N)
+        self.device_hook = device_hook
         depth = int(os.environ.get("GNNX_PIPE_DEPTH", depth))                        # (measurement knobs)
         reserve_cus = int(os.environ.get("GNNX_PIPE_RESERVE", reserve_cus))
         prepare_workers = int(os.environ.get("GNNX_PIPE_WORKERS", prepare_workers))
@@ -152,7 +159,8 @@ class BatchPipeline:
                 t_r = time.perf_counter()
                 total = int((dn.sizes.astype(np.int64) ** 2).sum())
                 try:
-                    box["raw"] = engine.init_edge_masks_raw(dn.sizes, seeds=self.seed_base + targets, threads=self.rng_threads,
+                    box["raw"] = engine.init_edge_masks_raw(dn.sizes, seeds=self.seed_base + targets,
+                                                            threads=self.rng_threads_big if total > 2e7 else self.rng_threads,
                                                             out=self._pin("raw", total, torch.float32, raw_slot))
                 except Exception as e:      # noqa: BLE001 - re-raised on the preparing thread
                     box["err"] = e
@@ -230,6 +238,8 @@ class BatchPipeline:
             self.s_fetch.wait_event(done)
             job.use_stream(self.s_fetch)
             vals_d = job.gather_edges_device()
+            if self.device_hook is not None:
+                self.device_hook(vals_d[:p.E], job)
             vals = self._pin("vals", max(p.E, 1), torch.float32, slot)
             vals[:p.E].copy_(vals_d[:p.E], non_blocking=True)
             fm = self._pin("fmask", job.T * engine.FEAT_STRIDE, torch.float32, slot).view(job.T, engine.FEAT_STRIDE)

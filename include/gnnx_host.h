@@ -22,6 +22,14 @@ extern "C" {
  * equal shares of the values.  Returns 0, or non-zero with the text in gnnx_host_last_error(). */
 int gnnx_host_draw_masks(int32_t num_targets, const int32_t* n, const int64_t* seeds, const int64_t* off, float* out, int32_t threads);
 
+/* The same draw with the slice length given: a target of more than 2 x slice_values values (a multiple of 16; the call above uses 2^21)
+ * is drawn as slices of that many values by several threads - a walker steps the raw mt19937 stream of the target and leaves the engine
+ * state at every slice boundary, ATen's normal_ then draws every slice from its state.  ATen's CPU normal_ fills a contiguous float
+ * tensor with one engine draw per value before it transforms 16 values at a time, so the slices are bit-identical to the one-call draw;
+ * without this the largest target of a batch (BA-House x100k: n = 5600, 31 M values) bounds the whole draw at 0.3 s. */
+int gnnx_host_draw_masks_sliced(int32_t num_targets, const int32_t* n, const int64_t* seeds, const int64_t* off, float* out, int32_t threads,
+                                int64_t slice_values);
+
 const char* gnnx_host_last_error(void);
 
 #ifdef __cplusplus

@@ -216,8 +216,22 @@ class ClosedFormOracle:
             dXd = direct_grads(dE, n, dims, self.t)
         dZ, dX0 = backward(Abar, U, R, w, dXd, (Xin, RS) if self.bn else None)
         G = grad_Abar(dZ, Xin, self.yhat, n, not self.graph_mode)
+        fsum = (dX0 * self.X).sum(0, dtype=F32)
+        noise = getattr(self, "grad_noise", None)
+        if noise is not None:      # conditioning probe (tests/golden/make_golden_noise_probe.py): every iteration, noise of +-1 ulp of the
+            # MAGNITUDE OF THE SUMMANDS (sum of |products|: the forward error scale of a sum, whatever its order) on the two quantities
+            # of the gradient that are long sums of products - dL/dAbar and the column sums of the feature-mask gradient.  Another
+            # summation order, or an algebraically equal formula (the kernels form colsum(dZ1 (.) (Abar X)) where this oracle forms
+            # colsum((Abar dZ1) (.) X)), differs by that much.  Where the summands cancel, or the prediction part of a gradient nearly
+            # cancels its regulariser part, Adam's scale-free step turns it into a large relative change of the step - the amplification
+            # that a perturbation of the START alone (make_golden_windows.py probe (ii)) under-samples.
+            eps = F32(2.0 ** -23)
+            Gabs = (np.abs(np.concatenate(dZ, 1)) @ np.abs(np.concatenate(Xin, 1)).T).astype(F32)
+            G = (G + eps * Gabs * (2 * noise.random(G.shape, dtype=np.float32) - 1)).astype(F32)
+            fabs = (np.abs(Abar) @ np.abs(dZ[0]) * np.abs(self.X)).sum(0, dtype=F32)
+            fsum = (fsum + eps * fabs * (2 * noise.random(fsum.shape, dtype=np.float32) - 1)).astype(F32)
         dM = mask_grad(G, self.A, S, n)
-        df = (((dX0 * self.X).sum(0, dtype=F32) + C_FEAT_SIZE / F32(self.D)) * phi * (F32(1) - phi)).astype(F32)
+        df = ((fsum + C_FEAT_SIZE / F32(self.D)) * phi * (F32(1) - phi)).astype(F32)
         # loss terms (logging parity only)
         size_l = C_SIZE * S.sum(dtype=F32)
         ent_l = C_ENT * (-S * np.log(S) - (F32(1) - S) * np.log(F32(1) - S)).mean(dtype=F32)

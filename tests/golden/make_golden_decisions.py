@@ -47,7 +47,7 @@ sys.path.insert(0, ROOT)
 
 import make_golden_windows as mgw  # noqa: E402
 
-EPOCHS, NEAR = 300, 1e-5
+EPOCHS, NEAR = 300, 1e-4
 POW = (1 << np.arange(20)).astype(np.uint32)
 
 

@@ -243,7 +243,8 @@ class Decisions:
         self.ids = z["targets"] if "targets" in z.files else z["graphs"]
         self.T = len(self.ids)
         self.graph_mode = "pool0" in z.files
-        self.near_tol = float(z["near"])
+        self.near_tol = float(z["near"])          # the NEAR list holds every gate with |U| below this (1e-4) and every pool with a smaller margin
+        self.near_tol_strict = 1e-5               # = the parity tolerance: a decision the reference takes by less may differ in any window
 
     def gate_words(self, k, e0, e1):
         """uint32 [e1 - e0, n_k, 2]: the reference's sign words at epochs e0 .. e1 - 1 of target k (fixture index)"""

@@ -109,6 +109,16 @@ def test_host_rng_library_draws_the_reference_masks_bit_for_bit():
         got = engine.init_edge_masks_raw(sizes, seeds=seeds, threads=threads)
         assert torch.equal(got, want), threads
     assert engine.init_edge_masks_raw([], seeds=[], threads=4).numel() == 0
+    # large targets are drawn as slices from engine states a walker leaves at the slice boundaries (gnnx_host_draw_masks_sliced): sizes
+    # around the slice length, totals that are and are not multiples of 16 (ATen redraws the last 16 values of such a tensor)
+    sizes = [9, 40, 33, 16, 41, 5, 12, 57]         # 81, 1600, 1089, 256, 1681, 25, 144, 3249 values
+    seeds = 2000 + np.arange(len(sizes)) * 3
+    want = torch.cat([helpers.seeded_mask0(int(s) - 1000, n).flatten() for s, n in zip(seeds, sizes)])
+    for threads, sl in ((4, 64), (2, 256), (7, 16), (3, 1024), (1, 64)):
+        got = engine.init_edge_masks_raw(sizes, seeds=seeds, threads=threads, slice_values=sl)
+        assert torch.equal(got, want), (threads, sl)
+    big = engine.init_edge_masks_raw([1500], seeds=[77], threads=8)          # 2.25 M values: sliced at the default length
+    assert torch.equal(big, helpers.seeded_mask0(77 - 1000, 1500).flatten())
 
 
 def test_engine_fails_loudly_without_gpu():

@@ -42,14 +42,15 @@ def _gate_words(U):
     return ((U > 0) * (1 << np.arange(U.shape[1]))).sum(1).astype(np.uint32)
 
 
-def test_logging_form_mixed_launch_loss_and_gates_vs_closed_form(be):
+def test_logging_form_mixed_launch_loss_and_gates_vs_closed_form(be, monkeypatch):
     """One mixed launch (64-thread and 512-thread classes, n = 6 / 48 / 310) with loss logging and the decision trace switched on: the
     five loss terms of every iteration agree with the closed form (the size and entropy sums include the n^2 - 2E entries OFF the edges,
     advanced by k_dead_entries), the gate words are the closed form's signs of U1 (rows within two hops) and U2 (the target and its
-    neighbours), and the masks are those of the plain run bit for bit."""
+    neighbours), and the masks are those of the plain run of the general form (which the logging form is) bit for bit."""
     ck = helpers.load_ckpt("syn1")
     subs = [_node_case("syn1", 302)[2], _node_case("syn1", 309)[2], _largest_syn1_case()]
     iters = 5
+    monkeypatch.setenv("GNNX_XCONST", "1")       # the plain run below: the general form's arithmetic (0 and 1 are bit-identical; the default, 2, is not)
     job = be.job(subs, ck["sd"])
     assert list(job.route()) == [6, 8, 8]
     plain = job.run([s.mask0 for s in subs], Hyper(num_iters=iters))
@@ -123,20 +124,31 @@ def test_trace_needs_the_sparse_resident_kernel(be):
 
 
 def test_constant_feature_form_is_bit_identical_to_the_general_form(be, monkeypatch):
-    """syn1 / syn4 features are constant rows (gengraph.py: ConstFeatureGen): the plan picks the constant-feature form
-    (gnnx_plan_analyze_features); GNNX_XCONST=0 keeps the general one.  Same products in the same order: every output bit-equal."""
+    """syn1 / syn4 features are constant rows (gengraph.py: ConstFeatureGen): the plan picks a constant-feature form
+    (gnnx_plan_analyze_features).  GNNX_XCONST=1: the general form's products in the general form's order without the gathers - every
+    output bit-equal to GNNX_XCONST=0 (the general form); the default, 2, is the algebraic form (layer 1 as a function of the row sums of
+    the masked adjacency): same mathematics, other rounding - within round-off of the others and of the closed form."""
     ck = helpers.load_ckpt("syn1")
     subs = [_node_case("syn1", 302)[2], _node_case("syn1", 309)[2], _largest_syn1_case()]
-    outs = []
-    for flag in ("1", "0"):
+    outs = {}
+    for flag in ("1", "0", "2"):
         monkeypatch.setenv("GNNX_XCONST", flag)
         job = be.job(subs, ck["sd"])
         job.set_masks([s.mask0 for s in subs])
         job.launch(Hyper(num_iters=6), keep_state=True)
         em = job.fetch_edges(with_mask=True)
-        outs.append((em.masked_adj, em.mask_rc, em.feat_mask) + job.fetch_state_edges()[1:])
-    for a, b in zip(*outs):
+        outs[flag] = (em.masked_adj, em.mask_rc, em.feat_mask) + job.fetch_state_edges()[1:]
+    for a, b in zip(outs["1"], outs["0"]):
         assert np.array_equal(a, b)
+    assert not np.array_equal(outs["2"][1], outs["0"][1])          # (another rounding: the form really ran)
+    for a, b, tol in zip(outs["2"], outs["0"], (1e-6, 1e-5, 1e-5, 1e-6, 1e-8, 1e-5)):
+        assert np.abs(a.astype(np.float64) - b).max() < tol
+    eoff = np.concatenate([[0], np.cumsum([int((np.triu(s.adj, 1) != 0).sum()) for s in subs])])
+    for i, sg in enumerate(subs):
+        o = closed_form.ClosedFormOracle(sg.adj, sg.feat, ck["sd"], sg.gt_label, sg.pred_label, sg.target_row, sg.mask0)
+        want = o.run(6)
+        r, c = np.nonzero(np.triu(sg.adj, 1))
+        assert np.abs(outs["2"][0][eoff[i]:eoff[i + 1]] - want[r, c]).max() < 2e-6
 
 
 def test_constant_feature_form_refuses_other_features_loudly(be):

@@ -32,10 +32,13 @@ src = src.replace(d1, "                PROBE(24);\n" + d1.replace("wsplit);\n", 
 d2 = "                sparse_store_cols(c16, sdZ1 + r * sD, D, first, h);\n                wave_sync();  // the other half-lane"
 assert d2 in src
 src = src.replace(d2, "                PROBE(26);\n" + d2, 1)
+d2a = "                    float* sCi = sdZ1;          // one float per row\n"      # the algebraic constant-feature form's counterpart of d2
+assert d2a in src
+src = src.replace(d2a, "                    PROBE(26);\n" + d2a, 1)
 d3 = "            // colsum(dZ1 * Zraw): over the 16 lanes of a DPP row"
 assert d3 in src
 src = src.replace(d3, "            PROBE(27);\n" + d3, 1)
-d4 = "        SYNC();\n        if (tid < D) {\n            float s = 0.0f;\n#pragma unroll\n            for (int w = 0; w < NW; ++w) s += sh.dfw[w][tid];"
+d4 = "        SYNC();\n        if constexpr (XC == 2) {\n            if (wave == 0) {   // dL/dphi[k]"
 assert d4 in src
 src = src.replace(d4, "        PROBE(28);\n" + d4, 1)
 src = src.replace("        if (iter + 1 < p.num_iters) publish_abar();  // the returned mask", "        PROBE(%d);\n        if (iter + 1 < p.num_iters) publish_abar();\n        PROBE(%d);  // the returned mask" % (k, k + 1), 1)
