@@ -173,6 +173,27 @@ def test_config4_graph_mode_512_of_4337_graphs_vs_reference():
     assert (e_dense[wd] <= TOL).sum() >= 0.6 * wd.sum()
 
 
+def test_config4_64_graphs_against_the_reference_outcome_sets():
+    """The 64 graphs of config4_explain.npz with the pre-declared alternate outcomes of the one sampler (make_golden_branches.py --what
+    config4: 24 one-ulp trials per graph; tests/golden/config4_branches.npz - 41 of the 64 graphs move by more than 2e-6 under a 1-ulp
+    perturbation of the initial mask, 37 by more than 1e-5, up to 6e-2: the max-pool ties of symmetric atoms).  Three numbers as for the
+    node configs: strict / with alternates / ungated; the gate proper of config 4 is tests/test_decision_parity.py (every decision of
+    every epoch against the live reference's), this one shows what the outcome-set argument alone buys in graph mode."""
+    z = _full("config4_explain.npz")
+    br = helpers.load_branches("config4")
+    assert br is not None and len(br["alt_target"]) > 0
+    sd = {k[2:]: z[k] for k in z.files if k.startswith("w:")}
+    gids = z["graphs"]
+    A, X, nn, y = synthetic.molecule_like_graphs(int(gids.max()) + 1, seed=0)
+    subs = [Subgraph(A[g], X[g], int(y[g]), 0, None, helpers.seeded_mask0(g, A.shape[1]).numpy()) for g in gids]
+    job = MaskOptimJob(subs, sd, graph_mode=True)
+    job.set_masks([s.mask0 for s in subs])
+    job.launch(Hyper(num_iters=int(z["epochs"])))
+    em = job.fetch_edges()
+    assert np.array_equal(em.eoff, z["eoff"])
+    _check(z, em.masked_adj, em.feat_mask, em.eoff, "full", "config4 (64 graphs)", 20, br, min_frac=0.90, jump_max=helpers.CONFIG4_WINDOW_JUMP)
+
+
 def test_config5_ba100k_route_stratified_targets_vs_reference():
     """BASELINE config 5 (BA-House x100k, 99 997 nodes): real targets from n = 6 to n > 4095, hubs of up to 749
     neighbours, one per kernel route - 64- / 256- / 512-thread sparse resident classes, k_sparse_large (n > 2000 and
