@@ -40,9 +40,11 @@ class BatchPipeline:
         self._edge_hyper = dataclasses.replace(hyper, edge_results_only=True)      # results leave as edge lists: no dense Abar blocks
         self.n_hops, self.seed_base = int(n_hops), int(seed_base)
         self.rng_threads = int(rng_threads) if rng_threads else engine.default_rng_threads()
-        # batches of more than 2e7 normals (BA-House x100k: 1e9 per 16 384 targets) are bound by the draw itself: up to half the host's cores,
-        # the largest targets cut into slices (gnnx_host_draw_masks_sliced); small batches lose to the hand-off beyond ~32 threads
-        self.rng_threads_big = int(rng_threads_big) if rng_threads_big else max(self.rng_threads, min(96, (os.cpu_count() or 2) // 2))
+        # batches of more than 2e7 normals (BA-House x100k: 1e9 per 16 384 targets = 4 GB written): measured on the 256-CPU host of the GPU box
+        # (tools/probe_rng_big.py, profiles/r04_host_rng_16384targets.txt) 32 threads 94-140 ms, 64 threads 100-190, 96-128 threads 160-230 -
+        # the draw is bound by the memory system, not the cores; the largest targets are cut into slices (gnnx_host_draw_masks_sliced:
+        # the 31 M values of the n = 5600 target 63 -> 10-14 ms), which matters when one target dominates a batch
+        self.rng_threads_big = int(rng_threads_big) if rng_threads_big else self.rng_threads
         # device_hook(values [E] on the device, job): called on the fetch stream once a batch's edge values are gathered, before their D2H
         # copy - the sharded job all-gathers the masks of every rank there (RCCL over xGMI; bench.py --gpus N)
         self.device_hook = device_hook

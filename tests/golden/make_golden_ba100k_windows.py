@@ -155,6 +155,14 @@ def main():
         out[nm] = np.stack([cat(i, j) for i in range(nck)]).astype(np.float32)
     for j, nm in ((3, "f"), (4, "mf"), (5, "vf")):
         out[nm] = np.stack([np.stack([r["coarse"][i][j] for r in res]) for i in range(nck)]).astype(np.float32)
+    # (the keys helpers.Windows expects of every <name>_windows.npz: no gate probe, no 10-epoch snapshots here)
+    E, D = int(out["eoff"][-1]), out["f"].shape[2]
+    out.update(gate50=np.full((T, nck), np.inf, np.float32), gate=np.float64(5e-7), fine_tw=np.zeros((0, 2), np.int32), fine_off=np.zeros(1, np.int64),
+               cond10=np.zeros((0, 5), np.float32), sens10=np.zeros((0, 5), np.float32), gate10=np.zeros((0, 5), np.float32))
+    for nm in ("fine_M", "fine_m", "fine_v"):
+        out[nm] = np.zeros((4, 0, 2), np.float32)
+    for nm in ("fine_f", "fine_mf", "fine_vf"):
+        out[nm] = np.zeros((4, 0, D), np.float32)
     np.savez_compressed(os.path.join(HERE, "ba100k_windows.npz"), **out)
     dec = mgd.assemble([r["piece"] for r in res], "targets", False)
     np.savez_compressed(os.path.join(HERE, "ba100k_decisions.npz"), **dec)
