@@ -26,14 +26,9 @@ timeout 300 python tools/probe_logging.py > $O/r04_loss_logging_explain_node.txt
 GNNX_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29617 bench.py --gpus 4 --steps 2 --warmup 1 --reps 1 --targets 4096 --no-single-gpu-leg > $O/r04_bench_sharded_4ranks_one_gpu_gloo.json 2> $O/bench_sharded.err
 timeout 300 python tools/probe_sparse.py 0 2>/dev/null | grep -v amdgpu > $O/r04_timeline_sparse_resident_syn1_n310.txt
 timeout 300 python tools/probe_sparse.py 150 2>/dev/null | grep -v amdgpu > $O/r04_timeline_sparse_resident_syn1_one_wave.txt
-# the dense streaming pair (k_conv / k_mask) on the BA-House x100k streaming set, the access-pattern micro-benchmark, method=att
-GNNX_SPARSE_RESIDENT=0 timeout 300 python tools/probe_conv.py 1024 1:0,1:1024,2:0 2>/dev/null | grep WIDE > $O/r04_conv_streaming_set.txt
-GNNX_SPARSE_RESIDENT=0 timeout 300 python tools/probe_conv_timeline.py 2>/dev/null | grep -v amdgpu > $O/r04_timeline_k_conv_ba100k.txt
-(cd tools/micro && for a in "4992 3" "1056 64" "4992 1"; do timeout 60 ./stream_pattern $a; done) > $O/r04_micro_stream_pattern.txt 2>&1
+# (the dense streaming pair was not touched in round 4: its probes / micro-benchmark / PMC passes of round 3 stand - profiles/r03_*)
 timeout 300 python tools/probe_att.py 2>/dev/null | grep -v Warning > $O/r04_method_att_syn1_400targets.txt
-bash tools/gpu_pmc_stream.sh ${1:-final_r04}/pmc_stream > /dev/null 2>&1
 bash tools/gpu_pmc.sh ${1:-final_r04}/pmc_syn1 syn1 > /dev/null 2>&1
-bash tools/gpu_pmc.sh ${1:-final_r04}/pmc_ba100k ba100k > /dev/null 2>&1
 cat $O/pytest_gpu_tail.txt
 for f in $O/r04_bench_*.json; do python -c "
 import json,sys; d=json.load(open('$f')); print('$f'.split('/')[-1], round(d['value']), round(d['ms_per_step'],3), 'loop', round(d.get('loop_only',{}).get('ms_per_step',0),3), d['roofline']['kernel'][:34], round(d['roofline']['frac'],4), d.get('parity',{}).get('rule','')[:80])"; done
