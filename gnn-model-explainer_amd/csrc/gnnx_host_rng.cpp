@@ -220,3 +220,107 @@ extern "C" int gnnx_host_draw_masks_sliced(int32_t T, const int32_t* n, const in
     }
     return 0;
 }
+
+// The edge-sparse kernels read the initial mask only on the EDGES of a sub-graph (the other n^2 - 2E entries of construct_edge_mask's
+// draw never reach an output of the reference, explain.py:665-678), but the values on the edges are positions of ONE mt19937 stream
+// per target, so the whole stream still has to be generated - what need not happen is writing it: the full draw of the 16 384-target
+// BA-House x100k set is 4 GB through the host's memory system (94-140 ms on 32 threads, SLOWER on more: tools/probe_rng_big.py), plus a
+// 4 GB H2D copy and a scatter kernel.  Here every thread draws its part of the stream slice by slice into a cache-resident buffer (the
+// same ATen normal_ calls on the same engine states as gnnx_host_draw_masks_sliced: bit-identical values) and keeps the two values of
+// every edge, out[e] = (M[r][c], M[c][r]) for edge e = (r, c) of the target's upper-triangle edge list - 12 MB instead of 4 GB leave
+// the host, and the draw scales with the cores again.
+// rc [E][2] int32: the edges of all targets, target after target (eoff [T + 1]), r < c, local node ids.  A chunk of a large target starts
+// from the seeded engine advanced by its first value's index (mt_advance: 0.3 ns per skipped draw).
+extern "C" int gnnx_host_draw_edge_masks(int32_t T, const int32_t* n, const int64_t* seeds, const int64_t* eoff, const int32_t* rc, float* out,
+                                         int32_t threads, int64_t slice_values) {
+    if (T < 0 || (T > 0 && (!n || !seeds || !eoff || !rc || !out))) {
+        g_err = "null argument";
+        return 1;
+    }
+    if (T == 0) return 0;
+    threads = std::max(1, std::min<int32_t>(threads, 128));
+    const int64_t L = std::max<int64_t>(1024, slice_values / 16 * 16);        // values per normal_ call (cache-resident buffer)
+    const int64_t CH = 32 * L;                                                   // values per work item
+    struct Chunk { int k; int64_t a, b; };
+    std::vector<Chunk> chunks;
+    for (int k = 0; k < T; ++k) {
+        const int64_t nn = (int64_t)n[k] * n[k];
+        if (nn == 0 || eoff[k + 1] == eoff[k]) continue;                         // no edge: nothing of this target's stream is needed
+        for (int64_t a = 0; a < nn; a += CH) {
+            const int64_t b = (nn - a < CH + 16) ? nn : a + CH;
+            chunks.push_back(Chunk{k, a, b});
+            if (b == nn) break;
+        }
+    }
+    // largest work items first, then dynamic hand-out
+    std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk& x, const Chunk& y) { return (x.b - x.a) > (y.b - y.a); });
+    // per target: (position in the n x n stream, index into out) of its 2E entries, sorted by position - built by the first chunk that needs it
+    std::vector<std::vector<std::pair<int64_t, int64_t>>> pos(T);
+    std::vector<std::once_flag> built(T);
+    std::atomic<bool> failed{false};
+    std::string err;
+    std::mutex err_mu;
+    auto work = [&](int ci) {
+        try {
+            c10::InferenceMode ng;
+            const Chunk c = chunks[ci];
+            const int k = c.k;
+            const int64_t nk = n[k], nn = nk * nk;
+            std::call_once(built[k], [&] {
+                auto& p = pos[k];
+                p.reserve(2 * (size_t)(eoff[k + 1] - eoff[k]));
+                for (int64_t e = eoff[k]; e < eoff[k + 1]; ++e) {
+                    const int64_t r = rc[2 * e], cc = rc[2 * e + 1];
+                    p.emplace_back(r * nk + cc, 2 * e);
+                    p.emplace_back(cc * nk + r, 2 * e + 1);
+                }
+                std::sort(p.begin(), p.end());
+            });
+            const auto& p = pos[k];
+            size_t it = std::lower_bound(p.begin(), p.end(), std::make_pair(c.a, (int64_t)-1)) - p.begin();
+            if (it == p.size() || p[it].first >= c.b) return;                     // no edge entry in this chunk: its values are not needed
+            at::Generator gen = at::detail::createCPUGenerator(0);
+            gen.set_current_seed((uint64_t)seeds[k]);
+            auto* impl = at::check_generator<at::CPUGeneratorImpl>(gen);
+            const double std_ = std::sqrt(2.0) * std::sqrt(2.0 / ((double)nk + (double)nk));
+            std::vector<float> buf((size_t)(L + 16));
+            int64_t at_draw = 0;      // draws the engine has made
+            for (int64_t s = c.a; s < c.b;) {
+                int64_t t = (c.b - s < L + 16) ? c.b : s + L;                     // (no last call shorter than 16 values: ATen redraws the last 16 of a ragged tensor)
+                if (it < p.size() && p[it].first >= t && t < c.b) {              // nothing wanted in [s, t): skip it without drawing
+                    s = t;
+                    continue;
+                }
+                if (at_draw != s) {
+                    at::mt19937 eng((uint64_t)seeds[k]);
+                    mt_advance(eng, 0, s);
+                    impl->set_engine(eng);
+                    impl->set_next_float_normal_sample(std::optional<float>());
+                    at_draw = s;
+                }
+                at::Tensor view = at::from_blob(buf.data(), {t - s}, at::TensorOptions().dtype(at::kFloat));
+                view.normal_(1.0, std_, gen);
+                at_draw = t;                                                      // (a ragged last call draws 16 more, but it is the last of its target)
+                for (; it < p.size() && p[it].first < t; ++it) out[p[it].second] = buf[(size_t)(p[it].first - s)];
+                s = t;
+                if (it == p.size() || p[it].first >= c.b) break;
+            }
+        } catch (const std::exception& e) {
+            std::lock_guard<std::mutex> lk(err_mu);
+            failed = true;
+            err = e.what();
+        }
+    };
+    if (chunks.size() == 1 || threads == 1) {
+        for (int ci = 0; ci < (int)chunks.size(); ++ci) work(ci);
+    } else if (!chunks.empty()) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (!g_pool || g_pool->size() < threads) g_pool = new Pool(std::max<int>(threads, 16));
+        g_pool->run((int)chunks.size(), work);
+    }
+    if (failed) {
+        g_err = err;
+        return 1;
+    }
+    return 0;
+}

@@ -544,6 +544,20 @@ class MaskOptimJob:
         _check(self.lib, self.lib.gnnx_scatter_masks(self.handle, self._raw.data_ptr(), self.M.data_ptr(), self._stream()))
         self._leave()
 
+    def set_masks_on_edges(self, vals: torch.Tensor):
+        """Upload the initial masks given on the edges only (init_edge_masks_on_edges: [E, 2] in the order of the edge layout) and place them
+        in M.  The other entries of M are NOT initialised: only for jobs whose every target runs on an edge-sparse kernel (route 4-8) and
+        whose results leave as edge lists - those kernels read M nowhere else."""
+        self._edge_layout()
+        E = int(self._eoff[-1])
+        if vals.dtype != torch.float32 or vals.numel() != 2 * E:
+            raise ValueError("vals must hold 2 E float32 values")
+        v = vals.view(-1, 2).to(self.device, non_blocking=True)
+        pos = self._epos[:E]
+        self.M.index_put_((pos[:, 0],), v[:, 0])
+        self.M.index_put_((pos[:, 1],), v[:, 1])
+        self._edge_vals0 = v
+
     def set_masks_raw_resident(self):
         """Reset M to the initial masks from the RNG stream uploaded by the last set_masks_raw (a device-only op)."""
         self._enter()
@@ -861,6 +875,9 @@ def host_library():
             lib.gnnx_host_draw_masks.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
             lib.gnnx_host_draw_masks_sliced.restype = ctypes.c_int
             lib.gnnx_host_draw_masks_sliced.argtypes = lib.gnnx_host_draw_masks.argtypes + [ctypes.c_int64]
+            lib.gnnx_host_draw_edge_masks.restype = ctypes.c_int
+            lib.gnnx_host_draw_edge_masks.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                      ctypes.c_int32, ctypes.c_int64]
             lib.gnnx_host_last_error.restype = ctypes.c_char_p
         _host_lib_cache.append(lib)
     return _host_lib_cache[0]
@@ -911,6 +928,29 @@ def init_edge_masks_raw(sizes, generator=None, seeds=None, pin=False, threads=1,
     cuts = [0] + [int(np.searchsorted(off, off[-1] * i / threads)) for i in range(1, threads)] + [len(sizes)]   # equal shares of the floats
     list(_rng_pool().map(lambda i: fill(cuts[i], cuts[i + 1], torch.Generator()), range(threads)))
     return buf
+
+
+def init_edge_masks_on_edges(sizes, seeds, eoff, rc, threads=1, out=None, slice_values=1 << 17):
+    """The initial edge masks of a batch on the EDGES only: out [E, 2] = (M[r][c], M[c][r]) for every upper-triangle edge (r, c) of every
+    target (rc [E, 2] int32 local node ids, eoff [T + 1]) - exactly the values init_edge_masks_raw puts at those positions (the same ATen
+    draws; gnnx_host_draw_edge_masks), without writing the sum(n^2) values in between.  The edge-sparse kernels read nothing else."""
+    hl = host_library()
+    if hl is None:
+        raise GnnxError("libgnnx_host.so is not built")
+    E = int(eoff[-1])
+    if out is None:
+        out = torch.empty(E, 2, dtype=torch.float32)
+    if out.dtype != torch.float32 or out.numel() != 2 * E or not out.is_contiguous():
+        raise ValueError("out must be a contiguous float32 buffer of 2 E values")
+    n32 = np.ascontiguousarray(sizes, np.int32)
+    sd = np.ascontiguousarray(np.asarray(seeds).astype(np.int64))
+    eo = np.ascontiguousarray(eoff, np.int64)
+    rc = rc if isinstance(rc, np.ndarray) else rc.numpy()
+    rc = np.ascontiguousarray(rc[:E], np.int32)
+    if E and hl.gnnx_host_draw_edge_masks(len(n32), n32.ctypes.data, sd.ctypes.data, eo.ctypes.data, rc.ctypes.data, out.data_ptr(), int(max(1, threads)),
+                                          int(slice_values)) != 0:
+        raise GnnxError(hl.gnnx_host_last_error().decode())
+    return out
 
 
 def init_edge_mask(n, generator=None):

@@ -32,7 +32,7 @@ class _Prepared:
 
 class BatchPipeline:
     def __init__(self, graph, state_dict, labels, hyper, n_hops=3, seed_base=1000, rng_threads=None, depth=3, prepare_workers=3, reserve_cus=0, lib=None,
-                 device_hook=None, rng_threads_big=None):
+                 device_hook=None, rng_threads_big=None, edge_draw_min_values=2e7):
         """graph: engine.DeviceGraph (resident); labels [N]: the label the prediction loss uses (explain.py:750-753); the initial
         mask of target v is drawn from a generator seeded with seed_base + v (the seed protocol of the golden runs)."""
         self.graph, self.sd, self.labels, self.hyper = graph, state_dict, np.asarray(labels), hyper
@@ -48,6 +48,11 @@ class BatchPipeline:
         # device_hook(values [E] on the device, job): called on the fetch stream once a batch's edge values are gathered, before their D2H
         # copy - the sharded job all-gathers the masks of every rank there (RCCL over xGMI; bench.py --gpus N)
         self.device_hook = device_hook
+        # large batches on the edge-sparse kernels: keep only the edge entries of the host draw (see _prepare); compute-bound, so it takes
+        # more threads than the memory-bound full draw (GNNX_PIPE_EDGE_DRAW=0 switches it off: measurement knob)
+        self.edge_draw = bool(int(os.environ.get("GNNX_PIPE_EDGE_DRAW", "1")))
+        self.edge_draw_min_values = float(edge_draw_min_values)      # batches of fewer normals keep the full draw (it overlaps the plan; syn1: 0.5 ms)
+        self.rng_threads_edges = int(os.environ.get("GNNX_PIPE_EDGE_THREADS", max(self.rng_threads, min(96, (os.cpu_count() or 2) // 2))))
         depth = int(os.environ.get("GNNX_PIPE_DEPTH", depth))                        # (measurement knobs)
         reserve_cus = int(os.environ.get("GNNX_PIPE_RESERVE", reserve_cus))
         prepare_workers = int(os.environ.get("GNNX_PIPE_WORKERS", prepare_workers))
@@ -167,8 +172,14 @@ class BatchPipeline:
                 except Exception as e:      # noqa: BLE001 - re-raised on the preparing thread
                     box["err"] = e
                 box["ms"] = (time.perf_counter() - t_r) * 1e3
+            # Batches of more than 2e7 normals whose every target runs on an edge-sparse kernel: the host keeps only the values on the
+            # EDGES of its draw (gnnx_host_draw_edge_masks: 12 MB instead of 4 GB for the 16 384-target BA-House x100k set - no 4 GB of
+            # pinned writes, H2D copy and scatter).  It needs the edge list first, so the draw follows the plan instead of overlapping it.
+            total_values = int((dn.sizes.astype(np.int64) ** 2).sum())
+            edges_only = self.edge_draw and total_values > self.edge_draw_min_values and not self.hyper.record_loss
             th = threading.Thread(target=draw)
-            th.start()
+            if not edges_only:
+                th.start()
             t1 = time.perf_counter()
             job = engine.MaskOptimJob.from_csr(self.graph, dn, None, self.labels[targets], self.sd, lib=self.lib)
             p.times["plan_pack_route_ms"] = (time.perf_counter() - t1) * 1e3
@@ -179,14 +190,26 @@ class BatchPipeline:
             rc_host[:E].copy_(job._rc[:E], non_blocking=True)
             p.times["edge_layout_ms"] = (time.perf_counter() - t1b) * 1e3
             p.times["plan_pack_route_layout_ms"] = (time.perf_counter() - t1) * 1e3
+            if edges_only and not np.isin(job.route(), (4, 5, 6, 7, 8)).all():
+                edges_only = False        # a target streams dense blocks: it needs every entry of its mask
+                th.start()
             t1c = time.perf_counter()
-            th.join()
-            p.times["wait_for_rng_ms"] = (time.perf_counter() - t1c) * 1e3
-            if "err" in box:
-                raise box["err"]
-            p.times["host_rng_ms"] = box["ms"]
-            t2 = time.perf_counter()
-            job.set_masks_raw(box["raw"])
+            if edges_only:
+                s_prep.synchronize()      # the edge ids are on the host now
+                vals = self._pin("edge_vals", 2 * max(E, 1), torch.float32, raw_slot)[:2 * E].view(-1, 2)
+                engine.init_edge_masks_on_edges(dn.sizes, self.seed_base + targets, job._eoff, rc_host[:E], threads=self.rng_threads_edges, out=vals)
+                p.times["host_rng_ms"] = (time.perf_counter() - t1c) * 1e3
+                p.times["host_rng_edges_only"] = 1.0
+                t2 = time.perf_counter()
+                job.set_masks_on_edges(vals)
+            else:
+                th.join()
+                p.times["wait_for_rng_ms"] = (time.perf_counter() - t1c) * 1e3
+                if "err" in box:
+                    raise box["err"]
+                p.times["host_rng_ms"] = box["ms"]
+                t2 = time.perf_counter()
+                job.set_masks_raw(box["raw"])
             p.ready = torch.cuda.Event()
             p.ready.record(s_prep)
             self._raw_done[raw_slot] = p.ready

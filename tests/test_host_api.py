@@ -117,6 +117,29 @@ def test_host_rng_library_draws_the_reference_masks_bit_for_bit():
     for threads, sl in ((4, 64), (2, 256), (7, 16), (3, 1024), (1, 64)):
         got = engine.init_edge_masks_raw(sizes, seeds=seeds, threads=threads, slice_values=sl)
         assert torch.equal(got, want), (threads, sl)
+    # the values on the edges only (gnnx_host_draw_edge_masks): random sparse graphs, slices shorter than a row, chunks, ragged totals
+    rng = np.random.default_rng(3)
+    sizes = [9, 40, 33, 16, 41, 5, 12, 57, 1, 130, 203]      # (203^2 = 41 209 values: two chunks of 32 slices at slice length 1024, a ragged total)
+    seeds = 3000 + np.arange(len(sizes)) * 5
+    full = engine.init_edge_masks_raw(sizes, seeds=seeds, threads=1)
+    off = np.concatenate([[0], np.cumsum(np.asarray(sizes, np.int64) ** 2)])
+    rcs, eoff = [], [0]
+    for n in sizes:
+        r, c = np.nonzero(np.triu(rng.random((n, n)) < (0.0 if n == 12 else 0.15), 1))      # (one target without any edge)
+        if n == 130:
+            r, c = np.concatenate([r, [0, 128]]), np.concatenate([c, [1, 129]])             # entries in the first and the last 16 values of a stream
+            o = np.lexsort((c, r))
+            r, c = r[o], c[o]
+            keep = np.concatenate([[True], (np.diff(r) != 0) | (np.diff(c) != 0)])
+            r, c = r[keep], c[keep]
+        rcs.append(np.stack([r, c], 1).astype(np.int32))
+        eoff.append(eoff[-1] + len(r))
+    rc = np.concatenate(rcs)
+    want = torch.stack([torch.stack([full[off[k] + r * sizes[k] + c], full[off[k] + c * sizes[k] + r]]) for k in range(len(sizes)) for r, c in rcs[k]]) \
+        if len(rc) else torch.zeros(0, 2)
+    for threads, sl in ((1, 1024), (4, 1024), (3, 1 << 17), (8, 2048)):
+        got = engine.init_edge_masks_on_edges(sizes, seeds, np.asarray(eoff), rc, threads=threads, slice_values=sl)
+        assert torch.equal(got, want), (threads, sl)
     big = engine.init_edge_masks_raw([1500], seeds=[77], threads=8)          # 2.25 M values: sliced at the default length
     assert torch.equal(big, helpers.seeded_mask0(77 - 1000, 1500).flatten())
 
