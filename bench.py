@@ -51,6 +51,15 @@ MFMA_F32_PEAK = 157.3e12     # flop/s, dense f32 MFMA
 LDS_PEAK_PER_CU = 128 * 2.4e9   # B/s: ds_read_b32 = 128 B/clk/CU at ~2.4 GHz (MI355X_MICROARCH.md, LDS table)
 NUM_CUS = 256
 PARITY_TOL = 1e-5
+def cpu_quota_cores():
+    """cores the cgroup of this process may use (cpu.max = quota period), or None: the GPU box's container gets 16 of the host's 256 CPUs"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        return None
+
+
 def rng_threads_for(total_values, world=1):
     """host threads drawing the seeded initial masks (targets are independent under the seed protocol): the pipeline's own setting for
     small and large batches alike (beyond ~32 threads the hand-off costs more than it saves: tools/probe_rng.py, tools/probe_rng_big.py)"""
@@ -142,7 +151,7 @@ def cpu_baselines(wl, sample, iters):
         dt = time.perf_counter() - t0
     res = {k: (ma, fs) for part in parts for k, _, ma, fs in part}
     cpu_s = sum(s for part in parts for _, s, _, _ in part)
-    base = {"value": len(sample) / dt, "unit": "explained nodes/s", "cores": procs, "host_cpus": os.cpu_count(), "kind": "port",
+    base = {"value": len(sample) / dt, "unit": "explained nodes/s", "cores": procs, "host_cpus": os.cpu_count(), "cgroup_cpu_quota_cores": cpu_quota_cores(), "kind": "port",
             "sample": f"{len(sample)} of {len(wl.targets)} targets (size-stratified, n={ns}), {iters} iters each, "
                       f"oracle/reference_restatement.py (bit-identical to the reference) on torch {torch.__version__} CPU, "
                       f"{procs} single-thread processes in parallel, wall {dt:.1f} s, {cpu_s:.1f} CPU-seconds; the LOOP only (explain.py:137-146 on "
@@ -291,7 +300,7 @@ def bench_config4(args, dev, log):
             t0 = time.perf_counter()
             parts = pool.map(_oracle_worker, jobs)
             dtc = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": len(sample) / dtc, "unit": "explained graphs/s", "cores": procs, "host_cpus": os.cpu_count(), "kind": "port",
+        out["cpu_baseline"] = {"value": len(sample) / dtc, "unit": "explained graphs/s", "cores": procs, "host_cpus": os.cpu_count(), "cgroup_cpu_quota_cores": cpu_quota_cores(), "kind": "port",
                                "sample": f"{len(sample)} of {G} graphs (size-stratified), {args.iters} iters each, oracle/reference_restatement.py (bit-identical to "
                                          f"the reference) on torch {torch.__version__} CPU, {procs} single-thread processes, wall {dtc:.1f} s; the loop only - "
                                          "the reference's Explainer.explain additionally slices the graph out of the dataset"}

@@ -32,7 +32,7 @@ class _Prepared:
 
 class BatchPipeline:
     def __init__(self, graph, state_dict, labels, hyper, n_hops=3, seed_base=1000, rng_threads=None, depth=3, prepare_workers=3, reserve_cus=0, lib=None,
-                 device_hook=None, rng_threads_big=None, edge_draw_min_values=2e7):
+                 device_hook=None, rng_threads_big=None, edge_draw=None, edge_draw_min_values=2e7):
         """graph: engine.DeviceGraph (resident); labels [N]: the label the prediction loss uses (explain.py:750-753); the initial
         mask of target v is drawn from a generator seeded with seed_base + v (the seed protocol of the golden runs)."""
         self.graph, self.sd, self.labels, self.hyper = graph, state_dict, np.asarray(labels), hyper
@@ -48,11 +48,16 @@ class BatchPipeline:
         # device_hook(values [E] on the device, job): called on the fetch stream once a batch's edge values are gathered, before their D2H
         # copy - the sharded job all-gathers the masks of every rank there (RCCL over xGMI; bench.py --gpus N)
         self.device_hook = device_hook
-        # large batches on the edge-sparse kernels: keep only the edge entries of the host draw (see _prepare); compute-bound, so it takes
-        # more threads than the memory-bound full draw (GNNX_PIPE_EDGE_DRAW=0 switches it off: measurement knob)
-        self.edge_draw = bool(int(os.environ.get("GNNX_PIPE_EDGE_DRAW", "1")))
+        # Large batches on the edge-sparse kernels can keep only the EDGE entries of the host draw (see _prepare: 16 MB instead of 4 GB leave
+        # the host for the 16 384-target BA-House x100k set).  OFF by default - measured on the GPU box (tools/probe_rng_edges.py,
+        # profiles/r04_host_rng_edges_16384targets.txt): its container has a CPU quota of 16 cores (cgroup cpu.max 1600000 100000 on a 2 x 64-core
+        # EPYC 9575F), the draw costs 4.6 ns of one core per normal whatever is kept of it (mt19937 + ATen's vectorised Box-Muller), so 1e9
+        # normals take 150-200 ms with 32 threads and LONGER with more, full stream (154 ms) or edges only (197 ms: the extraction and the
+        # engine advances on top); end to end 72.7 k vs 63-79 k nodes/s - no gain here.  It saves 4 GB of pinned writes, PCIe and HBM
+        # traffic per batch, which matters where the host is not the bound: edge_draw=True / GNNX_PIPE_EDGE_DRAW=1.
+        self.edge_draw = bool(int(os.environ.get("GNNX_PIPE_EDGE_DRAW", "0"))) if edge_draw is None else bool(edge_draw)
         self.edge_draw_min_values = float(edge_draw_min_values)      # batches of fewer normals keep the full draw (it overlaps the plan; syn1: 0.5 ms)
-        self.rng_threads_edges = int(os.environ.get("GNNX_PIPE_EDGE_THREADS", max(self.rng_threads, min(96, (os.cpu_count() or 2) // 2))))
+        self.rng_threads_edges = int(os.environ.get("GNNX_PIPE_EDGE_THREADS", self.rng_threads))
         depth = int(os.environ.get("GNNX_PIPE_DEPTH", depth))                        # (measurement knobs)
         reserve_cus = int(os.environ.get("GNNX_PIPE_RESERVE", reserve_cus))
         prepare_workers = int(os.environ.get("GNNX_PIPE_WORKERS", prepare_workers))

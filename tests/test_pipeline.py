@@ -23,7 +23,7 @@ def test_pipelined_batches_equal_sequential_jobs(name, edge_draw_min):
     rng = np.random.default_rng(3)
     batches = [np.sort(rng.choice(np.arange(first, ck["num_nodes"]), k, replace=False)) for k in (7, 64, 1, 33, 64)]   # ragged, one repeated size
     hy = Hyper(num_iters=25)
-    pipe = BatchPipeline(graph, ck["sd"], ck["label"], hy, rng_threads=4, edge_draw_min_values=edge_draw_min)
+    pipe = BatchPipeline(graph, ck["sd"], ck["label"], hy, rng_threads=4, edge_draw=True, edge_draw_min_values=edge_draw_min)
     got = list(pipe.run(batches))
     assert len(got) == len(batches) and len(pipe.stats) == len(batches)
     assert all(("host_rng_edges_only" in st) == (edge_draw_min == 0.0) for st in pipe.stats)
