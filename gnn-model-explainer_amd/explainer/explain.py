@@ -139,6 +139,12 @@ def _torch_route_reason(args, model, state_dict=None, graph_mode=False, record_l
                          ("attention weights in some layers only", not all(k + ".att_weight" in sd for k in ("conv_first", "conv_block.0", "conv_last")))):
             if on:
                 return "method='att' (models.py:62-68) with %s" % what
+    if unconstrained and record_loss:
+        # the kernels run the unconstrained forward with the engine's feature mask pinned at sigma = 1 and recover the reference's
+        # regulariser-only feature mask on the host afterwards: the masks are the reference's, the LOGGED feat_size term would not be
+        return "unconstrained=True with loss logging (explain.py:688-691 with :808-819)"
+    if unconstrained and getattr(args, "mask_act", "sigmoid") == "ReLU":
+        return "unconstrained=True with mask_act=ReLU (the reference's unconstrained forward always applies the sigmoid, explain.py:689)"
     extra = [k for k in sd if k.startswith("conv_block.") and not k.startswith("conv_block.0.")]
     if extra or "conv_block.0.weight" not in sd:
         return "an encoder with %d graph-convolution layers (the kernels implement 3)" % (2 + len({k.split(".")[1] for k in sd if k.startswith("conv_block.")}))

@@ -354,3 +354,23 @@ def test_torch_route_refuses_a_cpu_only_host(tmp_path):
     ck, ex = _route_explainer(tmp_path, "l4", num_gc_layers=4)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ex.explain(302)
+
+
+def test_unconstrained_runs_with_logging_or_relu_take_the_torch_route():
+    """the kernels run unconstrained=True with the engine's feature mask pinned at sigma = 1 (the reference's regulariser-only
+    feature mask is recovered on the host), so a loss LOGGED by them would carry feat_size = 1 where the reference logs mean(sigmoid(f));
+    and the reference's unconstrained forward always applies the sigmoid (explain.py:689), whatever mask_act says.  Both combinations go to
+    the PyTorch-ROCm route instead of differing silently; the plain unconstrained run stays on the kernels."""
+    ck = helpers.load_ckpt("syn1")
+    sd = {k: torch.tensor(v) for k, v in ck["sd"].items()}
+    a = _args()
+    a.method, a.mask_act = "base", "sigmoid"
+
+    class _M:          # (only its modules() are looked at, for dropout)
+        def modules(self):
+            return []
+    assert explain._torch_route_reason(a, _M(), state_dict=sd, unconstrained=True) is None
+    assert "unconstrained" in explain._torch_route_reason(a, _M(), state_dict=sd, unconstrained=True, record_loss=True)
+    a.mask_act = "ReLU"
+    assert "unconstrained" in explain._torch_route_reason(a, _M(), state_dict=sd, unconstrained=True)
+    assert explain._torch_route_reason(a, _M(), state_dict=sd) is None
