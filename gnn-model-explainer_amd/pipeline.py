@@ -31,7 +31,7 @@ class _Prepared:
 
 
 class BatchPipeline:
-    def __init__(self, graph, state_dict, labels, hyper, n_hops=3, seed_base=1000, rng_threads=None, depth=3, prepare_workers=3, reserve_cus=0, lib=None,
+    def __init__(self, graph, state_dict, labels, hyper, n_hops=3, seed_base=1000, rng_threads=None, depth=4, prepare_workers=3, reserve_cus=0, lib=None,
                  device_hook=None, rng_threads_big=None, edge_draw=None, edge_draw_min_values=2e7):
         """graph: engine.DeviceGraph (resident); labels [N]: the label the prediction loss uses (explain.py:750-753); the initial
         mask of target v is drawn from a generator seeded with seed_base + v (the seed protocol of the golden runs)."""
