@@ -322,8 +322,8 @@ def _noop(_):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--iters", type=int, default=300)
     ap.add_argument("--workload", default=None, choices=["syn1", "ba100k", "syn4", "syn5", "config4"],
                     help="default: syn1 at 1 GPU (the metric's configuration), ba100k (the scaling curve) at N > 1")
