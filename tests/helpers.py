@@ -149,12 +149,20 @@ def abar_from_mask_rc(mask_rc):
     return 0.5 * (_sig64(mask_rc[:, 0]) + _sig64(mask_rc[:, 1]))
 
 
+class _Arrays(dict):
+    """the arrays of an .npz file held in memory, with the `.files` attribute of the NpzFile they came from"""
+    @property
+    def files(self):
+        return list(self.keys())
+
+
 class Windows:
     """Accessors of a <name>_windows.npz fixture.  Boundary b = 0..6 is the state after 50 b steps (b = 0: the seeded initial
     mask with zero moments - not stored, None)."""
 
     def __init__(self, name):
-        self.z = z = np.load(os.path.join(GOLDEN, name + "_windows.npz"))
+        with np.load(os.path.join(GOLDEN, name + "_windows.npz")) as f:
+            self.z = z = _Arrays({k: f[k] for k in f.files})      # in memory once: an NpzFile decompresses an array on EVERY access
         self.ids = z["targets"] if "targets" in z.files else z["graphs"]
         self.eoff = z["eoff"]
         self.T, self.W = z["cond50"].shape
@@ -239,42 +247,49 @@ def window_errors(eoff, mask_rc, feat, want):
 # ---------------------------------------------------------------------------------------------------------------------------
 class Decisions:
     def __init__(self, name):
-        self.z = z = np.load(os.path.join(GOLDEN, name + "_decisions.npz"))
-        self.ids = z["targets"] if "targets" in z.files else z["graphs"]
+        with np.load(os.path.join(GOLDEN, name + "_decisions.npz")) as f:
+            self.z = z = {k: f[k] for k in f.files}          # in memory once: an NpzFile decompresses an array on EVERY access
+        self.ids = z["targets"] if "targets" in z else z["graphs"]
         self.T = len(self.ids)
-        self.graph_mode = "pool0" in z.files
+        self.graph_mode = "pool0" in z
         self.near_tol = float(z["near"])          # the NEAR list holds every gate with |U| below this (1e-4) and every pool with a smaller margin
         self.near_tol_strict = 1e-5               # = the parity tolerance: a decision the reference takes by less may differ in any window
+        self._cache = {}
+
+    @staticmethod
+    def _forward_fill(first, epoch, where, value, E):
+        """[E, *first.shape]: `first` at epoch 0, entry `where` set to `value` from `epoch` on (change events; values >= 0)"""
+        c = np.full((E,) + first.shape, -1, np.int64)
+        c[0] = first
+        c[(epoch,) + tuple(where)] = value
+        idx = np.where(c >= 0, np.arange(E).reshape((E,) + (1,) * first.ndim), 0)
+        np.maximum.accumulate(idx, axis=0, out=idx)
+        return np.take_along_axis(c, idx, axis=0)
+
+    def _all_gate_words(self, k):
+        """uint32 [epochs, n_k, 2] of target k, built once from the change events (cached: a window test asks for every window of a target)"""
+        c = self._cache.get(("g", k))
+        if c is None:
+            z = self.z
+            a, b = int(z["row_off"][k]), int(z["row_off"][k + 1])
+            E = int(z["epochs"])
+            ev = z["ev"][int(z["ev_off"][k]):int(z["ev_off"][k + 1])]
+            c = self._forward_fill(z["gates0"][a:b].astype(np.int64), ev[:, 0], (ev[:, 1], ev[:, 2]), ev[:, 3].astype(np.int64) & 0xffffffff, E).astype(np.uint32)
+            self._cache[("g", k)] = c
+        return c
 
     def gate_words(self, k, e0, e1):
         """uint32 [e1 - e0, n_k, 2]: the reference's sign words at epochs e0 .. e1 - 1 of target k (fixture index)"""
-        z = self.z
-        a, b = int(z["row_off"][k]), int(z["row_off"][k + 1])
-        cur = z["gates0"][a:b].copy()
-        ev = z["ev"][int(z["ev_off"][k]):int(z["ev_off"][k + 1])]
-        out = np.empty((e1 - e0, b - a, 2), np.uint32)
-        j = 0
-        for e in range(e1):
-            while j < len(ev) and ev[j, 0] == e:
-                cur[ev[j, 1], ev[j, 2]] = np.int32(ev[j, 3]).view(np.uint32)
-                j += 1
-            if e >= e0:
-                out[e - e0] = cur
-        return out
+        return self._all_gate_words(k)[e0:e1]
 
     def pool_rows(self, k, e0, e1):
-        z = self.z
-        cur = z["pool0"][k].astype(np.int32).copy()
-        ev = z["pev"][int(z["pev_off"][k]):int(z["pev_off"][k + 1])]
-        out = np.empty((e1 - e0, 3, 20), np.int32)
-        j = 0
-        for e in range(e1):
-            while j < len(ev) and ev[j, 0] == e:
-                cur[ev[j, 1], ev[j, 2]] = ev[j, 3]
-                j += 1
-            if e >= e0:
-                out[e - e0] = cur
-        return out
+        c = self._cache.get(("p", k))
+        if c is None:
+            z = self.z
+            ev = z["pev"][int(z["pev_off"][k]):int(z["pev_off"][k + 1])]
+            c = self._forward_fill(z["pool0"][k].astype(np.int64), ev[:, 0], (ev[:, 1], ev[:, 2]), ev[:, 3].astype(np.int64), int(z["epochs"])).astype(np.int32)
+            self._cache[("p", k)] = c
+        return c[e0:e1]
 
     def near_gates(self, k):
         """{(epoch, layer, row, column): U} of the gates of target k whose |U| < NEAR in the reference"""

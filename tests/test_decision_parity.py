@@ -65,7 +65,8 @@ def _decision_windows(W, Dn, make_job, ks_all, coarse_windows=None):
     fixture has the snapshots.  -> list of row dicts."""
     rows = []
     name = "config4" if Dn.graph_mode else [n for n in ("syn1", "syn4", "syn5") if np.array_equal(helpers.Windows(n).ids, W.ids)][0]
-    Nz = np.load(os.path.join(helpers.GOLDEN, name + "_noise.npz"))
+    with np.load(os.path.join(helpers.GOLDEN, name + "_noise.npz")) as f:
+        Nz = {k: f[k] for k in f.files}
     job = make_job(ks_all)
     eoff = np.concatenate([[0], np.cumsum(np.diff(W.eoff)[ks_all])])
     for w in (range(W.W) if coarse_windows is None else coarse_windows):
@@ -251,7 +252,8 @@ def _full_horizon_verdict(what, Dn, ids, err, gates, pool, cond, jump=None):
 
 def _horizon_conditioning(name, z_cond_mask, z_cond_feat):
     W = helpers.Windows(name)
-    Nz = np.load(os.path.join(helpers.GOLDEN, name + "_noise.npz"))
+    with np.load(os.path.join(helpers.GOLDEN, name + "_noise.npz")) as f:
+        Nz = {k: f[k] for k in f.files}
     win = np.maximum(np.maximum(W.z["cond50"], W.z["sens50"]), Nz["noise50"]).max(1)
     return np.maximum(np.maximum(z_cond_mask, z_cond_feat), win)
 
