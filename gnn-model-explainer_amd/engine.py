@@ -883,10 +883,27 @@ def host_library():
     return _host_lib_cache[0]
 
 
+def cpu_quota_cores():
+    """cores the cgroup of this process may use (cpu.max = quota / period), or None when unlimited / unknown"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        return None
+
+
 def default_rng_threads():
-    """Host threads for the seeded mask draw: the draw is memory-light and embarrassingly parallel over targets; beyond ~32 threads
-    the hand-off costs more than it saves (tools/probe_rng.py)."""
-    return max(1, min(32, (os.cpu_count() or 2) // 2))
+    """Host threads for the seeded mask draw: embarrassingly parallel over targets, but beyond ~32 threads the hand-off costs more than it
+    saves (tools/probe_rng.py), and never more than twice the cores the process may actually use (a container's CPU quota: the GPU box gives 16
+    of its host's 256 CPUs - tools/probe_rng_big.py).  GNNX_RNG_THREADS overrides."""
+    env = os.environ.get("GNNX_RNG_THREADS")
+    if env:
+        return max(1, int(env))
+    cores = (os.cpu_count() or 2) // 2
+    q = cpu_quota_cores()
+    if q:
+        cores = min(cores, int(2 * q))
+    return max(1, min(32, cores))
 
 
 def init_edge_masks_raw(sizes, generator=None, seeds=None, pin=False, threads=1, out=None, slice_values=None):
