@@ -42,6 +42,7 @@ __device__ __forceinline__ float att_sum32(float v) {  // over the 32 lanes of a
 }
 
 constexpr int ATT_THREADS = 1024;
+constexpr int ATT_UN = 8;    // edges whose row loads are in flight together in the gathers of k_att
 
 __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, const float* __restrict__ adam) {
     constexpr int NWV = ATT_THREADS / 64;
@@ -176,11 +177,26 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
                     const float cw = eon ? w[e0 + je] : 0.0f;
                     float cs = 0.0f;
                     const int cnt = (trip - j0 < 32) ? trip - j0 : 32;
-                    for (int jj = 0; jj < cnt; ++jj) {
-                        const int k = __shfl(ck, hbase | jj);
-                        const float se = att_sum32(ui * ul[(size_t)k * FS + ln]);
-                        acc = fmaf(__shfl(cw, hbase | jj) * se, xin[(size_t)k * FS + ln], acc);
-                        cs = (jj == ln) ? se : cs;
+                    // ATT_UN edges per trip: the row loads of all of them (L2: the row arrays live in the workspace) are issued before the first
+                    // butterfly, so a hub row costs a fraction of one L2 round trip per edge instead of a whole one; the products are taken in the
+                    // same order as one edge per trip (bit-identical sums)
+                    for (int jj = 0; jj < cnt; jj += ATT_UN) {
+                        int kk[ATT_UN];
+                        float uk[ATT_UN], xk[ATT_UN];
+#pragma unroll
+                        for (int u = 0; u < ATT_UN; ++u) kk[u] = __shfl(ck, hbase | ((jj + u < cnt) ? jj + u : jj));
+#pragma unroll
+                        for (int u = 0; u < ATT_UN; ++u) {
+                            uk[u] = ul[(size_t)kk[u] * FS + ln];
+                            xk[u] = xin[(size_t)kk[u] * FS + ln];
+                        }
+#pragma unroll
+                        for (int u = 0; u < ATT_UN; ++u)
+                            if (jj + u < cnt) {     // uniform over the wave (cnt is)
+                                const float se = att_sum32(ui * uk[u]);
+                                acc = fmaf(__shfl(cw, hbase | (jj + u)) * se, xk[u], acc);
+                                cs = (jj + u == ln) ? se : cs;
+                            }
                     }
                     if (eon) sl[e0 + je] = cs;
                 }
@@ -273,11 +289,23 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
                     const float cc = cw * cs;
                     float cg = 0.0f;
                     const int cnt = (trip - j0 < 32) ? trip - j0 : 32;
-                    for (int jj = 0; jj < cnt; ++jj) {
-                        const int k = __shfl(ck, hbase | jj);
-                        const float g = att_sum32(dzi * xin[(size_t)k * FS + ln]);
-                        acc = fmaf(__shfl(cc, hbase | jj), dZ[(size_t)k * FS + ln], acc);
-                        cg = (jj == ln) ? g : cg;
+                    for (int jj = 0; jj < cnt; jj += ATT_UN) {
+                        int kk[ATT_UN];
+                        float xk[ATT_UN], zk[ATT_UN];
+#pragma unroll
+                        for (int u = 0; u < ATT_UN; ++u) kk[u] = __shfl(ck, hbase | ((jj + u < cnt) ? jj + u : jj));
+#pragma unroll
+                        for (int u = 0; u < ATT_UN; ++u) {
+                            xk[u] = xin[(size_t)kk[u] * FS + ln];
+                            zk[u] = dZ[(size_t)kk[u] * FS + ln];
+                        }
+#pragma unroll
+                        for (int u = 0; u < ATT_UN; ++u)
+                            if (jj + u < cnt) {
+                                const float g = att_sum32(dzi * xk[u]);
+                                acc = fmaf(__shfl(cc, hbase | (jj + u)), zk[u], acc);
+                                cg = (jj + u == ln) ? g : cg;
+                            }
                     }
                     if (eon) {
                         dA[e0 + je] = (l == 2) ? cg * cs : dA[e0 + je] + cg * cs;
@@ -301,8 +329,14 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
                     const int ck = eon ? col[e0 + je] : 0;
                     const float cq = eon ? q[e0 + je] + q[mir[e0 + je]] : 0.0f;
                     const int cnt = (trip - j0 < 32) ? trip - j0 : 32;
-                    for (int jj = 0; jj < cnt; ++jj)
-                        du = fmaf(__shfl(cq, hbase | jj), ul[(size_t)__shfl(ck, hbase | jj) * FS + ln], du);
+                    for (int jj = 0; jj < cnt; jj += ATT_UN) {
+                        float uk[ATT_UN];
+#pragma unroll
+                        for (int u = 0; u < ATT_UN; ++u) uk[u] = ul[(size_t)__shfl(ck, hbase | ((jj + u < cnt) ? jj + u : jj)) * FS + ln];
+#pragma unroll
+                        for (int u = 0; u < ATT_UN; ++u)
+                            if (jj + u < cnt) du = fmaf(__shfl(cq, hbase | (jj + u)), uk[u], du);
+                    }
                 }
                 float dxa = 0.0f;
                 for (int c = 0; c < din; ++c) dxa = fmaf(__shfl(du, hbase | c), sWa[l][ln * 33 + c], dxa);
