@@ -32,12 +32,19 @@ struct AttScratch {
     float* rn[3];            // [R]
 };
 
-__device__ __forceinline__ float att_sum32(float v) {  // over the 32 lanes of a half-wave
+// sum over the 32 lanes of a half-wave, in every lane: four DPP rotations inside each 16-lane row (register speed) and ONE cross-row
+// shuffle, instead of five ds_bpermute round trips - this reduction sits on the per-edge chain of every gather below (a hub row of 250
+// edges x three layers x forward and backward)
+template <int S>
+__device__ __forceinline__ float att_row_ror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + S, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float att_sum32(float v) {
+    v += att_row_ror<8>(v);
+    v += att_row_ror<4>(v);
+    v += att_row_ror<2>(v);
+    v += att_row_ror<1>(v);
     v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 1);
     return v;
 }
 

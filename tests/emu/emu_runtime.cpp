@@ -114,6 +114,14 @@ int dpp_row_shl(int v, int shift) {
     return g_blk->waves[g_blk->cur >> 6].ia[buf][src];
 }
 
+// DPP row_ror:S (dpp_ctrl 0x120 + S): lane l <- lane (l - S) mod 16 of its 16-lane row
+int dpp_row_ror(int v, int shift) {
+    int buf = 0, lane = 0;
+    wave_collective([&](WaveSlot& w, int bf, int ln) { w.ia[bf][ln] = v; buf = bf; lane = ln; });
+    const int src = (lane & ~15) | ((lane - shift) & 15);
+    return g_blk->waves[g_blk->cur >> 6].ia[buf][src];
+}
+
 int shfl_xor_i(int v, int mask) {
     int buf = 0, lane = 0;
     wave_collective([&](WaveSlot& w, int bf, int ln) { w.ia[bf][ln] = v; buf = bf; lane = ln; });

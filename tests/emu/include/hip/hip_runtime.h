@@ -49,6 +49,7 @@ int shfl_i(int v, int src);
 unsigned long long ballot(bool pred);
 void wave_sync();
 int dpp_row_shl(int v, int shift);
+int dpp_row_ror(int v, int shift);
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 f32x16 mfma_32x32x2(float a, float b, f32x16 c);
 float hw_form(float v);   // identity, or +-1 ulp at random when GNNX_EMU_ULP_NOISE=<seed> (the hardware's v_rcp / v_sqrt / v_exp are ~1 ulp forms)
@@ -70,6 +71,7 @@ inline void __threadfence_block() {}
 // DPP row_shl:S (dpp_ctrl 0x100 + S, all rows / banks, bound_ctrl): lane l <- lane l + S of its 16-lane row, else 0
 inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     (void)old; (void)row_mask; (void)bank_mask; (void)bound_ctrl;
+    if (ctrl > 0x120 && ctrl < 0x130) return emu::dpp_row_ror(src, ctrl - 0x120);   // row_ror:S
     return emu::dpp_row_shl(src, ctrl - 0x100);
 }
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
