@@ -102,17 +102,62 @@ static hipError_t pool_free(void* ptr) {
     P.cached_bytes += it->second;
     return hipSuccess;
 }
+// Pinned host staging for the table uploads (BlockBuilder::commit): an upload from pinned memory is only ENQUEUED, so the thread that
+// builds a plan does not wait for a copy kernel to find a free compute unit; hipHostMalloc is as expensive as hipMalloc, hence the
+// same recycling (process-wide: pinned memory belongs to no device).
+namespace {
+struct PinPool {
+    std::mutex mu;
+    std::unordered_map<void*, size_t> bucket_of;
+    std::map<size_t, std::vector<void*>> free_blocks;
+};
+PinPool g_pin;
+}  // namespace
+static void* pin_alloc(size_t bytes) {
+    const size_t b = pool_bucket(bytes);
+    {
+        std::lock_guard<std::mutex> lk(g_pin.mu);
+        auto it = g_pin.free_blocks.find(b);
+        if (it != g_pin.free_blocks.end() && !it->second.empty()) {
+            void* ptr = it->second.back();
+            it->second.pop_back();
+            return ptr;
+        }
+    }
+    void* ptr = nullptr;
+    if (hipHostMalloc(&ptr, b, hipHostMallocDefault) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_pin.mu);
+    g_pin.bucket_of[ptr] = b;
+    return ptr;
+}
+static void pin_free(void* ptr) {
+    if (!ptr) return;
+    std::lock_guard<std::mutex> lk(g_pin.mu);
+    auto it = g_pin.bucket_of.find(ptr);
+    if (it == g_pin.bucket_of.end()) return;
+    g_pin.free_blocks[it->second].push_back(ptr);
+}
 extern "C" int gnnx_pool_trim(void) {
     DevPool& P = pool_here();
-    std::lock_guard<std::mutex> lk(P.mu);
-    for (auto& kv : P.free_blocks) {
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        for (auto& kv : P.free_blocks) {
+            for (void* ptr : kv.second) {
+                (void)hipFree(ptr);
+                P.bucket_of.erase(ptr);
+            }
+            kv.second.clear();
+        }
+        P.cached_bytes = 0;
+    }
+    std::lock_guard<std::mutex> lk(g_pin.mu);
+    for (auto& kv : g_pin.free_blocks) {
         for (void* ptr : kv.second) {
-            (void)hipFree(ptr);
-            P.bucket_of.erase(ptr);
+            (void)hipHostFree(ptr);
+            g_pin.bucket_of.erase(ptr);
         }
         kv.second.clear();
     }
-    P.cached_bytes = 0;
     return 0;
 }
 
@@ -212,6 +257,17 @@ struct gnnx_plan_s {
     size_t cap_slabs = 0;
     void* create_block = nullptr;    // d_meta, d_conv, d_mask, d_wts, d_raw_off, d_unit, d_join live in it (one upload)
     void* split_block = nullptr;     // d_res, d_sp[], d_big, d_conv_big, d_mask_big, d_unit_big, d_join_big (one upload per split)
+    // The two blocks are uploaded ASYNCHRONOUSLY from pinned staging when the calling thread has named a service stream
+    // (gnnx_set_service_stream): up_ev is recorded behind the last such upload on up_stream, every entry point that enqueues readers of
+    // the tables on another stream makes that stream wait for it (use_tables), and the staging blocks are recycled only once it completed.
+    void* create_pin = nullptr;
+    void* split_pin = nullptr;
+    hipEvent_t up_ev = nullptr;
+    hipStream_t up_stream = nullptr;
+    bool split_dirty = false;        // the split lists exist on the host only (gnnx_plan_create defers the upload: gnnx_plan_analyze usually
+                                     // replaces the default split at once); committed by the first call that needs them (use_tables)
+    std::vector<int64_t> edge_counts;   // upper-triangle edges per target, counted by the last gnnx_plan_analyze* (with the row starts in d_rowcnt)
+    bool adam_shared = false;        // d_adam points into the process-wide table cache (not this plan's to free)
     float* d_watt = nullptr;         // method="att": attention weights of the three layers (gnnx_set_att_weights); every run takes k_att
     // the resident kernels run beside the streaming launches, each group on its own stream:
     // [0..RES_NBMAX) dense resident kernels by row blocks, [RES_NBMAX + k] sparse resident kernel of size class k
@@ -279,6 +335,23 @@ static void wait_idle(gnnx_handle h) {
     for (auto& b : h->busy) (void)hipEventSynchronize(b.second);
 }
 
+// the asynchronous table uploads of this plan have completed (cheap when they already have)
+static void wait_uploads(gnnx_handle h) {
+    if (h->up_stream && h->up_ev) (void)hipEventSynchronize(h->up_ev);
+}
+static int build_split(gnnx_handle h, bool upload = true);
+static void edge_rows(gnnx_handle h, const float* A, int32_t* rowcnt, int64_t* counts, hipStream_t s);
+// Called by every entry point that enqueues work reading the plan's tables on stream `s`: the split lists are on the device
+// (need_split) and `s` is ordered behind the last asynchronous table upload.
+static int use_tables(gnnx_handle h, hipStream_t s, bool need_split = true) {
+    if (need_split && h->split_dirty)
+        if (int rc = build_split(h)) return rc;
+    if (h->up_stream && h->up_ev && s != h->up_stream) {
+        if (hipStreamWaitEvent(s, h->up_ev, 0) != hipSuccess) (void)hipEventSynchronize(h->up_ev);
+    }
+    return 0;
+}
+
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Units of k_conv for a tile table (row blocks of a target are adjacent in it), longest K range first, and the row blocks whose
@@ -344,14 +417,33 @@ struct BlockBuilder {
     }
     template <class T>
     void add(T*& slot, const std::vector<T>& v) { add(slot, v.data(), v.size()); }
-    hipError_t commit(void*& block) {
+    // (the caller has waited for the work that reads the block this one replaces: wait_idle)
+    hipError_t commit(gnnx_handle h, void*& block, void*& pin) {
+        if (block || pin) wait_uploads(h);   // an upload of the block / staging block about to be recycled may still be in flight
         if (block) (void)pool_free(block);
         block = nullptr;
+        pin_free(pin);
+        pin = nullptr;
         if (host.empty()) return hipSuccess;
         hipError_t e = pool_malloc(&block, host.size());
         if (e != hipSuccess) return e;
-        e = upload_sync(block, host.data(), host.size());
-        if (e != hipSuccess) return e;
+        if (g_service_stream) pin = pin_alloc(host.size());
+        if (pin) {   // enqueue only: the preparing thread does not wait for the copy kernel to get a compute unit
+            std::memcpy(pin, host.data(), host.size());
+            e = hipMemcpyAsync(block, pin, host.size(), hipMemcpyHostToDevice, g_service_stream);
+            if (e != hipSuccess) return e;
+            if (!h->up_ev) e = hipEventCreateWithFlags(&h->up_ev, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(h->up_ev, g_service_stream);
+            if (e != hipSuccess) {   // no event to order the readers by: wait here
+                (void)hipStreamSynchronize(g_service_stream);
+                h->up_stream = nullptr;
+            } else {
+                h->up_stream = g_service_stream;
+            }
+        } else {
+            e = upload_sync(block, host.data(), host.size());
+            if (e != hipSuccess) return e;
+        }
         for (auto& f : fix) *f.first = static_cast<char*>(block) + f.second;
         return hipSuccess;
     }
@@ -377,7 +469,7 @@ static hipError_t add_units(gnnx_handle h, BlockBuilder& bb, const std::vector<C
 
 // (Re)build the hybrid split from h->cat: id lists of the resident kernels, tile tables of the streaming remainder,
 // side streams.  Invalidates a captured graph.
-static int build_split(gnnx_handle h) {
+static int build_split(gnnx_handle h, bool upload) {
 #define SPLITCK(x)                                                                 \
     do {                                                                           \
         hipError_t e_ = (x);                                                       \
@@ -433,7 +525,18 @@ static int build_split(gnnx_handle h) {
         bb.add(h->d_conv_big, conv_big);
         SPLITCK(add_units(h, bb, conv_big, h->d_unit_big, h->n_unit_big, h->d_join_big, h->n_join_big));
     }
-    SPLITCK(bb.commit(h->split_block));
+    if (upload) {
+        SPLITCK(bb.commit(h, h->split_block, h->split_pin));
+        h->split_dirty = false;
+    } else {
+        // counts only; the device pointers stay null until use_tables() / the next build_split commits the lists
+        h->d_res = h->d_big = nullptr;
+        for (int k = 0; k < N_SPC; ++k) h->d_sp[k] = nullptr;
+        h->d_conv_big = nullptr;
+        h->d_unit_big = nullptr;
+        h->d_join_big = nullptr;
+        h->split_dirty = true;
+    }
     if (any_resident && !h->ev_in) SPLITCK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     // (Disjoint compute-unit masks for the sparse and the single-tile dense launch - hipExtStreamCreateWithCUMask - were
     // measured on syn1 and made the sparse launch slower, 9.7 vs 6.4 ms in situ: not used.)
@@ -561,10 +664,10 @@ extern "C" int gnnx_plan_create(const gnnx_problem* prob, const gnnx_model* mode
         PLANCK(add_units(h, bb, conv, h->d_unit, h->n_unit, h->d_join, h->n_join));
         bb.add(h->d_wts, w);
         bb.add(h->d_raw_off, ro);
-        PLANCK(bb.commit(h->create_block));
+        PLANCK(bb.commit(h, h->create_block, h->create_pin));
     }
 #undef PLANCK
-    if (int rc = build_split(h)) {
+    if (int rc = build_split(h, /*upload=*/false)) {
         gnnx_destroy(h);
         return rc;
     }
@@ -619,7 +722,7 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
         if (h->ev_t0[k]) (void)hipEventDestroy(h->ev_t0[k]);
     }
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
-    if (h->d_nnz) (void)pool_free(h->d_nnz);
+    if (h->d_nnz) (void)pool_free(reinterpret_cast<char*>(h->d_nnz) - sizeof(int64_t) * h->prob.num_targets);
     if (h->d_dead) (void)pool_free(h->d_dead);
     if (h->d_mask) (void)pool_free(h->d_mask);
     if (h->d_mask_big) (void)pool_free(h->d_mask_big);
@@ -628,10 +731,14 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
     if (h->d_csr_col) (void)pool_free(h->d_csr_col);
     if (h->d_csr_row) (void)pool_free(h->d_csr_row);
     if (h->d_csr_off) (void)pool_free(h->d_csr_off);
-    if (h->d_adam) (void)pool_free(h->d_adam);
+    if (h->d_adam && !h->adam_shared) (void)pool_free(h->d_adam);
     if (h->d_rowcnt) (void)pool_free(h->d_rowcnt);
     if (h->d_cpart) (void)pool_free(h->d_cpart);
     if (h->d_watt) (void)pool_free(h->d_watt);
+    wait_uploads(h);   // (a plan destroyed before anything read its tables: the uploads themselves may still be in flight)
+    if (h->up_ev) (void)hipEventDestroy(h->up_ev);
+    pin_free(h->create_pin);
+    pin_free(h->split_pin);
     if (h->create_block) (void)pool_free(h->create_block);
     if (h->split_block) (void)pool_free(h->split_block);
     delete h;
@@ -727,6 +834,32 @@ static void adam_scalars(const gnnx_hyper* hy, int it, float* step_size, float* 
         *step_size = (float)lr;
         *bc2s = (hy->opt == 1 && it > 0) ? (float)hy->momentum : 0.0f;   // SGD: the momentum buffer starts as the first gradient
     }
+}
+
+// Process-wide cache of per-iteration optimiser scalar tables (a few KB each, at most ADAM_CACHE entries per device, never freed): key =
+// the hyper-parameter struct (no schedule) + the first iteration.  Returns null when the cache is full or the upload fails - the caller
+// then keeps a private table as before.
+namespace {
+struct AdamEntry { gnnx_hyper hy; int first; int dev; float* d; };
+constexpr size_t ADAM_CACHE = 64;
+std::mutex g_adam_mu;
+std::vector<AdamEntry> g_adam_cache;
+}  // namespace
+static float* shared_adam_table(const gnnx_hyper* hy, int first_iter, const std::vector<float>& host) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_adam_mu);
+    for (const AdamEntry& e : g_adam_cache)
+        if (e.dev == dev && e.first == first_iter && std::memcmp(&e.hy, hy, sizeof(gnnx_hyper)) == 0) return e.d;
+    if (g_adam_cache.size() >= ADAM_CACHE) return nullptr;
+    float* d = nullptr;
+    if (hipMalloc(&d, sizeof(float) * host.size()) != hipSuccess) return nullptr;
+    if (upload_sync(d, host.data(), sizeof(float) * host.size()) != hipSuccess) {
+        (void)hipFree(d);
+        return nullptr;
+    }
+    g_adam_cache.push_back({*hy, first_iter, dev, d});
+    return d;
 }
 
 // which tile tables a launch sequence walks: all targets, or only the streaming ("big") set of a hybrid run
@@ -1024,6 +1157,7 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
     if (hy->lr_schedule && hy->use_graph) return fail("a learning-rate schedule cannot be captured into a hipGraph (use_graph = 0)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* lossp = hy->record_loss ? loss : nullptr;
+    if (int rc = use_tables(h, s)) return rc;
     if (hy->record_loss && !loss) return fail("record_loss set but loss buffer is null");
     if (hy->record_loss && h->prob.mask_relu) return fail("loss logging is not implemented for mask_act = ReLU (the reference's loss is NaN there)");
     Params p = make_params(h, hy, A, X, yhat, M, Abar, lossp, workspace);
@@ -1059,15 +1193,24 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
         if (int rc = init_stream_state(h, p, s)) return rc;
     if (resident) {
         if (!h->d_adam || hy->lr_schedule || h->adam_first != rs.first_iter || std::memcmp(&h->adam_for, hy, sizeof(gnnx_hyper)) != 0) {
-            if (h->d_adam) {
+            if (h->d_adam && !h->adam_shared) {
                 HIPCK(hipStreamSynchronize(s));   // an earlier run of this plan may still be reading the table (its side lanes join `s`)
                 (void)pool_free(h->d_adam);
             }
+            h->d_adam = nullptr;
+            h->adam_shared = false;
             h->adam_host.resize(2 * (size_t)hy->num_iters);
             for (int it = 0; it < hy->num_iters; ++it)
                 adam_scalars(hy, rs.first_iter + it, &h->adam_host[2 * it], &h->adam_host[2 * it + 1], it);
-            HIPCK(pool_malloc(&h->d_adam, sizeof(float) * h->adam_host.size()));
-            HIPCK(upload_sync(h->d_adam, h->adam_host.data(), sizeof(float) * h->adam_host.size()));
+            // The table depends on the hyper-parameters alone: the plans of a long job (one per batch) share ONE device copy, uploaded by the
+            // first of them - no per-batch upload on the launching thread.  (Runs with a learning-rate schedule keep a private table.)
+            if (!hy->lr_schedule) h->d_adam = shared_adam_table(hy, rs.first_iter, h->adam_host);
+            if (h->d_adam) {
+                h->adam_shared = true;
+            } else {
+                HIPCK(pool_malloc(&h->d_adam, sizeof(float) * h->adam_host.size()));
+                HIPCK(upload_sync(h->d_adam, h->adam_host.data(), sizeof(float) * h->adam_host.size()));
+            }
             h->adam_for = *hy;
             h->adam_first = rs.first_iter;
         }
@@ -1223,7 +1366,18 @@ extern "C" int gnnx_plan_analyze_features(gnnx_handle h, const float* A, const f
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int T = h->prob.num_targets;
     const bool look_at_x = X && !h->prob.graph_mode;   // constant feature rows: node mode (the form exists for the node encoder's shapes)
-    if (!h->d_nnz) HIPCK(pool_malloc(&h->d_nnz, sizeof(int32_t) * (3 + SPL_COUNTS) * T));
+    if (int rc = use_tables(h, s, /*need_split=*/false)) return rc;
+    // device block of the analysis: [T] int64 upper-triangle edge counts (the edge layout of the results, gnnx_edge_layout), then the int32 figures
+    // of the routing below - ONE copy back for both (every host-blocking round trip of a preparing thread waits for a copy kernel to
+    // find a free compute unit while the optimisations of the batches ahead fill the chip)
+    if (!h->d_nnz) {
+        char* blk = nullptr;
+        HIPCK(pool_malloc(&blk, sizeof(int64_t) * T + sizeof(int32_t) * (3 + SPL_COUNTS) * T));
+        h->d_nnz = reinterpret_cast<int32_t*>(blk + sizeof(int64_t) * T);
+    }
+    int64_t* d_ecount = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(h->d_nnz) - sizeof(int64_t) * T);
+    if (!h->d_rowcnt) HIPCK(pool_malloc(&h->d_rowcnt, sizeof(int32_t) * (size_t)h->R));
+    edge_rows(h, A, h->d_rowcnt, d_ecount, s);
     hipLaunchKernelGGL(k_count_edges, dim3(T), dim3(256), 0, s, h->d_meta, A, h->d_nnz, look_at_x ? X : nullptr,
                        look_at_x ? h->d_nnz + (2 + SPL_COUNTS) * (size_t)T : nullptr);
     if (!h->prob.graph_mode) {
@@ -1239,8 +1393,15 @@ extern "C" int gnnx_plan_analyze_features(gnnx_handle h, const float* A, const f
     HIPCK(hipGetLastError());
     // per target: (directed entries, row slots over all rows); then k_count_edges_large's SPL_COUNTS figures
     h->nnz.assign((3 + SPL_COUNTS) * (size_t)T, -1);   // ..., then one flag per target: constant feature rows (0 when X was not given)
-    HIPCK(hipMemcpyAsync(h->nnz.data(), h->d_nnz, sizeof(int32_t) * (h->prob.graph_mode ? 2 : (look_at_x ? 3 : 2) + SPL_COUNTS) * T, hipMemcpyDeviceToHost, s));
-    HIPCK(hipStreamSynchronize(s));
+    {
+        const size_t ints = (size_t)(h->prob.graph_mode ? 2 : (look_at_x ? 3 : 2) + SPL_COUNTS) * T;   // the written prefix of the int32 part
+        std::vector<char> back(sizeof(int64_t) * T + sizeof(int32_t) * ints);
+        HIPCK(hipMemcpyAsync(back.data(), d_ecount, back.size(), hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+        h->edge_counts.resize(T);
+        std::memcpy(h->edge_counts.data(), back.data(), sizeof(int64_t) * T);
+        std::memcpy(h->nnz.data(), back.data() + sizeof(int64_t) * T, sizeof(int32_t) * ints);
+    }
     h->xconst = 0;
     const bool graph = h->prob.graph_mode != 0;
     if (h->prob.C > RES_CMAX || h->prob.mask_relu || h->prob.bn) return 0;   // mask_act = "ReLU" and --bn run on the dense streaming kernels only
@@ -1357,8 +1518,10 @@ extern "C" int gnnx_plan_analyze_features(gnnx_handle h, const float* A, const f
         if (const char* env = std::getenv("GNNX_XCONST")) xc_form = std::max(0, std::min(2, std::atoi(env)));
         h->xconst = (any && all && exact_shape(h, 10)) ? xc_form : 0;
     }
-    if (changed)
+    if (changed || h->split_dirty) {
         if (int rc = build_split(h)) return rc;
+        if (int rc = use_tables(h, s, false)) return rc;   // (the kernels below read the new lists)
+    }
     // CSR of the large-class targets, built once per plan (the kernel would otherwise rescan its dense block per launch)
     if (h->n_sp[SPC_LARGE] > 0) {
         std::vector<long long> off(2 * (size_t)T, -1);   // -1: not a target of k_sparse_large (k_csr_emit_large skips its row blocks)
@@ -1399,6 +1562,7 @@ extern "C" int gnnx_pack_csr(gnnx_handle h, const int64_t* indptr, const int32_t
     if (!h->prob.graph_mode && (!pred_label || !yhat)) return fail("pred_label / yhat are required in node mode");
     hipStream_t s = static_cast<hipStream_t>(stream);
     // (k_pack zeroes its own 32-row blocks of A, X and yhat first: every block of the batch belongs to one workgroup)
+    if (int rc = use_tables(h, s, false)) return rc;
     PackArgs a{indptr, indices, weights, feat, feat_stride, pred_label, nb, nb_off, A, X, yhat, h->prob.D};
     hipLaunchKernelGGL(k_pack, dim3(h->n_conv), dim3(256), 0, s, a, h->d_conv);
     HIPCK(hipGetLastError());
@@ -1418,7 +1582,7 @@ extern "C" int gnnx_khop(const int64_t* indptr, const int32_t* indices, int32_t 
                          void* scratch, size_t scratch_bytes, void* stream) {
     if (!indptr || !indices || !targets || num_nodes < 1 || num_targets < 1 || n_hops < 1) return fail("bad argument");
     const bool emit = nb != nullptr;
-    if (emit ? (!nb_off || !target_row) : !sizes) return fail("null output");
+    if (emit ? !nb_off : !sizes) return fail("null output");   // (target_row: optional in both passes)
     const int words = (num_nodes + 31) / 32;
     const bool in_lds = words <= KH_LDS_WORDS;
     if (!in_lds && (!scratch || scratch_bytes < gnnx_khop_scratch_bytes(num_nodes, num_targets))) return fail("k-hop scratch too small");
@@ -1446,6 +1610,7 @@ extern "C" int64_t gnnx_total_raw(gnnx_handle h) { return h ? h->total_raw : -1;
 
 extern "C" int gnnx_scatter_masks(gnnx_handle h, const float* raw, float* M, void* stream) {
     if (!h || !raw || !M) return fail("null argument");
+    if (int rc = use_tables(h, static_cast<hipStream_t>(stream), false)) return rc;
     hipLaunchKernelGGL(k_scatter_masks, dim3(h->n_conv), dim3(256), 0, static_cast<hipStream_t>(stream), raw, h->d_raw_off, M, h->d_conv);
     HIPCK(hipGetLastError());
     mark_busy(h, static_cast<hipStream_t>(stream));
@@ -1465,6 +1630,8 @@ extern "C" int gnnx_edge_counts(gnnx_handle h, const float* A, int64_t* counts, 
     // has a workspace only in theory - every caller has one by now; keep the ABI: a private scratch per plan
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!h->d_rowcnt) HIPCK(pool_malloc(&h->d_rowcnt, sizeof(int32_t) * (size_t)h->R));
+    if (int rc = use_tables(h, s, false)) return rc;
+    h->edge_counts.clear();   // (the cached host counts belong to the adjacency the analysis saw; this call may count another one)
     edge_rows(h, A, h->d_rowcnt, counts, s);
     HIPCK(hipGetLastError());
     mark_busy(h, s);
@@ -1478,6 +1645,7 @@ extern "C" int gnnx_gather_edges(gnnx_handle h, const float* A, const float* Aba
     if (workspace_bytes < h->ws_bytes) return fail("workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     EdgeOut o{eoff, rc, abar, m_rc, edge_scratch(h, workspace), nullptr};
+    if (int rc = use_tables(h, s, false)) return rc;
     edge_rows(h, A, o.rowcnt, nullptr, s);
     hipLaunchKernelGGL(k_edge_emit, dim3(h->n_conv), dim3(256), 0, s, A, Abar, M, h->d_conv, o);
     HIPCK(hipGetLastError());
@@ -1491,7 +1659,28 @@ extern "C" int gnnx_edge_positions(gnnx_handle h, const float* A, const int64_t*
     if (workspace_bytes < h->ws_bytes) return fail("workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     EdgeOut o{eoff, rc, nullptr, nullptr, edge_scratch(h, workspace), epos};
+    if (int rc = use_tables(h, s, false)) return rc;
     edge_rows(h, A, o.rowcnt, nullptr, s);
+    hipLaunchKernelGGL(k_edge_emit, dim3(h->n_conv), dim3(256), 0, s, A, (const float*)nullptr, (const float*)nullptr, h->d_conv, o);
+    HIPCK(hipGetLastError());
+    mark_busy(h, s);
+    return 0;
+}
+
+extern "C" int gnnx_edge_counts_host(gnnx_handle h, int64_t* counts) {
+    if (!h || !counts) return fail("null argument");
+    if ((int)h->edge_counts.size() != h->prob.num_targets) return fail("gnnx_edge_counts_host: no analysis has counted the edges of this plan yet");
+    std::memcpy(counts, h->edge_counts.data(), sizeof(int64_t) * h->edge_counts.size());
+    return 0;
+}
+
+extern "C" int gnnx_edge_layout(gnnx_handle h, const float* A, const int64_t* eoff, int32_t* rc, int64_t* epos, void* stream) {
+    if (!h || !A || !eoff || !rc || !epos) return fail("null argument");
+    if (!h->d_rowcnt || (int)h->edge_counts.size() != h->prob.num_targets)
+        return fail("gnnx_edge_layout: needs the row starts of gnnx_plan_analyze* on this adjacency (use gnnx_edge_positions otherwise)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc2 = use_tables(h, s, false)) return rc2;
+    EdgeOut o{eoff, rc, nullptr, nullptr, h->d_rowcnt, epos};
     hipLaunchKernelGGL(k_edge_emit, dim3(h->n_conv), dim3(256), 0, s, A, (const float*)nullptr, (const float*)nullptr, h->d_conv, o);
     HIPCK(hipGetLastError());
     mark_busy(h, s);
@@ -1513,6 +1702,7 @@ extern "C" int gnnx_denoise_edges(gnnx_handle h, const int64_t* eoff, const int3
     if (!h || !eoff || !rc || !vals || !keep || !threshold || !stats || !workspace) return fail("null argument");
     if (threshold_num < 1) return fail("threshold_num must be positive");
     if (workspace_bytes < h->ws_bytes) return fail("workspace too small");
+    if (int rc = use_tables(h, static_cast<hipStream_t>(stream), false)) return rc;
     char* w = static_cast<char*>(workspace);
     DenoiseArgs a{h->d_meta, eoff, rc, vals, threshold_num, keep, threshold, stats, reinterpret_cast<int32_t*>(w + h->o_g3),
                   reinterpret_cast<int32_t*>(w + h->o_z3p)};
@@ -1540,6 +1730,7 @@ extern "C" int gnnx_forward(gnnx_handle h, const float* A, const float* X, const
     if (!h || !A || !X || !M || !Abar || !probs || !workspace) return fail("null argument");
     if (workspace_bytes < h->ws_bytes) return fail("workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = use_tables(h, s)) return rc;
     Params p = make_params(h, nullptr, A, X, nullptr, const_cast<float*>(M), Abar, nullptr, workspace);
     p.num_iters = 1;
     if (int rc = ensure_mask_all(h)) return rc;
@@ -1561,6 +1752,7 @@ extern "C" int gnnx_grad_baseline(gnnx_handle h, const float* A, const float* X,
     if (h->prob.bn) return fail("the gradient baseline with --bn is not implemented");
     if (workspace_bytes < h->ws_bytes) return fail("workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = use_tables(h, s)) return rc;
     // the streaming forward / backward with Abar := A (unmasked adjacency, diagonal included as the reference's model(x, adj))
     Params p = make_params(h, nullptr, A, X, nullptr, nullptr, const_cast<float*>(A), nullptr, workspace);
     p.num_iters = 1;
@@ -1589,6 +1781,7 @@ extern "C" int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hy, int32_t kin
     if (!h || !hy || !ms_avg || reps < 1) return fail("bad argument");
     if (workspace_bytes < h->ws_bytes) return fail("workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = use_tables(h, s)) return rc;
     Params p = make_params(h, hy, A, X, yhat, M, Abar, nullptr, workspace);
     hipEvent_t e0, e1;
     HIPCK(hipEventCreate(&e0));

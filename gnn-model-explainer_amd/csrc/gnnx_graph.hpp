@@ -109,12 +109,21 @@ __global__ __launch_bounds__(KH_THREADS) void k_khop(KhopArgs a) {
         const int base = kh_block_scan_exclusive(cnt, tid, s_wave, &total);
         if (!EMIT) {
             if (tid == 0) a.sizes[t] = total;
+            // node_idx_new falls out of the size pass as well (the reached bits below the target's own; explain.py:496), so the host learns
+            // sizes AND rows from ONE copy and the emit pass has nothing to report back
+            const int vw = v >> 5;
+            if (a.target_row && vw >= w0 && vw < w1) {
+                int pos = base;
+                for (int w = w0; w < vw; ++w) pos += __popc(reach[w]);
+                const uint32_t bits = reach[vw], bit = 1u << (v & 31);
+                a.target_row[t] = (bits & bit) ? pos + __popc(bits & (bit - 1u)) : -1;
+            }
         } else {
             int32_t* out = a.nb + a.nb_off[t];
             int pos = base;
             for (int w = w0; w < w1; ++w) {
                 uint32_t bits = reach[w];
-                if (w == (v >> 5)) {  // the target's own position (explain.py:496: number of neighbours with a smaller id)
+                if (a.target_row && w == (v >> 5)) {  // the target's own position (explain.py:496: number of neighbours with a smaller id)
                     const uint32_t bit = 1u << (v & 31);
                     a.target_row[t] = (bits & bit) ? pos + __popc(bits & (bit - 1u)) : -1;
                 }

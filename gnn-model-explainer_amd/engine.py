@@ -153,6 +153,8 @@ _API = {
                                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "gnnx_grad_baseline": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_size_t, ctypes.c_void_p]),
     "gnnx_edge_positions": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p]),
+    "gnnx_edge_counts_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "gnnx_edge_layout": (ctypes.c_int, [ctypes.c_void_p] * 6),
     "gnnx_gather_values": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 5),
     "gnnx_denoise_edges": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_void_p]),
     "gnnx_auc_counts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
@@ -293,28 +295,40 @@ class EdgeMasks:
         return out
 
 
+def _h2d(arr, dev):
+    """Host array -> device tensor without a host-blocking round trip: a pageable source makes the copy synchronous (the preparing thread of a
+    pipelined job then waits for a blit kernel to find a free compute unit); through pinned staging it is only enqueued."""
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    if dev.type == _DEVICE_TYPE:
+        return t.pin_memory().to(dev, non_blocking=True)
+    return t.to(dev)
+
+
 def khop_device(graph, targets, n_hops, lib=None) -> DeviceNeighbors:
     """k-hop walk sets of `targets` on the device from the resident CSR graph (gnnx_khop): the neighbour lists of
     graph_utils.neighborhoods + Explainer.extract_neighborhood (utils/graph_utils.py:147-158, explain.py:492-501)
-    without the host.  Two passes: sizes (the host needs them for the plan), then the ascending lists + node_idx_new."""
+    without the host.  Two passes: sizes and node_idx_new (ONE copy back: the host needs them for the plan), then the ascending
+    lists, which stay on the device (the emit pass reports nothing back, so nothing waits for it)."""
     lib = lib if lib is not None else get_library()
     dev = graph.feat.device
     T = len(targets)
-    tg = torch.from_numpy(np.ascontiguousarray(targets, dtype=np.int32)).to(dev)
-    sizes_d = torch.empty(T, dtype=torch.int32, device=dev)
+    tg = _h2d(np.asarray(targets, dtype=np.int32), dev)
+    sr_d = torch.empty(2, T, dtype=torch.int32, device=dev)          # sizes | rows
     sb = int(lib.gnnx_khop_scratch_bytes(graph.num_nodes, T))
     scratch = torch.empty(max(sb, 1), dtype=torch.uint8, device=dev)
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream if dev.type == _DEVICE_TYPE else 0)
     args = (graph.indptr.data_ptr(), graph.indices.data_ptr(), graph.num_nodes, int(n_hops), tg.data_ptr(), T)
-    _check(lib, lib.gnnx_khop(*args, sizes_d.data_ptr(), None, None, None, scratch.data_ptr(), sb, stream))
-    sizes = sizes_d.cpu().numpy()                      # synchronises
+    _check(lib, lib.gnnx_khop(*args, sr_d[0].data_ptr(), None, None, sr_d[1].data_ptr(), scratch.data_ptr(), sb, stream))
+    sr = sr_d.cpu().numpy()                            # synchronises
+    sizes = sr[0]
     off = np.zeros(T + 1, np.int64)
     np.cumsum(sizes, out=off[1:])
-    nb_off = torch.from_numpy(off).to(dev)
+    nb_off = _h2d(off, dev)
     nb_flat = torch.empty(max(int(off[-1]), 1), dtype=torch.int32, device=dev)
-    rows_d = torch.empty(T, dtype=torch.int32, device=dev)
-    _check(lib, lib.gnnx_khop(*args, None, nb_off.data_ptr(), nb_flat.data_ptr(), rows_d.data_ptr(), scratch.data_ptr(), sb, stream))
-    return DeviceNeighbors(sizes.astype(np.int32), rows_d.cpu().numpy(), nb_flat, nb_off)
+    _check(lib, lib.gnnx_khop(*args, None, nb_off.data_ptr(), nb_flat.data_ptr(), None, scratch.data_ptr(), sb, stream))
+    dn = DeviceNeighbors(sizes.astype(np.int32), sr[1].copy(), nb_flat, nb_off)
+    dn._keepalive = (tg, scratch)                      # inputs of the emit pass, which may still be running
+    return dn
 
 
 def device_graph(csr, feat, pred=None, device=None):
@@ -393,6 +407,11 @@ class MaskOptimJob:
         self._enter()
         _check(self.lib, self.lib.gnnx_plan_analyze_features(self.handle, self.A.data_ptr(), self.X.data_ptr(), self._stream()))
         self._leave()
+        # the analysis counted the upper-triangle edges as well (the layout of the results): no separate count + copy later
+        counts = np.zeros(self.T, np.int64)
+        _check(self.lib, self.lib.gnnx_edge_counts_host(self.handle, counts.ctypes.data))
+        self._edge_counts = counts
+        self._eoff = None
 
     def set_complete_graphs(self):
         """Replace every target's packed adjacency by the complete graph on its n nodes, A = 1 - I (ExplainModule.forward with
@@ -402,6 +421,7 @@ class MaskOptimJob:
             v[:n, :n] = 1.0 - np.eye(int(n), dtype=np.float32)
         self.A.copy_(torch.from_numpy(A))
         self._eoff = None          # the edge layout belongs to the old adjacency
+        self._edge_counts = None   # ... and so do the counts of the last analysis
 
     def adjacency(self):
         """Per-target dense sub-adjacencies as packed on the device (host copies)."""
@@ -567,21 +587,29 @@ class MaskOptimJob:
     def _edge_layout(self):
         dev = self.device
         if getattr(self, "_eoff", None) is None:      # the edge structure of the batch is fixed: count once
-            counts = torch.empty(self.T, dtype=torch.int64, device=dev)
-            self._enter()
-            _check(self.lib, self.lib.gnnx_edge_counts(self.handle, self.A.data_ptr(), counts.data_ptr(), self._stream()))
-            self._leave()
+            counts = getattr(self, "_edge_counts", None)
+            cached = counts is not None               # analyze() counted on this adjacency and left the row starts on the device
+            if not cached:
+                counts_d = torch.empty(self.T, dtype=torch.int64, device=dev)
+                self._enter()
+                _check(self.lib, self.lib.gnnx_edge_counts(self.handle, self.A.data_ptr(), counts_d.data_ptr(), self._stream()))
+                self._leave()
+                counts = counts_d.cpu().numpy()
             eoff = np.zeros(self.T + 1, np.int64)
-            np.cumsum(counts.cpu().numpy(), out=eoff[1:])
-            self._eoff, self._eoff_d = eoff, torch.from_numpy(eoff).to(dev)
+            np.cumsum(counts, out=eoff[1:])
+            self._eoff, self._eoff_d = eoff, _h2d(eoff, dev)
             E = max(int(eoff[-1]), 1)
             self._rc = torch.empty(E, 2, dtype=torch.int32, device=dev)
             self._ev = torch.empty(E, dtype=torch.float32, device=dev)
             self._em = torch.empty(E, 2, dtype=torch.float32, device=dev)
             self._epos = torch.empty(E, 2, dtype=torch.int64, device=dev)
             self._enter()        # the (fixed) edge structure, once: rc and the position of every edge in the packed arrays
-            _check(self.lib, self.lib.gnnx_edge_positions(self.handle, self.A.data_ptr(), self._eoff_d.data_ptr(), self._rc.data_ptr(),
-                                                          self._epos.data_ptr(), self.ws.data_ptr(), self.ws_bytes, self._stream()))
+            if cached:
+                _check(self.lib, self.lib.gnnx_edge_layout(self.handle, self.A.data_ptr(), self._eoff_d.data_ptr(), self._rc.data_ptr(),
+                                                           self._epos.data_ptr(), self._stream()))
+            else:
+                _check(self.lib, self.lib.gnnx_edge_positions(self.handle, self.A.data_ptr(), self._eoff_d.data_ptr(), self._rc.data_ptr(),
+                                                              self._epos.data_ptr(), self.ws.data_ptr(), self.ws_bytes, self._stream()))
             self._leave()
 
     def gather_edges_device(self, with_mask=False) -> torch.Tensor:

@@ -239,7 +239,9 @@ int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hyper, int32_t kind, int32
  * {u : (A + A^2 + ... + A^k)[v][u] > 0} of graph_utils.neighborhoods (utils/graph_utils.py:147-158; a dense O(N^3)
  * product on the whole graph in the reference) as the ascending id list Explainer.extract_neighborhood builds from it
  * (explain.py:492-501), plus node_idx_new = the target's position in its own list (explain.py:496).  Two passes:
- *   nb == NULL : sizes[t] = |set| for every target (the host needs them for gnnx_plan_create);
+ *   nb == NULL : sizes[t] = |set| for every target (the host needs them for gnnx_plan_create); when target_row is given the
+ *                size pass reports it too (same value as the emit pass), so ONE copy tells the host sizes and rows and the
+ *                emit pass may run with target_row == NULL and report nothing back;
  *   nb != NULL : nb[nb_off[t] .. nb_off[t+1]) = the list, target_row[t] = position of the target (-1: not in its own
  *                set, i.e. an isolated node - the reference then fails on an empty neighbourhood).
  * scratch: gnnx_khop_scratch_bytes(num_nodes, num_targets) bytes (0 when the bitmaps fit LDS: num_nodes <= 131072). */
@@ -267,6 +269,12 @@ int gnnx_gather_edges(gnnx_handle h, const float* A, const float* Abar, const fl
  * and gnnx_gather_values then reads the values of any later run with one indexed load per edge. */
 int gnnx_edge_positions(gnnx_handle h, const float* A, const int64_t* eoff, int32_t* rc, int64_t* epos, void* workspace,
                         size_t workspace_bytes, void* stream);
+/* gnnx_plan_analyze* counts the edges while it looks at the adjacency anyway (one copy back for the routing figures and the counts):
+ * gnnx_edge_counts_host hands those counts to the host (HOST int64 [T]; fails when no analysis has run), and gnnx_edge_layout is
+ * gnnx_edge_positions from the row starts that analysis left on the device - one launch instead of three, no workspace.  Only valid
+ * while A is the adjacency the analysis saw; gnnx_edge_counts / gnnx_edge_positions work on any A. */
+int gnnx_edge_counts_host(gnnx_handle h, int64_t* counts);
+int gnnx_edge_layout(gnnx_handle h, const float* A, const int64_t* eoff, int32_t* rc, int64_t* epos, void* stream);
 int gnnx_gather_values(const int64_t* epos, int64_t num_edges, const float* Abar, const float* M, float* abar, float* m_rc, void* stream);
 
 /* Post-processing of a batch of explanations on the device, on the edge lists of gnnx_gather_edges (all pointers DEVICE):

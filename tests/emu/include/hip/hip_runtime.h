@@ -98,6 +98,9 @@ inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "o
 inline hipError_t hipGetLastError() { return hipSuccess; }
 template <class T> hipError_t hipMalloc(T** p, size_t n) { *p = static_cast<T*>(malloc(n ? n : 1)); return hipSuccess; }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+constexpr unsigned hipHostMallocDefault = 0;
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n ? n : 1); return hipSuccess; }
+inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
