@@ -1361,9 +1361,14 @@ extern "C" int gnnx_get_route(gnnx_handle h, int32_t* route) {
 
 extern "C" int gnnx_plan_analyze(gnnx_handle h, const float* A, void* stream) { return gnnx_plan_analyze_features(h, A, nullptr, stream); }
 
+static int analyze_impl(gnnx_handle h, const float* A, const float* X, hipStream_t s, bool rows_from_pack);
 extern "C" int gnnx_plan_analyze_features(gnnx_handle h, const float* A, const float* X, void* stream) {
     if (!h || !A) return fail("null argument");
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    return analyze_impl(h, A, X, static_cast<hipStream_t>(stream), false);
+}
+// rows_from_pack: k_pack has just written every row's off-diagonal and upper-triangle counts into d_rowdeg / d_rowcnt
+// (gnnx_pack_csr_analyze): k_row_degrees and k_edge_rowcount are not launched
+static int analyze_impl(gnnx_handle h, const float* A, const float* X, hipStream_t s, bool rows_from_pack) {
     const int T = h->prob.num_targets;
     const bool look_at_x = X && !h->prob.graph_mode;   // constant feature rows: node mode (the form exists for the node encoder's shapes)
     if (int rc = use_tables(h, s, /*need_split=*/false)) return rc;
@@ -1377,14 +1382,20 @@ extern "C" int gnnx_plan_analyze_features(gnnx_handle h, const float* A, const f
     }
     int64_t* d_ecount = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(h->d_nnz) - sizeof(int64_t) * T);
     if (!h->d_rowcnt) HIPCK(pool_malloc(&h->d_rowcnt, sizeof(int32_t) * (size_t)h->R));
-    edge_rows(h, A, h->d_rowcnt, d_ecount, s);
-    hipLaunchKernelGGL(k_count_edges, dim3(T), dim3(256), 0, s, h->d_meta, A, h->d_nnz, look_at_x ? X : nullptr,
-                       look_at_x ? h->d_nnz + (2 + SPL_COUNTS) * (size_t)T : nullptr);
+    if (rows_from_pack) {   // degrees and upper-triangle counts of every row are in d_rowdeg / d_rowcnt: one per-target launch does the rest
+        hipLaunchKernelGGL(k_count_edges, dim3(T), dim3(256), 0, s, h->d_meta, A, h->d_nnz, look_at_x ? X : nullptr,
+                           look_at_x ? h->d_nnz + (2 + SPL_COUNTS) * (size_t)T : nullptr, (const int32_t*)h->d_rowdeg, h->d_rowcnt, d_ecount);
+    } else {
+        edge_rows(h, A, h->d_rowcnt, d_ecount, s);
+        hipLaunchKernelGGL(k_count_edges, dim3(T), dim3(256), 0, s, h->d_meta, A, h->d_nnz, look_at_x ? X : nullptr,
+                           look_at_x ? h->d_nnz + (2 + SPL_COUNTS) * (size_t)T : nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
+                           (int64_t*)nullptr);
+    }
     if (!h->prob.graph_mode) {
         int nmax = 0;
         for (int t = 0; t < T; ++t) nmax = std::max(nmax, h->meta[t].n);
         if (!h->d_rowdeg) HIPCK(pool_malloc(&h->d_rowdeg, sizeof(int32_t) * (size_t)h->R));
-        hipLaunchKernelGGL(k_row_degrees, dim3(h->n_conv), dim3(256), 0, s, A, h->d_conv, h->d_rowdeg);
+        if (!rows_from_pack) hipLaunchKernelGGL(k_row_degrees, dim3(h->n_conv), dim3(256), 0, s, A, h->d_conv, h->d_rowdeg);
         hipLaunchKernelGGL((k_count_edges_large<0, 4095>), dim3(T), dim3(1024), 0, s, h->d_meta, A, h->d_rowdeg, h->d_nnz + 2 * T);
         if (nmax > 4095)
             hipLaunchKernelGGL((k_count_edges_large<4095, SPL_N_MAX>), dim3(T), dim3(1024), 0, s, h->d_meta, A, h->d_rowdeg,
@@ -1563,11 +1574,29 @@ extern "C" int gnnx_pack_csr(gnnx_handle h, const int64_t* indptr, const int32_t
     hipStream_t s = static_cast<hipStream_t>(stream);
     // (k_pack zeroes its own 32-row blocks of A, X and yhat first: every block of the batch belongs to one workgroup)
     if (int rc = use_tables(h, s, false)) return rc;
-    PackArgs a{indptr, indices, weights, feat, feat_stride, pred_label, nb, nb_off, A, X, yhat, h->prob.D};
+    PackArgs a{indptr, indices, weights, feat, feat_stride, pred_label, nb, nb_off, A, X, yhat, h->prob.D, nullptr, nullptr};
     hipLaunchKernelGGL(k_pack, dim3(h->n_conv), dim3(256), 0, s, a, h->d_conv);
     HIPCK(hipGetLastError());
     mark_busy(h, s);
     return 0;
+}
+
+// gnnx_pack_csr + gnnx_plan_analyze_features in one call: the packing kernel counts every row's entries while it places them, so the
+// analysis starts from those counts instead of rescanning the dense blocks (two launches and two passes over A fewer per batch).
+extern "C" int gnnx_pack_csr_analyze(gnnx_handle h, const int64_t* indptr, const int32_t* indices, const float* weights,
+                                     const float* feat, int32_t feat_stride, const float* pred_label, const int32_t* nb,
+                                     const int64_t* nb_off, float* A, float* X, float* yhat, void* stream) {
+    if (!h || !indptr || !indices || !feat || !nb || !nb_off || !A || !X) return fail("null argument");
+    if (!h->prob.graph_mode && (!pred_label || !yhat)) return fail("pred_label / yhat are required in node mode");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = use_tables(h, s, false)) return rc;
+    if (!h->d_rowcnt) HIPCK(pool_malloc(&h->d_rowcnt, sizeof(int32_t) * (size_t)h->R));
+    if (!h->d_rowdeg) HIPCK(pool_malloc(&h->d_rowdeg, sizeof(int32_t) * (size_t)h->R));
+    PackArgs a{indptr, indices, weights, feat, feat_stride, pred_label, nb, nb_off, A, X, yhat, h->prob.D, h->d_rowdeg, h->d_rowcnt};
+    hipLaunchKernelGGL(k_pack, dim3(h->n_conv), dim3(256), 0, s, a, h->d_conv);
+    HIPCK(hipGetLastError());
+    mark_busy(h, s);
+    return analyze_impl(h, A, X, s, true);
 }
 
 extern "C" size_t gnnx_khop_scratch_bytes(int32_t num_nodes, int32_t num_targets) {

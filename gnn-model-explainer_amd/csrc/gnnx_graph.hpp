@@ -21,8 +21,8 @@ struct KhopArgs {
     int32_t num_nodes, n_hops;
     const int32_t* targets;  // [T] node ids
     int32_t num_targets;
-    int32_t* sizes;          // [T] out (size pass)
-    const int64_t* nb_off;   // [T + 1] (emit pass)
+    int32_t* sizes;          // [T] out (size pass; optional in the emit pass)
+    const int64_t* nb_off;   // [T + 1] (emit pass): the prefix sums of the sizes, or any offsets that leave room for every list
     int32_t* nb;             // concatenated ascending neighbour lists (emit pass)
     int32_t* target_row;     // [T] out (emit pass): position of the target in its own list, -1 if absent
     uint32_t* scratch;       // global bitmaps for graphs beyond the LDS capacity: gridDim.x * 3 * words
@@ -119,6 +119,7 @@ __global__ __launch_bounds__(KH_THREADS) void k_khop(KhopArgs a) {
                 a.target_row[t] = (bits & bit) ? pos + __popc(bits & (bit - 1u)) : -1;
             }
         } else {
+            if (tid == 0 && a.sizes) a.sizes[t] = total;   // one-pass use: lists at caller-chosen (padded) offsets, sizes reported alongside
             int32_t* out = a.nb + a.nb_off[t];
             int pos = base;
             for (int w = w0; w < w1; ++w) {

@@ -1242,6 +1242,11 @@ struct PackArgs {
     float* X;
     float* yhat;
     int32_t D;
+    // by-products for the analysis that follows the packing (gnnx_pack_csr_analyze), both [R] or null: every row's off-diagonal
+    // non-zeros (what k_row_degrees counts) and its upper-triangle non-zeros (k_edge_rowcount) - the packing places every entry of the
+    // row anyway, so two launches and two passes over A fall away.  (The CSR holds every (u, v) once: engine.device_graph sums duplicates.)
+    int32_t* rowdeg;
+    int32_t* rowcnt;
 };
 
 __global__ __launch_bounds__(256) void k_pack(PackArgs a, const ConvTile* tiles) {
@@ -1259,19 +1264,37 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a, const ConvTile* tiles)
         if (a.yhat && threadIdx.x < TILE) a.yhat[tm.offR + tl.rb * TILE + threadIdx.x] = 0.0f;
     }
     __syncthreads();
-    if (i >= tm.n) return;
+    const bool live = i < tm.n;   // (all eight lanes of a row agree; padding rows stay zero and report zero counts)
     const int32_t* nb = a.nb + a.nb_off[tl.t];
-    const int u = nb[i];
-    float* Arow = a.A + tm.offQ + (size_t)i * tm.ld;
-    for (int64_t e = a.indptr[u] + part; e < a.indptr[u + 1]; e += 8) {
-        const int v = a.indices[e];
-        int lo = 0, hi = tm.n - 1;
-        while (lo < hi) {  // lower bound of v in the ascending neighbour list
-            const int mid = (lo + hi) >> 1;
-            if (nb[mid] < v) lo = mid + 1; else hi = mid;
+    const int u = live ? nb[i] : 0;
+    int deg = 0, up = 0;
+    if (live) {
+        float* Arow = a.A + tm.offQ + (size_t)i * tm.ld;
+        for (int64_t e = a.indptr[u] + part; e < a.indptr[u + 1]; e += 8) {
+            const int v = a.indices[e];
+            int lo = 0, hi = tm.n - 1;
+            while (lo < hi) {  // lower bound of v in the ascending neighbour list
+                const int mid = (lo + hi) >> 1;
+                if (nb[mid] < v) lo = mid + 1; else hi = mid;
+            }
+            if (nb[lo] == v) {
+                const float w = a.weights ? a.weights[e] : 1.0f;
+                Arow[lo] = w;
+                deg += (w != 0.0f && lo != i);
+                up += (w != 0.0f && lo > i);
+            }
         }
-        if (nb[lo] == v) Arow[lo] = a.weights ? a.weights[e] : 1.0f;
     }
+    if (a.rowdeg || a.rowcnt) {   // the row's eight lanes are adjacent lanes of one wave
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            deg += __shfl_xor(deg, o);
+            up += __shfl_xor(up, o);
+        }
+        if (part == 0 && a.rowdeg) a.rowdeg[tm.offR + i] = deg;
+        if (part == 0 && a.rowcnt) a.rowcnt[tm.offR + i] = up;
+    }
+    if (!live) return;
     float* Xrow = a.X + ((size_t)tm.offR + i) * FS;
     for (int c = part; c < a.D; c += 8) Xrow[c] = a.feat[(size_t)u * a.feat_stride + c];
     if (part == 0 && a.pred_label) a.yhat[tm.offR + i] = a.pred_label[u];

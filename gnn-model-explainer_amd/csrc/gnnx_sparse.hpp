@@ -1680,14 +1680,35 @@ __global__ __launch_bounds__(512) void k_sparse_resident_mixed(Params p, const i
 // resident kernel would need (-1: more than SP_LD_MAX rows) -> out[2 t], out[2 t + 1]   (gnnx_plan_analyze)
 // X (may be null) -> xconst[t] = 1 when every feature row of the target equals its first row bit for bit (all FS columns: the
 // padding columns are zero in every row), else 0   (gnnx_plan_analyze_features: selects the constant-feature form of the kernel)
+// rowdeg / rowcnt / ecount (gnnx_pack_csr_analyze: the packing kernel has just counted every row): the degrees are READ instead of
+// rescanned from the dense block, and wave 0 turns the rows' upper-triangle counts into row starts + the target's edge count (what
+// k_edge_rowscan does as a launch of its own) - one per-target launch for the routing figures and the edge layout together.
 __global__ __launch_bounds__(256) void k_count_edges(const TargetMeta* meta, const float* A, int32_t* out, const float* X = nullptr,
-                                                     int32_t* xconst = nullptr) {
+                                                     int32_t* xconst = nullptr, const int32_t* rowdeg = nullptr, int32_t* rowcnt = nullptr,
+                                                     int64_t* ecount = nullptr) {
     __shared__ int deg[SP_LD_MAX];
     __shared__ int part[4];
     __shared__ int differs;
     const TargetMeta tm = meta[blockIdx.x];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool small = tm.ld <= SP_LD_MAX;
+    if (rowcnt && wave == 0) {   // exclusive scan of the rows' upper-triangle counts, in place (k_edge_rowscan)
+        int32_t* rc = rowcnt + tm.offR;
+        int carry = 0;
+        for (int r0 = 0; r0 < tm.n; r0 += 64) {
+            const int r = r0 + lane;
+            const int v = (r < tm.n) ? rc[r] : 0;
+            int incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int x = __shfl(incl, lane - d);
+                if (lane >= d) incl += x;
+            }
+            if (r < tm.n) rc[r] = carry + incl - v;
+            carry += __shfl(incl, 63);
+        }
+        if (lane == 0 && ecount) ecount[blockIdx.x] = carry;
+    }
     if (!small) {  // cannot take the sparse kernel whatever its edge count: skip the scan
         if (tid == 0) {
             out[2 * blockIdx.x] = -1;
@@ -1708,6 +1729,17 @@ __global__ __launch_bounds__(256) void k_count_edges(const TargetMeta* meta, con
         if (tid == 0) xconst[blockIdx.x] = differs ? 0 : 1;
     }
     int cnt = 0;
+    if (rowdeg) {   // one row per thread; the wave's rows summed with a butterfly
+        int d = 0;
+        for (int r = tid; r < tm.n; r += 256) {
+            const int dr = rowdeg[tm.offR + r];
+            deg[r] = dr;
+            d += dr;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o);
+        cnt = d;
+    } else
     for (int r = wave; r < tm.n; r += 4) {
         int d = 0;
         for (int c0 = 0; c0 < tm.n; c0 += 64) {

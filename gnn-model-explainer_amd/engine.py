@@ -147,6 +147,7 @@ _API = {
     "gnnx_resident_times": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
     "gnnx_set_trace": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "gnnx_pack_csr": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int32] + [ctypes.c_void_p] * 7),
+    "gnnx_pack_csr_analyze": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int32] + [ctypes.c_void_p] * 7),
     "gnnx_forward": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_void_p] * 7 + [ctypes.c_size_t, ctypes.c_void_p]),
     "gnnx_time_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper), ctypes.c_int32, ctypes.c_int32] +
                          [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
@@ -263,7 +264,7 @@ class DeviceNeighbors:
     sizes: np.ndarray          # host int32 [T]
     rows: np.ndarray           # host int32 [T]: node_idx_new of every target (-1: the target is not in its own set)
     nb_flat: torch.Tensor      # device int32 [sum sizes], ascending per target
-    nb_off: torch.Tensor       # device int64 [T + 1]
+    nb_off: torch.Tensor       # device int64 [T + 1]: start of every list in nb_flat (prefix sums of the sizes, or a fixed stride: khop_device(one_pass=True))
 
     def __len__(self):
         return len(self.sizes)
@@ -271,7 +272,7 @@ class DeviceNeighbors:
     def lists(self):
         """Host copies, one ascending id array per target (tests / inspection)."""
         flat, off = self.nb_flat.cpu().numpy(), self.nb_off.cpu().numpy()
-        return [flat[off[t]:off[t + 1]].astype(np.int64) for t in range(len(self.sizes))]
+        return [flat[off[t]:off[t] + int(self.sizes[t])].astype(np.int64) for t in range(len(self.sizes))]
 
 
 @dataclass
@@ -304,11 +305,16 @@ def _h2d(arr, dev):
     return t.to(dev)
 
 
-def khop_device(graph, targets, n_hops, lib=None) -> DeviceNeighbors:
+_ONE_PASS_MAX_INTS = 1 << 24      # padded lists of a one-pass k-hop batch: at most 64 MB
+
+
+def khop_device(graph, targets, n_hops, lib=None, one_pass=False) -> DeviceNeighbors:
     """k-hop walk sets of `targets` on the device from the resident CSR graph (gnnx_khop): the neighbour lists of
     graph_utils.neighborhoods + Explainer.extract_neighborhood (utils/graph_utils.py:147-158, explain.py:492-501)
     without the host.  Two passes: sizes and node_idx_new (ONE copy back: the host needs them for the plan), then the ascending
-    lists, which stay on the device (the emit pass reports nothing back, so nothing waits for it)."""
+    lists, which stay on the device (the emit pass reports nothing back, so nothing waits for it).
+    one_pass=True (pipeline.BatchPipeline): ONE launch - every list gets num_nodes slots (nb_off[t] = t * num_nodes, so the offsets do
+    not depend on the sizes) and the sizes come back from the same pass; falls back to two passes when the padded lists would exceed 64 MB."""
     lib = lib if lib is not None else get_library()
     dev = graph.feat.device
     T = len(targets)
@@ -318,6 +324,20 @@ def khop_device(graph, targets, n_hops, lib=None) -> DeviceNeighbors:
     scratch = torch.empty(max(sb, 1), dtype=torch.uint8, device=dev)
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream if dev.type == _DEVICE_TYPE else 0)
     args = (graph.indptr.data_ptr(), graph.indices.data_ptr(), graph.num_nodes, int(n_hops), tg.data_ptr(), T)
+    if one_pass and T * graph.num_nodes <= _ONE_PASS_MAX_INTS:
+        cache = graph.__dict__.setdefault("_padded_offsets", {})
+        nb_off = cache.get(T)
+        if nb_off is None:               # the same for every batch of T targets: uploaded once per graph
+            nb_off = _h2d(np.arange(T + 1, dtype=np.int64) * graph.num_nodes, dev)
+            if dev.type == _DEVICE_TYPE:
+                torch.cuda.current_stream(dev).synchronize()     # other threads will use it on THEIR streams: it must have arrived
+            cache[T] = nb_off
+        nb_flat = torch.empty(T * graph.num_nodes, dtype=torch.int32, device=dev)
+        _check(lib, lib.gnnx_khop(*args, sr_d[0].data_ptr(), nb_off.data_ptr(), nb_flat.data_ptr(), sr_d[1].data_ptr(), scratch.data_ptr(), sb, stream))
+        sr = sr_d.cpu().numpy()                        # synchronises
+        dn = DeviceNeighbors(sr[0].astype(np.int32), sr[1].copy(), nb_flat, nb_off)
+        dn._keepalive = (tg, scratch)
+        return dn
     _check(lib, lib.gnnx_khop(*args, sr_d[0].data_ptr(), None, None, sr_d[1].data_ptr(), scratch.data_ptr(), sb, stream))
     sr = sr_d.cpu().numpy()                            # synchronises
     sizes = sr[0]
@@ -390,7 +410,9 @@ class MaskOptimJob:
             nb_flat = torch.from_numpy(np.concatenate(neighbors).astype(np.int32)).to(self.device)
             nb_off_d = torch.from_numpy(nb_off).to(self.device)
         self._enter()
-        _check(self.lib, self.lib.gnnx_pack_csr(
+        # packing + routing analysis as one call (the packing kernel counts the rows' entries for the analysis as it places them)
+        pack = self.lib.gnnx_pack_csr_analyze if analyze else self.lib.gnnx_pack_csr
+        _check(self.lib, pack(
             self.handle, graph.indptr.data_ptr(), graph.indices.data_ptr(),
             graph.weights.data_ptr() if graph.weights is not None else None, graph.feat.data_ptr(), graph.feat.shape[1],
             graph.pred_label.data_ptr(), nb_flat.data_ptr(), nb_off_d.data_ptr(), self.A.data_ptr(), self.X.data_ptr(),
@@ -398,7 +420,7 @@ class MaskOptimJob:
         self._leave()
         self._keepalive = (nb_flat, nb_off_d, graph)
         if analyze:
-            self.analyze()
+            self._take_edge_counts()
         return self
 
     def analyze(self):
@@ -407,7 +429,10 @@ class MaskOptimJob:
         self._enter()
         _check(self.lib, self.lib.gnnx_plan_analyze_features(self.handle, self.A.data_ptr(), self.X.data_ptr(), self._stream()))
         self._leave()
-        # the analysis counted the upper-triangle edges as well (the layout of the results): no separate count + copy later
+        self._take_edge_counts()
+
+    def _take_edge_counts(self):
+        """The analysis counted the upper-triangle edges as well (the layout of the results): no separate count + copy later."""
         counts = np.zeros(self.T, np.int64)
         _check(self.lib, self.lib.gnnx_edge_counts_host(self.handle, counts.ctypes.data))
         self._edge_counts = counts

@@ -160,7 +160,7 @@ class BatchPipeline:
         if ev is not None:
             ev.synchronize()
         with torch.cuda.stream(s_prep):
-            dn = engine.khop_device(self.graph, targets, self.n_hops, lib=self.lib)
+            dn = engine.khop_device(self.graph, targets, self.n_hops, lib=self.lib, one_pass=True)
             p.times["khop_ms"] = (time.perf_counter() - t0) * 1e3
             if (dn.rows < 0).any():
                 raise ValueError("a target is not in its own %d-hop walk set (isolated node): the reference fails on it too" % self.n_hops)

@@ -208,6 +208,11 @@ int gnnx_resident_times(gnnx_handle h, float* ms);
 int gnnx_pack_csr(gnnx_handle h, const int64_t* indptr, const int32_t* indices, const float* weights, const float* feat,
                   int32_t feat_stride, const float* pred_label, const int32_t* nb, const int64_t* nb_off, float* A,
                   float* X, float* yhat, void* stream);
+/* gnnx_pack_csr followed by gnnx_plan_analyze_features(h, A, X) as ONE call: the packing kernel counts every row's entries while it
+ * places them, so the analysis needs no pass of its own over the dense blocks (two launches fewer per batch). */
+int gnnx_pack_csr_analyze(gnnx_handle h, const int64_t* indptr, const int32_t* indices, const float* weights, const float* feat,
+                          int32_t feat_stride, const float* pred_label, const int32_t* nb, const int64_t* nb_off, float* A, float* X,
+                          float* yhat, void* stream);
 
 /* One forward only (no update): fills Abar from M and returns softmax probabilities of the head,
  * probs device out [T][GNNX_MAX_CLASSES] (ExplainModule.forward, explain.py:685-715). */
@@ -242,7 +247,9 @@ int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hyper, int32_t kind, int32
  *   nb == NULL : sizes[t] = |set| for every target (the host needs them for gnnx_plan_create); when target_row is given the
  *                size pass reports it too (same value as the emit pass), so ONE copy tells the host sizes and rows and the
  *                emit pass may run with target_row == NULL and report nothing back;
- *   nb != NULL : nb[nb_off[t] .. nb_off[t+1]) = the list, target_row[t] = position of the target (-1: not in its own
+ *   nb != NULL : nb[nb_off[t] .. nb_off[t] + |set|) = the list (nb_off = the prefix sums of the sizes for compact lists; a caller that
+ *                cannot wait for the sizes may pass any offsets that leave room - e.g. t * num_nodes - and ask for sizes in the same
+ *                pass: ONE launch, lists padded), target_row[t] = position of the target (-1: not in its own
  *                set, i.e. an isolated node - the reference then fails on an empty neighbourhood).
  * scratch: gnnx_khop_scratch_bytes(num_nodes, num_targets) bytes (0 when the bitmaps fit LDS: num_nodes <= 131072). */
 size_t gnnx_khop_scratch_bytes(int32_t num_nodes, int32_t num_targets);

@@ -239,6 +239,40 @@ def test_device_side_packing_equals_host_packing(be):
     assert torch.equal(dev.A.cpu(), host.A.cpu()) and torch.equal(dev.X.cpu(), host.X.cpu()) and torch.equal(dev.yhat.cpu(), host.yhat.cpu())
 
 
+def test_pack_with_analysis_equals_the_separate_calls(be):
+    """gnnx_pack_csr_analyze (row degrees / upper-triangle counts as by-products of the packing kernel, edge counts from the analysis copy,
+    gnnx_edge_layout from the row starts left on the device) against gnnx_pack_csr + gnnx_plan_analyze_features + gnnx_edge_counts +
+    gnnx_edge_positions: same packed arrays, same route, same edge layout - also on a weighted graph with a self-loop."""
+    import torch
+    import scipy.sparse as sp
+    from gnn_model_explainer_amd.utils.graph_utils import KHopIndex
+    ck = helpers.load_ckpt("syn1")
+    idx = KHopIndex((ck["num_nodes"], ck["edges"]), 3)
+    targets = np.asarray([302, 309, 555, 300, 420, 699])
+    for weighted in (False, True):
+        csr = sp.csr_matrix(idx.csr, dtype=np.float32)
+        if weighted:
+            rng = np.random.default_rng(3)
+            w = sp.triu(csr, 1).tocoo()
+            vals = rng.uniform(0.5, 1.5, w.nnz).astype(np.float32)
+            up = sp.coo_matrix((vals, (w.row, w.col)), shape=csr.shape)
+            csr = (up + up.T + sp.diags(np.where(np.arange(csr.shape[0]) % 7 == 0, 2.0, 0.0).astype(np.float32))).tocsr()
+        graph = engine.device_graph(csr, ck["feat"], ck["pred"], device=be.device)
+        assert graph.binary == (not weighted)
+        dn = engine.khop_device(graph, targets, 3, lib=be.lib)
+        fused = engine.MaskOptimJob.from_csr(graph, dn, None, ck["label"][targets], ck["sd"], lib=be.lib)
+        plain = engine.MaskOptimJob.from_csr(graph, dn, None, ck["label"][targets], ck["sd"], lib=be.lib, analyze=False)
+        engine._check(plain.lib, plain.lib.gnnx_plan_analyze_features(plain.handle, plain.A.data_ptr(), plain.X.data_ptr(), plain._stream()))
+        assert getattr(plain, "_edge_counts", None) is None and fused._edge_counts is not None
+        assert torch.equal(fused.A.cpu(), plain.A.cpu()) and torch.equal(fused.X.cpu(), plain.X.cpu())
+        assert np.array_equal(fused.route(), plain.route())
+        fused._edge_layout()
+        plain._edge_layout()          # gnnx_edge_counts + gnnx_edge_positions
+        assert np.array_equal(fused._eoff, plain._eoff) and int(fused._eoff[-1]) > 0
+        E = int(fused._eoff[-1])
+        assert torch.equal(fused._rc[:E].cpu(), plain._rc[:E].cpu()) and torch.equal(fused._epos[:E].cpu(), plain._epos[:E].cpu())
+
+
 @pytest.mark.parametrize("D,H,O,C,n,graph_mode,path", [
     (7, 13, 9, 3, 21, False, "resident"),     # odd widths, single-tile resident kernel
     (7, 13, 9, 3, 21, False, "stream"),       # same through the streaming kernels
@@ -607,6 +641,27 @@ def test_device_khop_equals_reference_neighbor_lists(be):
         for v, nb, row in zip(more, dn.lists(), dn.rows):
             want = KHopIndex(idx.csr, hops).neighbors(int(v))
             assert np.array_equal(nb, want) and row == (np.searchsorted(want, v) if v in want else -1)
+
+
+def test_one_pass_khop_equals_two_passes(be):
+    """khop_device(one_pass=True): ONE launch, lists at fixed-stride offsets, sizes and rows from the same pass - same lists, same packed batch."""
+    import torch
+    ck = helpers.load_ckpt("syn1")
+    from gnn_model_explainer_amd.utils.graph_utils import KHopIndex
+    idx = KHopIndex((ck["num_nodes"], ck["edges"]), 3)
+    graph = engine.device_graph(idx.csr, ck["feat"], ck["pred"], device=be.device)
+    targets = np.asarray([302, 309, 555, 300, 699, 420, 301])
+    two = engine.khop_device(graph, targets, 3, lib=be.lib)
+    one = engine.khop_device(graph, targets, 3, lib=be.lib, one_pass=True)
+    assert np.array_equal(one.sizes, two.sizes) and np.array_equal(one.rows, two.rows)
+    assert np.array_equal(one.nb_off.cpu().numpy(), np.arange(len(targets) + 1) * graph.num_nodes)
+    for a, b in zip(one.lists(), two.lists()):
+        assert np.array_equal(a, b)
+    ja = engine.MaskOptimJob.from_csr(graph, one, None, ck["label"][targets], ck["sd"], lib=be.lib)
+    jb = engine.MaskOptimJob.from_csr(graph, two, None, ck["label"][targets], ck["sd"], lib=be.lib)
+    assert torch.equal(ja.A.cpu(), jb.A.cpu()) and torch.equal(ja.X.cpu(), jb.X.cpu()) and torch.equal(ja.yhat.cpu(), jb.yhat.cpu())
+    assert np.array_equal(ja.route(), jb.route())
+    assert engine.khop_device(graph, targets, 3, lib=be.lib, one_pass=True).nb_off is one.nb_off      # the offsets are cached per graph
 
 
 def test_device_khop_isolated_node_has_empty_set(be):
