@@ -41,6 +41,16 @@ __host__ __device__ constexpr int sp_ld_max(int nt) { return nt == 512 ? 512 : 3
 constexpr int SP_LD_MAX = 32 * (SP_THREADS / 64);
 __host__ __device__ constexpr int sp_pool_floats(int nt) { return nt >= 512 ? 39168 : nt >= 256 ? 18432 : 5120; }
 constexpr int SP_GATHER_UNROLL = 2;          // entries in flight per lane in the sparse gathers
+// measurement knobs of round 4 (tools/build_variants.sh builds one library per setting; the defaults are what ships)
+#ifndef GNNX_COMBINE_FMAC
+#define GNNX_COMBINE_FMAC 1
+#endif
+#ifndef GNNX_WSPLIT_SGPR
+#define GNNX_WSPLIT_SGPR 1
+#endif
+#ifndef GNNX_ROWT_PREFETCH
+#define GNNX_ROWT_PREFETCH 1
+#endif
 constexpr int SP_CHUNK = 16;                 // entries per row slot: longer rows are split over adjacent lanes of one wave
 // row slots of a class: NT / 2 (two lanes = column halves per slot)
 
@@ -364,11 +374,19 @@ template <int NQ, int S>
 __device__ __forceinline__ void sparse_combine_step(float (&acc)[NQ], int rem, int wsplit) {
     if constexpr (S < SP_MAX_SPLIT) {
         if (S < wsplit) {  // uniform per wave
+            // one v_fmac_f32 with a DPP source per register and step (acc += shifted * m, m = 1 while the source lane still belongs to this
+            // row, else 0: the same sum as a select + add, exactly) instead of v_mov_dpp + v_cndmask + v_add through one temporary
+#if GNNX_COMBINE_FMAC
+            const float m = (S < rem) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = fmaf(row_shl<S>(acc[q]), m, acc[q]);
+#else
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const float v = row_shl<S>(acc[q]);
                 acc[q] += (S < rem) ? v : 0.0f;
             }
+#endif
             sparse_combine_step<NQ, 2 * S>(acc, rem, wsplit);
         }
     }
@@ -669,7 +687,11 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             const int other = __shfl_xor(wsplit, o);
             wsplit = other > wsplit ? other : wsplit;
         }
+#if GNNX_WSPLIT_SGPR
+        z.wsplit = __builtin_amdgcn_readfirstlane(wsplit);   // (the same in every lane: say so, and the tests on it are scalar branches)
+#else
         z.wsplit = wsplit;
+#endif
         z.wave_active = wave * TILE < sh.set_slots[k];
         rs[k] = z;
     }
@@ -1044,7 +1066,30 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 const float e2 = (c < H) ? relu_(sU2[tr * sH + kc]) : 0.0f;
                 // row t of Abar . relu(U2): the two half-lanes take alternate entries
                 float z = 0.0f;
+#if GNNX_ROWT_PREFETCH
+                {   // the first four entries of a half-lane as ONE group: (Abar, column) pairs in one LDS round trip, the four rows in the
+                    // next (the loop made it two dependent round trips per entry); same products in the same order
+                    float a4[4];
+                    int c4[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int e = rt0 + h + 2 * k;
+                        const bool in = e < rt1;
+                        const float av = sAb[in ? e : rt0];
+                        a4[k] = in ? av : 0.0f;
+                        c4[k] = scol[in ? e : rt0];
+                    }
+                    float u4[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) u4[k] = sU2[c4[k] * sH + kc];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (rt0 + h + 2 * k < rt1) z = fmaf(a4[k], relu_(u4[k]), z);   // (uniform per half-lane: a short row adds nothing, not even a zero)
+                    for (int e = rt0 + h + 8; e < rt1; e += 2) z = fmaf(sAb[e], relu_(sU2[(int)scol[e] * sH + kc]), z);
+                }
+#else
                 for (int e = rt0 + h; e < rt1; e += 2) z = fmaf(sAb[e], relu_(sU2[(int)scol[e] * sH + kc]), z);
+#endif
                 z = (c < H) ? z : 0.0f;
                 z = xor32_sum(z);
                 const int zi = __builtin_bit_cast(int, z);
