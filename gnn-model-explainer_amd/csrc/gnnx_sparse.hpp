@@ -49,7 +49,13 @@ constexpr int SP_GATHER_UNROLL = 2;          // entries in flight per lane in th
 #define GNNX_WSPLIT_SGPR 1
 #endif
 #ifndef GNNX_ROWT_PREFETCH
-#define GNNX_ROWT_PREFETCH 1
+#define GNNX_ROWT_PREFETCH 0
+#endif
+#ifndef GNNX_BROW_CHUNK
+#define GNNX_BROW_CHUNK 1
+#endif
+#ifndef GNNX_RELU_STORE
+#define GNNX_RELU_STORE 1
 #endif
 constexpr int SP_CHUNK = 16;                 // entries per row slot: longer rows are split over adjacent lanes of one wave
 // row slots of a class: NT / 2 (two lanes = column halves per slot)
@@ -125,6 +131,7 @@ struct SparseFixed {
     int xconst;  // node mode: every feature row of the sub-graph equals row 0 bit for bit (constant / featureless inputs)
     int set_rows[2], set_slots[2];
     int set_chunk[2];  // entries per row slot of the set: the smallest of {4, 8, 16} (8, 16 for set A) whose slots fit the class
+    int chunk_b;       // node mode, set A: slot width of the rows of t and its neighbours (<= set_chunk[0]; see "slot width per row")
     int erow[96];  // graph mode: arg-max row of every pooled column
     float wt[32], vsum[32];  // algebraic constant-feature form: (x (.) phi) W1, and sum over the rows of s_r dY1[r]
     float lsum[SP_THREADS / 64][4];  // LOG form: per-wave partial sums of the logged size / entropy / Laplacian terms over the owned edges
@@ -431,6 +438,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     // The <5, 10> / <7, 10> instantiations serve exactly the reference's encoders (node: D = 10, graph: D = 14; H = O = 20): the
     // widths are compile-time constants there (every column predicate, row stride and trip count folds); other shapes take <16, 16>.
     constexpr bool EXACT = (DQ != 16);
+    constexpr bool RS = (XC == 2) && (GNNX_RELU_STORE != 0);   // algebraic form: sU1 holds relu(U1) (see layer 1)
     const int D = EXACT ? 2 * DQ : p.D, H = EXACT ? 2 * HQ : p.H, O = EXACT ? 2 * HQ : p.O, C = p.C;
     const float* Ag = p.A + tm.offQ;
     float* Mg = p.M + tm.offQ;
@@ -606,12 +614,48 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             }
         }
         sh.set_chunk[set] = ch;
+        // Slot width per row (node mode, set A).  In the layer-1 backward the slots of t's and its neighbours' rows carry the expensive
+        // part - a 20-term product per ENTRY (dZ2[i] . relu(U1[j])), where every other row of the set only stores one number per
+        // entry - and they are few rows with, in a scale-free graph, many entries (a motif node's neighbours include hubs).  They take
+        // the narrowest slots that still fit the class (4, 8 entries: two to four times as many lanes share those products and the
+        // gathers of those rows); a row too long for 16 slots of that width doubles it.
+        int chb = ch;
+#if GNNX_BROW_CHUNK
+        if (!GRAPH && set == 0) {
+            for (int cand = 4; cand < ch; cand <<= 1) {
+                int tot = 0, singles = 0;
+                for (int rr = 0; rr < n; ++rr) {
+                    if (level[rr] > lvlmax) continue;
+                    const int d = rowptr[rr + 1] - rowptr[rr];
+                    int w = level[rr] <= 1 ? cand : ch;
+                    while ((d + w - 1) / w > SP_MAX_SPLIT) w <<= 1;
+                    if (d > w) {
+                        const int ns = (d + w - 1) / w;
+                        tot = sparse_place(tot, ns) + ns;
+                    } else {
+                        ++singles;
+                    }
+                }
+                if (tot + singles <= NT / 2) {
+                    chb = cand;
+                    break;
+                }
+            }
+        }
+#endif
+        if (set == 0) sh.chunk_b = chb;
+        auto row_width = [&](int rr, int d) {
+            int w = (!GRAPH && set == 0 && level[rr] <= 1) ? chb : ch;
+            while ((d + w - 1) / w > SP_MAX_SPLIT && w < SP_CHUNK) w <<= 1;
+            return w;
+        };
         int pos = 0, p = 0, cnt = 0;
         for (int d = 0; d <= SP_CHUNK; ++d) bucket[d] = 0;
         for (int rr = 0; rr < n; ++rr) {
             if (level[rr] > lvlmax) continue;
             ++cnt;
             const int d = rowptr[rr + 1] - rowptr[rr];
+            const int ch = row_width(rr, d);   // (shadows the set's width from here to the end of the row's placement)
             if (d > ch) {
                 const int ns = (d + ch - 1) / ch;
                 if (ns > SP_MAX_SPLIT) sh.bad = 1;
@@ -633,7 +677,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         for (int rr = 0; rr < n; ++rr) {
             if (level[rr] > lvlmax) continue;
             const int d = rowptr[rr + 1] - rowptr[rr];
-            if (d <= ch) order[bucket[d]++] = rr;
+            if (d <= row_width(rr, d)) order[bucket[d]++] = rr;
         }
         for (int q = p; q < cnt; ++q) slot_start[q] = pos + (q - p);
         slot_start[cnt] = pos + (cnt - p);
@@ -667,7 +711,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             }
             const int row = order[lo];
             const int ra = rowptr[row], rb = rowptr[row + 1];
-            const int ch = sh.set_chunk[k];
+            int ch = (!GRAPH && k == 0 && level[row] <= 1) ? sh.chunk_b : sh.set_chunk[k];   // slot width of this row (see above)
+            while ((rb - ra + ch - 1) / ch > SP_MAX_SPLIT && ch < SP_CHUNK) ch <<= 1;
             const int ns = (rb - ra <= ch) ? 1 : (rb - ra + ch - 1) / ch, kk = sl - slot_start[lo];
             if (kk < ns) {  // otherwise: padding slot in front of a split row
                 z.row = row;
@@ -874,8 +919,10 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 const float rnorm = fmaxf(sqrt_(ss), 1e-12f);
                 const float rinv = rcp_(rnorm);
                 if (first) {
+                    // (RS: the array holds relu(U1) - every reader of ANOTHER row wants the activation: the layer-2 gather, the per-entry
+                    // products of the backward, row t's entry of the head; the row's owner recomputes its own U1 from s_r in the backward)
 #pragma unroll
-                    for (int q = 0; q < HQ; ++q) sU1[r * sH + 2 * q + h] = y[q] * rinv;
+                    for (int q = 0; q < HQ; ++q) sU1[r * sH + 2 * q + h] = RS ? relu_(y[q] * rinv) : y[q] * rinv;
                     if (h == 0) sRn1[r] = rnorm;
                 }
             } else {
@@ -913,7 +960,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             float acc[HQ];
 #pragma unroll
             for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
-            sparse_gather<true, HQ>(sAb, scol, sU1, sH, H, re0, re1, h, acc);
+            sparse_gather<!RS, HQ>(sAb, scol, sU1, sH, H, re0, re1, h, acc);
             sparse_combine<HQ>(acc, SB.rem, wsplit);
 #pragma unroll
             for (int q = 0; q < HQ; ++q) acc[q] = first ? acc[q] : 0.0f;
@@ -1317,10 +1364,12 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                     }
                 }
                 sparse_combine<HQ>(acc, SA.rem, wsplit);
+                const float rinv1 = RS ? rcp_(first ? sRn1[r] : 1.0f) : 0.0f;
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) {
                     const int c = 2 * q + h;
-                    const float ul = (EXACT || c < H) ? sU1[r * sH + c] : 0.0f;
+                    // (RS: the row's own U1 - negative columns included, the normalisation's Jacobian needs them - exactly as layer 1 formed it)
+                    const float ul = RS ? fmaf(sraw, sh.wt[c], sh.bias[0][c]) * rinv1 : ((EXACT || c < H) ? sU1[r * sH + c] : 0.0f);
                     const float u = (first && c < H) ? ul : 0.0f;
                     float dx = acc[q];
                     const float de = sh.dEs[c];
@@ -1336,7 +1385,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
 #pragma unroll
                     for (int q = 0; q < HQ; ++q) sd2[q & 1] = fmaf(acc[q], uu[q], sd2[q & 1]);
                     const float sdot = xor32_sum(sd2[0] + sd2[1]);
-                    const float rinv = rcp_(first ? sRn1[r] : 1.0f);
+                    const float rinv = RS ? rinv1 : rcp_(first ? sRn1[r] : 1.0f);
                     float cp[2] = {0.0f, 0.0f};
 #pragma unroll
                     for (int q = 0; q < HQ; ++q) {
@@ -1366,10 +1415,10 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                                 float a0 = cr, a1 = 0.0f, b0 = cr, b1 = 0.0f;
 #pragma unroll
                                 for (int c = 0; c < 2 * HQ; c += 2) {
-                                    a0 = fmaf(d2[c], relu_(u0[c]), a0);
-                                    a1 = fmaf(d2[c + 1], relu_(u0[c + 1]), a1);
-                                    b0 = fmaf(d2[c], relu_(u1[c]), b0);
-                                    b1 = fmaf(d2[c + 1], relu_(u1[c + 1]), b1);
+                                    a0 = fmaf(d2[c], RS ? u0[c] : relu_(u0[c]), a0);
+                                    a1 = fmaf(d2[c + 1], RS ? u0[c + 1] : relu_(u0[c + 1]), a1);
+                                    b0 = fmaf(d2[c], RS ? u1[c] : relu_(u1[c]), b0);
+                                    b1 = fmaf(d2[c + 1], RS ? u1[c + 1] : relu_(u1[c + 1]), b1);
                                 }
                                 sGe[e] = a0 + a1;
                                 if (two) sGe[e + 2] = b0 + b1;
