@@ -40,7 +40,10 @@ __host__ __device__ constexpr int sp_qmax(int nt) { return nt == 512 ? 4 : 2; } 
 __host__ __device__ constexpr int sp_ld_max(int nt) { return nt == 512 ? 512 : 32 * (nt / 64); }
 constexpr int SP_LD_MAX = 32 * (SP_THREADS / 64);
 __host__ __device__ constexpr int sp_pool_floats(int nt) { return nt >= 512 ? 39168 : nt >= 256 ? 18432 : 5120; }
-constexpr int SP_GATHER_UNROLL = 2;          // entries in flight per lane in the sparse gathers
+#ifndef GNNX_GATHER_UNROLL
+#define GNNX_GATHER_UNROLL 2
+#endif
+constexpr int SP_GATHER_UNROLL = GNNX_GATHER_UNROLL;   // entries in flight per lane in the sparse gathers
 // measurement knobs of round 4 (tools/build_variants.sh builds one library per setting; the defaults are what ships)
 #ifndef GNNX_COMBINE_FMAC
 #define GNNX_COMBINE_FMAC 1
@@ -56,6 +59,9 @@ constexpr int SP_GATHER_UNROLL = 2;          // entries in flight per lane in th
 #endif
 #ifndef GNNX_RELU_STORE
 #define GNNX_RELU_STORE 1
+#endif
+#ifndef GNNX_FAST_HEAD
+#define GNNX_FAST_HEAD 1
 #endif
 constexpr int SP_CHUNK = 16;                 // entries per row slot: longer rows are split over adjacent lanes of one wave
 // row slots of a class: NT / 2 (two lanes = column halves per slot)
@@ -1157,10 +1163,14 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                     for (int l = 0; l < 3; ++l) wp[l][cc] = sWp[cr * 96 + l * 32 + c];
                     bpv[cc] = sh.sbp[cr];
                 }
+                // (FH: the hardware forms of sqrt / 1/x / exp the rest of the kernel uses - rcp_, sqrt_, exp_, gnnx_kernels.hpp - instead of the
+                // IEEE sequences: one square root, six divisions and four exponentials sit on this single-wave chain in every iteration)
+                constexpr bool FH = GNNX_FAST_HEAD != 0;
                 const float y = (c < O) ? y0 + y1 + b3 : 0.0f;
                 const float ss = sum_lanes_0_31(y * y);
-                const float rnorm = fmaxf(sqrtf(ss), 1e-12f);
-                const float u3 = y / rnorm;  // U3[t][c]
+                const float rnorm = fmaxf(FH ? sqrt_(ss) : sqrtf(ss), 1e-12f);
+                const float rinv3 = FH ? rcp_(rnorm) : 0.0f;
+                const float u3 = FH ? y * rinv3 : y / rnorm;  // U3[t][c]
                 // logits: three products per lane and class, one 32-lane sum per class
                 float zl[CH];
                 float mx = -3.0e38f;
@@ -1173,14 +1183,15 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 float sum = 0.0f;
 #pragma unroll
                 for (int cc = 0; cc < CH; ++cc) {
-                    zl[cc] = (cc < C) ? expf(zl[cc] - mx) : 0.0f;
+                    zl[cc] = (cc < C) ? (FH ? exp_(zl[cc] - mx) : expf(zl[cc] - mx)) : 0.0f;
                     sum += zl[cc];
                 }
+                const float rsum = FH ? rcp_(sum) : 0.0f;
                 // g = p - onehot(y_gt) (explain.py:713-714, 750-753); dE = Wp^T g, the lane's entry of each of the three slices
                 float dE1 = 0.0f, dE2 = 0.0f, dE3 = 0.0f;
 #pragma unroll
                 for (int cc = 0; cc < CH; ++cc) {
-                    const float g = (cc < C) ? zl[cc] / sum - ((cc == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
+                    const float g = (cc < C) ? (FH ? zl[cc] * rsum : zl[cc] / sum) - ((cc == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
                     if constexpr (LOG)
                         if (Lrow && lane == 0 && cc == tm.y_gt) Lrow[0] = -logf(zl[cc] / sum);   // explain.py:750-753
                     dE1 = fmaf(wp[0][cc], g, dE1);
@@ -1192,7 +1203,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 for (int k = 0; k < 2 * HQ; ++k) w3[k] = sW3[kc * 33 + ((EXACT || k < O) ? k : 0)];
                 const float du3 = (c < O) ? dE3 : 0.0f;
                 const float sd = sum_lanes_0_31(du3 * u3);
-                const float dy3 = (du3 - u3 * sd) / rnorm;  // dY3[t][c]
+                const float dy3 = FH ? (du3 - u3 * sd) * rinv3 : (du3 - u3 * sd) / rnorm;  // dY3[t][c]
                 const int di = __builtin_bit_cast(int, dy3);
                 float v0 = 0.0f, v1 = 0.0f;
 #pragma unroll
@@ -1623,8 +1634,10 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                     }
                     G += G2;
                 } else {
-                    G += (i == tr) ? sG3[j] : 0.0f;
-                    G += (j == tr) ? sG3[i] : 0.0f;
+                    // (unconditional loads - i, j < ld always - and selects: a lane-varying condition around a load is an exec-mask region)
+                    const float g3j = sG3[j], g3i = sG3[i];
+                    G += (i == tr) ? g3j : 0.0f;
+                    G += (j == tr) ? g3i : 0.0f;
                 }
                 const float dy = sYhat[i] - sYhat[j];
                 const float gc = (0.5f * G + p.c_lap * 0.5f * dy * dy * inv_n2) * wgt[q];

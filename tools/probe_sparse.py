@@ -19,14 +19,14 @@ for k, a in enumerate(anchors):
 k = len(anchors)
 # finer stamps inside layer 2 (wave 0 = the hub rows): after the gather, after the split-row combine, after MFMA + epilogue
 SUB = 20
-l2 = "            sparse_gather<true, HQ>(sAb, scol, sU1, sH, H, re0, re1, h, acc);\n            sparse_combine<HQ>(acc, SB.rem, wsplit);\n"
+l2 = "            sparse_gather<!RS, HQ>(sAb, scol, sU1, sH, H, re0, re1, h, acc);\n            sparse_combine<HQ>(acc, SB.rem, wsplit);\n"
 assert l2 in src
 src = src.replace(l2, l2.replace(";\n            sparse_combine", ";\n            PROBE(%d);\n            sparse_combine" % SUB) + "            PROBE(%d);\n" % (SUB + 1), 1)
 l2b = "            sparse_forward_rowlocal<HQ>(acc, sW2, sh.bias[1], H, H, li, h, first, sU2 + r * sH, sRn2 + r);\n"
 assert l2b in src
 src = src.replace(l2b, l2b + "            PROBE(%d);\n" % (SUB + 2), 1)
 # finer stamps inside the layer-1 backward (thread 0 = wave 0 = the hub rows)
-d1 = "                sparse_combine<HQ>(acc, SA.rem, wsplit);\n#pragma unroll\n                for (int q = 0; q < HQ; ++q) {\n                    const int c = 2 * q + h;\n                    const float ul = (EXACT || c < H) ? sU1[r * sH + c] : 0.0f;"
+d1 = "                sparse_combine<HQ>(acc, SA.rem, wsplit);\n                const float rinv1 = RS ? rcp_(first ? sRn1[r] : 1.0f) : 0.0f;\n"
 assert d1 in src
 src = src.replace(d1, "                PROBE(24);\n" + d1.replace("wsplit);\n", "wsplit);\n                PROBE(25);\n", 1), 1)
 d2 = "                sparse_store_cols(c16, sdZ1 + r * sD, D, first, h);\n                wave_sync();  // the other half-lane"
