@@ -61,7 +61,7 @@ constexpr int SP_GATHER_UNROLL = GNNX_GATHER_UNROLL;   // entries in flight per 
 #define GNNX_RELU_STORE 1
 #endif
 #ifndef GNNX_FAST_HEAD
-#define GNNX_FAST_HEAD 1
+#define GNNX_FAST_HEAD 3
 #endif
 constexpr int SP_CHUNK = 16;                 // entries per row slot: longer rows are split over adjacent lanes of one wave
 // row slots of a class: NT / 2 (two lanes = column halves per slot)
@@ -1165,7 +1165,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 }
                 // (FH: the hardware forms of sqrt / 1/x / exp the rest of the kernel uses - rcp_, sqrt_, exp_, gnnx_kernels.hpp - instead of the
                 // IEEE sequences: one square root, six divisions and four exponentials sit on this single-wave chain in every iteration)
-                constexpr bool FH = GNNX_FAST_HEAD != 0;
+                constexpr bool FH = (GNNX_FAST_HEAD & 1) != 0;    // the two normalisations (sqrt, two divisions)
+                constexpr bool FSM = (GNNX_FAST_HEAD & 2) != 0;   // the softmax (exponentials, the division by their sum)
                 const float y = (c < O) ? y0 + y1 + b3 : 0.0f;
                 const float ss = sum_lanes_0_31(y * y);
                 const float rnorm = fmaxf(FH ? sqrt_(ss) : sqrtf(ss), 1e-12f);
@@ -1183,15 +1184,15 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 float sum = 0.0f;
 #pragma unroll
                 for (int cc = 0; cc < CH; ++cc) {
-                    zl[cc] = (cc < C) ? (FH ? exp_(zl[cc] - mx) : expf(zl[cc] - mx)) : 0.0f;
+                    zl[cc] = (cc < C) ? (FSM ? exp_(zl[cc] - mx) : expf(zl[cc] - mx)) : 0.0f;
                     sum += zl[cc];
                 }
-                const float rsum = FH ? rcp_(sum) : 0.0f;
+                const float rsum = FSM ? rcp_(sum) : 0.0f;
                 // g = p - onehot(y_gt) (explain.py:713-714, 750-753); dE = Wp^T g, the lane's entry of each of the three slices
                 float dE1 = 0.0f, dE2 = 0.0f, dE3 = 0.0f;
 #pragma unroll
                 for (int cc = 0; cc < CH; ++cc) {
-                    const float g = (cc < C) ? (FH ? zl[cc] * rsum : zl[cc] / sum) - ((cc == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
+                    const float g = (cc < C) ? (FSM ? zl[cc] * rsum : zl[cc] / sum) - ((cc == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
                     if constexpr (LOG)
                         if (Lrow && lane == 0 && cc == tm.y_gt) Lrow[0] = -logf(zl[cc] / sum);   // explain.py:750-753
                     dE1 = fmaf(wp[0][cc], g, dE1);
