@@ -60,8 +60,17 @@ constexpr int SP_GATHER_UNROLL = GNNX_GATHER_UNROLL;   // entries in flight per 
 #ifndef GNNX_RELU_STORE
 #define GNNX_RELU_STORE 1
 #endif
+#ifndef GNNX_MERGE_PUBLISH
+#define GNNX_MERGE_PUBLISH 1
+#endif
+#ifndef GNNX_DFW_ROWS
+#define GNNX_DFW_ROWS 1
+#endif
+#ifndef GNNX_DFP_READLANE
+#define GNNX_DFP_READLANE 1
+#endif
 #ifndef GNNX_FAST_HEAD
-#define GNNX_FAST_HEAD 3
+#define GNNX_FAST_HEAD 2   // bit 0: the head's two normalisations, bit 1: its softmax, in the hardware forms (measured: see the head)
 #endif
 constexpr int SP_CHUNK = 16;                 // entries per row slot: longer rows are split over adjacent lanes of one wave
 // row slots of a class: NT / 2 (two lanes = column halves per slot)
@@ -445,6 +454,9 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     // widths are compile-time constants there (every column predicate, row stride and trip count folds); other shapes take <16, 16>.
     constexpr bool EXACT = (DQ != 16);
     constexpr bool RS = (XC == 2) && (GNNX_RELU_STORE != 0);   // algebraic form: sU1 holds relu(U1) (see layer 1)
+    // algebraic form: the next masked adjacency is published by the edge phase itself and the feature mask / wt are refreshed by wave 0 in
+    // front of it - one workgroup barrier per iteration fewer and no serial section between two barriers (see the edge phase)
+    constexpr bool MP = (XC == 2) && (GNNX_MERGE_PUBLISH != 0);
     const int D = EXACT ? 2 * DQ : p.D, H = EXACT ? 2 * HQ : p.H, O = EXACT ? 2 * HQ : p.O, C = p.C;
     const float* Ag = p.A + tm.offQ;
     float* Mg = p.M + tm.offQ;
@@ -883,6 +895,17 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             sh.wt[li] = a;
         }
     };
+    float step_size = 0.0f, bc2s = 0.0f;   // this iteration's optimiser scalars (set at the top of the loop)
+    auto feature_mask_step = [&]() {   // threads tid < D: Adam on the feature mask from dfp, then phi for the next iteration
+        const float ph = sh.phi[tid];
+        const float gf = (sh.dfp[tid] + p.c_feat_size / (float)D) * ph * (1.0f - ph);
+        float fn = sh.fcur[tid], m = sh.mf[tid], v = sh.vf[tid];
+        adam_update(fn, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
+        sh.fcur[tid] = fn;
+        sh.mf[tid] = m;
+        sh.vf[tid] = v;
+        sh.phi[tid] = sigmoidf_(fn);  // for the next iteration's layer 1 / edge phase (this iteration's readers are done)
+    };
     if constexpr (XC == 2) update_wt();   // (sX, the model block and phi are in place since the barrier above; publish_abar's barrier publishes wt)
     publish_abar();
     if constexpr (XC) {   // the plan promised constant feature rows for THIS X (gnnx_plan_analyze_features): anything else must fail loudly
@@ -901,7 +924,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     };
     float* Lrow = nullptr;   // LOG form: this target's row of the loss array for the current iteration
     for (int iter = 0; iter < p.num_iters; ++iter) {
-        const float step_size = adam_tab[2 * iter], bc2s = adam_tab[2 * iter + 1];
+        step_size = adam_tab[2 * iter];
+        bc2s = adam_tab[2 * iter + 1];
         if constexpr (LOG) Lrow = p.loss ? p.loss + ((size_t)t * p.num_iters + iter) * NLOSS : nullptr;
 
         // ======== layer 1: Zraw = Abar . X (kept in registers for the feature-mask gradient), U1 ========
@@ -1163,8 +1187,11 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                     for (int l = 0; l < 3; ++l) wp[l][cc] = sWp[cr * 96 + l * 32 + c];
                     bpv[cc] = sh.sbp[cr];
                 }
-                // (FH: the hardware forms of sqrt / 1/x / exp the rest of the kernel uses - rcp_, sqrt_, exp_, gnnx_kernels.hpp - instead of the
-                // IEEE sequences: one square root, six divisions and four exponentials sit on this single-wave chain in every iteration)
+                // Hardware forms (rcp_, sqrt_, exp_: gnnx_kernels.hpp) instead of the IEEE sequences on this single-wave chain - measured per part
+                // (session q of round 4, syn1 launch / syn5 windows of the round-3 test beyond 1e-5 / windows with a differing decision):
+                // IEEE head 3.015 ms / 12 / 5; softmax only (FSM: four exponentials, four divisions by their sum) 2.928 ms / 13 / 5; normalisations
+                // only (FH: one square root, two divisions) 2.987 ms / 18 / 7; both 2.885 ms / 18 (worst 7.7e-3) / 5.  The softmax takes the
+                // hardware forms (three quarters of the gain, the parity figures of the IEEE head); the normalisations keep the IEEE ones.
                 constexpr bool FH = (GNNX_FAST_HEAD & 1) != 0;    // the two normalisations (sqrt, two divisions)
                 constexpr bool FSM = (GNNX_FAST_HEAD & 2) != 0;   // the softmax (exponentials, the division by their sum)
                 const float y = (c < O) ? y0 + y1 + b3 : 0.0f;
@@ -1531,6 +1558,10 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             // colsum(dZ1 * Zraw): over the 16 lanes of a DPP row (row shifts), the two rows of a half (one shuffle), then
             // over the waves in fixed order   (algebraic form: sum over the rows of s_r dY1[r], H columns instead of D)
             if constexpr (XC == 2) {
+                // (DFWR: the two 16-lane rows of a half store their sums side by side and the reader adds them - the same sum, r0 + r1, without
+                // ten cross-row shuffles through the LDS crossbar on every wave's way to the barrier; classes of up to 8 waves: dfw has 16 rows)
+                constexpr bool DFWR = (GNNX_DFW_ROWS != 0) && NW <= 8;
+                float* dfw2 = &sh.dfw[0][0];
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) {
                     float v = dvq[q];
@@ -1538,8 +1569,12 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                     v += row_shl<4>(v);
                     v += row_shl<2>(v);
                     v += row_shl<1>(v);
-                    v = xor16_sum(v);
-                    if (li == 0) sh.dfw[wave][2 * q + h] = v;
+                    if constexpr (DFWR) {
+                        if ((li & 15) == 0) dfw2[(2 * wave + (li >> 4)) * 32 + 2 * q + h] = v;
+                    } else {
+                        v = xor16_sum(v);
+                        if (li == 0) sh.dfw[wave][2 * q + h] = v;
+                    }
                 }
             } else
 #pragma unroll
@@ -1556,9 +1591,31 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         SYNC();
         if constexpr (XC == 2) {
             if (wave == 0) {   // dL/dphi[k] = x_k W1[k] . vsum, vsum = the waves' partial sums in wave order
+                constexpr bool DFWR = (GNNX_DFW_ROWS != 0) && NW <= 8;
+                const float* dfw2 = &sh.dfw[0][0];
+#if GNNX_DFP_READLANE
+                // lane c holds vsum[c]; the product reads it with v_readlane (an SGPR operand of the FMA) instead of a store -> wave sync ->
+                // load round trip, and lane k's row of W1 is fetched together with the partial sums; same FMA chain, same order
+                const int kr = (tid < D) ? tid : 0;
+                float w1r[2 * HQ];
+#pragma unroll
+                for (int c = 0; c < 2 * HQ; ++c) w1r[c] = sW1[kr * 33 + c];
+#endif
                 float v = 0.0f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) v += sh.dfw[w][li];
+                for (int w = 0; w < NW; ++w) v += DFWR ? dfw2[(2 * w) * 32 + li] + dfw2[(2 * w + 1) * 32 + li] : sh.dfw[w][li];
+#if GNNX_DFP_READLANE
+                const int vi = __builtin_bit_cast(int, (li < H) ? v : 0.0f);
+                float a = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 2 * HQ; ++c) a = fmaf(w1r[c], __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, c)), a);
+                if (tid < D) sh.dfp[tid] = sX[tid] * a;
+                if constexpr (MP) {   // (dfp[tid] is read back by the thread that wrote it; phi of all D columns before wt)
+                    if (tid < D) feature_mask_step();
+                    wave_sync();
+                    update_wt();
+                }
+#else
                 if (h == 0) sh.vsum[li] = (li < H) ? v : 0.0f;
                 wave_sync();
                 if (tid < D) {
@@ -1567,6 +1624,12 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                     for (int c = 0; c < 2 * HQ; ++c) a = fmaf(sW1[tid * 33 + c], sh.vsum[c], a);
                     sh.dfp[tid] = sX[tid] * a;
                 }
+                if constexpr (MP) {
+                    if (tid < D) feature_mask_step();
+                    wave_sync();
+                    update_wt();
+                }
+#endif
             }
         } else
         if (tid < D) {
@@ -1652,6 +1715,19 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                     const float g = (gc + p.c_size - p.c_ent * Mji[q] * inv_n2) * S * (1.0f - S);
                     adam_update<ADAM>(Mji[q], mji[q], vji[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
                 }
+                if constexpr (MP) {
+                    // publish in place (publish_abar's body for this edge): nothing reads sAb / sArt between the barrier behind the layer-1
+                    // backward and the next iteration's layer 1.  Not after the last iteration: the returned mask is the one of the LAST forward.
+                    if (iter + 1 < p.num_iters) {
+                        Sij[q] = sigmoidf_(Mij[q]);
+                        Sji[q] = sigmoidf_(Mji[q]);
+                        const float a = wgt[q] * (0.5f * (Sij[q] + Sji[q]));
+                        sAb[epk[q] & 0xffffu] = a;
+                        sAb[epk[q] >> 16] = a;
+                        if (i == tr) sArt[j] = a;
+                        if (j == tr) sArt[i] = a;
+                    }
+                }
             }
         };
         if (p.opt == 0) edge_phase(std::true_type{}); else edge_phase(std::false_type{});   // one branch around the loop, not one per update
@@ -1687,21 +1763,14 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 wave_sync();
             }
         }
-        if (tid < D) {  // feature mask
-            const float ph = sh.phi[tid];
-            const float gf = (sh.dfp[tid] + p.c_feat_size / (float)D) * ph * (1.0f - ph);
-            float fn = sh.fcur[tid], m = sh.mf[tid], v = sh.vf[tid];
-            adam_update(fn, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
-            sh.fcur[tid] = fn;
-            sh.mf[tid] = m;
-            sh.vf[tid] = v;
-            sh.phi[tid] = sigmoidf_(fn);  // for the next iteration's layer 1 / edge phase (this iteration's readers are done)
-        }
+        if constexpr (!MP) {
+        if (tid < D) feature_mask_step();
         if constexpr (XC == 2) {
             if (wave == 0) wave_sync();   // phi of all D columns (threads of wave 0) before wt is refreshed; publish_abar's barrier publishes wt
             update_wt();
         }
         if (iter + 1 < p.num_iters) publish_abar();  // the returned mask is the one of the LAST forward (explain.py:209-211)
+        }
     }
     SYNC();
     // ---------------- results: dense Abar block (zero off the edges), M on the edges, feature mask ----------------
