@@ -40,38 +40,11 @@ __host__ __device__ constexpr int sp_qmax(int nt) { return nt == 512 ? 4 : 2; } 
 __host__ __device__ constexpr int sp_ld_max(int nt) { return nt == 512 ? 512 : 32 * (nt / 64); }
 constexpr int SP_LD_MAX = 32 * (SP_THREADS / 64);
 __host__ __device__ constexpr int sp_pool_floats(int nt) { return nt >= 512 ? 39168 : nt >= 256 ? 18432 : 5120; }
-#ifndef GNNX_GATHER_UNROLL
-#define GNNX_GATHER_UNROLL 2
-#endif
-constexpr int SP_GATHER_UNROLL = GNNX_GATHER_UNROLL;   // entries in flight per lane in the sparse gathers
-// measurement knobs of round 4 (tools/build_variants.sh builds one library per setting; the defaults are what ships)
-#ifndef GNNX_COMBINE_FMAC
-#define GNNX_COMBINE_FMAC 1
-#endif
-#ifndef GNNX_WSPLIT_SGPR
-#define GNNX_WSPLIT_SGPR 1
-#endif
-#ifndef GNNX_ROWT_PREFETCH
-#define GNNX_ROWT_PREFETCH 0
-#endif
-#ifndef GNNX_BROW_CHUNK
-#define GNNX_BROW_CHUNK 1
-#endif
-#ifndef GNNX_RELU_STORE
-#define GNNX_RELU_STORE 1
-#endif
-#ifndef GNNX_MERGE_PUBLISH
-#define GNNX_MERGE_PUBLISH 1
-#endif
-#ifndef GNNX_DFW_ROWS
-#define GNNX_DFW_ROWS 1
-#endif
-#ifndef GNNX_DFP_READLANE
-#define GNNX_DFP_READLANE 1
-#endif
-#ifndef GNNX_FAST_HEAD
-#define GNNX_FAST_HEAD 2   // bit 0: the head's two normalisations, bit 1: its softmax, in the hardware forms (measured: see the head)
-#endif
+constexpr int SP_GATHER_UNROLL = 2;          // entries in flight per lane in the sparse gathers (4: measured, no gain)
+// Forms measured one by one in round 4 (tools/gpu_r4n.sh ... gpu_r4r.sh; syn1 launch 3.18 -> 2.84 ms); the losers are gone, these stay switches:
+constexpr bool SP_RELU_STORE = true;         // algebraic form: sU1 holds relu(U1), the row's owner recomputes its own U1 in the backward
+constexpr bool SP_MERGE_PUBLISH = true;      // algebraic form, classes of up to 256 threads: the edge phase publishes the next masked adjacency itself
+constexpr int SP_FAST_HEAD = 2;              // bit 0: the head's two normalisations, bit 1: its softmax, in the hardware forms (measured: see the head)
 constexpr int SP_CHUNK = 16;                 // entries per row slot: longer rows are split over adjacent lanes of one wave
 // row slots of a class: NT / 2 (two lanes = column halves per slot)
 
@@ -398,17 +371,9 @@ __device__ __forceinline__ void sparse_combine_step(float (&acc)[NQ], int rem, i
         if (S < wsplit) {  // uniform per wave
             // one v_fmac_f32 with a DPP source per register and step (acc += shifted * m, m = 1 while the source lane still belongs to this
             // row, else 0: the same sum as a select + add, exactly) instead of v_mov_dpp + v_cndmask + v_add through one temporary
-#if GNNX_COMBINE_FMAC
             const float m = (S < rem) ? 1.0f : 0.0f;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) acc[q] = fmaf(row_shl<S>(acc[q]), m, acc[q]);
-#else
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const float v = row_shl<S>(acc[q]);
-                acc[q] += (S < rem) ? v : 0.0f;
-            }
-#endif
             sparse_combine_step<NQ, 2 * S>(acc, rem, wsplit);
         }
     }
@@ -453,10 +418,11 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     // The <5, 10> / <7, 10> instantiations serve exactly the reference's encoders (node: D = 10, graph: D = 14; H = O = 20): the
     // widths are compile-time constants there (every column predicate, row stride and trip count folds); other shapes take <16, 16>.
     constexpr bool EXACT = (DQ != 16);
-    constexpr bool RS = (XC == 2) && (GNNX_RELU_STORE != 0);   // algebraic form: sU1 holds relu(U1) (see layer 1)
+    constexpr bool RS = (XC == 2) && SP_RELU_STORE;   // algebraic form: sU1 holds relu(U1) (see layer 1)
     // algebraic form: the next masked adjacency is published by the edge phase itself and the feature mask / wt are refreshed by wave 0 in
     // front of it - one workgroup barrier per iteration fewer and no serial section between two barriers (see the edge phase)
-    constexpr bool MP = (XC == 2) && (GNNX_MERGE_PUBLISH != 0);
+    // (measured: syn5 - 64- / 256-thread classes - 2.82 -> 2.77 ms; the 512-thread class, which already spills, 2.84 -> 2.87: not there)
+    constexpr bool MP = (XC == 2) && SP_MERGE_PUBLISH && NT <= 256;
     const int D = EXACT ? 2 * DQ : p.D, H = EXACT ? 2 * HQ : p.H, O = EXACT ? 2 * HQ : p.O, C = p.C;
     const float* Ag = p.A + tm.offQ;
     float* Mg = p.M + tm.offQ;
@@ -638,7 +604,6 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         // the narrowest slots that still fit the class (4, 8 entries: two to four times as many lanes share those products and the
         // gathers of those rows); a row too long for 16 slots of that width doubles it.
         int chb = ch;
-#if GNNX_BROW_CHUNK
         if (!GRAPH && set == 0) {
             for (int cand = 4; cand < ch; cand <<= 1) {
                 int tot = 0, singles = 0;
@@ -660,7 +625,6 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 }
             }
         }
-#endif
         if (set == 0) sh.chunk_b = chb;
         auto row_width = [&](int rr, int d) {
             int w = (!GRAPH && set == 0 && level[rr] <= 1) ? chb : ch;
@@ -750,11 +714,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             const int other = __shfl_xor(wsplit, o);
             wsplit = other > wsplit ? other : wsplit;
         }
-#if GNNX_WSPLIT_SGPR
         z.wsplit = __builtin_amdgcn_readfirstlane(wsplit);   // (the same in every lane: say so, and the tests on it are scalar branches)
-#else
-        z.wsplit = wsplit;
-#endif
         z.wave_active = wave * TILE < sh.set_slots[k];
         rs[k] = z;
     }
@@ -1143,30 +1103,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 const float e2 = (c < H) ? relu_(sU2[tr * sH + kc]) : 0.0f;
                 // row t of Abar . relu(U2): the two half-lanes take alternate entries
                 float z = 0.0f;
-#if GNNX_ROWT_PREFETCH
-                {   // the first four entries of a half-lane as ONE group: (Abar, column) pairs in one LDS round trip, the four rows in the
-                    // next (the loop made it two dependent round trips per entry); same products in the same order
-                    float a4[4];
-                    int c4[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int e = rt0 + h + 2 * k;
-                        const bool in = e < rt1;
-                        const float av = sAb[in ? e : rt0];
-                        a4[k] = in ? av : 0.0f;
-                        c4[k] = scol[in ? e : rt0];
-                    }
-                    float u4[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) u4[k] = sU2[c4[k] * sH + kc];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (rt0 + h + 2 * k < rt1) z = fmaf(a4[k], relu_(u4[k]), z);   // (uniform per half-lane: a short row adds nothing, not even a zero)
-                    for (int e = rt0 + h + 8; e < rt1; e += 2) z = fmaf(sAb[e], relu_(sU2[(int)scol[e] * sH + kc]), z);
-                }
-#else
                 for (int e = rt0 + h; e < rt1; e += 2) z = fmaf(sAb[e], relu_(sU2[(int)scol[e] * sH + kc]), z);
-#endif
                 z = (c < H) ? z : 0.0f;
                 z = xor32_sum(z);
                 const int zi = __builtin_bit_cast(int, z);
@@ -1192,8 +1129,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 // IEEE head 3.015 ms / 12 / 5; softmax only (FSM: four exponentials, four divisions by their sum) 2.928 ms / 13 / 5; normalisations
                 // only (FH: one square root, two divisions) 2.987 ms / 18 / 7; both 2.885 ms / 18 (worst 7.7e-3) / 5.  The softmax takes the
                 // hardware forms (three quarters of the gain, the parity figures of the IEEE head); the normalisations keep the IEEE ones.
-                constexpr bool FH = (GNNX_FAST_HEAD & 1) != 0;    // the two normalisations (sqrt, two divisions)
-                constexpr bool FSM = (GNNX_FAST_HEAD & 2) != 0;   // the softmax (exponentials, the division by their sum)
+                constexpr bool FH = (SP_FAST_HEAD & 1) != 0;    // the two normalisations (sqrt, two divisions)
+                constexpr bool FSM = (SP_FAST_HEAD & 2) != 0;   // the softmax (exponentials, the division by their sum)
                 const float y = (c < O) ? y0 + y1 + b3 : 0.0f;
                 const float ss = sum_lanes_0_31(y * y);
                 const float rnorm = fmaxf(FH ? sqrt_(ss) : sqrtf(ss), 1e-12f);
@@ -1560,7 +1497,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             if constexpr (XC == 2) {
                 // (DFWR: the two 16-lane rows of a half store their sums side by side and the reader adds them - the same sum, r0 + r1, without
                 // ten cross-row shuffles through the LDS crossbar on every wave's way to the barrier; classes of up to 8 waves: dfw has 16 rows)
-                constexpr bool DFWR = (GNNX_DFW_ROWS != 0) && NW <= 8;
+                constexpr bool DFWR = NW <= 8;
                 float* dfw2 = &sh.dfw[0][0];
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) {
@@ -1591,20 +1528,17 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         SYNC();
         if constexpr (XC == 2) {
             if (wave == 0) {   // dL/dphi[k] = x_k W1[k] . vsum, vsum = the waves' partial sums in wave order
-                constexpr bool DFWR = (GNNX_DFW_ROWS != 0) && NW <= 8;
+                constexpr bool DFWR = NW <= 8;
                 const float* dfw2 = &sh.dfw[0][0];
-#if GNNX_DFP_READLANE
                 // lane c holds vsum[c]; the product reads it with v_readlane (an SGPR operand of the FMA) instead of a store -> wave sync ->
                 // load round trip, and lane k's row of W1 is fetched together with the partial sums; same FMA chain, same order
                 const int kr = (tid < D) ? tid : 0;
                 float w1r[2 * HQ];
 #pragma unroll
                 for (int c = 0; c < 2 * HQ; ++c) w1r[c] = sW1[kr * 33 + c];
-#endif
                 float v = 0.0f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) v += DFWR ? dfw2[(2 * w) * 32 + li] + dfw2[(2 * w + 1) * 32 + li] : sh.dfw[w][li];
-#if GNNX_DFP_READLANE
                 const int vi = __builtin_bit_cast(int, (li < H) ? v : 0.0f);
                 float a = 0.0f;
 #pragma unroll
@@ -1615,21 +1549,6 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                     wave_sync();
                     update_wt();
                 }
-#else
-                if (h == 0) sh.vsum[li] = (li < H) ? v : 0.0f;
-                wave_sync();
-                if (tid < D) {
-                    float a = 0.0f;
-#pragma unroll
-                    for (int c = 0; c < 2 * HQ; ++c) a = fmaf(sW1[tid * 33 + c], sh.vsum[c], a);
-                    sh.dfp[tid] = sX[tid] * a;
-                }
-                if constexpr (MP) {
-                    if (tid < D) feature_mask_step();
-                    wave_sync();
-                    update_wt();
-                }
-#endif
             }
         } else
         if (tid < D) {

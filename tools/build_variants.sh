@@ -1,6 +1,8 @@
 #!/bin/bash
 # A/B builds of the kernel library (same sources, one -D setting each) under tools/_build/ab/ for the measurement sessions:
 #   tools/build_variants.sh name1 "-DGNNX_X=0" name2 "-DGNNX_Y=0 -DGNNX_Z=1" ...      (builds run in parallel)
+# (round 4 measured the resident kernel's forms this way - sessions n ... r2; the macros those sessions switched are gone from the sources:
+#  the winners are plain code, three stay constexpr switches at the top of gnnx_sparse.hpp; GNNX_IEEE_MATH still is a -D)
 # A session selects one with GNNX_LIBRARY_PATH=tools/_build/ab/libgnnx_hip_<name>.so (engine.library_path).
 cd "$(dirname "$0")/.."
 mkdir -p tools/_build/ab

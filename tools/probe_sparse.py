@@ -42,6 +42,9 @@ d4 = "        SYNC();\n        if constexpr (XC == 2) {\n            if (wave ==
 assert d4 in src
 src = src.replace(d4, "        PROBE(28);\n" + d4, 1)
 src = src.replace("        if (iter + 1 < p.num_iters) publish_abar();  // the returned mask", "        PROBE(%d);\n        if (iter + 1 < p.num_iters) publish_abar();\n        PROBE(%d);  // the returned mask" % (k, k + 1), 1)
+tail = "        }\n    }\n    SYNC();\n    // ---------------- results"      # classes whose edge phase publishes by itself (MP): the row reads ~0
+assert tail in src
+src = src.replace(tail, "        }\n        if constexpr (MP) { PROBE(%d); PROBE(%d); }\n    }\n    SYNC();\n    // ---------------- results" % (k, k + 1), 1)
 names += ["publish Abar"]
 capi += '\nextern "C" int gnnx_probe_read(unsigned long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gnnx::g_probe), sizeof(unsigned long long) * n); }\n'
 # `--build`: cross-compile here (no GPU needed) into tools/_build/ - the .so travels with the gpurun snapshot, so the GPU
