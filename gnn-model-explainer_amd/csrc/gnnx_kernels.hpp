@@ -142,6 +142,11 @@ __device__ __forceinline__ float sigmoidf_(float x) { return rcp_(1.0f + exp_(-x
 // v + v[lane ^ 32] / v + v[lane ^ 16].  (Measured in round 3: the gfx950 lane-swap instructions v_permlane32_swap_b32 /
 // v_permlane16_swap_b32 in place of the ds_bpermute_b32 these shuffles compile to changed the iteration of the sparse resident
 // kernel by 0.1 of 11.3 us - the LDS crossbar round trip is not what the chain waits for - so the portable form stays.)
+// From here on the value of a register is unknown to the optimiser (no instruction is emitted): expressions derived from it are formed where
+// they are used instead of being kept in registers across a whole loop.  (tests/emu/include/hip/hip_runtime.h defines it for the host compiler.)
+#ifndef GNNX_OPAQUE
+#define GNNX_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
 __device__ __forceinline__ float xor32_sum(float v) { return v + __shfl_xor(v, 32); }
 __device__ __forceinline__ float xor16_sum(float v) { return v + __shfl_xor(v, 16); }
 

@@ -886,6 +886,18 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     for (int iter = 0; iter < p.num_iters; ++iter) {
         step_size = adam_tab[2 * iter];
         bc2s = adam_tab[2 * iter + 1];
+        if constexpr (NT == 512) {
+            // The 512-thread class sits at its 256 registers and spills.  What the compiler keeps across the whole iteration, per owned edge, is
+            // not only the edge's state but the LDS ADDRESSES it derives from the two packed index words (ten per edge: both entries of Abar
+            // and of the row-side products, yhat, g3 and Abar[t][.] of both end points - loop invariant, hence hoisted out of the iteration
+            // loop: 40 registers for four edges).  Declaring the packed words modified here makes those addresses per-iteration values again:
+            // a handful of shifts and adds in the edge phase instead of scratch stores and reloads along wave 0's chain.  (No instruction is emitted.)
+#pragma unroll
+            for (int q = 0; q < SP_QMAX; ++q) {
+                GNNX_OPAQUE(epk[q]);
+                GNNX_OPAQUE(npk[q]);
+            }
+        }
         if constexpr (LOG) Lrow = p.loss ? p.loss + ((size_t)t * p.num_iters + iter) * NLOSS : nullptr;
 
         // ======== layer 1: Zraw = Abar . X (kept in registers for the feature-mask gradient), U1 ========

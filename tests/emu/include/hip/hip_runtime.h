@@ -65,6 +65,7 @@ inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline void __threadfence_block() {}
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define GNNX_OPAQUE(x) asm volatile("" : "+r"(x))   // (the product's default names a VGPR)
 #define __builtin_amdgcn_wave_barrier() emu::wave_sync()
 #define __builtin_amdgcn_readfirstlane(v) emu::shfl_i((v), 0)
 #define __builtin_amdgcn_readlane(v, k) emu::shfl_i((v), (k))
