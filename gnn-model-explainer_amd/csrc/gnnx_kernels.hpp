@@ -163,14 +163,17 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // ADAM_ONLY: the caller has already branched on the optimiser around a whole loop of updates - inside an unrolled loop the uniform
 // test below would put every update in its own basic block, and the independent sqrt -> rcp chains of a thread's 8 mask entries
 // would run one after the other instead of interleaved (measured: the edge phase of the sparse resident kernel 0.76 -> 1.28 us).
-template <bool ADAM_ONLY = false>
+// HAVE_R: the caller passes rbc2 = 1.0f / bc2s, formed ONCE per iteration (and made opaque, GNNX_OPAQUE): left to itself the compiler sinks the
+// IEEE division - ten instructions - into every predicated per-edge block that uses it (the ISA of the sparse resident kernel's edge phase
+// had one per owned edge and iteration); the same value, so the same results.
+template <bool ADAM_ONLY = false, bool HAVE_R = false>
 __device__ __forceinline__ void adam_update(float& theta, float& m, float& v, float g, float omb1, float beta2, float omb2,
-                                            float eps, float step_size, float bc2s, int opt = 0) {
+                                            float eps, float step_size, float bc2s, int opt = 0, float rbc2 = 0.0f) {
     if (ADAM_ONLY || opt == 0) {   // Adam (uniform branch: the optimiser is a property of the whole job)
         m = m + (g - m) * omb1;
         v = v * beta2 + omb2 * g * g;
 #ifndef GNNX_IEEE_MATH
-        theta = theta - step_size * (m * rcp_(sqrt_(v) * (1.0f / bc2s) + eps));   // (1 / bc2s: uniform, hoisted out of the per-entry code)
+        theta = theta - step_size * (m * rcp_(sqrt_(v) * (HAVE_R ? rbc2 : 1.0f / bc2s) + eps));   // (1 / bc2s: uniform)
 #else
         theta = theta + (-step_size * m) / (sqrtf(v) / bc2s + eps);   // addcdiv_: self + value * t1 / t2, denom = sqrt(v) / bc2s + eps
 #endif

@@ -43,7 +43,7 @@ __host__ __device__ constexpr int sp_pool_floats(int nt) { return nt >= 512 ? 39
 constexpr int SP_GATHER_UNROLL = 2;          // entries in flight per lane in the sparse gathers (4: measured, no gain)
 // Forms measured one by one in round 4 (tools/gpu_r4n.sh ... gpu_r4r.sh; syn1 launch 3.18 -> 2.84 ms); the losers are gone, these stay switches:
 constexpr bool SP_RELU_STORE = true;         // algebraic form: sU1 holds relu(U1), the row's owner recomputes its own U1 in the backward
-constexpr bool SP_MERGE_PUBLISH = true;      // algebraic form, classes of up to 256 threads: the edge phase publishes the next masked adjacency itself
+constexpr bool SP_MERGE_PUBLISH = true;      // algebraic form, classes of up to 512 threads: the edge phase publishes the next masked adjacency itself
 constexpr int SP_FAST_HEAD = 2;              // bit 0: the head's two normalisations, bit 1: its softmax, in the hardware forms (measured: see the head)
 constexpr int SP_CHUNK = 16;                 // entries per row slot: longer rows are split over adjacent lanes of one wave
 // row slots of a class: NT / 2 (two lanes = column halves per slot)
@@ -421,8 +421,9 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     constexpr bool RS = (XC == 2) && SP_RELU_STORE;   // algebraic form: sU1 holds relu(U1) (see layer 1)
     // algebraic form: the next masked adjacency is published by the edge phase itself and the feature mask / wt are refreshed by wave 0 in
     // front of it - one workgroup barrier per iteration fewer and no serial section between two barriers (see the edge phase)
-    // (measured: syn5 - 64- / 256-thread classes - 2.82 -> 2.77 ms; the 512-thread class, which already spills, 2.84 -> 2.87: not there)
-    constexpr bool MP = (XC == 2) && SP_MERGE_PUBLISH && NT <= 256;
+    // (measured: syn5 - 64- / 256-thread classes - 2.82 -> 2.77 ms; the 512-thread class 2.84 -> 2.87 ms while it spilled, 2.81 -> 2.77 ms since
+    // it does not - see GNNX_OPAQUE at the top of the iteration)
+    constexpr bool MP = (XC == 2) && SP_MERGE_PUBLISH && NT <= 512;
     const int D = EXACT ? 2 * DQ : p.D, H = EXACT ? 2 * HQ : p.H, O = EXACT ? 2 * HQ : p.O, C = p.C;
     const float* Ag = p.A + tm.offQ;
     float* Mg = p.M + tm.offQ;
@@ -855,12 +856,12 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             sh.wt[li] = a;
         }
     };
-    float step_size = 0.0f, bc2s = 0.0f;   // this iteration's optimiser scalars (set at the top of the loop)
+    float step_size = 0.0f, bc2s = 0.0f, rbc2 = 0.0f;   // this iteration's optimiser scalars (set at the top of the loop)
     auto feature_mask_step = [&]() {   // threads tid < D: Adam on the feature mask from dfp, then phi for the next iteration
         const float ph = sh.phi[tid];
         const float gf = (sh.dfp[tid] + p.c_feat_size / (float)D) * ph * (1.0f - ph);
         float fn = sh.fcur[tid], m = sh.mf[tid], v = sh.vf[tid];
-        adam_update(fn, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
+        adam_update<false, true>(fn, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt, rbc2);
         sh.fcur[tid] = fn;
         sh.mf[tid] = m;
         sh.vf[tid] = v;
@@ -886,6 +887,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     for (int iter = 0; iter < p.num_iters; ++iter) {
         step_size = adam_tab[2 * iter];
         bc2s = adam_tab[2 * iter + 1];
+        rbc2 = 1.0f / bc2s;      // once per iteration (adam_update<.., HAVE_R>)
+        GNNX_OPAQUE(rbc2);
         if constexpr (NT == 512) {
             // The 512-thread class sits at its 256 registers and spills.  What the compiler keeps across the whole iteration, per owned edge, is
             // not only the edge's state but the LDS ADDRESSES it derives from the two packed index words (ten per edge: both entries of Abar
@@ -1639,12 +1642,12 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 {
                     const float S = Sij[q];
                     const float g = (gc + p.c_size - p.c_ent * Mij[q] * inv_n2) * S * (1.0f - S);
-                    adam_update<ADAM>(Mij[q], mij[q], vij[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
+                    adam_update<ADAM, true>(Mij[q], mij[q], vij[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt, rbc2);
                 }
                 {
                     const float S = Sji[q];
                     const float g = (gc + p.c_size - p.c_ent * Mji[q] * inv_n2) * S * (1.0f - S);
-                    adam_update<ADAM>(Mji[q], mji[q], vji[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
+                    adam_update<ADAM, true>(Mji[q], mji[q], vji[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt, rbc2);
                 }
                 if constexpr (MP) {
                     // publish in place (publish_abar's body for this edge): nothing reads sAb / sArt between the barrier behind the layer-1

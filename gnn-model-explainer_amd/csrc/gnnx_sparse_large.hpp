@@ -617,6 +617,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         if (tid < 32) sh.phi[tid] = (tid < D) ? sigmoidf_(sh.fcur[tid]) : 0.0f;
         __syncthreads();
         const float step_size = adam_tab[2 * iter], bc2s = adam_tab[2 * iter + 1];
+        float rbc2 = 1.0f / bc2s;   // once per iteration (adam_update<.., HAVE_R>)
+        GNNX_OPAQUE(rbc2);
 
         // ======== layer 1 on the rows within two hops: Zraw = Abar . X (kept for the feature-mask gradient), U1 ========
         for (int round = 0; round < roundsA; ++round) {
@@ -935,12 +937,12 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                     {
                         const float S = sigmoidf_(Mij[u]);
                         const float g = (gc + p.c_size - p.c_ent * Mij[u] * inv_n2) * S * (1.0f - S);
-                        adam_update<ADAM>(Mij[u], mij[u], vij[u], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
+                        adam_update<ADAM, true>(Mij[u], mij[u], vij[u], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt, rbc2);
                     }
                     {
                         const float S = sigmoidf_(Mji[u]);
                         const float g = (gc + p.c_size - p.c_ent * Mji[u] * inv_n2) * S * (1.0f - S);
-                        adam_update<ADAM>(Mji[u], mji[u], vji[u], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
+                        adam_update<ADAM, true>(Mji[u], mji[u], vji[u], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt, rbc2);
                     }
                 }
             };
