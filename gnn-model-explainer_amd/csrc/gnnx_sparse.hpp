@@ -735,11 +735,17 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     unsigned epk[SP_QMAX], npk[SP_QMAX];   // (eij | eji << 16), (i | j << 16): rows and directed entries are < 65536 (sparse_fits) - two registers per edge instead of four
     int eflag[SP_QMAX];   // bit 0 / 1: row i / j lies within two hops of t (dZ1 can be non-zero there); bit 2 / 3: row i / j is t
                           // or a neighbour of t (dZ2 can be non-zero there); graph mode: all set
+    // Edge k of the target belongs to thread k mod NT in round k / NT - except in the LAST round, which is dealt from the top thread down:
+    // that round is usually partial, and wave 0, whose chain through the feature-mask update makes it the last to reach the edge phase,
+    // then owns one edge fewer than the waves that wait for it (n = 310, 1432 edges, 512 threads: two instead of three).  Which thread
+    // updates an edge does not enter its arithmetic.  (The logging form keeps the plain order: its per-thread sums are order dependent.)
+    const int qlast = eup > 0 ? (eup - 1) / NT : 0;
+    auto edge_k = [&](int q) { return (!LOG && q == qlast) ? (NT - 1 - tid) + NT * q : tid + NT * q; };
     {
         bool asym = (2 * eup != nnz);
 #pragma unroll
         for (int q = 0; q < SP_QMAX; ++q) {
-            const int k = tid + NT * q;
+            const int k = edge_k(q);
             Mij[q] = Mji[q] = mij[q] = mji[q] = vij[q] = vji[q] = wgt[q] = 0.0f;
             Sij[q] = Sji[q] = 0.5f;
             epk[q] = npk[q] = 0u;
@@ -834,7 +840,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     auto publish_abar = [&]() {
 #pragma unroll
         for (int q = 0; q < SP_QMAX; ++q)
-            if (tid + NT * q < eup) {
+            if (edge_k(q) < eup) {
                 Sij[q] = sigmoidf_(Mij[q]);   // kept for the next update: sigma'(M) = S (1 - S)
                 Sji[q] = sigmoidf_(Mji[q]);
                 const float a = wgt[q] * (0.5f * (Sij[q] + Sji[q]));
@@ -1578,7 +1584,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         constexpr bool ADAM = decltype(ADAMc)::value;
 #pragma unroll
         for (int q = 0; q < SP_QMAX; ++q)
-            if (tid + NT * q < eup) {
+            if (edge_k(q) < eup) {
                 const int i = (int)(npk[q] & 0xffffu), j = (int)(npk[q] >> 16);
                 if constexpr (LOG) {   // explain.py:755-770, 780-793 on the current iterate (before its update)
                     const float Sa = Sij[q], Sb = Sji[q];
@@ -1717,7 +1723,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     SYNC();
 #pragma unroll
     for (int q = 0; q < SP_QMAX; ++q)
-        if (tid + NT * q < eup) {
+        if (edge_k(q) < eup) {
             const int i = (int)(npk[q] & 0xffffu), j = (int)(npk[q] >> 16);
             const float a = sAb[epk[q] & 0xffffu];
             p.Abar[tm.offQ + (size_t)i * ld + j] = a;
