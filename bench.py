@@ -561,6 +561,8 @@ def main():
         e2e_stats["repetitions"] = {"count": len(reps), "reported": "median", "values": [n_targets * args.steps / r[0] for r in reps],
                                     "spread_pct": 100.0 * (max(r[0] for r in reps) - min(r[0] for r in reps)) / dt}
         e2e_stats["rng_threads"] = pipe.rng_threads
+        e2e_stats["prepare_workers"] = pipe.prepare_workers
+        e2e_stats["optimisations_in_flight"] = pipe.depth
         e2e_stats["rng_threads_big_batches"] = pipe.rng_threads_big
         e2e_stats["stream_candidates_rejected"] = len(pipe._rejected)          # (hardware-queue calibration of the pipeline's six streams)
         e2e_stats["streams_without_own_queue"] = getattr(pipe, "queue_fallbacks", 0)
@@ -731,7 +733,8 @@ def main():
         if e2e_stats is not None:
             out["value_definition"] = ("SURVEY.md section 8(d): targets / wall time of the whole batched job with only the graph resident - device k-hop, plan, "
                                        "device-side packing, routing, seeded host RNG (C++ threads), H2D + scatter, the 300 iterations, gather + D2H of "
-                                       "the masks - K batches through pipeline.BatchPipeline (two prepare workers, up to three optimisations sharing the chip, one fetch stream), fill and drain inside the timed region")
+                                       "the masks - K batches through pipeline.BatchPipeline (%d prepare workers, up to %d optimisations sharing the chip, one fetch stream), fill and drain inside the timed region"
+                                       % (e2e_stats.get("prepare_workers", 0), e2e_stats.get("optimisations_in_flight", 0)))
             out["end_to_end_stage_ms"] = e2e_stats
         if parity is not None:
             out["parity"] = parity
