@@ -296,9 +296,12 @@ int gnnx_denoise_edges(gnnx_handle h, const int64_t* eoff, const int32_t* rc, co
  * AUC = (counts[1] + counts[2] / 2) / (counts[0] counts[3]).  pos_scratch: DEVICE, E floats. */
 int gnnx_auc_counts(const float* vals, const uint8_t* real, int64_t num_edges, float* pos_scratch, unsigned long long* counts, void* stream);
 
-/* Pipelined jobs (pipeline.BatchPipeline): the calling THREAD's plan-building uploads (gnnx_plan_create, gnnx_plan_analyze, the Adam
- * table of gnnx_run) go to `stream` instead of the null stream, whose hardware queue may be busy with another batch's launch;
- * NULL restores the default.  gnnx_lane_stream(i), i = 0..2: the library's process-wide launch lanes (hipStream_t) - the
+/* Pipelined jobs (pipeline.BatchPipeline): the calling THREAD's plan-building uploads (gnnx_plan_create, gnnx_plan_analyze) go to
+ * `stream` instead of the null stream, whose hardware queue may be busy with another batch's launch; NULL restores the default.
+ * With a service stream the table blocks of a plan are copied from pinned staging and only ENQUEUED there (the call does not wait for
+ * the copy); every later call on that plan that takes another stream orders it behind the upload with an event, so the caller needs no
+ * synchronisation of its own.  With the default (NULL) uploads stay synchronous.  (The per-iteration optimiser scalar table of gnnx_run
+ * is uploaded once per process and hyper-parameter set and shared by all plans.)  gnnx_lane_stream(i), i = 0..2: the library's process-wide launch lanes (hipStream_t) - the
  * streams the resident launches of gnnx_run execute on; gnnx_debug_spin keeps a stream busy for `micros` microseconds.  The
  * last two exist so that a caller can check which of ITS streams share a hardware queue with a lane (HIP binds streams to
  * GPU_MAX_HW_QUEUES queues round-robin; streams on one queue execute in order). */
