@@ -334,7 +334,7 @@ def main():
     ap.add_argument("--no-parity-gate", action="store_true", help="measurement sessions: report parity but do not fail the run")
     ap.add_argument("--no-single-gpu-leg", action="store_true", help="N > 1: skip the same-workload single-GPU run on rank 0")
     ap.add_argument("--no-calibration", action="store_true", help="N > 1: shard by the default cost table instead of measuring it on rank 0")
-    ap.add_argument("--reps", type=int, default=5, help="end-to-end line: the K-step timed region is repeated this many times (each repetition: exactly "
+    ap.add_argument("--reps", type=int, default=0, help="end-to-end line: the K-step timed region is repeated this many times (each repetition: exactly "
                                                        "K batches between two barriers) and the MEDIAN repetition is reported - one 20-batch region lasts "
                                                        "50 ms and ten consecutive runs of it spanned 134.8-166.6 k nodes/s (profiles/r03_bench_syn1_ten_runs.txt)")
     ap.add_argument("--loop-only", action="store_true", help="N = 1: report the resident-input loop rate as `value` (rounds 1-2) instead of the end-to-end rate")
@@ -540,7 +540,7 @@ def main():
             pass
         reps = []
         last = None
-        for _ in range(max(1, args.reps)):
+        for _ in range(args.reps if args.reps > 0 else (9 if world == 1 else 5)):   # default: nine repetitions of a millisecond-scale region (syn1: 40 ms each), five of the sharded one
             pipe.stats.clear()
             barrier()
             t0 = time.perf_counter()
