@@ -662,6 +662,12 @@ def test_one_pass_khop_equals_two_passes(be):
     assert torch.equal(ja.A.cpu(), jb.A.cpu()) and torch.equal(ja.X.cpu(), jb.X.cpu()) and torch.equal(ja.yhat.cpu(), jb.yhat.cpu())
     assert np.array_equal(ja.route(), jb.route())
     assert engine.khop_device(graph, targets, 3, lib=be.lib, one_pass=True).nb_off is one.nb_off      # the offsets are cached per graph
+    cap, engine._ONE_PASS_MAX_INTS = engine._ONE_PASS_MAX_INTS, len(targets) * graph.num_nodes - 1   # padded lists beyond the cap: two passes, compact lists
+    try:
+        back = engine.khop_device(graph, targets, 3, lib=be.lib, one_pass=True)
+    finally:
+        engine._ONE_PASS_MAX_INTS = cap
+    assert np.array_equal(back.nb_off.cpu().numpy(), two.nb_off.cpu().numpy()) and np.array_equal(back.rows, two.rows)
 
 
 def test_device_khop_isolated_node_has_empty_set(be):
