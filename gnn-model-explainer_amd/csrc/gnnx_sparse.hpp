@@ -121,7 +121,7 @@ struct SparseFixed {
     int set_chunk[2];  // entries per row slot of the set: the smallest of {4, 8, 16} (8, 16 for set A) whose slots fit the class
     int chunk_b;       // node mode, set A: slot width of the rows of t and its neighbours (<= set_chunk[0]; see "slot width per row")
     int erow[96];  // graph mode: arg-max row of every pooled column
-    float wt[32], vsum[32];  // algebraic constant-feature form: (x (.) phi) W1, and sum over the rows of s_r dY1[r]
+    float wt[32], vsum[32];  // algebraic constant-feature form: (x (.) phi) W1; vsum (sum over the rows of s_r dY1[r]) lives in wave 0's registers since round 4 - the slot keeps the struct's size, which the LDS budget of the mixed launch is built on
     float lsum[SP_THREADS / 64][4];  // LOG form: per-wave partial sums of the logged size / entropy / Laplacian terms over the owned edges
 };
 
