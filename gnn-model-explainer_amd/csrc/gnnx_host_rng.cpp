@@ -7,10 +7,12 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstring>
 #include <condition_variable>
 #include <exception>
 #include <functional>
 #include <mutex>
+#include <optional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -89,7 +91,7 @@ struct Slice { int k; int64_t a, b; at::mt19937 eng; };
 // recurrence of MT19937RNGEngine.h's next_state, the standard MT19937 one) with next_ = r, left_ = 625 - r, r = (d - 1) % 624 + 1 draws
 // taken from the current block.  The block update alone is a short vectorisable loop (0.3 ns per skipped draw instead of the 2-3 ns of
 // operator(), which also tempers every output).
-inline void mt_block_update(uint32_t* st) {
+__attribute__((target_clones("avx512f", "avx2", "default"))) void mt_block_update(uint32_t* st) {   // (resolved once at load time for the host's widest vectors)
     constexpr int N = 624, M = 397;
     constexpr uint32_t A = 0x9908b0dfu, UM = 0x80000000u, LM = 0x7fffffffu;
     auto tw = [](uint32_t u, uint32_t v) { return (((u & UM) | (v & LM)) >> 1) ^ ((v & 1u) ? A : 0u); };
@@ -222,15 +224,65 @@ extern "C" int gnnx_host_draw_masks_sliced(int32_t T, const int32_t* n, const in
 }
 
 // The edge-sparse kernels read the initial mask only on the EDGES of a sub-graph (the other n^2 - 2E entries of construct_edge_mask's
-// draw never reach an output of the reference, explain.py:665-678), but the values on the edges are positions of ONE mt19937 stream
-// per target, so the whole stream still has to be generated - what need not happen is writing it: the full draw of the 16 384-target
-// BA-House x100k set is 4 GB through the host's memory system (94-140 ms on 32 threads, SLOWER on more: tools/probe_rng_big.py), plus a
-// 4 GB H2D copy and a scatter kernel.  Here every thread draws its part of the stream slice by slice into a cache-resident buffer (the
-// same ATen normal_ calls on the same engine states as gnnx_host_draw_masks_sliced: bit-identical values) and keeps the two values of
-// every edge, out[e] = (M[r][c], M[c][r]) for edge e = (r, c) of the target's upper-triangle edge list - 12 MB instead of 4 GB leave
-// the host, and the draw scales with the cores again.
-// rc [E][2] int32: the edges of all targets, target after target (eoff [T + 1]), r < c, local node ids.  A chunk of a large target starts
-// from the seeded engine advanced by its first value's index (mt_advance: 0.3 ns per skipped draw).
+// draw never reach an output of the reference, explain.py:665-678).  The values on the edges are positions of ONE mt19937 stream per
+// target, so the engine has to pass over the whole stream - but only its STATE: ATen's normal_ (normal_fill, see above) is one engine
+// draw per value followed by a Box-Muller transform of 16 values at a time, and 624 = 39 x 16, so a 16-value block never straddles two
+// states of the engine.  Per target (per chunk of a large one) a walker regenerates the raw state block by block (0.3 ns per draw: no
+// tempering, no uniform, no logarithm / sine / cosine), copies the 16 raw words of every block that holds an edge entry into a staging
+// state, and lets ATEN ITSELF temper and transform 38 such blocks per call: an engine whose state array holds the staged words yields
+// exactly the draws of those blocks, so `normal_` of 16 x 38 values from it IS the reference's arithmetic on them - bit-identical to the
+// full draw by construction (tests/test_host_api.py), whatever vector path ATen takes on the host.  A ragged stream (n^2 not a multiple
+// of 16) has its last 16 values redrawn from the 16 draws that follow the fill: the same staging, from those words.  Streams of fewer
+// than 16 values take ATen's scalar path as a whole.  For the 16 384-target BA-House x100k set 6.6 % of the 62.5 M blocks hold an edge
+// entry: the draw that bounded its batches (1.0e9 normals, 4.6 ns of one core each) becomes 1.0e9 block-update steps + 4 M staged blocks.
+// rc [E][2] int32: the edges of all targets, target after target (eoff [T + 1]), r < c, local node ids; out[e] = (M[r][c], M[c][r]).
+namespace {
+constexpr int MTN = 624;
+constexpr int STAGE_SLOTS = 38;     // 16-word blocks per staged engine state: words 1 .. 608 (next_ = 1, left_ = 624: a valid engine that
+                                    // yields 623 draws without regenerating)
+inline void mt_seed_state(uint32_t* st, uint64_t seed) {   // at::mt19937::init_with_uint32
+    st[0] = (uint32_t)(seed & 0xffffffffu);
+    for (int j = 1; j < MTN; ++j) st[j] = 1812433253u * (st[j - 1] ^ (st[j - 1] >> 30)) + (uint32_t)j;
+}
+struct EdgeTarget {                 // one target of the edge draw
+    int k = 0;
+    int64_t nn = 0, reg_end = 0;    // values; positions >= reg_end come from the redrawn last 16 values (reg_end = nn when nn % 16 == 0)
+    std::vector<std::pair<int64_t, int64_t>> pos;   // (position in the n x n stream, index into out), ascending
+};
+struct EdgeChunk { int ti; int64_t b0, b1; std::vector<uint32_t> start; };   // state blocks [b0, b1); `start` = the raw state before block b0's update
+struct Stager {
+    at::Generator gen = at::detail::createCPUGenerator(0);
+    at::CPUGeneratorImpl* impl = at::check_generator<at::CPUGeneratorImpl>(gen);
+    uint32_t words[1 + 16 * STAGE_SLOTS];
+    float vals[16 * STAGE_SLOTS];
+    int slots = 0;
+    std::vector<std::pair<int, int64_t>> wants;     // (16 * slot + lane, index into out)
+    double std_ = 1.0;
+    float* out = nullptr;
+    int add(const uint32_t* w16) {
+        std::memcpy(words + 1 + 16 * slots, w16, 16 * sizeof(uint32_t));
+        return slots++;
+    }
+    void flush() {
+        if (!slots) return;
+        at::mt19937 eng;
+        at::mt19937_data_pod pod = eng.data();
+        pod.seeded_ = true;
+        pod.next_ = 1;
+        pod.left_ = MTN;
+        std::memcpy(pod.state_.data() + 1, words + 1, sizeof(uint32_t) * 16 * (size_t)slots);
+        eng.set_data(pod);
+        impl->set_engine(eng);
+        impl->set_next_float_normal_sample(std::optional<float>());
+        at::Tensor view = at::from_blob(vals, {(int64_t)16 * slots}, at::TensorOptions().dtype(at::kFloat));
+        view.normal_(1.0, std_, gen);       // 16 * slots >= 16 values, a multiple of 16: normal_fill, no redraw of a ragged tail
+        for (const auto& w : wants) out[w.second] = vals[w.first];
+        wants.clear();
+        slots = 0;
+    }
+};
+}  // namespace
+
 extern "C" int gnnx_host_draw_edge_masks(int32_t T, const int32_t* n, const int64_t* seeds, const int64_t* eoff, const int32_t* rc, float* out,
                                          int32_t threads, int64_t slice_values) {
     if (T < 0 || (T > 0 && (!n || !seeds || !eoff || !rc || !out))) {
@@ -239,84 +291,142 @@ extern "C" int gnnx_host_draw_edge_masks(int32_t T, const int32_t* n, const int6
     }
     if (T == 0) return 0;
     threads = std::max(1, std::min<int32_t>(threads, 128));
-    const int64_t L = std::max<int64_t>(1024, slice_values / 16 * 16);        // values per normal_ call (cache-resident buffer)
-    const int64_t CH = 32 * L;                                                   // values per work item
-    struct Chunk { int k; int64_t a, b; };
-    std::vector<Chunk> chunks;
+    const int64_t CHB = std::max<int64_t>(1, 32 * std::max<int64_t>(1024, slice_values) / MTN);   // engine state blocks per work item
+    std::vector<EdgeTarget> tg;
+    tg.reserve(T);
     for (int k = 0; k < T; ++k) {
         const int64_t nn = (int64_t)n[k] * n[k];
         if (nn == 0 || eoff[k + 1] == eoff[k]) continue;                         // no edge: nothing of this target's stream is needed
-        for (int64_t a = 0; a < nn; a += CH) {
-            const int64_t b = (nn - a < CH + 16) ? nn : a + CH;
-            chunks.push_back(Chunk{k, a, b});
-            if (b == nn) break;
-        }
+        EdgeTarget t;
+        t.k = k;
+        t.nn = nn;
+        t.reg_end = (nn % 16 == 0) ? nn : nn - 16;
+        tg.push_back(std::move(t));
     }
-    // largest work items first, then dynamic hand-out
-    std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk& x, const Chunk& y) { return (x.b - x.a) > (y.b - y.a); });
-    // per target: (position in the n x n stream, index into out) of its 2E entries, sorted by position - built by the first chunk that needs it
-    std::vector<std::vector<std::pair<int64_t, int64_t>>> pos(T);
-    std::vector<std::once_flag> built(T);
     std::atomic<bool> failed{false};
     std::string err;
     std::mutex err_mu;
-    auto work = [&](int ci) {
+    auto fail = [&](const std::exception& e) {
+        std::lock_guard<std::mutex> lk(err_mu);
+        failed = true;
+        err = e.what();
+    };
+    auto std_of = [&](int k) { return std::sqrt(2.0) * std::sqrt(2.0 / ((double)n[k] + (double)n[k])); };
+    // the blocks [b0, b1) of one target from the raw state `st` (the state BEFORE block b0's update); `last`: this call also serves the
+    // redrawn tail of a ragged stream
+    // (b0 == b1: the tail alone, from the state a walker left behind the last regular block)
+    auto run_blocks = [&](const EdgeTarget& t, uint32_t* st, int64_t b0, int64_t b1, bool last, Stager& sg) {
+        sg.std_ = std_of(t.k);
+        sg.out = out;
+        auto it = std::lower_bound(t.pos.begin(), t.pos.end(), std::make_pair(b0 == b1 ? t.reg_end : b0 * MTN, (int64_t)-1));
+        const auto end = t.pos.end();
+        int64_t b = b0;
+        for (; b < b1; ++b) {
+            mt_block_update(st);                                                 // st = the words of draws [624 b, 624 b + 624)
+            const int64_t lim = std::min<int64_t>((b + 1) * MTN, t.reg_end);
+            while (it != end && it->first < lim) {
+                const int64_t q16 = it->first / 16;
+                const int slot = sg.add(st + (16 * q16 - b * MTN));
+                for (; it != end && it->first < 16 * q16 + 16 && it->first < t.reg_end; ++it)
+                    sg.wants.emplace_back(16 * slot + (int)(it->first - 16 * q16), it->second);
+                if (sg.slots == STAGE_SLOTS) sg.flush();
+            }
+        }
+        if (last && t.reg_end != t.nn && it != end) {                            // entries among the last 16 values of a ragged stream: draws [nn, nn + 16)
+            const int64_t bt = t.nn / MTN;
+            for (; b <= bt; ++b) mt_block_update(st);                            // st = block bt (b1 - 1 <= bt always)
+            uint32_t w16[16];
+            const int w0 = (int)(t.nn % MTN), first = std::min(16, MTN - w0);
+            std::memcpy(w16, st + w0, sizeof(uint32_t) * first);
+            if (first < 16) {
+                mt_block_update(st);
+                std::memcpy(w16 + first, st, sizeof(uint32_t) * (16 - first));
+            }
+            const int slot = sg.add(w16);
+            for (; it != end; ++it) sg.wants.emplace_back(16 * slot + (int)(it->first - (t.nn - 16)), it->second);
+        }
+        sg.flush();
+    };
+    std::vector<EdgeChunk> chunks;     // the chunks of the large targets (filled by their walkers in phase 1)
+    std::mutex chunks_mu;
+    // phase 1, one work item per target: build its sorted positions; a stream of fewer than 16 values as a whole (ATen's scalar path); a target
+    // of up to CHB blocks entirely; a larger one only WALKS here and leaves the raw state at every chunk boundary for phase 2
+    auto phase1 = [&](int ti) {
         try {
             c10::InferenceMode ng;
-            const Chunk c = chunks[ci];
-            const int k = c.k;
-            const int64_t nk = n[k], nn = nk * nk;
-            std::call_once(built[k], [&] {
-                auto& p = pos[k];
-                p.reserve(2 * (size_t)(eoff[k + 1] - eoff[k]));
-                for (int64_t e = eoff[k]; e < eoff[k + 1]; ++e) {
-                    const int64_t r = rc[2 * e], cc = rc[2 * e + 1];
-                    p.emplace_back(r * nk + cc, 2 * e);
-                    p.emplace_back(cc * nk + r, 2 * e + 1);
-                }
-                std::sort(p.begin(), p.end());
-            });
-            const auto& p = pos[k];
-            size_t it = std::lower_bound(p.begin(), p.end(), std::make_pair(c.a, (int64_t)-1)) - p.begin();
-            if (it == p.size() || p[it].first >= c.b) return;                     // no edge entry in this chunk: its values are not needed
-            at::Generator gen = at::detail::createCPUGenerator(0);
-            gen.set_current_seed((uint64_t)seeds[k]);
-            auto* impl = at::check_generator<at::CPUGeneratorImpl>(gen);
-            const double std_ = std::sqrt(2.0) * std::sqrt(2.0 / ((double)nk + (double)nk));
-            std::vector<float> buf((size_t)(L + 16));
-            int64_t at_draw = 0;      // draws the engine has made
-            for (int64_t s = c.a; s < c.b;) {
-                int64_t t = (c.b - s < L + 16) ? c.b : s + L;                     // (no last call shorter than 16 values: ATen redraws the last 16 of a ragged tensor)
-                if (it < p.size() && p[it].first >= t && t < c.b) {              // nothing wanted in [s, t): skip it without drawing
-                    s = t;
-                    continue;
-                }
-                if (at_draw != s) {
-                    at::mt19937 eng((uint64_t)seeds[k]);
-                    mt_advance(eng, 0, s);
-                    impl->set_engine(eng);
-                    impl->set_next_float_normal_sample(std::optional<float>());
-                    at_draw = s;
-                }
-                at::Tensor view = at::from_blob(buf.data(), {t - s}, at::TensorOptions().dtype(at::kFloat));
-                view.normal_(1.0, std_, gen);
-                at_draw = t;                                                      // (a ragged last call draws 16 more, but it is the last of its target)
-                for (; it < p.size() && p[it].first < t; ++it) out[p[it].second] = buf[(size_t)(p[it].first - s)];
-                s = t;
-                if (it == p.size() || p[it].first >= c.b) break;
+            EdgeTarget& t = tg[ti];
+            const int k = t.k;
+            const int64_t nk = n[k];
+            t.pos.reserve(2 * (size_t)(eoff[k + 1] - eoff[k]));
+            for (int64_t e = eoff[k]; e < eoff[k + 1]; ++e) {
+                const int64_t r = rc[2 * e], cc = rc[2 * e + 1];
+                t.pos.emplace_back(r * nk + cc, 2 * e);
+                t.pos.emplace_back(cc * nk + r, 2 * e + 1);
             }
+            std::sort(t.pos.begin(), t.pos.end());
+            if (t.nn < 16) {
+                at::Generator gen = at::detail::createCPUGenerator(0);
+                gen.set_current_seed((uint64_t)seeds[k]);
+                float buf[16];
+                at::Tensor view = at::from_blob(buf, {t.nn}, at::TensorOptions().dtype(at::kFloat));
+                view.normal_(1.0, std_of(k), gen);
+                for (const auto& pr : t.pos) out[pr.second] = buf[pr.first];
+                return;
+            }
+            const bool tail = t.reg_end != t.nn && t.pos.back().first >= t.reg_end;
+            int64_t last_reg = -1;                                               // last wanted position in the regular part
+            for (auto it = t.pos.rbegin(); it != t.pos.rend(); ++it)
+                if (it->first < t.reg_end) {
+                    last_reg = it->first;
+                    break;
+                }
+            const int64_t nblk = last_reg >= 0 ? last_reg / MTN + 1 : 0;         // state blocks the regular entries need
+            std::vector<uint32_t> st(MTN);
+            mt_seed_state(st.data(), (uint64_t)seeds[k]);
+            if (nblk <= CHB) {
+                Stager sg;
+                run_blocks(t, st.data(), 0, nblk, true, sg);
+                return;
+            }
+            std::vector<EdgeChunk> mine;
+            for (int64_t b0 = 0; b0 < nblk; b0 += CHB) {
+                const int64_t b1 = std::min(nblk, b0 + CHB);
+                mine.push_back(EdgeChunk{ti, b0, b1, st});
+                if (b1 < nblk || tail)                                           // (the last chunk's own pass ends the walk unless the tail needs a start of its own)
+                    for (int64_t b = b0; b < b1; ++b) mt_block_update(st.data());
+            }
+            if (tail) mine.push_back(EdgeChunk{ti, nblk, nblk, st});             // an empty block range: run_blocks goes straight to the tail
+            std::lock_guard<std::mutex> lk(chunks_mu);
+            for (auto& c : mine) chunks.push_back(std::move(c));
         } catch (const std::exception& e) {
-            std::lock_guard<std::mutex> lk(err_mu);
-            failed = true;
-            err = e.what();
+            fail(e);
         }
     };
-    if (chunks.size() == 1 || threads == 1) {
-        for (int ci = 0; ci < (int)chunks.size(); ++ci) work(ci);
-    } else if (!chunks.empty()) {
+    auto phase2 = [&](int ci) {
+        try {
+            c10::InferenceMode ng;
+            EdgeChunk& c = chunks[ci];
+            Stager sg;
+            // (a regular chunk stops at its own last block - the entries of later blocks belong to later chunks; the tail chunk is the empty range)
+            run_blocks(tg[c.ti], c.start.data(), c.b0, c.b1, c.b0 == c.b1, sg);
+        } catch (const std::exception& e) {
+            fail(e);
+        }
+    };
+    const int nt = (int)tg.size();
+    if (nt == 0) return 0;
+    if (threads == 1) {
+        for (int i = 0; i < nt; ++i) phase1(i);
+        for (int i = 0; i < (int)chunks.size() && !failed; ++i) phase2(i);
+    } else {
+        // the largest targets first (their walkers are the long poles), then dynamic hand-out
+        std::vector<int> order(nt);
+        for (int i = 0; i < nt; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return tg[a].nn > tg[b].nn; });
         std::lock_guard<std::mutex> lk(g_pool_mu);
         if (!g_pool || g_pool->size() < threads) g_pool = new Pool(std::max<int>(threads, 16));
-        g_pool->run((int)chunks.size(), work);
+        g_pool->run(nt, [&](int i) { phase1(order[i]); });
+        if (!failed && !chunks.empty()) g_pool->run((int)chunks.size(), phase2);
     }
     if (failed) {
         g_err = err;

@@ -48,14 +48,15 @@ class BatchPipeline:
         # device_hook(values [E] on the device, job): called on the fetch stream once a batch's edge values are gathered, before their D2H
         # copy - the sharded job all-gathers the masks of every rank there (RCCL over xGMI; bench.py --gpus N)
         self.device_hook = device_hook
-        # Large batches on the edge-sparse kernels can keep only the EDGE entries of the host draw (see _prepare: 16 MB instead of 4 GB leave
-        # the host for the 16 384-target BA-House x100k set).  OFF by default - measured on the GPU box (tools/probe_rng_edges.py,
-        # profiles/r04_host_rng_edges_16384targets.txt): its container has a CPU quota of 16 cores (cgroup cpu.max 1600000 100000 on a 2 x 64-core
-        # EPYC 9575F), the draw costs 4.6 ns of one core per normal whatever is kept of it (mt19937 + ATen's vectorised Box-Muller), so 1e9
-        # normals take 150-200 ms with 32 threads and LONGER with more, full stream (154 ms) or edges only (197 ms: the extraction and the
-        # engine advances on top); end to end 72.7 k vs 63-79 k nodes/s - no gain here.  It saves 4 GB of pinned writes, PCIe and HBM
-        # traffic per batch, which matters where the host is not the bound: edge_draw=True / GNNX_PIPE_EDGE_DRAW=1.
-        self.edge_draw = bool(int(os.environ.get("GNNX_PIPE_EDGE_DRAW", "0"))) if edge_draw is None else bool(edge_draw)
+        # Large batches on the edge-sparse kernels keep only the EDGE entries of the host draw (see _prepare: 16 MB instead of 4 GB leave the host
+        # for the 16 384-target BA-House x100k set).  History: the first form of gnnx_host_draw_edge_masks still ran ATen's normal_ over every
+        # slice of the stream that held an edge entry - all of them, for targets of thousands of nodes - so it cost what the full draw costs
+        # (4.6 ns of one core per normal: 154 ms full vs 197 ms edges only on the GPU box's 16-core quota, profiles/r04_host_rng_edges_16384targets.txt)
+        # and stayed off.  The block-granular form passes over the stream as engine STATE only (0.3 ns per draw) and lets ATen transform just the
+        # 16-value blocks that hold an entry (6.6 % of them on that set): 0.8 ns per normal of the stream, 550 -> 96-110 ms in the 8-core build
+        # container (profiles/r04_host_rng_edges_blocks.txt), bit-identical - ON by default; edge_draw=False / GNNX_PIPE_EDGE_DRAW=0 restores the
+        # full stream.
+        self.edge_draw = bool(int(os.environ.get("GNNX_PIPE_EDGE_DRAW", "1"))) if edge_draw is None else bool(edge_draw)
         self.edge_draw_min_values = float(edge_draw_min_values)      # batches of fewer normals keep the full draw (it overlaps the plan; syn1: 0.5 ms)
         self.rng_threads_edges = int(os.environ.get("GNNX_PIPE_EDGE_THREADS", self.rng_threads))
         depth = int(os.environ.get("GNNX_PIPE_DEPTH", depth))                        # (measurement knobs)

@@ -31,11 +31,13 @@ int gnnx_host_draw_masks_sliced(int32_t num_targets, const int32_t* n, const int
                                 int64_t slice_values);
 
 /* The same draws, keeping only the values on the EDGES: out[e] = (M[r][c], M[c][r]) for edge e = (rc[2e], rc[2e + 1]), r < c, local node ids,
- * the edges of all targets target after target (eoff [T + 1]).  The edge-sparse kernels read the initial mask nowhere else, and the values
- * on the edges are positions of one mt19937 stream per target - so the stream is still generated (the same ATen normal_ calls on the same
- * engine states: bit-identical to the full draw), slice by slice into cache-resident buffers, but only 2E values leave the host instead of
- * sum(n^2): 12 MB instead of 4 GB for the 16 384-target BA-House x100k set, whose full draw is bound by the host's memory system.  Stretches
- * of a stream that hold no edge entry are skipped without drawing (mt19937 block updates only). */
+ * the edges of all targets target after target (eoff [T + 1]).  The edge-sparse kernels read the initial mask nowhere else.  The values on
+ * the edges are positions of one mt19937 stream per target, so the engine passes over the whole stream - as STATE only: ATen's normal_ is one
+ * engine draw per value, then a Box-Muller transform of 16 values at a time, and 624 = 39 x 16, so a walker regenerates the raw state block by
+ * block (no tempering, no transform), copies the 16 raw words of every block that holds an edge entry into a staged engine state, and ATen
+ * itself draws 38 such blocks per normal_ call from it: bit-identical to the full draw by construction, at 0.8 instead of 4.6 ns per normal of
+ * the stream, and only 2E values leave the host instead of sum(n^2) (12 MB instead of 4 GB for the 16 384-target BA-House x100k set).
+ * slice_values: work-item length (large targets are cut into chunks of 32 * slice_values values from states a walker leaves behind). */
 int gnnx_host_draw_edge_masks(int32_t num_targets, const int32_t* n, const int64_t* seeds, const int64_t* eoff, const int32_t* rc, float* out,
                               int32_t threads, int64_t slice_values);
 

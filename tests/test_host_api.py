@@ -140,6 +140,33 @@ def test_host_rng_library_draws_the_reference_masks_bit_for_bit():
     for threads, sl in ((1, 1024), (4, 1024), (3, 1 << 17), (8, 2048)):
         got = engine.init_edge_masks_on_edges(sizes, seeds, np.asarray(eoff), rc, threads=threads, slice_values=sl)
         assert torch.equal(got, want), (threads, sl)
+    # ... and random batches: sizes around the engine's 624-draw state block and the 16-value transform block, densities from empty to complete,
+    # entries among the first and the last values of a stream, several chunk lengths (the block-granular form of the edge draw)
+    rng = np.random.default_rng(11)
+    for trial in range(3):
+        T = int(rng.integers(3, 24))
+        sizes = [int(x) for x in rng.choice([1, 2, 3, 4, 5, 7, 15, 16, 17, 31, 33, 64, 100, 129, 250, 399, 624, 700], T)]
+        seeds = 5000 + np.arange(T) * 3 + trial
+        full = engine.init_edge_masks_raw(sizes, seeds=seeds, threads=4)
+        off = np.concatenate([[0], np.cumsum(np.asarray(sizes, np.int64) ** 2)])
+        rcs, eoff = [], [0]
+        for n in sizes:
+            m = np.triu(rng.random((n, n)) < float(rng.choice([0.0, 0.002, 0.02, 0.3, 1.0])), 1)
+            if n >= 2 and rng.random() < 0.5:
+                m[n - 2, n - 1] = True
+            if n >= 2 and rng.random() < 0.5:
+                m[0, 1] = True
+            r, c = np.nonzero(m)
+            rcs.append(np.stack([r, c], 1).astype(np.int32))
+            eoff.append(eoff[-1] + len(r))
+        rc = np.concatenate(rcs)
+        if not len(rc):
+            continue
+        want = torch.cat([torch.stack([full[off[k] + rcs[k][:, 0].astype(np.int64) * sizes[k] + rcs[k][:, 1]],
+                                       full[off[k] + rcs[k][:, 1].astype(np.int64) * sizes[k] + rcs[k][:, 0]]], 1) for k in range(T) if len(rcs[k])])
+        for threads, sl in ((1, 1024), (8, 1024), (5, 4096), (8, 1 << 17)):
+            got = engine.init_edge_masks_on_edges(sizes, seeds, np.asarray(eoff), rc, threads=threads, slice_values=sl)
+            assert torch.equal(got, want), (trial, threads, sl)
     big = engine.init_edge_masks_raw([1500], seeds=[77], threads=8)          # 2.25 M values: sliced at the default length
     assert torch.equal(big, helpers.seeded_mask0(77 - 1000, 1500).flatten())
 
