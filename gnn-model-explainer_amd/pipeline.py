@@ -58,7 +58,7 @@ class BatchPipeline:
         # full stream.
         self.edge_draw = bool(int(os.environ.get("GNNX_PIPE_EDGE_DRAW", "1"))) if edge_draw is None else bool(edge_draw)
         self.edge_draw_min_values = float(edge_draw_min_values)      # batches of fewer normals keep the full draw (it overlaps the plan; syn1: 0.5 ms)
-        self.rng_threads_edges = int(os.environ.get("GNNX_PIPE_EDGE_THREADS", self.rng_threads))
+        self.rng_threads_edges = int(os.environ.get("GNNX_PIPE_EDGE_THREADS", self.rng_threads_big))   # (the ranks of a node share its cores: the sharded bench passes its share)
         depth = int(os.environ.get("GNNX_PIPE_DEPTH", depth))                        # (measurement knobs)
         reserve_cus = int(os.environ.get("GNNX_PIPE_RESERVE", reserve_cus))
         prepare_workers = int(os.environ.get("GNNX_PIPE_WORKERS", prepare_workers))
