@@ -31,9 +31,11 @@ class Pool {
     }
     int size() const { return (int)workers_.size(); }
     // run fn(i) for i in [0, parts) on the workers and wait
-    void run(int parts, const std::function<void(int)>& fn) {
+    // (limit: at most that many workers take items - the ranks of a node share its cores, each is told its share)
+    void run(int parts, const std::function<void(int)>& fn, int limit = 1 << 30) {
         std::unique_lock<std::mutex> lk(mu_);
         fn_ = &fn;
+        limit_ = limit;
         parts_ = parts;
         next_ = 0;
         done_ = 0;
@@ -44,14 +46,14 @@ class Pool {
     }
 
   private:
-    void loop(int) {
+    void loop(int me) {
         c10::InferenceMode ng;
         unsigned long long seen = 0;
         for (;;) {
             std::unique_lock<std::mutex> lk(mu_);
             cv_.wait(lk, [&] { return epoch_ != seen; });
             seen = epoch_;
-            while (next_ < parts_) {
+            while (me < limit_ && next_ < parts_) {
                 const int i = next_++;
                 lk.unlock();
                 (*fn_)(i);
@@ -64,7 +66,7 @@ class Pool {
     std::mutex mu_;
     std::condition_variable cv_, cv_done_;
     const std::function<void(int)>* fn_ = nullptr;
-    int parts_ = 0, next_ = 0, done_ = 0;
+    int parts_ = 0, next_ = 0, done_ = 0, limit_ = 1 << 30;
     unsigned long long epoch_ = 0;
 };
 
@@ -425,8 +427,8 @@ extern "C" int gnnx_host_draw_edge_masks(int32_t T, const int32_t* n, const int6
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return tg[a].nn > tg[b].nn; });
         std::lock_guard<std::mutex> lk(g_pool_mu);
         if (!g_pool || g_pool->size() < threads) g_pool = new Pool(std::max<int>(threads, 16));
-        g_pool->run(nt, [&](int i) { phase1(order[i]); });
-        if (!failed && !chunks.empty()) g_pool->run((int)chunks.size(), phase2);
+        g_pool->run(nt, [&](int i) { phase1(order[i]); }, threads);
+        if (!failed && !chunks.empty()) g_pool->run((int)chunks.size(), phase2, threads);
     }
     if (failed) {
         g_err = err;
