@@ -66,7 +66,13 @@ def rng_threads_for(total_values, world=1):
     from gnn_model_explainer_amd import engine
     # (more threads do not help the big batches either: 1e9 normals take 94-140 ms on 32 threads of the GPU box's 256-CPU host and 160-230 ms on
     #  96-128 - the draw is bound by the memory system, tools/probe_rng_big.py; N ranks on one host share its cores)
-    return max(2, min(engine.default_rng_threads(), (os.cpu_count() or 4) // (2 * max(1, world))))
+    # (... of the cores the process may USE: the GPU box's container has a quota of 16 of its host's 256 CPUs, and eight ranks of sixteen threads
+    #  each on sixteen cores only take turns)
+    cores = (os.cpu_count() or 4) // 2
+    quota = engine.cpu_quota_cores()
+    if quota:
+        cores = min(cores, int(2 * quota))
+    return max(2, min(engine.default_rng_threads(), cores // max(1, world)))
 
 
 WELL = 2e-6                  # CPU-vs-CPU deviation (reference vs closed-form oracle) up to which a target is well conditioned
