@@ -283,6 +283,23 @@ struct Stager {
         slots = 0;
     }
 };
+// per worker thread: one staging engine (creating a generator per target cost as much as a small target's draw) and the merge scratch
+Stager& thread_stager() {
+    thread_local Stager sg;
+    return sg;
+}
+std::vector<std::pair<int64_t, int64_t>>& scratch_up() {
+    thread_local std::vector<std::pair<int64_t, int64_t>> v;
+    return v;
+}
+std::vector<std::pair<int64_t, int64_t>>& scratch_lo() {
+    thread_local std::vector<std::pair<int64_t, int64_t>> v;
+    return v;
+}
+std::vector<int64_t>& scratch_cnt() {
+    thread_local std::vector<int64_t> v;
+    return v;
+}
 }  // namespace
 
 extern "C" int gnnx_host_draw_edge_masks(int32_t T, const int32_t* n, const int64_t* seeds, const int64_t* eoff, const int32_t* rc, float* out,
@@ -359,16 +376,40 @@ extern "C" int gnnx_host_draw_edge_masks(int32_t T, const int32_t* n, const int6
             EdgeTarget& t = tg[ti];
             const int k = t.k;
             const int64_t nk = n[k];
-            t.pos.reserve(2 * (size_t)(eoff[k + 1] - eoff[k]));
-            for (int64_t e = eoff[k]; e < eoff[k + 1]; ++e) {
-                const int64_t r = rc[2 * e], cc = rc[2 * e + 1];
-                t.pos.emplace_back(r * nk + cc, 2 * e);
-                t.pos.emplace_back(cc * nk + r, 2 * e + 1);
+            // Positions in ascending order without a sort when the caller's list is row-major (what gnnx_edge_layout / gnnx_gather_edges emit):
+            // the entries (r, c) then ascend as they come, and the mirrored ones (c, r) ascend after a stable bucketing by column - two
+            // sorted runs, merged.  Any other order falls back to the sort.
+            const int64_t e0 = eoff[k], ne = eoff[k + 1] - eoff[k];
+            bool row_major = true;
+            for (int64_t e = e0 + 1; e < e0 + ne && row_major; ++e)
+                row_major = (int64_t)rc[2 * e - 2] * nk + rc[2 * e - 1] < (int64_t)rc[2 * e] * nk + rc[2 * e + 1];
+            t.pos.resize(2 * (size_t)ne);
+            if (row_major) {
+                std::vector<std::pair<int64_t, int64_t>>& up = scratch_up();
+                std::vector<std::pair<int64_t, int64_t>>& lo = scratch_lo();
+                std::vector<int64_t>& cnt = scratch_cnt();
+                up.resize((size_t)ne);
+                lo.resize((size_t)ne);
+                cnt.assign((size_t)nk + 1, 0);
+                for (int64_t e = e0; e < e0 + ne; ++e) ++cnt[(size_t)rc[2 * e + 1] + 1];
+                for (int64_t c = 0; c < nk; ++c) cnt[(size_t)c + 1] += cnt[(size_t)c];
+                for (int64_t e = e0; e < e0 + ne; ++e) {
+                    const int64_t r = rc[2 * e], cc = rc[2 * e + 1];
+                    up[(size_t)(e - e0)] = {r * nk + cc, 2 * e};
+                    lo[(size_t)cnt[(size_t)cc]++] = {cc * nk + r, 2 * e + 1};
+                }
+                std::merge(up.begin(), up.end(), lo.begin(), lo.end(), t.pos.begin());
+            } else {
+                for (int64_t e = e0; e < e0 + ne; ++e) {
+                    const int64_t r = rc[2 * e], cc = rc[2 * e + 1];
+                    t.pos[2 * (size_t)(e - e0)] = {r * nk + cc, 2 * e};
+                    t.pos[2 * (size_t)(e - e0) + 1] = {cc * nk + r, 2 * e + 1};
+                }
+                std::sort(t.pos.begin(), t.pos.end());
             }
-            std::sort(t.pos.begin(), t.pos.end());
             if (t.nn < 16) {
-                at::Generator gen = at::detail::createCPUGenerator(0);
-                gen.set_current_seed((uint64_t)seeds[k]);
+                at::Generator& gen = thread_stager().gen;
+                gen.set_current_seed((uint64_t)seeds[k]);   // (fresh mt19937, no cached normal - as torch.manual_seed)
                 float buf[16];
                 at::Tensor view = at::from_blob(buf, {t.nn}, at::TensorOptions().dtype(at::kFloat));
                 view.normal_(1.0, std_of(k), gen);
@@ -383,11 +424,11 @@ extern "C" int gnnx_host_draw_edge_masks(int32_t T, const int32_t* n, const int6
                     break;
                 }
             const int64_t nblk = last_reg >= 0 ? last_reg / MTN + 1 : 0;         // state blocks the regular entries need
-            std::vector<uint32_t> st(MTN);
+            thread_local std::vector<uint32_t> st;
+            st.resize(MTN);
             mt_seed_state(st.data(), (uint64_t)seeds[k]);
             if (nblk <= CHB) {
-                Stager sg;
-                run_blocks(t, st.data(), 0, nblk, true, sg);
+                run_blocks(t, st.data(), 0, nblk, true, thread_stager());
                 return;
             }
             std::vector<EdgeChunk> mine;
@@ -408,9 +449,8 @@ extern "C" int gnnx_host_draw_edge_masks(int32_t T, const int32_t* n, const int6
         try {
             c10::InferenceMode ng;
             EdgeChunk& c = chunks[ci];
-            Stager sg;
             // (a regular chunk stops at its own last block - the entries of later blocks belong to later chunks; the tail chunk is the empty range)
-            run_blocks(tg[c.ti], c.start.data(), c.b0, c.b1, c.b0 == c.b1, sg);
+            run_blocks(tg[c.ti], c.start.data(), c.b0, c.b1, c.b0 == c.b1, thread_stager());
         } catch (const std::exception& e) {
             fail(e);
         }
