@@ -28,7 +28,10 @@ timeout 300 python bench.py --workload ba100k --targets 2048 --steps 5 --warmup 
 timeout 300 python bench.py --workload config4 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r04_bench_config4.json
 timeout 120 python tools/probe_att.py 2>/dev/null | grep -v Warning > $O/r04_method_att_syn1_400targets.txt
 timeout 120 python tools/probe_logging.py > $O/r04_loss_logging_explain_node.txt 2>&1
-timeout 400 python bench.py --workload ba100k --targets 16384 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r04_bench_ba100k_16384targets_full_draw.json
+# (when this script ran - sessions final_r04b / final_r04c - the full host draw was the pipeline's default; the block-granular edge draw is now:
+#  the first line below reproduces what was measured, the second is the new default, not yet measured on the GPU box)
+GNNX_PIPE_EDGE_DRAW=0 timeout 400 python bench.py --workload ba100k --targets 16384 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r04_bench_ba100k_16384targets_full_draw.json
+timeout 400 python bench.py --workload ba100k --targets 16384 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r04_bench_ba100k_16384targets.json
 for f in $O/r04_bench_*.json; do python -c "
 import json,sys; d=json.load(open('$f')); print('$f'.split('/')[-1], round(d['value']), round(d['ms_per_step'],3), 'loop', round(d.get('loop_only',{}).get('ms_per_step',0),3), d['roofline']['kernel'][:34], round(d['roofline']['frac'],4), d.get('parity',{}).get('rule','')[:80])" 2>/dev/null; done
 head -3 $O/r04_kernel_stats_syn1_loop_only.csv | cut -c1-200
