@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <condition_variable>
 #include <exception>
@@ -257,36 +258,93 @@ struct Stager {
     at::CPUGeneratorImpl* impl = at::check_generator<at::CPUGeneratorImpl>(gen);
     uint32_t words[1 + 16 * STAGE_SLOTS];
     float vals[16 * STAGE_SLOTS];
-    int slots = 0;
-    std::vector<std::pair<int, int64_t>> wants;     // (16 * slot + lane, index into out)
+    int pairs = 0;                                  // staged Box-Muller pairs: pair s sits in lanes (s % 8, s % 8 + 8) of synthetic block s / 8
+    std::vector<std::pair<int, int64_t>> wants;     // (index into vals, index into out)
     double std_ = 1.0;
     float* out = nullptr;
-    int add(const uint32_t* w16) {
-        std::memcpy(words + 1 + 16 * slots, w16, 16 * sizeof(uint32_t));
-        return slots++;
+    // The transform of a 16-value block works on the eight pairs (j, j + 8) independently - values j and j + 8 come from the uniforms j and
+    // j + 8 alone - and every lane computes the same function, so only the PAIR that holds a wanted value is staged, eight pairs of any
+    // blocks to a synthetic block: an eighth of the logarithms / sines / cosines of staging whole blocks.  (The bit-comparison against the
+    // full draw in tests/test_host_api.py covers every lane position.)
+    int add_pair(uint32_t a, uint32_t b) {
+        uint32_t* w = words + 1 + 16 * (pairs >> 3) + (pairs & 7);
+        w[0] = a;
+        w[8] = b;
+        return pairs++;
     }
+    bool full() const { return pairs == 8 * STAGE_SLOTS; }
+    // whole-block staging (the fallback when the host's normal_ should ever treat lanes differently - see pair_staging_ok): the eight pairs of a
+    // real block in their own lanes of one synthetic block; returns the synthetic block's first value index
+    int add_block(const uint32_t* w16) {
+        while (pairs & 7) add_pair(0u, 0u);
+        if (full()) flush();
+        const int base = 16 * (pairs >> 3);
+        for (int j = 0; j < 8; ++j) add_pair(w16[j], w16[j + 8]);
+        return base;
+    }
+    static int value_index(int pair, bool second) { return 16 * (pair >> 3) + (pair & 7) + (second ? 8 : 0); }
     void flush() {
-        if (!slots) return;
+        if (!pairs) return;
+        const int blocks = (pairs + 7) >> 3;
+        for (int s = pairs; s < 8 * blocks; ++s) {   // (unused lanes of the last synthetic block: any defined words - u = 0 gives radius 0)
+            words[1 + 16 * (s >> 3) + (s & 7)] = 0u;
+            words[1 + 16 * (s >> 3) + (s & 7) + 8] = 0u;
+        }
         at::mt19937 eng;
         at::mt19937_data_pod pod = eng.data();
         pod.seeded_ = true;
         pod.next_ = 1;
         pod.left_ = MTN;
-        std::memcpy(pod.state_.data() + 1, words + 1, sizeof(uint32_t) * 16 * (size_t)slots);
+        std::memcpy(pod.state_.data() + 1, words + 1, sizeof(uint32_t) * 16 * (size_t)blocks);
         eng.set_data(pod);
         impl->set_engine(eng);
         impl->set_next_float_normal_sample(std::optional<float>());
-        at::Tensor view = at::from_blob(vals, {(int64_t)16 * slots}, at::TensorOptions().dtype(at::kFloat));
-        view.normal_(1.0, std_, gen);       // 16 * slots >= 16 values, a multiple of 16: normal_fill, no redraw of a ragged tail
+        at::Tensor view = at::from_blob(vals, {(int64_t)16 * blocks}, at::TensorOptions().dtype(at::kFloat));
+        view.normal_(1.0, std_, gen);       // 16 * blocks >= 16 values, a multiple of 16: normal_fill, no redraw of a ragged tail
         for (const auto& w : wants) out[w.second] = vals[w.first];
         wants.clear();
-        slots = 0;
+        pairs = 0;
     }
 };
 // per worker thread: one staging engine (creating a generator per target cost as much as a small target's draw) and the merge scratch
 Stager& thread_stager() {
     thread_local Stager sg;
     return sg;
+}
+// Pair staging rests on one property of the host's normal_ beyond its documented structure: every lane of the 16-value transform computes
+// the same function of its own pair of uniforms.  Checked once per process on a fixed stream (pairs staged into OTHER lanes than their own
+// must reproduce ATen's one-call draw bit for bit); if it ever fails, whole blocks are staged in their own lanes instead (slower, no assumption).
+bool pair_staging_ok() {
+    static std::once_flag once;
+    static bool ok = false;
+    std::call_once(once, [] {
+        try {
+            c10::InferenceMode ng;
+            constexpr int NV = 96;
+            float ref[NV];
+            at::Generator gen = at::detail::createCPUGenerator(0);
+            gen.set_current_seed(20240923u);
+            at::Tensor view = at::from_blob(ref, {(int64_t)NV}, at::TensorOptions().dtype(at::kFloat));
+            view.normal_(1.0, 0.25, gen);
+            uint32_t st[MTN];
+            mt_seed_state(st, 20240923u);
+            mt_block_update(st);                       // the words of draws 0 .. 623
+            Stager sg;
+            float got[NV];
+            sg.std_ = 0.25;
+            sg.out = got;
+            for (int k = 0; k < NV; ++k) {             // positions in a scrambled order: a pair lands in another lane than its own
+                const int p = (k * 37 + 11) % NV, q = p / 16, lane = p % 16, j = lane & 7;
+                if (sg.full()) sg.flush();
+                sg.wants.emplace_back(Stager::value_index(sg.add_pair(st[16 * q + j], st[16 * q + j + 8]), lane >= 8), (int64_t)p);
+            }
+            sg.flush();
+            ok = std::memcmp(ref, got, sizeof ref) == 0;
+        } catch (...) {
+            ok = false;
+        }
+    });
+    return ok;
 }
 std::vector<std::pair<int64_t, int64_t>>& scratch_up() {
     thread_local std::vector<std::pair<int64_t, int64_t>> v;
@@ -311,6 +369,8 @@ extern "C" int gnnx_host_draw_edge_masks(int32_t T, const int32_t* n, const int6
     if (T == 0) return 0;
     threads = std::max(1, std::min<int32_t>(threads, 128));
     const int64_t CHB = std::max<int64_t>(1, 32 * std::max<int64_t>(1024, slice_values) / MTN);   // engine state blocks per work item
+    static const bool force_blocks = std::getenv("GNNX_HOST_STAGE_BLOCKS") != nullptr;             // (test knob: exercise the fallback)
+    const bool by_pairs = !force_blocks && pair_staging_ok();
     std::vector<EdgeTarget> tg;
     tg.reserve(T);
     for (int k = 0; k < T; ++k) {
@@ -343,12 +403,25 @@ extern "C" int gnnx_host_draw_edge_masks(int32_t T, const int32_t* n, const int6
         for (; b < b1; ++b) {
             mt_block_update(st);                                                 // st = the words of draws [624 b, 624 b + 624)
             const int64_t lim = std::min<int64_t>((b + 1) * MTN, t.reg_end);
+            int64_t last_key = -1;                                               // (block, pair) of the pair staged last: entries of one pair share it
+            int last_pair = 0;
+            while (!by_pairs && it != end && it->first < lim) {                  // fallback: whole blocks in their own lanes
+                const int64_t q16 = it->first / 16;
+                const int base = sg.add_block(st + (16 * q16 - b * MTN));
+                for (; it != end && it->first < 16 * q16 + 16 && it->first < t.reg_end; ++it)
+                    sg.wants.emplace_back(base + (int)(it->first - 16 * q16), it->second);
+            }
             while (it != end && it->first < lim) {
                 const int64_t q16 = it->first / 16;
-                const int slot = sg.add(st + (16 * q16 - b * MTN));
-                for (; it != end && it->first < 16 * q16 + 16 && it->first < t.reg_end; ++it)
-                    sg.wants.emplace_back(16 * slot + (int)(it->first - 16 * q16), it->second);
-                if (sg.slots == STAGE_SLOTS) sg.flush();
+                const int lane = (int)(it->first - 16 * q16), j = lane & 7;
+                if (8 * q16 + j != last_key) {
+                    if (sg.full()) sg.flush();
+                    const uint32_t* w = st + (16 * q16 - b * MTN);
+                    last_pair = sg.add_pair(w[j], w[j + 8]);
+                    last_key = 8 * q16 + j;
+                }
+                sg.wants.emplace_back(Stager::value_index(last_pair, lane >= 8), it->second);
+                ++it;
             }
         }
         if (last && t.reg_end != t.nn && it != end) {                            // entries among the last 16 values of a ragged stream: draws [nn, nn + 16)
@@ -361,8 +434,15 @@ extern "C" int gnnx_host_draw_edge_masks(int32_t T, const int32_t* n, const int6
                 mt_block_update(st);
                 std::memcpy(w16 + first, st, sizeof(uint32_t) * (16 - first));
             }
-            const int slot = sg.add(w16);
-            for (; it != end; ++it) sg.wants.emplace_back(16 * slot + (int)(it->first - (t.nn - 16)), it->second);
+            if (!by_pairs) {
+                const int base = sg.add_block(w16);
+                for (; it != end; ++it) sg.wants.emplace_back(base + (int)(it->first - (t.nn - 16)), it->second);
+            }
+            for (; it != end; ++it) {
+                const int lane = (int)(it->first - (t.nn - 16)), j = lane & 7;
+                if (sg.full()) sg.flush();
+                sg.wants.emplace_back(Stager::value_index(sg.add_pair(w16[j], w16[j + 8]), lane >= 8), it->second);
+            }
         }
         sg.flush();
     };

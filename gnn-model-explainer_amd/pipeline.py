@@ -53,7 +53,7 @@ class BatchPipeline:
         # slice of the stream that held an edge entry - all of them, for targets of thousands of nodes - so it cost what the full draw costs
         # (4.6 ns of one core per normal: 154 ms full vs 197 ms edges only on the GPU box's 16-core quota, profiles/r04_host_rng_edges_16384targets.txt)
         # and stayed off.  The block-granular form passes over the stream as engine STATE only (0.3 ns per draw) and lets ATen transform just the
-        # 16-value blocks that hold an entry (6.6 % of them on that set): 0.6 ns per normal of the stream, 560 -> 89-99 ms in the 8-core build
+        # 16-value blocks that hold an entry (6.6 % of them on that set): 0.4 ns per normal of the stream, 560 -> 57-66 ms in the 8-core build
         # container (profiles/r04_host_rng_edges_blocks.txt), bit-identical - ON by default; edge_draw=False / GNNX_PIPE_EDGE_DRAW=0 restores the
         # full stream.
         self.edge_draw = bool(int(os.environ.get("GNNX_PIPE_EDGE_DRAW", "1"))) if edge_draw is None else bool(edge_draw)

@@ -35,7 +35,8 @@ int gnnx_host_draw_masks_sliced(int32_t num_targets, const int32_t* n, const int
  * the edges are positions of one mt19937 stream per target, so the engine passes over the whole stream - as STATE only: ATen's normal_ is one
  * engine draw per value, then a Box-Muller transform of 16 values at a time, and 624 = 39 x 16, so a walker regenerates the raw state block by
  * block (no tempering, no transform), copies the 16 raw words of every block that holds an edge entry into a staged engine state, and ATen
- * itself draws 38 such blocks per normal_ call from it: bit-identical to the full draw by construction, at 0.6 instead of 4.6 ns per normal of
+ * itself draws them from it, 38 synthetic blocks per normal_ call (only the Box-Muller pair that holds a wanted value is staged, eight pairs
+ * to a synthetic block - checked once per process against ATen's own draw, whole blocks otherwise): bit-identical to the full draw by construction, at 0.4 instead of 4.6 ns per normal of
  * the stream, and only 2E values leave the host instead of sum(n^2) (12 MB instead of 4 GB for the 16 384-target BA-House x100k set).
  * slice_values: work-item length (large targets are cut into chunks of 32 * slice_values values from states a walker leaves behind). */
 int gnnx_host_draw_edge_masks(int32_t num_targets, const int32_t* n, const int64_t* seeds, const int64_t* eoff, const int32_t* rc, float* out,

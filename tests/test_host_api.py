@@ -167,6 +167,17 @@ def test_host_rng_library_draws_the_reference_masks_bit_for_bit():
         for threads, sl in ((1, 1024), (8, 1024), (5, 4096), (8, 1 << 17)):
             got = engine.init_edge_masks_on_edges(sizes, seeds, np.asarray(eoff), rc, threads=threads, slice_values=sl)
             assert torch.equal(got, want), (trial, threads, sl)
+    # the whole-block fallback of the edge draw (taken when the host's normal_ should ever treat the lanes of its transform differently; the
+    # switch is read once per process): the same bit-identity, in a child process
+    code = ("import os, sys, numpy as np, torch\nsys.path.insert(0, %r); sys.path.insert(0, %r)\nfrom gnn_model_explainer_amd import engine\n"
+            "sizes = [40, 33, 5, 57, 130]; seeds = 3000 + np.arange(5) * 5\nfull = engine.init_edge_masks_raw(sizes, seeds=seeds, threads=1)\n"
+            "off = np.concatenate([[0], np.cumsum(np.asarray(sizes, np.int64) ** 2)]); rng = np.random.default_rng(5); rcs, eoff = [], [0]\n"
+            "for n in sizes:\n    r, c = np.nonzero(np.triu(rng.random((n, n)) < 0.2, 1)); rcs.append(np.stack([r, c], 1).astype(np.int32)); eoff.append(eoff[-1] + len(r))\n"
+            "rc = np.concatenate(rcs)\nwant = torch.cat([torch.stack([full[off[k] + rcs[k][:, 0].astype(np.int64) * sizes[k] + rcs[k][:, 1]], full[off[k] + rcs[k][:, 1].astype(np.int64) * sizes[k] + rcs[k][:, 0]]], 1) for k in range(5)])\n"
+            "got = engine.init_edge_masks_on_edges(sizes, seeds, np.asarray(eoff), rc, threads=3, slice_values=1024)\nassert torch.equal(got, want)\nprint('fallback ok')\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    child = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, GNNX_HOST_STAGE_BLOCKS="1"))
+    assert child.returncode == 0 and "fallback ok" in child.stdout, child.stderr[-2000:]
     big = engine.init_edge_masks_raw([1500], seeds=[77], threads=8)          # 2.25 M values: sliced at the default length
     assert torch.equal(big, helpers.seeded_mask0(77 - 1000, 1500).flatten())
 
