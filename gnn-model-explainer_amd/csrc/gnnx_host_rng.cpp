@@ -14,6 +14,7 @@
 #include <functional>
 #include <mutex>
 #include <optional>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -214,10 +215,11 @@ extern "C" int gnnx_host_draw_masks_sliced(int32_t T, const int32_t* n, const in
     } else {
         std::lock_guard<std::mutex> lk(g_pool_mu);   // one batch at a time draws on the pool
         if (!g_pool || g_pool->size() < threads) g_pool = new Pool(std::max<int>(threads, 16));   // (an outgrown pool is leaked on purpose: its threads sleep)
-        if (parts1) g_pool->run(parts1, phase1);
+        // (limit = the caller's `threads`: the pool may hold more workers than this call was given - the ranks of a node share its cores)
+        if (parts1) g_pool->run(parts1, phase1, threads);
         for (auto& sl : slices)
             for (auto& x : sl) all.push_back(&x);
-        if (!failed && !all.empty()) g_pool->run((int)all.size(), phase2);
+        if (!failed && !all.empty()) g_pool->run((int)all.size(), phase2, threads);
     }
     if (failed) {
         g_err = err;
@@ -460,6 +462,9 @@ extern "C" int gnnx_host_draw_edge_masks(int32_t T, const int32_t* n, const int6
             // the entries (r, c) then ascend as they come, and the mirrored ones (c, r) ascend after a stable bucketing by column - two
             // sorted runs, merged.  Any other order falls back to the sort.
             const int64_t e0 = eoff[k], ne = eoff[k + 1] - eoff[k];
+            for (int64_t e = e0; e < e0 + ne; ++e)      // the ids index this target's n x n stream (and the bucket table below): check them
+                if (rc[2 * e] < 0 || rc[2 * e] >= nk || rc[2 * e + 1] < 0 || rc[2 * e + 1] >= nk)
+                    throw std::out_of_range("gnnx_host_draw_edge_masks: edge (r, c) outside its target's n x n block");
             bool row_major = true;
             for (int64_t e = e0 + 1; e < e0 + ne && row_major; ++e)
                 row_major = (int64_t)rc[2 * e - 2] * nk + rc[2 * e - 1] < (int64_t)rc[2 * e] * nk + rc[2 * e + 1];

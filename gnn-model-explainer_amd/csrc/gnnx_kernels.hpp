@@ -1252,7 +1252,8 @@ struct PackArgs {
     int32_t D;
     // by-products for the analysis that follows the packing (gnnx_pack_csr_analyze), both [R] or null: every row's off-diagonal
     // non-zeros (what k_row_degrees counts) and its upper-triangle non-zeros (k_edge_rowcount) - the packing places every entry of the
-    // row anyway, so two launches and two passes over A fall away.  (The CSR holds every (u, v) once: engine.device_graph sums duplicates.)
+    // row anyway, so two launches and two passes over A fall away.  (The CSR holds every (u, v) once - engine.device_graph sums duplicates; a
+    // hand-built CSR with sorted rows may repeat an entry: it is counted once, as it occupies one cell of A.)
     int32_t* rowdeg;
     int32_t* rowcnt;
 };
@@ -1288,8 +1289,11 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a, const ConvTile* tiles)
             if (nb[lo] == v) {
                 const float w = a.weights ? a.weights[e] : 1.0f;
                 Arow[lo] = w;
-                deg += (w != 0.0f && lo != i);
-                up += (w != 0.0f && lo > i);
+                // A repeated (u, v) lands in ONE cell of A, so it must count once: in a row with sorted indices (the precondition of
+                // gnnx_pack_csr; engine.device_graph canonicalises and sums duplicates) a repeat is adjacent to its first occurrence.
+                const bool rep = e > a.indptr[u] && a.indices[e - 1] == v;
+                deg += (!rep && w != 0.0f && lo != i);
+                up += (!rep && w != 0.0f && lo > i);
             }
         }
     }

@@ -571,6 +571,7 @@ class MaskOptimJob:
         for m, v, n in zip(masks, self._square_views(M), self.n):
             v[:n, :n] = m
         self.M.copy_(torch.from_numpy(M), non_blocking=False)
+        self._M_on_edges_only = False
 
     def set_masks_raw(self, raw: torch.Tensor):
         """Upload the initial edge masks as the host generator produced them - ONE contiguous n x n draw per target,
@@ -587,6 +588,7 @@ class MaskOptimJob:
             c["event"].record(torch.cuda.current_stream(self.device))
         self._enter()
         _check(self.lib, self.lib.gnnx_scatter_masks(self.handle, self._raw.data_ptr(), self.M.data_ptr(), self._stream()))
+        self._M_on_edges_only = False
         self._leave()
 
     def set_masks_on_edges(self, vals: torch.Tensor):
@@ -602,11 +604,13 @@ class MaskOptimJob:
         self.M.index_put_((pos[:, 0],), v[:, 0])
         self.M.index_put_((pos[:, 1],), v[:, 1])
         self._edge_vals0 = v
+        self._M_on_edges_only = True      # launch() refuses the kernels that read M off the edges
 
     def set_masks_raw_resident(self):
         """Reset M to the initial masks from the RNG stream uploaded by the last set_masks_raw (a device-only op)."""
         self._enter()
         _check(self.lib, self.lib.gnnx_scatter_masks(self.handle, self._raw.data_ptr(), self.M.data_ptr(), self._stream()))
+        self._M_on_edges_only = False
         self._leave()
 
     def _edge_layout(self):
@@ -740,14 +744,21 @@ class MaskOptimJob:
                 rs.m_out, rs.v_out, rs.feat_out = out.m.data_ptr(), out.v.data_ptr(), out.feat.data_ptr()
                 self.state_out = out
             self._state_keepalive = st
+        if getattr(self, "_M_on_edges_only", False) and (not hyper.use_resident or hyper.record_loss or
+                                                         not np.isin(self.route(), (4, 5, 6, 7, 8)).all()):
+            # set_masks_on_edges left every entry of M off the edges uninitialised: only the edge-sparse kernels may run on it
+            raise ValueError("this job's initial masks were given on the edges only (set_masks_on_edges): it needs the edge-sparse resident kernels "
+                             "(Hyper.use_resident, no loss logging, every target on routes 4-8)")
         self._enter()
-        _check(self.lib, self.lib.gnnx_run_resume(self.handle, ctypes.byref(hy), ctypes.byref(rs) if rs is not None else None,
-                                                  self.A.data_ptr(), self.X.data_ptr(), self.yhat.data_ptr(), self.M.data_ptr(),
-                                                  self.Abar.data_ptr(), self.fmask.data_ptr(), loss_ptr, self.ws.data_ptr(),
-                                                  self.ws_bytes, self._stream()))
+        try:
+            _check(self.lib, self.lib.gnnx_run_resume(self.handle, ctypes.byref(hy), ctypes.byref(rs) if rs is not None else None,
+                                                      self.A.data_ptr(), self.X.data_ptr(), self.yhat.data_ptr(), self.M.data_ptr(),
+                                                      self.Abar.data_ptr(), self.fmask.data_ptr(), loss_ptr, self.ws.data_ptr(),
+                                                      self.ws_bytes, self._stream()))
+        finally:
+            if trace:      # the handle must not keep the trace pointers when the run raised (later launches would fail or write into this buffer)
+                self.lib.gnnx_set_trace(self.handle, None, None)
         self._leave()
-        if trace:
-            _check(self.lib, self.lib.gnnx_set_trace(self.handle, None, None))
 
     def fetch_trace(self):
         """The decision trace of the last launch(trace=True): (gates, pool).  gates[k] = uint32 [iters, n_k, 2] for target k - bit c of

@@ -182,7 +182,10 @@ class BatchPipeline:
             # EDGES of its draw (gnnx_host_draw_edge_masks: 12 MB instead of 4 GB for the 16 384-target BA-House x100k set - no 4 GB of
             # pinned writes, H2D copy and scatter).  It needs the edge list first, so the draw follows the plan instead of overlapping it.
             total_values = int((dn.sizes.astype(np.int64) ** 2).sum())
-            edges_only = self.edge_draw and total_values > self.edge_draw_min_values and not self.hyper.record_loss
+            # (only when the resident kernels will really take the batch: with use_resident off the dense streaming kernels run, and those read
+            #  and update EVERY entry of M - ADVICE r4)
+            edges_only = (self.edge_draw and total_values > self.edge_draw_min_values and not self.hyper.record_loss and
+                          bool(self.hyper.use_resident))
             th = threading.Thread(target=draw)
             if not edges_only:
                 th.start()

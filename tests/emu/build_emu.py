@@ -18,15 +18,23 @@ def build(force=False):
             os.path.join(ROOT, "include", "gnnx.h"), os.path.join(CSRC, "gnnx_resident.hpp"),
             os.path.join(CSRC, "gnnx_sparse.hpp"), os.path.join(CSRC, "gnnx_sparse_large.hpp"),
             os.path.join(CSRC, "gnnx_graph.hpp"), os.path.join(CSRC, "gnnx_att.hpp")]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in srcs):
+    fresh = lambda: os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in srcs)
+    if not force and fresh():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cxx = "/opt/rocm/lib/llvm/bin/clang++"
-    if not os.path.exists(cxx):
-        cxx = "clang++"
-    cmd = [cxx, "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=on", "-Wno-psabi", "-I", os.path.join(HERE, "include"),
-           "-x", "c++", srcs[0], srcs[2], "-o", OUT]
-    subprocess.check_call(cmd)
+    import fcntl
+    with open(OUT + ".lock", "w") as lock:      # pytest-xdist workers: one of them builds, the others wait and find the library fresh
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and fresh():
+            return OUT
+        cxx = "/opt/rocm/lib/llvm/bin/clang++"
+        if not os.path.exists(cxx):
+            cxx = "clang++"
+        tmp = OUT + ".tmp%d" % os.getpid()
+        cmd = [cxx, "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=on", "-Wno-psabi", "-I", os.path.join(HERE, "include"),
+               "-x", "c++", srcs[0], srcs[2], "-o", tmp]
+        subprocess.check_call(cmd)
+        os.replace(tmp, OUT)      # never a half-written library under the final name
     return OUT
 
 

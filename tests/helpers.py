@@ -104,11 +104,11 @@ BRANCH_JUMP_MAX = 5e-3   # largest distance between two outcomes of one non-chao
 # activations are equal in exact arithmetic: which of them wins the max-pool is decided by the summation order of each
 # implementation - graph 2477 switches rows at epoch ~32 in the edge-sparse kernel while the dense streaming kernels stay with the
 # reference, both on the same GPU; tests/golden/debug_graph2477.py).
-# Round 3, 512 graphs instead of 64: a flipped max-pool tie followed by 250 more epochs moves single masks by up to 0.45, so the full
-# horizon carries no useful jump bound (masks live in [0, 1]); what replaces it is the requirement that EVERY miss has a window the
-# CPU-only analysis of make_golden_windows.py flags (test_gpu_full_configs.py) - and inside a window (50 / 10 epochs) the jump stays
-# below CONFIG4_WINDOW_JUMP (test_windowed_parity.py).
-CONFIG4_FULL_RULE = dict(min_frac=0.70, jump_max=1.0)
+# Round 3, 512 graphs instead of 64: a flipped max-pool tie followed by 250 more epochs moves single masks by up to 0.45 on graphs that are
+# NOT calm, so a percentage of graphs within 1e-5 says nothing in graph mode.  The full-horizon gate of config 4 is decision-based
+# (tests/test_decision_parity.py: every decision of every epoch against the live reference's; calm graphs bounded by CONFIG4_WINDOW_JUMP);
+# the outcome comparisons (test_gpu_full_configs.py, bench.py --workload config4) require that EVERY miss has a window the CPU-only
+# analysis of make_golden_windows.py flags.  (The 70 % rule of rounds 2-4 is gone.)
 CONFIG4_EARLY_RULE = dict(min_frac=0.95, jump_max=6e-2)
 CONFIG4_WINDOW_JUMP = 6e-2
 

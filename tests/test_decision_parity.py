@@ -296,7 +296,10 @@ def test_full_horizon_decisions_config4_gpu():
     d = np.abs(em.masked_adj.astype(np.float64) - z["vals"].astype(np.float64))
     err = np.asarray([d[a:b].max() if b > a else 0.0 for a, b in zip(W.eoff[:-1], W.eoff[1:])])
     ferr = np.abs(helpers._sig64(em.feat_mask) - z["feat_sig"].astype(np.float64)).max(1)
-    _full_horizon_verdict("config4", Dn, W.ids, np.maximum(err, ferr), gates, pool, _horizon_conditioning("config4", z["cond_mask"], z["cond_feat"]))
+    # (jump: the largest move of a graph under a 1-ulp perturbation of its initial mask over the full horizon, measured on the CPU alone by
+    #  make_golden_branches.py before any implementation ran - a calm graph that leaves at a pool tie must stay inside it)
+    _full_horizon_verdict("config4", Dn, W.ids, np.maximum(err, ferr), gates, pool, _horizon_conditioning("config4", z["cond_mask"], z["cond_feat"]),
+                          helpers.CONFIG4_WINDOW_JUMP)
 
 
 # ------------------------------------------------------------------ BASELINE config 5: BA-House x100k against the reference's own state ------------------------------------------------------------------
@@ -358,4 +361,4 @@ def test_windows_ba100k_route_stratified_targets_against_the_reference_gpu():
     bound = np.maximum(TOL, ROUNDOFF_BUDGET * np.asarray([o[4] for o in out]))
     print(f"ba100k (k_sparse_large, {len(big_k)} targets, n = {int(z['size'][big_k].min())} ... {int(z['size'][big_k].max())}): {len(out)} windows against the reference's state, "
           f"{int((err <= TOL).sum())} within 1e-5, worst {err.max():.2e}; beyond 1e-5: {[o for o in out if o[3] > TOL][:20]}")
-    assert (err <= np.maximum(bound, TOL)).mean() >= 0.97 and err.max() <= helpers.BRANCH_JUMP_MAX, [o for o in out if o[3] > TOL]
+    assert (err <= np.maximum(bound, TOL)).all(), [o for o in out if o[3] > TOL]      # every window (measured: 126 / 126 within 1e-5, worst 9.1e-7)

@@ -160,17 +160,21 @@ def test_config4_graph_mode_512_of_4337_graphs_vs_reference():
     assert set(route) <= {5, 6}, set(route)                      # the graph-mode classes of the sparse resident kernel
     sub8 = allk[::8]
     e_dense, route_d = run(sub8, False, False)
-    ok, msg = helpers.parity_verdict(e_sparse, e_sparse, well, **helpers.CONFIG4_FULL_RULE)
+    # No percentage rule (VERDICT r4 #4b): the full-horizon GATE of graph mode is decision-based (test_decision_parity.py); what this test
+    # asserts about OUTCOMES is that every miss on a graph two CPU implementations agree on has a window the CPU-only analysis flags - for the
+    # edge-sparse route and, independently, for the dense streaming route on every eighth graph.
+    inside = int((e_sparse[well] <= TOL).sum())
     miss = np.nonzero(well & (e_sparse > TOL))[0]
     unexplained = [int(gids[k]) for k in miss if not W.flagged[k].any()]
     wd = well[sub8]
-    print(f"config4 [full, 512 graphs]: {msg}; misses {len(miss)}, of which {len(miss) - len(unexplained)} have a flagged window on the CPU, unexplained: "
+    miss_d = [int(k) for k in sub8[wd & (e_dense > TOL)]]
+    unexplained_d = [int(gids[k]) for k in miss_d if not W.flagged[k].any()]
+    print(f"config4 [full, 512 graphs]: {inside} / {int(well.sum())} non-chaotic graphs within 1e-5 of the reference's output, worst {float(e_sparse[well].max()):.2e}; "
+          f"misses {len(miss)}, of which {len(miss) - len(unexplained)} have a flagged window on the CPU, unexplained: "
           f"{unexplained}; dense streaming route on {len(sub8)} graphs: {int((e_dense[wd] <= TOL).sum())} / {int(wd.sum())} non-chaotic within 1e-5 "
-          f"(sparse route on the same graphs: {int((e_sparse[sub8][wd] <= TOL).sum())})")
-    assert ok, msg
+          f"(sparse route on the same graphs: {int((e_sparse[sub8][wd] <= TOL).sum())}), its misses without a flagged window: {unexplained_d}")
     assert not unexplained, unexplained
-    # the two routes are independent implementations of the same mathematics: both must do comparably well against the reference
-    assert (e_dense[wd] <= TOL).sum() >= 0.6 * wd.sum()
+    assert not unexplained_d, unexplained_d
 
 
 def test_config4_64_graphs_against_the_reference_outcome_sets():

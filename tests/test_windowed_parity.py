@@ -226,7 +226,7 @@ def test_windows_config4_512_graphs_gpu():
         job = MaskOptimJob(subs, sd, graph_mode=True)
         job.set_masks([s.mask0 for s in subs])
         return job
-    # graph mode: a max-pool tie that flips moves the mask by up to 6e-2 (helpers.CONFIG4_FULL_RULE, measured on the CPU in round 2)
+    # graph mode: a max-pool tie that flips moves the mask by up to 6e-2 (helpers.CONFIG4_WINDOW_JUMP, measured on the CPU in round 2)
     _windows_of_job(W, make, np.arange(W.T), "config4", bound=helpers.CONFIG4_WINDOW_JUMP)
 
 

@@ -57,8 +57,9 @@ def main():
         fs = 1.0 / (1.0 + np.exp(-em.feat_mask[gids].astype(np.float64)))
         err, ferr, matched = helpers.branch_errors(z, helpers.load_branches("config4"), eoff, vals, fs)
         well = (z["cond_mask"] <= helpers.WELL) & (z["cond_feat"] <= helpers.WELL)
-        ok, msg = helpers.parity_verdict(err, ferr, well, **helpers.CONFIG4_FULL_RULE)
-        out["parity"] = {"graphs_checked": int(len(gids)), "rule": msg, "ok": bool(ok)}
+        e = np.maximum(err, ferr)
+        out["parity"] = {"graphs_checked": int(len(gids)), "non_chaotic": int(well.sum()), "within_1e-5": int((well & (e <= 1e-5)).sum()),
+                         "note": "reported only: the gate of graph mode is decision-based (tests/test_decision_parity.py)"}
     print(json.dumps(out))
 
 
