@@ -332,7 +332,7 @@ def _noop(_):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--iters", type=int, default=300)
     ap.add_argument("--workload", default=None, choices=["syn1", "ba100k", "syn4", "syn5", "config4"],
@@ -403,19 +403,40 @@ def main():
             t_r = time.perf_counter()
             box["raw"] = engine.init_edge_masks_raw(dn.sizes, seeds=1000 + targets, pin=True, threads=rng_threads)
             box["ms"] = (time.perf_counter() - t_r) * 1e3
+        # large batches on the edge-sparse kernels (what pipeline.BatchPipeline does too): the engine of the seeded draw walks on the device, the
+        # host transforms the word pairs of the edge entries only (gnnx_mt_edge_words + gnnx_host_transform_edge_words)
+        edges_path = (float((dn.sizes.astype(np.float64) ** 2).sum()) > 2e7 and not args.no_resident and engine.pair_staging_ok()
+                      and os.environ.get("GNNX_PIPE_EDGE_DRAW", "1") != "0" and os.environ.get("GNNX_PIPE_DEVICE_WALK", "1") != "0")
         t0 = time.perf_counter()
         th = threading.Thread(target=draw)
-        th.start()
+        if not edges_path:
+            th.start()
         job = MaskOptimJob.from_csr(graph, dn, None, wl.label[targets], wl.ck["sd"])
         torch.cuda.synchronize()
         tm["plan_pack_analyze_ms"] = (time.perf_counter() - t0) * 1e3
-        th.join()
-        raw = box["raw"]
+        if edges_path and not np.isin(job.route(), (4, 5, 6, 7, 8)).all():
+            edges_path = False
+            th.start()
         tm["host_rng_threads"] = rng_threads
-        tm["host_rng_ms"] = box["ms"]
-        tm["plan_and_rng_overlapped_ms"] = (time.perf_counter() - t0) * 1e3
-        t0 = time.perf_counter()
-        job.set_masks_raw(raw)
+        if edges_path:
+            t1 = time.perf_counter()
+            words = job.draw_edge_words_device(1000 + targets)
+            E_ = int(job._eoff[-1])
+            words_h = words.cpu()
+            tm["device_walk_ms"] = (time.perf_counter() - t1) * 1e3
+            t1 = time.perf_counter()
+            vals = engine.transform_edge_words(dn.sizes, 1000 + targets, job._eoff, job._rc[:E_].cpu().numpy(), words_h, threads=rng_threads)
+            tm["host_rng_ms"] = tm["host_transform_ms"] = (time.perf_counter() - t1) * 1e3
+            tm["plan_and_rng_overlapped_ms"] = (time.perf_counter() - t0) * 1e3
+            t0 = time.perf_counter()
+            job.set_masks_on_edges(vals)
+        else:
+            th.join()
+            raw = box["raw"]
+            tm["host_rng_ms"] = box["ms"]
+            tm["plan_and_rng_overlapped_ms"] = (time.perf_counter() - t0) * 1e3
+            t0 = time.perf_counter()
+            job.set_masks_raw(raw)
         torch.cuda.synchronize()
         tm["mask_h2d_scatter_ms"] = (time.perf_counter() - t0) * 1e3
         if timings is not None:
@@ -472,7 +493,7 @@ def main():
 
     def step():
         job = jobs[0]
-        job.set_masks_raw_resident()          # device op: re-spread the resident RNG stream over the padded masks
+        job.reset_masks()                     # device op: re-spread the resident RNG stream over the padded masks / the resident edge values over M
         job.launch(hy)
         if dist is not None:                  # the masks of every rank, as edge entries, on every rank (RCCL over xGMI)
             vals = job.gather_edges_device()
@@ -658,7 +679,7 @@ def main():
                                      "avg_launch_us": {nm: x[0] * 1e3 for nm, x in zip(names, per)}}
         rts = []
         for _ in range(5):
-            job.set_masks_raw_resident()
+            job.reset_masks()
             job.launch(hy)
             torch.cuda.synchronize()
             rts.append(job.resident_times())
@@ -666,11 +687,17 @@ def main():
         res_names = {1: "k_resident<1>", 4: "k_sparse_resident<.., 1024>", 5: "k_sparse_resident<.., 256>", 6: "k_sparse_resident<.., 64>",
                      7: "k_sparse_large", 8: "k_sparse_resident<.., 512>"}
         res_ms = {1: rt[0], 4: rt[3], 5: rt[4], 6: rt[5], 7: rt[6], 8: rt[7]}
-        mixed = bool((route == 6).any() and (route == 8).any() and not rt[5] and rt[7])   # one launch for both groups
+        # ONE launch (k_sparse_resident_mixed) for the 512-thread targets, the single-tile targets (eight per workgroup) and - "pair" workgroups,
+        # round 5 - the 256-thread targets two to a workgroup: it is timed in the slot of the class that starts it (512 threads, else 256)
+        pairs = bool((route == 5).any() and ((rt[7] and not rt[4]) or (rt[4] and not rt[5] and (route == 6).any() and not (route == 8).any())))
+        mixed = bool(((route == 6).any() and (route == 8).any() and not rt[5] and rt[7]) or pairs)
+        mixed_rv = 8 if rt[7] else 5
         tiny_per_wg = 8 if (job.D + 2 * job.H) * 33 + job.C * 96 >= 1658 else 6   # sp_mix_tiny() of gnnx_sparse.hpp
         if mixed:
-            res_names[8] = f"k_sparse_resident_mixed (512-thread targets + {tiny_per_wg} single-tile targets per workgroup)"
-        sel_of = {rv: ((route == 8) | (route == 6)) if (mixed and rv == 8) else (route == rv) for rv in res_ms}
+            res_names[mixed_rv] = (f"k_sparse_resident_mixed (512-thread targets" + (", 256-thread targets two per workgroup" if pairs else "") +
+                                   f" + {tiny_per_wg} single-tile targets per workgroup)")
+        in_mixed = (route == 8) | (route == 6) | ((route == 5) if pairs else np.zeros(len(route), bool))
+        sel_of = {rv: in_mixed if (mixed and rv == mixed_rv) else (route == rv) for rv in res_ms}
         for rv, ms_v in res_ms.items():
             if ms_v:
                 launches[res_names[rv]] = {"targets": int(sel_of[rv].sum()), "ms_total": ms_v}
@@ -709,12 +736,14 @@ def main():
                 by = wm.executed_lds_bytes_per_iter(Ssel, job.D, job.H, job.H, job.C, xc, large=large)
                 ops = wm.chain_ops_per_iter(Ssel, job.D, job.H, job.H, job.C, xc, large=large)
                 ch = wm.chain_ns_per_iter(ops, lat)
-                if mixed and rv == 8:      # workgroups [0, n_big): one 512-thread target each; then tiny_per_wg single-tile targets per workgroup
+                if mixed and rv == mixed_rv:      # workgroups [0, n_big): one 512-thread target each; then two 256-thread targets each; then tiny_per_wg single-tile targets each
                     r_sel = route[idx]
                     wg = np.zeros(len(idx), np.int64)
                     nb = int((r_sel == 8).sum())
                     wg[r_sel == 8] = np.arange(nb)
-                    wg[r_sel == 6] = nb + np.arange(int((r_sel == 6).sum())) // tiny_per_wg
+                    np_ = int((r_sel == 5).sum())
+                    wg[r_sel == 5] = nb + np.arange(np_) // 2
+                    wg[r_sel == 6] = nb + (np_ + 1) // 2 + np.arange(int((r_sel == 6).sum())) // tiny_per_wg
                 else:
                     wg = np.arange(len(idx))
                 b = wm.launch_bounds(fl, by, ch, args.iters, wg, wgs_per_cu.get(rv, 1))

@@ -280,6 +280,7 @@ struct gnnx_plan_s {
                                      // 0 general form, 1 the general form's products without the gathers (bit-identical), 2 the algebraic form
     std::vector<int32_t> nnz;        // per target (directed edge entries, row slots) from gnnx_plan_analyze, empty before
     int n_sp[N_SPC] = {};            // targets of the sparse resident kernel, per size class (1024 / 256 / 64 threads)
+    bool pair256 = false;            // the 256-thread class runs two targets to a 512-thread workgroup of the mixed launch (gnnx_plan_analyze)
     int32_t* d_sp[N_SPC] = {};
     int n_sparse() const { return n_sp[0] + n_sp[1] + n_sp[2] + n_sp[3] + n_sp[4]; }
     int32_t* d_nnz = nullptr;
@@ -1225,6 +1226,7 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
             }
         }
         HIPCK(hipEventRecord(h->ev_in, s));
+        for (int k = 0; k < N_SIDE; ++k) h->launched[k] = false;      // (which groups launch can change between runs: a class may ride in the mixed launch)
         // Launch order: sparse resident kernel (gnnx_plan_analyze), largest size class FIRST - its workgroups need a whole
         // CU (1024 threads x 128 VGPRs), so they must be placed before the small workgroups of the other launches spread
         // over every CU (measured on syn1: 21.5 -> 13.4 ms) - then the dense resident kernels.  Every group has its own
@@ -1236,12 +1238,16 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
         // three optimisations going: a syn1 batch fills 141 of 256 CUs and lasts as long as its slowest workgroup) do not queue behind each
         // other on one stream; a run with several groups still takes consecutive lanes from there
         // node-mode batches of 512-thread and single-tile (64-thread class) targets: ONE launch (k_sparse_resident_mixed)
-        const bool mixed = !h->prob.graph_mode && h->n_sp[SPC_512] > 0 && h->n_sp[2] > 0;
+        // (with pair workgroups the 256-thread class rides in the same launch, two targets to a workgroup: h->pair256)
+        const bool pairs = !h->prob.graph_mode && h->pair256 && h->n_sp[1] > 0;
+        const bool mixed = !h->prob.graph_mode && ((h->n_sp[SPC_512] > 0 && h->n_sp[2] > 0) || pairs);
+        const int mixed_at = !mixed ? -1 : h->n_sp[SPC_512] > 0 ? SPC_512 : pairs ? 1 : 2;     // the class whose turn in the launch order starts the mixed launch
+        auto own_launch = [&](int k) { return h->n_sp[k] > 0 && (!mixed || k == mixed_at || !(k == 2 || k == SPC_512 || (pairs && k == 1))); };
         // A run whose targets all sit in ONE launch group (syn1 / syn4 / syn5: the mixed launch; config 4: the 256-thread class) needs no
         // side lane at all - nothing has to overlap inside the run: it goes to the caller's stream.  Fewer busy streams = fewer
         // hardware queues (HIP has eight at most) for the streams of a pipelined job to collide with.
         int n_groups = 0;
-        for (int k = 0; k < N_SPC; ++k) n_groups += (h->n_sp[k] > 0 && !(mixed && k == 2));
+        for (int k = 0; k < N_SPC; ++k) n_groups += own_launch(k);
         for (int nb = 1; nb <= RES_NBMAX; ++nb) n_groups += h->res_count[nb] > 0;
         const bool single_group = n_groups == 1 && !streaming;
         static std::atomic<unsigned> g_lane_base{0};
@@ -1254,30 +1260,32 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
         const int launch_order[N_SPC] = {SPC_LARGE, 0, SPC_512, 1, 2};   // the longest workgroups first, then the other whole-CU ones
         for (int ko = 0; ko < N_SPC; ++ko) {
             const int k = launch_order[ko];
-            if (!h->n_sp[k] || (mixed && k == 2)) continue;
-            const int g = RES_NBMAX + k;
+            if (!own_launch(k)) continue;
+            const int g = RES_NBMAX + k;      // (the mixed launch is timed in the slot of the class that starts it: 512 threads, else 256)
             hipStream_t ss = group_stream(g);
             if (ss != s) HIPCK(hipStreamWaitEvent(ss, h->ev_in, 0));
             HIPCK(hipEventRecord(h->ev_t0[g], ss));
             h->launched[g] = true;
-            if (mixed && k == SPC_512) {
+            if (mixed && k == mixed_at) {
                 const int per_wg = sp_mix_tiny(h->prob.D, h->prob.H, h->prob.C);   // single-tile targets per workgroup
-                const dim3 grid(h->n_sp[SPC_512] + (h->n_sp[2] + per_wg - 1) / per_wg), block(512);
+                const int n_pair = pairs ? h->n_sp[1] : 0;
+                const int32_t* pair_ids = pairs ? h->d_sp[1] : nullptr;
+                const dim3 grid(h->n_sp[SPC_512] + (n_pair + 1) / 2 + (h->n_sp[2] + per_wg - 1) / per_wg), block(512);
                 if (log_resident)
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, 0, true>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
-                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C));
+                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
                 else if (exact_shape(h, 10) && h->xconst == 2)
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, 2>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
-                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C));
+                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
                 else if (exact_shape(h, 10) && h->xconst == 1)
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, 1>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
-                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C));
+                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
                 else if (exact_shape(h, 10))
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
-                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C));
+                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
                 else
                     hipLaunchKernelGGL((k_sparse_resident_mixed<16, 16>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
-                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C));
+                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
             } else {
                 launch_sparse(h, p, k, h->d_adam, ss, log_resident);
             }
@@ -1460,12 +1468,33 @@ static int analyze_impl(gnnx_handle h, const float* A, const float* X, hipStream
         has_large |= (new_cat[t] == CAT_SPARSE || new_cat[t] == CAT_SPARSE + SPC_512);
         has_1024 |= (new_cat[t] == CAT_SPARSE);
     }
-    int mix_on = 1;
+    int mix_on = 1, pair_on = 1;
     if (const char* env = std::getenv("GNNX_SPARSE_MIXED")) mix_on = std::atoi(env);
+    if (const char* env = std::getenv("GNNX_PAIR_256")) pair_on = std::atoi(env);
+    // Throughput regime: with more big workgroups than the chip has CUs nothing needs to overlap - every launch fills the
+    // GPU by itself - and what counts is workgroups per CU: a 256-thread target (n <= 128) then keeps its own class (two per
+    // CU, 72 KB of LDS each) instead of taking a whole CU as a 512-thread workgroup.  Measured on the BA-House x100k set:
+    // see DESIGN.md.  GNNX_KEEP_256 = 0 / 1 overrides.
+    int n_bigwg = 0, n256 = 0, n64 = 0;
+    for (int t = 0; t < T; ++t) {
+        n_bigwg += (new_cat[t] == CAT_SPARSE || new_cat[t] == CAT_SPARSE + 1 || new_cat[t] == CAT_SPARSE + SPC_512);
+        n256 += new_cat[t] == CAT_SPARSE + 1;
+        n64 += new_cat[t] == CAT_SPARSE + 2;
+    }
+    bool keep256 = n_bigwg > 2 * 256;
+    if (const char* env = std::getenv("GNNX_KEEP_256")) keep256 = std::atoi(env) != 0;
+    // Pair workgroups (round 5; k_sparse_resident_mixed): below that regime the 256-thread targets of a node-mode batch stay in their class and
+    // run TWO to a 512-thread workgroup of the mixed launch instead of one each (GNNX_PAIR_256=0: the round-4 behaviour).  A batch without
+    // larger targets (syn4, syn5) pairs them when all its workgroups then fit the chip at once - the condition of the round-4 merge below.
+    bool pair256 = false;
+    if (!graph && mix_on && pair_on && tiny_on && c512_on && !has_1024 && !keep256 && n256 > 0) {
+        const int per_wg = sp_mix_tiny(h->prob.D, h->prob.H, h->prob.C);
+        pair256 = has_large || (n64 > 0 && (n256 + 1) / 2 + (n64 + per_wg - 1) / per_wg <= 256);
+    }
     // Node-mode batches of 256-thread and single-tile targets only (syn4, syn5): when all their workgroups fit the chip at
     // once, the 256-thread targets take the 512-thread class and the batch becomes ONE mixed launch - as fast as the two
     // small-class launches when those overlap (3.5 vs 3.6 ms on syn5) and not at the mercy of the queues when they do not (6.3 ms).
-    if (!graph && mix_on && tiny_on && c512_on && !has_large) {
+    if (!graph && mix_on && tiny_on && c512_on && !has_large && !pair256) {
         int n1 = 0, n2 = 0;
         bool all_fit = true;
         for (int t = 0; t < T; ++t) {
@@ -1485,18 +1514,11 @@ static int analyze_impl(gnnx_handle h, const float* A, const float* X, hipStream
     }
     // ... unless the big targets all take the 512-thread class: then they and the single-tile targets (64-thread code path,
     // eight per workgroup) share ONE launch, k_sparse_resident_mixed, and nothing needs to overlap
-    const bool mixable = !graph && mix_on && tiny_on && has_large && !has_1024;
-    // Throughput regime: with more big workgroups than the chip has CUs nothing needs to overlap - every launch fills the
-    // GPU by itself - and what counts is workgroups per CU: a 256-thread target (n <= 128) then keeps its own class (two per
-    // CU, 72 KB of LDS each) instead of taking a whole CU as a 512-thread workgroup.  Measured on the BA-House x100k set:
-    // see DESIGN.md.  GNNX_KEEP_256 = 0 / 1 overrides.
-    int n_bigwg = 0;
-    for (int t = 0; t < T; ++t) n_bigwg += (new_cat[t] == CAT_SPARSE || new_cat[t] == CAT_SPARSE + 1 || new_cat[t] == CAT_SPARSE + SPC_512);
-    bool keep256 = n_bigwg > 2 * 256;
-    if (const char* env = std::getenv("GNNX_KEEP_256")) keep256 = std::atoi(env) != 0;
-    if (has_large)
+    const bool mixable = !graph && mix_on && tiny_on && (has_large || pair256) && !has_1024;
+    h->pair256 = pair256;
+    if (has_large || pair256)
         for (int t = 0; t < T; ++t) {
-            if (new_cat[t] == CAT_SPARSE + 1 && !keep256) {  // a 256-thread target in such a batch joins the 512-thread class (else the 1024 one)
+            if (new_cat[t] == CAT_SPARSE + 1 && !keep256 && !pair256) {  // a 256-thread target in such a batch joins the 512-thread class (else the 1024 one)
                 const TargetMeta& m = h->meta[t];
                 const int* lg = &h->nnz[2 * (size_t)T + SPL_COUNTS * (size_t)t];
                 const bool f512 = !graph && c512_on && lg[0] >= 0 &&
@@ -1723,6 +1745,20 @@ extern "C" int gnnx_gather_values(const int64_t* epos, int64_t num_edges, const 
     hipLaunchKernelGGL(k_gather_values, dim3((unsigned)((num_edges + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), epos,
                        num_edges, Abar, M, abar, m_rc);
     HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gnnx_mt_edge_words(gnnx_handle h, const int64_t* seeds, const int64_t* eoff, const int32_t* rc, uint32_t* scratch, uint32_t* words,
+                                  void* stream) {
+    if (!h || !seeds || !eoff || !rc || !scratch || !words) return fail("null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc_ = use_tables(h, s, false)) return rc_;
+    const int T = h->prob.num_targets;
+    if (T == 0) return 0;
+    hipLaunchKernelGGL(k_mt_stream, dim3(T), dim3(256), 0, s, h->d_meta, seeds, scratch);
+    hipLaunchKernelGGL(k_mt_gather_pairs, dim3(T), dim3(256), 0, s, h->d_meta, eoff, rc, scratch, words);
+    HIPCK(hipGetLastError());
+    mark_busy(h, s);
     return 0;
 }
 

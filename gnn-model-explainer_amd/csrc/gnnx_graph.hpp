@@ -254,6 +254,91 @@ __global__ __launch_bounds__(256) void k_gather_values(const int64_t* epos, int6
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The seeded initial masks without the host walking their streams (round 5).  construct_edge_mask draws the n x n mask of a target with
+// ONE normal_ call from a torch CPU generator seeded per target (explain.py:645-652; the seed protocol of the golden runs), and the
+// edge-sparse kernels read that draw on the EDGES only.  ATen's normal_ of >= 16 values (normal_fill) is one 32-bit engine draw per value
+// followed by a Box-Muller transform of the pairs (j, j + 8) of every 16 values (and, for a ragged stream, a redraw of the last 16 values
+// from the 16 draws that follow the fill).  The transform cannot be restated on a device bit for bit (DESIGN: it is whatever libm the
+// host's ATen build calls), but the ENGINE is plain integer arithmetic: mt19937, whose state after d draws is the seeded state after
+// ceil(d / 624) block updates.  So the device walks every target's engine (k_mt_stream: one workgroup per target, the 624-word state in
+// LDS, a block update = three data-parallel sweeps - words [0, 227) depend on the old block only, [227, 454) on those, [454, 624) on
+// those) and writes the RAW state words of draws [0, n^2 (+ 16)) into the target's block of a scratch array (the Abar array: unused
+// before the run); k_mt_gather_pairs then picks, for every directed edge entry, the two words of its Box-Muller pair; only those
+// 16 bytes per entry cross PCIe, and the host lets ATen temper and transform exactly them (gnnx_host_transform_edge_words: the pair
+// staging of gnnx_host_draw_edge_masks).  Per 16 384-target BA-House x100k batch the host walked 1.0e9 draws (0.4 core-seconds, what
+// made eight ranks of a node host-bound on a 16-core quota); now it transforms 8 M pairs.
+// ---------------------------------------------------------------------------------------------
+constexpr int MT_N = 624, MT_M = 397;
+__device__ __forceinline__ uint32_t mt_twist(uint32_t u, uint32_t v) {
+    return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
+}
+// stream[offQ[t] + d] = raw state word of draw d of target t's engine, d < n^2 (+ 16 when n^2 is not a multiple of 16: the draws of the
+// redrawn tail); targets with fewer than 16 values are left to the host (ATen's scalar path).  seeds [T] int64 (at::mt19937(seed): the low 32 bits).
+__global__ __launch_bounds__(256) void k_mt_stream(const TargetMeta* meta, const int64_t* seeds, uint32_t* stream) {
+    __shared__ uint32_t st[2][MT_N];
+    const TargetMeta tm = meta[blockIdx.x];
+    const int tid = threadIdx.x;
+    const long long nn = (long long)tm.n * tm.n;
+    if (nn < 16) return;
+    const long long total = nn + ((nn & 15) ? 16 : 0);
+    if (tid == 0) {   // at::mt19937::init_with_uint32
+        uint32_t x = (uint32_t)((unsigned long long)seeds[blockIdx.x] & 0xffffffffull);
+        st[0][0] = x;
+        for (int j = 1; j < MT_N; ++j) {
+            x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)j;
+            st[0][j] = x;
+        }
+    }
+    __syncthreads();
+    uint32_t* out = stream + tm.offQ;
+    int cur = 0;
+    for (long long d0 = 0; d0 < total; d0 += MT_N) {
+        const uint32_t* o = st[cur];
+        uint32_t* nw = st[cur ^ 1];
+        // next_state of MT19937RNGEngine.h (the host's mt_block_update), old block -> new block
+        if (tid < MT_N - MT_M) nw[tid] = o[tid + MT_M] ^ mt_twist(o[tid], o[tid + 1]);
+        __syncthreads();
+        if (tid < MT_N - MT_M) {
+            const int k = tid + (MT_N - MT_M);
+            nw[k] = nw[k - (MT_N - MT_M)] ^ mt_twist(o[k], o[k + 1]);
+        }
+        __syncthreads();
+        if (tid < MT_N - 2 * (MT_N - MT_M)) {
+            const int k = tid + 2 * (MT_N - MT_M);      // 454 .. 623
+            nw[k] = nw[k - (MT_N - MT_M)] ^ mt_twist(o[k], k + 1 < MT_N ? o[k + 1] : nw[0]);
+        }
+        __syncthreads();
+        cur ^= 1;
+        for (int k = tid; k < MT_N; k += 256)
+            if (d0 + k < total) out[d0 + k] = nw[k];
+    }
+}
+
+// words[e] = {w(j), w(j + 8)} of entry (r, c), then of entry (c, r), for every upper-triangle edge e of the batch (rc [E][2], eoff [T + 1]):
+// the raw words of the Box-Muller pair that holds the entry's value - pair j = lane & 7 of the 16 values around position p = r n + c, or
+// of the redrawn tail (draws [n^2, n^2 + 16)) for the last 16 positions of a ragged stream.  One workgroup per target.
+__global__ __launch_bounds__(256) void k_mt_gather_pairs(const TargetMeta* meta, const int64_t* eoff, const int32_t* rc, const uint32_t* stream,
+                                                         uint32_t* words) {
+    const TargetMeta tm = meta[blockIdx.x];
+    const long long n = tm.n, nn = n * n;
+    if (nn < 16) return;
+    const long long reg_end = (nn & 15) ? nn - 16 : nn;
+    const uint32_t* src = stream + tm.offQ;
+    for (long long e = eoff[blockIdx.x] + threadIdx.x; e < eoff[blockIdx.x + 1]; e += 256) {
+        const long long r = rc[2 * e], c = rc[2 * e + 1];
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            const long long p = dir ? c * n + r : r * n + c;
+            const long long base = p < reg_end ? (p & ~15ll) : nn;
+            const int lane = (int)(p < reg_end ? (p & 15) : p - (nn - 16));
+            words[4 * e + 2 * dir] = src[base + (lane & 7)];
+            words[4 * e + 2 * dir + 1] = src[base + (lane & 7) + 8];
+        }
+    }
+}
+
 }  // namespace gnnx
 
 namespace gnnx {

@@ -561,3 +561,93 @@ extern "C" int gnnx_host_draw_edge_masks(int32_t T, const int32_t* n, const int6
     }
     return 0;
 }
+
+extern "C" int gnnx_host_pair_staging_ok(void) { return pair_staging_ok() ? 1 : 0; }
+
+// The values on the edges from the raw engine words the device picked (gnnx_mt_edge_words: k_mt_stream walks every target's mt19937 on the
+// GPU, k_mt_gather_pairs picks the two words of each entry's Box-Muller pair).  What is left for the host is what only the host can do
+// bit for bit - ATen's tempering + transform of exactly those pairs: the pair staging of gnnx_host_draw_edge_masks without its walk, O(E)
+// instead of O(sum n^2).  Work items = runs of targets of about 64 K entries; one Stager flush per target (the standard deviation is the
+// target's).  Targets of fewer than 16 values are drawn whole from their seed (ATen's scalar path, as there).
+extern "C" int gnnx_host_transform_edge_words(int32_t T, const int32_t* n, const int64_t* seeds, const int64_t* eoff, const int32_t* rc,
+                                              const uint32_t* words, float* out, int32_t threads) {
+    if (T < 0 || (T > 0 && (!n || !seeds || !eoff || !rc || !words || !out))) {
+        g_err = "null argument";
+        return 1;
+    }
+    if (T == 0) return 0;
+    if (!pair_staging_ok()) {
+        g_err = "the host's normal_ does not have the pair-staging property: use gnnx_host_draw_edge_masks";
+        return 1;
+    }
+    threads = std::max(1, std::min<int32_t>(threads, 128));
+    std::vector<std::pair<int, int>> items;      // [first target, last target) per work item
+    {
+        const int64_t per = 65536;
+        int a = 0;
+        while (a < T) {
+            int b = a + 1;
+            while (b < T && eoff[b] - eoff[a] < per) ++b;
+            items.emplace_back(a, b);
+            a = b;
+        }
+    }
+    std::atomic<bool> failed{false};
+    std::string err;
+    std::mutex err_mu;
+    auto work = [&](int it) {
+        try {
+            c10::InferenceMode ng;
+            Stager& sg = thread_stager();
+            sg.out = out;
+            for (int k = items[it].first; k < items[it].second; ++k) {
+                const int64_t nk = n[k], nn = nk * nk, e0 = eoff[k], e1 = eoff[k + 1];
+                if (nn == 0 || e1 == e0) continue;
+                sg.std_ = std::sqrt(2.0) * std::sqrt(2.0 / ((double)nk + (double)nk));
+                if (nn < 16) {      // ATen's scalar path on the whole stream
+                    at::Generator& gen = sg.gen;
+                    gen.set_current_seed((uint64_t)seeds[k]);
+                    float buf[16];
+                    at::Tensor view = at::from_blob(buf, {nn}, at::TensorOptions().dtype(at::kFloat));
+                    view.normal_(1.0, sg.std_, gen);
+                    for (int64_t e = e0; e < e1; ++e) {
+                        const int64_t r = rc[2 * e], c = rc[2 * e + 1];
+                        if (r < 0 || r >= nk || c < 0 || c >= nk) throw std::out_of_range("gnnx_host_transform_edge_words: edge outside its target's block");
+                        out[2 * e] = buf[r * nk + c];
+                        out[2 * e + 1] = buf[c * nk + r];
+                    }
+                    continue;
+                }
+                const int64_t reg_end = (nn % 16 == 0) ? nn : nn - 16;
+                for (int64_t e = e0; e < e1; ++e) {
+                    const int64_t r = rc[2 * e], c = rc[2 * e + 1];
+                    if (r < 0 || r >= nk || c < 0 || c >= nk) throw std::out_of_range("gnnx_host_transform_edge_words: edge outside its target's block");
+                    for (int dir = 0; dir < 2; ++dir) {
+                        const int64_t p = dir ? c * nk + r : r * nk + c;
+                        const int lane = (int)(p < reg_end ? p % 16 : p - (nn - 16));
+                        if (sg.full()) sg.flush();
+                        const int pr = sg.add_pair(words[4 * e + 2 * dir], words[4 * e + 2 * dir + 1]);
+                        sg.wants.emplace_back(Stager::value_index(pr, lane >= 8), 2 * e + dir);
+                    }
+                }
+                sg.flush();      // (the next target has another standard deviation)
+            }
+        } catch (const std::exception& e) {
+            std::lock_guard<std::mutex> lk(err_mu);
+            failed = true;
+            err = e.what();
+        }
+    };
+    if (threads == 1 || items.size() == 1) {
+        for (int i = 0; i < (int)items.size(); ++i) work(i);
+    } else {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (!g_pool || g_pool->size() < threads) g_pool = new Pool(std::max<int>(threads, 16));
+        g_pool->run((int)items.size(), work, threads);
+    }
+    if (failed) {
+        g_err = err;
+        return 1;
+    }
+    return 0;
+}

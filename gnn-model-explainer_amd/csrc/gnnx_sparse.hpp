@@ -403,9 +403,12 @@ __device__ __forceinline__ void sparse_combine(float (&acc)[NQ], int rem, int ws
 // LOG: the logging form - per iteration the loss scalars of explain.py:808-819 (prediction, and the size / entropy / Laplacian sums
 // over the entries on EDGES; the entries off the edges follow a closed scalar recursion each and are added by k_dead_entries) and the
 // decision trace (Params::trace_gates / trace_pool).  A separate instantiation: the hot form carries none of it.
+// pair_flag != nullptr: this body shares its workgroup - and therefore every __syncthreads() - with a second 256-thread body working on
+// another target (k_sparse_resident_mixed, "pair" workgroups).  The two run the same code, so their barrier sequences are identical as long
+// as they take the same side of the one target-dependent choice that changes it (`fuseB`): they agree on it through *pair_flag.
 template <int DQ, int HQ, bool GRAPH, int NT, int XC = 0, bool LOG = false>
 __device__ __forceinline__ void sparse_resident_body(const Params p, int t, const float* adam_tab, float* pool, SparseFixed& sh,
-                                                     int tid, float* shared_w = nullptr) {
+                                                     int tid, float* shared_w = nullptr, int* pair_flag = nullptr) {
     constexpr int SCAN = (sp_ld_max(NT) + 63) / 64;  // rows per lane in the setup prefix scans
     constexpr int SP_QMAX = sp_qmax(NT);
     auto SYNC = []() {
@@ -725,8 +728,18 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     // wave (the usual case: a motif node has a handful of neighbours), wave 0 runs those four phases back to back with
     // wave-level syncs while the other waves wait at ONE workgroup barrier instead of four.
     const bool fuseB = !GRAPH && sh.set_slots[NSET - 1] <= TILE;
+    // A pair workgroup's two bodies share every workgroup barrier, so they must execute the same NUMBER of them: wave-level syncs in those
+    // phases only when BOTH fuse (*pair_flag starts at 1; the barriers of the setup lie in between), else workgroup barriers - padded to the
+    // count of the unfused path (see the head).  Which ARITHMETIC a body runs (the register head, who gathers row t) depends on its own
+    // target alone (`fuseB`), so a target's result does not depend on its partner: pair == alone, bit for bit.
+    bool fuse_sync = fuseB;
+    if (pair_flag) {
+        if (tid == 0 && !fuseB) *pair_flag = 0;
+        SYNC();
+        fuse_sync = *pair_flag != 0;
+    }
     auto SYNC_B = [&]() {
-        if (!fuseB) SYNC();
+        if (!fuse_sync) SYNC();
         else if (wave == 0) wave_sync();
     };
     // owned undirected edges: k = tid + NT q; mask entries and Adam moments stay in registers
@@ -1209,6 +1222,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 if (C <= 4) head(std::integral_constant<int, 4>{}); else head(std::integral_constant<int, RES_CMAX>{});
             }
             SYNC_B();
+            if (pair_flag && !fuse_sync) SYNC();   // (the partner runs the LDS form of the head: one barrier more)
         } else {
         const int nwz = fuseB ? 1 : NW;  // waves that share row t's entries
         if (!fuseB || wave == 0) {   // row t of Abar . relu(U2): its entries dealt over the waves, lane = column; partials summed in wave order
@@ -1772,22 +1786,53 @@ __host__ __device__ inline int sp_mix_tiny(int D, int H, int C) {
     const int wsz = sp_model_floats(D, H, C);
     return wsz + 8 * (sp_pool_floats(64) - wsz) + 8 * sp_fixed_floats() <= sp_pool_floats(512) ? 8 : 6;
 }
+// Pair workgroups (round 5): a target of the 256-thread class (n <= 128, <= 512 edges, 72 KB of LDS) used to take a whole 512-thread workgroup
+// - a whole CU for the 2.4 ms of its chain - whenever its batch also held larger targets, because a SEPARATE 256-thread launch does not pack:
+// the dispatcher spreads its workgroups one per CU, where each blocks a 153 KB workgroup of the other launch (measured in round 4:
+// GNNX_KEEP_256=1 on syn1 147.9 k vs 183.9 k nodes/s).  Here two such targets share one 512-thread workgroup: threads [0, 256) run one body,
+// [256, 512) the other, each in its half of the pool.  s_barrier is workgroup-wide, and the bodies are the same code with the same barrier
+// sequence (see sparse_resident_body: pair_flag), so every __syncthreads() is simply a barrier for both - the pair moves in lockstep,
+// phase by phase, and a CU holds two targets.  On syn1 60 of the 101 larger targets qualify: 141 -> 111 workgroups per batch.
 template <int DQ, int HQ, int XC = 0, bool LOG = false>
 __global__ __launch_bounds__(512) void k_sparse_resident_mixed(Params p, const int32_t* big_ids, int n_big, const int32_t* tiny_ids,
-                                                               int n_tiny, const float* adam_tab, int per_wg, int wsz) {
+                                                               int n_tiny, const float* adam_tab, int per_wg, int wsz,
+                                                               const int32_t* pair_ids = nullptr, int n_pair = 0) {
     __shared__ float pool[sp_pool_floats(512)];
     __shared__ SparseFixed sh_big;
+    __shared__ int pair_flag;
     static_assert(6 * sp_pool_floats(64) + 6 * (int)((sizeof(SparseFixed) + 3) / 4) <= sp_pool_floats(512),
                   "six single-tile slices and their SparseFixed blocks must fit the 512-thread pool whatever the model");
+    static_assert(2 * sp_pool_floats(256) + (int)((sizeof(SparseFixed) + 3) / 4) <= sp_pool_floats(512),
+                  "two 256-thread pools and the second body's SparseFixed block must fit the 512-thread pool");
     if ((int)blockIdx.x < n_big) {
         sparse_resident_body<DQ, HQ, false, 512, XC, LOG>(p, big_ids[blockIdx.x], adam_tab, pool, sh_big, (int)threadIdx.x);
+        return;
+    }
+#ifdef GNNX_NO_PAIR_BODY      // (measurement knob, tools/build_variants.sh: the kernel without the pair body - what its presence costs the other two)
+    const int n_pair_wg = 0;
+    if (false) {
+#else
+    const int n_pair_wg = (n_pair + 1) >> 1;
+    if ((int)blockIdx.x < n_big + n_pair_wg) {
+#endif
+        const int half = (int)threadIdx.x >> 8;
+        const int idx = 2 * ((int)blockIdx.x - n_big) + half;
+        if (threadIdx.x == 0) pair_flag = 1;      // (read behind the setup's barriers)
+        if (idx >= n_pair) return;                // an odd target count: the last workgroup's second half leaves (whole waves; s_barrier waits on the surviving ones)
+        // the second body's wave 0 - the wave that runs the single-wave phases - sits on another SIMD than the first body's
+        // (hardware waves 0 and 4 share SIMD 0): its threads are rotated by one wave
+        const int t256 = (int)threadIdx.x & 255;
+        const int tid = half ? ((t256 + 192) & 255) : t256;      // hardware wave 5 -> body wave 0
+        SparseFixed* shp = half ? reinterpret_cast<SparseFixed*>(pool + 2 * sp_pool_floats(256)) : &sh_big;
+        sparse_resident_body<DQ, HQ, false, 256, XC, LOG>(p, pair_ids[idx], adam_tab, pool + half * sp_pool_floats(256), *shp, tid, nullptr,
+                                                          &pair_flag);
         return;
     }
     // per_wg = sp_mix_tiny(D, H, C), wsz = sp_model_floats(D, H, C) from the host (reading a field of p here makes the compiler
     // pass the by-value Params of the bodies through scratch: 416 bytes per lane)
     const int slice = sp_pool_floats(64) - wsz;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int idx = ((int)blockIdx.x - n_big) * per_wg + wave;
+    const int idx = ((int)blockIdx.x - n_big - n_pair_wg) * per_wg + wave;
     if (wave >= per_wg || idx >= n_tiny) return;  // whole waves leave: the 64-thread body has no workgroup barrier
     SparseFixed* shp = reinterpret_cast<SparseFixed*>(pool + wsz + per_wg * slice) + wave;
     sparse_resident_body<DQ, HQ, false, 64, XC, LOG>(p, tiny_ids[idx], adam_tab, pool + wsz + wave * slice, *shp, lane, pool);

@@ -157,6 +157,7 @@ _API = {
     "gnnx_edge_counts_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "gnnx_edge_layout": (ctypes.c_int, [ctypes.c_void_p] * 6),
     "gnnx_gather_values": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 5),
+    "gnnx_mt_edge_words": (ctypes.c_int, [ctypes.c_void_p] * 7),
     "gnnx_denoise_edges": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_void_p]),
     "gnnx_auc_counts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "gnnx_khop_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
@@ -606,12 +607,39 @@ class MaskOptimJob:
         self._edge_vals0 = v
         self._M_on_edges_only = True      # launch() refuses the kernels that read M off the edges
 
+    def draw_edge_words_device(self, seeds):
+        """First half of the seeded initial masks with the engine walked on the DEVICE (gnnx_mt_edge_words): enqueue the walk of every
+        target's mt19937 stream (its raw state words land in the Abar array, which nothing reads before the run) and the gather of the two
+        raw words of every directed edge entry's Box-Muller pair -> device uint32 [E, 4] (view of an int32 tensor).  The caller copies them
+        to the host and finishes with transform_edge_words + set_masks_on_edges."""
+        self._edge_layout()
+        E = int(self._eoff[-1])
+        sd = _h2d(np.ascontiguousarray(np.asarray(seeds).astype(np.int64)), self.device)
+        words = torch.empty(max(E, 1), 4, dtype=torch.int32, device=self.device)
+        self._enter()
+        _check(self.lib, self.lib.gnnx_mt_edge_words(self.handle, sd.data_ptr(), self._eoff_d.data_ptr(), self._rc.data_ptr(), self.Abar.data_ptr(),
+                                                     words.data_ptr(), self._stream()))
+        self._leave()
+        self._seeds_keepalive = sd
+        return words[:E]
+
     def set_masks_raw_resident(self):
         """Reset M to the initial masks from the RNG stream uploaded by the last set_masks_raw (a device-only op)."""
         self._enter()
         _check(self.lib, self.lib.gnnx_scatter_masks(self.handle, self._raw.data_ptr(), self.M.data_ptr(), self._stream()))
         self._M_on_edges_only = False
         self._leave()
+
+    def reset_masks(self):
+        """Reset M to the initial masks this job was given last - the resident RNG stream (set_masks_raw) or the values on the edges
+        (set_masks_on_edges) - without another host draw or upload: what a repeated run of the same batch starts from."""
+        if getattr(self, "_M_on_edges_only", False):
+            E = int(self._eoff[-1])
+            pos, v = self._epos[:E], self._edge_vals0
+            self.M.index_put_((pos[:, 0],), v[:, 0])
+            self.M.index_put_((pos[:, 1],), v[:, 1])
+        else:
+            self.set_masks_raw_resident()
 
     def _edge_layout(self):
         dev = self.device
@@ -942,6 +970,10 @@ def host_library():
             lib.gnnx_host_draw_edge_masks.restype = ctypes.c_int
             lib.gnnx_host_draw_edge_masks.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                       ctypes.c_int32, ctypes.c_int64]
+            lib.gnnx_host_pair_staging_ok.restype = ctypes.c_int
+            lib.gnnx_host_pair_staging_ok.argtypes = []
+            lib.gnnx_host_transform_edge_words.restype = ctypes.c_int
+            lib.gnnx_host_transform_edge_words.argtypes = [ctypes.c_int32] + [ctypes.c_void_p] * 6 + [ctypes.c_int32]
             lib.gnnx_host_last_error.restype = ctypes.c_char_p
         _host_lib_cache.append(lib)
     return _host_lib_cache[0]
@@ -1030,6 +1062,38 @@ def init_edge_masks_on_edges(sizes, seeds, eoff, rc, threads=1, out=None, slice_
     rc = np.ascontiguousarray(rc[:E], np.int32)
     if E and hl.gnnx_host_draw_edge_masks(len(n32), n32.ctypes.data, sd.ctypes.data, eo.ctypes.data, rc.ctypes.data, out.data_ptr(), int(max(1, threads)),
                                           int(slice_values)) != 0:
+        raise GnnxError(hl.gnnx_host_last_error().decode())
+    return out
+
+
+def pair_staging_ok():
+    """True when the host's normal_ has the property the device-side walk rests on (every lane of its 16-value transform computes the same
+    function of its own pair of uniforms: checked once per process against ATen's one-call draw by libgnnx_host.so)."""
+    hl = host_library()
+    return hl is not None and bool(hl.gnnx_host_pair_staging_ok())
+
+
+def transform_edge_words(sizes, seeds, eoff, rc, words, threads=1, out=None):
+    """Second half of the device-side draw: words [E, 4] (HOST int32 / uint32: MaskOptimJob.draw_edge_words_device) -> out [E, 2] =
+    (M[r][c], M[c][r]), the values ATen's normal_ gives those raw engine words (gnnx_host_transform_edge_words) - bit-identical to
+    init_edge_masks_on_edges, without a pass over the n^2 draws of any target."""
+    hl = host_library()
+    if hl is None:
+        raise GnnxError("libgnnx_host.so is not built")
+    E = int(eoff[-1])
+    if out is None:
+        out = torch.empty(E, 2, dtype=torch.float32)
+    if out.dtype != torch.float32 or out.numel() != 2 * E or not out.is_contiguous():
+        raise ValueError("out must be a contiguous float32 buffer of 2 E values")
+    if words.numel() != 4 * E or not words.is_contiguous() or words.element_size() != 4:
+        raise ValueError("words must be a contiguous 32-bit buffer of 4 E values")
+    n32 = np.ascontiguousarray(sizes, np.int32)
+    sd = np.ascontiguousarray(np.asarray(seeds).astype(np.int64))
+    eo = np.ascontiguousarray(eoff, np.int64)
+    rc = rc if isinstance(rc, np.ndarray) else rc.numpy()
+    rc = np.ascontiguousarray(rc[:E], np.int32)
+    if E and hl.gnnx_host_transform_edge_words(len(n32), n32.ctypes.data, sd.ctypes.data, eo.ctypes.data, rc.ctypes.data, words.data_ptr(),
+                                               out.data_ptr(), int(max(1, threads))) != 0:
         raise GnnxError(hl.gnnx_host_last_error().decode())
     return out
 

@@ -32,7 +32,7 @@ class _Prepared:
 
 class BatchPipeline:
     def __init__(self, graph, state_dict, labels, hyper, n_hops=3, seed_base=1000, rng_threads=None, depth=4, prepare_workers=3, reserve_cus=0, lib=None,
-                 device_hook=None, rng_threads_big=None, edge_draw=None, edge_draw_min_values=2e7):
+                 device_hook=None, rng_threads_big=None, edge_draw=None, edge_draw_min_values=2e7, device_walk=None):
         """graph: engine.DeviceGraph (resident); labels [N]: the label the prediction loss uses (explain.py:750-753); the initial
         mask of target v is drawn from a generator seeded with seed_base + v (the seed protocol of the golden runs)."""
         self.graph, self.sd, self.labels, self.hyper = graph, state_dict, np.asarray(labels), hyper
@@ -59,6 +59,12 @@ class BatchPipeline:
         self.edge_draw = bool(int(os.environ.get("GNNX_PIPE_EDGE_DRAW", "1"))) if edge_draw is None else bool(edge_draw)
         self.edge_draw_min_values = float(edge_draw_min_values)      # batches of fewer normals keep the full draw (it overlaps the plan; syn1: 0.5 ms)
         self.rng_threads_edges = int(os.environ.get("GNNX_PIPE_EDGE_THREADS", self.rng_threads_big))   # (the ranks of a node share its cores: the sharded bench passes its share)
+        # Round 5: the engine of the edge draw walks on the DEVICE (gnnx_mt_edge_words: every target's mt19937 stream as raw state words, the two
+        # words of each entry's Box-Muller pair gathered, 16 bytes per directed entry to the host) and the host only lets ATen transform those
+        # pairs (gnnx_host_transform_edge_words): bit-identical, O(E) instead of O(sum n^2) host work - the 16 384-target BA-House x100k batch
+        # cost 0.64 core-seconds per step with the host walk, which bound a node's ranks to its CPU quota beyond two GPUs.  Needs the
+        # pair-staging property of the host's normal_ (checked once per process); device_walk=False / GNNX_PIPE_DEVICE_WALK=0: the host walk.
+        self.device_walk = bool(int(os.environ.get("GNNX_PIPE_DEVICE_WALK", "1"))) if device_walk is None else bool(device_walk)
         depth = int(os.environ.get("GNNX_PIPE_DEPTH", depth))                        # (measurement knobs)
         reserve_cus = int(os.environ.get("GNNX_PIPE_RESERVE", reserve_cus))
         prepare_workers = int(os.environ.get("GNNX_PIPE_WORKERS", prepare_workers))
@@ -204,9 +210,20 @@ class BatchPipeline:
                 th.start()
             t1c = time.perf_counter()
             if edges_only:
-                s_prep.synchronize()      # the edge ids are on the host now
                 vals = self._pin("edge_vals", 2 * max(E, 1), torch.float32, raw_slot)[:2 * E].view(-1, 2)
-                engine.init_edge_masks_on_edges(dn.sizes, self.seed_base + targets, job._eoff, rc_host[:E], threads=self.rng_threads_edges, out=vals)
+                if self.device_walk and engine.pair_staging_ok():
+                    words_d = job.draw_edge_words_device(self.seed_base + targets)        # the engine walk + pair gather, enqueued on this stream
+                    words_h = self._pin("edge_words", 4 * max(E, 1), torch.int32, raw_slot)[:4 * E].view(-1, 4)
+                    words_h.copy_(words_d, non_blocking=True)
+                    s_prep.synchronize()      # the edge ids and the word pairs are on the host now
+                    p.times["device_walk_ms"] = (time.perf_counter() - t1c) * 1e3
+                    t1d = time.perf_counter()
+                    engine.transform_edge_words(dn.sizes, self.seed_base + targets, job._eoff, rc_host[:E], words_h, threads=self.rng_threads_edges, out=vals)
+                    p.times["host_transform_ms"] = (time.perf_counter() - t1d) * 1e3
+                    p.times["host_rng_device_walk"] = 1.0
+                else:
+                    s_prep.synchronize()      # the edge ids are on the host now
+                    engine.init_edge_masks_on_edges(dn.sizes, self.seed_base + targets, job._eoff, rc_host[:E], threads=self.rng_threads_edges, out=vals)
                 p.times["host_rng_ms"] = (time.perf_counter() - t1c) * 1e3
                 p.times["host_rng_edges_only"] = 1.0
                 t2 = time.perf_counter()

@@ -284,6 +284,17 @@ int gnnx_edge_counts_host(gnnx_handle h, int64_t* counts);
 int gnnx_edge_layout(gnnx_handle h, const float* A, const int64_t* eoff, int32_t* rc, int64_t* epos, void* stream);
 int gnnx_gather_values(const int64_t* epos, int64_t num_edges, const float* Abar, const float* M, float* abar, float* m_rc, void* stream);
 
+/* The seeded initial masks (explain.py:645-652: one normal_ draw of n x n values per target from a CPU generator seeded per target) for the
+ * edge-sparse kernels, with the engine walked on the DEVICE: seeds [T] (DEVICE int64: the generator seed of every target), eoff / rc = the
+ * edge layout of gnnx_edge_layout (DEVICE); scratch = a DEVICE array with room for every target's ld x ld block (the Abar array serves:
+ * nothing reads it before the run) - it receives the raw mt19937 state words of every target's draws; words [E][4] (DEVICE uint32) = for
+ * every upper-triangle edge (r, c) the two raw words of the Box-Muller pair that holds M[r][c], then those of M[c][r].  The host turns them
+ * into the values ATen's normal_ gives them (gnnx_host_transform_edge_words, include/gnnx_host.h): bit-identical to
+ * torch.manual_seed(seed); torch.FloatTensor(n, n).normal_(1.0, std) on the edges, with 16 bytes per directed entry crossing PCIe instead of
+ * the host stepping through all n^2 draws.  Targets of fewer than 16 values (n <= 3) are left untouched (the host draws them whole). */
+int gnnx_mt_edge_words(gnnx_handle h, const int64_t* seeds, const int64_t* eoff, const int32_t* rc, uint32_t* scratch, uint32_t* words,
+                       void* stream);
+
 /* Post-processing of a batch of explanations on the device, on the edge lists of gnnx_gather_edges (all pointers DEVICE):
  * gnnx_denoise_edges = io_utils.denoise_graph(masked_adj, node_idx, threshold_num=k, max_component=True)
  * (utils/io_utils.py:193-245, called at explain.py:306-308, 364-370) for every target: keep[e] = 1 for the edges of the largest

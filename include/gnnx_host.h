@@ -42,6 +42,16 @@ int gnnx_host_draw_masks_sliced(int32_t num_targets, const int32_t* n, const int
 int gnnx_host_draw_edge_masks(int32_t num_targets, const int32_t* n, const int64_t* seeds, const int64_t* eoff, const int32_t* rc, float* out,
                               int32_t threads, int64_t slice_values);
 
+/* The same values from the raw engine words the DEVICE picked (gnnx_mt_edge_words, include/gnnx.h): words [E][4] (HOST uint32) = for edge e
+ * the two raw mt19937 state words of the Box-Muller pair that holds M[r][c], then those of M[c][r]; the host stages them - eight pairs to a
+ * synthetic 16-value block - and ATen's own normal_ tempers and transforms them: out[e] = (M[r][c], M[c][r]), bit-identical to
+ * gnnx_host_draw_edge_masks, without stepping through the n^2 draws of any target (targets of fewer than 16 values, which take ATen's
+ * scalar path, are drawn here from their seed).  Needs the pair-staging property of the host's normal_ (gnnx_host_pair_staging_ok(): 1 / 0,
+ * checked once per process against ATen's one-call draw); without it the caller falls back to gnnx_host_draw_edge_masks. */
+int gnnx_host_pair_staging_ok(void);
+int gnnx_host_transform_edge_words(int32_t num_targets, const int32_t* n, const int64_t* seeds, const int64_t* eoff, const int32_t* rc,
+                                   const uint32_t* words, float* out, int32_t threads);
+
 const char* gnnx_host_last_error(void);
 
 #ifdef __cplusplus

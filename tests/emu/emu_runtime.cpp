@@ -23,6 +23,7 @@ struct Block {
     ucontext_t main;
     int cur = 0, nthreads = 0;
     int bar_count = 0, bar_gen = 0;
+    int nexited = 0;   // threads that have returned: s_barrier waits on the surviving waves only (the hardware's rule)
     std::vector<WaveSlot> waves;
     const std::function<void()>* body = nullptr;
 };
@@ -36,6 +37,11 @@ void trampoline() {
     (*b->body)();
     b->fibers[b->cur].done = true;
     ++g_progress;
+    ++b->nexited;      // a barrier the others already wait at may be complete now ("if some waves have terminated, waits on the surviving ones")
+    if (b->bar_count > 0 && b->bar_count == b->nthreads - b->nexited) {
+        b->bar_count = 0;
+        b->bar_gen++;
+    }
     swapcontext(&b->fibers[b->cur].ctx, &b->main);
 }
 
@@ -60,7 +66,7 @@ void wave_collective(F publish) {
 void syncthreads() {
     Block* b = g_blk;
     const int g = b->bar_gen;
-    if (++b->bar_count == b->nthreads) {
+    if (++b->bar_count == b->nthreads - b->nexited) {
         b->bar_count = 0;
         b->bar_gen++;
         ++g_progress;
@@ -173,6 +179,7 @@ void launch(unsigned grid, unsigned block, const std::function<void()>& body) {
     blockDim = {block, 1, 1};
     for (unsigned bid = 0; bid < grid; ++bid) {
         blk.bar_count = 0;
+        blk.nexited = 0;
         for (auto& w : blk.waves) w.arrived = 0;
         for (unsigned t = 0; t < block; ++t) {
             Fiber& f = blk.fibers[t];

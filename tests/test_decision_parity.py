@@ -243,6 +243,18 @@ def _full_horizon_verdict(what, Dn, ids, err, gates, pool, cond, jump=None):
         desc = (f"U{d[1] + 1}[{d[2]}][{d[3]}] = {d[4]}" if d[0] == "gate" else f"pool {d[1] + 1} column {d[2]}: row {d[3]} vs {d[4]}, margin {d[5]}")
         print(f"{what}: tie   id {r['id']} (calm, {r['err']:.2e} from the reference's output): first differing decision at epoch {r['epoch']} "
               f"({desc}), largest margin of the reference on the {len(r['what'])} differing decision(s) {r['margin']:.2e}")
+    # the other targets beyond the tolerance, each with the epoch and the decision at which the engine first leaves the reference's side (or
+    # "none": a smooth drift) and the conditioning that keeps it out of the gate - so that every target a bench line lists beyond 1e-5 has
+    # its trace here (syn1 / 464)
+    for r in sorted([r for r in rest if r["err"] > TOL], key=lambda r: -r["err"])[:40]:
+        if r["agree"]:
+            desc = "every decision of all 300 epochs identical to the reference's (a smooth drift)"
+        else:
+            d = r["what"][0]
+            desc = (f"first differing decision at epoch {r['epoch']}: " + (f"U{d[1] + 1}[{d[2]}][{d[3]}] = {d[4]}" if d[0] == "gate" else
+                    f"pool {d[1] + 1} column {d[2]}: row {d[3]} vs {d[4]}, margin {d[5]}") + f", the reference's margin on it {r['margin']:.2e}")
+        print(f"{what}: other id {r['id']} (conditioning over the horizon {r['cond']:.2e} > 2e-6: not gated here, covered window by window), {r['err']:.2e} from the "
+              f"reference's output: {desc}")
     assert not bad, msg + f"; {[(r['id'], r['err'], r['cond']) for r in bad]}"
     assert not unjust, msg + f"; first: {unjust[0]}"
     if jump is not None:

@@ -7,6 +7,7 @@ on TWO backends through one body:
     so every edge case (hub rows split over slots, > 512 row slots, edgeless / isolated targets, weighted adjacency with
     self-loops, the mixed launch, ...) has its hardware twin here."""
 import numpy as np
+import torch
 import pytest
 
 import helpers
@@ -340,12 +341,11 @@ def test_plan_routing_by_size_and_edge_count(be):
     subs = [sub(20, 0.2), sub(60, 0.1), sub(200, 0.02), sub(120, 0.5)]
     assert (subs[3].adj != 0).sum() // 2 > 2048
     route = list(be.job(subs, sd).route())
-    # a 512-thread target in the batch: the mid-size target joins its class, the single-tile one stays in the 64-thread
-    # class and shares the launch (k_sparse_resident_mixed)
-    assert route == [6, 8, 8, 0]
-    # a small batch of 256-thread and single-tile targets becomes one mixed launch too (the 256-thread target takes the
-    # 512-thread class); a 256-thread target alone keeps its class
-    assert list(be.job(subs[:2], sd).route()) == [6, 8]
+    # a 512-thread target in the batch: the mid-size target keeps its 256-thread class and the single-tile one its 64-thread class, and
+    # all three share ONE launch (k_sparse_resident_mixed: the 256-thread targets two to a workgroup - "pair" workgroups, round 5)
+    assert route == [6, 5, 8, 0]
+    # a small batch of 256-thread and single-tile targets becomes one mixed launch too; a 256-thread target alone has its own launch
+    assert list(be.job(subs[:2], sd).route()) == [6, 5]
     assert list(be.job(subs[1:2], sd).route()) == [5]
     assert list(be.job(subs, sd, analyze=False).route()) == [1, 0, 0, 0]
     small = [sub(20, 0.2), sub(60, 0.1)]
@@ -614,6 +614,84 @@ def test_mixed_launch_of_large_and_single_tile_targets(be):
         solo = be.job([s], sd).run([s.mask0], hy)
         assert np.array_equal(solo.masked_adj[0], res.masked_adj[i])
         assert np.array_equal(solo.feat_mask[0], res.feat_mask[i])
+
+
+def test_pair_workgroups_two_256_thread_targets_per_workgroup(be, monkeypatch):
+    """Targets of the 256-thread class (n <= 128) run TWO to a 512-thread workgroup of the mixed launch, each body in its half of the threads
+    and of the LDS pool, every __syncthreads() a barrier for both (k_sparse_resident_mixed).  Three of them (an odd count: the last pair
+    workgroup holds one body, its other half leaves) beside a 512-thread target and single-tile targets; one of the three has so many
+    neighbours that its layer-2 rows do not fit one wave, so its partner must drop the single-wave fusion too (the joint `fuseB`).  Every
+    target must match its solo run - the stand-alone 256-thread launch - bit for bit, and the closed form; a batch of 256-thread and
+    single-tile targets alone (no larger one) pairs as well; GNNX_PAIR_256=0 restores the round-4 routing."""
+    rng = np.random.default_rng(11)
+    sd = helpers.random_model(rng, 10, 20, 20, 4)
+
+    def sub(n, density, t, hub=0):
+        A, X = helpers.random_graph(rng, n, 10, density=density)
+        if hub:      # target t with `hub` neighbours: more rows in the layer-2 row set than one wave has slots
+            A[t, :] = 0
+            A[:, t] = 0
+            nb = rng.choice(np.setdiff1d(np.arange(n), [t]), hub, replace=False)
+            A[t, nb] = 1
+            A[nb, t] = 1
+        m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
+        return Subgraph(A, X, 1, t, rng.integers(0, 4, n), m0)
+
+    subs = [sub(200, 0.02, 3), sub(70, 0.06, 5), sub(100, 0.05, 7, hub=40), sub(50, 0.1, 0)] + [sub(int(rng.integers(6, 33)), 0.2, 2) for _ in range(3)]
+    job = be.job(subs, sd)
+    assert list(job.route()) == [8, 5, 5, 5, 6, 6, 6]
+    hy = Hyper(num_iters=4)
+    res = job.run([s.mask0 for s in subs], hy)
+    for i, s in enumerate(subs):
+        o = closed_form.ClosedFormOracle(s.adj, s.feat, sd, s.gt_label, s.pred_label, s.target_row, s.mask0)
+        assert np.abs(res.masked_adj[i] - o.run(4)).max() < 5e-6, i
+        solo = be.job([s], sd).run([s.mask0], hy)
+        assert np.array_equal(solo.masked_adj[0], res.masked_adj[i]), i
+        assert np.array_equal(solo.feat_mask[0], res.feat_mask[i]), i
+    few = subs[1:3] + subs[4:6]          # no 512-thread target: the two 256-thread targets still share a workgroup of the mixed launch
+    job2 = be.job(few, sd)
+    assert list(job2.route()) == [5, 5, 6, 6]
+    res2 = job2.run([s.mask0 for s in few], hy)
+    for i, k in enumerate((1, 2, 4, 5)):
+        assert np.array_equal(res2.masked_adj[i], res.masked_adj[k]) and np.array_equal(res2.feat_mask[i], res.feat_mask[k])
+    monkeypatch.setenv("GNNX_PAIR_256", "0")
+    assert list(be.job(subs, sd).route()) == [8, 8, 8, 8, 6, 6, 6]
+
+
+def test_device_side_engine_walk_draws_the_reference_masks_on_the_edges(be):
+    """The seeded initial masks with the mt19937 walk on the DEVICE (gnnx_mt_edge_words: k_mt_stream + k_mt_gather_pairs) and only the
+    transform of the picked word pairs on the host (gnnx_host_transform_edge_words, through ATen's own normal_): on every edge entry the
+    value torch.manual_seed(seed); torch.FloatTensor(n, n).normal_(1.0, std) puts there, bit for bit - for streams below 16 values (the
+    scalar path), of exactly 16, ragged ones (the redrawn tail: entries among the last 16 positions), multiples of 16, and streams of
+    several engine blocks whose 16-value groups straddle nothing (624 = 39 x 16)."""
+    if not engine.pair_staging_ok():
+        pytest.skip("the host's normal_ lacks the pair-staging property (the pipeline then keeps the host walk)")
+    rng = np.random.default_rng(21)
+    sd = helpers.random_model(rng, 10, 20, 20, 4)
+    sizes = [3, 4, 5, 7, 16, 31, 32, 33, 50, 64, 70, 97, 130]
+    subs = []
+    for n in sizes:
+        A, X = helpers.random_graph(rng, n, 10, density=min(0.9, 6.0 / n))
+        A[n - 1, n - 2] = A[n - 2, n - 1] = 1.0      # an entry among the last positions of the stream: the tail rule of ragged streams
+        A[0, 1] = A[1, 0] = 1.0
+        subs.append(Subgraph(A, X, 1, 0, rng.integers(0, 4, n), None))
+    job = be.job(subs, sd)
+    seeds = 1000 + np.arange(len(sizes)) * 7
+    words = job.draw_edge_words_device(seeds)
+    em_rc = job._rc.cpu().numpy()
+    eoff = job._eoff
+    got = engine.transform_edge_words(sizes, seeds, eoff, em_rc, words.cpu().contiguous(), threads=3)
+    raw = engine.init_edge_masks_raw(sizes, seeds=seeds)
+    off = 0
+    for k, n in enumerate(sizes):
+        full = raw[off:off + n * n].view(n, n)
+        off += n * n
+        a, b = int(eoff[k]), int(eoff[k + 1])
+        assert b > a
+        r, c = em_rc[a:b, 0], em_rc[a:b, 1]
+        assert torch.equal(got[a:b, 0], full[r, c]) and torch.equal(got[a:b, 1], full[c, r]), (k, n)
+    # and it is what the host walk gives (the path it replaces in the pipeline)
+    assert torch.equal(got, engine.init_edge_masks_on_edges(sizes, seeds, eoff, em_rc, threads=2))
 
 
 def test_device_khop_equals_reference_neighbor_lists(be):

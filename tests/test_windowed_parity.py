@@ -57,11 +57,13 @@ def _split_equals_straight(be, subs, sd, analyze, use_resident, graph_mode=False
     assert np.abs(outs[0][3]).max() > 0 and np.abs(outs[0][4]).max() > 0      # the moments really travelled
 
 
-@pytest.mark.parametrize("analyze,use_resident,routes", [(True, True, (6, 8)), (False, True, (1, 2)), (False, False, None)])
+@pytest.mark.parametrize("analyze,use_resident,routes", [(True, True, (5, 6, 8)), (False, True, (1, 2)), (False, False, None)])
 def test_resumed_segments_equal_straight_run_node(be, analyze, use_resident, routes):
-    """Sparse resident (64-thread + 512-thread classes in one mixed launch), dense resident (1 and 2 row blocks), streaming."""
+    """Sparse resident (64-, 256- and 512-thread classes in one mixed launch: single-tile waves, a pair workgroup, a whole workgroup), dense
+    resident (1 and 2 row blocks), streaming."""
+    from test_logging_and_trace import _largest_syn1_case
     ck = helpers.load_ckpt("syn1")
-    subs = [_node_case("syn1", 302)[2], _node_case("syn1", 309)[2], _node_case("syn4", 511)[2]]
+    subs = [_node_case("syn1", 302)[2], _node_case("syn1", 309)[2], _node_case("syn4", 511)[2]] + ([_largest_syn1_case()] if analyze else [])
     _split_equals_straight(be, subs, ck["sd"], analyze, use_resident, routes=routes)
 
 

@@ -33,25 +33,47 @@ __global__ void k_chain(int steps, float* out, long long* cyc) {
     f32x16 c16;
     for (int g = 0; g < 16; ++g) c16[g] = 0.0f;
     const long long t0 = clock64();
+    // (every chain is unrolled 16-fold: a lone wave spends ~24 cycles on a loop trip's own add / compare / branch)
     if (OP == 0) {
-        for (int s = 0; s < steps; ++s) idx = lds[idx];
+        for (int s = 0; s < steps; s += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) idx = lds[idx];
+        }
     } else if (OP == 1) {
-        for (int s = 0; s < steps; ++s) {
-            const int col = lds[idx];                       // the entry's column
-            idx = lds[(col + 1) & (LDS_WORDS - 1)];         // the row it points at
+        for (int s = 0; s < steps; s += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int col = lds[idx];                       // the entry's column
+                idx = lds[(col + 1) & (LDS_WORDS - 1)];         // the row it points at
+            }
         }
     } else if (OP == 2) {
-        for (int s = 0; s < steps; ++s) v = v * 0.999f + __shfl_xor(v, 32);
+        for (int s = 0; s < steps; s += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v = v * 0.999f + __shfl_xor(v, 32);      // (ds_bpermute + one fma: the kernels' xor32_sum)
+        }
     } else if (OP == 3) {
-        for (int s = 0; s < steps; ++s)
-            v = v * 0.999f + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
+        for (int s = 0; s < steps; s += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)      // (one v_fmac with a DPP source: the kernels' row_shl combine step)
+                v = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true)), 0.5f, v * 0.999f);
+        }
     } else if (OP == 4) {
-        for (int s = 0; s < steps; ++s) v = fmaf(v, 0.999f, 1e-3f);
+        for (int s = 0; s < steps; s += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v = fmaf(v, 0.999f, 1e-3f);
+        }
     } else if (OP == 5) {
-        for (int s = 0; s < steps; ++s) c16 = __builtin_amdgcn_mfma_f32_32x32x2f32(v, 1e-3f, c16, 0, 0, 0);
+        for (int s = 0; s < steps; s += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) c16 = __builtin_amdgcn_mfma_f32_32x32x2f32(v, 1e-3f, c16, 0, 0, 0);
+        }
         v += c16[0] + c16[7];
     } else if (OP == 6) {
-        for (int s = 0; s < steps; ++s) v = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+        for (int s = 0; s < steps; s += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v = __builtin_amdgcn_rcpf(1.0f + __expf(-v));      // (one sigmoid: exp, add, rcp; "transc" = half of it)
+        }
     } else if (OP == 7) {
         float* fl = reinterpret_cast<float*>(lds);
         for (int s = 0; s < steps; ++s) {
@@ -101,7 +123,7 @@ int main() {
     long long* cyc;
     CK(hipMalloc(&out, sizeof(float) * 1024 * 1024));
     CK(hipMalloc(&cyc, sizeof(long long) * 1024));
-    const int steps = 200000;
+    const int steps = 204800;
     const int shapes[4][2] = {{64, 1}, {256, 256}, {512, 256}, {1024, 256}};   // one wave alone; 1 / 2 / 4 waves per SIMD on every CU
     for (auto& sh : shapes) {
         run<0>("lds_load", sh[0], sh[1], steps, out, cyc);
