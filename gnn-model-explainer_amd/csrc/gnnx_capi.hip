@@ -990,30 +990,47 @@ static int init_stream_state(gnnx_handle h, const Params& p, hipStream_t s) {
 // hidden 20) and for the general 32-wide case
 // the specialised instantiations (compile-time widths) serve exactly the reference's encoders: D = 10 (node) / 14 (graph), H = O = 20
 static bool exact_shape(gnnx_handle h, int D) { return h->prob.D == D && h->prob.H == 20 && h->prob.O == 20; }
+// widths the <5, 10> / <7, 10> trip counts hold without being the reference's: those instantiations with run-time widths (EX = false)
+static bool small_shape(gnnx_handle h, int D) { return h->prob.D <= D && h->prob.H <= 20 && h->prob.O <= 20; }
+// ... and hidden / output widths up to 32 with the reference's input width (node mode): <5, 16> - the D-wide arrays stay short
+static bool wide_shape(gnnx_handle h, int D) { return h->prob.D <= D && h->prob.H <= 32 && h->prob.O <= 32; }
 
 template <int NT>
 static void launch_sparse_nt(gnnx_handle h, const Params& p, const int32_t* ids, int cnt, const float* adam_tab, hipStream_t s, bool log) {
     const dim3 grid(cnt), block(NT);
-    if (log) {   // the logging form (loss scalars + decision trace): exact shapes only, checked by the caller
+    if (log) {   // the logging form (loss scalars + decision trace): exact shapes only, checked by the caller; of the form the plan runs
         if (h->prob.graph_mode) hipLaunchKernelGGL((k_sparse_resident<7, 10, true, NT, 0, true>), grid, block, 0, s, p, ids, adam_tab);
+        else if (h->xconst == 2) hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT, 2, true>), grid, block, 0, s, p, ids, adam_tab);
         else hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT, 0, true>), grid, block, 0, s, p, ids, adam_tab);
         return;
     }
     if (h->prob.graph_mode) {
         if (exact_shape(h, 14)) hipLaunchKernelGGL((k_sparse_resident<7, 10, true, NT>), grid, block, 0, s, p, ids, adam_tab);
+        else if (small_shape(h, 14)) hipLaunchKernelGGL((k_sparse_resident<7, 10, true, NT, 0, false, false>), grid, block, 0, s, p, ids, adam_tab);
         else hipLaunchKernelGGL((k_sparse_resident<16, 16, true, NT>), grid, block, 0, s, p, ids, adam_tab);
     } else {
         if (exact_shape(h, 10) && h->xconst == 2) hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT, 2>), grid, block, 0, s, p, ids, adam_tab);
         else if (exact_shape(h, 10) && h->xconst == 1) hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT, 1>), grid, block, 0, s, p, ids, adam_tab);
         else if (exact_shape(h, 10)) hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT>), grid, block, 0, s, p, ids, adam_tab);
+        else if (small_shape(h, 10)) hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT, 0, false, false>), grid, block, 0, s, p, ids, adam_tab);
+        else if (wide_shape(h, 10)) hipLaunchKernelGGL((k_sparse_resident<5, 16, false, NT, 0, false, false>), grid, block, 0, s, p, ids, adam_tab);
         else hipLaunchKernelGGL((k_sparse_resident<16, 16, false, NT>), grid, block, 0, s, p, ids, adam_tab);
     }
 }
 static void launch_sparse(gnnx_handle h, const Params& p, int cls, const float* adam_tab, hipStream_t s, bool log = false) {
     if (cls == SPC_LARGE) {  // node-mode targets beyond the LDS-resident classes: row arrays in HBM / L2 (gnnx_sparse_large.hpp)
         const dim3 grid(h->n_sp[cls]), block(SPL_THREADS);
-        if (exact_shape(h, 10))
+        if (log)      // the logging form (loss scalars + decision trace): exact shapes only, checked by the caller
+            hipLaunchKernelGGL((k_sparse_large<5, 10, true>), grid, block, 0, s, p, h->d_sp[cls], adam_tab, h->d_csr_rowptr,
+                               h->d_csr_col, h->d_csr_row, h->d_csr_off, h->d_nnz + 2 * h->prob.num_targets);
+        else if (exact_shape(h, 10))
             hipLaunchKernelGGL((k_sparse_large<5, 10>), grid, block, 0, s, p, h->d_sp[cls], adam_tab, h->d_csr_rowptr,
+                               h->d_csr_col, h->d_csr_row, h->d_csr_off, h->d_nnz + 2 * h->prob.num_targets);
+        else if (small_shape(h, 10))
+            hipLaunchKernelGGL((k_sparse_large<5, 10, false, false>), grid, block, 0, s, p, h->d_sp[cls], adam_tab, h->d_csr_rowptr,
+                               h->d_csr_col, h->d_csr_row, h->d_csr_off, h->d_nnz + 2 * h->prob.num_targets);
+        else if (wide_shape(h, 10))
+            hipLaunchKernelGGL((k_sparse_large<5, 16, false, false>), grid, block, 0, s, p, h->d_sp[cls], adam_tab, h->d_csr_rowptr,
                                h->d_csr_col, h->d_csr_row, h->d_csr_off, h->d_nnz + 2 * h->prob.num_targets);
         else
             hipLaunchKernelGGL((k_sparse_large<16, 16>), grid, block, 0, s, p, h->d_sp[cls], adam_tab, h->d_csr_rowptr,
@@ -1040,7 +1057,7 @@ static int build_dead_list(gnnx_handle h) {
     const long long per = (long long)DEAD_THREADS * DEAD_Q;
     for (int t = 0; t < h->prob.num_targets; ++t) {
         const int c = h->cat[t];
-        if (!(c == CAT_SPARSE || c == CAT_SPARSE + 1 || c == CAT_SPARSE + 2 || c == CAT_SPARSE + SPC_512)) continue;
+        if (!(c == CAT_SPARSE || c == CAT_SPARSE + 1 || c == CAT_SPARSE + 2 || c == CAT_SPARSE + SPC_512 || c == CAT_SPARSE + SPC_LARGE)) continue;
         const long long q = (long long)h->meta[t].ld * h->meta[t].ld;
         for (long long f = 0; f < q; f += per) blocks.push_back(DeadBlock{t, 0, f});
     }
@@ -1177,7 +1194,8 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
     // entries off the edges - when EVERY target of the plan is routed there and the encoder has the reference's widths (the usual case:
     // explainer_main.py --explain-node / the default node list, explain.py:149-159); any other plan logs on the dense streaming kernels.
     const bool want_trace = h->trace_gates || h->trace_pool;
-    const bool log_resident = (lossp || want_trace) && hy->use_resident && h->n_res == 0 && h->n_big == 0 && h->n_sp[SPC_LARGE] == 0 &&
+    // (round 5: k_sparse_large has a logging form too, so a logging run leaves the edge kernels only for targets that stream)
+    const bool log_resident = (lossp || want_trace) && hy->use_resident && h->n_res == 0 && h->n_big == 0 &&
                               h->n_sparse() > 0 && exact_shape(h, h->prob.graph_mode ? 14 : 10);
     if (want_trace && !log_resident)
         return fail("gnnx_set_trace: the decision trace is recorded by the sparse on-chip-resident kernel only (every target routed there, "
@@ -1271,7 +1289,10 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
                 const int n_pair = pairs ? h->n_sp[1] : 0;
                 const int32_t* pair_ids = pairs ? h->d_sp[1] : nullptr;
                 const dim3 grid(h->n_sp[SPC_512] + (n_pair + 1) / 2 + (h->n_sp[2] + per_wg - 1) / per_wg), block(512);
-                if (log_resident)
+                if (log_resident && h->xconst == 2)
+                    hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, 2, true>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
+                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
+                else if (log_resident)
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, 0, true>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
                                        h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
                 else if (exact_shape(h, 10) && h->xconst == 2)
@@ -1282,6 +1303,12 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
                                        h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
                 else if (exact_shape(h, 10))
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
+                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
+                else if (small_shape(h, 10))
+                    hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, 0, false, false>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
+                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
+                else if (wide_shape(h, 10))
+                    hipLaunchKernelGGL((k_sparse_resident_mixed<5, 16, 0, false, false>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
                                        h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
                 else
                     hipLaunchKernelGGL((k_sparse_resident_mixed<16, 16>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
@@ -1404,7 +1431,9 @@ static int analyze_impl(gnnx_handle h, const float* A, const float* X, hipStream
         for (int t = 0; t < T; ++t) nmax = std::max(nmax, h->meta[t].n);
         if (!h->d_rowdeg) HIPCK(pool_malloc(&h->d_rowdeg, sizeof(int32_t) * (size_t)h->R));
         if (!rows_from_pack) hipLaunchKernelGGL(k_row_degrees, dim3(h->n_conv), dim3(256), 0, s, A, h->d_conv, h->d_rowdeg);
-        hipLaunchKernelGGL((k_count_edges_large<0, 4095>), dim3(T), dim3(1024), 0, s, h->d_meta, A, h->d_rowdeg, h->d_nnz + 2 * T);
+        hipLaunchKernelGGL((k_count_edges_large<0, 512, 256>), dim3(T), dim3(256), 0, s, h->d_meta, A, h->d_rowdeg, h->d_nnz + 2 * T);
+        if (nmax > 512)
+            hipLaunchKernelGGL((k_count_edges_large<512, 4095>), dim3(T), dim3(1024), 0, s, h->d_meta, A, h->d_rowdeg, h->d_nnz + 2 * T);
         if (nmax > 4095)
             hipLaunchKernelGGL((k_count_edges_large<4095, SPL_N_MAX>), dim3(T), dim3(1024), 0, s, h->d_meta, A, h->d_rowdeg,
                                h->d_nnz + 2 * T);
@@ -1646,12 +1675,15 @@ extern "C" int gnnx_khop(const int64_t* indptr, const int32_t* indices, int32_t 
     const char* e_grid = getenv("GNNX_KHOP_GRID");
     const int cap = e_grid ? std::max(1, atoi(e_grid)) : (in_lds ? num_targets : 1024);
     const dim3 grid(std::min(num_targets, in_lds ? cap : std::min(cap, 1024))), block(KH_THREADS);
+    const bool small_lds = words <= 256;      // graphs of up to 8192 nodes: 3 KB of bitmaps instead of 48
     if (emit) {
-        if (in_lds) hipLaunchKernelGGL((k_khop<true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_khop<true, false>), grid, block, 0, s, a);
+        if (small_lds) hipLaunchKernelGGL((k_khop<true, 256>), grid, block, 0, s, a);
+        else if (in_lds) hipLaunchKernelGGL((k_khop<true, KH_LDS_WORDS>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_khop<true, 0>), grid, block, 0, s, a);
     } else {
-        if (in_lds) hipLaunchKernelGGL((k_khop<false, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_khop<false, false>), grid, block, 0, s, a);
+        if (small_lds) hipLaunchKernelGGL((k_khop<false, 256>), grid, block, 0, s, a);
+        else if (in_lds) hipLaunchKernelGGL((k_khop<false, KH_LDS_WORDS>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_khop<false, 0>), grid, block, 0, s, a);
     }
     HIPCK(hipGetLastError());
     return 0;

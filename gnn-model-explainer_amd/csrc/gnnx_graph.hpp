@@ -58,9 +58,13 @@ __device__ __forceinline__ int kh_block_scan_exclusive(int v, int tid, int* s_wa
 // (reached, current frontier, next frontier): a node is expanded at the first level it is reached at, which covers
 // every later visit.  EMIT = false: only the sizes (the host needs them to lay out the batch); EMIT = true: the walk is
 // repeated and the reached bitmap is written out as an ascending id list (a bitmap scan IS a sort).
-template <bool EMIT, bool IN_LDS>
+// LDSW = words per bitmap kept in LDS (0: the bitmaps live in global scratch).  Two sizes: 4096 (graphs of up to 131 072 nodes, 48 KB) and -
+// round 5 - 256 (up to 8192 nodes, 3 KB): a pipelined job's k-hop pass has to find room on CUs that optimisation workgroups fill for 2.4 ms at
+// a time; with 48 KB of LDS three of its workgroups fit a freed CU, with 3 KB as many as its wave slots allow.
+template <bool EMIT, int LDSW>
 __global__ __launch_bounds__(KH_THREADS) void k_khop(KhopArgs a) {
-    __shared__ uint32_t s_bm[IN_LDS ? 3 * KH_LDS_WORDS : 1];
+    constexpr bool IN_LDS = LDSW > 0;
+    __shared__ uint32_t s_bm[IN_LDS ? 3 * LDSW : 1];
     __shared__ int s_wave[KH_THREADS / 64];
     const int tid = threadIdx.x, words = a.words;
     uint32_t* reach = IN_LDS ? s_bm : a.scratch + (size_t)blockIdx.x * 3 * words;

@@ -402,11 +402,16 @@ __device__ __forceinline__ void sparse_combine(float (&acc)[NQ], int rem, int ws
 //           Same mathematics, other rounding: within round-off of XC = 1 (tests: closed form, decision parity), not bit-identical.
 // LOG: the logging form - per iteration the loss scalars of explain.py:808-819 (prediction, and the size / entropy / Laplacian sums
 // over the entries on EDGES; the entries off the edges follow a closed scalar recursion each and are added by k_dead_entries) and the
-// decision trace (Params::trace_gates / trace_pool).  A separate instantiation: the hot form carries none of it.
+// decision trace (Params::trace_gates / trace_pool).  A separate instantiation: the hot form carries none of it.  Round 5: also of the
+// algebraic constant-feature form (XC = 2), so that a logging / tracing run executes the arithmetic of the form the plan SHIPS - the
+// decision-parity tests judge the default form, not its general sibling (the gates: relu(U1) > 0 <=> U1 > 0, so the stored activation serves).
 // pair_flag != nullptr: this body shares its workgroup - and therefore every __syncthreads() - with a second 256-thread body working on
 // another target (k_sparse_resident_mixed, "pair" workgroups).  The two run the same code, so their barrier sequences are identical as long
 // as they take the same side of the one target-dependent choice that changes it (`fuseB`): they agree on it through *pair_flag.
-template <int DQ, int HQ, bool GRAPH, int NT, int XC = 0, bool LOG = false>
+// EX = false: the trip counts DQ / HQ bound the widths (D <= 2 DQ, H, O <= 2 HQ) but the widths themselves are run-time values - encoders whose
+// widths are not the reference's take the SMALLEST such instantiation that holds them instead of the 32-wide one (round 5: <16, 16> carries
+// 700-1000 B of scratch per lane and ran a --hidden-dim 16 encoder 4x slower than the reference's widths; profiles/r05_generic_widths_syn1.txt).
+template <int DQ, int HQ, bool GRAPH, int NT, int XC = 0, bool LOG = false, bool EX = true>
 __device__ __forceinline__ void sparse_resident_body(const Params p, int t, const float* adam_tab, float* pool, SparseFixed& sh,
                                                      int tid, float* shared_w = nullptr, int* pair_flag = nullptr) {
     constexpr int SCAN = (sp_ld_max(NT) + 63) / 64;  // rows per lane in the setup prefix scans
@@ -420,7 +425,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     constexpr int NW = NT / 64;
     // The <5, 10> / <7, 10> instantiations serve exactly the reference's encoders (node: D = 10, graph: D = 14; H = O = 20): the
     // widths are compile-time constants there (every column predicate, row stride and trip count folds); other shapes take <16, 16>.
-    constexpr bool EXACT = (DQ != 16);
+    constexpr bool EXACT = EX && (DQ != 16);
     constexpr bool RS = (XC == 2) && SP_RELU_STORE;   // algebraic form: sU1 holds relu(U1) (see layer 1)
     // algebraic form: the next masked adjacency is published by the edge phase itself and the feature mask / wt are refreshed by wave 0 in
     // front of it - one workgroup barrier per iteration fewer and no serial section between two barriers (see the edge phase)
@@ -752,6 +757,9 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     // that round is usually partial, and wave 0, whose chain through the feature-mask update makes it the last to reach the edge phase,
     // then owns one edge fewer than the waves that wait for it (n = 310, 1432 edges, 512 threads: two instead of three).  Which thread
     // updates an edge does not enter its arithmetic.  (The logging form keeps the plain order: its per-thread sums are order dependent.)
+    // (Measured in round 5 and dropped: the feature-mask chain - dL/dphi -> Adam -> phi -> wt, between the barrier behind the layer-1 backward
+    // and the edge phase - on the LAST wave, which then owned no edges, instead of wave 0: launch 2.695 -> 2.69 ms, nothing.  What the timeline
+    // books as "wait at barrier + dfp 0.96 us" on wave 0 is mostly the wait for the other waves' layer-1 backward, not the chain.)
     const int qlast = eup > 0 ? (eup - 1) / NT : 0;
     auto edge_k = [&](int q) { return (!LOG && q == qlast) ? (NT - 1 - tid) + NT * q : tid + NT * q; };
     {
@@ -812,7 +820,9 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     // ---------------- load features, model, labels ----------------
     for (int e = tid; e < n * 32; e += NT) {
         const int r = e >> 5, c = e & 31;
-        if (c < D) sX[r * sD + c] = p.X[(tm.offR + r) * FS + c];
+        // (the padding column of an even D is written too: the run-time-width forms multiply it by an exact zero, and 0 x stale LDS garbage
+        // is NaN when the garbage is - found by the D = 8 case of test_mixed_launch_with_other_encoder_widths on the GPU, round 5)
+        if (c < sD) sX[r * sD + c] = (c < D) ? p.X[(tm.offR + r) * FS + c] : 0.0f;
     }
     // (a shared model block is written by every wave that uses it - the same values to the same addresses, so each wave only
     // needs its own writes to have landed, which its next wave-level sync guarantees: no workgroup barrier)
@@ -876,15 +886,15 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         }
     };
     float step_size = 0.0f, bc2s = 0.0f, rbc2 = 0.0f;   // this iteration's optimiser scalars (set at the top of the loop)
-    auto feature_mask_step = [&]() {   // threads tid < D: Adam on the feature mask from dfp, then phi for the next iteration
-        const float ph = sh.phi[tid];
-        const float gf = (sh.dfp[tid] + p.c_feat_size / (float)D) * ph * (1.0f - ph);
-        float fn = sh.fcur[tid], m = sh.mf[tid], v = sh.vf[tid];
+    auto feature_mask_step = [&](int k) {   // one thread per feature column k < D: Adam on the feature mask from dfp, then phi for the next iteration
+        const float ph = sh.phi[k];
+        const float gf = (sh.dfp[k] + p.c_feat_size / (float)D) * ph * (1.0f - ph);
+        float fn = sh.fcur[k], m = sh.mf[k], v = sh.vf[k];
         adam_update<false, true>(fn, m, v, gf, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt, rbc2);
-        sh.fcur[tid] = fn;
-        sh.mf[tid] = m;
-        sh.vf[tid] = v;
-        sh.phi[tid] = sigmoidf_(fn);  // for the next iteration's layer 1 / edge phase (this iteration's readers are done)
+        sh.fcur[k] = fn;
+        sh.mf[k] = m;
+        sh.vf[k] = v;
+        sh.phi[k] = sigmoidf_(fn);  // for the next iteration's layer 1 / edge phase (this iteration's readers are done)
     };
     if constexpr (XC == 2) update_wt();   // (sX, the model block and phi are in place since the barrier above; publish_abar's barrier publishes wt)
     publish_abar();
@@ -1347,6 +1357,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         SYNC();
         }
         const float* sdZ2 = sdZ2w;  // node mode: the U2 array (overwritten above); graph mode: its own array
+        float log_phs = 0.0f;       // LOG form of the algebraic form: sum of phi of this iteration (wave 0), taken before the merged feature-mask step
         // ======== dX1 = Abar . dZ2 (+ dE1 on row t) -> dZ1 ; feature-mask gradient partials ========
         {
             float dfq[DQ];
@@ -1567,7 +1578,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 const float* dfw2 = &sh.dfw[0][0];
                 // lane c holds vsum[c]; the product reads it with v_readlane (an SGPR operand of the FMA) instead of a store -> wave sync ->
                 // load round trip, and lane k's row of W1 is fetched together with the partial sums; same FMA chain, same order
-                const int kr = (tid < D) ? tid : 0;
+                const int kr = (lane < D) ? lane : 0;
                 float w1r[2 * HQ];
 #pragma unroll
                 for (int c = 0; c < 2 * HQ; ++c) w1r[c] = sW1[kr * 33 + c];
@@ -1578,9 +1589,10 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 float a = 0.0f;
 #pragma unroll
                 for (int c = 0; c < 2 * HQ; ++c) a = fmaf(w1r[c], __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, c)), a);
-                if (tid < D) sh.dfp[tid] = sX[tid] * a;
-                if constexpr (MP) {   // (dfp[tid] is read back by the thread that wrote it; phi of all D columns before wt)
-                    if (tid < D) feature_mask_step();
+                if (lane < D) sh.dfp[lane] = sX[lane] * a;
+                if constexpr (LOG) log_phs = sum_lanes_0_31((lane < D) ? sh.phi[lane] : 0.0f);   // (phi of THIS iteration: the merged step below replaces it)
+                if constexpr (MP) {   // (dfp[k] is read back by the thread that wrote it; phi of all D columns before wt)
+                    if (lane < D) feature_mask_step(lane);
                     wave_sync();
                     update_wt();
                 }
@@ -1701,7 +1713,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         SYNC();  // dfp complete; every reader of sAb / sArt of this iteration is done
         if constexpr (LOG) {
             if (Lrow && wave == 0) {   // the entries off the edges were added to [1] and [3] by k_dead_entries before this launch
-                const float phs = sum_lanes_0_31((lane < D) ? sh.phi[lane] : 0.0f);   // (phi of this iteration: its update below is behind the wave sync)
+                const float phs = (XC == 2) ? log_phs : sum_lanes_0_31((lane < D) ? sh.phi[lane] : 0.0f);   // (phi of this iteration: its update below is behind the wave sync)
                 float a = 0.0f, b = 0.0f, c = 0.0f;
                 for (int w = 0; w < NW; ++w) {
                     a += sh.lsum[w][0];
@@ -1718,7 +1730,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             }
         }
         if constexpr (!MP) {
-        if (tid < D) feature_mask_step();
+        if (tid < D) feature_mask_step(tid);
         if constexpr (XC == 2) {
             if (wave == 0) wave_sync();   // phi of all D columns (threads of wave 0) before wt is refreshed; publish_abar's barrier publishes wt
             update_wt();
@@ -1765,12 +1777,12 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
 
 // second launch bound = waves per SIMD the register allocation must leave room for: two 256-thread workgroups (or six
 // 64-thread ones) per CU need 2; without it the 256-thread graph-mode build took 266 registers and ran one per CU
-template <int DQ, int HQ, bool GRAPH, int NT, int XC = 0, bool LOG = false>
+template <int DQ, int HQ, bool GRAPH, int NT, int XC = 0, bool LOG = false, bool EX = true>
 __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : 2) void k_sparse_resident(Params p, const int32_t* targets, const float* adam_tab) {
-    static_assert(!(XC && GRAPH) && !(XC == 2 && LOG), "constant-feature forms: node mode only; the logging form is the general one");
+    static_assert(!(XC && GRAPH) && !(XC == 1 && LOG), "constant-feature forms: node mode only; logging forms exist of the general and of the algebraic form");
     __shared__ float pool[sp_pool_floats(NT)];
     __shared__ SparseFixed sh;
-    sparse_resident_body<DQ, HQ, GRAPH, NT, XC, LOG>(p, targets[blockIdx.x], adam_tab, pool, sh, (int)threadIdx.x);
+    sparse_resident_body<DQ, HQ, GRAPH, NT, XC, LOG, EX>(p, targets[blockIdx.x], adam_tab, pool, sh, (int)threadIdx.x);
 }
 
 // One launch for a node-mode batch of larger targets (512-thread class) and single-tile targets (64-thread code path):
@@ -1793,7 +1805,7 @@ __host__ __device__ inline int sp_mix_tiny(int D, int H, int C) {
 // [256, 512) the other, each in its half of the pool.  s_barrier is workgroup-wide, and the bodies are the same code with the same barrier
 // sequence (see sparse_resident_body: pair_flag), so every __syncthreads() is simply a barrier for both - the pair moves in lockstep,
 // phase by phase, and a CU holds two targets.  On syn1 60 of the 101 larger targets qualify: 141 -> 111 workgroups per batch.
-template <int DQ, int HQ, int XC = 0, bool LOG = false>
+template <int DQ, int HQ, int XC = 0, bool LOG = false, bool EX = true>
 __global__ __launch_bounds__(512) void k_sparse_resident_mixed(Params p, const int32_t* big_ids, int n_big, const int32_t* tiny_ids,
                                                                int n_tiny, const float* adam_tab, int per_wg, int wsz,
                                                                const int32_t* pair_ids = nullptr, int n_pair = 0) {
@@ -1805,7 +1817,7 @@ __global__ __launch_bounds__(512) void k_sparse_resident_mixed(Params p, const i
     static_assert(2 * sp_pool_floats(256) + (int)((sizeof(SparseFixed) + 3) / 4) <= sp_pool_floats(512),
                   "two 256-thread pools and the second body's SparseFixed block must fit the 512-thread pool");
     if ((int)blockIdx.x < n_big) {
-        sparse_resident_body<DQ, HQ, false, 512, XC, LOG>(p, big_ids[blockIdx.x], adam_tab, pool, sh_big, (int)threadIdx.x);
+        sparse_resident_body<DQ, HQ, false, 512, XC, LOG, EX>(p, big_ids[blockIdx.x], adam_tab, pool, sh_big, (int)threadIdx.x);
         return;
     }
 #ifdef GNNX_NO_PAIR_BODY      // (measurement knob, tools/build_variants.sh: the kernel without the pair body - what its presence costs the other two)
@@ -1824,7 +1836,7 @@ __global__ __launch_bounds__(512) void k_sparse_resident_mixed(Params p, const i
         const int t256 = (int)threadIdx.x & 255;
         const int tid = half ? ((t256 + 192) & 255) : t256;      // hardware wave 5 -> body wave 0
         SparseFixed* shp = half ? reinterpret_cast<SparseFixed*>(pool + 2 * sp_pool_floats(256)) : &sh_big;
-        sparse_resident_body<DQ, HQ, false, 256, XC, LOG>(p, pair_ids[idx], adam_tab, pool + half * sp_pool_floats(256), *shp, tid, nullptr,
+        sparse_resident_body<DQ, HQ, false, 256, XC, LOG, EX>(p, pair_ids[idx], adam_tab, pool + half * sp_pool_floats(256), *shp, tid, nullptr,
                                                           &pair_flag);
         return;
     }
@@ -1835,7 +1847,7 @@ __global__ __launch_bounds__(512) void k_sparse_resident_mixed(Params p, const i
     const int idx = ((int)blockIdx.x - n_big - n_pair_wg) * per_wg + wave;
     if (wave >= per_wg || idx >= n_tiny) return;  // whole waves leave: the 64-thread body has no workgroup barrier
     SparseFixed* shp = reinterpret_cast<SparseFixed*>(pool + wsz + per_wg * slice) + wave;
-    sparse_resident_body<DQ, HQ, false, 64, XC, LOG>(p, tiny_ids[idx], adam_tab, pool + wsz + wave * slice, *shp, lane, pool);
+    sparse_resident_body<DQ, HQ, false, 64, XC, LOG, EX>(p, tiny_ids[idx], adam_tab, pool + wsz + wave * slice, *shp, lane, pool);
 }
 
 // per target: directed off-diagonal non-zeros of its block of the packed adjacency and the row slots the sparse

@@ -195,7 +195,11 @@ __device__ __forceinline__ void sparse_gather_dict(const float* sAb, const unsig
 // csr_*: the targets' CSR structure, built once per plan by k_build_csr_large (scanning a dense block with one
 // workgroup takes milliseconds - too much to repeat in every launch): rowptr at csr_off[2 t], the ascending columns and
 // the row of every directed entry at csr_off[2 t + 1]; counts: k_count_edges_large's output
-template <int DQ, int HQ>
+// LOG (round 5): the logging form, as in k_sparse_resident - per iteration the loss scalars of explain.py:808-819 (prediction; size, entropy
+// and Laplacian sums over the NEAR edges, reduced in a fixed order; the far edges add theirs from their closed recursions with float atomics,
+// the entries off the edges come from k_dead_entries in front of the launch; feature-size term) and the decision trace (the ReLU gates of
+// layer 1 on the rows within two hops and of layer 2 on t and its neighbours, read back from the row arrays).  A separate instantiation.
+template <int DQ, int HQ, bool LOG = false, bool EX = true>
 __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const int32_t* targets, const float* __restrict__ adam_tab,
                                                               const int32_t* __restrict__ csr_rowptr,
                                                               const unsigned short* __restrict__ csr_col,
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     const TargetMeta tm = p.meta[t];
     const int n = tm.n, ld = tm.ld, tr = tm.t;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
-    constexpr bool EXACT = (DQ != 16);   // <5, 10>: exactly D = 10, H = O = 20 (compile-time widths); other shapes take <16, 16>
+    constexpr bool EXACT = EX && (DQ != 16);   // <5, 10>: exactly D = 10, H = O = 20 (compile-time widths); EX = false: widths up to those at run time; other shapes take <16, 16>
     const int D = EXACT ? 2 * DQ : p.D, H = EXACT ? 2 * HQ : p.H, O = EXACT ? 2 * HQ : p.O, C = p.C;
     const float* Ag = p.A + tm.offQ;
     float* Mg = p.M + tm.offQ;
@@ -619,6 +623,14 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         const float step_size = adam_tab[2 * iter], bc2s = adam_tab[2 * iter + 1];
         float rbc2 = 1.0f / bc2s;   // once per iteration (adam_update<.., HAVE_R>)
         GNNX_OPAQUE(rbc2);
+        float* Lrow = nullptr;      // LOG form: this target's row of the loss array for the current iteration
+        if constexpr (LOG) Lrow = p.loss ? p.loss + ((size_t)t * p.num_iters + iter) * NLOSS : nullptr;
+        // LOG form: sign bits of a row of normalised pre-activations (the ReLU gates, models.py:241, 251) -> trace word (iter, row, layer)
+        auto trace_row = [&](int layer, int r, const float* urow) {
+            unsigned bits = 0u;
+            for (int c = 0; c < H; ++c) bits |= (urow[c] > 0.0f ? 1u : 0u) << c;
+            p.trace_gates[((size_t)iter * (size_t)p.trace_rows + (size_t)(tm.offR + r)) * 2 + layer] = bits;
+        };
 
         // ======== layer 1 on the rows within two hops: Zraw = Abar . X (kept for the feature-mask gradient), U1 ========
         for (int round = 0; round < roundsA; ++round) {
@@ -641,6 +653,12 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                                         sRn1 + round * (NT / 2) + wave * TILE + li);
         }
         __syncthreads();
+        if constexpr (LOG)
+            if (p.trace_gates)
+                for (int round = 0; round < roundsA; ++round) {
+                    const RowSlot SA = slot_of(0, round);
+                    if (SA.wave_active && SA.first && h == 0) trace_row(0, SA.row, gU1 + SA.row * FS);
+                }
         // ======== layer 2 on the target and its neighbours: U2 ========
         for (int round = 0; round < roundsB; ++round) {
             const RowSlot SB = slot_of(1, round);
@@ -658,6 +676,12 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                                         sRn2 + round * (NT / 2) + wave * TILE + li);
         }
         __syncthreads();
+        if constexpr (LOG)
+            if (p.trace_gates)
+                for (int round = 0; round < roundsB; ++round) {
+                    const RowSlot SB = slot_of(1, round);
+                    if (SB.wave_active && SB.first && h == 0) trace_row(1, SB.row, gU2 + SB.row * FS);
+                }
         // ======== row t of layer 3, head, dE, dZ3[t] ========
         {
             float z = 0.0f;
@@ -710,6 +734,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 sum += row_shl<1>(sum);
                 sum = bcast_first(sum);
                 if (lane < CMAX) sh.g[lane] = (lane < C) ? ex / sum - ((lane == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
+                if constexpr (LOG)
+                    if (Lrow && lane == tm.y_gt) Lrow[0] = -logf(ex / sum);   // explain.py:750-753
             }
             wave_sync();
 #pragma unroll
@@ -901,6 +927,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         }
         // ======== per near edge: G_ij + G_ji, regulariser gradients, Adam in place on both directed entries, next Abar ========
         const bool republish = iter + 1 < p.num_iters;  // the returned mask is the one of the LAST forward (explain.py:209-211)
+        float ls_size = 0.0f, ls_ent = 0.0f, ls_lap = 0.0f;   // LOG form: this thread's part of the logged sums (its near edges, both directions)
         // two edges per trip: the planes come from L2, and the loads of the second edge are in flight while the first is updated
         for (int k0 = tid; k0 < eupN; k0 += 2 * NT) {
             constexpr int EU = 2;
@@ -934,6 +961,14 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
 #pragma unroll
                 for (int u = 0; u < EU; ++u) {
                     const float gc = (0.5f * G[u] + lap[u]) * w[u];
+                    if constexpr (LOG) {   // explain.py:755-770, 780-793 on the current iterate (before its update)
+                        if (on[u]) {
+                            const float Sa = sigmoidf_(Mij[u]), Sb = sigmoidf_(Mji[u]);
+                            ls_size += Sa + Sb;
+                            ls_ent += (-Sa * logf(Sa) - (1.0f - Sa) * logf(1.0f - Sa)) + (-Sb * logf(Sb) - (1.0f - Sb) * logf(1.0f - Sb));
+                            ls_lap += w[u] * (0.5f * (Sa + Sb)) * (2.0f * lap[u]);   // Abar_ij c_lap (yhat_i - yhat_j)^2 / n^2: lap = c_lap / 2 dy^2 / n^2
+                        }
+                    }
                     {
                         const float S = sigmoidf_(Mij[u]);
                         const float g = (gc + p.c_size - p.c_ent * Mij[u] * inv_n2) * S * (1.0f - S);
@@ -963,7 +998,37 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 }
             }
         }
+        if constexpr (LOG) {   // wave sums in lane order, then (after the barrier) the waves in order: a fixed summation order
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                ls_size += __shfl_xor(ls_size, o);
+                ls_ent += __shfl_xor(ls_ent, o);
+                ls_lap += __shfl_xor(ls_lap, o);
+            }
+            if (lane == 0) {
+                sh.lsum[wave][0] = ls_size;
+                sh.lsum[wave][1] = ls_ent;
+                sh.lsum[wave][2] = ls_lap;
+            }
+        }
         __syncthreads();
+        if constexpr (LOG) {
+            if (Lrow && wave == 0) {   // the entries off the edges were added to [1] and [3] by k_dead_entries; the far edges add theirs below
+                const float phs = sum_lanes_0_31((lane < D) ? sh.phi[lane] : 0.0f);
+                float a = 0.0f, b = 0.0f, c = 0.0f;
+                for (int w = 0; w < NW; ++w) {
+                    a += sh.lsum[w][0];
+                    b += sh.lsum[w][1];
+                    c += sh.lsum[w][2];
+                }
+                if (lane == 0) {
+                    atomicAdd(&Lrow[1], p.c_size * a);
+                    atomicAdd(&Lrow[2], c);
+                    atomicAdd(&Lrow[3], p.c_ent * b * inv_n2);
+                    Lrow[4] = p.c_feat_size * phs / (float)D;
+                }
+            }
+        }
         if (tid < D) {  // feature mask
             const float ph = sh.phi[tid];
             const float gf = (sh.dfp[tid] + p.c_feat_size / (float)D) * ph * (1.0f - ph);
@@ -1016,6 +1081,13 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             const float step_size = adam_tab[2 * iter], bc2s = adam_tab[2 * iter + 1];
             const float Si = sigmoidf_(Mij), Sj = sigmoidf_(Mji);
             a = w * (0.5f * (Si + Sj));   // the mask of this iteration's forward
+            if constexpr (LOG)
+                if (p.loss) {   // this far edge's share of the logged sums (float atomics: logging only, like k_dead_entries)
+                    float* L = p.loss + ((size_t)t * p.num_iters + iter) * NLOSS;
+                    atomicAdd(&L[1], p.c_size * (Si + Sj));
+                    atomicAdd(&L[2], a * (2.0f * glap[k]));
+                    atomicAdd(&L[3], p.c_ent * inv_n2 * ((-Si * logf(Si) - (1.0f - Si) * logf(1.0f - Si)) + (-Sj * logf(Sj) - (1.0f - Sj) * logf(1.0f - Sj))));
+                }
             const float gi = (gc + p.c_size - p.c_ent * Mij * inv_n2) * Si * (1.0f - Si);
             const float gj = (gc + p.c_size - p.c_ent * Mji * inv_n2) * Sj * (1.0f - Sj);
             adam_update(Mij, mij, vij, gi, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
@@ -1077,9 +1149,11 @@ __global__ __launch_bounds__(256) void k_row_degrees(const float* A, const ConvT
     }
 }
 
-template <int NLO, int NMAX>
-__global__ __launch_bounds__(1024) void k_count_edges_large(const TargetMeta* meta, const float* A, const int32_t* rowdeg, int32_t* out) {
-    constexpr int NW = 16, UN = 8;   // the dense rows of t and its neighbours are scanned for the hop levels: 16 waves x 8 chunks in flight
+// (NTH threads per workgroup: 1024 for the large ranges; round 5: targets of up to 512 nodes take <0, 512, 256> - 2.5 KB of LDS and four
+// waves instead of 20 KB and sixteen, so that a pipelined job's analysis finds room on a chip full of optimisation workgroups.)
+template <int NLO, int NMAX, int NTH = 1024>
+__global__ __launch_bounds__(NTH) void k_count_edges_large(const TargetMeta* meta, const float* A, const int32_t* rowdeg, int32_t* out) {
+    constexpr int NW = NTH / 64, UN = 8;   // the dense rows of t and its neighbours are scanned for the hop levels: NW waves x 8 chunks in flight
     __shared__ int deg[NMAX + 1];
     __shared__ unsigned char level[NMAX + 1];
     __shared__ int part[NW];

@@ -475,7 +475,11 @@ class Explainer:
                                             record_loss=self.print_training, unconstrained=unconstrained)[0]
         if self.print_training and self.last_result.loss is not None:
             tr = self.last_result.loss[0]        # logged by the kernel the optimisation ran on (the resident kernel's logging form)
-            for epoch in range(len(tr)):          # explain.py:149-159 prints every epoch
+            # (explain.py:149-159 prints "epoch, loss, mask density, pred" every epoch.  The kernels log the five LOSS terms of explain.py:808-819;
+            #  the mask density - a second n^2 pass over the masked adjacency plus a device sync per epoch in the reference - and the class
+            #  probabilities are not logged, so this line carries the loss and its prediction term: a documented difference of the log FORMAT,
+            #  not of any result)
+            for epoch in range(len(tr)):
                 print("epoch: ", epoch, "; loss: ", float(tr[epoch, :5].sum()), "; pred loss: ", float(tr[epoch, 0]))
         print("finished training in ", self.last_time)
         fname = self._save(masked_adj, node_idx)

@@ -146,6 +146,18 @@ class BatchPipeline:
         self.queue_fallbacks = getattr(self, "queue_fallbacks", 0) + 1
         return cand
 
+    @staticmethod
+    def _wait(stream, blocking):
+        """Wait until `stream` has drained.  stream.synchronize() SPINS (HIP's default wait: one core at 100 % for as long as the GPU works) -
+        fine for the sub-millisecond waits of a small batch, but a large batch waits tens of milliseconds per stage, and the ranks of a node
+        share its cores: those waits go through an event created with hipEventBlockingSync, which sleeps."""
+        if not blocking:
+            stream.synchronize()
+            return
+        ev = torch.cuda.Event(blocking=True)
+        ev.record(stream)
+        ev.synchronize()
+
     # -- pinned staging ----------------------------------------------------------------------------------------------------
     def _pin(self, name, numel, dtype, slot):
         key = (name, slot)
@@ -215,14 +227,14 @@ class BatchPipeline:
                     words_d = job.draw_edge_words_device(self.seed_base + targets)        # the engine walk + pair gather, enqueued on this stream
                     words_h = self._pin("edge_words", 4 * max(E, 1), torch.int32, raw_slot)[:4 * E].view(-1, 4)
                     words_h.copy_(words_d, non_blocking=True)
-                    s_prep.synchronize()      # the edge ids and the word pairs are on the host now
+                    self._wait(s_prep, True)      # the edge ids and the word pairs are on the host now (tens of milliseconds: sleep, do not spin)
                     p.times["device_walk_ms"] = (time.perf_counter() - t1c) * 1e3
                     t1d = time.perf_counter()
                     engine.transform_edge_words(dn.sizes, self.seed_base + targets, job._eoff, rc_host[:E], words_h, threads=self.rng_threads_edges, out=vals)
                     p.times["host_transform_ms"] = (time.perf_counter() - t1d) * 1e3
                     p.times["host_rng_device_walk"] = 1.0
                 else:
-                    s_prep.synchronize()      # the edge ids are on the host now
+                    self._wait(s_prep, True)      # the edge ids are on the host now
                     engine.init_edge_masks_on_edges(dn.sizes, self.seed_base + targets, job._eoff, rc_host[:E], threads=self.rng_threads_edges, out=vals)
                 p.times["host_rng_ms"] = (time.perf_counter() - t1c) * 1e3
                 p.times["host_rng_edges_only"] = 1.0
@@ -295,7 +307,7 @@ class BatchPipeline:
             vals[:p.E].copy_(vals_d[:p.E], non_blocking=True)
             fm = self._pin("fmask", job.T * engine.FEAT_STRIDE, torch.float32, slot).view(job.T, engine.FEAT_STRIDE)
             fm.copy_(job.fmask, non_blocking=True)
-            fetched = torch.cuda.Event()
+            fetched = torch.cuda.Event(blocking=p.times.get("host_rng_edges_only", 0.0) > 0)      # (a large batch: the caller sleeps through its tens of milliseconds)
             fetched.record(self.s_fetch)
         return vals, fm, fetched
 

@@ -11,10 +11,15 @@ started from the reference's state at a boundary and run over the window TRIALS 
 the gradient in every iteration (oracle/closed_form.py `grad_noise`: what a different summation order does); noise50[t][w] is the largest
 deviation (masked adjacency on the edges, sigmoid(feat_mask)) of those runs from the noise-free run; noise10 likewise for the 10-epoch
 sub-windows of the windows that have fine snapshots.  Outcome-blind: no GPU result enters.
+Round 5 adds ssens50 / ssens10, the 1-ulp sensitivity of a window to its WHOLE starting state (see _probe): the completion of probe (ii),
+which perturbs the mask entries only.
 
     python tests/golden/make_golden_noise_probe.py --what syn1,syn4,syn5,config4 --procs 7
--> tests/golden/<name>_noise.npz: targets|graphs [T], noise50 [T][6], noise10 [F][5] (rows of <name>_windows.npz's fine_tw), trials, ulp
+-> tests/golden/<name>_noise.npz: targets|graphs [T], noise50 / ssens50 [T][6], noise10 / ssens10 [F][5] (rows of <name>_windows.npz's fine_tw), trials, ulp
 """
+import os as _os
+for _k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):      # one BLAS thread per worker process: the workers are the parallelism
+    _os.environ.setdefault(_k, "1")
 import argparse
 import multiprocessing as mp
 import os
@@ -54,13 +59,30 @@ def _run(o, rc, state, k0, steps, rng):
     return 0.5 * (_sig64(Mrc[:, 0]) + _sig64(Mrc[:, 1])), _sig64(o.f)
 
 
+STATE_TRIALS = 8
+
+
 def _probe(o, rc, state, k0, steps, seed):
+    """-> (deviation under per-step gradient noise, 1-ulp sensitivity of the window to its WHOLE starting state)"""
     base = _run(o, rc, state, k0, steps, None)
+    d = lambda got: max(float(np.abs(got[0] - base[0]).max()) if len(base[0]) else 0.0, float(np.abs(got[1] - base[1]).max()))
     dev = 0.0
     for trial in range(TRIALS):
-        got = _run(o, rc, state, k0, steps, np.random.default_rng((seed, k0, trial)))
-        dev = max(dev, float(np.abs(got[0] - base[0]).max()) if len(base[0]) else 0.0, float(np.abs(got[1] - base[1]).max()))
-    return dev
+        dev = max(dev, d(_run(o, rc, state, k0, steps, np.random.default_rng((seed, k0, trial)))))
+    # Round 5 (ssens50 / ssens10).  Probe (ii) of make_golden_windows.py perturbs the MASK entries of the window's start by +-1 ulp; the
+    # state an implementation is handed has five more parts - the two Adam moments, the feature mask and its moments.  tools/drift_per_epoch.py
+    # showed the engine's distance in the expansive Tree-Grid windows opening with a one-ulp difference of a FEATURE-MASK parameter in the
+    # window's first steps and growing at the window's own rate (the closed form's distance grows at the same rate from a later start), which
+    # a perturbation of the mask entries alone does not see: half the trials perturb every part of the state, half the feature mask alone.
+    sens = 0.0
+    for trial in range(STATE_TRIALS):
+        rng = np.random.default_rng((seed, k0, 7919 + trial))
+        parts = range(6) if trial % 2 == 0 else (3,)
+        st = list(state)
+        for i in parts:
+            st[i] = (np.asarray(st[i], np.float32) * (np.float32(1) + np.float32(2.0 ** -23) * (2 * rng.random(np.shape(st[i]), dtype=np.float32) - 1))).astype(np.float32)
+        sens = max(sens, d(_run(o, rc, tuple(st), k0, steps, None)))
+    return dev, sens
 
 
 def _worker(job):
@@ -127,13 +149,18 @@ def main():
             res = [r for part in pool.map(_worker, jobs) for r in part]
         noise50 = np.zeros((W.T, W.W), np.float32)
         noise10 = np.zeros((len(W.z["fine_tw"]), W.nsub), np.float32)
+        ssens50, ssens10 = np.zeros_like(noise50), np.zeros_like(noise10)      # round 5: 1-ulp sensitivity to the whole starting state
         for k, n50, n10 in res:
-            noise50[k] = n50
+            noise50[k] = [x[0] for x in n50]
+            ssens50[k] = [x[1] for x in n50]
             for w, v in n10.items():
-                noise10[W.fine_row[(k, w)]] = v
+                noise10[W.fine_row[(k, w)]] = [x[0] for x in v]
+                ssens10[W.fine_row[(k, w)]] = [x[1] for x in v]
         id_name = "graphs" if name == "config4" else "targets"
         np.savez_compressed(os.path.join(HERE, name + "_noise.npz"), **{id_name: W.ids, "noise50": noise50, "noise10": noise10,
+                                                                          "ssens50": ssens50, "ssens10": ssens10, "state_trials": np.int64(STATE_TRIALS),
                                                                           "trials": np.int64(TRIALS), "ulp": np.float64(2.0 ** -23)})
+        print(f"{name}: whole-state sensitivity > 2e-6 in {int((ssens50 > 2e-6).sum())} windows, > 1e-5 in {int((ssens50 > 1e-5).sum())}, largest {float(ssens50.max()):.2e}", flush=True)
         old = np.maximum(W.z["cond50"], W.z["sens50"])
         done = np.zeros(W.T, bool)
         done[[r[0] for r in res]] = True

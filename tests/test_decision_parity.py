@@ -14,19 +14,20 @@ which one of them changes sides the optimiser state is a smooth function of its 
       required to agree - and the window's error stays below the largest jump a flipped tie causes (5e-3; graph mode 6e-2).  These
       windows are listed with the epoch, the gate and the reference's margin: that list is the trace of every miss.
   (c) "within round-off" needs a scale.  This very test found smooth stretches - every decision identical - at whose end the engine
-      sits 1e-5 .. 7e-5 from the reference (a dozen 50-epoch Tree-Grid windows, all in sigmoid(feat_mask): where the prediction part of a
-      gradient nearly cancels its regulariser part, Adam's scale-free step amplifies the round-off every iteration adds, without any
-      discrete event).  The scale is the window's own conditioning c, measured on the reference's side by three CPU-only probes before
-      any implementation ran: CPU-vs-CPU deviation and 1-ulp sensitivity of the window's start (make_golden_windows.py) and the
-      deviation under 1 ulp of summand-scale noise on the gradient sums in every iteration (make_golden_noise_probe.py, added for
-      exactly these windows).  A window with identical decisions must end within max(1e-5, 50 c): 1e-5 wherever c <= 2e-7, and never
-      more than 50 ulp-equivalents of per-step noise (the kernels' sums of up to ~50 products, 1-4 ulp hardware forms of exp / rcp /
-      sqrt, and four probe trials that under-sample the worst case).  Windows with c > 2e-6 are re-run as 10-epoch sub-windows where the
-      fixture has the snapshots (the amplification then has a fifth of the time to act) and judged there by the same rule; the same
-      50 c is the margin up to which a differing decision counts as a tie in (b).  Every window beyond 1e-5 is listed with its c.
-      The third probe of round 3 (a gate within 5e-7 of zero; it flagged a third of syn1's windows) is NOT used: what it guessed at is
-      now measured.
-  Anything else - a differing decision the reference takes by a clear margin, an agreed window beyond max(1e-5, 50 c) - fails.
+      sits 1e-5 .. 7e-5 from the reference (a dozen 50-epoch Tree-Grid windows, all in sigmoid(feat_mask)).  The scale is the window's own
+      conditioning c, measured on the reference's side by CPU-only probes before any implementation ran: CPU-vs-CPU deviation and 1-ulp
+      sensitivity of the window's starting MASK (make_golden_windows.py), the deviation under 1 ulp of summand-scale noise on the gradient
+      sums in every iteration, and - round 5 - the 1-ulp sensitivity of the window to its WHOLE starting state (make_golden_noise_probe.py:
+      ssens50).  The last one is what explains those windows: tools/drift_per_epoch.py (profiles/r05_syn5_drift_per_epoch.txt) shows the
+      engine's distance opening in the window's FIRST steps with a one-ulp difference of a feature-mask parameter and then growing at the
+      window's own rate - the closed form's distance to the reference grows at the same rate from a later start - and a window that turns
+      one ulp of its feature mask into 3e-5 cannot be reproduced to better than that by any implementation whose update differs by an ulp.
+      With it every such window ends within 1.7 c (round 4 needed 50 c of the three older probes: they perturbed the mask entries only).
+      A window with identical decisions must end within max(1e-5, 4 c) - 4 = the room for a worse case than the eight random trials the
+      probe samples - and never more than the largest jump of a flipped tie.  Windows with c > 2e-6 are re-run as 10-epoch sub-windows where
+      the fixture has the snapshots and judged there by the same rule; the same 4 c is the margin up to which a differing decision counts
+      as a tie in (b).  Every window beyond 1e-5 is listed with its c.
+  Anything else - a differing decision the reference takes by a clear margin, an agreed window beyond max(1e-5, 4 c) - fails.
 
 Windows are the 50-epoch windows of tests/golden/<name>_windows.npz (the live reference's Adam state, teacher forcing through
 gnnx_run_resume); a window of kind (b) is re-run as its five 10-epoch sub-windows where the fixture holds the 10-epoch snapshots, so
@@ -46,7 +47,7 @@ from test_windowed_parity import _node_subgraph_job
 
 TOL = helpers.WIN_TOL
 MIN_GATED_SHARE = 0.90
-ROUNDOFF_BUDGET = 50.0     # ulp-equivalents of per-step noise an implementation may differ by (see (c) above)
+ROUNDOFF_BUDGET = 4.0      # factor over the window's CPU-measured conditioning c an implementation may differ by (see (c) above; 50 in round 4)
 
 
 def _judge(Dn, k, e0, gates, pool, err, ident, w, sub, smooth):
@@ -75,7 +76,7 @@ def _decision_windows(W, Dn, make_job, ks_all, coarse_windows=None):
         redo = []
         for i, k in enumerate(ks_all):
             row = _judge(Dn, k, W.win * w, gates[i], None if pool is None else pool[i], max(em[i], ef[i]), W.ids[k], w, -1,
-                         max(W.z["cond50"][k, w], W.z["sens50"][k, w], Nz["noise50"][k, w]))
+                         max(W.z["cond50"][k, w], W.z["sens50"][k, w], Nz["noise50"][k, w], Nz["ssens50"][k, w]))
             if (not row["agree"] or row["expansive"]) and (int(k), int(w)) in W.fine_row:
                 redo.append(int(k))
             else:
@@ -91,7 +92,7 @@ def _decision_windows(W, Dn, make_job, ks_all, coarse_windows=None):
             for i, k in enumerate(ks):
                 f = W.fine_row[(int(k), int(w))]
                 rows.append(_judge(Dn, k, W.win * w + W.sub * s, gates[i], None if pool is None else pool[i], max(em[i], ef[i]), W.ids[k], w, s,
-                                   max(W.z["cond10"][f, s], W.z["sens10"][f, s], Nz["noise10"][f, s])))
+                                   max(W.z["cond10"][f, s], W.z["sens10"][f, s], Nz["noise10"][f, s], Nz["ssens10"][f, s])))
     return rows
 
 
@@ -103,7 +104,7 @@ def _verdict(what, rows, Dn, jump, min_share=MIN_GATED_SHARE):
     total = sum(r["iters"] for r in rows)
     gated = sum(r["iters"] for r in agreed)
     strict = sum(r["iters"] for r in agreed if r["err"] <= TOL)
-    over = [r for r in agreed if r["err"] > TOL]                              # identical decisions, beyond 1e-5: listed, bounded by 50 c
+    over = [r for r in agreed if r["err"] > TOL]                              # identical decisions, beyond 1e-5: listed, bounded by 4 c
     bad_agreed = [r for r in over if r["err"] > min(bound(r), jump)]
     tie_margin = lambda r: max(Dn.near_tol_strict, ROUNDOFF_BUDGET * r["smooth"])
     unknown = [r for r in ties if not np.isfinite(r["margin"])]                # a differing gate beyond the fixture's NEAR list (|U| >= 1e-4)
@@ -111,7 +112,7 @@ def _verdict(what, rows, Dn, jump, min_share=MIN_GATED_SHARE):
     mg = np.asarray([r["margin"] for r in ties if np.isfinite(r["margin"])])
     msg = (f"{what}: {len(rows)} windows ({total} target-epochs); every decision identical to the reference's in {len(agreed)} windows = "
            f"{100.0 * gated / max(1, total):.2f} % of the target-epochs (within 1e-5: {len(agreed) - len(over)} windows = {100.0 * strict / max(1, total):.2f} %; the other "
-           f"{len(over)} within 50 x their CPU-measured conditioning, worst {max([r['err'] for r in over], default=0.0):.2e}; beyond that: {len(bad_agreed)}); "
+           f"{len(over)} within 4 x their CPU-measured conditioning, worst {max([r['err'] for r in over], default=0.0):.2e}; beyond that: {len(bad_agreed)}); "
            f"a differing decision in {len(ties)} windows: {len(ties) - len(unjust)} first at a tie of the reference (its margin there: {int((mg < 1e-7).sum())} below 1e-7, "
            f"{int((mg < 1e-6).sum())} below 1e-6, {int((mg < 1e-5).sum())} below 1e-5, {len(unknown)} not on the fixture's list), {int(sum(r['err'] <= TOL for r in ties))} of them "
            f"within 1e-5 anyway, worst {max([r['err'] for r in ties], default=0.0):.2e}; not at a tie: {len(unjust)}")
@@ -209,7 +210,7 @@ def _full_horizon_verdict(what, Dn, ids, err, gates, pool, cond, jump=None):
     """300 epochs from the seeded masks, no teacher forcing.  cond[k] = the target's conditioning over the WHOLE horizon, measured on the CPU
     alone: the largest of the CPU-vs-CPU deviation after 300 epochs (cond_mask / cond_feat of the fixture) and the three window probes of
     its six windows.  On the calm targets (cond <= 2e-6: nothing amplifies round-off beyond the tolerance anywhere along the trajectory) the
-    rule of the windowed test applies to the whole run, with the per-window bound max(1e-5, 50 cond) counted once per 50-epoch window
+    rule of the windowed test applies to the whole run, with the per-window bound max(1e-5, 4 cond) counted once per 50-epoch window
     passed (nothing resets the engine to the reference's state here, so the windows' deviations add up): decisions identical in all
     300 epochs -> within 6 x that of the reference's ONE output; otherwise the first differing decision, at epoch e, must be one the
     reference takes by less than (1 + e // 50) x that.  On the
@@ -231,7 +232,7 @@ def _full_horizon_verdict(what, Dn, ids, err, gates, pool, cond, jump=None):
     rest = [r for r in rows if not r["calm"]]
     msg = (f"{what} [300 epochs from the seeds]: {len(rows)} targets, {len(calm)} calm (conditioning over the whole horizon <= 2e-6 on the CPU): every decision of "
            f"all 300 epochs identical to the reference's on {len(same)} of them - {len(same) - len(over)} within 1e-5 of the reference's output, the other {len(over)} within "
-           f"50 x their conditioning (worst {max([r['err'] for r in over], default=0.0):.2e}; beyond: {len(bad)}) - and a differing decision on {len(ties)}: "
+           f"4 x their conditioning (worst {max([r['err'] for r in over], default=0.0):.2e}; beyond: {len(bad)}) - and a differing decision on {len(ties)}: "
            f"{len(ties) - len(unjust)} first at a tie of the reference, {int(sum(r['err'] <= TOL for r in ties))} of them within 1e-5 anyway, worst "
            f"{max([r['err'] for r in ties], default=0.0):.2e}; not at a tie: {len(unjust)}.  The other {len(rest)} targets (reported): decisions identical on "
            f"{int(sum(r['agree'] for r in rest))}, within 1e-5 of the reference's output {int(sum(r['err'] <= TOL for r in rest))}, worst {max([r['err'] for r in rest], default=0.0):.2e}")
@@ -266,7 +267,7 @@ def _horizon_conditioning(name, z_cond_mask, z_cond_feat):
     W = helpers.Windows(name)
     with np.load(os.path.join(helpers.GOLDEN, name + "_noise.npz")) as f:
         Nz = {k: f[k] for k in f.files}
-    win = np.maximum(np.maximum(W.z["cond50"], W.z["sens50"]), Nz["noise50"]).max(1)
+    win = np.maximum(np.maximum(np.maximum(W.z["cond50"], W.z["sens50"]), Nz["noise50"]), Nz["ssens50"]).max(1)
     return np.maximum(np.maximum(z_cond_mask, z_cond_feat), win)
 
 
@@ -320,7 +321,7 @@ def test_windows_ba100k_route_stratified_targets_against_the_reference_gpu():
     """tests/golden/ba100k_windows.npz: the LIVE reference's ExplainModule (explain.py:582-820) on sparse-BFS sub-graphs of the 99 997-node
     graph, 39 route-stratified targets from n = 6 to n > 4095, its Adam state every 50 epochs and its decisions at every epoch.
     k_sparse_large - the kernel of the scaling workload's largest targets, pinned only to the dense streaming kernels in round 3 - is started
-    from the reference's state at every boundary and must reproduce its state 50 epochs later within max(1e-5, 50 c) (c: the CPU-only
+    from the reference's state at every boundary and must reproduce its state 50 epochs later within max(1e-5, 4 c) (c: the CPU-only
     conditioning probes, computed for n <= 700; 0 beyond: plain 1e-5); the targets of the LDS-resident classes run with the decision trace
     and are judged by the rules of this file."""
     from gnn_model_explainer_amd.utils import synthetic
@@ -359,18 +360,20 @@ def test_windows_ba100k_route_stratified_targets_against_the_reference_gpu():
         em, ef = helpers.window_errors(eoff, mask_rc, fm, W.boundary(w + 1, res_k))
         rows += [_judge(Dn, k, W.win * w, gates[i], None, max(em[i], ef[i]), targets[k], w, -1, cond[k, w]) for i, k in enumerate(res_k)]
     _verdict("ba100k (LDS-resident classes)", rows, Dn, helpers.BRANCH_JUMP_MAX)
-    # (b) k_sparse_large: no trace in that kernel - the plain windowed comparison, every window listed
+    # (b) k_sparse_large (round 5: its logging form records the decision trace too): the same rules, every window listed
     big_k = np.nonzero(route == 7)[0]
     job = make(big_k)
     assert set(job.route()) == {7}
     eoff = np.concatenate([[0], np.cumsum(np.diff(W.eoff)[big_k])])
-    out = []
+    out, rows = [], []
     for w in range(W.W):
-        mask_rc, fm = helpers.run_window(job, W.boundary(w, big_k), W.win)
+        mask_rc, fm, gates, pool = helpers.run_window(job, W.boundary(w, big_k), W.win, trace=True)
         em, ef = helpers.window_errors(eoff, mask_rc, fm, W.boundary(w + 1, big_k))
         out += [(int(targets[k]), int(z["size"][k]), w, float(max(em[i], ef[i])), float(cond[k, w])) for i, k in enumerate(big_k)]
+        rows += [_judge(Dn, k, W.win * w, gates[i], None, max(em[i], ef[i]), targets[k], w, -1, cond[k, w]) for i, k in enumerate(big_k)]
     err = np.asarray([o[3] for o in out])
     bound = np.maximum(TOL, ROUNDOFF_BUDGET * np.asarray([o[4] for o in out]))
     print(f"ba100k (k_sparse_large, {len(big_k)} targets, n = {int(z['size'][big_k].min())} ... {int(z['size'][big_k].max())}): {len(out)} windows against the reference's state, "
           f"{int((err <= TOL).sum())} within 1e-5, worst {err.max():.2e}; beyond 1e-5: {[o for o in out if o[3] > TOL][:20]}")
-    assert (err <= np.maximum(bound, TOL)).all(), [o for o in out if o[3] > TOL]      # every window (measured: 126 / 126 within 1e-5, worst 9.1e-7)
+    _verdict("ba100k (k_sparse_large)", rows, Dn, helpers.BRANCH_JUMP_MAX)
+    assert (err <= np.maximum(bound, TOL)).all() or all(not r["agree"] for r, e, b in zip(rows, err, bound) if e > b), [o for o in out if o[3] > TOL]

@@ -616,6 +616,28 @@ def test_mixed_launch_of_large_and_single_tile_targets(be):
         assert np.array_equal(solo.feat_mask[0], res.feat_mask[i])
 
 
+@pytest.mark.parametrize("D,H,O", [(10, 16, 16), (8, 20, 12), (10, 32, 32)])
+def test_mixed_launch_with_other_encoder_widths(be, D, H, O):
+    """Encoders whose widths are not the reference's (hidden = output = 20, D = 10) through the mixed launch - a 512-thread target, a pair
+    workgroup, single-tile targets - and k_sparse_large: widths up to the reference's take the <5, 10> instantiations with run-time widths
+    (round 5; the 32-wide <16, 16> ones carry 700-1000 B of scratch per lane), wider ones <16, 16>.  Closed form, 3 iterations."""
+    rng = np.random.default_rng(D * 100 + H)
+    sd = helpers.random_model(rng, D, H, O, 4)
+
+    def sub(n, density, t):
+        A, X = helpers.random_graph(rng, n, D, density=density)
+        m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
+        return Subgraph(A, X, 1, t, rng.integers(0, 4, n), m0)
+
+    subs = [sub(200, 0.02, 3), sub(70, 0.06, 5), sub(50, 0.1, 0), sub(20, 0.2, 2), sub(600, 0.004, 7)]
+    job = be.job(subs, sd)
+    assert list(job.route()) == [8, 5, 5, 6, 7]
+    res = job.run([s.mask0 for s in subs], Hyper(num_iters=3))
+    for i, s in enumerate(subs):
+        o = closed_form.ClosedFormOracle(s.adj, s.feat, sd, s.gt_label, s.pred_label, s.target_row, s.mask0)
+        assert np.abs(res.masked_adj[i] - o.run(3)).max() < 5e-6, i
+
+
 def test_pair_workgroups_two_256_thread_targets_per_workgroup(be, monkeypatch):
     """Targets of the 256-thread class (n <= 128) run TWO to a 512-thread workgroup of the mixed launch, each body in its half of the threads
     and of the LDS pool, every __syncthreads() a barrier for both (k_sparse_resident_mixed).  Three of them (an odd count: the last pair

@@ -75,6 +75,38 @@ def test_logging_form_mixed_launch_loss_and_gates_vs_closed_form(be, monkeypatch
         assert np.abs(res.mask[i] - o.M).max() < 2e-5          # every entry of M, on and off the edges
 
 
+def test_logging_form_of_the_large_target_kernel_loss_and_gates_vs_closed_form(be):
+    """Route 7 (k_sparse_large: n = 900, far edges run their closed recursions outside the loop) with loss logging and the decision trace:
+    the five loss terms of every iteration agree with the closed form - the size / entropy / Laplacian sums are completed by the far edges
+    (float atomics from their recursions) and by the entries off the edges (k_dead_entries) -, the gate words are the closed form's signs on
+    the rows within two hops (layer 1) and on the target and its neighbours (layer 2), the masks are the plain run's bit for bit, and every
+    entry of M (on and off the edges) is the dense optimisation's."""
+    from test_emu_kernels import _hub_case
+    sd, subs = _hub_case()
+    iters = 4
+    job = be.job(subs, sd)
+    assert list(job.route()) == [7]
+    plain = job.run([s.mask0 for s in subs], Hyper(num_iters=iters))
+    job.set_masks([s.mask0 for s in subs])
+    hy = Hyper(num_iters=iters, record_loss=True)
+    job.launch(hy, trace=True)
+    res = job.fetch(hy)
+    gates, pool = job.fetch_trace()
+    sg = subs[0]
+    assert np.array_equal(res.masked_adj[0], plain.masked_adj[0]) and np.array_equal(res.feat_mask[0], plain.feat_mask[0])
+    o = closed_form.ClosedFormOracle(sg.adj, sg.feat, sd, sg.gt_label, sg.pred_label, sg.target_row, sg.mask0)
+    lvl = _levels(sg)
+    for it in range(iters):
+        o.iterate()
+        for l, lim in ((0, 2), (1, 1)):
+            want = _gate_words(o.stages["U"][l])
+            want[lvl > lim] = 0
+            assert np.array_equal(want, gates[0][it, :, l]), (it, l)
+    tr = np.asarray(o.trace)            # total, pred, size, lap, ent, feat_size
+    assert np.allclose(res.loss[0][:, :5], tr[:, 1:6], rtol=5e-5, atol=1e-7), (res.loss[0][:, :5], tr[:, 1:6])
+    assert np.abs(res.mask[0] - o.M).max() < 2e-5
+
+
 def test_logging_form_graph_mode_loss_gates_and_pool_rows(be):
     z = np.load(helpers.GOLDEN + "/graphmode_explain.npz")
     sd = {k[2:]: z[k] for k in z.files if k.startswith("w:")}
