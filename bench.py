@@ -279,11 +279,34 @@ def bench_config4(args, dev, log):
              "k_sparse_resident<7,10,graph,64>", "k_sparse_large", "k_sparse_resident<.., 512>"]
     rcode = {3: 4, 4: 5, 5: 6, 6: 7, 7: 8}.get(top, top + 1)
     sel = route == rcode
+    # the executed-work model of the node-mode lines (gnn_model_explainer_amd/utils/work_model.py), graph mode: three full layers on all rows, max-pool
+    # head, three row-local backwards; SURVEY.md section 8(d)'s dense figure (6 n^2 (D+2H) flop with the reference's padded n = 100) as `dense_equivalent`
+    from gnn_model_explainer_amd.utils import work_model as wm
+    lat = wm.load_latency_table(ROOT)
+    idx = np.nonzero(sel)[0]
+    eoff_np = np.asarray(job._eoff)
+    S = wm.target_structure(np.full(G, n), eoff_np, rc_host, None, graph_mode=True)
+    Ssel = {kk: v[idx] for kk, v in S.items()}
+    fl = wm.executed_flops_per_iter(Ssel, job.D, job.H, job.H, job.C, 0, graph_mode=True)
+    by = wm.executed_lds_bytes_per_iter(Ssel, job.D, job.H, job.H, job.C, 0, graph_mode=True)
+    ops = wm.chain_ops_per_iter(Ssel, job.D, job.H, job.H, job.C, 0, graph_mode=True)
+    ch = wm.chain_ns_per_iter(ops, lat)
+    wpc = {4: 1, 5: 2, 6: 6}.get(rcode, 1)
+    bnd = wm.launch_bounds(fl, by, ch, args.iters, np.arange(len(idx)), wpc)
+    tb = {"flops": bnd["flops_s"], "lds": bnd["lds_s"], "chain": bnd["chain_s"]}
+    bname = max(tb, key=tb.get)
     f_alg = 6.0 * float(sel.sum()) * n * n * kagg * args.iters        # the reference optimises the padded 100 x 100 graphs
-    roof = {"kernel": names[top] + " (edge-sparse on-chip-resident optimisation, graph mode)", "bound": "mfma", "achieved": f_alg / (ms * 1e-3) / 1e12,
-            "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": f_alg / (ms * 1e-3) / MFMA_F32_PEAK, "traffic": None, "avg_launch_us": ms * 1e3,
-            "definition": "SURVEY.md section 8(d): 6 n^2 (D+2H) flop per graph and iteration with the reference's padded n = 100, of the launch's graphs / "
-                          "its duration (HIP events on its lane stream, in situ)",
+    roof = {"kernel": names[top] + " (edge-sparse on-chip-resident optimisation, graph mode)", "bound": bname, "achieved": args.iters / (ms * 1e-3),
+            "peak": args.iters / tb[bname], "unit": "iterations/s of the launch", "frac": tb[bname] / (ms * 1e-3), "traffic": None, "avg_launch_us": ms * 1e3,
+            "definition": "executed-work model (work_model.py): the largest of the lower bounds executed flops / executed LDS bytes on the busy CUs / critical chain "
+                          "of dependent operations at unloaded measured latencies (saturated regime: sum of the chains / (CUs x workgroups per CU)), over the measured "
+                          "launch time (HIP events on its lane stream, in situ)",
+            "model": {"workgroups": bnd["workgroups"], "workgroups_per_cu": wpc, "lower_bounds_ms": {kk: v * 1e3 for kk, v in tb.items()},
+                      "frac_by_bound": {kk: v / (ms * 1e-3) for kk, v in tb.items()},
+                      "chain_ns_per_iteration_mean": bnd["chain_ns_per_iter_mean"], "latency_source": lat["source"],
+                      "executed_tflops": bnd["executed_flops"] / (ms * 1e-3) / 1e12},
+            "dense_equivalent": {"mfma_frac": f_alg / (ms * 1e-3) / MFMA_F32_PEAK,
+                                 "note": "6 n^2 (D+2H) flop per graph and iteration with the reference's padded n = 100: not what the edge formulation executes"},
             "launches": {names[i]: {"targets": int((route == {3: 4, 4: 5, 5: 6, 6: 7, 7: 8}.get(i, i + 1)).sum()), "ms_total": rts[i]} for i in range(8) if rts[i]}}
     out = {"metric": "explained graphs/sec (300 mask-opt iters, graph-level explanation)", "value": value, "unit": "explained graphs/s", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -582,6 +605,8 @@ def main():
         last = None
         for _ in range(args.reps if args.reps > 0 else (9 if world == 1 else 5)):   # default: nine repetitions of a millisecond-scale region (syn1: 40 ms each), five of the sharded one
             pipe.stats.clear()
+            gc.collect()
+            gc.disable()                         # (no cyclic-GC pause inside a 80 ms timed region: the batches' objects are freed by reference counting)
             barrier()
             c0 = time.process_time()             # CPU time of every thread of this process (Python stages + the C++ draw pool)
             t0 = time.perf_counter()
@@ -589,6 +614,7 @@ def main():
                 pass
             barrier()
             dt_r = time.perf_counter() - t0
+            gc.enable()
             host_cpu_s.append((time.process_time() - c0) / args.steps)
             if dist is not None:
                 tt = torch.tensor([dt_r], device=dev)
@@ -811,7 +837,7 @@ def main():
                     "other_resident_launches": {res_names[rv]: {kk: mv[kk] for kk in ("targets", "workgroups", "measured_ms", "bound", "frac", "frac_by_bound")}
                                                 for rv, mv in models.items() if rv != top}}
         import glob
-        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_summary_{name}.json")))
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_summary_{name}*.json")))      # (the newest round's summary of this workload)
         pmc = cand[-1] if cand else ""
         if pmc:   # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc, committed summary)
             try:
