@@ -39,6 +39,20 @@ import time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the first HIP call: see gnn-model-explainer_amd/__init__.py
 os.environ.setdefault("GPU_FORCE_BLIT_COPY_SIZE", "1024")   # (KB) table uploads / result downloads as blit kernels, not SDMA: ibid.
 
+def _cpu_quota_cores():      # (gnn-model-explainer_amd/__init__.py: torch's CPU pool sized to the container's quota, before torch is imported)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        return None
+
+
+_Q = _cpu_quota_cores()
+if _Q and _Q < (os.cpu_count() or 1):
+    for _v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+        os.environ.setdefault(_v, str(max(1, int(_Q) // 2)))
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 import numpy as np
 import torch
 
@@ -372,6 +386,8 @@ def main():
                                                        "50 ms and ten consecutive runs of it spanned 134.8-166.6 k nodes/s (profiles/r03_bench_syn1_ten_runs.txt)")
     ap.add_argument("--loop-only", action="store_true", help="N = 1: report the resident-input loop rate as `value` (rounds 1-2) instead of the end-to-end rate")
     args = ap.parse_args()
+    if os.environ.get("GNNX_SWITCH_INTERVAL"):      # (measurement knob: CPython's GIL hand-over interval, default 5 ms)
+        sys.setswitchinterval(float(os.environ["GNNX_SWITCH_INTERVAL"]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -726,7 +742,7 @@ def main():
         pairs = bool((route == 5).any() and ((rt[7] and not rt[4]) or (rt[4] and not rt[5] and (route == 6).any() and not (route == 8).any())))
         mixed = bool(((route == 6).any() and (route == 8).any() and not rt[5] and rt[7]) or pairs)
         mixed_rv = 8 if rt[7] else 5
-        tiny_per_wg = 8 if (job.D + 2 * job.H) * 33 + job.C * 96 >= 1658 else 6   # sp_mix_tiny() of gnnx_sparse.hpp
+        tiny_per_wg = int(engine.get_library().gnnx_sparse_tiny_per_workgroup(int(job.D), int(job.H), int(job.C)))   # sp_mix_tiny() of gnnx_sparse.hpp
         if mixed:
             res_names[mixed_rv] = (f"k_sparse_resident_mixed (512-thread targets" + (", 256-thread targets two per workgroup" if pairs else "") +
                                    f" + {tiny_per_wg} single-tile targets per workgroup)")

@@ -16,3 +16,21 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # (the runtime's upper lim
 # inside the pipeline, end to end 112-141 k -> 139-164 k nodes/s (one session, alternating runs); 0 (everything on SDMA) gave
 # 92-105 k.  The 8 MB of initial masks per batch stay on SDMA.  Effective when set before the first HIP call.
 _os.environ.setdefault("GPU_FORCE_BLIT_COPY_SIZE", "1024")
+
+# A container's CPU quota (cgroup cpu.max; the GPU boxes: 16 cores of a 256-CPU host).  torch sizes its intra-op pool from the CPU COUNT: one
+# parallel CPU op wakes 128 OpenMP threads that spin after the region, the cgroup spends its 1.6 core-seconds within a few milliseconds and the
+# kernel freezes EVERY thread of the process until the next 100 ms period - 20-batch timed regions of 169 k beside 250 k nodes/s
+# (profiles/r05_cpu_quota_throttling.txt: nr_throttled rises in every run).  Before torch is imported: size the pool to the quota.
+def _cpu_quota_cores():
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        return None
+
+
+_q = _cpu_quota_cores()
+if _q and _q < (_os.cpu_count() or 1):
+    for _v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+        _os.environ.setdefault(_v, str(max(1, int(_q) // 2)))
+    _os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")

@@ -137,6 +137,8 @@ static void pin_free(void* ptr) {
     if (it == g_pin.bucket_of.end()) return;
     g_pin.free_blocks[it->second].push_back(ptr);
 }
+extern "C" int gnnx_sparse_tiny_per_workgroup(int32_t D, int32_t H, int32_t C) { return gnnx::sp_mix_tiny(D, H, C); }
+
 extern "C" int gnnx_pool_trim(void) {
     DevPool& P = pool_here();
     {

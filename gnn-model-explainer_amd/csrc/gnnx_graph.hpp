@@ -62,7 +62,7 @@ __device__ __forceinline__ int kh_block_scan_exclusive(int v, int tid, int* s_wa
 // round 5 - 256 (up to 8192 nodes, 3 KB): a pipelined job's k-hop pass has to find room on CUs that optimisation workgroups fill for 2.4 ms at
 // a time; with 48 KB of LDS three of its workgroups fit a freed CU, with 3 KB as many as its wave slots allow.
 template <bool EMIT, int LDSW>
-__global__ __launch_bounds__(KH_THREADS) void k_khop(KhopArgs a) {
+__global__ __launch_bounds__(KH_THREADS) GNNX_SERVICE_ATTR void k_khop(KhopArgs a) {
     constexpr bool IN_LDS = LDSW > 0;
     __shared__ uint32_t s_bm[IN_LDS ? 3 * LDSW : 1];
     __shared__ int s_wave[KH_THREADS / 64];

@@ -118,6 +118,26 @@ struct Params {
     float c_size, c_feat_size, c_ent, c_lap;
 };
 
+// Room beside a resident workgroup (round 5).  A workgroup of the edge-sparse resident kernels used to take ALL of its compute unit: 162 KB of
+// the 160 KB + of LDS and 2 waves x 256 registers per lane and SIMD.  The short kernels of a pipelined job's prepare stage (k-hop, packing, edge
+// counts, edge lists of the NEXT batches) then waited for a compute unit to drain - 5 to 30 times their own duration (profiles/r05_kernel_stats_
+// syn1.csv), and three preparing threads could not keep the optimisations fed.  Now the mixed resident kernel is capped at GNNX_MIXED_NUM_VGPR
+// registers and its pool leaves 5 KB of LDS, and the service kernels are capped at GNNX_SERVICE_NUM_VGPR: their workgroups find a place BESIDE
+// a resident workgroup (whose waves issue 22 % of the time).  The attribute counts HALF of gfx950's unified register file (112 -> 224 per lane).
+#if defined(__HIPCC__)
+#define GNNX_NUM_VGPR_ATTR(n) __attribute__((amdgpu_num_vgpr(n)))
+#else
+#define GNNX_NUM_VGPR_ATTR(n)      // (the CPU emulator of tests/emu compiles the same sources)
+#endif
+#ifndef GNNX_SERVICE_NUM_VGPR
+#define GNNX_SERVICE_NUM_VGPR 16   // 32 registers per lane: two service waves fit the 64 a resident pair of waves leaves on a SIMD
+#endif
+#if GNNX_SERVICE_NUM_VGPR
+#define GNNX_SERVICE_ATTR GNNX_NUM_VGPR_ATTR(GNNX_SERVICE_NUM_VGPR)
+#else
+#define GNNX_SERVICE_ATTR
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

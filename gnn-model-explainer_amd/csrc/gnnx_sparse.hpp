@@ -39,7 +39,10 @@ constexpr int SP_THREADS = 1024;             // the largest class (bounds shared
 __host__ __device__ constexpr int sp_qmax(int nt) { return nt == 512 ? 4 : 2; }             // undirected edges per thread
 __host__ __device__ constexpr int sp_ld_max(int nt) { return nt == 512 ? 512 : 32 * (nt / 64); }
 constexpr int SP_LD_MAX = 32 * (SP_THREADS / 64);
-__host__ __device__ constexpr int sp_pool_floats(int nt) { return nt >= 512 ? 39168 : nt >= 256 ? 18432 : 5120; }
+#ifndef GNNX_POOL512_FLOATS       // 38 272 floats + SparseFixed = 158.5 KB: 5.3 KB of the compute unit's LDS stay free for service kernels (39 168 filled it)
+#define GNNX_POOL512_FLOATS 38272
+#endif
+__host__ __device__ constexpr int sp_pool_floats(int nt) { return nt >= 512 ? GNNX_POOL512_FLOATS : nt >= 256 ? 18432 : 5120; }
 constexpr int SP_GATHER_UNROLL = 2;          // entries in flight per lane in the sparse gathers (4: measured, no gain)
 // Forms measured one by one in round 4 (tools/gpu_r4n.sh ... gpu_r4r.sh; syn1 launch 3.18 -> 2.84 ms); the losers are gone, these stay switches:
 constexpr bool SP_RELU_STORE = true;         // algebraic form: sU1 holds relu(U1), the row's owner recomputes its own U1 in the backward
@@ -1793,10 +1796,12 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : 2) void k_sparse_resident(Para
 __host__ __device__ inline int sp_model_floats(int D, int H, int C) { return (D + 2 * H) * 33 + C * 96; }
 __host__ __device__ inline int sp_fixed_floats() { return (int)((sizeof(SparseFixed) + 3) / 4); }
 // single-tile targets per workgroup: eight (one per wave) when eight slices (a 64-thread pool minus the shared model block)
-// and their SparseFixed blocks fit the 512-thread pool, else six
+// and their SparseFixed blocks fit the 512-thread pool, else as many as fit (at least five)
 __host__ __device__ inline int sp_mix_tiny(int D, int H, int C) {
     const int wsz = sp_model_floats(D, H, C);
-    return wsz + 8 * (sp_pool_floats(64) - wsz) + 8 * sp_fixed_floats() <= sp_pool_floats(512) ? 8 : 6;
+    for (int k = 8; k > 5; --k)
+        if (wsz + k * (sp_pool_floats(64) - wsz) + k * sp_fixed_floats() <= sp_pool_floats(512)) return k;
+    return 5;
 }
 // Pair workgroups (round 5): a target of the 256-thread class (n <= 128, <= 512 edges, 72 KB of LDS) used to take a whole 512-thread workgroup
 // - a whole CU for the 2.4 ms of its chain - whenever its batch also held larger targets, because a SEPARATE 256-thread launch does not pack:
@@ -1805,15 +1810,23 @@ __host__ __device__ inline int sp_mix_tiny(int D, int H, int C) {
 // [256, 512) the other, each in its half of the pool.  s_barrier is workgroup-wide, and the bodies are the same code with the same barrier
 // sequence (see sparse_resident_body: pair_flag), so every __syncthreads() is simply a barrier for both - the pair moves in lockstep,
 // phase by phase, and a CU holds two targets.  On syn1 60 of the 101 larger targets qualify: 141 -> 111 workgroups per batch.
+#ifndef GNNX_MIXED_NUM_VGPR      // (see GNNX_NUM_VGPR_ATTR in gnnx_kernels.hpp; 0 = uncapped, 256 registers per lane)
+#define GNNX_MIXED_NUM_VGPR 112
+#endif
+#if GNNX_MIXED_NUM_VGPR
+#define GNNX_MIXED_ATTR GNNX_NUM_VGPR_ATTR(GNNX_MIXED_NUM_VGPR)
+#else
+#define GNNX_MIXED_ATTR
+#endif
 template <int DQ, int HQ, int XC = 0, bool LOG = false, bool EX = true>
-__global__ __launch_bounds__(512) void k_sparse_resident_mixed(Params p, const int32_t* big_ids, int n_big, const int32_t* tiny_ids,
+__global__ __launch_bounds__(512) GNNX_MIXED_ATTR void k_sparse_resident_mixed(Params p, const int32_t* big_ids, int n_big, const int32_t* tiny_ids,
                                                                int n_tiny, const float* adam_tab, int per_wg, int wsz,
                                                                const int32_t* pair_ids = nullptr, int n_pair = 0) {
     __shared__ float pool[sp_pool_floats(512)];
     __shared__ SparseFixed sh_big;
     __shared__ int pair_flag;
-    static_assert(6 * sp_pool_floats(64) + 6 * (int)((sizeof(SparseFixed) + 3) / 4) <= sp_pool_floats(512),
-                  "six single-tile slices and their SparseFixed blocks must fit the 512-thread pool whatever the model");
+    static_assert(5 * sp_pool_floats(64) + 5 * (int)((sizeof(SparseFixed) + 3) / 4) <= sp_pool_floats(512),
+                  "five single-tile slices and their SparseFixed blocks must fit the 512-thread pool whatever the model");
     static_assert(2 * sp_pool_floats(256) + (int)((sizeof(SparseFixed) + 3) / 4) <= sp_pool_floats(512),
                   "two 256-thread pools and the second body's SparseFixed block must fit the 512-thread pool");
     if ((int)blockIdx.x < n_big) {
@@ -1857,7 +1870,7 @@ __global__ __launch_bounds__(512) void k_sparse_resident_mixed(Params p, const i
 // rowdeg / rowcnt / ecount (gnnx_pack_csr_analyze: the packing kernel has just counted every row): the degrees are READ instead of
 // rescanned from the dense block, and wave 0 turns the rows' upper-triangle counts into row starts + the target's edge count (what
 // k_edge_rowscan does as a launch of its own) - one per-target launch for the routing figures and the edge layout together.
-__global__ __launch_bounds__(256) void k_count_edges(const TargetMeta* meta, const float* A, int32_t* out, const float* X = nullptr,
+__global__ __launch_bounds__(256) GNNX_SERVICE_ATTR void k_count_edges(const TargetMeta* meta, const float* A, int32_t* out, const float* X = nullptr,
                                                      int32_t* xconst = nullptr, const int32_t* rowdeg = nullptr, int32_t* rowcnt = nullptr,
                                                      int64_t* ecount = nullptr) {
     __shared__ int deg[SP_LD_MAX];

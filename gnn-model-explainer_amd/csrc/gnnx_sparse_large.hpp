@@ -1152,7 +1152,7 @@ __global__ __launch_bounds__(256) void k_row_degrees(const float* A, const ConvT
 // (NTH threads per workgroup: 1024 for the large ranges; round 5: targets of up to 512 nodes take <0, 512, 256> - 2.5 KB of LDS and four
 // waves instead of 20 KB and sixteen, so that a pipelined job's analysis finds room on a chip full of optimisation workgroups.)
 template <int NLO, int NMAX, int NTH = 1024>
-__global__ __launch_bounds__(NTH) void k_count_edges_large(const TargetMeta* meta, const float* A, const int32_t* rowdeg, int32_t* out) {
+__global__ __launch_bounds__(NTH) GNNX_SERVICE_ATTR void k_count_edges_large(const TargetMeta* meta, const float* A, const int32_t* rowdeg, int32_t* out) {
     constexpr int NW = NTH / 64, UN = 8;   // the dense rows of t and its neighbours are scanned for the hop levels: NW waves x 8 chunks in flight
     __shared__ int deg[NMAX + 1];
     __shared__ unsigned char level[NMAX + 1];

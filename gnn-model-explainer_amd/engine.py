@@ -168,6 +168,7 @@ _API = {
     "gnnx_edge_counts": (ctypes.c_int, [ctypes.c_void_p] * 4),
     "gnnx_gather_edges": (ctypes.c_int, [ctypes.c_void_p] * 9 + [ctypes.c_size_t, ctypes.c_void_p]),
     "gnnx_pool_trim": (ctypes.c_int, []),
+    "gnnx_sparse_tiny_per_workgroup": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "gnnx_set_service_stream": (ctypes.c_int, [ctypes.c_void_p]),
     "gnnx_lane_stream": (ctypes.c_void_p, [ctypes.c_int32]),
     "gnnx_stream_create_cu_mask": (ctypes.c_void_p, [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int32]),
@@ -990,15 +991,15 @@ def cpu_quota_cores():
 
 def default_rng_threads():
     """Host threads for the seeded mask draw: embarrassingly parallel over targets, but beyond ~32 threads the hand-off costs more than it
-    saves (tools/probe_rng.py), and never more than twice the cores the process may actually use (a container's CPU quota: the GPU box gives 16
+    saves (tools/probe_rng.py), and never more than half the cores the process may actually use (a container's CPU quota: the GPU box gives 16
     of its host's 256 CPUs - tools/probe_rng_big.py).  GNNX_RNG_THREADS overrides."""
     env = os.environ.get("GNNX_RNG_THREADS")
     if env:
         return max(1, int(env))
     cores = (os.cpu_count() or 2) // 2
     q = cpu_quota_cores()
-    if q:
-        cores = min(cores, int(2 * q))
+    if q:      # half the quota: three preparing threads draw at once, and a cgroup that spends its quota inside a 100 ms period is frozen until the
+        cores = min(cores, max(2, int(q) // 2))      # next one (profiles/r05_cpu_quota_throttling.txt; 2 x quota until round 5)
     return max(1, min(32, cores))
 
 

@@ -327,6 +327,11 @@ int gnnx_debug_spin(void* stream, int32_t micros);
  * job: hipFree synchronises the device); this returns the idle ones of the current device to the driver. */
 int gnnx_pool_trim(void);
 
+/* Packing of the one mixed launch of the edge-sparse resident kernels (gnnx_sparse.hpp: k_sparse_resident_mixed, sp_mix_tiny): how many
+ * single-tile targets (n <= 32) share one 512-thread workgroup for a model of these widths - 8 when their LDS slices and the shared model
+ * block fit the pool, else as many as fit (>= 5).  bench.py maps targets to workgroups with it for the executed-work roofline. */
+int gnnx_sparse_tiny_per_workgroup(int32_t D, int32_t H, int32_t C);
+
 const char* gnnx_last_error(void);
 const char* gnnx_version(void);
 
