@@ -655,7 +655,8 @@ def main():
                                                       "host core-seconds / quota, not by the optimisation"}
         e2e_stats["rng_threads"] = pipe.rng_threads
         e2e_stats["prepare_workers"] = pipe.prepare_workers
-        e2e_stats["optimisations_in_flight"] = pipe.depth
+        e2e_stats["optimisations_in_flight"] = pipe.depth_now
+        e2e_stats["optimisations_in_flight_rule"] = ("auto: ceil(1.3 x 256 CUs / CUs one launch keeps busy), 2..5" if pipe.auto_depth else "fixed")
         e2e_stats["rng_threads_big_batches"] = pipe.rng_threads_big
         e2e_stats["stream_candidates_rejected"] = len(pipe._rejected)          # (hardware-queue calibration of the pipeline's six streams)
         e2e_stats["streams_without_own_queue"] = getattr(pipe, "queue_fallbacks", 0)

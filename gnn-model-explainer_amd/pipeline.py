@@ -27,11 +27,11 @@ from . import engine
 
 
 class _Prepared:
-    __slots__ = ("targets", "job", "dn", "ready", "rc", "eoff", "E", "times", "error")
+    __slots__ = ("targets", "job", "dn", "ready", "rc", "eoff", "E", "times", "error", "launch_cus")
 
 
 class BatchPipeline:
-    def __init__(self, graph, state_dict, labels, hyper, n_hops=3, seed_base=1000, rng_threads=None, depth=4, prepare_workers=3, reserve_cus=0, lib=None,
+    def __init__(self, graph, state_dict, labels, hyper, n_hops=3, seed_base=1000, rng_threads=None, depth=None, prepare_workers=2, reserve_cus=0, lib=None,
                  device_hook=None, rng_threads_big=None, edge_draw=None, edge_draw_min_values=2e7, device_walk=None):
         """graph: engine.DeviceGraph (resident); labels [N]: the label the prediction loss uses (explain.py:750-753); the initial
         mask of target v is drawn from a generator seeded with seed_base + v (the seed protocol of the golden runs)."""
@@ -65,10 +65,19 @@ class BatchPipeline:
         # cost 0.64 core-seconds per step with the host walk, which bound a node's ranks to its CPU quota beyond two GPUs.  Needs the
         # pair-staging property of the host's normal_ (checked once per process); device_walk=False / GNNX_PIPE_DEVICE_WALK=0: the host walk.
         self.device_walk = bool(int(os.environ.get("GNNX_PIPE_DEVICE_WALK", "1"))) if device_walk is None else bool(device_walk)
-        depth = int(os.environ.get("GNNX_PIPE_DEPTH", depth))                        # (measurement knobs)
+        # Optimisations in flight.  depth=None (default): as many as keep the chip full and no more - ceil(1.3 x 256 CUs / the compute units ONE
+        # launch keeps busy), between 2 and 5, re-evaluated per batch (_launch_cus): every further launch in flight only queues behind the
+        # others and lengthens the fill and drain of a short job.  Measured (profiles/r05_pipeline_workers_depth_room.txt): syn1 (116 workgroups
+        # per launch) 20-batch regions 234-241 k nodes/s at four in flight, 249-250 k at three; Tree-Cycles (360 single-wave workgroups, six per
+        # CU) 365-373 k at three, 449-455 k at four or more; steady state (300 batches) indifferent.  A number fixes it.
+        env_depth = os.environ.get("GNNX_PIPE_DEPTH")                               # (measurement knobs)
+        if env_depth:
+            depth = int(env_depth)
         reserve_cus = int(os.environ.get("GNNX_PIPE_RESERVE", reserve_cus))
         prepare_workers = int(os.environ.get("GNNX_PIPE_WORKERS", prepare_workers))
-        self.depth = max(1, int(depth))
+        self.auto_depth = depth is None
+        self.depth = 5 if depth is None else max(1, int(depth))     # streams (2 prepare + 1 fetch + 5 optimise = the 8 hardware queues)
+        self.depth_now = 3 if depth is None else self.depth
         self.lib = lib if lib is not None else engine.get_library()
         dev = graph.feat.device
         self.device = dev
@@ -167,6 +176,21 @@ class BatchPipeline:
             self._pinned[key] = buf
         return buf[:numel]
 
+    @staticmethod
+    def _launch_cus(route, num_cus=256):
+        """Compute units one optimisation launch of this batch keeps busy (an estimate from the routing: gnnx_sparse.hpp's classes - a 512-thread
+        target, a PAIR of 256-thread targets or eight single-wave targets per workgroup of the mixed launch, one workgroup per CU; alone, the
+        single-wave class packs six workgroups per CU and the 256-thread class two)."""
+        route = np.asarray(route)
+        n8, n5, n6 = int((route == 8).sum()), int((route == 5).sum()), int((route == 6).sum())
+        n47 = int(np.isin(route, (4, 7)).sum())
+        other = int((~np.isin(route, (4, 5, 6, 7, 8))).sum())
+        if n8 or (n5 and n6):
+            cus = n8 + (n5 + 1) // 2 + (n6 + 7) // 8
+        else:
+            cus = (n5 + 1) // 2 + (n6 + 5) // 6
+        return min(cus + n47, num_cus) if not other else num_cus
+
     # -- stage 1 -----------------------------------------------------------------------------------------------------------
     def _prepare(self, targets, k, s_prep):
         p = _Prepared()
@@ -217,6 +241,7 @@ class BatchPipeline:
             rc_host[:E].copy_(job._rc[:E], non_blocking=True)
             p.times["edge_layout_ms"] = (time.perf_counter() - t1b) * 1e3
             p.times["plan_pack_route_layout_ms"] = (time.perf_counter() - t1) * 1e3
+            p.launch_cus = self._launch_cus(job.route())
             if edges_only and not np.isin(job.route(), (4, 5, 6, 7, 8)).all():
                 edges_only = False        # a target streams dense blocks: it needs every entry of its mask
                 th.start()
@@ -313,7 +338,7 @@ class BatchPipeline:
 
     def run(self, batches):
         """batches: iterable of int arrays of target node ids.  Yields one engine.EdgeMasks per batch, in order."""
-        q = queue.Queue(maxsize=self.depth + 1)
+        q = queue.Queue(maxsize=min(self.depth, 3) + 1)      # prepared batches waiting for their launch
         th = threading.Thread(target=self._worker, args=(iter(batches), q), daemon=True)
         th.start()
         pending = deque()
@@ -335,9 +360,11 @@ class BatchPipeline:
                 break
             if p.error is not None:
                 raise p.error
+            if self.auto_depth:
+                self.depth_now = int(min(self.depth, max(2, -(-(13 * 256) // (10 * max(1, p.launch_cus))))))
             pending.append((p,) + self._launch(p, slot))
             slot = (slot + 1) % (self.depth * 8)      # (a multiple of the optimise streams: launch k goes to stream k mod depth)
-            while len(pending) > self.depth:
+            while len(pending) > self.depth_now:
                 yield finish(pending.popleft())
         while pending:
             yield finish(pending.popleft())

@@ -204,3 +204,15 @@ def test_denoise_graph_matches_reference_postprocessing():
             assert sorted(G.nodes()) == list(gx[f"{t}:denoised_nodes"])
             edges = sorted((min(u, v), max(u, v)) for u, v in G.edges())
             assert edges == [tuple(e) for e in gx[f"{t}:denoised_edges"]]
+
+
+def test_pipeline_launch_cus_estimate():
+    """pipeline.BatchPipeline._launch_cus: compute units one optimisation launch keeps busy, from the routing (the automatic number of
+    optimisations in flight is ceil(1.3 x 256 / it), between 2 and 5)."""
+    from gnn_model_explainer_amd.pipeline import BatchPipeline
+    cus = BatchPipeline._launch_cus
+    assert cus([8] * 54 + [5] * 50 + [6] * 296) == 54 + 25 + 37          # syn1's batch: the mixed launch
+    assert cus([6] * 360) == 60                                          # single-wave class alone: six workgroups per CU
+    assert cus([5] * 10) == 5 and cus([5] * 3 + [6] * 9) == 2 + 2
+    assert cus([7] * 3 + [8] * 2) == 5
+    assert cus([8] * 5000) == 256 and cus([0, 8]) == 256                 # saturating launches, streaming targets
