@@ -13,10 +13,11 @@
 //                     + (sum_e (q_e + q_mirror(e)) u_k) W_att^T  (att_ik = u_i . u_k: u_i sits on both sides)
 //
 // followed by the same regularisers, symmetrisation and Adam step as k_mask (gnnx_kernels.hpp), edge by edge.  Rows are worked
-// on by half-waves (lane = feature column; the two halves of a wave take two rows in lockstep, padded to the longer one), the
-// per-edge dot products are 32-lane butterflies; every sum has a fixed order (deterministic, batch-invariant).  This is a
-// correct, parallel-over-targets kernel for a flag the reference's experiments rarely use, not a roofline kernel: its time is
-// the chain of dependent row gathers of the busiest row pair.
+// on by half-waves (lane = feature column; the two halves of a wave work in lockstep, padded to the longer one), the per-edge dot
+// products are 32-lane butterflies; every sum has a fixed order (deterministic, batch-invariant).  Round 5: the phases walk only the
+// rows their results are read from (hop pruning) in chunks of at most 32 entries (a hub row is shared by several half-waves) - see
+// k_att.  The row arrays still live in the workspace (L2): this is the complete, parallel kernel for a flag the reference's experiments
+// rarely use, not a roofline kernel.
 #pragma once
 #include "gnnx_kernels.hpp"
 
@@ -26,15 +27,20 @@ struct AttScratch {
     const float* watt;       // [3][32][32] zero padded, W_att of layer l at l * 1024 + b * 32 + a  (b = input column)
     const long long* eoff;   // [T + 1] first directed edge of target t in the edge arrays
     int32_t* rowptr;         // [R + T]: the n + 1 row pointers of target t start at offR + t (relative to eoff[t])
-    int32_t *col, *mir;      // [E] column of the entry, position of the mirror entry (k, i) (relative to eoff[t])
+    int32_t *col, *mir;      // [E] column of the entry (bits 16-17: the column's level, see lev), position of the mirror entry (k, i) (relative to eoff[t])
     float *w, *s[3], *q, *dA;  // [E]
     float *xin[3], *u[3], *U[3], *dZ, *dX;  // [R][32]
     float* rn[3];            // [R]
+    // round 5: hop pruning and chunked rows
+    int32_t* lev;            // [R] hop distance of the row from the target's node, capped at 3 (graph mode: 0 everywhere)
+    int32_t* order;          // [R + T] the rows sorted by level (stable): the rows within k hops are the prefix [0, nr[k])
+    int32_t* chunk;          // [R + T + E / 32 + T] row | (first entry >> 5) << 16 of every chunk of <= 32 entries, rows in `order`
+    int32_t *mrow, *mfirst;  // [E / 32 + T] the rows of more than 32 entries (in `order`) and their first chunk
+    float* pacc;             // [R + T + E / 32 + T][32] partial row sums of the chunks of those rows
 };
 
 // sum over the 32 lanes of a half-wave, in every lane: four DPP rotations inside each 16-lane row (register speed) and ONE cross-row
-// shuffle, instead of five ds_bpermute round trips - this reduction sits on the per-edge chain of every gather below (a hub row of 250
-// edges x three layers x forward and backward)
+// shuffle, instead of five ds_bpermute round trips - this reduction sits on the per-edge chain of every gather below
 template <int S>
 __device__ __forceinline__ float att_row_ror(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + S, 0xf, 0xf, false));
@@ -51,6 +57,17 @@ __device__ __forceinline__ float att_sum32(float v) {
 constexpr int ATT_THREADS = 1024;
 constexpr int ATT_UN = 8;    // edges whose row loads are in flight together in the gathers of k_att
 
+// Round 5 (what 130 ms per 400-target syn1 batch were): every phase walked ALL rows of the sub-graph, and a half-wave walked ALL entries of its
+// row - the 250 entries of a hub row one after the other, 0.12 us each, while the other 31 half-waves waited at the barrier: 30 us per phase,
+// twelve phases per iteration.
+//  * HOP PRUNING (node mode).  The loss reads row t of layer 3 only: layer l's output is needed on the rows within 2 - l hops of t (its
+//    inputs one hop further), and the backward of layer l has dZ on those rows and passes dXin to the rows within 3 - l hops.  The rows are
+//    sorted by hop distance once (`order`), every phase walks a prefix.  Rows outside a phase's set are not touched - what the old kernel
+//    computed there was multiplied by zero or never read; the guards below (levels of a row / of an entry's column) keep stale values of
+//    earlier phases out.  Graph mode: every row is at level 0 (the max-pools read all rows).
+//  * CHUNKED ROWS.  The unit of work of an edge phase is a CHUNK of at most 32 entries of one row; the 8 chunks of a hub row go to 8
+//    half-waves.  A row of one chunk finishes as before; the partial sums of the others go through `pacc` and a second, short pass adds them in
+//    chunk order (fixed order: deterministic, batch-invariant) and runs the row-local part.
 __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, const float* __restrict__ adam) {
     constexpr int NWV = ATT_THREADS / 64;
     __shared__ float sW[3][32 * 33], sWa[3][32 * 33], sb[3][32];
@@ -59,6 +76,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
     __shared__ float emb[96], gcls[CMAX], dEs[96];
     __shared__ int erow[96];
     __shared__ float part[2 * NWV][32];
+    __shared__ int s_nr[4], s_nch[4], s_nm[4];   // rows / chunks / rows of several chunks within k hops, k = 0 .. 3
     const int t = blockIdx.x;
     const TargetMeta tm = p.meta[t];
     const int n = tm.n, ld = tm.ld, tr = tm.t;
@@ -72,6 +90,13 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
     float* w = a.w + eb;
     float* q = a.q + eb;
     float* dA = a.dA + eb;
+    int32_t* lev = a.lev + tm.offR;
+    int32_t* order = a.order + tm.offR + t;
+    const size_t cbase = (size_t)tm.offR + t + (size_t)(eb >> 5);
+    int32_t* chunk = a.chunk + cbase;
+    float* pacc = a.pacc + cbase * 32;
+    int32_t* mrow = a.mrow + (eb >> 5) + t;
+    int32_t* mfirst = a.mfirst + (eb >> 5) + t;
     const size_t ro = (size_t)tm.offR * FS;
     const float* X = p.X + ro;
     const float* Ad = p.A + tm.offQ;
@@ -125,6 +150,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
             pos += __popcll(bal);
         }
     }
+    for (int i = tid; i < n; i += ATT_THREADS) lev[i] = (p.graph_mode || i == tr) ? 0 : 3;
     __syncthreads();
     // mirror positions, Adam moments of the live entries, the first masked adjacency
     for (int i = wave; i < n; i += NWV) {
@@ -144,13 +170,84 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
         }
     }
     __syncthreads();
+    // hop distances from the target's node (two rounds over the rows of the current level; concurrent writers store the same value)
+    if (!p.graph_mode)
+        for (int round = 0; round < 2; ++round) {
+            for (int i = wave; i < n; i += NWV)
+                if (lev[i] == round)
+                    for (int e = rowptr[i] + lane; e < rowptr[i + 1]; e += 64)
+                        if (lev[col[e]] > round + 1) lev[col[e]] = round + 1;
+            __syncthreads();
+        }
+    // every entry carries its column's level; rows sorted by level, cut into chunks
+    for (int i = wave; i < n; i += NWV)
+        for (int e = rowptr[i] + lane; e < rowptr[i + 1]; e += 64) col[e] |= lev[col[e]] << 16;
+    if (tid == 0) {
+        int pos = 0, nc = 0, nm = 0;
+        for (int L = 0; L < 4; ++L) {
+            for (int i = 0; i < n; ++i)
+                if (lev[i] == L) {
+                    order[pos++] = i;
+                    const int deg = rowptr[i + 1] - rowptr[i];
+                    if (deg > 32) {
+                        mrow[nm] = i;
+                        mfirst[nm] = nc;
+                        ++nm;
+                    }
+                    int j0 = 0;
+                    do {   // (a row without entries still has its row-local part: one empty chunk)
+                        chunk[nc++] = i | ((j0 >> 5) << 16);
+                        j0 += 32;
+                    } while (j0 < deg);
+                }
+            s_nr[L] = pos;
+            s_nch[L] = nc;
+            s_nm[L] = nm;
+        }
+    }
+    __syncthreads();
     const float inv_n2 = 1.0f / ((float)n * (float)n);
+
+    // the chunk this half-wave works on in trip c0 of a walk over the first NC chunks: its row, the row's entries, the chunk's entry records
+    // one per lane (coalesced; handed out by shuffles in the gathers).  `cnt` is the trip count of the WAVE (the longer of its two chunks).
+    struct Chunk {
+        int c, i, e0, deg, j0, mine, cnt;
+        bool on, multi;
+    };
+    auto chunk_of = [&](int c0, int NC) {
+        Chunk k;
+        k.c = c0 + hf;
+        k.on = k.c < NC;
+        const int rec = k.on ? chunk[k.c] : 0;
+        k.i = rec & 0xffff;
+        k.j0 = (rec >> 16) << 5;
+        k.e0 = k.on ? rowptr[k.i] : 0;
+        k.deg = k.on ? rowptr[k.i + 1] - k.e0 : 0;
+        const int left = k.deg - k.j0;
+        k.mine = left < 0 ? 0 : (left < 32 ? left : 32);
+        const int other = __shfl_xor(k.mine, 32);
+        k.cnt = k.mine > other ? k.mine : other;
+        k.multi = k.deg > 32;
+        return k;
+    };
+    // the rows of several chunks among the first NM of them: their partial sums added in chunk order
+    auto multi_sum = [&](int m0, int NM, int& i, bool& on) {
+        const int m = m0 + hf;
+        on = m < NM;
+        i = on ? mrow[m] : 0;
+        const int c1 = on ? mfirst[m] : 0;
+        const int nck = on ? (rowptr[i + 1] - rowptr[i] + 31) >> 5 : 0;
+        const int onck = __shfl_xor(nck, 32), trip = nck > onck ? nck : onck;
+        float acc = 0.0f;
+        for (int k = 0; k < trip; ++k) acc += (k < nck) ? pacc[(size_t)(c1 + k) * 32 + ln] : 0.0f;
+        return acc;
+    };
 
     for (int iter = 0; iter < p.num_iters; ++iter) {
         // ======== forward ========
         if (tid < 32) phi[tid] = (tid < D) ? sigmoidf_(fcur[tid]) : 0.0f;
         __syncthreads();
-        // masked features and their attention projection (row-local)
+        // masked features and their attention projection (row-local; every row: layer 1's gathers reach three hops)
         for (int i0 = 2 * wave; i0 < n; i0 += 2 * NWV) {
             const int i = i0 + hf;
             const bool on = i < n;
@@ -168,46 +265,8 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
             const float* xin = a.xin[l] + ro;
             const float* ul = a.u[l] + ro;
             float* sl = a.s[l] + eb;
-            for (int i0 = 2 * wave; i0 < n; i0 += 2 * NWV) {
-                const int i = i0 + hf;
-                const bool ron = i < n;
-                const int e0 = ron ? rowptr[i] : 0, deg = ron ? rowptr[i + 1] - e0 : 0;
-                const int odeg = __shfl_xor(deg, 32), trip = deg > odeg ? deg : odeg;
-                const float ui = ron ? ul[(size_t)i * FS + ln] : 0.0f;
-                float acc = 0.0f;
-                for (int j0 = 0; j0 < trip; j0 += 32) {
-                    // this chunk's edge records, one per lane (coalesced), handed out by shuffles: the gathers of successive
-                    // edges do not wait for an index load each
-                    const int je = j0 + ln;
-                    const bool eon = je < deg;
-                    const int ck = eon ? col[e0 + je] : 0;
-                    const float cw = eon ? w[e0 + je] : 0.0f;
-                    float cs = 0.0f;
-                    const int cnt = (trip - j0 < 32) ? trip - j0 : 32;
-                    // ATT_UN edges per trip: the row loads of all of them (L2: the row arrays live in the workspace) are issued before the first
-                    // butterfly, so a hub row costs a fraction of one L2 round trip per edge instead of a whole one; the products are taken in the
-                    // same order as one edge per trip (bit-identical sums)
-                    for (int jj = 0; jj < cnt; jj += ATT_UN) {
-                        int kk[ATT_UN];
-                        float uk[ATT_UN], xk[ATT_UN];
-#pragma unroll
-                        for (int u = 0; u < ATT_UN; ++u) kk[u] = __shfl(ck, hbase | ((jj + u < cnt) ? jj + u : jj));
-#pragma unroll
-                        for (int u = 0; u < ATT_UN; ++u) {
-                            uk[u] = ul[(size_t)kk[u] * FS + ln];
-                            xk[u] = xin[(size_t)kk[u] * FS + ln];
-                        }
-#pragma unroll
-                        for (int u = 0; u < ATT_UN; ++u)
-                            if (jj + u < cnt) {     // uniform over the wave (cnt is)
-                                const float se = att_sum32(ui * uk[u]);
-                                acc = fmaf(__shfl(cw, hbase | (jj + u)) * se, xk[u], acc);
-                                cs = (jj + u == ln) ? se : cs;
-                            }
-                    }
-                    if (eon) sl[e0 + je] = cs;
-                }
-                // row-local: Y = Z W + b, U = Y / max(|Y|, 1e-12), the next layer's input and its attention projection
+            // row-local: Y = Z W + b, U = Y / max(|Y|, 1e-12), the next layer's input and its attention projection
+            auto rowlocal = [&](int i, bool ron, float acc) {
                 float y = 0.0f;
                 for (int b = 0; b < din; ++b) y = fmaf(__shfl(acc, hbase | b), sW[l][b * 33 + ln], y);
                 y = (ln < dout) ? y + sb[l][ln] : 0.0f;
@@ -225,6 +284,45 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
                         a.u[l + 1][ro + (size_t)i * FS + ln] = uu;
                     }
                 }
+            };
+            const int NC = s_nch[2 - l], NM = s_nm[2 - l];
+            for (int c0 = 2 * wave; c0 < NC; c0 += 2 * NWV) {
+                const Chunk k = chunk_of(c0, NC);
+                const float ui = k.on ? ul[(size_t)k.i * FS + ln] : 0.0f;
+                const bool eon = ln < k.mine;
+                const int ck = eon ? (col[k.e0 + k.j0 + ln] & 0xffff) : 0;
+                const float cw = eon ? w[k.e0 + k.j0 + ln] : 0.0f;
+                float cs = 0.0f, acc = 0.0f;
+                // ATT_UN edges per trip: the row loads of all of them (L2: the row arrays live in the workspace) are issued before the first
+                // butterfly, so an entry costs a fraction of one L2 round trip; the products are taken in entry order
+                for (int jj = 0; jj < k.cnt; jj += ATT_UN) {
+                    int kk[ATT_UN];
+                    float uk[ATT_UN], xk[ATT_UN];
+#pragma unroll
+                    for (int u = 0; u < ATT_UN; ++u) kk[u] = __shfl(ck, hbase | ((jj + u < k.cnt) ? jj + u : jj));
+#pragma unroll
+                    for (int u = 0; u < ATT_UN; ++u) {
+                        uk[u] = ul[(size_t)kk[u] * FS + ln];
+                        xk[u] = xin[(size_t)kk[u] * FS + ln];
+                    }
+#pragma unroll
+                    for (int u = 0; u < ATT_UN; ++u)
+                        if (jj + u < k.cnt) {     // uniform over the wave (cnt is)
+                            const float se = att_sum32(ui * uk[u]);
+                            acc = fmaf(__shfl(cw, hbase | (jj + u)) * se, xk[u], acc);
+                            cs = (jj + u == ln) ? se : cs;
+                        }
+                }
+                if (eon) sl[k.e0 + k.j0 + ln] = cs;
+                if (k.on && k.multi) pacc[(size_t)k.c * 32 + ln] = acc;
+                rowlocal(k.i, k.on && !k.multi, acc);
+            }
+            __syncthreads();
+            for (int m0 = 2 * wave; m0 < NM; m0 += 2 * NWV) {
+                int i;
+                bool on;
+                const float acc = multi_sum(m0, NM, i, on);
+                rowlocal(i, on, acc);
             }
             __syncthreads();
         }
@@ -252,6 +350,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
                 erow[tid] = tr;
             }
         }
+        for (int e = tid; e < nnz; e += ATT_THREADS) dA[e] = 0.0f;   // (the rows a layer's backward does not reach add nothing)
         __syncthreads();
         head_softmax(p, tm, t, iter, true, sWp, emb, gcls, dEs);
 
@@ -263,88 +362,79 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
             const float* sl = a.s[l] + eb;
             float* dZ = a.dZ + ro;
             float* dX = a.dX + ro;
+            const int LZ = 2 - l;                    // rows within LZ hops have a dZ of this layer
+            const int NRZ = s_nr[LZ];
+            const int NC = s_nch[LZ + 1 > 3 ? 3 : LZ + 1], NM = s_nm[LZ + 1 > 3 ? 3 : LZ + 1];   // dXin: one hop further
             // row-local: gradient of the layer's output -> dZ
-            for (int i0 = 2 * wave; i0 < n; i0 += 2 * NWV) {
-                const int i = i0 + hf;
-                const bool ron = i < n;
-                const size_t r = (size_t)(ron ? i : 0) * FS + ln;
+            for (int r0 = 2 * wave; r0 < NRZ; r0 += 2 * NWV) {
+                const bool ron = r0 + hf < NRZ;
+                const int i = ron ? order[r0 + hf] : 0;
+                const size_t r = (size_t)i * FS + ln;
                 float dx = (l < 2) ? dX[r] : 0.0f;
                 if (ron && erow[l * 32 + ln] == i) dx += dEs[l * 32 + ln];   // the direct part lands on row t / on the arg-max row of the column
                 const float un = a.U[l][ro + r];
                 float du = (ln < dout) ? dx : 0.0f;
                 if (l < 2) du = (un > 0.0f) ? du : 0.0f;
                 const float sd = att_sum32(du * un);
-                const float dy = (du - un * sd) / a.rn[l][tm.offR + (ron ? i : 0)];
+                const float dy = (du - un * sd) / a.rn[l][tm.offR + i];
                 float dz = 0.0f;
                 for (int c = 0; c < dout; ++c) dz = fmaf(__shfl(dy, hbase | c), sW[l][ln * 33 + c], dz);
                 if (ron) dZ[r] = (ln < din) ? dz : 0.0f;
             }
             __syncthreads();
-            // edges: dL/dadj' -> dAbar, dL/datt, and the adj'-path of dXin
-            for (int i0 = 2 * wave; i0 < n; i0 += 2 * NWV) {
-                const int i = i0 + hf;
-                const bool ron = i < n;
-                const int e0 = ron ? rowptr[i] : 0, deg = ron ? rowptr[i + 1] - e0 : 0;
-                const int odeg = __shfl_xor(deg, 32), trip = deg > odeg ? deg : odeg;
-                const float dzi = ron ? dZ[(size_t)i * FS + ln] : 0.0f;
-                float acc = 0.0f;
-                for (int j0 = 0; j0 < trip; j0 += 32) {
-                    const int je = j0 + ln;
-                    const bool eon = je < deg;
-                    const int ck = eon ? col[e0 + je] : 0;
-                    const float cw = eon ? w[e0 + je] : 0.0f, cs = eon ? sl[e0 + je] : 0.0f;
-                    const float cc = cw * cs;
-                    float cg = 0.0f;
-                    const int cnt = (trip - j0 < 32) ? trip - j0 : 32;
-                    for (int jj = 0; jj < cnt; jj += ATT_UN) {
-                        int kk[ATT_UN];
-                        float xk[ATT_UN], zk[ATT_UN];
+            // edges: dL/dadj' -> dAbar, dL/datt, and the adj'-path of dXin.  A row beyond LZ hops has no dZ (g = 0) but takes the adj' path
+            // from its neighbours within LZ hops - adj' is symmetric, the attention value of such an entry is its mirror's.
+            for (int c0 = 2 * wave; c0 < NC; c0 += 2 * NWV) {
+                const Chunk k = chunk_of(c0, NC);
+                const bool inz = k.on && lev[k.i] <= LZ;
+                const float dzi = inz ? dZ[(size_t)k.i * FS + ln] : 0.0f;
+                const bool eon = ln < k.mine;
+                const int e = k.e0 + k.j0 + ln;
+                const int ckp = eon ? col[e] : 0;
+                const int ck = ckp & 0xffff;
+                const bool kin = eon && (ckp >> 16) <= LZ;
+                const float cw = eon ? w[e] : 0.0f;
+                const float cs = !eon ? 0.0f : inz ? sl[e] : kin ? sl[mir[e]] : 0.0f;
+                const float cc = kin ? cw * cs : 0.0f;
+                float cg = 0.0f, acc = 0.0f;
+                for (int jj = 0; jj < k.cnt; jj += ATT_UN) {
+                    int kk[ATT_UN];
+                    float xk[ATT_UN], zk[ATT_UN];
 #pragma unroll
-                        for (int u = 0; u < ATT_UN; ++u) kk[u] = __shfl(ck, hbase | ((jj + u < cnt) ? jj + u : jj));
+                    for (int u = 0; u < ATT_UN; ++u) kk[u] = __shfl(ck, hbase | ((jj + u < k.cnt) ? jj + u : jj));
 #pragma unroll
-                        for (int u = 0; u < ATT_UN; ++u) {
-                            xk[u] = xin[(size_t)kk[u] * FS + ln];
-                            zk[u] = dZ[(size_t)kk[u] * FS + ln];
+                    for (int u = 0; u < ATT_UN; ++u) {
+                        xk[u] = xin[(size_t)kk[u] * FS + ln];
+                        zk[u] = dZ[(size_t)kk[u] * FS + ln];
+                    }
+#pragma unroll
+                    for (int u = 0; u < ATT_UN; ++u)
+                        if (jj + u < k.cnt) {
+                            const float g = att_sum32(dzi * xk[u]);
+                            acc = fmaf(__shfl(cc, hbase | (jj + u)), zk[u], acc);
+                            cg = (jj + u == ln) ? g : cg;
                         }
-#pragma unroll
-                        for (int u = 0; u < ATT_UN; ++u)
-                            if (jj + u < cnt) {
-                                const float g = att_sum32(dzi * xk[u]);
-                                acc = fmaf(__shfl(cc, hbase | (jj + u)), zk[u], acc);
-                                cg = (jj + u == ln) ? g : cg;
-                            }
-                    }
-                    if (eon) {
-                        dA[e0 + je] = (l == 2) ? cg * cs : dA[e0 + je] + cg * cs;
-                        q[e0 + je] = cg * cw;
-                    }
                 }
-                if (ron) dX[(size_t)i * FS + ln] = acc;
+                if (eon) {
+                    if (inz) dA[e] += cg * cs;
+                    q[e] = inz ? cg * cw : 0.0f;
+                }
+                if (k.on) {
+                    if (k.multi) pacc[(size_t)k.c * 32 + ln] = acc;
+                    else dX[(size_t)k.i * FS + ln] = acc;
+                }
+            }
+            __syncthreads();
+            for (int m0 = 2 * wave; m0 < NM; m0 += 2 * NWV) {
+                int i;
+                bool on;
+                const float acc = multi_sum(m0, NM, i, on);
+                if (on) dX[(size_t)i * FS + ln] = acc;
             }
             __syncthreads();
             // edges: the attention path, then dXin complete (+ the feature-mask partials in layer 1)
             float fp = 0.0f;
-            for (int i0 = 2 * wave; i0 < n; i0 += 2 * NWV) {
-                const int i = i0 + hf;
-                const bool ron = i < n;
-                const int e0 = ron ? rowptr[i] : 0, deg = ron ? rowptr[i + 1] - e0 : 0;
-                const int odeg = __shfl_xor(deg, 32), trip = deg > odeg ? deg : odeg;
-                float du = 0.0f;
-                for (int j0 = 0; j0 < trip; j0 += 32) {
-                    const int je = j0 + ln;
-                    const bool eon = je < deg;
-                    const int ck = eon ? col[e0 + je] : 0;
-                    const float cq = eon ? q[e0 + je] + q[mir[e0 + je]] : 0.0f;
-                    const int cnt = (trip - j0 < 32) ? trip - j0 : 32;
-                    for (int jj = 0; jj < cnt; jj += ATT_UN) {
-                        float uk[ATT_UN];
-#pragma unroll
-                        for (int u = 0; u < ATT_UN; ++u) uk[u] = ul[(size_t)__shfl(ck, hbase | ((jj + u < cnt) ? jj + u : jj)) * FS + ln];
-#pragma unroll
-                        for (int u = 0; u < ATT_UN; ++u)
-                            if (jj + u < cnt) du = fmaf(__shfl(cq, hbase | (jj + u)), uk[u], du);
-                    }
-                }
+            auto finish = [&](int i, bool ron, float du) {
                 float dxa = 0.0f;
                 for (int c = 0; c < din; ++c) dxa = fmaf(__shfl(du, hbase | c), sWa[l][ln * 33 + c], dxa);
                 if (ron) {
@@ -353,6 +443,34 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
                     dX[r] = dxi;
                     if (l == 0) fp = fmaf(dxi, X[r], fp);
                 }
+            };
+            for (int c0 = 2 * wave; c0 < NC; c0 += 2 * NWV) {
+                const Chunk k = chunk_of(c0, NC);
+                const bool inz = k.on && lev[k.i] <= LZ;
+                const bool eon = ln < k.mine;
+                const int e = k.e0 + k.j0 + ln;
+                const int ckp = eon ? col[e] : 0;
+                const int ck = ckp & 0xffff;
+                const bool kin = eon && (ckp >> 16) <= LZ;
+                const float cq = (inz && eon ? q[e] : 0.0f) + (kin ? q[mir[e]] : 0.0f);   // q lives on the rows within LZ hops
+                float du = 0.0f;
+                for (int jj = 0; jj < k.cnt; jj += ATT_UN) {
+                    float uk[ATT_UN];
+#pragma unroll
+                    for (int u = 0; u < ATT_UN; ++u) uk[u] = ul[(size_t)__shfl(ck, hbase | ((jj + u < k.cnt) ? jj + u : jj)) * FS + ln];
+#pragma unroll
+                    for (int u = 0; u < ATT_UN; ++u)
+                        if (jj + u < k.cnt) du = fmaf(__shfl(cq, hbase | (jj + u)), uk[u], du);
+                }
+                if (k.on && k.multi) pacc[(size_t)k.c * 32 + ln] = du;
+                finish(k.i, k.on && !k.multi, du);
+            }
+            __syncthreads();
+            for (int m0 = 2 * wave; m0 < NM; m0 += 2 * NWV) {
+                int i;
+                bool on;
+                const float du = multi_sum(m0, NM, i, on);
+                finish(i, on, du);
             }
             if (l == 0) part[2 * wave + hf][ln] = fp;
             __syncthreads();
@@ -363,7 +481,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
         for (int i = wave; i < n; i += NWV) {
             const float yi = p.graph_mode ? 0.0f : yh[i];
             for (int e = rowptr[i] + lane; e < rowptr[i + 1]; e += 64) {
-                const int k = col[e];
+                const int k = col[e] & 0xffff;
                 const size_t idx = (size_t)i * ld + k;
                 float Gs = 0.5f * (dA[e] + dA[mir[e]]);
                 if (!p.graph_mode) {
@@ -394,7 +512,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
         if (iter + 1 < p.num_iters) {  // the result is the masked adjacency of the LAST forward (explain.py:209-211)
             for (int i = wave; i < n; i += NWV)
                 for (int e = rowptr[i] + lane; e < rowptr[i + 1]; e += 64) {
-                    const int k = col[e];
+                    const int k = col[e] & 0xffff;
                     const size_t idx = (size_t)i * ld + k;
                     w[e] = Ad[idx] * (0.5f * (sigmoidf_(Md[idx]) + sigmoidf_(Md[(size_t)k * ld + i])));
                 }
@@ -405,7 +523,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
     // ---------------- results ----------------
     for (int i = wave; i < n; i += NWV)
         for (int e = rowptr[i] + lane; e < rowptr[i + 1]; e += 64) {
-            const size_t idx = (size_t)i * ld + col[e];
+            const size_t idx = (size_t)i * ld + (col[e] & 0xffff);
             p.Abar[tm.offQ + idx] = w[e];
             if (p.m_out) p.m_out[tm.offQ + idx] = md[idx];
             if (p.v_out) p.v_out[tm.offQ + idx] = vd[idx];
@@ -417,7 +535,6 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
         fs[FS] = (tid < D) ? mf[tid] : 0.0f;
         fs[2 * FS] = (tid < D) ? vf[tid] : 0.0f;
     }
-    (void)nnz;
 }
 
 // directed off-diagonal entries of every target (the host sizes the edge arrays from them)

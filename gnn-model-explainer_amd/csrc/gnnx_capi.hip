@@ -1112,8 +1112,15 @@ static int run_att(gnnx_handle h, const gnnx_hyper* hy, const gnnx_resume& rs, P
     for (auto& x : o_e) x = take(4 * E);
     for (auto& x : o_r) x = take(4 * R * FS);
     for (auto& x : o_rn) x = take(4 * R);
+    // round 5 (hop pruning, chunked rows): levels, rows by level, chunk table, rows of several chunks, their partial sums
+    const size_t NCH = R + (size_t)T + E / 32 + (size_t)T, NMU = E / 32 + (size_t)T;
+    const size_t o_lev = take(4 * R), o_order = take(4 * (R + T)), o_chunk = take(4 * NCH), o_mrow = take(4 * NMU), o_mfirst = take(4 * NMU),
+                 o_pacc = take(4 * NCH * 32);
     char* d = nullptr;
     HIPCK(pool_malloc(&d, o));
+    // rows / entries a pruned phase does not write are READ (times an exact zero) by its neighbours: no NaN patterns of a recycled block
+    HIPCK(hipMemsetAsync(d, 0, o, s));
+    HIPCK(hipStreamSynchronize(s));      // (the uploads below go through the service stream)
     float* d_tab = nullptr;
     std::vector<float> tab(2 * (size_t)hy->num_iters);
     for (int it = 0; it < hy->num_iters; ++it) adam_scalars(hy, rs.first_iter + it, &tab[2 * it], &tab[2 * it + 1], it);
@@ -1143,6 +1150,12 @@ static int run_att(gnnx_handle h, const gnnx_hyper* hy, const gnnx_resume& rs, P
     }
     a.dZ = reinterpret_cast<float*>(d + o_r[9]);
     a.dX = reinterpret_cast<float*>(d + o_r[10]);
+    a.lev = reinterpret_cast<int32_t*>(d + o_lev);
+    a.order = reinterpret_cast<int32_t*>(d + o_order);
+    a.chunk = reinterpret_cast<int32_t*>(d + o_chunk);
+    a.mrow = reinterpret_cast<int32_t*>(d + o_mrow);
+    a.mfirst = reinterpret_cast<int32_t*>(d + o_mfirst);
+    a.pacc = reinterpret_cast<float*>(d + o_pacc);
     hipLaunchKernelGGL(k_att, dim3(T), dim3(ATT_THREADS), 0, s, p, a, d_tab);
     if (feat_mask)
         (void)hipMemcpyAsync(feat_mask, p.f[hy->num_iters & 1], sizeof(float) * T * FS, hipMemcpyDeviceToDevice, s);

@@ -261,6 +261,50 @@ def test_method_att_one_step_equals_autograd(be):
         assert np.abs(res.feat_mask[k][:10] - mod.feat_mask.detach().numpy()).max() < 2e-5
 
 
+def test_method_att_hub_rows_and_hop_pruning_equal_autograd(be):
+    """k_att's round-5 structure against torch autograd through the mirror encoder on a graph built for it: a hub of 70 entries (three chunks of
+    32: its partial sums go through the second pass) two hops from the target, its other leaves three hops away (rows the pruned phases skip:
+    they only feed layer 1's gathers), a chain that reaches three hops on the other side, a row without entries beyond the diagonal.  Three Adam
+    steps: the third forward has consumed gradients that passed every pruned phase twice."""
+    from gnn_model_explainer_amd import models
+    from gnn_model_explainer_amd.explainer import torch_route
+    _, sd, _ = _att_case(302)
+    rng = np.random.default_rng(5)
+    n = 78
+    A = np.zeros((n, n), np.float32)
+    def link(i, j):
+        A[i, j] = A[j, i] = 1.0
+    t, hub = 0, 1
+    for leaf in range(2, 72):
+        link(hub, leaf)            # rows 2 .. 71: the hub's leaves
+    link(t, 2)                     # t - leaf 2 - hub: the hub two hops away, the other leaves three
+    link(t, 72); link(72, 73); link(73, 74)      # a chain: one, two, three hops
+    link(72, 75); link(75, 76)     # (row 77 stays isolated: the reference's neighbourhoods never hold such a row, the kernel must not trip on it)
+    link(3, 4); link(5, 6)         # entries between rows three hops away
+    X = rng.normal(size=(n, 10)).astype(np.float32)
+    yhat = rng.integers(0, 4, n)
+    sg = Subgraph(A, X, 1, t, yhat, helpers.seeded_mask0(7, n).numpy())
+    args = argparse.Namespace(method="att", bias=True, num_gc_layers=3, mask_act="sigmoid", num_epochs=3, lr=0.1, opt="adam", opt_scheduler="none")
+    model = models.GcnEncoderNode(10, 20, 20, 4, 3, bn=False, args=args)
+    model.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    res = be.job([sg], sd).run([sg.mask0], explain._hyper(args))
+    mod = torch_route.TorchExplainModule(torch.tensor(sg.adj[None]), torch.tensor(sg.feat[None]), model, torch.tensor([[0] * sg.target_row + [sg.gt_label]]),
+                                         args, explain.COEFFS, sg.mask0, device="cpu")
+    opt = torch.optim.Adam([mod.mask, mod.feat_mask], lr=0.1)
+    model.eval()
+    for _ in range(3):
+        opt.zero_grad()
+        pred, _ = mod(sg.target_row)
+        mod.loss(pred, sg.pred_label, sg.target_row).backward()
+        opt.step()
+    e = sg.adj != 0
+    em = np.abs(res.masked_adj[0] - mod.masked_adj[0].detach().numpy())[e].max()
+    ep = np.abs(res.mask[0] - mod.mask.detach().numpy())[e].max()
+    ef = np.abs(res.feat_mask[0][:10] - mod.feat_mask.detach().numpy()).max()
+    print(f"method=att hub graph: masked adjacency {em:.2e}, mask parameter {ep:.2e}, feature mask {ef:.2e}")
+    assert em < 2e-6 and ep < 3e-5 and ef < 3e-5
+
+
 # ---------------------------------------------------------------- the PyTorch-ROCm route (explainer/torch_route.py) ----------------------------------------------------------------
 def _route_explainer(tmp, tag, **kw):
     from gnn_model_explainer_amd import models
