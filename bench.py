@@ -86,7 +86,7 @@ def rng_threads_for(total_values, world=1):
     quota = engine.cpu_quota_cores()
     if quota:
         cores = min(cores, int(2 * quota))
-    return max(2, min(engine.default_rng_threads(), cores // max(1, world)))
+    return max(2, min(engine.default_rng_threads(big=total_values > 2e7), cores // max(1, world)))
 
 
 WELL = 2e-6                  # CPU-vs-CPU deviation (reference vs closed-form oracle) up to which a target is well conditioned
@@ -369,7 +369,7 @@ def _noop(_):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20, help="batches per timed region (20 / 5 = the command the round driver runs; --steps 300 --warmup 10: the steady state)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--iters", type=int, default=300)
     ap.add_argument("--workload", default=None, choices=["syn1", "ba100k", "syn4", "syn5", "config4"],

@@ -989,7 +989,7 @@ def cpu_quota_cores():
         return None
 
 
-def default_rng_threads():
+def default_rng_threads(big=False):
     """Host threads for the seeded mask draw: embarrassingly parallel over targets, but beyond ~32 threads the hand-off costs more than it
     saves (tools/probe_rng.py), and never more than half the cores the process may actually use (a container's CPU quota: the GPU box gives 16
     of its host's 256 CPUs - tools/probe_rng_big.py).  GNNX_RNG_THREADS overrides."""
@@ -999,7 +999,8 @@ def default_rng_threads():
     cores = (os.cpu_count() or 2) // 2
     q = cpu_quota_cores()
     if q:      # half the quota: three preparing threads draw at once, and a cgroup that spends its quota inside a 100 ms period is frozen until the
-        cores = min(cores, max(2, int(q) // 2))      # next one (profiles/r05_cpu_quota_throttling.txt; 2 x quota until round 5)
+        cores = min(cores, max(2, int(q) // (1 if big else 2)))      # next one (profiles/r05_cpu_quota_throttling.txt; 2 x quota until round 5).
+        # (big=True - batches of more than 2e7 normals, tens of milliseconds of draw: the whole quota; 75 M normals 36.6 ms on 8 threads, 23 on 32)
     return max(1, min(32, cores))
 
 

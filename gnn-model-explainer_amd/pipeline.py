@@ -44,7 +44,7 @@ class BatchPipeline:
         # (tools/probe_rng_big.py, profiles/r04_host_rng_16384targets.txt) 32 threads 94-140 ms, 64 threads 100-190, 96-128 threads 160-230 -
         # the draw is bound by the memory system, not the cores; the largest targets are cut into slices (gnnx_host_draw_masks_sliced:
         # the 31 M values of the n = 5600 target 63 -> 10-14 ms), which matters when one target dominates a batch
-        self.rng_threads_big = int(rng_threads_big) if rng_threads_big else self.rng_threads
+        self.rng_threads_big = int(rng_threads_big) if rng_threads_big else (int(rng_threads) if rng_threads else engine.default_rng_threads(big=True))
         # device_hook(values [E] on the device, job): called on the fetch stream once a batch's edge values are gathered, before their D2H
         # copy - the sharded job all-gathers the masks of every rank there (RCCL over xGMI; bench.py --gpus N)
         self.device_hook = device_hook
@@ -66,7 +66,7 @@ class BatchPipeline:
         # pair-staging property of the host's normal_ (checked once per process); device_walk=False / GNNX_PIPE_DEVICE_WALK=0: the host walk.
         self.device_walk = bool(int(os.environ.get("GNNX_PIPE_DEVICE_WALK", "1"))) if device_walk is None else bool(device_walk)
         # Optimisations in flight.  depth=None (default): as many as keep the chip full and no more - ceil(1.3 x 256 CUs / the compute units ONE
-        # launch keeps busy), between 2 and 5, re-evaluated per batch (_launch_cus): every further launch in flight only queues behind the
+        # launch keeps busy), between 2 and 5, re-evaluated per batch (_launch_cus; four when a batch has streaming targets): every further launch in flight only queues behind the
         # others and lengthens the fill and drain of a short job.  Measured (profiles/r05_pipeline_workers_depth_room.txt): syn1 (116 workgroups
         # per launch) 20-batch regions 234-241 k nodes/s at four in flight, 249-250 k at three; Tree-Cycles (360 single-wave workgroups, six per
         # CU) 365-373 k at three, 449-455 k at four or more; steady state (300 batches) indifferent.  A number fixes it.
@@ -189,7 +189,7 @@ class BatchPipeline:
             cus = n8 + (n5 + 1) // 2 + (n6 + 7) // 8
         else:
             cus = (n5 + 1) // 2 + (n6 + 5) // 6
-        return min(cus + n47, num_cus) if not other else num_cus
+        return min(cus + n47, num_cus) if not other else -1      # (-1: streaming targets in the batch)
 
     # -- stage 1 -----------------------------------------------------------------------------------------------------------
     def _prepare(self, targets, k, s_prep):
@@ -361,7 +361,9 @@ class BatchPipeline:
             if p.error is not None:
                 raise p.error
             if self.auto_depth:
-                self.depth_now = int(min(self.depth, max(2, -(-(13 * 256) // (10 * max(1, p.launch_cus))))))
+                # (batches with streaming targets: four, as measured - 4.78 k nodes/s on the 1024-target dense sample against 3.87 k at two: the
+                #  tail of one batch's 300 launches overlaps the head of the next)
+                self.depth_now = 4 if p.launch_cus < 0 else int(min(self.depth, max(2, -(-(13 * 256) // (10 * max(1, p.launch_cus))))))
             pending.append((p,) + self._launch(p, slot))
             slot = (slot + 1) % (self.depth * 8)      # (a multiple of the optimise streams: launch k goes to stream k mod depth)
             while len(pending) > self.depth_now:

@@ -215,4 +215,4 @@ def test_pipeline_launch_cus_estimate():
     assert cus([6] * 360) == 60                                          # single-wave class alone: six workgroups per CU
     assert cus([5] * 10) == 5 and cus([5] * 3 + [6] * 9) == 2 + 2
     assert cus([7] * 3 + [8] * 2) == 5
-    assert cus([8] * 5000) == 256 and cus([0, 8]) == 256                 # saturating launches, streaming targets
+    assert cus([8] * 5000) == 256 and cus([0, 8]) == -1                  # saturating launches; streaming targets in the batch

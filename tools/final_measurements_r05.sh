@@ -10,7 +10,12 @@ grep -h "every decision identical\|300 epochs from the seeds\|same decisions, be
 timeout 100 python __graft_entry__.py smoke 2>&1 | tail -1 >> $O/pytest_gpu_tail.txt
 cat $O/pytest_gpu_tail.txt
 timeout 120 tools/micro/chain_latency > $O/r05_chain_latency.txt 2>&1
-timeout 400 python bench.py 2>$O/bench_default.err | tail -1 > $O/r05_bench_syn1_default.json
+stat() { grep -h "nr_throttled\|throttled_usec\|nr_periods" /sys/fs/cgroup/cpu.stat 2>/dev/null | tr '\n' ' '; }
+echo "before the driver's command: $(stat)" > $O/r05_cpu_throttle_around_driver_command.txt
+timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 2>$O/bench_default.err | tail -1 > $O/r05_bench_syn1_default.json
+echo "after: $(stat)" >> $O/r05_cpu_throttle_around_driver_command.txt
+for i in 2 3; do timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r05_bench_syn1_default_run$i.json; done
+timeout 400 python bench.py --steps 300 --warmup 10 --reps 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r05_bench_syn1_steady_state_300_batches.json
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_syn1_loop -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline --loop-only > $GRAFT_REPO_ROOT/$O/r05_bench_syn1_loop_only_under_rocprof.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_syn1 -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/r05_bench_syn1_under_rocprof.json 2>/dev/null
@@ -24,10 +29,10 @@ find $O/prof_syn1_loop -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O
 find $O/prof_syn1 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/r05_kernel_stats_syn1.csv; rm -rf $O/prof_syn1
 python tools/pmc_summary.py $O/r05_pmc_summary_syn1_loop_only.json $O/r05_pmc_per_kernel_syn1_loop_only.csv $O/pmc_insts $O/pmc_lds $O/pmc_fetch $O/pmc_write > /dev/null
 rm -rf $O/pmc_insts $O/pmc_lds $O/pmc_fetch $O/pmc_write
-timeout 60 python tools/probe_sparse.py 0 2>/dev/null | grep -v amdgpu > $O/r05_timeline_sparse_resident_syn1_n310.txt
-timeout 60 python tools/probe_sparse.py 150 2>/dev/null | grep -v amdgpu > $O/r05_timeline_sparse_resident_syn1_one_wave.txt
-timeout 200 python bench.py --workload syn5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r05_bench_syn5.json
-timeout 200 python bench.py --workload syn4 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r05_bench_syn4.json
+timeout 60 python tools/probe_sparse_waves.py 0 2>/dev/null | grep -v amdgpu > $O/r05_timeline_per_wave_syn1_n310.txt
+timeout 60 python tools/probe_sparse_waves.py 150 2>/dev/null | grep -v amdgpu > $O/r05_timeline_per_wave_syn1_one_wave.txt
+timeout 200 python bench.py --workload syn5 --steps 300 --warmup 10 --reps 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r05_bench_syn5.json
+timeout 200 python bench.py --workload syn4 --steps 300 --warmup 10 --reps 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r05_bench_syn4.json
 timeout 300 python bench.py --workload config4 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r05_bench_config4.json
 timeout 300 python bench.py --workload ba100k --targets 2048 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r05_bench_ba100k_2048targets.json
 timeout 500 python bench.py --workload ba100k --targets 16384 --steps 3 --warmup 2 --no-cpu-baseline 2>$O/bench_ba100k.err | tail -1 > $O/r05_bench_ba100k_16384targets.json
