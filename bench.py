@@ -53,12 +53,14 @@ if _Q and _Q < (os.cpu_count() or 1):
         os.environ.setdefault(_v, str(max(1, int(_Q) // 2)))
     os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+import gnn_model_explainer_amd as _pkg      # BEFORE torch: environment defaults above + the process confined to one NUMA node (its __init__)
+
+import numpy as np
+import torch
+
 
 HBM_PEAK = 8.0e12            # B/s, MI355X spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK = 157.3e12     # flop/s, dense f32 MFMA
@@ -654,6 +656,8 @@ def main():
                                               "note": "process CPU time (all threads) per batch x ranks; beyond knee_n_gpus GPUs on this box the step is bound by "
                                                       "host core-seconds / quota, not by the optimisation"}
         e2e_stats["rng_threads"] = pipe.rng_threads
+        e2e_stats["cpu_affinity"] = {"cpus": len(os.sched_getaffinity(0)), "confined_to_one_numa_node": _pkg.NUMA_CPUS is not None,
+                                     "omp_num_threads": os.environ.get("OMP_NUM_THREADS")}
         e2e_stats["prepare_workers"] = pipe.prepare_workers
         e2e_stats["optimisations_in_flight"] = pipe.depth_now
         e2e_stats["optimisations_in_flight_rule"] = ("auto: ceil(1.3 x 256 CUs / CUs one launch keeps busy), 2..5" if pipe.auto_depth else "fixed")

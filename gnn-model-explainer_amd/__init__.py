@@ -34,3 +34,36 @@ if _q and _q < (_os.cpu_count() or 1):
     for _v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
         _os.environ.setdefault(_v, str(max(1, int(_q) // 2)))
     _os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
+# One NUMA node.  The GPU boxes are two-socket hosts (2 x 64 cores, 256 CPUs) and the container's threads may run on any CPU: the pipeline's
+# handful of threads (prepare workers, launch / fetch thread, RNG pool, HIP's own) migrate between the sockets, their pinned staging buffers
+# and the runtime's queues sit on one.  Measured on syn1 (profiles/r05_cpu_affinity_numa.txt; the driver's command, five alternating runs):
+# free 233-246 k nodes/s, prepare stage 2.65 ms, single repetitions down to 142 k; confined to EITHER node 254-264 k, prepare 1.9-2.2 ms.
+# Called at import (before torch / HIP create their threads, which inherit it) when the process is in a quota-limited container and its
+# affinity spans several nodes; GNNX_CPU_AFFINITY=0 leaves the affinity alone.  The ranks of a node spread over its NUMA nodes.
+def confine_to_one_numa_node():
+    import glob as _glob
+    if _os.environ.get("GNNX_CPU_AFFINITY", "1") == "0" or not hasattr(_os, "sched_setaffinity"):
+        return None
+    try:
+        cur = _os.sched_getaffinity(0)
+        nodes = []
+        for path in sorted(_glob.glob("/sys/devices/system/node/node[0-9]*/cpulist")):
+            cpus = set()
+            for part in open(path).read().strip().split(","):
+                if part:
+                    a, _, b = part.partition("-")
+                    cpus.update(range(int(a), int(b or a) + 1))
+            if cpus & cur:
+                nodes.append(cpus & cur)
+        if len(nodes) < 2:
+            return None                      # one node, or already confined
+        rank, world = int(_os.environ.get("LOCAL_RANK", "0")), max(1, int(_os.environ.get("LOCAL_WORLD_SIZE", "1")))
+        pick = nodes[min(len(nodes) - 1, rank * len(nodes) // world)]
+        _os.sched_setaffinity(0, pick)
+        return sorted(pick)
+    except Exception:
+        return None
+
+
+NUMA_CPUS = confine_to_one_numa_node() if (_q and _q < (_os.cpu_count() or 1)) else None
