@@ -50,8 +50,7 @@ __device__ __forceinline__ float att_sum32(float v) {
     v += att_row_ror<4>(v);
     v += att_row_ror<2>(v);
     v += att_row_ror<1>(v);
-    v += __shfl_xor(v, 16);
-    return v;
+    return xor16_sum(v);      // (gfx950: a lane swap, not a ds_bpermute - gnnx_kernels.hpp)
 }
 
 constexpr int ATT_THREADS = 1024;

@@ -167,8 +167,28 @@ __device__ __forceinline__ float sigmoidf_(float x) { return rcp_(1.0f + exp_(-x
 #ifndef GNNX_OPAQUE
 #define GNNX_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
+// v + (v of lane ^ 32) / v + (v of lane ^ 16) in every lane.  gfx950's lane swaps (v_permlane32_swap: the upper half of the first operand <->
+// the lower half of the second; v_permlane16_swap: odd 16-lane rows of the first <-> even rows of the second) on two copies of v leave
+// {lo, lo} / {hi, hi} (resp. {r0, r0, r2, r2} / {r1, r1, r3, r3}) in the pair: their sum is the shuffle form's, operand for operand (the addition
+// commutes: bit-identical in all 64 lanes, tools/micro/permlane_swap.hip) - a VALU instruction instead of a ds_bpermute round trip through the
+// LDS crossbar: 25.1 ns instead of 38.5 / 36.8 ns per dependent step (profiles/r05_permlane_swap.txt), and no lgkmcnt wait shared with the
+// loads in flight.  Inline assembly: with this compiler (ROCm 7.2) the sum of the builtin's two results comes out as r[0] + r[0]; the one wait
+// state the hazard recogniser puts in front of a lane swap is written out.  The CPU emulator of tests/emu keeps the shuffle form.
+#if defined(__HIPCC__)
+__device__ __forceinline__ float xor32_sum(float v) {
+    int a = __builtin_bit_cast(int, v), b = a;
+    asm("s_nop 0\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float xor16_sum(float v) {
+    int a = __builtin_bit_cast(int, v), b = a;
+    asm("s_nop 0\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+#else
 __device__ __forceinline__ float xor32_sum(float v) { return v + __shfl_xor(v, 32); }
 __device__ __forceinline__ float xor16_sum(float v) { return v + __shfl_xor(v, 16); }
+#endif
 
 // row of the 32x32 MFMA accumulator held in register r of a lane in half h (lane>>5); column = lane&31
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }

@@ -22,6 +22,12 @@
 // are needed only for the logged size/entropy scalars, so loss logging stays on the dense streaming path).
 // Mathematics as in gnnx_kernels.hpp / SURVEY.md Appendix A; parity: tests/test_emu_kernels.py, tests/test_gpu_parity.py.
 #pragma once
+#ifndef GNNX_OPAQUE_ROWS
+#define GNNX_OPAQUE_ROWS 2
+#endif
+#ifndef GNNX_OPAQUE_ALL
+#define GNNX_OPAQUE_ALL 1
+#endif
 #include <type_traits>
 #include "gnnx_kernels.hpp"
 #include "gnnx_resident.hpp"
@@ -921,7 +927,25 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         bc2s = adam_tab[2 * iter + 1];
         rbc2 = 1.0f / bc2s;      // once per iteration (adam_update<.., HAVE_R>)
         GNNX_OPAQUE(rbc2);
-        if constexpr (NT == 512) {
+        // Round 5, under the 224-register cap of the mixed kernel (room for the prepare stage's kernels, gnnx_kernels.hpp): what the compiler
+        // spilled were loop INVARIANTS it had hoisted out of this loop - the LDS addresses derived from a lane's row slots and (below) from its
+        // owned edges' index words.  Declared modified here they are per-iteration values again: a few shifts and adds where they are used
+        // instead of scratch reloads along the chain - spilled registers 74 -> 23, scratch loads per iteration 14 / 65 / 18 -> 0 / 20 / 6
+        // (512-thread / pair / single-wave body), syn1 loop-only 2.805 -> 2.766 ms (the uncapped kernel's time), steady state 306.8 -> 314 k
+        // nodes/s (tools/gpu_r5af.sh).  Also measured: the head's lane index (spills 9, but more instructions on wave 0's chain: 312.5 k) and the
+        // lane's column index everywhere (spills 5: no difference).  (No instruction is emitted.)
+        // (node mode only: the uncapped graph-mode kernels of config 4 lose 3 % with it - 52.5 -> 54.3 ms, tools/gpu_r5ah.sh)
+        if constexpr (GNNX_OPAQUE_ROWS && !GRAPH) {
+#pragma unroll
+            for (int k = 0; k < NSET; ++k) {
+                GNNX_OPAQUE(rs[k].row);
+                if constexpr (GNNX_OPAQUE_ROWS > 1) {
+                    GNNX_OPAQUE(rs[k].e0);
+                    GNNX_OPAQUE(rs[k].e1);
+                }
+            }
+        }
+        if constexpr (NT == 512 || (GNNX_OPAQUE_ALL && !GRAPH)) {
             // The 512-thread class sits at its 256 registers and spills.  What the compiler keeps across the whole iteration, per owned edge, is
             // not only the edge's state but the LDS ADDRESSES it derives from the two packed index words (ten per edge: both entries of Abar
             // and of the row-side products, yhat, g3 and Abar[t][.] of both end points - loop invariant, hence hoisted out of the iteration
@@ -1186,10 +1210,23 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 // logits: three products per lane and class, one 32-lane sum per class
                 float zl[CH];
                 float mx = -3.0e38f;
+                // (the CH lane sums step by step over all classes: the DPP steps / the cross-row shuffle of one sum depend on each other, those
+                //  of different classes do not - same sums, same order within each)
+#pragma unroll
+                for (int cc = 0; cc < CH; ++cc) zl[cc] = fmaf(wp[0][cc], e1, fmaf(wp[1][cc], e2, wp[2][cc] * u3));
+#pragma unroll
+                for (int cc = 0; cc < CH; ++cc) zl[cc] += row_shl<8>(zl[cc]);
+#pragma unroll
+                for (int cc = 0; cc < CH; ++cc) zl[cc] += row_shl<4>(zl[cc]);
+#pragma unroll
+                for (int cc = 0; cc < CH; ++cc) zl[cc] += row_shl<2>(zl[cc]);
+#pragma unroll
+                for (int cc = 0; cc < CH; ++cc) zl[cc] += row_shl<1>(zl[cc]);
+#pragma unroll
+                for (int cc = 0; cc < CH; ++cc) zl[cc] = xor16_sum(zl[cc]);
 #pragma unroll
                 for (int cc = 0; cc < CH; ++cc) {
-                    const float pc = fmaf(wp[0][cc], e1, fmaf(wp[1][cc], e2, wp[2][cc] * u3));
-                    zl[cc] = (cc < C) ? sum_lanes_0_31(pc) + bpv[cc] : -3.0e38f;
+                    zl[cc] = (cc < C) ? bcast_first(zl[cc]) + bpv[cc] : -3.0e38f;
                     mx = fmaxf(mx, zl[cc]);
                 }
                 float sum = 0.0f;
@@ -1548,13 +1585,19 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 // ten cross-row shuffles through the LDS crossbar on every wave's way to the barrier; classes of up to 8 waves: dfw has 16 rows)
                 constexpr bool DFWR = NW <= 8;
                 float* dfw2 = &sh.dfw[0][0];
+                // (step by step over ALL columns: the DPP steps of one column depend on each other - two wait states each - those of different
+                //  columns do not)
+#pragma unroll
+                for (int q = 0; q < HQ; ++q) dvq[q] += row_shl<8>(dvq[q]);
+#pragma unroll
+                for (int q = 0; q < HQ; ++q) dvq[q] += row_shl<4>(dvq[q]);
+#pragma unroll
+                for (int q = 0; q < HQ; ++q) dvq[q] += row_shl<2>(dvq[q]);
+#pragma unroll
+                for (int q = 0; q < HQ; ++q) dvq[q] += row_shl<1>(dvq[q]);
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) {
                     float v = dvq[q];
-                    v += row_shl<8>(v);
-                    v += row_shl<4>(v);
-                    v += row_shl<2>(v);
-                    v += row_shl<1>(v);
                     if constexpr (DFWR) {
                         if ((li & 15) == 0) dfw2[(2 * wave + (li >> 4)) * 32 + 2 * q + h] = v;
                     } else {
@@ -1563,15 +1606,20 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                     }
                 }
             } else
+            {
 #pragma unroll
-            for (int q = 0; q < DQ; ++q) {
-                float v = dfq[q];
-                v += row_shl<8>(v);
-                v += row_shl<4>(v);
-                v += row_shl<2>(v);
-                v += row_shl<1>(v);
-                v = xor16_sum(v);
-                if (li == 0) sh.dfw[wave][2 * q + h] = v;
+                for (int q = 0; q < DQ; ++q) dfq[q] += row_shl<8>(dfq[q]);
+#pragma unroll
+                for (int q = 0; q < DQ; ++q) dfq[q] += row_shl<4>(dfq[q]);
+#pragma unroll
+                for (int q = 0; q < DQ; ++q) dfq[q] += row_shl<2>(dfq[q]);
+#pragma unroll
+                for (int q = 0; q < DQ; ++q) dfq[q] += row_shl<1>(dfq[q]);
+#pragma unroll
+                for (int q = 0; q < DQ; ++q) dfq[q] = xor16_sum(dfq[q]);
+#pragma unroll
+                for (int q = 0; q < DQ; ++q)
+                    if (li == 0) sh.dfw[wave][2 * q + h] = dfq[q];
             }
         }
         SYNC();
