@@ -10,6 +10,8 @@ grep -h "every decision identical\|300 epochs from the seeds\|same decisions, be
 timeout 100 python __graft_entry__.py smoke 2>&1 | tail -1 >> $O/pytest_gpu_tail.txt
 cat $O/pytest_gpu_tail.txt
 timeout 120 tools/micro/chain_latency > $O/r05_chain_latency.txt 2>&1
+timeout 60 tools/micro/permlane_swap > $O/r05_permlane_swap.txt 2>&1
+python tools/chain_latency_json.py $O/r05_chain_latency.txt profiles/r05_chain_latency.json $O/r05_permlane_swap.txt > /dev/null   # (the bench runs below read it)
 stat() { grep -h "nr_throttled\|throttled_usec\|nr_periods" /sys/fs/cgroup/cpu.stat 2>/dev/null | tr '\n' ' '; }
 echo "before the driver's command: $(stat)" > $O/r05_cpu_throttle_around_driver_command.txt
 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 2>$O/bench_default.err | tail -1 > $O/r05_bench_syn1_default.json
