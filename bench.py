@@ -49,8 +49,9 @@ def _cpu_quota_cores():      # (gnn-model-explainer_amd/__init__.py: torch's CPU
 
 _Q = _cpu_quota_cores()
 if _Q and _Q < (os.cpu_count() or 1):
+    _RANKS = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     for _v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
-        os.environ.setdefault(_v, str(max(1, int(_Q) // 2)))
+        os.environ.setdefault(_v, str(max(1, int(_Q) // (2 * _RANKS))))
     os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

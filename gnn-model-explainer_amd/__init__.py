@@ -31,8 +31,9 @@ def _cpu_quota_cores():
 
 _q = _cpu_quota_cores()
 if _q and _q < (_os.cpu_count() or 1):
+    _ranks = max(1, int(_os.environ.get("LOCAL_WORLD_SIZE", "1")))      # (torchrun: the ranks of a node share the quota)
     for _v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
-        _os.environ.setdefault(_v, str(max(1, int(_q) // 2)))
+        _os.environ.setdefault(_v, str(max(1, int(_q) // (2 * _ranks))))
     _os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 
 # One NUMA node.  The GPU boxes are two-socket hosts (2 x 64 cores, 256 CPUs) and the container's threads may run on any CPU: the pipeline's

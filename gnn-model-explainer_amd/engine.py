@@ -999,7 +999,8 @@ def default_rng_threads(big=False):
     cores = (os.cpu_count() or 2) // 2
     q = cpu_quota_cores()
     if q:      # half the quota: three preparing threads draw at once, and a cgroup that spends its quota inside a 100 ms period is frozen until the
-        cores = min(cores, max(2, int(q) // (1 if big else 2)))      # next one (profiles/r05_cpu_quota_throttling.txt; 2 x quota until round 5).
+        ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))      # (torchrun: the ranks of a node share the quota)
+        cores = min(cores, max(2, int(q) // ((1 if big else 2) * ranks)))      # next one (profiles/r05_cpu_quota_throttling.txt; 2 x quota until round 5).
         # (big=True - batches of more than 2e7 normals, tens of milliseconds of draw: the whole quota; 75 M normals 36.6 ms on 8 threads, 23 on 32)
     return max(1, min(32, cores))
 
