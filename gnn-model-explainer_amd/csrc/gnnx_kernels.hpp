@@ -31,7 +31,8 @@ namespace gnnx {
 constexpr int TILE = 32;  // MFMA 32x32x2 tile edge
 constexpr int FS = 32;    // floats per feature row
 constexpr int CMAX = 32;  // max classes
-constexpr int NLOSS = 8;
+constexpr int NLOSS = 16;   // per (target, iteration): pred, size, lap, ent, feat_size, mask density (after the step), 2 spare, class probabilities [LOGP .. LOGP + 8)
+constexpr int LOGD = 5, LOGP = 8, LOGPN = 8;
 
 // offsets (floats) inside the packed, zero-padded model block
 constexpr int WT_W = 0;                   // W_l   [32][32]  at WT_W + l*1024   (row = input k, col = output c)
@@ -681,6 +682,7 @@ __device__ __forceinline__ void head_softmax(const Params& p, const TargetMeta& 
             if (write) p.probs[t * CMAX + tid] = (tid < p.C) ? pr : 0.0f;
         }
         if (write && p.loss && tid == tm.y_gt) p.loss[((size_t)t * p.num_iters + iter) * NLOSS + 0] = -logf(pr);
+        if (write && p.loss && tid < p.C && tid < LOGPN) p.loss[((size_t)t * p.num_iters + iter) * NLOSS + LOGP + tid] = pr;   // explain.py:710-714, 157-158
     }
     __syncthreads();
     if (tid < 96) {
@@ -1097,6 +1099,17 @@ __global__ __launch_bounds__(256, 4) void k_mask(Params p, const MaskTile* tiles
         *reinterpret_cast<f32x4*>(p.vM + own) = vo;
     }
     __syncthreads();
+    float s_den = 0.0f, s_adj = 0.0f;
+    if (UPDATE && LOSS) {   // ExplainModule.mask_density (explain.py:680-683) after optimizer.step() (:142-148): the masked adjacency of the UPDATED mask
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = c4 + e;
+            const float ab = Ao[e] * (0.5f * (Sown[e] + sS[j * LS + i]));
+            const float both = diag ? 1.0f : 2.0f;       // an off-diagonal tile's thread also stands for the mirror entry
+            s_den += (gi != J0 + j) ? both * ab : 0.0f;
+            s_adj += both * Ao[e];
+        }
+    }
     if (WRITE_ABAR) {
         f32x4 ab4;
 #pragma unroll
@@ -1137,9 +1150,13 @@ __global__ __launch_bounds__(256, 4) void k_mask(Params p, const MaskTile* tiles
             s_size += __shfl_xor(s_size, o);
             s_ent += __shfl_xor(s_ent, o);
             s_lap += __shfl_xor(s_lap, o);
+            s_den += __shfl_xor(s_den, o);
+            s_adj += __shfl_xor(s_adj, o);
         }
         if (lane == 0) {  // logging only: float atomics, summation order not fixed
             float* L = p.loss + ((size_t)tl.t * p.num_iters + iter) * NLOSS;
+            atomicAdd(&L[LOGD + 1], s_den);   // numerator / denominator of the density: the host forms the quotient (engine.py) - the tiles of a
+            atomicAdd(&L[LOGD + 2], s_adj);   // target finish in no particular order
             atomicAdd(&L[1], p.c_size * s_size);
             atomicAdd(&L[2], p.c_lap * s_lap * inv_n2);
             atomicAdd(&L[3], p.c_ent * s_ent * inv_n2);

@@ -131,7 +131,7 @@ struct SparseFixed {
     int chunk_b;       // node mode, set A: slot width of the rows of t and its neighbours (<= set_chunk[0]; see "slot width per row")
     int erow[96];  // graph mode: arg-max row of every pooled column
     float wt[32], vsum[32];  // algebraic constant-feature form: (x (.) phi) W1; vsum (sum over the rows of s_r dY1[r]) lives in wave 0's registers since round 4 - the slot keeps the struct's size, which the LDS budget of the mixed launch is built on
-    float lsum[SP_THREADS / 64][4];  // LOG form: per-wave partial sums of the logged size / entropy / Laplacian terms over the owned edges
+    float lsum[SP_THREADS / 64][6];  // LOG form: per-wave partial sums over the owned edges: the logged size / entropy / Laplacian terms, [3] the masked adjacency AFTER the step and [4] the adjacency (mask density, explain.py:680-683)
 };
 
 // every lane of a wave has finished its LDS accesses before any lane continues (LDS operations of one wave
@@ -1097,6 +1097,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 if (lane < CMAX) sh.g[lane] = (lane < C) ? ex / sum - ((lane == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
                 if constexpr (LOG)
                     if (Lrow && lane == tm.y_gt) Lrow[0] = -logf(ex / sum);   // explain.py:750-753
+                    if (Lrow && lane < C && lane < LOGPN) Lrow[LOGP + lane] = ex / sum;   // the class probabilities the reference prints (explain.py:710-714, 157-158)
             }
             wave_sync();
 #pragma unroll
@@ -1243,6 +1244,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                     const float g = (cc < C) ? (FSM ? zl[cc] * rsum : zl[cc] / sum) - ((cc == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
                     if constexpr (LOG)
                         if (Lrow && lane == 0 && cc == tm.y_gt) Lrow[0] = -logf(zl[cc] / sum);   // explain.py:750-753
+                    if constexpr (LOG)
+                        if (Lrow && lane == 0 && cc < C && cc < LOGPN) Lrow[LOGP + cc] = zl[cc] / sum;   // explain.py:710-714, 157-158
                     dE1 = fmaf(wp[0][cc], g, dE1);
                     dE2 = fmaf(wp[1][cc], g, dE2);
                     dE3 = fmaf(wp[2][cc], g, dE3);
@@ -1336,6 +1339,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 if (lane < CMAX) sh.g[lane] = (lane < C) ? ex / sum - ((lane == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
                 if constexpr (LOG)
                     if (Lrow && lane == tm.y_gt) Lrow[0] = -logf(ex / sum);   // explain.py:750-753
+                    if (Lrow && lane < C && lane < LOGPN) Lrow[LOGP + lane] = ex / sum;   // the class probabilities the reference prints (explain.py:710-714, 157-158)
             }
             wave_sync();
 #pragma unroll
@@ -1656,7 +1660,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
             sh.dfp[tid] = s;
         }
         // ======== per owned edge: G_ij + G_ji, regulariser gradients, Adam on both directed entries ========
-        float ls_size = 0.0f, ls_ent = 0.0f, ls_lap = 0.0f;   // LOG form: this thread's part of the logged sums (its owned edges, both directions)
+        float ls_size = 0.0f, ls_ent = 0.0f, ls_lap = 0.0f, ls_den = 0.0f, ls_adj = 0.0f;   // LOG form: this thread's part of the logged sums (its owned edges, both directions)
         auto edge_phase = [&](auto ADAMc) {
         constexpr bool ADAM = decltype(ADAMc)::value;
 #pragma unroll
@@ -1732,6 +1736,10 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                     const float g = (gc + p.c_size - p.c_ent * Mji[q] * inv_n2) * S * (1.0f - S);
                     adam_update<ADAM, true>(Mji[q], mji[q], vji[q], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt, rbc2);
                 }
+                if constexpr (LOG) {   // ExplainModule.mask_density (explain.py:680-683), taken after optimizer.step() (:142-148): the UPDATED entries
+                    ls_den += wgt[q] * (0.5f * (sigmoidf_(Mij[q]) + sigmoidf_(Mji[q])));
+                    ls_adj += wgt[q];
+                }
                 if constexpr (MP) {
                     // publish in place (publish_abar's body for this edge): nothing reads sAb / sArt between the barrier behind the layer-1
                     // backward and the next iteration's layer 1.  Not after the last iteration: the returned mask is the one of the LAST forward.
@@ -1754,24 +1762,31 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 ls_size += __shfl_xor(ls_size, o);
                 ls_ent += __shfl_xor(ls_ent, o);
                 ls_lap += __shfl_xor(ls_lap, o);
+                ls_den += __shfl_xor(ls_den, o);
+                ls_adj += __shfl_xor(ls_adj, o);
             }
             if (lane == 0) {
                 sh.lsum[wave][0] = ls_size;
                 sh.lsum[wave][1] = ls_ent;
                 sh.lsum[wave][2] = ls_lap;
+                sh.lsum[wave][3] = ls_den;
+                sh.lsum[wave][4] = ls_adj;
             }
         }
         SYNC();  // dfp complete; every reader of sAb / sArt of this iteration is done
         if constexpr (LOG) {
             if (Lrow && wave == 0) {   // the entries off the edges were added to [1] and [3] by k_dead_entries before this launch
                 const float phs = (XC == 2) ? log_phs : sum_lanes_0_31((lane < D) ? sh.phi[lane] : 0.0f);   // (phi of this iteration: its update below is behind the wave sync)
-                float a = 0.0f, b = 0.0f, c = 0.0f;
+                float a = 0.0f, b = 0.0f, c = 0.0f, den = 0.0f, adj = 0.0f;
                 for (int w = 0; w < NW; ++w) {
                     a += sh.lsum[w][0];
                     b += sh.lsum[w][1];
                     c += sh.lsum[w][2];
+                    den += sh.lsum[w][3];
+                    adj += sh.lsum[w][4];
                 }
                 if (lane == 0) {
+                    Lrow[LOGD] = den / adj;
                     Lrow[1] += p.c_size * a;
                     Lrow[2] = GRAPH ? 0.0f : p.c_lap * c * inv_n2;
                     Lrow[3] += p.c_ent * b * inv_n2;

@@ -736,6 +736,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 if (lane < CMAX) sh.g[lane] = (lane < C) ? ex / sum - ((lane == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
                 if constexpr (LOG)
                     if (Lrow && lane == tm.y_gt) Lrow[0] = -logf(ex / sum);   // explain.py:750-753
+                    if (Lrow && lane < C && lane < LOGPN) Lrow[LOGP + lane] = ex / sum;   // the class probabilities the reference prints (explain.py:710-714, 157-158)
             }
             wave_sync();
 #pragma unroll
@@ -927,7 +928,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         }
         // ======== per near edge: G_ij + G_ji, regulariser gradients, Adam in place on both directed entries, next Abar ========
         const bool republish = iter + 1 < p.num_iters;  // the returned mask is the one of the LAST forward (explain.py:209-211)
-        float ls_size = 0.0f, ls_ent = 0.0f, ls_lap = 0.0f;   // LOG form: this thread's part of the logged sums (its near edges, both directions)
+        float ls_size = 0.0f, ls_ent = 0.0f, ls_lap = 0.0f, ls_den = 0.0f, ls_adj = 0.0f;   // LOG form: this thread's part of the logged sums (its near edges, both directions)
         // two edges per trip: the planes come from L2, and the loads of the second edge are in flight while the first is updated
         for (int k0 = tid; k0 < eupN; k0 += 2 * NT) {
             constexpr int EU = 2;
@@ -979,6 +980,12 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                         const float g = (gc + p.c_size - p.c_ent * Mji[u] * inv_n2) * S * (1.0f - S);
                         adam_update<ADAM, true>(Mji[u], mji[u], vji[u], g, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt, rbc2);
                     }
+                    if constexpr (LOG) {   // ExplainModule.mask_density (explain.py:680-683) after optimizer.step() (:142-148): the UPDATED entries
+                        if (on[u]) {
+                            ls_den += w[u] * (0.5f * (sigmoidf_(Mij[u]) + sigmoidf_(Mji[u])));
+                            ls_adj += w[u];
+                        }
+                    }
                 }
             };
             if (p.opt == 0) update(std::true_type{}); else update(std::false_type{});
@@ -1004,24 +1011,32 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 ls_size += __shfl_xor(ls_size, o);
                 ls_ent += __shfl_xor(ls_ent, o);
                 ls_lap += __shfl_xor(ls_lap, o);
+                ls_den += __shfl_xor(ls_den, o);
+                ls_adj += __shfl_xor(ls_adj, o);
             }
             if (lane == 0) {
                 sh.lsum[wave][0] = ls_size;
                 sh.lsum[wave][1] = ls_ent;
                 sh.lsum[wave][2] = ls_lap;
+                sh.lsum[wave][3] = ls_den;
+                sh.lsum[wave][4] = ls_adj;
             }
         }
         __syncthreads();
         if constexpr (LOG) {
             if (Lrow && wave == 0) {   // the entries off the edges were added to [1] and [3] by k_dead_entries; the far edges add theirs below
                 const float phs = sum_lanes_0_31((lane < D) ? sh.phi[lane] : 0.0f);
-                float a = 0.0f, b = 0.0f, c = 0.0f;
+                float a = 0.0f, b = 0.0f, c = 0.0f, den = 0.0f, adj = 0.0f;
                 for (int w = 0; w < NW; ++w) {
                     a += sh.lsum[w][0];
                     b += sh.lsum[w][1];
                     c += sh.lsum[w][2];
+                    den += sh.lsum[w][3];
+                    adj += sh.lsum[w][4];
                 }
                 if (lane == 0) {
+                    atomicAdd(&Lrow[LOGD + 1], den);   // mask density: numerator and denominator of the near edges; the far edges add theirs below, the
+                    atomicAdd(&Lrow[LOGD + 2], adj);   // quotient is formed at the end of the launch
                     atomicAdd(&Lrow[1], p.c_size * a);
                     atomicAdd(&Lrow[2], c);
                     atomicAdd(&Lrow[3], p.c_ent * b * inv_n2);
@@ -1092,6 +1107,12 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             const float gj = (gc + p.c_size - p.c_ent * Mji * inv_n2) * Sj * (1.0f - Sj);
             adam_update(Mij, mij, vij, gi, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
             adam_update(Mji, mji, vji, gj, p.omb1, p.beta2, p.omb2, p.eps, step_size, bc2s, p.opt);
+            if constexpr (LOG)
+                if (p.loss) {   // mask density after the step (explain.py:142-148, 680-683)
+                    float* L = p.loss + ((size_t)t * p.num_iters + iter) * NLOSS;
+                    atomicAdd(&L[LOGD + 1], w * (0.5f * (sigmoidf_(Mij) + sigmoidf_(Mji))));
+                    atomicAdd(&L[LOGD + 2], w);
+                }
         }
         p.Abar[tm.offQ + (size_t)i * ld + j] = a;
         p.Abar[tm.offQ + (size_t)j * ld + i] = a;
@@ -1106,6 +1127,15 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             p.v_out[tm.offQ + (size_t)j * ld + i] = vji;
         }
     }
+    if constexpr (LOG)
+        if (p.loss) {   // every edge has added its share: the density of each epoch
+            __threadfence_block();
+            __syncthreads();
+            for (int it = tid; it < p.num_iters; it += NT) {
+                float* L = p.loss + ((size_t)t * p.num_iters + it) * NLOSS;
+                L[LOGD] = L[LOGD + 1] / L[LOGD + 2];
+            }
+        }
     if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = (tid < D) ? sh.fcur[tid] : 0.0f;
     if (p.fs_out && tid < FS) {
         float* fs = p.fs_out + (size_t)t * 3 * FS + tid;

@@ -21,7 +21,7 @@ import torch
 
 FEAT_STRIDE = 32
 MAX_CLASSES = 32
-LOSS_TERMS = 8
+LOSS_TERMS = 16      # [0..4] pred, size, lap, ent, feat_size; [5] mask density after the step; [8..15] class probabilities (include/gnnx.h)
 _DEVICE_TYPE = "cuda"          # PyTorch-ROCm exposes HIP devices as "cuda"
 _LIB_NAME = "libgnnx_hip.so"
 
@@ -244,7 +244,7 @@ class JobResult:
     masked_adj: List[np.ndarray]    # per target [n, n] float32: sigma-symmetrised mask * adj of the last forward
     mask: List[np.ndarray]          # per target [n, n] final mask parameter
     feat_mask: np.ndarray           # [T, D] final feature-mask parameter (pre-sigmoid)
-    loss: Optional[np.ndarray] = None   # [T, iters, LOSS_TERMS]: pred, size, lap, ent, feat_size
+    loss: Optional[np.ndarray] = None   # [T, iters, LOSS_TERMS]: pred, size, lap, ent, feat_size, mask density, -, -, class probabilities
     stats: dict = field(default_factory=dict)
 
 
@@ -842,6 +842,10 @@ class MaskOptimJob:
         ma = [v[:n, :n].copy() for v, n in zip(self._square_views(Abar), self.n)]
         mk = [v[:n, :n].copy() for v, n in zip(self._square_views(M), self.n)]
         loss = self.loss.cpu().numpy() if hyper.record_loss else None
+        if loss is not None:      # the dense streaming kernels log the density as numerator [6] / denominator [7] (their tiles finish in no order)
+            den = loss[:, :, 7]
+            part = den != 0
+            loss[:, :, 5] = np.where(part & (loss[:, :, 5] == 0), loss[:, :, 6] / np.where(part, den, 1.0), loss[:, :, 5])
         return JobResult(ma, mk, self.fmask.cpu().numpy()[:, :self.D].copy(), loss)
 
     def run(self, masks, hyper: Hyper) -> JobResult:

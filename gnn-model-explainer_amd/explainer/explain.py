@@ -475,12 +475,12 @@ class Explainer:
                                             record_loss=self.print_training, unconstrained=unconstrained)[0]
         if self.print_training and self.last_result.loss is not None:
             tr = self.last_result.loss[0]        # logged by the kernel the optimisation ran on (the resident kernel's logging form)
-            # (explain.py:149-159 prints "epoch, loss, mask density, pred" every epoch.  The kernels log the five LOSS terms of explain.py:808-819;
-            #  the mask density - a second n^2 pass over the masked adjacency plus a device sync per epoch in the reference - and the class
-            #  probabilities are not logged, so this line carries the loss and its prediction term: a documented difference of the log FORMAT,
-            #  not of any result)
+            # explain.py:149-159 prints "epoch, loss, mask density, pred" every epoch: the five terms of ExplainModule.loss (:808-819), the density
+            # ExplainModule.mask_density takes AFTER the epoch's step (:142-148, 680-683) and the class probabilities of the epoch's forward
+            # (:710-714) - all logged by the kernels (include/gnnx.h: GNNX_LOSS_TERMS), no second pass, no device sync per epoch
+            C = min(int(_np(self.pred).shape[-1]), 8)
             for epoch in range(len(tr)):
-                print("epoch: ", epoch, "; loss: ", float(tr[epoch, :5].sum()), "; pred loss: ", float(tr[epoch, 0]))
+                print("epoch: ", epoch, "; loss: ", float(tr[epoch, :5].sum()), "; mask density: ", float(tr[epoch, 5]), "; pred: ", tr[epoch, 8:8 + C])
         print("finished training in ", self.last_time)
         fname = self._save(masked_adj, node_idx)
         print("Saved adjacency matrix to ", fname)

@@ -27,7 +27,9 @@ extern "C" {
 
 #define GNNX_FEAT_STRIDE 32 /* floats per row of row arrays; D, H, O <= 32 */
 #define GNNX_MAX_CLASSES 32
-#define GNNX_LOSS_TERMS 8   /* per (target, iteration): pred, size, lap, ent, feat_size, 3 spare */
+#define GNNX_LOSS_TERMS 16  /* per (target, iteration): [0..4] pred, size, lap, ent, feat_size (explain.py:808-819); [5] the mask density the reference prints
+                             * (ExplainModule.mask_density, explain.py:680-683: sum of the masked adjacency / sum of the adjacency, AFTER the epoch's step,
+                             * :142-148); [8..15] the class probabilities of the epoch's forward (explain.py:710-714; the first 8 classes) */
 
 typedef struct gnnx_plan_s* gnnx_handle;
 

@@ -196,6 +196,7 @@ class ClosedFormOracle:
         self.step = 0
         self.stages = {}
         self.trace = []
+        self.trace_log = []
 
     def iterate(self):
         n, w = self.n, self.w
@@ -243,11 +244,17 @@ class ClosedFormOracle:
             lap_l = C_LAP * F32((y * y * Abar.sum(0, dtype=F32)).sum(dtype=F32) - y @ Abar @ y) / F32(n * n)
         loss = pred_loss + size_l + lap_l + ent_l + fs_l
         self.trace.append((float(loss), float(pred_loss), float(size_l), float(lap_l), float(ent_l), float(fs_l)))
+        # what the reference prints next to the loss every epoch (explain.py:148-159): ExplainModule.mask_density (:680-683: sum of the masked
+        # adjacency / sum of the adjacency) and the class probabilities of the forward (:710-714)
+        self._log_p = np.asarray(p, F32).copy()
         self.stages = dict(Abar=Abar, S=S, phi=phi, X0=X0, U=U, R=R, Xin=Xin, p=p, dE=dE, dXd=dXd,
                            dZ=dZ, dX0=dX0, G=G, dM=dM, df=df)
         self.step += 1
         self.M, self.mM, self.vM = adam(self.M, self.mM, self.vM, dM, self.step, self.lr)
         self.f, self.mf, self.vf = adam(self.f, self.mf, self.vf, df, self.step, self.lr)
+        # (the density is taken AFTER optimizer.step(), explain.py:142-148: the masked adjacency of the updated mask)
+        with np.errstate(invalid="ignore", divide="ignore"):      # (a graph without edges: 0 / 0, as in the reference)
+            self.trace_log.append((float(masked_adj(self.M, self.A)[0].sum(dtype=F32) / self.A.sum(dtype=F32)), self._log_p))
 
     def run(self, num_epochs):
         for _ in range(num_epochs):

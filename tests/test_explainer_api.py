@@ -307,3 +307,40 @@ def test_cli_default_mode_batched_on_gpu(tmp_path, monkeypatch):
     out = explainer_main.main(["--dataset=syn1", "--epochs=100", "--ckptdir", ckptdir, "--logdir", str(tmp_path / "log")])
     assert len(out) == 60 and all(np.array_equal(m, m.T) for m in out)
     assert len([f for f in os.listdir(tmp_path / "log") if f.startswith("masked_adj_")]) == 60
+
+
+def _printed_epochs(text):
+    import re
+    rows = []
+    for line in text.splitlines():
+        m = re.match(r"epoch:\s+(\d+)\s+; loss:\s+(\S+)\s+; mask density:\s+(\S+)\s+; pred:\s+\[(.*)\]", line)
+        if m:
+            rows.append((int(m.group(1)), float(m.group(2)), float(m.group(3)), np.asarray([float(v) for v in m.group(4).split()])))
+    return rows
+
+
+def _check_print_training(ex, capsys, targets):
+    """print_training=True: one line per epoch with the reference's fields - "epoch: e ; loss: L ; mask density: d ; pred: [p ...]" (explain.py:149-159) -
+    whose values are the LIVE reference's (tests/golden/logging_explain.npz: the density is the one AFTER the epoch's step, :142-148)."""
+    z = np.load(os.path.join(helpers.GOLDEN, "logging_explain.npz"))
+    ex.print_training = True
+    for t in targets:
+        torch.manual_seed(1000 + t)
+        capsys.readouterr()
+        ex.explain(t)
+        rows = _printed_epochs(capsys.readouterr().out)
+        assert [r[0] for r in rows] == list(range(int(z["epochs"])))
+        assert np.allclose([r[1] for r in rows], z[f"{t}:loss"], rtol=1e-5)
+        assert np.abs(np.asarray([r[2] for r in rows]) - z[f"{t}:density"]).max() < 1e-5
+        assert np.abs(np.stack([r[3] for r in rows]) - z[f"{t}:pred"]).max() < 1e-5
+
+
+def test_print_training_prints_the_references_fields_on_the_emulator(tmp_path, emu_engine, capsys):
+    _, _, ex = _explainer(tmp_path, 40)
+    _check_print_training(ex, capsys, (302, 309))
+
+
+@pytest.mark.gpu
+def test_print_training_prints_the_references_fields_on_gpu(tmp_path, capsys):
+    _, _, ex = _explainer(tmp_path, 40)
+    _check_print_training(ex, capsys, (302, 309, 300))

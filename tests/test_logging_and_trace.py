@@ -38,6 +38,37 @@ def _levels(sg):
     return lvl
 
 
+def _check_density_and_pred(loss, o):
+    """What the reference prints next to the loss every epoch (explain.py:148-159): ExplainModule.mask_density AFTER the epoch's step (slot 5 of the
+    kernels' log) and the class probabilities of the epoch's forward (slots 8 ...) against the closed form (pinned to the live reference's
+    values by test_closed_form_density_and_pred_vs_live_reference)."""
+    dens = np.asarray([x[0] for x in o.trace_log])
+    pred = np.stack([x[1] for x in o.trace_log])
+    C = min(pred.shape[1], 8)
+    assert np.allclose(loss[:, 5], dens, rtol=2e-5, atol=1e-7), (loss[:, 5], dens)
+    assert np.abs(loss[:, 8:8 + C] - pred[:, :C]).max() < 2e-6, (loss[:, 8:8 + C], pred[:, :C])
+
+
+def test_closed_form_density_and_pred_vs_live_reference():
+    """tests/golden/logging_explain.npz (make_golden_logging.py: the LIVE reference's per-epoch mask density and class probabilities, n = 6 / 48 / 310):
+    the closed form reproduces them - the density is the one of the UPDATED mask (explain.py:142-148)."""
+    z = np.load(os.path.join(helpers.GOLDEN, "logging_explain.npz"))
+    ck = helpers.load_ckpt("syn1")
+    from gnn_model_explainer_amd.utils.graph_utils import KHopIndex
+    idx = KHopIndex((ck["num_nodes"], ck["edges"]), 3)
+    for t in (int(v) for v in z["targets"]):
+        nb = idx.neighbors_batch(np.asarray([t]))[0]
+        A, X, lab, yhat = helpers.subgraph(ck, nb)
+        new = int(np.searchsorted(nb, t))
+        o = closed_form.ClosedFormOracle(A, X, ck["sd"], int(lab[new]), yhat, new, helpers.seeded_mask0(t, len(nb)).numpy())
+        for _ in range(int(z["epochs"])):
+            o.iterate()
+        dens = np.asarray([x[0] for x in o.trace_log])
+        pred = np.stack([x[1] for x in o.trace_log])
+        assert np.abs(dens - z[f"{t}:density"]).max() < 1e-6 and np.abs(pred - z[f"{t}:pred"]).max() < 2e-6
+        assert np.allclose(np.asarray(o.trace)[:, 0], z[f"{t}:loss"], rtol=2e-6)
+
+
 def _gate_words(U):
     return ((U > 0) * (1 << np.arange(U.shape[1]))).sum(1).astype(np.uint32)
 
@@ -72,6 +103,7 @@ def test_logging_form_mixed_launch_loss_and_gates_vs_closed_form(be, monkeypatch
                 assert np.array_equal(want, gates[i][it, :, l]), (i, it, l)
         tr = np.asarray(o.trace)            # total, pred, size, lap, ent, feat_size
         assert np.allclose(res.loss[i][:, :5], tr[:, 1:6], rtol=2e-5, atol=1e-7)
+        _check_density_and_pred(res.loss[i], o)
         assert np.abs(res.mask[i] - o.M).max() < 2e-5          # every entry of M, on and off the edges
 
 
@@ -104,6 +136,7 @@ def test_logging_form_of_the_large_target_kernel_loss_and_gates_vs_closed_form(b
             assert np.array_equal(want, gates[0][it, :, l]), (it, l)
     tr = np.asarray(o.trace)            # total, pred, size, lap, ent, feat_size
     assert np.allclose(res.loss[0][:, :5], tr[:, 1:6], rtol=5e-5, atol=1e-7), (res.loss[0][:, :5], tr[:, 1:6])
+    _check_density_and_pred(res.loss[0], o)
     assert np.abs(res.mask[0] - o.M).max() < 2e-5
 
 
@@ -131,6 +164,7 @@ def test_logging_form_graph_mode_loss_gates_and_pool_rows(be):
                 assert (pool[i, it, l, a.shape[1]:] == -1).all()
         tr = np.asarray(o.trace)
         assert np.allclose(res.loss[i][:, [0, 1, 3, 4]], tr[:, [1, 2, 4, 5]], rtol=2e-5, atol=1e-7) and (res.loss[i][:, 2] == 0).all()
+        _check_density_and_pred(res.loss[i], o)
 
 
 def test_logged_loss_is_the_streaming_kernels_loss(be):
@@ -142,7 +176,9 @@ def test_logged_loss_is_the_streaming_kernels_loss(be):
         job = be.job(subs, ck["sd"])
         out.append(job.run([s.mask0 for s in subs], Hyper(num_iters=8, record_loss=True, use_resident=use_resident)))
     for i in range(len(subs)):
-        assert np.allclose(out[0].loss[i], out[1].loss[i], rtol=2e-5, atol=1e-7)
+        keep = [0, 1, 2, 3, 4, 5] + list(range(8, 16))       # (6, 7: the streaming kernels' numerator / denominator of the density)
+        assert np.allclose(out[0].loss[i][:, keep], out[1].loss[i][:, keep], rtol=2e-5, atol=1e-7)
+        assert (out[0].loss[i][:, 5] > 0).all() and (out[0].loss[i][:, 8:12].sum(1) > 0.99).all()
         assert np.abs(out[0].mask[i] - out[1].mask[i]).max() < 2e-5
 
 
