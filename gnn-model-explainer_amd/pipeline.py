@@ -64,7 +64,11 @@ class BatchPipeline:
         # pairs (gnnx_host_transform_edge_words): bit-identical, O(E) instead of O(sum n^2) host work - the 16 384-target BA-House x100k batch
         # cost 0.64 core-seconds per step with the host walk, which bound a node's ranks to its CPU quota beyond two GPUs.  Needs the
         # pair-staging property of the host's normal_ (checked once per process); device_walk=False / GNNX_PIPE_DEVICE_WALK=0: the host walk.
-        self.device_walk = bool(int(os.environ.get("GNNX_PIPE_DEVICE_WALK", "1"))) if device_walk is None else bool(device_walk)
+        # Default: the device walk when the ranks of a node share its cores (LOCAL_WORLD_SIZE > 1), the host walk for a single process - its 0.66
+        # core-seconds per 16 384-target step fit one process's quota, and the device walk's kernels share the chip with the optimisation of the
+        # batch before: 204.0 k (host) against 183.8 k nodes/s (device) on one GPU in the closing session (profiles/r05_bench_ba100k_16384targets*.json)
+        auto_walk = "1" if int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > 1 else "0"
+        self.device_walk = bool(int(os.environ.get("GNNX_PIPE_DEVICE_WALK", auto_walk))) if device_walk is None else bool(device_walk)
         # Optimisations in flight.  depth=None (default): as many as keep the chip full and no more - ceil(1.3 x 256 CUs / the compute units ONE
         # launch keeps busy), between 2 and 5, re-evaluated per batch (_launch_cus; four when a batch has streaming targets): every further launch in flight only queues behind the
         # others and lengthens the fill and drain of a short job.  Measured (profiles/r05_pipeline_workers_depth_room.txt): syn1 (116 workgroups
