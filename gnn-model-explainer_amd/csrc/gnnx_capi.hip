@@ -224,6 +224,20 @@ extern "C" void* gnnx_stream_create_cu_mask(const uint32_t* mask, int32_t words)
     return (void*)st;
 }
 extern "C" void* gnnx_lane_stream(int32_t i) { return (i >= 0 && i < N_LANES) ? (void*)lane_stream(i) : nullptr; }
+__global__ void k_debug_lane_sums(const float* in, float* out) {
+    const float v = in[threadIdx.x];
+    out[threadIdx.x] = xor32_sum(v);
+    out[64 + threadIdx.x] = v + __shfl_xor(v, 32);
+    out[128 + threadIdx.x] = xor16_sum(v);
+    out[192 + threadIdx.x] = v + __shfl_xor(v, 16);
+}
+extern "C" int gnnx_debug_lane_sums(const float* in, float* out, void* stream) {
+    if (!in || !out) return fail("null argument");
+    hipLaunchKernelGGL(k_debug_lane_sums, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), in, out);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int gnnx_debug_spin(void* stream, int32_t micros) {
     int rate_khz = 100000;   // wall_clock64 ticks at 100 MHz on gfx950
     int dev = 0;

@@ -173,6 +173,7 @@ _API = {
     "gnnx_lane_stream": (ctypes.c_void_p, [ctypes.c_int32]),
     "gnnx_stream_create_cu_mask": (ctypes.c_void_p, [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int32]),
     "gnnx_debug_spin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
+    "gnnx_debug_lane_sums": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "gnnx_last_error": (ctypes.c_char_p, []),
     "gnnx_version": (ctypes.c_char_p, []),
 }

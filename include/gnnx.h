@@ -324,6 +324,10 @@ int gnnx_set_service_stream(void* stream);
 void* gnnx_stream_create_cu_mask(const uint32_t* mask, int32_t words);
 void* gnnx_lane_stream(int32_t i);
 int gnnx_debug_spin(void* stream, int32_t micros);
+/* Self-check of the lane sums the kernels are built on (gnnx_kernels.hpp: xor32_sum / xor16_sum - gfx950's v_permlane32_swap / v_permlane16_swap
+ * through inline assembly): in = 64 device floats (one wave), out = 256 device floats: [0, 64) xor32_sum, [64, 128) v + shfl_xor(v, 32),
+ * [128, 192) xor16_sum, [192, 256) v + shfl_xor(v, 16).  The two forms of each must agree bit for bit (tests/test_gpu_lane_sums.py). */
+int gnnx_debug_lane_sums(const float* in, float* out, void* stream);
 
 /* The library keeps the device blocks of destroyed plans for the next plan (hipMalloc / hipFree per batch serialise a pipelined
  * job: hipFree synchronises the device); this returns the idle ones of the current device to the driver. */
