@@ -12,10 +12,11 @@ from gnn_model_explainer_amd.utils.graph_utils import KHopIndex
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,edge_draw_min", [("syn4", 2e7), ("syn1", 2e7), ("syn1", 0.0)])
-def test_pipelined_batches_equal_sequential_jobs(name, edge_draw_min):
+@pytest.mark.parametrize("name,edge_draw_min,device_walk", [("syn4", 2e7, None), ("syn1", 2e7, None), ("syn1", 0.0, False), ("syn1", 0.0, True)])
+def test_pipelined_batches_equal_sequential_jobs(name, edge_draw_min, device_walk):
     """(edge_draw_min = 0: the host keeps only the values on the edges of its draw - gnnx_host_draw_edge_masks, the path of the large
-    BA-House x100k batches - and the results must still be the sequential path's bit for bit)"""
+    BA-House x100k batches - and the results must still be the sequential path's bit for bit; device_walk: the engine of that draw on the
+    host (a single process's default) or on the device (gnnx_mt_edge_words: the default of a node's ranks))"""
     ck = helpers.load_ckpt(name)
     idx = KHopIndex((ck["num_nodes"], ck["edges"]), 3)
     graph = engine.device_graph(idx.csr, ck["feat"], ck["pred"])
@@ -23,10 +24,11 @@ def test_pipelined_batches_equal_sequential_jobs(name, edge_draw_min):
     rng = np.random.default_rng(3)
     batches = [np.sort(rng.choice(np.arange(first, ck["num_nodes"]), k, replace=False)) for k in (7, 64, 1, 33, 64)]   # ragged, one repeated size
     hy = Hyper(num_iters=25)
-    pipe = BatchPipeline(graph, ck["sd"], ck["label"], hy, rng_threads=4, edge_draw=True, edge_draw_min_values=edge_draw_min)
+    pipe = BatchPipeline(graph, ck["sd"], ck["label"], hy, rng_threads=4, edge_draw=True, edge_draw_min_values=edge_draw_min, device_walk=device_walk)
     got = list(pipe.run(batches))
     assert len(got) == len(batches) and len(pipe.stats) == len(batches)
     assert all(("host_rng_edges_only" in st) == (edge_draw_min == 0.0) for st in pipe.stats)
+    assert all(("host_rng_device_walk" in st) == bool(device_walk and edge_draw_min == 0.0 and engine.pair_staging_ok()) for st in pipe.stats)
     for targets, em in zip(batches, got):
         dn = engine.khop_device(graph, targets, 3)
         job = MaskOptimJob.from_csr(graph, dn, None, ck["label"][targets], ck["sd"])
