@@ -42,14 +42,15 @@ if _q and _q < (_os.cpu_count() or 1):
 # free 233-246 k nodes/s, prepare stage 2.65 ms, single repetitions down to 142 k; confined to EITHER node 254-264 k, prepare 1.9-2.2 ms.
 # Called at import (before torch / HIP create their threads, which inherit it) when the process is in a quota-limited container and its
 # affinity spans several nodes; GNNX_CPU_AFFINITY=0 leaves the affinity alone.  The ranks of a node spread over its NUMA nodes.
-def confine_to_one_numa_node():
+def confine_to_one_numa_node(node_root="/sys/devices/system/node", get_affinity=None, set_affinity=None):
+    """(node_root / get_affinity / set_affinity: injected by tests/test_host_api.py)"""
     import glob as _glob
     if _os.environ.get("GNNX_CPU_AFFINITY", "1") == "0" or not hasattr(_os, "sched_setaffinity"):
         return None
     try:
-        cur = _os.sched_getaffinity(0)
+        cur = set(get_affinity() if get_affinity else _os.sched_getaffinity(0))
         nodes = []
-        for path in sorted(_glob.glob("/sys/devices/system/node/node[0-9]*/cpulist")):
+        for path in sorted(_glob.glob(_os.path.join(node_root, "node[0-9]*", "cpulist"))):
             cpus = set()
             for part in open(path).read().strip().split(","):
                 if part:
@@ -61,7 +62,7 @@ def confine_to_one_numa_node():
             return None                      # one node, or already confined
         rank, world = int(_os.environ.get("LOCAL_RANK", "0")), max(1, int(_os.environ.get("LOCAL_WORLD_SIZE", "1")))
         pick = nodes[min(len(nodes) - 1, rank * len(nodes) // world)]
-        _os.sched_setaffinity(0, pick)
+        (set_affinity or (lambda cpus: _os.sched_setaffinity(0, cpus)))(pick)
         return sorted(pick)
     except Exception:
         return None

@@ -216,3 +216,30 @@ def test_pipeline_launch_cus_estimate():
     assert cus([5] * 10) == 5 and cus([5] * 3 + [6] * 9) == 2 + 2
     assert cus([7] * 3 + [8] * 2) == 5
     assert cus([8] * 5000) == 256 and cus([0, 8]) == -1                  # saturating launches; streaming targets in the batch
+
+
+def test_confine_to_one_numa_node(tmp_path, monkeypatch):
+    """gnn_model_explainer_amd.confine_to_one_numa_node on a fake two-node host: a process whose affinity spans both nodes is confined to one
+    (the ranks of a node spread over them), one that already sits on one node - or is told not to - is left alone."""
+    import gnn_model_explainer_amd as pkg
+    for k, cpus in enumerate(("0-3,8-11", "4-7,12-15")):
+        d = tmp_path / ("node%d" % k)
+        d.mkdir()
+        (d / "cpulist").write_text(cpus + "\n")
+    seen = []
+    run = lambda aff: pkg.confine_to_one_numa_node(str(tmp_path), lambda: aff, seen.append)
+    monkeypatch.delenv("GNNX_CPU_AFFINITY", raising=False)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    assert run(set(range(16))) == [0, 1, 2, 3, 8, 9, 10, 11] and seen[-1] == {0, 1, 2, 3, 8, 9, 10, 11}
+    assert run({0, 1, 2, 3}) is None and len(seen) == 1                   # already on one node
+    assert run({2, 3, 4, 5}) == [2, 3]                                   # only the CPUs the process may use
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    picks = []
+    for r in range(8):
+        monkeypatch.setenv("LOCAL_RANK", str(r))
+        picks.append(run(set(range(16)))[0])
+    assert picks == [0, 0, 0, 0, 4, 4, 4, 4]                             # ranks 0-3 on node 0, 4-7 on node 1
+    monkeypatch.setenv("GNNX_CPU_AFFINITY", "0")
+    n = len(seen)
+    assert run(set(range(16))) is None and len(seen) == n
