@@ -36,28 +36,14 @@ import sys
 import threading
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the first HIP call: see gnn-model-explainer_amd/__init__.py
-os.environ.setdefault("GPU_FORCE_BLIT_COPY_SIZE", "1024")   # (KB) table uploads / result downloads as blit kernels, not SDMA: ibid.
-
-def _cpu_quota_cores():      # (gnn-model-explainer_amd/__init__.py: torch's CPU pool sized to the container's quota, before torch is imported)
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        return None if q == "max" else float(q) / float(per)
-    except Exception:
-        return None
-
-
-_Q = _cpu_quota_cores()
-if _Q and _Q < (os.cpu_count() or 1):
-    _RANKS = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
-    for _v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
-        os.environ.setdefault(_v, str(max(1, int(_Q) // (2 * _RANKS))))
-    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-import gnn_model_explainer_amd as _pkg      # BEFORE torch: environment defaults above + the process confined to one NUMA node (its __init__)
+import gnn_model_explainer_amd as _pkg
+
+# BEFORE torch is imported and before the first HIP call: eight hardware queues, small copies as blit kernels, torch's CPU pool sized to the
+# container's quota, the process confined to one NUMA node - an explicit call since round 6 (importing the package changes nothing any more).
+_pkg.tune_process()
 
 import numpy as np
 import torch

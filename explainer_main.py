@@ -7,6 +7,9 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+if __name__ == "__main__":
+    import gnn_model_explainer_amd
+    gnn_model_explainer_amd.tune_process()      # before torch is imported: this process exists to run the engine
 from gnn_model_explainer_amd.explainer_main import main  # noqa: E402
 
 if __name__ == "__main__":

@@ -600,9 +600,16 @@ extern "C" int gnnx_host_transform_edge_words(int32_t T, const int32_t* n, const
             c10::InferenceMode ng;
             Stager& sg = thread_stager();
             sg.out = out;
+            sg.pairs = 0;          // (an exception in an earlier call on this thread may have left pairs staged for ANOTHER out buffer: ADVICE r5)
+            sg.wants.clear();
             for (int k = items[it].first; k < items[it].second; ++k) {
                 const int64_t nk = n[k], nn = nk * nk, e0 = eoff[k], e1 = eoff[k + 1];
                 if (nn == 0 || e1 == e0) continue;
+                // a target's edge ids are validated BEFORE anything is staged (as gnnx_host_draw_edge_masks does): nothing half-staged survives a throw
+                for (int64_t e = e0; e < e1; ++e) {
+                    const int64_t r = rc[2 * e], c = rc[2 * e + 1];
+                    if (r < 0 || r >= nk || c < 0 || c >= nk) throw std::out_of_range("gnnx_host_transform_edge_words: edge outside its target's block");
+                }
                 sg.std_ = std::sqrt(2.0) * std::sqrt(2.0 / ((double)nk + (double)nk));
                 if (nn < 16) {      // ATen's scalar path on the whole stream
                     at::Generator& gen = sg.gen;
@@ -633,6 +640,9 @@ extern "C" int gnnx_host_transform_edge_words(int32_t T, const int32_t* n, const
                 sg.flush();      // (the next target has another standard deviation)
             }
         } catch (const std::exception& e) {
+            Stager& sg = thread_stager();
+            sg.pairs = 0;
+            sg.wants.clear();
             std::lock_guard<std::mutex> lk(err_mu);
             failed = true;
             err = e.what();

@@ -160,9 +160,6 @@ __device__ __forceinline__ float exp_(float x) { return expf(x); }
 #endif
 __device__ __forceinline__ float sigmoidf_(float x) { return rcp_(1.0f + exp_(-x)); }
 
-// v + v[lane ^ 32] / v + v[lane ^ 16].  (Measured in round 3: the gfx950 lane-swap instructions v_permlane32_swap_b32 /
-// v_permlane16_swap_b32 in place of the ds_bpermute_b32 these shuffles compile to changed the iteration of the sparse resident
-// kernel by 0.1 of 11.3 us - the LDS crossbar round trip is not what the chain waits for - so the portable form stays.)
 // From here on the value of a register is unknown to the optimiser (no instruction is emitted): expressions derived from it are formed where
 // they are used instead of being kept in registers across a whole loop.  (tests/emu/include/hip/hip_runtime.h defines it for the host compiler.)
 #ifndef GNNX_OPAQUE
@@ -173,22 +170,38 @@ __device__ __forceinline__ float sigmoidf_(float x) { return rcp_(1.0f + exp_(-x
 // {lo, lo} / {hi, hi} (resp. {r0, r0, r2, r2} / {r1, r1, r3, r3}) in the pair: their sum is the shuffle form's, operand for operand (the addition
 // commutes: bit-identical in all 64 lanes, tools/micro/permlane_swap.hip) - a VALU instruction instead of a ds_bpermute round trip through the
 // LDS crossbar: 25.1 ns instead of 38.5 / 36.8 ns per dependent step (profiles/r05_permlane_swap.txt), and no lgkmcnt wait shared with the
-// loads in flight.  Inline assembly: with this compiler (ROCm 7.2) the sum of the builtin's two results comes out as r[0] + r[0]; the one wait
-// state the hazard recogniser puts in front of a lane swap is written out.  The CPU emulator of tests/emu keeps the shuffle form.
+// loads in flight.  Inline assembly: with this compiler (ROCm 7.2) the sum of the builtin's two results comes out as r[0] + r[0].  The hazard
+// recogniser puts TWO wait states (`s_nop 1`) between the VALU write of an operand (the `b = a` copy) and the lane swap that reads it - checked
+// on the ISA hipcc emits for __builtin_amdgcn_permlane32_swap on gfx950 - so the inline form writes out the same two (round 5 had `s_nop 0`, one
+// short: ADVICE r5).  The CPU emulator of tests/emu runs swap_halves_sum below: the same two-copy exchange, lane for lane, on the emulator's
+// shuffles - so the CPU suite exercises the pairing the instruction performs; tests/test_gpu_lane_sums.py pins the instruction itself.
 #if defined(__HIPCC__)
 __device__ __forceinline__ float xor32_sum(float v) {
     int a = __builtin_bit_cast(int, v), b = a;
-    asm("s_nop 0\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
 }
 __device__ __forceinline__ float xor16_sum(float v) {
     int a = __builtin_bit_cast(int, v), b = a;
-    asm("s_nop 0\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
 }
 #else
-__device__ __forceinline__ float xor32_sum(float v) { return v + __shfl_xor(v, 32); }
-__device__ __forceinline__ float xor16_sum(float v) { return v + __shfl_xor(v, 16); }
+// v_permlane{32,16}_swap_b32 a, b on the emulator: groups of W lanes; the ODD groups of a <-> the EVEN groups of b (W = 32: a's upper half <->
+// b's lower half).  Lane l of an even group: a' = a[l], b' = a[l + W] (taken from a's odd group);  lane l of an odd group: a' = b[l - W], b' = b[l].
+template <int W>
+__device__ __forceinline__ float swap_halves_sum(float v) {
+    const float a = v, b = v;
+    const int lane = (int)(threadIdx.x & 63u);
+    const bool odd = (lane / W) & 1;
+    const float a_from_b = __shfl_xor(b, W);   // what an odd-group lane of a receives: b of the even group below it
+    const float b_from_a = __shfl_xor(a, W);   // what an even-group lane of b receives: a of the odd group above it
+    const float a2 = odd ? a_from_b : a;
+    const float b2 = odd ? b : b_from_a;
+    return a2 + b2;
+}
+__device__ __forceinline__ float xor32_sum(float v) { return swap_halves_sum<32>(v); }
+__device__ __forceinline__ float xor16_sum(float v) { return swap_halves_sum<16>(v); }
 #endif
 
 // row of the 32x32 MFMA accumulator held in register r of a lane in half h (lane>>5); column = lane&31

@@ -1095,9 +1095,10 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 sum += row_shl<1>(sum);
                 sum = bcast_first(sum);
                 if (lane < CMAX) sh.g[lane] = (lane < C) ? ex / sum - ((lane == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
-                if constexpr (LOG)
+                if constexpr (LOG) {
                     if (Lrow && lane == tm.y_gt) Lrow[0] = -logf(ex / sum);   // explain.py:750-753
-                    if (Lrow && lane < C && lane < LOGPN) Lrow[LOGP + lane] = ex / sum;   // the class probabilities the reference prints (explain.py:710-714, 157-158)
+                    if (Lrow && lane < C && lane < LOGPN) Lrow[LOGP + lane] = ex / sum;   // the class probabilities the reference prints (explain.py:710-714, 157-158; the first LOGPN classes: include/gnnx.h)
+                }
             }
             wave_sync();
 #pragma unroll
@@ -1337,9 +1338,10 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 sum += row_shl<1>(sum);
                 sum = bcast_first(sum);
                 if (lane < CMAX) sh.g[lane] = (lane < C) ? ex / sum - ((lane == tm.y_gt) ? 1.0f : 0.0f) : 0.0f;
-                if constexpr (LOG)
+                if constexpr (LOG) {
                     if (Lrow && lane == tm.y_gt) Lrow[0] = -logf(ex / sum);   // explain.py:750-753
-                    if (Lrow && lane < C && lane < LOGPN) Lrow[LOGP + lane] = ex / sum;   // the class probabilities the reference prints (explain.py:710-714, 157-158)
+                    if (Lrow && lane < C && lane < LOGPN) Lrow[LOGP + lane] = ex / sum;   // the class probabilities the reference prints (explain.py:710-714, 157-158; the first LOGPN classes: include/gnnx.h)
+                }
             }
             wave_sync();
 #pragma unroll

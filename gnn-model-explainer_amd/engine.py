@@ -13,6 +13,7 @@ torch autograd; torch.optim.Adam via utils/train_utils.py:9-10).
 import ctypes
 import math
 import os
+from contextlib import nullcontext as _nullcontext
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -638,8 +639,11 @@ class MaskOptimJob:
         if getattr(self, "_M_on_edges_only", False):
             E = int(self._eoff[-1])
             pos, v = self._epos[:E], self._edge_vals0
-            self.M.index_put_((pos[:, 0],), v[:, 0])
-            self.M.index_put_((pos[:, 1],), v[:, 1])
+            self._enter()          # (ordered with the job's stream like every other writer of M: ADVICE r5)
+            with torch.cuda.stream(self.stream) if self.stream is not None else _nullcontext():
+                self.M.index_put_((pos[:, 0],), v[:, 0])
+                self.M.index_put_((pos[:, 1],), v[:, 1])
+            self._leave()
         else:
             self.set_masks_raw_resident()
 

@@ -108,4 +108,8 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
+    # this process exists to run the engine: eight HIP queues, CPU pool sized to the container's quota, one NUMA node - an explicit call
+    # (a caller that imports the package, or calls main() from its own process, gets none of it)
+    from . import tune_process
+    tune_process()
     main()
