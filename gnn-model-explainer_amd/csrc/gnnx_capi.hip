@@ -1038,19 +1038,19 @@ static void launch_sparse(gnnx_handle h, const Params& p, int cls, const float* 
         const dim3 grid(h->n_sp[cls]), block(SPL_THREADS);
         if (log)      // the logging form (loss scalars + decision trace): exact shapes only, checked by the caller
             hipLaunchKernelGGL((k_sparse_large<5, 10, true>), grid, block, 0, s, p, h->d_sp[cls], adam_tab, h->d_csr_rowptr,
-                               h->d_csr_col, h->d_csr_row, h->d_csr_off, h->d_nnz + 2 * h->prob.num_targets);
+                               h->d_csr_col, h->d_csr_row, h->d_csr_off, h->d_nnz + 2 * h->prob.num_targets, XlIo{});
         else if (exact_shape(h, 10))
             hipLaunchKernelGGL((k_sparse_large<5, 10>), grid, block, 0, s, p, h->d_sp[cls], adam_tab, h->d_csr_rowptr,
-                               h->d_csr_col, h->d_csr_row, h->d_csr_off, h->d_nnz + 2 * h->prob.num_targets);
+                               h->d_csr_col, h->d_csr_row, h->d_csr_off, h->d_nnz + 2 * h->prob.num_targets, XlIo{});
         else if (small_shape(h, 10))
             hipLaunchKernelGGL((k_sparse_large<5, 10, false, false>), grid, block, 0, s, p, h->d_sp[cls], adam_tab, h->d_csr_rowptr,
-                               h->d_csr_col, h->d_csr_row, h->d_csr_off, h->d_nnz + 2 * h->prob.num_targets);
+                               h->d_csr_col, h->d_csr_row, h->d_csr_off, h->d_nnz + 2 * h->prob.num_targets, XlIo{});
         else if (wide_shape(h, 10))
             hipLaunchKernelGGL((k_sparse_large<5, 16, false, false>), grid, block, 0, s, p, h->d_sp[cls], adam_tab, h->d_csr_rowptr,
-                               h->d_csr_col, h->d_csr_row, h->d_csr_off, h->d_nnz + 2 * h->prob.num_targets);
+                               h->d_csr_col, h->d_csr_row, h->d_csr_off, h->d_nnz + 2 * h->prob.num_targets, XlIo{});
         else
             hipLaunchKernelGGL((k_sparse_large<16, 16>), grid, block, 0, s, p, h->d_sp[cls], adam_tab, h->d_csr_rowptr,
-                               h->d_csr_col, h->d_csr_row, h->d_csr_off, h->d_nnz + 2 * h->prob.num_targets);
+                               h->d_csr_col, h->d_csr_row, h->d_csr_off, h->d_nnz + 2 * h->prob.num_targets, XlIo{});
         return;
     }
     if (cls == SPC_512) launch_sparse_nt<512>(h, p, h->d_sp[cls], h->n_sp[cls], adam_tab, s, log);
@@ -1998,6 +1998,349 @@ extern "C" int gnnx_time_kernel(gnnx_handle h, const gnnx_hyper* hy, int32_t kin
     if (alg_flops) {
         const double d = (kind == 1) ? h->prob.D : h->prob.H;
         *alg_flops = (kind == 0) ? 2.0 * sum_n2 * kagg : contraction ? 2.0 * sum_n2 * d : 0.0;
+    }
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+// =============================================================================================================================
+// The XL route (include/gnnx.h: gnnx_xl_*): node-mode targets of ANY size, CSR-native from the resident graph to the edge lists of the
+// result - k_xl_rowdeg / k_xl_rowptr / k_xl_emit (gnnx_xl.hpp) build every target's sub-graph CSR, k_sparse_large<.., XL = true>
+// (gnnx_sparse_large.hpp) runs all iterations with its state in the target's scratch block.  No dense n x n block exists anywhere.
+// =============================================================================================================================
+#include "gnnx_xl.hpp"
+
+struct gnnx_xl_s {
+    gnnx_problem prob{};
+    std::vector<TargetMeta> meta;
+    std::vector<XlBlock> blocks;
+    std::vector<int32_t> ids;
+    int64_t R = 0;                    // rows of the row arrays (sum of ld)
+    int64_t E = -1, NNZ = -1;         // upper-triangle edges / directed entries of the batch (after gnnx_xl_count)
+    std::vector<int64_t> edges;       // per target
+    std::vector<long long> csr_off, eoff, scr_off;
+    long long scr_floats = 0;
+    bool weighted = false;
+    bool built = false;
+    // device tables (library-owned, recycled)
+    void* block1 = nullptr;           // meta, blocks, ids, wts
+    TargetMeta* d_meta = nullptr;
+    XlBlock* d_blocks = nullptr;
+    int32_t* d_ids = nullptr;
+    float* d_wts = nullptr;
+    void* block2 = nullptr;           // csr_off, eoff, scr_off, rp_off
+    long long* d_csr_off = nullptr;
+    long long* d_eoff = nullptr;
+    long long* d_scr_off = nullptr;
+    long long* d_rp_off = nullptr;
+    float* d_adam = nullptr;
+    bool adam_shared = false;
+    gnnx_hyper adam_for{};
+    int adam_first = -1;
+    uint32_t* trace_gates = nullptr;
+    // carve-out of the caller's two workspaces (bytes)
+    size_t r_X, r_yhat, r_deg, r_updeg, r_rowptr, r_uprow, r_totals, rows_bytes = 0;
+    size_t e_col, e_row, e_w, e_scr, entries_bytes = 0;
+};
+
+static size_t xl_take(size_t& o, size_t bytes) {
+    const size_t r = o;
+    o = align_up(o + bytes, 256);
+    return r;
+}
+
+extern "C" int gnnx_xl_create(const gnnx_problem* prob, const gnnx_model* model, gnnx_xl_handle* out) {
+    if (!prob || !model || !out) return fail("null argument");
+    if (prob->num_targets <= 0) return fail("num_targets must be positive");
+    if (prob->graph_mode || prob->mask_relu || prob->bn) return fail("the XL route implements node mode, sigmoid masks, no --bn");
+    if (prob->D < 1 || prob->D > FS || prob->H < 2 || prob->H > FS || prob->O < 1 || prob->O > FS) return fail("D, H, O must be in [1, 32] (H >= 2)");
+    if (prob->C < 1 || prob->C > RES_CMAX) return fail("the XL route takes at most " + std::to_string(RES_CMAX) + " classes");
+    auto* h = new gnnx_xl_s();
+    h->prob = *prob;
+    const int T = prob->num_targets;
+    h->meta.resize(T);
+    std::vector<long long> rp_off(T);
+    for (int t = 0; t < T; ++t) {
+        TargetMeta& m = h->meta[t];
+        m.n = prob->n[t];
+        if (m.n < 1) {
+            delete h;
+            return fail("empty sub-graph (n < 1) for target " + std::to_string(t));
+        }
+        m.ld = (m.n + TILE - 1) / TILE * TILE;
+        m.t = prob->target_row[t];
+        m.y_gt = prob->gt_label[t];
+        if (m.t < 0 || m.t >= m.n || m.y_gt < 0 || m.y_gt >= prob->C) {
+            delete h;
+            return fail("target_row / gt_label out of range for target " + std::to_string(t));
+        }
+        m.offQ = 0;
+        m.offR = h->R;
+        rp_off[t] = h->R + t;            // rowptr / uprow: ld + 1 ints per target
+        h->R += m.ld;
+        for (int r0 = 0; r0 < m.ld; r0 += XL_ROWS_PER_BLOCK) h->blocks.push_back({t, r0});
+        h->ids.push_back(t);
+    }
+    // largest targets first: their workgroups are the long poles of the one launch
+    std::stable_sort(h->ids.begin(), h->ids.end(), [&](int a, int b) { return h->meta[a].n > h->meta[b].n; });
+    h->csr_off.assign(2 * (size_t)T, 0);
+    for (int t = 0; t < T; ++t) h->csr_off[2 * t] = rp_off[t];
+    std::vector<float> w(WT_TOTAL, 0.0f);
+    const int din[3] = {prob->D, prob->H, prob->H}, dout[3] = {prob->H, prob->H, prob->O};
+    for (int l = 0; l < 3; ++l) {
+        for (int k = 0; k < din[l]; ++k)
+            for (int c = 0; c < dout[l]; ++c) w[WT_W + l * 1024 + k * 32 + c] = model->W[l][k * dout[l] + c];
+        for (int c = 0; c < dout[l]; ++c) w[WT_B + l * 32 + c] = model->b[l] ? model->b[l][c] : 0.0f;
+    }
+    const int Ecat = prob->H + prob->H + prob->O;
+    const int eo[3] = {0, prob->H, 2 * prob->H};
+    for (int c = 0; c < prob->C; ++c) {
+        for (int l = 0; l < 3; ++l)
+            for (int j = 0; j < dout[l]; ++j) w[WT_WP + c * 96 + l * 32 + j] = model->Wp[c * Ecat + eo[l] + j];
+        w[WT_BP + c] = model->bp[c];
+    }
+    // one block, one (synchronous) upload: meta | blocks | ids | wts | rp_off
+    std::vector<char> host;
+    auto add = [&](const void* src, size_t bytes) {
+        const size_t off = align_up(host.size(), 256);
+        host.resize(off + bytes);
+        std::memcpy(host.data() + off, src, bytes);
+        return off;
+    };
+    const size_t o_meta = add(h->meta.data(), sizeof(TargetMeta) * T), o_blk = add(h->blocks.data(), sizeof(XlBlock) * h->blocks.size()),
+                 o_ids = add(h->ids.data(), sizeof(int32_t) * T), o_w = add(w.data(), sizeof(float) * w.size()),
+                 o_rp = add(rp_off.data(), sizeof(long long) * T);
+    if (pool_malloc(&h->block1, host.size()) != hipSuccess || upload_sync(h->block1, host.data(), host.size()) != hipSuccess) {
+        if (h->block1) (void)pool_free(h->block1);
+        delete h;
+        return fail("gnnx_xl_create: device table upload failed");
+    }
+    char* b = static_cast<char*>(h->block1);
+    h->d_meta = reinterpret_cast<TargetMeta*>(b + o_meta);
+    h->d_blocks = reinterpret_cast<XlBlock*>(b + o_blk);
+    h->d_ids = reinterpret_cast<int32_t*>(b + o_ids);
+    h->d_wts = reinterpret_cast<float*>(b + o_w);
+    h->d_rp_off = reinterpret_cast<long long*>(b + o_rp);
+    size_t o = 0;
+    h->r_X = xl_take(o, sizeof(float) * (size_t)h->R * FS);
+    h->r_yhat = xl_take(o, sizeof(float) * (size_t)h->R);
+    h->r_deg = xl_take(o, sizeof(int32_t) * (size_t)h->R);
+    h->r_updeg = xl_take(o, sizeof(int32_t) * (size_t)h->R);
+    h->r_rowptr = xl_take(o, sizeof(int32_t) * (size_t)(h->R + T));
+    h->r_uprow = xl_take(o, sizeof(int32_t) * (size_t)(h->R + T));
+    h->r_totals = xl_take(o, sizeof(int32_t) * 2 * (size_t)T);
+    h->rows_bytes = o;
+    *out = h;
+    return 0;
+}
+
+extern "C" int gnnx_xl_destroy(gnnx_xl_handle h) {
+    if (!h) return 0;
+    if (h->block1) (void)pool_free(h->block1);
+    if (h->block2) (void)pool_free(h->block2);
+    if (h->d_adam && !h->adam_shared) (void)pool_free(h->d_adam);
+    delete h;
+    return 0;
+}
+
+extern "C" int64_t gnnx_xl_total_rows(gnnx_xl_handle h) { return h ? h->R : -1; }
+extern "C" size_t gnnx_xl_rows_bytes(gnnx_xl_handle h) { return h ? h->rows_bytes : 0; }
+extern "C" int64_t gnnx_xl_total_edges(gnnx_xl_handle h) { return h ? h->E : -1; }
+extern "C" size_t gnnx_xl_entries_bytes(gnnx_xl_handle h) { return (h && h->E >= 0) ? h->entries_bytes : 0; }
+extern "C" int gnnx_xl_get_layout(gnnx_xl_handle h, int32_t* ld, int64_t* offR, int64_t* eoff) {
+    if (!h) return fail("null plan");
+    const size_t T = h->meta.size();
+    for (size_t t = 0; t < T; ++t) {
+        if (ld) ld[t] = h->meta[t].ld;
+        if (offR) offR[t] = h->meta[t].offR;
+    }
+    if (eoff) {
+        if (h->E < 0) return fail("gnnx_xl_get_layout: the edge offsets exist after gnnx_xl_count");
+        for (size_t t = 0; t <= T; ++t) eoff[t] = h->eoff[t];
+    }
+    return 0;
+}
+
+extern "C" int gnnx_xl_count(gnnx_xl_handle h, const int64_t* indptr, const int32_t* indices, const float* weights, const int32_t* nb,
+                             const int64_t* nb_off, const float* feat, int32_t feat_stride, const float* pred_label, void* ws_rows,
+                             size_t ws_rows_bytes, int64_t* edges_host, void* stream) {
+    if (!h || !indptr || !nb || !nb_off || !feat || !ws_rows) return fail("null argument");      // (indices may be null: a graph without edges)
+    if (ws_rows_bytes < h->rows_bytes) return fail("row workspace too small");
+    if (feat_stride < h->prob.D) return fail("feat_stride smaller than D");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int T = h->prob.num_targets;
+    char* w = static_cast<char*>(ws_rows);
+    int32_t* deg = reinterpret_cast<int32_t*>(w + h->r_deg);
+    int32_t* updeg = reinterpret_cast<int32_t*>(w + h->r_updeg);
+    int32_t* totals = reinterpret_cast<int32_t*>(w + h->r_totals);
+    hipLaunchKernelGGL(k_xl_rowdeg, dim3((unsigned)h->blocks.size()), dim3(XL_ROWS_PER_BLOCK), 0, s, h->d_meta, h->d_blocks, indptr, indices, weights, nb,
+                       nb_off, feat, (int)feat_stride, (int)h->prob.D, pred_label, reinterpret_cast<float*>(w + h->r_X),
+                       reinterpret_cast<float*>(w + h->r_yhat), deg, updeg);
+    hipLaunchKernelGGL(k_xl_rowptr, dim3(T), dim3(1024), 0, s, h->d_meta, deg, updeg, h->d_rp_off, reinterpret_cast<int32_t*>(w + h->r_rowptr),
+                       reinterpret_cast<int32_t*>(w + h->r_uprow), totals);
+    HIPCK(hipGetLastError());
+    std::vector<int32_t> tot(2 * (size_t)T);
+    HIPCK(hipMemcpyAsync(tot.data(), totals, sizeof(int32_t) * tot.size(), hipMemcpyDeviceToHost, s));
+    HIPCK(hipStreamSynchronize(s));
+    h->edges.assign(T, 0);
+    h->eoff.assign((size_t)T + 1, 0);
+    h->scr_off.assign(T, 0);
+    long long nnz_all = 0, scr = 0;
+    for (int t = 0; t < T; ++t) {
+        const long long nnz = tot[2 * t], up = tot[2 * t + 1];
+        if (nnz != 2 * up) {
+            h->E = -1;
+            return fail("gnnx_xl_count: the sub-graph of target " + std::to_string(t) + " is not symmetric (" + std::to_string(nnz) + " directed entries, " +
+                        std::to_string(up) + " above the diagonal)");
+        }
+        h->edges[t] = up;
+        h->eoff[t + 1] = h->eoff[t] + up;
+        h->csr_off[2 * t + 1] = nnz_all;
+        nnz_all += nnz;
+        h->scr_off[t] = scr;
+        scr += xl_layout(h->meta[t].n, h->meta[t].ld, (int)nnz).total;
+        if (edges_host) edges_host[t] = up;
+    }
+    h->E = h->eoff[T];
+    h->NNZ = nnz_all;
+    h->scr_floats = scr;
+    h->weighted = weights != nullptr;
+    size_t o = 0;
+    h->e_col = xl_take(o, sizeof(int32_t) * (size_t)std::max<long long>(nnz_all, 1));
+    h->e_row = xl_take(o, sizeof(int32_t) * (size_t)std::max<long long>(nnz_all, 1));
+    h->e_w = h->weighted ? xl_take(o, sizeof(float) * (size_t)std::max<long long>(nnz_all, 1)) : 0;
+    h->e_scr = xl_take(o, sizeof(float) * (size_t)scr);
+    h->entries_bytes = o;
+    // csr_off | eoff | scr_off: one block
+    if (h->block2) (void)pool_free(h->block2);
+    h->block2 = nullptr;
+    std::vector<char> host;
+    auto add = [&](const void* src, size_t bytes) {
+        const size_t off = align_up(host.size(), 256);
+        host.resize(off + bytes);
+        std::memcpy(host.data() + off, src, bytes);
+        return off;
+    };
+    const size_t o_c = add(h->csr_off.data(), sizeof(long long) * h->csr_off.size()), o_e = add(h->eoff.data(), sizeof(long long) * h->eoff.size()),
+                 o_s = add(h->scr_off.data(), sizeof(long long) * h->scr_off.size());
+    HIPCK(pool_malloc(&h->block2, host.size()));
+    HIPCK(upload_sync(h->block2, host.data(), host.size()));
+    char* b = static_cast<char*>(h->block2);
+    h->d_csr_off = reinterpret_cast<long long*>(b + o_c);
+    h->d_eoff = reinterpret_cast<long long*>(b + o_e);
+    h->d_scr_off = reinterpret_cast<long long*>(b + o_s);
+    h->built = false;
+    return 0;
+}
+
+extern "C" int gnnx_xl_build(gnnx_xl_handle h, const int64_t* indptr, const int32_t* indices, const float* weights, const int32_t* nb,
+                             const int64_t* nb_off, void* ws_rows, void* ws_entries, size_t ws_entries_bytes, int32_t* rc, void* stream) {
+    if (!h || !indptr || !nb || !nb_off || !ws_rows || !ws_entries || !rc) return fail("null argument");
+    if (h->E < 0) return fail("gnnx_xl_build: call gnnx_xl_count first");
+    if (ws_entries_bytes < h->entries_bytes) return fail("entry workspace too small");
+    if ((weights != nullptr) != h->weighted) return fail("gnnx_xl_build: pass the weights gnnx_xl_count saw");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* w = static_cast<char*>(ws_rows);
+    char* e = static_cast<char*>(ws_entries);
+    hipLaunchKernelGGL(k_xl_emit, dim3((unsigned)h->blocks.size()), dim3(XL_ROWS_PER_BLOCK), 0, s, h->d_meta, h->d_blocks, indptr, indices, weights, nb,
+                       nb_off, h->d_csr_off, reinterpret_cast<const int32_t*>(w + h->r_rowptr), reinterpret_cast<const int32_t*>(w + h->r_uprow), h->d_eoff,
+                       reinterpret_cast<int32_t*>(e + h->e_col), reinterpret_cast<int32_t*>(e + h->e_row),
+                       h->weighted ? reinterpret_cast<float*>(e + h->e_w) : nullptr, rc);
+    HIPCK(hipGetLastError());
+    h->built = true;
+    return 0;
+}
+
+extern "C" int gnnx_xl_set_trace(gnnx_xl_handle h, uint32_t* gates) {
+    if (!h) return fail("null argument");
+    h->trace_gates = gates;
+    return 0;
+}
+
+extern "C" int gnnx_xl_run(gnnx_xl_handle h, const gnnx_hyper* hy, const gnnx_xl_state* st, float* abar_e, float* feat_mask, void* ws_rows,
+                           void* ws_entries, void* stream) {
+    if (!h || !hy || !st || !st->M_e || !abar_e || !feat_mask || !ws_rows || !ws_entries) return fail("null argument");
+    if (!h->built) return fail("gnnx_xl_run: call gnnx_xl_count and gnnx_xl_build first");
+    if (hy->num_iters < 1) return fail("num_iters must be >= 1");
+    if (hy->opt < 0 || hy->opt > 3) return fail("opt must be 0 (adam), 1 (sgd), 2 (rmsprop) or 3 (adagrad)");
+    if (hy->record_loss) return fail("the XL route has no loss logging (the decision trace: gnnx_xl_set_trace)");
+    if (st->first_iter < 0) return fail("first_iter must be >= 0");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int T = h->prob.num_targets;
+    if (!h->d_adam || hy->lr_schedule || h->adam_first != st->first_iter || std::memcmp(&h->adam_for, hy, sizeof(gnnx_hyper)) != 0) {
+        if (h->d_adam && !h->adam_shared) {
+            HIPCK(hipStreamSynchronize(s));
+            (void)pool_free(h->d_adam);
+        }
+        h->d_adam = nullptr;
+        h->adam_shared = false;
+        std::vector<float> tab(2 * (size_t)hy->num_iters);
+        for (int it = 0; it < hy->num_iters; ++it) adam_scalars(hy, st->first_iter + it, &tab[2 * it], &tab[2 * it + 1], it);
+        if (!hy->lr_schedule) h->d_adam = shared_adam_table(hy, st->first_iter, tab);
+        if (h->d_adam) {
+            h->adam_shared = true;
+        } else {
+            HIPCK(pool_malloc(&h->d_adam, sizeof(float) * tab.size()));
+            HIPCK(upload_sync(h->d_adam, tab.data(), sizeof(float) * tab.size()));
+        }
+        h->adam_for = *hy;
+        h->adam_first = st->first_iter;
+    }
+    char* w = static_cast<char*>(ws_rows);
+    char* e = static_cast<char*>(ws_entries);
+    Params p{};
+    p.meta = h->d_meta;
+    p.X = reinterpret_cast<const float*>(w + h->r_X);
+    p.yhat = reinterpret_cast<const float*>(w + h->r_yhat);
+    p.f[0] = p.f[1] = feat_mask;
+    p.fs_in = st->feat;
+    p.fs_out = st->feat_out;
+    p.wts = h->d_wts;
+    p.D = h->prob.D;
+    p.H = h->prob.H;
+    p.O = h->prob.O;
+    p.C = h->prob.C;
+    p.num_iters = hy->num_iters;
+    p.opt = hy->opt;
+    p.edge_only = 1;
+    p.lr = (float)hy->lr;
+    p.beta2 = (float)(hy->opt == 2 ? hy->alpha : hy->beta2);
+    p.omb1 = (float)(1.0 - hy->beta1);
+    p.omb2 = (float)(1.0 - (hy->opt == 2 ? hy->alpha : hy->beta2));
+    p.eps = (float)hy->eps;
+    p.c_size = hy->c_size;
+    p.c_feat_size = hy->c_feat_size;
+    p.c_ent = hy->c_ent;
+    p.c_lap = hy->c_lap;
+    p.trace_gates = h->trace_gates;
+    p.trace_rows = h->R;
+    XlIo io{};
+    io.w = h->weighted ? reinterpret_cast<const float*>(e + h->e_w) : nullptr;
+    io.eoff = h->d_eoff;
+    io.M_e = st->M_e;
+    io.m_in_e = st->m_e;
+    io.v_in_e = st->v_e;
+    io.m_out_e = st->m_out_e;
+    io.v_out_e = st->v_out_e;
+    io.abar_e = abar_e;
+    io.scr = reinterpret_cast<float*>(e + h->e_scr);
+    io.scr_off = h->d_scr_off;
+    const int32_t* rowptr = reinterpret_cast<const int32_t*>(w + h->r_rowptr);
+    const void* col = e + h->e_col;
+    const void* row = e + h->e_row;
+    const dim3 grid(T), block(SPL_THREADS);
+    const bool exact = h->prob.D == 10 && h->prob.H == 20 && h->prob.O == 20;
+    if (h->trace_gates) {
+        if (!exact) return fail("gnnx_xl_set_trace: the decision trace needs the reference's widths (D = 10, H = O = 20)");
+        HIPCK(hipMemsetAsync(h->trace_gates, 0, sizeof(uint32_t) * 2 * (size_t)h->R * hy->num_iters, s));
+        hipLaunchKernelGGL((k_sparse_large<5, 10, true, true, true>), grid, block, 0, s, p, h->d_ids, h->d_adam, rowptr, col, row, h->d_csr_off,
+                           (const int32_t*)nullptr, io);
+    } else if (exact) {
+        hipLaunchKernelGGL((k_sparse_large<5, 10, false, true, true>), grid, block, 0, s, p, h->d_ids, h->d_adam, rowptr, col, row, h->d_csr_off,
+                           (const int32_t*)nullptr, io);
+    } else {
+        hipLaunchKernelGGL((k_sparse_large<16, 16, false, true, true>), grid, block, 0, s, p, h->d_ids, h->d_adam, rowptr, col, row, h->d_csr_off,
+                           (const int32_t*)nullptr, io);
     }
     HIPCK(hipGetLastError());
     return 0;

@@ -111,8 +111,8 @@ __device__ __forceinline__ int wave_exclusive_scan_array(T* a, int len, int lane
 // cache-line access per lane whatever its width.  The slot's two lanes therefore split its ENTRIES (parity), load whole
 // rows with 16-byte loads (3 accesses per 10-column row instead of 10) and swap the column sums they owe each other at
 // the end.  UN entries in flight per lane.
-template <bool RELU, int NQ, int UN>
-__device__ __forceinline__ void sparse_gather_rows(const float* sAb, const unsigned short* scol, const float* B, int W, int e0,
+template <bool RELU, int NQ, int UN, class CT>
+__device__ __forceinline__ void sparse_gather_rows(const float* sAb, const CT* scol, const float* B, int W, int e0,
                                                    int e1, int half, float (&acc)[NQ]) {
     constexpr int NV = (2 * NQ + 3) / 4;
     float full[2 * NQ];
@@ -152,8 +152,8 @@ __device__ __forceinline__ void sparse_gather_rows(const float* sAb, const unsig
 }
 
 // The same gather when the feature rows come from the LDS dictionary (xd [.][sS], xi = dictionary index per node).
-template <int NQ, int UN>
-__device__ __forceinline__ void sparse_gather_dict(const float* sAb, const unsigned short* scol, const unsigned char* xi, const float* xd,
+template <int NQ, int UN, class CT>
+__device__ __forceinline__ void sparse_gather_dict(const float* sAb, const CT* scol, const unsigned char* xi, const float* xd,
                                                    int sS, int W, int e0, int e1, int half, float (&acc)[NQ]) {
     float full[2 * NQ];
 #pragma unroll
@@ -192,6 +192,104 @@ __device__ __forceinline__ void sparse_gather_dict(const float* sAb, const unsig
     }
 }
 
+// first position in [lo, hi) of a sorted id array whose value is >= key
+template <class CT>
+__device__ __forceinline__ int lower_bound_ids(const CT* a, int lo, int hi, int key) {
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((int)a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// k_sparse_xl = k_sparse_large<.., XL = true> (round 6): the SAME iteration loop - one source, one arithmetic, results bit-identical to the
+// LDS form on every target both take - for targets of ANY size, CSR-native from end to end.  What it lifts, and how:
+//   * no dense n x n block anywhere.  k_sparse_large reads the weights and the initial mask from the packed dense A / M blocks and writes dense
+//     Abar / M blocks back (28 n^2 bytes of packing traffic per target; 9.6 GB per array at n = 49 028).  The XL form takes the target's CSR
+//     (built from the FULL graph's CSR and the k-hop list by k_xl_rowdeg / k_xl_emit, gnnx_xl.hpp), the weights per directed entry, and the mask /
+//     Adam moments as EDGE LISTS in the order of gnnx_gather_edges (upper-triangle edges, row-major: XlIo), and writes edge lists back;
+//   * no 16-bit ids: rows, columns, compact entries and slots are 32-bit (n > 16 383, > 65 535 entries within two hops);
+//   * the active entries (masked adjacency + column per directed entry of the rows within two hops: 23 k ... 218 k entries on the BA-House x100k
+//     targets beyond 16 383 nodes, 1.4 per sub-graph node) live in the target's global scratch block - L2-resident, read by coalesced-per-slot
+//     loads - instead of LDS; so do the per-slot norms, the slot records and the setup's temporaries (hop levels, row lists: O(n));
+//     LDS keeps the weights, the staging tiles, the layer-3 partials and the feature dictionary (+ one byte per node while that fits);
+//   * nothing is sized by the plan: the kernel derives the counts k_count_edges_large hands the LDS form (rows / entries within two hops, row
+//     slots) itself during setup, in a scratch block laid out from upper bounds that depend on (n, nnz) alone (xl_layout).
+// Limits that remain: a row within two hops of the target has at most SPL_TDEG_MAX = 1024 entries (16 slots of 64), C <= RES_CMAX.
+// ------------------------------------------------------------------------------------------------------------------------------------------
+struct XlIo {
+    const float* w;             // weight of every directed entry, laid out like csr_col (offset csr_off[2 t + 1]); null = all ones
+    const long long* eoff;      // [T + 1] upper-triangle edges of every target (row-major order: the layout of gnnx_gather_edges)
+    float* M_e;                 // [E][2] in: the mask entries (M[r][c], M[c][r]) to start from; out: after num_iters steps
+    const float* m_in_e;        // [E][2] exp_avg / exp_avg_sq to start from (gnnx_run_resume), or null = zeros
+    const float* v_in_e;
+    float* m_out_e;             // [E][2] the moments after the run, or null
+    float* v_out_e;
+    float* abar_e;              // [E] out: masked adjacency of the LAST forward on every edge (explain.py:209-211)
+    float* scr;                 // the targets' scratch blocks
+    const long long* scr_off;   // [T] float offset of target t's block (xl_layout(n, ld, nnz).total floats)
+};
+
+template <bool XL> struct SplTypes { using id_t = unsigned short; static constexpr int NOTA = 0xffff; };
+template <> struct SplTypes<true> { using id_t = int; static constexpr int NOTA = -1; };
+
+// info = len | nsplit << 8 | wsplit << 13 | first << 18 | rem << 19 | inB << 24 (set A: m0 / m1 as in SlotRec; set B: m0 = compact index of (t, row), ~0 for t)
+struct SlotRecXL { unsigned row, e0, info, m0, m1, pad0, pad1, pad2; };
+
+// float offsets inside a target's scratch block; every array sized from bounds that hold for ANY hop structure: entries within two hops <= nnz,
+// rows within two hops <= n, row slots <= n + nnz / 4 (one per row + one per started 64 entries + the alignment of split rows)
+struct XlLayout {
+    long long oAb, oCol, oGe, oRec, oRn1, oRn2, oEst, oLap, oEi, oU1, oU2, oZraw, oLevel, oAidx, oAlist, oAdeg, oArp, oCbase, oSlot, total;
+    int pad_max;
+};
+__host__ __device__ inline XlLayout xl_layout(int n, int ld, int nnz) {
+    XlLayout L;
+    const long long eup = nnz / 2, nact = (long long)nnz + 1, nA = n;
+    const long long pad = (((long long)n + nnz / 4 + 32) + 31) & ~31LL;
+    L.pad_max = (int)pad;
+    long long o = 0;
+    auto take = [&](long long words) { const long long r = o; o += (words + 63) & ~63LL; return r; };   // 256-B aligned arrays
+    L.oAb = take(nact + 1);
+    L.oCol = take(nact + 1);
+    L.oGe = take(nact + 1);
+    L.oRec = take(2 * pad * 8);
+    L.oRn1 = take(pad);
+    L.oRn2 = take(pad);
+    L.oEst = take(7 * eup);
+    L.oLap = take(eup);
+    L.oEi = take(5 * eup);          // per near / far edge: i, j, compact entries c_ij, c_ji, index in the caller's edge list
+    L.oU1 = take((long long)ld * FS);
+    L.oU2 = take((long long)ld * FS);
+    L.oZraw = take((long long)ld * FS);
+    L.oLevel = take((ld + 3) / 4);
+    L.oAidx = take(ld);
+    L.oAlist = take(nA);
+    L.oAdeg = take(nA);
+    L.oArp = take(nA);
+    L.oCbase = take(nA + 1);
+    L.oSlot = take(2 * (nA + 1 + nA + 1 + SPL_CHUNK + 4));
+    L.total = o;
+    return L;
+}
+// LDS of the XL form (floats): weights, head, staging tiles, layer-3 partials of t's neighbours, feature dictionary, one byte per node (oXi < 0:
+// the sub-graph has too many nodes for that - the feature rows then come from L2)
+struct XlLds { int oW, oWp, oStage, oG3, oXd, oXi, total; };
+__host__ __device__ inline XlLds xl_lds(int ld, int D, int H, int C) {
+    XlLds L;
+    int o = 0;
+    L.oW = o;      o += (D + 2 * H) * 33;
+    L.oWp = o;     o += C * 96;
+    L.oStage = o;  o += spl_stage_floats(D);
+    L.oG3 = o;     o += SPL_TDEG_MAX;
+    L.oXd = o;     o += SPL_XD_MAX * (D | 1);
+    const int xi = (ld + 3) / 4;
+    L.oXi = (o + xi <= SPL_POOL_FLOATS) ? o : -1;
+    if (L.oXi >= 0) o += xi;
+    L.total = o;
+    return L;
+}
+
 // csr_*: the targets' CSR structure, built once per plan by k_build_csr_large (scanning a dense block with one
 // workgroup takes milliseconds - too much to repeat in every launch): rowptr at csr_off[2 t], the ascending columns and
 // the row of every directed entry at csr_off[2 t + 1]; counts: k_count_edges_large's output
@@ -199,13 +297,15 @@ __device__ __forceinline__ void sparse_gather_dict(const float* sAb, const unsig
 // and Laplacian sums over the NEAR edges, reduced in a fixed order; the far edges add theirs from their closed recursions with float atomics,
 // the entries off the edges come from k_dead_entries in front of the launch; feature-size term) and the decision trace (the ReLU gates of
 // layer 1 on the rows within two hops and of layer 2 on t and its neighbours, read back from the row arrays).  A separate instantiation.
-template <int DQ, int HQ, bool LOG = false, bool EX = true>
+template <int DQ, int HQ, bool LOG = false, bool EX = true, bool XL = false>
 __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const int32_t* targets, const float* __restrict__ adam_tab,
                                                               const int32_t* __restrict__ csr_rowptr,
-                                                              const unsigned short* __restrict__ csr_col,
-                                                              const unsigned short* __restrict__ csr_row,
-                                                              const long long* __restrict__ csr_off, const int32_t* __restrict__ counts) {
+                                                              const void* __restrict__ csr_col_v,     // uint16 ids (XL: int32)
+                                                              const void* __restrict__ csr_row_v,
+                                                              const long long* __restrict__ csr_off, const int32_t* __restrict__ counts, const XlIo xl) {
     constexpr int NT = SPL_THREADS, NW = NT / 64;
+    using id_t = typename SplTypes<XL>::id_t;       // rows / columns of the sub-graph, indices into the list of rows within two hops
+    constexpr int NOTA = SplTypes<XL>::NOTA;        // "not within two hops"
     __shared__ float pool[SPL_POOL_FLOATS];
     __shared__ SparseFixed sh;
     __shared__ int s_wn[NW], s_wf[NW], s_misc[4];
@@ -215,33 +315,74 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     constexpr bool EXACT = EX && (DQ != 16);   // <5, 10>: exactly D = 10, H = O = 20 (compile-time widths); EX = false: widths up to those at run time; other shapes take <16, 16>
     const int D = EXACT ? 2 * DQ : p.D, H = EXACT ? 2 * HQ : p.H, O = EXACT ? 2 * HQ : p.O, C = p.C;
-    const float* Ag = p.A + tm.offQ;
-    float* Mg = p.M + tm.offQ;
-    // row arrays in the caller's workspace (stride FS); dZ2 overwrites U2 row by row as in the resident kernel
+    const float* Ag = XL ? nullptr : p.A + tm.offQ;      // (the XL form has no dense blocks: XlIo)
+    float* Mg = XL ? nullptr : p.M + tm.offQ;
+    const int32_t* grp = csr_rowptr + csr_off[2 * t];
+    const id_t* gcol = static_cast<const id_t*>(csr_col_v) + csr_off[2 * t + 1];
+    const id_t* grow = static_cast<const id_t*>(csr_row_v) + csr_off[2 * t + 1];
+    int nnz, slotsA, nact, nA, slotsB;     // LDS form: k_count_edges_large's figures (verified below); XL form: derived by the setup
+    if constexpr (XL) {
+        nnz = grp[ld];
+        slotsA = slotsB = nact = nA = 0;
+    } else {
+        const int32_t* cn = counts + (size_t)SPL_COUNTS * t;
+        nnz = cn[0], slotsA = cn[1], nact = cn[3], nA = cn[4], slotsB = cn[5];
+    }
+    const int eup = nnz >> 1;
+    int padA = (slotsA + 31) & ~31, padB = (slotsB + 31) & ~31;
+    float* xscr = XL ? xl.scr + xl.scr_off[t] : nullptr;
+    const XlLayout XG = XL ? xl_layout(n, ld, nnz) : XlLayout{};
+    // row arrays (stride FS; dZ2 overwrites U2 row by row as in the resident kernel): the caller's workspace / XL: the target's scratch block
     const float* gX = p.X + tm.offR * FS;
-    float* gU1 = p.U[0] + tm.offR * FS;
-    float* gU2 = p.U[1] + tm.offR * FS;
-    float* gZraw = p.Zraw + tm.offR * FS;
-    float* gGe = p.dZT[0] + tm.offR * FS;   // dL/dAbar per active entry (row-side products), [nact + 1]: the dummy stays zero
-    float* glap = p.dZT[1] + tm.offR * FS;  // per edge: c_lap / 2 (yhat_i - yhat_j)^2 / n^2 (explain.py:793-811 on a 0/1 label vector pair)
-    float* est = p.UT[2] + tm.offR * FS;    // per-edge planes [7][eup]: M_ij, M_ji, m_ij, m_ji, v_ij, v_ji, weight
-    unsigned* eidx = reinterpret_cast<unsigned*>(p.UT[0] + tm.offR * FS);  // [eup][2]: i | j << 16, c_ij | c_ji << 16 (compact entries; near edges)
-    SlotRec* srec = reinterpret_cast<SlotRec*>(p.UT[1] + tm.offR * FS);
+    float* gU1 = XL ? xscr + XG.oU1 : p.U[0] + tm.offR * FS;
+    float* gU2 = XL ? xscr + XG.oU2 : p.U[1] + tm.offR * FS;
+    float* gZraw = XL ? xscr + XG.oZraw : p.Zraw + tm.offR * FS;
+    float* gGe = XL ? xscr + XG.oGe : p.dZT[0] + tm.offR * FS;   // dL/dAbar per active entry (row-side products), [nact + 1]: the dummy stays zero
+    float* glap = XL ? xscr + XG.oLap : p.dZT[1] + tm.offR * FS;  // per edge: c_lap / 2 (yhat_i - yhat_j)^2 / n^2 (explain.py:793-811 on a 0/1 label vector pair)
+    float* est = XL ? xscr + XG.oEst : p.UT[2] + tm.offR * FS;    // per-edge planes [7][eup]: M_ij, M_ji, m_ij, m_ji, v_ij, v_ji, weight
+    // LDS form: eidx [eup][2] = i | j << 16, c_ij | c_ji << 16 (compact entries; near edges); XL form: five int planes [eup]: i, j, c_ij, c_ji, q
+    // (q = the edge's index in the caller's edge lists)
+    unsigned* eidx = reinterpret_cast<unsigned*>(XL ? xscr + XG.oEi : p.UT[0] + tm.offR * FS);
+    SlotRec* srec = reinterpret_cast<SlotRec*>(XL ? nullptr : p.UT[1] + tm.offR * FS);
+    SlotRecXL* srecx = reinterpret_cast<SlotRecXL*>(XL ? xscr + XG.oRec : nullptr);
+    auto edge_entries = [&](int k, int& cij, int& cji) {      // the two compact entries of near edge k
+        if constexpr (XL) {
+            cij = (int)eidx[2 * (size_t)eup + k];
+            cji = (int)eidx[3 * (size_t)eup + k];
+        } else {
+            const unsigned en = eidx[2 * k + 1];
+            cij = en & 0xffffu;
+            cji = en >> 16;
+        }
+    };
+    auto edge_nodes = [&](int k, int& i, int& j) {
+        if constexpr (XL) {
+            i = (int)eidx[k];
+            j = (int)eidx[(size_t)eup + k];
+        } else {
+            const unsigned nd = eidx[2 * k];
+            i = nd & 0xffffu;
+            j = nd >> 16;
+        }
+    };
 
     auto fail_nan = [&]() {
         const float qnan = __builtin_nanf("");
-        for (size_t e = tid; e < (size_t)ld * ld; e += NT) p.Abar[tm.offQ + e] = qnan;
+        if constexpr (XL) {
+            for (long long e = xl.eoff[t] + tid; e < xl.eoff[t + 1]; e += NT) xl.abar_e[e] = qnan;
+        } else {
+            for (size_t e = tid; e < (size_t)ld * ld; e += NT) p.Abar[tm.offQ + e] = qnan;
+        }
         if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = qnan;
     };
-    const int32_t* grp = csr_rowptr + csr_off[2 * t];
-    const unsigned short* gcol = csr_col + csr_off[2 * t + 1];
-    const unsigned short* grow = csr_row + csr_off[2 * t + 1];
-    const int32_t* cn = counts + (size_t)SPL_COUNTS * t;
-    const int nnz = cn[0], slotsA = cn[1], nact = cn[3], nA = cn[4], slotsB = cn[5];
-    const int eup = nnz >> 1;
-    const int padA = (slotsA + 31) & ~31, padB = (slotsB + 31) & ~31;
-    {
+    if constexpr (XL) {
+        if ((nnz & 1) || nnz < 0 || C > RES_CMAX || H < 2 || (long long)(xl.eoff[t + 1] - xl.eoff[t]) != (long long)eup) {  // uniform
+            fail_nan();
+            return;
+        }
+    } else {
         int cc[SPL_COUNTS];
+        const int32_t* cn = counts + (size_t)SPL_COUNTS * t;
 #pragma unroll
         for (int k = 0; k < SPL_COUNTS; ++k) cc[k] = cn[k];
         if (!sparse_large_fits(n, ld, cc, D, H, C) || grp[ld] != nnz) {  // uniform
@@ -254,32 +395,34 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         fail_nan();
         return;
     }
-    const SparseLargeLayout L = sparse_large_layout(ld, nact, nA, padA, padB, D, H, C);
-    float* sW1 = pool + L.oW;
+    const SparseLargeLayout L = XL ? SparseLargeLayout{} : sparse_large_layout(ld, nact, nA, padA, padB, D, H, C);
+    const XlLds XS = XL ? xl_lds(ld, D, H, C) : XlLds{};
+    float* sW1 = pool + (XL ? XS.oW : L.oW);
     float* sW2 = sW1 + D * 33;
     float* sW3 = sW2 + H * 33;
-    float* sWp = pool + L.oWp;
-    float* sAb = pool + L.oAb;
-    unsigned short* scol = reinterpret_cast<unsigned short*>(pool + L.oCol);
+    float* sWp = pool + (XL ? XS.oWp : L.oWp);
+    float* sAb = XL ? xscr + XG.oAb : pool + L.oAb;           // XL: the active entries live in the scratch block (L2)
+    id_t* scol = reinterpret_cast<id_t*>(XL ? xscr + XG.oCol : pool + L.oCol);
     const int sS = D | 1;
-    float* stage = pool + L.oStage + wave * (TILE * sS);
-    float* sRn1 = pool + L.oRn1;
-    float* sRn2 = pool + L.oRn2;
-    float* sG3 = pool + L.oG3;
-    float* sXd = pool + L.oXd;
-    unsigned char* sXi = reinterpret_cast<unsigned char*>(pool + L.oXi);
+    float* stage = pool + (XL ? XS.oStage : L.oStage) + wave * (TILE * sS);
+    float* sRn1 = XL ? xscr + XG.oRn1 : pool + L.oRn1;
+    float* sRn2 = XL ? xscr + XG.oRn2 : pool + L.oRn2;
+    float* sG3 = pool + (XL ? XS.oG3 : L.oG3);
+    float* sXd = pool + (XL ? XS.oXd : L.oXd);
+    const bool have_xi = !XL || XS.oXi >= 0;                  // XL: one byte per node fits LDS (else the feature rows come from L2)
+    unsigned char* sXi = reinterpret_cast<unsigned char*>(pool + (XL ? (XS.oXi >= 0 ? XS.oXi : 0) : L.oXi));
     // setup temporaries
-    unsigned char* level = reinterpret_cast<unsigned char*>(pool + L.tLevel);
-    unsigned short* aidx = reinterpret_cast<unsigned short*>(pool + L.tAidx);
-    unsigned short* alist = reinterpret_cast<unsigned short*>(pool + L.tAlist);
-    unsigned short* adeg = reinterpret_cast<unsigned short*>(pool + L.tAdeg);
-    int* arp = reinterpret_cast<int*>(pool + L.tArp);
-    int* cbase = reinterpret_cast<int*>(pool + L.tCbase);
+    unsigned char* level = reinterpret_cast<unsigned char*>(XL ? xscr + XG.oLevel : pool + L.tLevel);
+    id_t* aidx = reinterpret_cast<id_t*>(XL ? xscr + XG.oAidx : pool + L.tAidx);
+    id_t* alist = reinterpret_cast<id_t*>(XL ? xscr + XG.oAlist : pool + L.tAlist);
+    id_t* adeg = reinterpret_cast<id_t*>(XL ? xscr + XG.oAdeg : pool + L.tAdeg);
+    int* arp = reinterpret_cast<int*>(XL ? xscr + XG.oArp : pool + L.tArp);
+    int* cbase = reinterpret_cast<int*>(XL ? xscr + XG.oCbase : pool + L.tCbase);
 
     // ---------------- setup 1: hop levels 0..3 from the plan's CSR ----------------
     for (int r = tid; r < ld; r += NT) {
         level[r] = (r == tr) ? 0 : 3;
-        aidx[r] = 0xffffu;
+        aidx[r] = (id_t)NOTA;
     }
     if (tid == 0) sh.bad = 0;
     __syncthreads();
@@ -311,15 +454,16 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         }
         if (inA) {
             const int k = base + __popcll(b & ((1ull << lane) - 1ull));
-            if (k < nA) {
-                alist[k] = (unsigned short)r;
-                aidx[r] = (unsigned short)k;
+            if (XL || k < nA) {      // (XL: k < n by construction - the list is sized for n rows)
+                alist[k] = (id_t)r;
+                aidx[r] = (id_t)k;
             }
         }
         cntA += tot;
         __syncthreads();
     }
-    if (cntA != nA) {  // uniform: the plan's counts do not describe this adjacency
+    if constexpr (XL) nA = cntA;      // (the XL form derives what the LDS form verifies)
+    if (cntA != nA || nA <= 0) {  // uniform: the plan's counts do not describe this adjacency
         fail_nan();
         return;
     }
@@ -327,7 +471,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         const int r = alist[k];
         const int ra = grp[r], rb = grp[r + 1];
         arp[k] = ra;
-        adeg[k] = (unsigned short)(rb - ra);
+        adeg[k] = (id_t)(rb - ra);
         cbase[k] = (r == tr) ? 0 : rb - ra;
         if (rb - ra > SPL_TDEG_MAX) sh.bad = 1;
     }
@@ -338,6 +482,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     }
     __syncthreads();
     for (int k = tid; k < nA; k += NT) cbase[k] = ((int)alist[k] == tr) ? 0 : cbase[k] + degT;
+    if constexpr (XL) nact = s_misc[0];
     if (s_misc[0] != nact || sh.bad) {  // uniform
         __syncthreads();
         fail_nan();
@@ -346,19 +491,22 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     __syncthreads();
     // column ids of the active entries (one pass over the directed entries, coalesced)
     for (int e = tid; e < nnz; e += NT) {
-        const int ai = aidx[grow[e]];
-        if (ai != 0xffff) scol[cbase[ai] + (e - arp[ai])] = gcol[e];
+        const int ai = (int)aidx[grow[e]];
+        if (ai != NOTA) scol[cbase[ai] + (e - arp[ai])] = gcol[e];
     }
     __syncthreads();
     // ---------------- setup 3: row slots of the two row sets ----------------
     constexpr int SETSZ_U16 = SPL_CHUNK + 4;
-    const int set_words = nA + 1 + (nA + 1) / 2 + SETSZ_U16 / 2;  // ints per set: slot_start [nA + 1], then uint16 order [nA], bucket [CHUNK + 1]
+    // ints per set: slot_start [nA + 1], then order [nA], bucket [CHUNK + 1] (uint16; XL: int)
+    const int set_words = XL ? (nA + 1) + (nA + 1) + SETSZ_U16 : nA + 1 + (nA + 1) / 2 + SETSZ_U16 / 2;
+    int* const slot_tables = reinterpret_cast<int*>(XL ? xscr + XG.oSlot : pool + L.tSlot);
+    const int order_stride = XL ? nA + 1 : ((nA + 1) & ~1);      // ids from `order` to `bucket`
     if ((tid & 31) == 0 && (tid >> 5) < 2) {  // one thread per row set: A (level <= 2), B (level <= 1)
         const int set = tid >> 5;
         const int lvlmax = 2 - set;
-        int* slot_start = reinterpret_cast<int*>(pool + L.tSlot) + set * set_words;
-        unsigned short* order = reinterpret_cast<unsigned short*>(slot_start + nA + 1);
-        unsigned short* bucket = order + ((nA + 1) & ~1);
+        int* slot_start = slot_tables + set * set_words;
+        id_t* order = reinterpret_cast<id_t*>(slot_start + nA + 1);
+        id_t* bucket = order + order_stride;
         int pos = 0, pcount = 0, cnt = 0;
         for (int d = 0; d <= SPL_CHUNK; ++d) bucket[d] = 0;
         for (int k = 0; k < nA; ++k) {
@@ -368,7 +516,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             if (d > SPL_CHUNK) {
                 const int ns = sparse_slots_of_c(d, SPL_CHUNK);
                 pos = sparse_place(pos, ns);
-                order[pcount] = (unsigned short)k;
+                order[pcount] = (id_t)k;
                 slot_start[pcount] = pos;
                 pos += ns;
                 ++pcount;
@@ -379,29 +527,39 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         int run = pcount;
         for (int d = SPL_CHUNK; d >= 0; --d) {
             const int c = bucket[d];
-            bucket[d] = (unsigned short)run;
+            bucket[d] = (id_t)run;
             run += c;
         }
         for (int k = 0; k < nA; ++k) {
             if (level[alist[k]] > lvlmax) continue;
             const int d = adeg[k];
-            if (d <= SPL_CHUNK) order[bucket[d]++] = (unsigned short)k;
+            if (d <= SPL_CHUNK) order[bucket[d]++] = (id_t)k;
         }
         for (int q = pcount; q < cnt; ++q) slot_start[q] = pos + (q - pcount);
         slot_start[cnt] = pos + (cnt - pcount);
         sh.set_rows[set] = cnt;
         sh.set_slots[set] = pos + (cnt - pcount);
-        if (pos + (cnt - pcount) != (set ? slotsB : slotsA)) sh.bad = 1;
+        if (!XL && pos + (cnt - pcount) != (set ? slotsB : slotsA)) sh.bad = 1;
     }
     __syncthreads();
+    if constexpr (XL) {
+        slotsA = sh.set_slots[0];
+        slotsB = sh.set_slots[1];
+        padA = (slotsA + 31) & ~31;
+        padB = (slotsB + 31) & ~31;
+        if (padA > XG.pad_max || padB > XG.pad_max) {  // (cannot happen: xl_layout's bound) - uniform
+            fail_nan();
+            return;
+        }
+    }
     if (sh.bad) {
         fail_nan();
         return;
     }
     // slot records -> workspace (set A first, then set B, each padded to whole half-waves): the phases walk them 256 at a time
     for (int k = 0; k < 2; ++k) {
-        const int* slot_start = reinterpret_cast<const int*>(pool + L.tSlot) + k * set_words;
-        const unsigned short* order = reinterpret_cast<const unsigned short*>(slot_start + nA + 1);
+        const int* slot_start = slot_tables + k * set_words;
+        const id_t* order = reinterpret_cast<const id_t*>(slot_start + nA + 1);
         const int cnt = sh.set_rows[k], nslots = k ? slotsB : slotsA, npad = k ? padB : padA, base = k ? padA : 0;
         for (int s0 = wave * TILE; s0 < npad; s0 += NW * TILE) {  // one wave per 32 slots (both half-waves compute the same)
             const int sl = s0 + li;
@@ -430,7 +588,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                         for (int k2 = 0; k2 < zlen; ++k2)
                             if (level[scol[ze0 + k2]] <= 1) (k2 < 32 ? zm0 : zm1) |= 1u << (k2 & 31);
                     } else {  // the entry (t, row): row t's compact entries are 0 .. degT - 1, ascending columns
-                        const int pe = lower_bound_u16(scol, 0, degT, row);
+                        const int pe = lower_bound_ids(scol, 0, degT, row);
                         zm0 = (row != tr && pe < degT && (int)scol[pe] == row) ? (unsigned)pe : 0xffffffffu;
                     }
                 }
@@ -442,13 +600,25 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 wsplit = other > wsplit ? other : wsplit;
             }
             if (h == 0) {
-                SlotRec rec;
-                rec.x = (unsigned)zrow | ((unsigned)zns << 15) | ((unsigned)wsplit << 20) | ((unsigned)zfirst << 25) | ((unsigned)zrem << 26) |
-                        ((unsigned)zinb << 31);
-                rec.y = (unsigned)ze0 | ((unsigned)zlen << 16);
-                rec.m0 = zm0;
-                rec.m1 = zm1;
-                srec[base + sl] = rec;
+                if constexpr (XL) {
+                    SlotRecXL rec;
+                    rec.row = (unsigned)zrow;
+                    rec.e0 = (unsigned)ze0;
+                    rec.info = (unsigned)zlen | ((unsigned)zns << 8) | ((unsigned)wsplit << 13) | ((unsigned)zfirst << 18) | ((unsigned)zrem << 19) |
+                               ((unsigned)zinb << 24);
+                    rec.m0 = zm0;
+                    rec.m1 = zm1;
+                    rec.pad0 = rec.pad1 = rec.pad2 = 0u;
+                    srecx[base + sl] = rec;
+                } else {
+                    SlotRec rec;
+                    rec.x = (unsigned)zrow | ((unsigned)zns << 15) | ((unsigned)wsplit << 20) | ((unsigned)zfirst << 25) | ((unsigned)zrem << 26) |
+                            ((unsigned)zinb << 31);
+                    rec.y = (unsigned)ze0 | ((unsigned)zlen << 16);
+                    rec.m0 = zm0;
+                    rec.m1 = zm1;
+                    srec[base + sl] = rec;
+                }
             }
         }
     }
@@ -456,20 +626,37 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         const int sl = round * (NT / 2) + wave * TILE + li;
         const int npad = set ? padB : padA;
         RowSlot z;
-        SlotRec rec;
-        rec.x = rec.y = rec.m0 = rec.m1 = 0u;
-        if (sl < npad) rec = srec[(set ? padA : 0) + sl];
-        z.row = rec.x & 32767u;
-        z.nsplit = (rec.x >> 15) & 31u;
-        z.wsplit = (rec.x >> 20) & 31u;
-        z.first = (rec.x >> 25) & 1u;
-        z.rem = (rec.x >> 26) & 31u;
-        if (z.rem == 0) z.rem = 1;
-        z.inB = (rec.x >> 31) & 1u;
-        z.bmask = rec.m0;
-        z.bmask_hi = rec.m1;
-        z.e0 = rec.y & 0xffffu;
-        z.e1 = z.e0 + (int)(rec.y >> 16);
+        if constexpr (XL) {
+            SlotRecXL rec;
+            rec.row = rec.e0 = rec.info = rec.m0 = rec.m1 = 0u;
+            if (sl < npad) rec = srecx[(set ? padA : 0) + sl];
+            z.row = (int)rec.row;
+            z.nsplit = (rec.info >> 8) & 31u;
+            z.wsplit = (rec.info >> 13) & 31u;
+            z.first = (rec.info >> 18) & 1u;
+            z.rem = (rec.info >> 19) & 31u;
+            if (z.rem == 0) z.rem = 1;
+            z.inB = (rec.info >> 24) & 1u;
+            z.bmask = rec.m0;
+            z.bmask_hi = rec.m1;
+            z.e0 = (int)rec.e0;
+            z.e1 = z.e0 + (int)(rec.info & 255u);
+        } else {
+            SlotRec rec;
+            rec.x = rec.y = rec.m0 = rec.m1 = 0u;
+            if (sl < npad) rec = srec[(set ? padA : 0) + sl];
+            z.row = rec.x & 32767u;
+            z.nsplit = (rec.x >> 15) & 31u;
+            z.wsplit = (rec.x >> 20) & 31u;
+            z.first = (rec.x >> 25) & 1u;
+            z.rem = (rec.x >> 26) & 31u;
+            if (z.rem == 0) z.rem = 1;
+            z.inB = (rec.x >> 31) & 1u;
+            z.bmask = rec.m0;
+            z.bmask_hi = rec.m1;
+            z.e0 = rec.y & 0xffffu;
+            z.e1 = z.e0 + (int)(rec.y >> 16);
+        }
         z.wave_active = round * (NT / 2) + wave * TILE < npad;
         if (z.nsplit == 0) z.nsplit = 1;
         if (z.wsplit == 0) z.wsplit = 1;
@@ -490,8 +677,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 j = gcol[e];
                 up = j > i;
             }
-            const int ai = up ? (int)aidx[i] : 0xffff, aj = up ? (int)aidx[j] : 0xffff;
-            const bool near = up && (ai != 0xffff || aj != 0xffff);
+            const int ai = up ? (int)aidx[i] : NOTA, aj = up ? (int)aidx[j] : NOTA;
+            const bool near = up && (ai != NOTA || aj != NOTA);
             const bool far = up && !near;
             const unsigned long long bn = __ballot(near), bf = __ballot(far);
             if (lane == 0) {
@@ -510,28 +697,50 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             }
             if (up) {
                 const unsigned long long lower = (1ull << lane) - 1ull;
-                const int k = near ? nb + __popcll(bn & lower) : eup - 1 - (fb + __popcll(bf & lower));
-                const float w = Ag[(size_t)i * ld + j];
-                if (Ag[(size_t)j * ld + i] != w) asym = true;
+                const int nbv = nb + __popcll(bn & lower), fbv = fb + __popcll(bf & lower);
+                const int k = near ? nbv : eup - 1 - fbv;
+                // (XL: the upper entries before this one in CSR order = its index in the caller's row-major edge lists)
+                const long long q = XL ? xl.eoff[t] + (nbv + fbv) : 0;
+                float w;
+                if constexpr (XL) {
+                    w = xl.w ? xl.w[csr_off[2 * t + 1] + e] : 1.0f;      // (symmetry of the weights: checked when the graph is uploaded)
+                } else {
+                    w = Ag[(size_t)i * ld + j];
+                    if (Ag[(size_t)j * ld + i] != w) asym = true;
+                }
                 if (k >= 0 && k < eup) {
                     int cij = nact, cji = nact;
-                    if (ai != 0xffff) cij = cbase[ai] + (e - arp[ai]);
-                    if (aj != 0xffff) {
+                    if (ai != NOTA) cij = cbase[ai] + (e - arp[ai]);
+                    if (aj != NOTA) {
                         const int lo = cbase[aj], hi = lo + (int)adeg[aj];
-                        cji = lower_bound_u16(scol, lo, hi, i);
+                        cji = lower_bound_ids(scol, lo, hi, i);
                         if (cji >= hi || (int)scol[cji] != i) {
                             asym = true;
                             cji = nact;
                         }
                     }
-                    eidx[2 * k] = (unsigned)i | ((unsigned)j << 16);
-                    eidx[2 * k + 1] = (unsigned)cij | ((unsigned)cji << 16);
-                    est[0 * eup + k] = Mg[(size_t)i * ld + j];
-                    est[1 * eup + k] = Mg[(size_t)j * ld + i];
-                    est[2 * eup + k] = p.m_in ? p.m_in[tm.offQ + (size_t)i * ld + j] : 0.0f;   // gnnx_run_resume: Adam moments
-                    est[3 * eup + k] = p.m_in ? p.m_in[tm.offQ + (size_t)j * ld + i] : 0.0f;
-                    est[4 * eup + k] = p.v_in ? p.v_in[tm.offQ + (size_t)i * ld + j] : 0.0f;
-                    est[5 * eup + k] = p.v_in ? p.v_in[tm.offQ + (size_t)j * ld + i] : 0.0f;
+                    if constexpr (XL) {
+                        eidx[k] = (unsigned)i;
+                        eidx[(size_t)eup + k] = (unsigned)j;
+                        eidx[2 * (size_t)eup + k] = (unsigned)cij;
+                        eidx[3 * (size_t)eup + k] = (unsigned)cji;
+                        eidx[4 * (size_t)eup + k] = (unsigned)(nbv + fbv);
+                        est[0 * eup + k] = xl.M_e[2 * q];
+                        est[1 * eup + k] = xl.M_e[2 * q + 1];
+                        est[2 * eup + k] = xl.m_in_e ? xl.m_in_e[2 * q] : 0.0f;   // gnnx_xl_run with a state to resume from
+                        est[3 * eup + k] = xl.m_in_e ? xl.m_in_e[2 * q + 1] : 0.0f;
+                        est[4 * eup + k] = xl.v_in_e ? xl.v_in_e[2 * q] : 0.0f;
+                        est[5 * eup + k] = xl.v_in_e ? xl.v_in_e[2 * q + 1] : 0.0f;
+                    } else {
+                        eidx[2 * k] = (unsigned)i | ((unsigned)j << 16);
+                        eidx[2 * k + 1] = (unsigned)cij | ((unsigned)cji << 16);
+                        est[0 * eup + k] = Mg[(size_t)i * ld + j];
+                        est[1 * eup + k] = Mg[(size_t)j * ld + i];
+                        est[2 * eup + k] = p.m_in ? p.m_in[tm.offQ + (size_t)i * ld + j] : 0.0f;   // gnnx_run_resume: Adam moments
+                        est[3 * eup + k] = p.m_in ? p.m_in[tm.offQ + (size_t)j * ld + i] : 0.0f;
+                        est[4 * eup + k] = p.v_in ? p.v_in[tm.offQ + (size_t)i * ld + j] : 0.0f;
+                        est[5 * eup + k] = p.v_in ? p.v_in[tm.offQ + (size_t)j * ld + i] : 0.0f;
+                    }
                     est[6 * eup + k] = w;
                     const float dy = p.yhat[tm.offR + i] - p.yhat[tm.offR + j];
                     glap[k] = p.c_lap * 0.5f * dy * dy * inv_n2;
@@ -563,7 +772,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     for (int e = tid; e < C * 96; e += NT) sWp[e] = p.wts[WT_WP + e];
     if (tid < CMAX) sh.sbp[tid] = p.wts[WT_BP + tid];
     for (int e = tid; e < SPL_TDEG_MAX; e += NT) sG3[e] = 0.0f;
-    for (int r = tid; r < ld; r += NT) sXi[r] = 255;
+    if (have_xi)
+        for (int r = tid; r < ld; r += NT) sXi[r] = 255;
     if (tid == 0) s_misc[1] = 0;
     if (tid < 32) {
         const float* fs = p.fs_in ? p.fs_in + (size_t)t * 3 * FS + tid : nullptr;   // gnnx_run_resume
@@ -574,15 +784,16 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     if (tid == 0) sAb[nact] = 0.0f;
     // sigma(M) -> symmetrised masked adjacency, one float per active directed entry
     for (int k = tid; k < eupN; k += NT) {
-        const unsigned en = eidx[2 * k + 1];
+        int cij, cji;
+        edge_entries(k, cij, cji);
         const float a = est[6 * eup + k] * (0.5f * (sigmoidf_(est[0 * eup + k]) + sigmoidf_(est[1 * eup + k])));
-        sAb[en & 0xffffu] = a;
-        sAb[en >> 16] = a;
+        sAb[cij] = a;
+        sAb[cji] = a;
     }
     __syncthreads();
     // ---------------- feature dictionary: the distinct rows of X, if there are at most SPL_XD_MAX (bit-exact comparison) ----------------
-    bool xdict = true;
-    {
+    bool xdict = have_xi;      // (uniform; XL without room for a byte per node: the feature rows come from L2)
+    if (have_xi) {
         int nd = 0;
         for (;;) {
             if (tid == 0) s_misc[0] = 0x7fffffff;
@@ -940,9 +1151,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             for (int u = 0; u < EU; ++u) {
                 on[u] = k0 + u * NT < eupN;
                 kk[u] = on[u] ? k0 + u * NT : k0;
-                const unsigned en = eidx[2 * kk[u] + 1];
-                cij[u] = en & 0xffffu;
-                cji[u] = en >> 16;
+                edge_entries(kk[u], cij[u], cji[u]);
                 w[u] = est[6 * eup + kk[u]];
                 lap[u] = glap[kk[u]];
                 Mij[u] = est[0 * eup + kk[u]];
@@ -1059,35 +1268,55 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     // ---------------- results: dense Abar block (zero off the edges), M on the edges, feature mask ----------------
     // (a separate zero-fill kernel in front of this launch was measured: it queues behind the resident launch on the other
     // stream and delays this one by more than the 0.2-0.8 ms the fill costs here)
-    {
+    if constexpr (!XL) {
         f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
         if (!p.edge_only)   // (gnnx_hyper.edge_results_only: the caller reads Abar on the edges only - skip the ld^2 zero-fill)
             for (size_t e = (size_t)tid * 4; e < (size_t)ld * ld; e += 4 * NT) *reinterpret_cast<f32x4*>(p.Abar + tm.offQ + e) = z4;
     }
     __threadfence_block();
     __syncthreads();
+    // one edge's results: the masked adjacency of the last forward, the mask entries and (on request) their moments - into the dense blocks, or
+    // (XL) into the caller's edge lists at the edge's row-major index
+    auto put_edge = [&](int k, int i, int j, float a, float Mij, float Mji, float mij, float mji, float vij, float vji) {
+        if constexpr (XL) {
+            const long long q = xl.eoff[t] + (long long)eidx[4 * (size_t)eup + k];
+            xl.abar_e[q] = a;
+            xl.M_e[2 * q] = Mij;
+            xl.M_e[2 * q + 1] = Mji;
+            if (xl.m_out_e) {
+                xl.m_out_e[2 * q] = mij;
+                xl.m_out_e[2 * q + 1] = mji;
+            }
+            if (xl.v_out_e) {
+                xl.v_out_e[2 * q] = vij;
+                xl.v_out_e[2 * q + 1] = vji;
+            }
+        } else {
+            p.Abar[tm.offQ + (size_t)i * ld + j] = a;
+            p.Abar[tm.offQ + (size_t)j * ld + i] = a;
+            Mg[(size_t)i * ld + j] = Mij;
+            Mg[(size_t)j * ld + i] = Mji;
+            if (p.m_out) {
+                p.m_out[tm.offQ + (size_t)i * ld + j] = mij;
+                p.m_out[tm.offQ + (size_t)j * ld + i] = mji;
+            }
+            if (p.v_out) {
+                p.v_out[tm.offQ + (size_t)i * ld + j] = vij;
+                p.v_out[tm.offQ + (size_t)j * ld + i] = vji;
+            }
+        }
+    };
     for (int k = tid; k < eupN; k += NT) {
-        const unsigned nd = eidx[2 * k], en = eidx[2 * k + 1];
-        const int i = nd & 0xffffu, j = nd >> 16;
-        const int cij = en & 0xffffu, cji = en >> 16;
+        int i, j, cij, cji;
+        edge_nodes(k, i, j);
+        edge_entries(k, cij, cji);
         const float a = sAb[cij != nact ? cij : cji];   // a near edge has at least one of its two entries in a row of A
-        p.Abar[tm.offQ + (size_t)i * ld + j] = a;
-        p.Abar[tm.offQ + (size_t)j * ld + i] = a;
-        Mg[(size_t)i * ld + j] = est[0 * eup + k];
-        Mg[(size_t)j * ld + i] = est[1 * eup + k];
-        if (p.m_out) {
-            p.m_out[tm.offQ + (size_t)i * ld + j] = est[2 * eup + k];
-            p.m_out[tm.offQ + (size_t)j * ld + i] = est[3 * eup + k];
-        }
-        if (p.v_out) {
-            p.v_out[tm.offQ + (size_t)i * ld + j] = est[4 * eup + k];
-            p.v_out[tm.offQ + (size_t)j * ld + i] = est[5 * eup + k];
-        }
+        put_edge(k, i, j, a, est[0 * eup + k], est[1 * eup + k], est[2 * eup + k], est[3 * eup + k], est[4 * eup + k], est[5 * eup + k]);
     }
     // ---------------- far edges: the whole trajectory of both mask entries in registers ----------------
     for (int k = eupN + tid; k < eup; k += NT) {
-        const unsigned nd = eidx[2 * k];
-        const int i = nd & 0xffffu, j = nd >> 16;
+        int i, j;
+        edge_nodes(k, i, j);
         const float w = est[6 * eup + k];
         const float gc = glap[k] * w;   // (0.5 G + lap) w with G = 0 exactly
         float Mij = est[0 * eup + k], Mji = est[1 * eup + k], mij = est[2 * eup + k], mji = est[3 * eup + k], vij = est[4 * eup + k],
@@ -1115,18 +1344,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                     atomicAdd(&L[LOGD + 2], w);
                 }
         }
-        p.Abar[tm.offQ + (size_t)i * ld + j] = a;
-        p.Abar[tm.offQ + (size_t)j * ld + i] = a;
-        Mg[(size_t)i * ld + j] = Mij;
-        Mg[(size_t)j * ld + i] = Mji;
-        if (p.m_out) {
-            p.m_out[tm.offQ + (size_t)i * ld + j] = mij;
-            p.m_out[tm.offQ + (size_t)j * ld + i] = mji;
-        }
-        if (p.v_out) {
-            p.v_out[tm.offQ + (size_t)i * ld + j] = vij;
-            p.v_out[tm.offQ + (size_t)j * ld + i] = vji;
-        }
+        put_edge(k, i, j, a, Mij, Mji, mij, mji, vij, vji);
     }
     if constexpr (LOG)
         if (p.loss) {   // every edge has added its share: the density of each epoch

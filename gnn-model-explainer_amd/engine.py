@@ -70,6 +70,11 @@ class _Resume(ctypes.Structure):
                 ("m_out", ctypes.c_void_p), ("v_out", ctypes.c_void_p), ("feat_out", ctypes.c_void_p)]
 
 
+class _XlState(ctypes.Structure):
+    _fields_ = [("first_iter", ctypes.c_int32), ("M_e", ctypes.c_void_p), ("m_e", ctypes.c_void_p), ("v_e", ctypes.c_void_p), ("feat", ctypes.c_void_p),
+                ("m_out_e", ctypes.c_void_p), ("v_out_e", ctypes.c_void_p), ("feat_out", ctypes.c_void_p)]
+
+
 @dataclass
 class AdamState:
     """Optimiser state of a batch (gnnx_resume, include/gnnx.h): what torch.optim.Adam keeps for ExplainModule's two
@@ -175,6 +180,17 @@ _API = {
     "gnnx_stream_create_cu_mask": (ctypes.c_void_p, [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int32]),
     "gnnx_debug_spin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "gnnx_debug_lane_sums": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "gnnx_xl_create": (ctypes.c_int, [ctypes.POINTER(_Problem), ctypes.POINTER(_Model), ctypes.POINTER(ctypes.c_void_p)]),
+    "gnnx_xl_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "gnnx_xl_total_rows": (ctypes.c_int64, [ctypes.c_void_p]),
+    "gnnx_xl_rows_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
+    "gnnx_xl_count": (ctypes.c_int, [ctypes.c_void_p] * 7 + [ctypes.c_int32] + [ctypes.c_void_p] * 2 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
+    "gnnx_xl_total_edges": (ctypes.c_int64, [ctypes.c_void_p]),
+    "gnnx_xl_entries_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
+    "gnnx_xl_get_layout": (ctypes.c_int, [ctypes.c_void_p] * 4),
+    "gnnx_xl_build": (ctypes.c_int, [ctypes.c_void_p] * 8 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
+    "gnnx_xl_set_trace": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "gnnx_xl_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper), ctypes.POINTER(_XlState)] + [ctypes.c_void_p] * 5),
     "gnnx_last_error": (ctypes.c_char_p, []),
     "gnnx_version": (ctypes.c_char_p, []),
 }
@@ -935,6 +951,222 @@ class MaskOptimJob:
             self.close()
         except Exception:
             pass
+
+
+class XLJob:
+    """A batch of node-mode targets of ANY size on the XL route (include/gnnx.h: gnnx_xl_*): what Explainer.explain does per target
+    (explain.py:80-117 sub-graph slicing + ExplainModule, :137-146 the loop, :208-211 the result) with every sub-graph built ON THE DEVICE as a CSR of
+    local ids from the resident full-graph CSR and the k-hop lists - no dense n x n block exists on the host or the device - and masks, optimiser state
+    and results as edge lists (engine.EdgeMasks).  Same kernel arithmetic as MaskOptimJob's route 7 (k_sparse_large), for the targets that route
+    cannot take: n > 16 383 (9.6 GB per dense array at the BA-House x100k maximum) or more entries within two hops than its LDS holds."""
+
+    def __init__(self, graph: DeviceGraph, neighbors, target_rows, gt_labels, state_dict, lib=None):
+        self.lib = lib if lib is not None else get_library()
+        self.device = graph.feat.device
+        self.graph = graph
+        self.graph_mode = False
+        MaskOptimJob._init_model(self, state_dict)
+        if self.att is not None:
+            raise NotImplementedError("method='att' has no XL form")
+        if graph.feat.shape[1] != self.D:
+            raise ValueError("feature width does not match the encoder")
+        on_device = isinstance(neighbors, DeviceNeighbors)
+        self.T = len(neighbors)
+        if self.T == 0:
+            raise ValueError("empty batch")
+        self.n = np.ascontiguousarray(neighbors.sizes, np.int32) if on_device else np.asarray([len(nb) for nb in neighbors], np.int32)
+        if on_device and target_rows is None:
+            target_rows = neighbors.rows
+        rows = np.ascontiguousarray(target_rows, np.int32)
+        if (rows < 0).any():
+            raise IndexError("targets %s are not in their own k-hop walk sets (isolated nodes?)" % np.nonzero(rows < 0)[0][:8].tolist())
+        labels = np.ascontiguousarray(gt_labels, np.int32)
+        prob = _Problem(self.T, self.n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                        labels.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), self.D, self.H, self.O, self.C, 0, 0, 0)
+        mdl = _Model()
+        for l, k in enumerate(("conv_first", "conv_block.0", "conv_last")):
+            mdl.W[l] = _fptr(self.w[k + ".weight"])
+            mdl.b[l] = _fptr(self.w[k + ".bias"])
+        mdl.Wp = _fptr(self.w["pred_model.weight"])
+        mdl.bp = _fptr(self.w["pred_model.bias"])
+        self.handle = ctypes.c_void_p()
+        _check(self.lib, self.lib.gnnx_xl_create(ctypes.byref(prob), ctypes.byref(mdl), ctypes.byref(self.handle)))
+        dev = self.device
+        self.stream = _engine_stream(dev) if dev.type == _DEVICE_TYPE else None
+        if on_device:
+            nb_flat, nb_off_d = neighbors.nb_flat, neighbors.nb_off
+        else:
+            off = np.zeros(self.T + 1, np.int64)
+            np.cumsum(self.n, out=off[1:])
+            nb_flat = torch.from_numpy(np.concatenate([np.asarray(nb) for nb in neighbors]).astype(np.int32)).to(dev)
+            nb_off_d = torch.from_numpy(off).to(dev)
+        self._nb = (nb_flat, nb_off_d)
+        self.R = int(self.lib.gnnx_xl_total_rows(self.handle))
+        self.ld = np.zeros(self.T, np.int32)
+        self.offR = np.zeros(self.T, np.int64)
+        self.ws_rows = torch.empty(int(self.lib.gnnx_xl_rows_bytes(self.handle)), dtype=torch.uint8, device=dev)
+        g = graph
+        gargs = (g.indptr.data_ptr(), g.indices.data_ptr(), g.weights.data_ptr() if g.weights is not None else None, nb_flat.data_ptr(), nb_off_d.data_ptr())
+        counts = np.zeros(self.T, np.int64)
+        MaskOptimJob._enter(self)
+        _check(self.lib, self.lib.gnnx_xl_count(self.handle, *gargs, g.feat.data_ptr(), g.feat.shape[1], g.pred_label.data_ptr() if g.pred_label is not None else None,
+                                                self.ws_rows.data_ptr(), self.ws_rows.numel(), counts.ctypes.data, self._stream()))      # synchronises
+        self.E = int(self.lib.gnnx_xl_total_edges(self.handle))
+        self._eoff = np.zeros(self.T + 1, np.int64)
+        _check(self.lib, self.lib.gnnx_xl_get_layout(self.handle, self.ld.ctypes.data, self.offR.ctypes.data, self._eoff.ctypes.data))
+        self.ws_entries = torch.empty(int(self.lib.gnnx_xl_entries_bytes(self.handle)), dtype=torch.uint8, device=dev)
+        E1 = max(self.E, 1)
+        self._rc = torch.empty(E1, 2, dtype=torch.int32, device=dev)
+        _check(self.lib, self.lib.gnnx_xl_build(self.handle, *gargs, self.ws_rows.data_ptr(), self.ws_entries.data_ptr(), self.ws_entries.numel(),
+                                                self._rc.data_ptr(), self._stream()))
+        MaskOptimJob._leave(self)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.M_e = torch.empty(E1, 2, **f32)
+        self._ev = torch.empty(E1, **f32)
+        self.fmask = torch.empty(self.T, FEAT_STRIDE, **f32)
+        self._M0 = None
+
+    _stream = MaskOptimJob._stream
+    _enter = MaskOptimJob._enter
+    _leave = MaskOptimJob._leave
+    use_stream = MaskOptimJob.use_stream
+
+    @property
+    def sum_n2(self):
+        return float((self.n.astype(np.float64) ** 2).sum())
+
+    def edge_ids(self):
+        """(eoff [T + 1] host int64, rc [E, 2] DEVICE int32): the upper-triangle edges (r < c, local ids) of every target in row-major order"""
+        return self._eoff, self._rc[:self.E]
+
+    def set_masks_on_edges(self, vals: torch.Tensor):
+        """The initial masks on the edges: [E, 2] = (M[r][c], M[c][r]) in the order of edge_ids() (engine.init_edge_masks_on_edges /
+        transform_edge_words produce exactly that from the seeds)."""
+        if vals.dtype != torch.float32 or vals.numel() != 2 * self.E:
+            raise ValueError("vals must hold 2 E float32 values")
+        self._M0 = vals.reshape(-1, 2).to(self.device, non_blocking=True).clone() if self.E else vals.reshape(0, 2)
+        self.reset_masks()
+
+    def set_masks_seeded(self, seeds, threads=None):
+        """construct_edge_mask (explain.py:645-652) under the seed protocol - target k's n x n normal_ draw from a generator seeded with seeds[k] - on the
+        edges only (the host walks the engine state and lets ATen transform the blocks that hold an edge entry: gnnx_host_draw_edge_masks)."""
+        rc = self._rc[:self.E].cpu()
+        vals = init_edge_masks_on_edges(self.n, seeds, self._eoff, rc, threads=threads or default_rng_threads(big=True))
+        self.set_masks_on_edges(vals)
+
+    def reset_masks(self):
+        if self._M0 is None:
+            raise ValueError("no initial masks set")
+        if self.E:
+            self.M_e[:self.E].copy_(self._M0)
+
+    def launch(self, hyper: Hyper, state: Optional["XLState"] = None, keep_state=False, trace=False):
+        """Enqueue all iterations of every target (ONE launch, asynchronous).  state / keep_state / trace as MaskOptimJob.launch."""
+        if hyper.record_loss:
+            raise NotImplementedError("the XL route has no loss logging")
+        if trace:
+            self.trace_gates = torch.empty(hyper.num_iters, self.R, 2, dtype=torch.int32, device=self.device)
+            _check(self.lib, self.lib.gnnx_xl_set_trace(self.handle, self.trace_gates.data_ptr()))
+        hy = hyper.c()
+        ptr = lambda x: None if x is None else x.data_ptr()
+        st = state if state is not None else XLState()
+        xs = _XlState(int(st.first_iter), self.M_e.data_ptr(), ptr(st.m), ptr(st.v), ptr(st.feat), None, None, None)
+        if keep_state:
+            f32 = dict(dtype=torch.float32, device=self.device)
+            out = XLState(int(st.first_iter) + int(hyper.num_iters), torch.zeros(max(self.E, 1), 2, **f32), torch.zeros(max(self.E, 1), 2, **f32),
+                          torch.zeros(self.T, 3, FEAT_STRIDE, **f32))
+            xs.m_out_e, xs.v_out_e, xs.feat_out = out.m.data_ptr(), out.v.data_ptr(), out.feat.data_ptr()
+            self.state_out = out
+        self._state_keepalive = st
+        self._enter()
+        try:
+            _check(self.lib, self.lib.gnnx_xl_run(self.handle, ctypes.byref(hy), ctypes.byref(xs), self._ev.data_ptr(), self.fmask.data_ptr(),
+                                                  self.ws_rows.data_ptr(), self.ws_entries.data_ptr(), self._stream()))
+        finally:
+            if trace:
+                self.lib.gnnx_xl_set_trace(self.handle, None)
+        self._leave()
+
+    def gather_edges_device(self, with_mask=False) -> torch.Tensor:
+        return self._ev[:self.E]
+
+    def fetch_edges(self, with_mask=False) -> EdgeMasks:
+        if self.device.type == _DEVICE_TYPE:
+            torch.cuda.synchronize(self.device)
+        return EdgeMasks(self.n.copy(), self._eoff, self._rc[:self.E].cpu().numpy(), self._ev[:self.E].cpu().numpy(),
+                         self.fmask.cpu().numpy()[:, :self.D].copy(), self.M_e[:self.E].cpu().numpy() if with_mask else None)
+
+    def set_state_edges(self, first_iter, mask_rc, m_rc, v_rc, feat=None, feat_m=None, feat_v=None) -> "XLState":
+        """An optimiser state given on the edges ([E, 2] arrays in the order of edge_ids(); feat* [T, D]) -> the state for launch(state=...);
+        the mask entries go into self.M_e."""
+        to = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(self.device)
+        st = XLState(int(first_iter), None, None, torch.zeros(self.T, 3, FEAT_STRIDE, dtype=torch.float32, device=self.device))
+        if mask_rc is not None and self.E:
+            self.M_e[:self.E].copy_(to(mask_rc))
+        if m_rc is not None:
+            st.m = to(m_rc).reshape(-1, 2)
+        if v_rc is not None:
+            st.v = to(v_rc).reshape(-1, 2)
+        for k, src in enumerate((feat, feat_m, feat_v)):
+            if src is not None:
+                st.feat[:, k, :self.D] = to(src)
+        return st
+
+    def fetch_state_edges(self):
+        """(mask_rc, m_rc, v_rc [E, 2], feat [T, 3, D]) after a launch(keep_state=True)"""
+        if self.device.type == _DEVICE_TYPE:
+            torch.cuda.synchronize(self.device)
+        st = self.state_out
+        return (self.M_e[:self.E].cpu().numpy(), st.m[:self.E].cpu().numpy(), st.v[:self.E].cpu().numpy(), st.feat[:, :, :self.D].cpu().numpy())
+
+    def fetch_trace(self):
+        if self.device.type == _DEVICE_TYPE:
+            torch.cuda.synchronize(self.device)
+        g = self.trace_gates.cpu().numpy().view(np.uint32)
+        return [g[:, o:o + n, :].copy() for o, n in zip(self.offR, self.n)], None
+
+    def close(self):
+        if getattr(self, "handle", None):
+            if self.device.type == _DEVICE_TYPE:
+                torch.cuda.synchronize(self.device)      # the plan's tables go back to the pool: nothing may still read them
+            self.lib.gnnx_xl_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class XLState:
+    """Optimiser state of an XLJob batch on the edges: exp_avg / exp_avg_sq [E, 2] (None = zeros), feat [T, 3, 32]."""
+    first_iter: int = 0
+    m: Optional[torch.Tensor] = None
+    v: Optional[torch.Tensor] = None
+    feat: Optional[torch.Tensor] = None
+
+
+def xl_job_from_subgraphs(subgraphs: Sequence[Subgraph], state_dict, device=None, lib=None) -> XLJob:
+    """An XLJob whose targets are given as dense Subgraph objects (tests, small callers): the sub-graphs become the blocks of one
+    block-diagonal "full graph" and every target's k-hop list is its own block."""
+    import scipy.sparse as sp
+    blocks, feats, preds, nbs, off = [], [], [], [], 0
+    for sgr in subgraphs:
+        a = np.asarray(sgr.adj, np.float32)
+        blocks.append(sp.csr_matrix(a))
+        feats.append(np.asarray(sgr.feat, np.float32))
+        preds.append(np.asarray(sgr.pred_label, np.float32))
+        nbs.append(np.arange(off, off + a.shape[0], dtype=np.int64))
+        off += a.shape[0]
+    csr = sp.block_diag(blocks, format="csr")
+    feat = np.concatenate(feats)
+    if device is None:
+        device = torch.device(_DEVICE_TYPE, torch.cuda.current_device())
+    g = device_graph(csr, feat, None, device=device)
+    g.pred_label = torch.from_numpy(np.concatenate(preds)).to(g.feat.device)
+    return XLJob(g, nbs, [s.target_row for s in subgraphs], [s.gt_label for s in subgraphs], state_dict, lib=lib)
 
 
 _PIN_CACHE = {"buf": None, "event": None}

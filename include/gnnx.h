@@ -338,6 +338,56 @@ int gnnx_pool_trim(void);
  * block fit the pool, else as many as fit (>= 5).  bench.py maps targets to workgroups with it for the executed-work roofline. */
 int gnnx_sparse_tiny_per_workgroup(int32_t D, int32_t H, int32_t C);
 
+/* ---- the XL route: node-mode targets of ANY size, CSR-native (csrc/gnnx_xl.hpp, k_sparse_large<.., XL> in csrc/gnnx_sparse_large.hpp) ----------------
+ *
+ * What the reference does per target in Explainer.explain (explain.py:80-117: `sub_adj = adj[nb][:, nb]`, `sub_feat`, ExplainModule with its dense
+ * n x n mask, :137-146 the loop, :208-211 the masked adjacency handed back) WITHOUT a dense n x n block anywhere: the sub-graphs are built as CSRs of
+ * local ids from the resident full-graph CSR and the k-hop lists of gnnx_khop; masks, Adam moments and results are EDGE LISTS - for target t the
+ * upper-triangle edges (r < c) of its sub-graph in row-major order, eoff[t] .. eoff[t + 1], one (M[r][c], M[c][r]) pair per edge: the layout of
+ * gnnx_gather_edges.  Same arithmetic as route 7 (one source; bit-identical on targets both take), no limit on n, on the rows or entries within
+ * two hops; a row within two hops of the target may hold at most 1024 entries.  The explain loop of a 100k-node graph (explainer_main.py:309-313 ->
+ * explain.py:296-299) routes here every target the LDS-resident classes cannot take (BA-House x100k: 2.4 % of the nodes have sub-graphs of
+ * 16 384 ... 49 028 nodes - 9.6 GB per dense array - and another 1.5 % exceed route 7's LDS budget).
+ *
+ *   gnnx_xl_create   plan for T targets: prob->n / target_row / gt_label as in gnnx_plan_create (node mode, sigmoid mask, no --bn, C <= 8)
+ *   gnnx_xl_count    k_xl_rowdeg + k_xl_rowptr: every sub-graph row's entries among the list members (binary search in the ascending list), the
+ *                    packed feature rows / predicted class ids, the row pointers; edges_host [T] (HOST, may be NULL) = upper-triangle edges per
+ *                    target.  Synchronises `stream` (the host sizes the second workspace and the caller's edge lists from the counts).
+ *   gnnx_xl_build    k_xl_emit: columns / rows / weights of every directed entry and rc [E][2] (DEVICE out) = the (r, c) local ids of every edge
+ *   gnnx_xl_run      all num_iters iterations of every target in ONE launch, one workgroup per target (explain.py:137-146); asynchronous.
+ *                    state->M_e [E][2] in: initial masks (construct_edge_mask, explain.py:645-652, on the edges), out: after the steps;
+ *                    m_e / v_e / feat: optimiser state to resume from (gnnx_resume) or NULL; *_out: the state afterwards or NULL;
+ *                    abar_e [E]: masked adjacency of the LAST forward (explain.py:209-211); feat_mask [T][32].
+ *   gnnx_xl_set_trace  gates [num_iters][R][2] (R = gnnx_xl_total_rows) as gnnx_set_trace; reference widths only; NULL = off
+ * Workspaces (DEVICE, caller-owned): ws_rows of gnnx_xl_rows_bytes (known at create), ws_entries of gnnx_xl_entries_bytes (known after count);
+ * both must live from count to the last run.  indptr / indices / weights / nb / nb_off / feat / pred_label: as gnnx_pack_csr. */
+typedef struct gnnx_xl_s* gnnx_xl_handle;
+typedef struct {
+    int32_t first_iter;
+    float* M_e;
+    const float* m_e;
+    const float* v_e;
+    const float* feat;   /* [T][3][32] */
+    float* m_out_e;
+    float* v_out_e;
+    float* feat_out;     /* [T][3][32] */
+} gnnx_xl_state;
+int gnnx_xl_create(const gnnx_problem* prob, const gnnx_model* model, gnnx_xl_handle* out);
+int gnnx_xl_destroy(gnnx_xl_handle h);
+int64_t gnnx_xl_total_rows(gnnx_xl_handle h);
+size_t gnnx_xl_rows_bytes(gnnx_xl_handle h);
+int gnnx_xl_count(gnnx_xl_handle h, const int64_t* indptr, const int32_t* indices, const float* weights, const int32_t* nb, const int64_t* nb_off,
+                  const float* feat, int32_t feat_stride, const float* pred_label, void* ws_rows, size_t ws_rows_bytes, int64_t* edges_host,
+                  void* stream);
+int64_t gnnx_xl_total_edges(gnnx_xl_handle h);
+size_t gnnx_xl_entries_bytes(gnnx_xl_handle h);
+int gnnx_xl_get_layout(gnnx_xl_handle h, int32_t* ld, int64_t* offR, int64_t* eoff); /* HOST out: ld [T], offR [T], eoff [T + 1]; any may be NULL */
+int gnnx_xl_build(gnnx_xl_handle h, const int64_t* indptr, const int32_t* indices, const float* weights, const int32_t* nb, const int64_t* nb_off,
+                  void* ws_rows, void* ws_entries, size_t ws_entries_bytes, int32_t* rc, void* stream);
+int gnnx_xl_set_trace(gnnx_xl_handle h, uint32_t* gates);
+int gnnx_xl_run(gnnx_xl_handle h, const gnnx_hyper* hyper, const gnnx_xl_state* state, float* abar_e, float* feat_mask, void* ws_rows,
+                void* ws_entries, void* stream);
+
 const char* gnnx_last_error(void);
 const char* gnnx_version(void);
 

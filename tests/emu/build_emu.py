@@ -17,7 +17,7 @@ def build(force=False):
             os.path.join(HERE, "emu_runtime.cpp"), os.path.join(HERE, "include", "hip", "hip_runtime.h"),
             os.path.join(ROOT, "include", "gnnx.h"), os.path.join(CSRC, "gnnx_resident.hpp"),
             os.path.join(CSRC, "gnnx_sparse.hpp"), os.path.join(CSRC, "gnnx_sparse_large.hpp"),
-            os.path.join(CSRC, "gnnx_graph.hpp"), os.path.join(CSRC, "gnnx_att.hpp")]
+            os.path.join(CSRC, "gnnx_graph.hpp"), os.path.join(CSRC, "gnnx_att.hpp"), os.path.join(CSRC, "gnnx_xl.hpp")]
     fresh = lambda: os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in srcs)
     if not force and fresh():
         return OUT
