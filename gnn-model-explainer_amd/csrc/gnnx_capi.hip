@@ -2345,3 +2345,15 @@ extern "C" int gnnx_xl_run(gnnx_xl_handle h, const gnnx_hyper* hy, const gnnx_xl
     HIPCK(hipGetLastError());
     return 0;
 }
+
+extern "C" int gnnx_xl_mt_edge_words(gnnx_xl_handle h, const int64_t* seeds, void* ws_rows, void* ws_entries, uint32_t* words, void* stream) {
+    if (!h || !seeds || !ws_rows || !ws_entries || !words) return fail("null argument");
+    if (!h->built) return fail("gnnx_xl_mt_edge_words: call gnnx_xl_count and gnnx_xl_build first");
+    char* w = static_cast<char*>(ws_rows);
+    char* e = static_cast<char*>(ws_entries);
+    hipLaunchKernelGGL(k_mt_edge_words_xl, dim3(h->prob.num_targets), dim3(MTX_THREADS), 0, static_cast<hipStream_t>(stream), h->d_meta, seeds, h->d_csr_off,
+                       reinterpret_cast<const int32_t*>(w + h->r_rowptr), reinterpret_cast<const int32_t*>(w + h->r_uprow),
+                       reinterpret_cast<const int32_t*>(e + h->e_col), reinterpret_cast<const int32_t*>(e + h->e_row), h->d_eoff, words);
+    HIPCK(hipGetLastError());
+    return 0;
+}

@@ -190,6 +190,7 @@ _API = {
     "gnnx_xl_get_layout": (ctypes.c_int, [ctypes.c_void_p] * 4),
     "gnnx_xl_build": (ctypes.c_int, [ctypes.c_void_p] * 8 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     "gnnx_xl_set_trace": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "gnnx_xl_mt_edge_words": (ctypes.c_int, [ctypes.c_void_p] * 6),
     "gnnx_xl_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper), ctypes.POINTER(_XlState)] + [ctypes.c_void_p] * 5),
     "gnnx_last_error": (ctypes.c_char_p, []),
     "gnnx_version": (ctypes.c_char_p, []),
@@ -1052,6 +1053,26 @@ class XLJob:
         edges only (the host walks the engine state and lets ATen transform the blocks that hold an edge entry: gnnx_host_draw_edge_masks)."""
         rc = self._rc[:self.E].cpu()
         vals = init_edge_masks_on_edges(self.n, seeds, self._eoff, rc, threads=threads or default_rng_threads(big=True))
+        self.set_masks_on_edges(vals)
+
+    def draw_edge_words_device(self, seeds):
+        """First half of the seeded masks with the engine walked on the DEVICE (gnnx_xl_mt_edge_words: no n^2 scratch): -> device int32 [E, 4] raw
+        engine words; finish with engine.transform_edge_words(self.n, seeds, eoff, rc, words_host) + set_masks_on_edges."""
+        sd = _h2d(np.ascontiguousarray(np.asarray(seeds).astype(np.int64)), self.device)
+        words = torch.empty(max(self.E, 1), 4, dtype=torch.int32, device=self.device)
+        self._enter()
+        _check(self.lib, self.lib.gnnx_xl_mt_edge_words(self.handle, sd.data_ptr(), self.ws_rows.data_ptr(), self.ws_entries.data_ptr(), words.data_ptr(), self._stream()))
+        self._leave()
+        self._seeds_keepalive = sd
+        return words[:self.E]
+
+    def set_masks_seeded_device(self, seeds, threads=None):
+        """set_masks_seeded with the engine walk on the device: O(E) host work (ATen's own transform of the picked pairs), bit-identical."""
+        if not pair_staging_ok():
+            return self.set_masks_seeded(seeds, threads)
+        words = self.draw_edge_words_device(seeds).cpu()
+        rc = self._rc[:self.E].cpu()
+        vals = transform_edge_words(self.n, seeds, self._eoff, rc, words.contiguous(), threads=threads or default_rng_threads(big=True))
         self.set_masks_on_edges(vals)
 
     def reset_masks(self):

@@ -220,3 +220,34 @@ def test_xl_sub_csr_from_a_full_graph_and_seeded_masks(be):
         want = z["vals_early"][a:b]
         got = xe.masked_adj[int(xe.eoff[k]):int(xe.eoff[k + 1])]
         assert np.abs(got - want).max() < 1e-5, (t, np.abs(got - want).max())
+
+
+def test_xl_device_engine_walk_without_n2_scratch(be):
+    """gnnx_xl_mt_edge_words: the raw engine words of every directed entry's Box-Muller pair, picked as the stream positions pass - no n^2 scratch -
+    then ATen's own transform on the host: torch.equal with `manual_seed; normal_` on every edge entry, for streams below 16 values, of exactly 16,
+    ragged ones (the redrawn tail), several blocks, entries of one engine block spread over two staged chunks."""
+    if not engine.pair_staging_ok():
+        pytest.skip("the host's normal_ lacks the pair-staging property")
+    rng = np.random.default_rng(3)
+    sd = helpers.random_model(rng, 10, 20, 20, 4)
+    sgs, seeds = [], []
+    for n, dens in ((3, 1.0), (4, 1.0), (5, 0.9), (37, 0.3), (64, 0.9), (129, 0.05), (700, 0.004), (25, 1.0)):
+        A, X = helpers.random_graph(rng, n, 10, density=dens)
+        sgs.append(Subgraph(A, X, 0, 0, rng.integers(0, 4, n), None))
+        seeds.append(int(rng.integers(0, 2 ** 31)))
+    xj = engine.xl_job_from_subgraphs(sgs, sd, device=be.device, lib=be.lib)
+    seeds = np.asarray(seeds, np.int64)
+    xj.set_masks_seeded_device(seeds, threads=2)
+    got = xj.M_e[:xj.E].cpu().numpy()
+    eoff, rc = xj.edge_ids()
+    rc = rc.cpu().numpy()
+    for k, sgr in enumerate(sgs):
+        n = sgr.adj.shape[0]
+        torch.manual_seed(int(seeds[k]))
+        m0 = torch.empty(n, n).normal_(1.0, np.sqrt(2.0) * np.sqrt(2.0 / (n + n))).numpy()
+        e = rc[eoff[k]:eoff[k + 1]]
+        want = np.stack([m0[e[:, 0], e[:, 1]], m0[e[:, 1], e[:, 0]]], 1)
+        assert np.array_equal(got[eoff[k]:eoff[k + 1]], want), (k, n)
+    # and the host walk gives the same
+    xj.set_masks_seeded(seeds, threads=2)
+    assert np.array_equal(xj.M_e[:xj.E].cpu().numpy(), got)

@@ -1,0 +1,28 @@
+#!/bin/bash
+# ONE parametrised GPU session script (round 6; replaces the ~75 one-off gpu_r3*.sh ... gpu_r5*.sh of the earlier rounds - their measurements
+# live on in profiles/ and DESIGN_HISTORY.md):
+#     gpurun --timeout 1500 -- 'bash tools/gpu_session.sh <session-name> <step> [<step> ...]'
+# Every step writes under gpurun_out/<session-name>/ and prints a short tail; steps are independent.  A step may carry arguments after a colon,
+# e.g. bench:--workload=ba100k-all or pytest:tests/test_xl_route.py.
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+ROOT=$PWD
+NAME=${1:-session}; shift
+O=$ROOT/gpurun_out/$NAME; mkdir -p "$O"
+export TMPDIR=/tmp
+stats_csv() { find "$1" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$2"; rm -rf "$1"; }
+for step in "$@"; do
+  s=${step%%:*}; arg=""; [[ "$step" == *:* ]] && arg=${step#*:}; arg=${arg//,/ }
+  echo "=== $step"
+  case $s in
+    build)        timeout 900 python __graft_entry__.py 2>&1 | tail -2 ;;
+    smoke)        timeout 600 python __graft_entry__.py smoke 2>&1 | tail -4 ;;
+    pytest)       timeout 3000 python -m pytest ${arg:-tests} -m gpu -x -q 2>&1 | tail -15 | tee "$O/pytest_$(echo "$arg" | tr '/ :' '___').txt" ;;
+    pytest_all)   timeout 5000 python -m pytest tests -m gpu -q 2>&1 | tail -25 | tee "$O/pytest_all.txt" ;;
+    probe_xl)     timeout 1500 python tools/probe_xl.py $arg --out "$O/probe_xl.json" 2>&1 | tail -12 ;;
+    bench)        tag=$(echo "$arg" | tr -c 'a-zA-Z0-9' '_'); timeout 1500 python bench.py $arg > "$O/bench_$tag.json" 2> "$O/bench_$tag.err"; tail -c 1500 "$O/bench_$tag.json"; tail -3 "$O/bench_$tag.err" ;;
+    rocprof)      tag=$(echo "$arg" | tr -c 'a-zA-Z0-9' '_'); (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$tag" -- python "$ROOT/bench.py" $arg > "$O/bench_under_rocprof_$tag.json" 2>/dev/null); stats_csv "$O/prof_$tag" "$O/kernel_stats_$tag.csv"; head -8 "$O/kernel_stats_$tag.csv" | cut -c1-200 ;;
+    py)           timeout 1500 python $arg 2>&1 | tail -30 ;;
+    sh)           timeout 1500 bash $arg 2>&1 | tail -30 ;;
+    *)            echo "unknown step $s" ;;
+  esac
+done
