@@ -2038,6 +2038,7 @@ struct gnnx_xl_s {
     gnnx_hyper adam_for{};
     int adam_first = -1;
     uint32_t* trace_gates = nullptr;
+    long long* clk = nullptr;         // gnnx_xl_set_clocks: [T][4] device ticks of every target's workgroup (measurement hook)
     // carve-out of the caller's two workspaces (bytes)
     size_t r_X, r_yhat, r_deg, r_updeg, r_rowptr, r_uprow, r_totals, rows_bytes = 0;
     size_t e_col, e_row, e_w, e_scr, entries_bytes = 0;
@@ -2257,6 +2258,12 @@ extern "C" int gnnx_xl_set_trace(gnnx_xl_handle h, uint32_t* gates) {
     return 0;
 }
 
+extern "C" int gnnx_xl_set_clocks(gnnx_xl_handle h, int64_t* ticks) {
+    if (!h) return fail("null argument");
+    h->clk = reinterpret_cast<long long*>(ticks);
+    return 0;
+}
+
 extern "C" int gnnx_xl_run(gnnx_xl_handle h, const gnnx_hyper* hy, const gnnx_xl_state* st, float* abar_e, float* feat_mask, void* ws_rows,
                            void* ws_entries, void* stream) {
     if (!h || !hy || !st || !st->M_e || !abar_e || !feat_mask || !ws_rows || !ws_entries) return fail("null argument");
@@ -2325,6 +2332,7 @@ extern "C" int gnnx_xl_run(gnnx_xl_handle h, const gnnx_hyper* hy, const gnnx_xl
     io.abar_e = abar_e;
     io.scr = reinterpret_cast<float*>(e + h->e_scr);
     io.scr_off = h->d_scr_off;
+    io.clk = h->clk;
     const int32_t* rowptr = reinterpret_cast<const int32_t*>(w + h->r_rowptr);
     const void* col = e + h->e_col;
     const void* row = e + h->e_row;

@@ -229,6 +229,8 @@ struct XlIo {
     float* abar_e;              // [E] out: masked adjacency of the LAST forward on every edge (explain.py:209-211)
     float* scr;                 // the targets' scratch blocks
     const long long* scr_off;   // [T] float offset of target t's block (xl_layout(n, ld, nnz).total floats)
+    long long* clk;             // measurement hook, or null: [T][4] wall_clock64 ticks (100 MHz) at the workgroup's start, after the setup, after the
+                                // iteration loop and at its end - the per-target cost model of the sharded job is calibrated on them (parallel.py)
 };
 
 template <bool XL> struct SplTypes { using id_t = unsigned short; static constexpr int NOTA = 0xffff; };
@@ -390,6 +392,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             return;
         }
     }
+    if constexpr (XL)
+        if (xl.clk && tid == 0) xl.clk[4 * t] = wall_clock64();
     const int rt0 = grp[tr], degT = grp[tr + 1] - rt0;
     if (degT > SPL_TDEG_MAX) {
         fail_nan();
@@ -828,6 +832,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         }
     }
 
+    if constexpr (XL)
+        if (xl.clk && tid == 0) xl.clk[4 * t + 1] = wall_clock64();
     for (int iter = 0; iter < p.num_iters; ++iter) {
         if (tid < 32) sh.phi[tid] = (tid < D) ? sigmoidf_(sh.fcur[tid]) : 0.0f;
         __syncthreads();
@@ -1265,6 +1271,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         }
         __syncthreads();
     }
+    if constexpr (XL)
+        if (xl.clk && tid == 0) xl.clk[4 * t + 2] = wall_clock64();
     // ---------------- results: dense Abar block (zero off the edges), M on the edges, feature mask ----------------
     // (a separate zero-fill kernel in front of this launch was measured: it queues behind the resident launch on the other
     // stream and delays this one by more than the 0.2-0.8 ms the fill costs here)
@@ -1355,6 +1363,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 L[LOGD] = L[LOGD + 1] / L[LOGD + 2];
             }
         }
+    if constexpr (XL)
+        if (xl.clk && tid == 0) xl.clk[4 * t + 3] = wall_clock64();
     if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = (tid < D) ? sh.fcur[tid] : 0.0f;
     if (p.fs_out && tid < FS) {
         float* fs = p.fs_out + (size_t)t * 3 * FS + tid;

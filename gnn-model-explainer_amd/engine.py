@@ -191,6 +191,7 @@ _API = {
     "gnnx_xl_build": (ctypes.c_int, [ctypes.c_void_p] * 8 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     "gnnx_xl_set_trace": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "gnnx_xl_mt_edge_words": (ctypes.c_int, [ctypes.c_void_p] * 6),
+    "gnnx_xl_set_clocks": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "gnnx_xl_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper), ctypes.POINTER(_XlState)] + [ctypes.c_void_p] * 5),
     "gnnx_last_error": (ctypes.c_char_p, []),
     "gnnx_version": (ctypes.c_char_p, []),
@@ -1110,6 +1111,18 @@ class XLJob:
 
     def gather_edges_device(self, with_mask=False) -> torch.Tensor:
         return self._ev[:self.E]
+
+    def record_clocks(self, on=True):
+        """Measurement hook (gnnx_xl_set_clocks): the launches that follow stamp every target's workgroup; target_ms() reads them."""
+        self._clk = torch.zeros(self.T, 4, dtype=torch.int64, device=self.device) if on else None
+        _check(self.lib, self.lib.gnnx_xl_set_clocks(self.handle, self._clk.data_ptr() if on else None))
+
+    def target_ms(self):
+        """[T, 3] milliseconds of the last launch per target: setup, iteration loop, results (far edges + write-back)"""
+        if self.device.type == _DEVICE_TYPE:
+            torch.cuda.synchronize(self.device)
+        c = self._clk.cpu().numpy().astype(np.float64)
+        return np.diff(c, axis=1) / 1e5
 
     def fetch_edges(self, with_mask=False) -> EdgeMasks:
         if self.device.type == _DEVICE_TYPE:

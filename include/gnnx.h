@@ -390,6 +390,9 @@ int gnnx_xl_build(gnnx_xl_handle h, const int64_t* indptr, const int32_t* indice
  * torch.manual_seed(seed); torch.FloatTensor(n, n).normal_(1.0, std) on the edges (construct_edge_mask, explain.py:645-652). */
 int gnnx_xl_mt_edge_words(gnnx_xl_handle h, const int64_t* seeds, void* ws_rows, void* ws_entries, uint32_t* words, void* stream);
 int gnnx_xl_set_trace(gnnx_xl_handle h, uint32_t* gates);
+/* Measurement hook: ticks [T][4] (DEVICE int64) receives, from every later gnnx_xl_run, the wall_clock64 value (100 MHz) at the start of target t's
+ * workgroup, after its setup, after its iteration loop and at its end; NULL = off.  parallel.py calibrates the sharded job's cost model on them. */
+int gnnx_xl_set_clocks(gnnx_xl_handle h, int64_t* ticks);
 int gnnx_xl_run(gnnx_xl_handle h, const gnnx_hyper* hyper, const gnnx_xl_state* state, float* abar_e, float* feat_mask, void* ws_rows,
                 void* ws_entries, void* stream);
 

@@ -128,12 +128,17 @@ def test_xl_ragged_batch_more_than_512_row_slots_resume_and_trace(be):
         X = np.ones((n, 10), np.float32)
         m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
         sgs.append(Subgraph(A, X, int(rng.integers(0, 4)), int(idx[0]), rng.integers(0, 4, n), m0))
-    em, xe, job, xj = _both(be, sgs, sd, 5, keep_state=True, trace=True)
+    em, xe, job, xj = _both(be, sgs, sd, 5, keep_state=True)
     _same(em, xe)
     s7, sx = job.fetch_state_edges(), xj.fetch_state_edges()
     for a, b in zip(s7, sx):
         assert np.array_equal(a, b)
-    g7, gx = job.fetch_trace()[0], xj.fetch_trace()[0]
+    # the decision trace (the LOG instantiations - separate kernels: on the GPU the compiler contracts a product of the two differently, 1 ulp after five
+    # iterations; on the emulator they are bit-identical too): every decision equal, values within 2 ulp
+    emt, xet, jobt, xjt = _both(be, sgs, sd, 5, trace=True)
+    assert np.abs(xet.masked_adj - emt.masked_adj).max() <= (0.0 if be.name == "emu" else 2.4e-7)
+    assert np.abs(xet.masked_adj - xe.masked_adj).max() <= (0.0 if be.name == "emu" else 2.4e-7)
+    g7, gx = jobt.fetch_trace()[0], xjt.fetch_trace()[0]
     for a, b in zip(g7, gx):
         assert np.array_equal(a, b) and a.any()
     # resume: 2 iterations, then 3 from the state handed back
