@@ -291,6 +291,15 @@ class DeviceNeighbors:
     def __len__(self):
         return len(self.sizes)
 
+    def subset(self, idx):
+        """The lists of the targets idx (host int array) as another DeviceNeighbors over the SAME device list buffer: only the per-target start offsets
+        are gathered (the packing kernels read a target's start and take its length from the plan)."""
+        idx = np.asarray(idx, np.int64)
+        it = torch.from_numpy(idx).to(self.nb_off.device)
+        dn = DeviceNeighbors(np.ascontiguousarray(self.sizes[idx]), np.ascontiguousarray(self.rows[idx]), self.nb_flat, self.nb_off.index_select(0, it).contiguous())
+        dn._keepalive = getattr(self, "_keepalive", None)
+        return dn
+
     def lists(self):
         """Host copies, one ascending id array per target (tests / inspection)."""
         flat, off = self.nb_flat.cpu().numpy(), self.nb_off.cpu().numpy()

@@ -26,13 +26,18 @@ import torch
 from . import engine
 
 
+class _Part:
+    """One route group of a prepared batch: the targets idx (positions in the batch) on a MaskOptimJob (dense-packed classes) or an XLJob (CSR-native)."""
+    __slots__ = ("idx", "job", "xl", "rc", "eoff", "E")
+
+
 class _Prepared:
-    __slots__ = ("targets", "job", "dn", "ready", "rc", "eoff", "E", "times", "error", "launch_cus")
+    __slots__ = ("targets", "job", "dn", "ready", "rc", "eoff", "E", "times", "error", "launch_cus", "parts")
 
 
 class BatchPipeline:
     def __init__(self, graph, state_dict, labels, hyper, n_hops=3, seed_base=1000, rng_threads=None, depth=None, prepare_workers=2, reserve_cus=0, lib=None,
-                 device_hook=None, rng_threads_big=None, edge_draw=None, edge_draw_min_values=2e7, device_walk=None):
+                 device_hook=None, rng_threads_big=None, edge_draw=None, edge_draw_min_values=2e7, device_walk=None, xl_min_n=None, xl_device_walk=None):
         """graph: engine.DeviceGraph (resident); labels [N]: the label the prediction loss uses (explain.py:750-753); the initial
         mask of target v is drawn from a generator seeded with seed_base + v (the seed protocol of the golden runs)."""
         self.graph, self.sd, self.labels, self.hyper = graph, state_dict, np.asarray(labels), hyper
@@ -69,6 +74,20 @@ class BatchPipeline:
         # batch before: 204.0 k (host) against 183.8 k nodes/s (device) on one GPU in the closing session (profiles/r05_bench_ba100k_16384targets*.json)
         auto_walk = "1" if int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > 1 else "0"
         self.device_walk = bool(int(os.environ.get("GNNX_PIPE_DEVICE_WALK", auto_walk))) if device_walk is None else bool(device_walk)
+        # Round 6: targets of more than xl_min_n sub-graph nodes take the XL route (engine.XLJob: sub-graph CSRs built from the resident graph, no dense
+        # n x n block, edge-list state) instead of being packed into dense blocks for k_sparse_large / the streaming kernels.  Beyond 16 383 nodes
+        # there is no alternative (a dense block of the largest BA-House x100k sub-graph is 9.6 GB per array); below, the two kernels are the same
+        # source and bit-identical (tests/test_xl_route.py) and the XL prepare stage is O(nnz) instead of O(n^2) - measured in profiles/r06_*.
+        # GNNX_XL_MIN_N overrides; 0 / a huge value sends everything / nothing there.
+        if xl_min_n is None:
+            xl_min_n = int(os.environ.get("GNNX_XL_MIN_N", "512"))
+        self.xl_min_n = int(xl_min_n)
+        n_classes = int(np.asarray(state_dict["pred_model.weight"].detach().cpu() if torch.is_tensor(state_dict["pred_model.weight"]) else state_dict["pred_model.weight"]).shape[0])
+        self.xl_ok = (not hyper.record_loss) and bool(hyper.use_resident) and n_classes <= 8      # (what gnnx_xl_create takes)
+        # the XL targets' seeded masks: engine walk on the device (k_mt_edge_words_xl, one serial pass per target: the 2.3e9 draws of a 48 k-node
+        # sub-graph take 1.7 s of one workgroup, hidden behind the other batches of a long job) or on the host (gnnx_host_draw_edge_masks: 0.3 ns per
+        # draw and core).  Default: the device when the ranks of a node share its cores or the batch is large, else the host.
+        self.xl_device_walk = (None if os.environ.get("GNNX_XL_DEVICE_WALK") is None else bool(int(os.environ["GNNX_XL_DEVICE_WALK"]))) if xl_device_walk is None else bool(xl_device_walk)
         # Optimisations in flight.  depth=None (default): as many as keep the chip full and no more - ceil(1.3 x 256 CUs / the compute units ONE
         # launch keeps busy), between 2 and 5, re-evaluated per batch (_launch_cus; four when a batch has streaming targets): every further launch in flight only queues behind the
         # others and lengthens the fill and drain of a short job.  Measured (profiles/r05_pipeline_workers_depth_room.txt): syn1 (116 workgroups
@@ -211,79 +230,133 @@ class BatchPipeline:
             p.times["khop_ms"] = (time.perf_counter() - t0) * 1e3
             if (dn.rows < 0).any():
                 raise ValueError("a target is not in its own %d-hop walk set (isolated node): the reference fails on it too" % self.n_hops)
-            # the seeded masks only need the sizes: C++ threads draw them while the device builds the plan
-            box = {}
-
-            def draw():
-                t_r = time.perf_counter()
-                total = int((dn.sizes.astype(np.int64) ** 2).sum())
-                try:
-                    box["raw"] = engine.init_edge_masks_raw(dn.sizes, seeds=self.seed_base + targets,
-                                                            threads=self.rng_threads_big if total > 2e7 else self.rng_threads,
-                                                            out=self._pin("raw", total, torch.float32, raw_slot))
-                except Exception as e:      # noqa: BLE001 - re-raised on the preparing thread
-                    box["err"] = e
-                box["ms"] = (time.perf_counter() - t_r) * 1e3
-            # Batches of more than 2e7 normals whose every target runs on an edge-sparse kernel: the host keeps only the values on the
-            # EDGES of its draw (gnnx_host_draw_edge_masks: 12 MB instead of 4 GB for the 16 384-target BA-House x100k set - no 4 GB of
-            # pinned writes, H2D copy and scatter).  It needs the edge list first, so the draw follows the plan instead of overlapping it.
-            total_values = int((dn.sizes.astype(np.int64) ** 2).sum())
-            # (only when the resident kernels will really take the batch: with use_resident off the dense streaming kernels run, and those read
-            #  and update EVERY entry of M - ADVICE r4)
-            edges_only = (self.edge_draw and total_values > self.edge_draw_min_values and not self.hyper.record_loss and
-                          bool(self.hyper.use_resident))
-            th = threading.Thread(target=draw)
-            if not edges_only:
-                th.start()
-            t1 = time.perf_counter()
-            job = engine.MaskOptimJob.from_csr(self.graph, dn, None, self.labels[targets], self.sd, lib=self.lib)
-            p.times["plan_pack_route_ms"] = (time.perf_counter() - t1) * 1e3
-            t1b = time.perf_counter()
-            job._edge_layout()
-            E = int(job._eoff[-1])
-            rc_host = self._pin("rc", 2 * max(E, 1), torch.int32, slot).view(-1, 2)
-            rc_host[:E].copy_(job._rc[:E], non_blocking=True)
-            p.times["edge_layout_ms"] = (time.perf_counter() - t1b) * 1e3
-            p.times["plan_pack_route_layout_ms"] = (time.perf_counter() - t1) * 1e3
-            p.launch_cus = self._launch_cus(job.route())
-            if edges_only and not np.isin(job.route(), (4, 5, 6, 7, 8)).all():
-                edges_only = False        # a target streams dense blocks: it needs every entry of its mask
-                th.start()
-            t1c = time.perf_counter()
-            if edges_only:
-                vals = self._pin("edge_vals", 2 * max(E, 1), torch.float32, raw_slot)[:2 * E].view(-1, 2)
-                if self.device_walk and engine.pair_staging_ok():
-                    words_d = job.draw_edge_words_device(self.seed_base + targets)        # the engine walk + pair gather, enqueued on this stream
-                    words_h = self._pin("edge_words", 4 * max(E, 1), torch.int32, raw_slot)[:4 * E].view(-1, 4)
-                    words_h.copy_(words_d, non_blocking=True)
-                    self._wait(s_prep, True)      # the edge ids and the word pairs are on the host now (tens of milliseconds: sleep, do not spin)
-                    p.times["device_walk_ms"] = (time.perf_counter() - t1c) * 1e3
-                    t1d = time.perf_counter()
-                    engine.transform_edge_words(dn.sizes, self.seed_base + targets, job._eoff, rc_host[:E], words_h, threads=self.rng_threads_edges, out=vals)
-                    p.times["host_transform_ms"] = (time.perf_counter() - t1d) * 1e3
-                    p.times["host_rng_device_walk"] = 1.0
-                else:
-                    self._wait(s_prep, True)      # the edge ids are on the host now
-                    engine.init_edge_masks_on_edges(dn.sizes, self.seed_base + targets, job._eoff, rc_host[:E], threads=self.rng_threads_edges, out=vals)
-                p.times["host_rng_ms"] = (time.perf_counter() - t1c) * 1e3
-                p.times["host_rng_edges_only"] = 1.0
-                t2 = time.perf_counter()
-                job.set_masks_on_edges(vals)
-            else:
-                th.join()
-                p.times["wait_for_rng_ms"] = (time.perf_counter() - t1c) * 1e3
-                if "err" in box:
-                    raise box["err"]
-                p.times["host_rng_ms"] = box["ms"]
-                t2 = time.perf_counter()
-                job.set_masks_raw(box["raw"])
+            big = (dn.sizes > self.xl_min_n) if self.xl_ok else np.zeros(len(targets), bool)
+            p.parts = []
+            p.launch_cus = 0
+            if not big.all():
+                idx = np.nonzero(~big)[0]
+                whole = len(idx) == len(targets)
+                p.parts.append(self._prepare_dense(p, idx, targets if whole else targets[idx], dn if whole else dn.subset(idx), slot, raw_slot, s_prep))
+            if big.any():
+                idx = np.nonzero(big)[0]
+                whole = len(idx) == len(targets)
+                p.parts.append(self._prepare_xl(p, idx, targets if whole else targets[idx], dn if whole else dn.subset(idx), slot, raw_slot, s_prep))
+                p.times["xl_targets"] = float(len(idx))
             p.ready = torch.cuda.Event()
             p.ready.record(s_prep)
             self._raw_done[raw_slot] = p.ready
-            p.times["h2d_scatter_enqueue_ms"] = (time.perf_counter() - t2) * 1e3
-        p.job, p.dn, p.rc, p.eoff, p.E = job, dn, rc_host, job._eoff, E
+        first = p.parts[0]
+        p.job, p.dn, p.rc, p.eoff, p.E = first.job, dn, first.rc, first.eoff, first.E        # (single-part batches: the attributes of rounds 3-5)
         p.times["prepare_ms"] = (time.perf_counter() - t0) * 1e3
         return p
+
+    def _prepare_xl(self, p, idx, targets, dn, slot, raw_slot, s_prep):
+        """The XL part of a batch (stream s_prep is current): sub-graph CSRs from the resident graph, seeded masks on the edges."""
+        t1 = time.perf_counter()
+        xj = engine.XLJob(self.graph, dn, None, self.labels[targets], self.sd, lib=self.lib)       # count (one host wait) + build
+        p.times["xl_count_build_ms"] = (time.perf_counter() - t1) * 1e3
+        E = xj.E
+        rc_host = self._pin("rc_xl", 2 * max(E, 1), torch.int32, slot).view(-1, 2)
+        rc_host[:E].copy_(xj._rc[:E], non_blocking=True)
+        vals = self._pin("edge_vals_xl", 2 * max(E, 1), torch.float32, raw_slot)[:2 * E].view(-1, 2)
+        t2 = time.perf_counter()
+        seeds = self.seed_base + targets
+        dw = self.xl_device_walk
+        if dw is None:      # auto: the device when the host is the shared resource or the batch is large; a handful of huge targets: the host
+            dw = self.device_walk or len(targets) >= 64
+        if dw and engine.pair_staging_ok():
+            words_d = xj.draw_edge_words_device(seeds)
+            words_h = self._pin("edge_words_xl", 4 * max(E, 1), torch.int32, raw_slot)[:4 * E].view(-1, 4)
+            words_h.copy_(words_d, non_blocking=True)
+            self._wait(s_prep, True)
+            p.times["xl_device_walk_ms"] = (time.perf_counter() - t2) * 1e3
+            t3 = time.perf_counter()
+            engine.transform_edge_words(dn.sizes, seeds, xj._eoff, rc_host[:E], words_h, threads=self.rng_threads_edges, out=vals)
+            p.times["xl_host_transform_ms"] = (time.perf_counter() - t3) * 1e3
+        else:
+            self._wait(s_prep, True)
+            engine.init_edge_masks_on_edges(dn.sizes, seeds, xj._eoff, rc_host[:E], threads=self.rng_threads_edges, out=vals)
+        p.times["xl_masks_ms"] = (time.perf_counter() - t2) * 1e3
+        xj.set_masks_on_edges(vals)
+        p.times["host_rng_edges_only"] = 1.0
+        part = _Part()
+        part.idx, part.job, part.xl, part.rc, part.eoff, part.E = idx, xj, True, rc_host, xj._eoff, E
+        p.launch_cus += min(len(targets), 256)
+        return part
+
+    def _prepare_dense(self, p, idx, targets, dn, slot, raw_slot, s_prep):
+        """The dense-packed part of a batch (stream s_prep is current): plan, device-side packing, routing, edge layout, seeded masks."""
+        # the seeded masks only need the sizes: C++ threads draw them while the device builds the plan
+        box = {}
+
+        def draw():
+            t_r = time.perf_counter()
+            total = int((dn.sizes.astype(np.int64) ** 2).sum())
+            try:
+                box["raw"] = engine.init_edge_masks_raw(dn.sizes, seeds=self.seed_base + targets,
+                                                        threads=self.rng_threads_big if total > 2e7 else self.rng_threads,
+                                                        out=self._pin("raw", total, torch.float32, raw_slot))
+            except Exception as e:      # noqa: BLE001 - re-raised on the preparing thread
+                box["err"] = e
+            box["ms"] = (time.perf_counter() - t_r) * 1e3
+        # Batches of more than 2e7 normals whose every target runs on an edge-sparse kernel: the host keeps only the values on the
+        # EDGES of its draw (gnnx_host_draw_edge_masks: 12 MB instead of 4 GB for the 16 384-target BA-House x100k set - no 4 GB of
+        # pinned writes, H2D copy and scatter).  It needs the edge list first, so the draw follows the plan instead of overlapping it.
+        total_values = int((dn.sizes.astype(np.int64) ** 2).sum())
+        # (only when the resident kernels will really take the batch: with use_resident off the dense streaming kernels run, and those read
+        #  and update EVERY entry of M - ADVICE r4)
+        edges_only = (self.edge_draw and total_values > self.edge_draw_min_values and not self.hyper.record_loss and
+                      bool(self.hyper.use_resident))
+        th = threading.Thread(target=draw)
+        if not edges_only:
+            th.start()
+        t1 = time.perf_counter()
+        job = engine.MaskOptimJob.from_csr(self.graph, dn, None, self.labels[targets], self.sd, lib=self.lib)
+        p.times["plan_pack_route_ms"] = (time.perf_counter() - t1) * 1e3
+        t1b = time.perf_counter()
+        job._edge_layout()
+        E = int(job._eoff[-1])
+        rc_host = self._pin("rc", 2 * max(E, 1), torch.int32, slot).view(-1, 2)
+        rc_host[:E].copy_(job._rc[:E], non_blocking=True)
+        p.times["edge_layout_ms"] = (time.perf_counter() - t1b) * 1e3
+        p.times["plan_pack_route_layout_ms"] = (time.perf_counter() - t1) * 1e3
+        lc = self._launch_cus(job.route())
+        p.launch_cus = -1 if (lc < 0 or p.launch_cus < 0) else p.launch_cus + lc
+        if edges_only and not np.isin(job.route(), (4, 5, 6, 7, 8)).all():
+            edges_only = False        # a target streams dense blocks: it needs every entry of its mask
+            th.start()
+        t1c = time.perf_counter()
+        if edges_only:
+            vals = self._pin("edge_vals", 2 * max(E, 1), torch.float32, raw_slot)[:2 * E].view(-1, 2)
+            if self.device_walk and engine.pair_staging_ok():
+                words_d = job.draw_edge_words_device(self.seed_base + targets)        # the engine walk + pair gather, enqueued on this stream
+                words_h = self._pin("edge_words", 4 * max(E, 1), torch.int32, raw_slot)[:4 * E].view(-1, 4)
+                words_h.copy_(words_d, non_blocking=True)
+                self._wait(s_prep, True)      # the edge ids and the word pairs are on the host now (tens of milliseconds: sleep, do not spin)
+                p.times["device_walk_ms"] = (time.perf_counter() - t1c) * 1e3
+                t1d = time.perf_counter()
+                engine.transform_edge_words(dn.sizes, self.seed_base + targets, job._eoff, rc_host[:E], words_h, threads=self.rng_threads_edges, out=vals)
+                p.times["host_transform_ms"] = (time.perf_counter() - t1d) * 1e3
+                p.times["host_rng_device_walk"] = 1.0
+            else:
+                self._wait(s_prep, True)      # the edge ids are on the host now
+                engine.init_edge_masks_on_edges(dn.sizes, self.seed_base + targets, job._eoff, rc_host[:E], threads=self.rng_threads_edges, out=vals)
+            p.times["host_rng_ms"] = (time.perf_counter() - t1c) * 1e3
+            p.times["host_rng_edges_only"] = 1.0
+            t2 = time.perf_counter()
+            job.set_masks_on_edges(vals)
+        else:
+            th.join()
+            p.times["wait_for_rng_ms"] = (time.perf_counter() - t1c) * 1e3
+            if "err" in box:
+                raise box["err"]
+            p.times["host_rng_ms"] = box["ms"]
+            t2 = time.perf_counter()
+            job.set_masks_raw(box["raw"])
+        p.times["h2d_scatter_enqueue_ms"] = (time.perf_counter() - t2) * 1e3
+        part = _Part()
+        part.idx, part.job, part.xl, part.rc, part.eoff, part.E = idx, job, False, rc_host, job._eoff, E
+        return part
 
     def _worker(self, batches, out_q):
         """Feeds out_q with prepared batches IN ORDER; the preparation itself runs on `prepare_workers` threads, each with its own
@@ -318,27 +391,57 @@ class BatchPipeline:
 
     # -- stages 2 + 3 ------------------------------------------------------------------------------------------------------
     def _launch(self, p, slot):
-        job = p.job
-        s_loop = self.s_loops[slot % len(self.s_loops)]
-        with torch.cuda.stream(s_loop):
-            s_loop.wait_event(p.ready)
-            job.use_stream(s_loop)
-            job.launch(self._edge_hyper)
-            done = torch.cuda.Event()
-            done.record(s_loop)
+        out = []
+        for pi, part in enumerate(p.parts):
+            job = part.job
+            s_loop = self.s_loops[(slot + pi) % len(self.s_loops)]          # (the two parts of a mixed batch optimise side by side)
+            with torch.cuda.stream(s_loop):
+                s_loop.wait_event(p.ready)
+                job.use_stream(s_loop)
+                job.launch(self.hyper if part.xl else self._edge_hyper)
+                done = torch.cuda.Event()
+                done.record(s_loop)
+            with torch.cuda.stream(self.s_fetch):
+                self.s_fetch.wait_event(done)
+                job.use_stream(self.s_fetch)
+                vals_d = job.gather_edges_device()
+                if self.device_hook is not None:
+                    self.device_hook(vals_d[:part.E], job)
+                nm = "_xl" if part.xl else ""
+                vals = self._pin("vals" + nm, max(part.E, 1), torch.float32, slot)
+                vals[:part.E].copy_(vals_d[:part.E], non_blocking=True)
+                fm = self._pin("fmask" + nm, job.T * engine.FEAT_STRIDE, torch.float32, slot).view(job.T, engine.FEAT_STRIDE)
+                fm.copy_(job.fmask, non_blocking=True)
+                out.append((vals, fm))
         with torch.cuda.stream(self.s_fetch):
-            self.s_fetch.wait_event(done)
-            job.use_stream(self.s_fetch)
-            vals_d = job.gather_edges_device()
-            if self.device_hook is not None:
-                self.device_hook(vals_d[:p.E], job)
-            vals = self._pin("vals", max(p.E, 1), torch.float32, slot)
-            vals[:p.E].copy_(vals_d[:p.E], non_blocking=True)
-            fm = self._pin("fmask", job.T * engine.FEAT_STRIDE, torch.float32, slot).view(job.T, engine.FEAT_STRIDE)
-            fm.copy_(job.fmask, non_blocking=True)
             fetched = torch.cuda.Event(blocking=p.times.get("host_rng_edges_only", 0.0) > 0)      # (a large batch: the caller sleeps through its tens of milliseconds)
             fetched.record(self.s_fetch)
-        return vals, fm, fetched
+        return out, None, fetched
+
+    @staticmethod
+    def _merge(n_targets, parts, fetched_parts, D):
+        """EdgeMasks of a mixed batch in TARGET order from its parts' edge lists (each part: its targets ascending in batch position)."""
+        counts = np.zeros(n_targets, np.int64)
+        for part in parts:
+            counts[part.idx] = np.diff(part.eoff)
+        eoff = np.zeros(n_targets + 1, np.int64)
+        np.cumsum(counts, out=eoff[1:])
+        E = int(eoff[-1])
+        rc = np.zeros((E, 2), np.int32)
+        vals = np.zeros(E, np.float32)
+        fm = np.zeros((n_targets, D), np.float32)
+        n = np.zeros(n_targets, np.int32)
+        for part, (pv, pf) in zip(parts, fetched_parts):
+            pe = int(part.eoff[-1])
+            if pe:
+                # destination of the part's e-th edge: its target's start in the merged list + its offset inside the target
+                cnt = np.diff(part.eoff)
+                dst = np.repeat(eoff[part.idx] - part.eoff[:-1], cnt) + np.arange(pe)
+                rc[dst] = part.rc[:pe].numpy()
+                vals[dst] = pv[:pe].numpy()
+            fm[part.idx] = pf.numpy()[:, :D]
+            n[part.idx] = part.job.n
+        return n, eoff, rc, vals, fm
 
     def run(self, batches):
         """batches: iterable of int arrays of target node ids.  Yields one engine.EdgeMasks per batch, in order."""
@@ -349,13 +452,23 @@ class BatchPipeline:
         slot = 0
 
         def finish(item):
-            p, vals, fm, fetched = item
+            p, got, _, fetched = item
             fetched.synchronize()
-            em = engine.EdgeMasks(p.job.n.copy(), p.eoff, p.rc[:p.E].numpy().copy(), vals[:p.E].numpy().copy(),
-                                  fm.numpy()[:, :p.job.D].copy())
+            if len(p.parts) == 1:
+                part, (vals, fm) = p.parts[0], got[0]
+                em = engine.EdgeMasks(part.job.n.copy(), part.eoff, part.rc[:part.E].numpy().copy(), vals[:part.E].numpy().copy(),
+                                      fm.numpy()[:, :part.job.D].copy())
+            else:
+                em = engine.EdgeMasks(*self._merge(len(p.targets), p.parts, got, p.parts[0].job.D))
             em.neighbors = p.dn
+            em.routes = [("xl" if part.xl else "dense", len(part.idx)) for part in p.parts]
             self.stats.append(p.times)
-            p.job.close()          # the plan's device tables go back to the library's pool (no hipFree: gnnx_capi.hip)
+            for part in p.parts:
+                if part.xl:
+                    part.job.lib.gnnx_xl_destroy(part.job.handle)      # (the fetch has completed: nothing reads its tables any more)
+                    part.job.handle = None
+                else:
+                    part.job.close()      # the plan's device tables go back to the library's pool (no hipFree: gnnx_capi.hip)
             return em
 
         while True:
