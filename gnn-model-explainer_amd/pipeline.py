@@ -391,7 +391,7 @@ class BatchPipeline:
 
     # -- stages 2 + 3 ------------------------------------------------------------------------------------------------------
     def _launch(self, p, slot):
-        out = []
+        out, hooked = [], []
         for pi, part in enumerate(p.parts):
             job = part.job
             s_loop = self.s_loops[(slot + pi) % len(self.s_loops)]          # (the two parts of a mixed batch optimise side by side)
@@ -405,8 +405,7 @@ class BatchPipeline:
                 self.s_fetch.wait_event(done)
                 job.use_stream(self.s_fetch)
                 vals_d = job.gather_edges_device()
-                if self.device_hook is not None:
-                    self.device_hook(vals_d[:part.E], job)
+                hooked.append(vals_d[:part.E])
                 nm = "_xl" if part.xl else ""
                 vals = self._pin("vals" + nm, max(part.E, 1), torch.float32, slot)
                 vals[:part.E].copy_(vals_d[:part.E], non_blocking=True)
@@ -414,6 +413,8 @@ class BatchPipeline:
                 fm.copy_(job.fmask, non_blocking=True)
                 out.append((vals, fm))
         with torch.cuda.stream(self.s_fetch):
+            if self.device_hook is not None:      # ONCE per batch (a collective: every rank must call it equally often, whatever its batch's parts)
+                self.device_hook(hooked[0] if len(hooked) == 1 else torch.cat(hooked), p.parts[0].job)
             fetched = torch.cuda.Event(blocking=p.times.get("host_rng_edges_only", 0.0) > 0)      # (a large batch: the caller sleeps through its tens of milliseconds)
             fetched.record(self.s_fetch)
         return out, None, fetched
