@@ -351,7 +351,8 @@ def bench_config4(args, dev, log):
 
 
 ALL_BINS = (0, 32, 128, 512, 2048, 8192, 16383, 24000, 1 << 30)          # strata of the all-node workload: sub-graph nodes in (lo, hi]
-ALL_TAKE = (2048, 2048, 2048, 1024, 512, 256, 48, 16)                     # sampled targets per stratum (>= 8 beyond 16 383 nodes)
+ALL_TAKE = (2048, 2048, 2048, 1024, 512, 256, 256, 256)                   # sampled targets per stratum: every batch fills the chip (one workgroup per CU in
+                                                                          # the strata beyond 512 nodes), 512 of them beyond 16 383 nodes
 
 
 def all_node_sample(sizes, seed=2026, take=ALL_TAKE, scale=1.0):

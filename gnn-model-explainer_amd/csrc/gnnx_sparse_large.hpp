@@ -36,6 +36,11 @@ constexpr int SPL_N_MAX = 16383;            // rows of a sub-graph (row ids are 
 constexpr int SPL_A_MAX = 8192;             // rows within two hops of the target
 constexpr int SPL_TDEG_MAX = SP_MAX_SPLIT * SPL_CHUNK;   // entries of one row in A (1024), also of row t
 constexpr int SPL_POOL_FLOATS = 39168;      // 153 KB of LDS
+// The XL form keeps nothing in LDS that scales with the entries (gnnx_sparse_large.hpp below): weights, staging tiles, layer-3 partials, the feature
+// dictionary and one byte per node - 96 KB hold sub-graphs of up to 62 000 nodes (the BA-House x100k maximum is 49 028; beyond, the feature rows
+// come from L2).  What matters is the 60 KB it LEAVES: the prepare kernels of the next batches (sub-graph CSRs, the engine walk of the seeded
+// masks: 8 KB of LDS per workgroup) run beside an XL workgroup instead of waiting milliseconds for a compute unit to drain ("room").
+constexpr int SPL_POOL_FLOATS_XL = 24576;
 constexpr int SPL_XD_MAX = 32;              // distinct feature rows kept as a dictionary in LDS (constant / one-hot / categorical features)
 constexpr int SPL_COUNTS = 6;               // k_count_edges_large: nnz, slots of 64 (A), slots of 16 (A), active entries, rows in A, slots of 64 (B)
 __host__ __device__ constexpr int spl_stage_floats(int D) { return 16 * TILE * (D | 1); }  // a [32][D|1] dZ1 tile per wave
@@ -277,7 +282,7 @@ __host__ __device__ inline XlLayout xl_layout(int n, int ld, int nnz) {
 // LDS of the XL form (floats): weights, head, staging tiles, layer-3 partials of t's neighbours, feature dictionary, one byte per node (oXi < 0:
 // the sub-graph has too many nodes for that - the feature rows then come from L2)
 struct XlLds { int oW, oWp, oStage, oG3, oXd, oXi, total; };
-__host__ __device__ inline XlLds xl_lds(int ld, int D, int H, int C) {
+__host__ __device__ inline XlLds xl_lds(int ld, int D, int H, int C, int pool_floats) {
     XlLds L;
     int o = 0;
     L.oW = o;      o += (D + 2 * H) * 33;
@@ -286,7 +291,7 @@ __host__ __device__ inline XlLds xl_lds(int ld, int D, int H, int C) {
     L.oG3 = o;     o += SPL_TDEG_MAX;
     L.oXd = o;     o += SPL_XD_MAX * (D | 1);
     const int xi = (ld + 3) / 4;
-    L.oXi = (o + xi <= SPL_POOL_FLOATS) ? o : -1;
+    L.oXi = (o + xi <= pool_floats) ? o : -1;
     if (L.oXi >= 0) o += xi;
     L.total = o;
     return L;
@@ -308,7 +313,9 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     constexpr int NT = SPL_THREADS, NW = NT / 64;
     using id_t = typename SplTypes<XL>::id_t;       // rows / columns of the sub-graph, indices into the list of rows within two hops
     constexpr int NOTA = SplTypes<XL>::NOTA;        // "not within two hops"
-    __shared__ float pool[SPL_POOL_FLOATS];
+    // (XL: the small pool for the reference's widths; the 32-wide instantiation's staging tiles alone are 66 KB)
+    constexpr int POOL = (XL && DQ != 16) ? SPL_POOL_FLOATS_XL : SPL_POOL_FLOATS;
+    __shared__ float pool[POOL];
     __shared__ SparseFixed sh;
     __shared__ int s_wn[NW], s_wf[NW], s_misc[4];
     const int t = targets[blockIdx.x];
@@ -400,7 +407,11 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         return;
     }
     const SparseLargeLayout L = XL ? SparseLargeLayout{} : sparse_large_layout(ld, nact, nA, padA, padB, D, H, C);
-    const XlLds XS = XL ? xl_lds(ld, D, H, C) : XlLds{};
+    const XlLds XS = XL ? xl_lds(ld, D, H, C, POOL) : XlLds{};
+    if (XL && XS.total > POOL) {      // uniform (cannot happen for D, H <= 2 DQ, 2 HQ)
+        fail_nan();
+        return;
+    }
     float* sW1 = pool + (XL ? XS.oW : L.oW);
     float* sW2 = sW1 + D * 33;
     float* sW3 = sW2 + H * 33;

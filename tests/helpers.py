@@ -109,25 +109,67 @@ BRANCH_JUMP_MAX = 5e-3   # largest distance between two outcomes of one non-chao
 # (tests/test_decision_parity.py: every decision of every epoch against the live reference's; calm graphs bounded by CONFIG4_WINDOW_JUMP);
 # the outcome comparisons (test_gpu_full_configs.py, bench.py --workload config4) require that EVERY miss has a window the CPU-only
 # analysis of make_golden_windows.py flags.  (The 70 % rule of rounds 2-4 is gone.)
-CONFIG4_EARLY_RULE = dict(min_frac=0.95, jump_max=6e-2)
 CONFIG4_WINDOW_JUMP = 6e-2
 
 
-def parity_verdict(err, ferr, well, min_frac=0.99, jump_max=None):
-    """The parity rule of the full-config tests and of bench.py.  On the targets the two CPU implementations agree on (`well`):
-      * at least `min_frac` of them lie within 1e-5 (mask AND feature mask) of an outcome the reference itself produces -
-        its output or an alternate outcome under a 1-ulp perturbation of the initial mask (helpers.branch_errors);
-      * the others - targets whose alternate branch the perturbation sampling has not hit - stay within the largest branch
-        jump observed on non-chaotic targets (BRANCH_JUMP_MAX): a wrong kernel is off by far more, on every target.
-    -> (ok, message)"""
-    e = np.maximum(err, ferr)[well]
-    inside = int((e <= PARITY_TOL).sum())
-    frac = inside / max(1, len(e))
-    worst = float(e.max()) if len(e) else 0.0
+# ---------------------------------------------------------------------------------------------------------------------------
+# Outcome rule of the full-config tests and of bench.py's in-run gate (round 6: NO percentage anywhere - VERDICT r5 "next" 4).
+# The gate proper is decision-based (tests/test_decision_parity.py: every decision of every epoch against the live reference's).  What an
+# OUTCOME comparison (300 / 50 epochs from the seeds against the reference's one output) may assert on top of it:
+#   * a CALM target - conditioning over the horizon <= 2e-6, measured on the CPU alone before any implementation ran (CPU-vs-CPU deviation of the
+#     fixture + the window probes: horizon_conditioning) - lies within 1e-5 of the reference's output, OR it is on the committed list
+#     tests/golden/<name>_ties.json: the calm targets the decision suite, run on the GPU at the commit that wrote the list
+#     (GNNX_WRITE_TIES=1 pytest tests/test_decision_parity.py -m gpu), found beyond 1e-5 - each with its reason: the first differing decision is
+#     a tie of the reference (epoch, margin), or every decision identical and the drift within the accumulated round-off bound - and then it must
+#     stay within the largest jump a flipped tie causes;
+#   * anything else FAILS: a new miss is a regression until the decision suite has explained it and the list is regenerated.
+# Targets that are not calm cannot be gated at a horizon by any implementation (two CPU implementations already differ on them); they are
+# reported, and covered window by window by the decision suite.
+# ---------------------------------------------------------------------------------------------------------------------------
+def ties_path(name):
+    return os.path.join(GOLDEN, name + "_ties.json")
+
+
+def load_ties(name):
+    """-> {"windows": {(id, w, sub): row}, "full": {id: row}, "early": {id: row}} or None when the list has not been generated"""
+    import json
+    p = ties_path(name)
+    if not os.path.exists(p):
+        return None
+    z = json.load(open(p))
+    return {"windows": {(int(r["id"]), int(r["w"]), int(r["sub"])): r for r in z.get("windows", [])},
+            "full": {int(r["id"]): r for r in z.get("full", [])},
+            "early": {int(r["id"]) for r in z.get("windows", []) if int(r["w"]) == 0}}
+
+
+def horizon_conditioning(name, cond_mask, cond_feat, early=False):
+    """One number per target, CPU-only: the largest of the CPU-vs-CPU deviation at the horizon (fixture) and the conditioning probes of the windows the
+    horizon spans (all six; the first one for the 50-epoch horizon)."""
+    W = Windows(name)
+    with np.load(os.path.join(GOLDEN, name + "_noise.npz")) as f:
+        Nz = {k: f[k] for k in f.files}
+    win = np.maximum(np.maximum(np.maximum(W.z["cond50"], W.z["sens50"]), Nz["noise50"]), Nz["ssens50"])
+    win = win[:, 0] if early else win.max(1)
+    return np.maximum(np.maximum(cond_mask, cond_feat), win)
+
+
+def explained_outcome(name, horizon, ids, err, ferr, calm, jump_max=None):
+    """The outcome rule above.  err / ferr: per target distance to the reference's ONE output (masked adjacency, sigmoid(feat_mask)); calm: the
+    CPU-only classification.  -> (ok, message, unexplained ids)"""
     jump_max = BRANCH_JUMP_MAX if jump_max is None else jump_max
-    ok = frac >= min_frac and worst <= jump_max
-    return ok, (f"{inside} / {len(e)} non-chaotic targets within 1e-5 of an outcome of the reference ({100 * frac:.1f} %, need "
-                f"{100 * min_frac:.0f} %), worst {worst:.2e} (limit {jump_max:.0e})")
+    ties = load_ties(name)
+    listed = set() if ties is None else (set(ties["full"]) if horizon == "full" else ties["early"])
+    e = np.maximum(err, ferr)
+    miss = [k for k in np.nonzero(calm & (e > PARITY_TOL))[0]]
+    unexplained = [int(ids[k]) for k in miss if int(ids[k]) not in listed]
+    too_far = [int(ids[k]) for k in miss if e[k] > jump_max]
+    inside = int((calm & (e <= PARITY_TOL)).sum())
+    msg = (f"{inside} / {int(calm.sum())} calm targets within 1e-5 of the reference's output; beyond: {len(miss)} "
+           f"({len(miss) - len(unexplained)} on the decision suite's committed list {os.path.basename(ties_path(name))}"
+           f"{'' if ties is not None else ' - NOT GENERATED'}, unexplained: {unexplained}), worst {float(e[calm].max()) if calm.any() else 0.0:.2e} "
+           f"(jump limit {jump_max:.0e}, beyond it: {too_far}); not calm (reported): {int((~calm).sum())} targets, "
+           f"{int(((~calm) & (e <= PARITY_TOL)).sum())} of them within 1e-5 anyway, worst {float(e[~calm].max()) if (~calm).any() else 0.0:.2e}")
+    return (not unexplained and not too_far), msg, unexplained
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
