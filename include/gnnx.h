@@ -386,7 +386,7 @@ int gnnx_xl_build(gnnx_xl_handle h, const int64_t* indptr, const int32_t* indice
                   void* ws_rows, void* ws_entries, size_t ws_entries_bytes, int32_t* rc, void* stream);
 /* gnnx_mt_edge_words for XL targets WITHOUT the n^2 scratch: seeds [T] (DEVICE int64) -> words [E][4] (DEVICE uint32) = the two raw mt19937 words of the
  * Box-Muller pair of M[r][c], then of M[c][r], for every edge - one pass of each target's engine over its n^2 (+ 16) draws, the entries picked as
- * their stream positions pass (k_mt_edge_words_xl).  The host finishes with gnnx_host_transform_edge_words (include/gnnx_host.h): bit-identical to
+ * their stream positions pass (k_mt_edge_words_xl).  The host finishes with the transform of include/gnnx_host.h - gnnx_host_transform_edge_words -: bit-identical to
  * torch.manual_seed(seed); torch.FloatTensor(n, n).normal_(1.0, std) on the edges (construct_edge_mask, explain.py:645-652). */
 int gnnx_xl_mt_edge_words(gnnx_xl_handle h, const int64_t* seeds, void* ws_rows, void* ws_entries, uint32_t* words, void* stream);
 int gnnx_xl_set_trace(gnnx_xl_handle h, uint32_t* gates);

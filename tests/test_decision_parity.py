@@ -31,8 +31,14 @@ which one of them changes sides the optimiser state is a smooth function of its 
 
 Windows are the 50-epoch windows of tests/golden/<name>_windows.npz (the live reference's Adam state, teacher forcing through
 gnnx_run_resume); a window of kind (b) is re-run as its five 10-epoch sub-windows where the fixture holds the 10-epoch snapshots, so
-that only the 10 epochs around the tie stay ungated.  The share of (target, epoch) pairs inside windows of kind (a) is printed and
-asserted (>= 90 %).  GPU: every target of syn1 / syn4 / syn5 and the 512 config-4 graphs; emulator: a few targets per config.
+that only the 10 epochs around the tie stay ungated.  GPU: every target of syn1 / syn4 / syn5 and the 512 config-4 graphs; emulator: a few
+targets per config.
+
+Round 6: no percentage anywhere.  The windows of kind (b) / (c) - everything this suite does NOT gate at plain 1e-5 - are a COMMITTED list
+(tests/golden/<name>_ties.json: id, window, sub-window, kind, epoch, the reference's margin, the error, the conditioning), written by this suite on the
+GPU with GNNX_WRITE_TIES=1 and checked on every later run: a window of kind (b) / (c) that is not on the list fails (the regression floor the
+90 % share of rounds 4-5 stood for), and the outcome tests (tests/test_gpu_full_configs.py, bench.py's in-run gate) accept a calm target beyond
+1e-5 only when the full-horizon part of the list explains it (helpers.explained_outcome).
 """
 import os
 
@@ -46,7 +52,6 @@ from test_emu_kernels import _Backend
 from test_windowed_parity import _node_subgraph_job
 
 TOL = helpers.WIN_TOL
-MIN_GATED_SHARE = 0.90
 ROUNDOFF_BUDGET = 4.0      # factor over the window's CPU-measured conditioning c an implementation may differ by (see (c) above; 50 in round 4)
 
 
@@ -96,8 +101,46 @@ def _decision_windows(W, Dn, make_job, ks_all, coarse_windows=None):
     return rows
 
 
-def _verdict(what, rows, Dn, jump, min_share=MIN_GATED_SHARE):
-    """rows of _decision_windows -> summary string; asserts the rules of the module docstring."""
+_TIES = {}      # name -> {"windows": [...], "full": [...]} collected by this session's GPU runs (written by _write_ties when GNNX_WRITE_TIES=1)
+
+
+def _tie_row(r, **extra):
+    d = r.get("what", [None])[0]
+    out = dict(id=int(r["id"]), kind="tie" if not r["agree"] else "drift", epoch=int(r.get("epoch", -1)),
+               margin=(None if not np.isfinite(r.get("margin", 0.0)) else float(r.get("margin", 0.0))), err=float(r["err"]),
+               c=float(r.get("smooth", r.get("cond", 0.0))), decision=(None if d is None else [x if not isinstance(x, (np.integer, np.floating)) else x.item() for x in d]))
+    out.update(extra)
+    return out
+
+
+def _write_ties(name):
+    import json
+    if os.environ.get("GNNX_WRITE_TIES") != "1" or name not in _TIES:
+        return
+    path = helpers.ties_path(name)
+    old = json.load(open(path)) if os.path.exists(path) else {}
+    old.update(_TIES[name])
+    old["generated_by"] = "GNNX_WRITE_TIES=1 python -m pytest tests/test_decision_parity.py -m gpu (MI355X, libgnnx_hip.so of this commit)"
+    json.dump(old, open(path, "w"), indent=0, sort_keys=True)
+
+
+def _check_listed(name, part, keys_rows, key_of):
+    """Every row this run could not gate at plain 1e-5 must be on the committed list (unless the list is being written)."""
+    if name is None:
+        return
+    _TIES.setdefault(name, {})[part] = [r for _, r in keys_rows]
+    if os.environ.get("GNNX_WRITE_TIES") == "1":
+        _write_ties(name)
+        return
+    ties = helpers.load_ties(name)
+    assert ties is not None, f"{helpers.ties_path(name)} missing: generate it with GNNX_WRITE_TIES=1 on the GPU"
+    new = [k for k, _ in keys_rows if key_of(k) not in ties[part]]
+    assert not new, f"{name}: {len(new)} {part} rows beyond plain 1e-5 that the committed list does not hold (a regression until explained): {new[:10]}"
+
+
+def _verdict(what, rows, Dn, jump, list_name=None):
+    """rows of _decision_windows -> summary string; asserts the rules of the module docstring.  list_name: the fixture name whose committed list
+    (tests/golden/<name>_ties.json, part "windows") every row not gated at plain 1e-5 must be on (GPU runs over ALL targets; None: a partial run)."""
     bound = lambda r: max(TOL, ROUNDOFF_BUDGET * r["smooth"])
     agreed = [r for r in rows if r["agree"]]
     ties = [r for r in rows if not r["agree"]]
@@ -133,7 +176,7 @@ def _verdict(what, rows, Dn, jump, min_share=MIN_GATED_SHARE):
     assert not bad_agreed, msg + f"; {[(r['id'], r['w'], r['sub'], r['err'], r['smooth']) for r in bad_agreed[:10]]}"
     assert not unjust, msg + f"; first: {unjust[0]}"
     assert all(r["err"] <= jump for r in ties), msg
-    assert gated >= min_share * total, msg
+    _check_listed(list_name, "windows", [((r["id"], r["w"], r["sub"]), _tie_row(r, w=int(r["w"]), sub=int(r["sub"]))) for r in over + ties], lambda k: k)
     return msg
 
 
@@ -151,7 +194,7 @@ def test_decision_windows_on_the_emulator_few_targets(name, picks):
         ks[-1] = fl[0]
     ks = np.asarray(sorted(set(int(k) for k in ks)), np.int64)
     rows = _decision_windows(W, Dn, _node_subgraph_job(be, name, W, full), ks)
-    _verdict(f"{name} (emulator, targets {[int(W.ids[k]) for k in ks]})", rows, Dn, helpers.BRANCH_JUMP_MAX, min_share=0.0)
+    _verdict(f"{name} (emulator, targets {[int(W.ids[k]) for k in ks]})", rows, Dn, helpers.BRANCH_JUMP_MAX)
 
 
 def _config4_job_maker(W, be=None):
@@ -172,7 +215,7 @@ def test_decision_windows_graph_mode_on_the_emulator():
     assert np.array_equal(W.ids, Dn.ids)
     ks = np.asarray([0, int(np.nonzero(W.flagged.any(1))[0][0])], np.int64)
     rows = _decision_windows(W, Dn, _config4_job_maker(W, _Backend("emu")), ks, coarse_windows=(0, 3))
-    _verdict("config4 (emulator)", rows, Dn, helpers.CONFIG4_WINDOW_JUMP, min_share=0.0)
+    _verdict("config4 (emulator)", rows, Dn, helpers.CONFIG4_WINDOW_JUMP)
 
 
 @pytest.mark.gpu
@@ -193,7 +236,7 @@ def test_decision_windows_every_target_every_window_gpu(name):
         job = MaskOptimJob.from_csr(graph, nbs, full["node_idx_new"][ks], ck["label"][targets], ck["sd"])
         job.set_masks_raw(engine.init_edge_masks_raw([len(nb) for nb in nbs], seeds=1000 + targets))
         return job
-    _verdict(name, _decision_windows(W, Dn, make, np.arange(W.T)), Dn, helpers.BRANCH_JUMP_MAX)
+    _verdict(name, _decision_windows(W, Dn, make, np.arange(W.T)), Dn, helpers.BRANCH_JUMP_MAX, list_name=name)
 
 
 @pytest.mark.gpu
@@ -202,11 +245,11 @@ def test_decision_windows_config4_512_graphs_gpu():
     the three max-pools pick (molecule-like graphs are full of symmetric atoms whose activations tie)."""
     W, Dn = helpers.Windows("config4"), helpers.Decisions("config4")
     assert np.array_equal(W.ids, Dn.ids)
-    _verdict("config4", _decision_windows(W, Dn, _config4_job_maker(W), np.arange(W.T)), Dn, helpers.CONFIG4_WINDOW_JUMP)
+    _verdict("config4", _decision_windows(W, Dn, _config4_job_maker(W), np.arange(W.T)), Dn, helpers.CONFIG4_WINDOW_JUMP, list_name="config4")
 
 
 # ------------------------------------------------------------------ the full horizon: 300 epochs from the seeded masks ------------------------------------------------------------------
-def _full_horizon_verdict(what, Dn, ids, err, gates, pool, cond, jump=None):
+def _full_horizon_verdict(what, Dn, ids, err, gates, pool, cond, jump=None, list_name=None):
     """300 epochs from the seeded masks, no teacher forcing.  cond[k] = the target's conditioning over the WHOLE horizon, measured on the CPU
     alone: the largest of the CPU-vs-CPU deviation after 300 epochs (cond_mask / cond_feat of the fixture) and the three window probes of
     its six windows.  On the calm targets (cond <= 2e-6: nothing amplifies round-off beyond the tolerance anywhere along the trajectory) the
@@ -263,15 +306,13 @@ def _full_horizon_verdict(what, Dn, ids, err, gates, pool, cond, jump=None):
     assert not unjust, msg + f"; first: {unjust[0]}"
     if jump is not None:
         assert all(r["err"] <= jump for r in calm), msg
+    # the calm targets beyond 1e-5 - each explained above - are the "full" part of the committed list the outcome tests consult
+    _check_listed(list_name, "full", [(r["id"], _tie_row(r)) for r in over + [t for t in ties if t["err"] > TOL]], lambda k: k)
     return msg
 
 
 def _horizon_conditioning(name, z_cond_mask, z_cond_feat):
-    W = helpers.Windows(name)
-    with np.load(os.path.join(helpers.GOLDEN, name + "_noise.npz")) as f:
-        Nz = {k: f[k] for k in f.files}
-    win = np.maximum(np.maximum(np.maximum(W.z["cond50"], W.z["sens50"]), Nz["noise50"]), Nz["ssens50"]).max(1)
-    return np.maximum(np.maximum(z_cond_mask, z_cond_feat), win)
+    return helpers.horizon_conditioning(name, z_cond_mask, z_cond_feat)
 
 
 @pytest.mark.gpu
@@ -294,7 +335,7 @@ def test_full_horizon_decisions_node_configs_gpu(name):
     assert np.array_equal(em.eoff, z["eoff"])
     err, ferr, _ = helpers.branch_errors(z, None, em.eoff, em.masked_adj, helpers._sig64(em.feat_mask))
     _full_horizon_verdict(name, Dn, targets, np.maximum(err, ferr), gates, pool, _horizon_conditioning(name, z["cond_mask"], z["cond_feat"]),
-                          helpers.BRANCH_JUMP_MAX)
+                          helpers.BRANCH_JUMP_MAX, list_name=name)
 
 
 @pytest.mark.gpu
@@ -315,7 +356,7 @@ def test_full_horizon_decisions_config4_gpu():
     # (jump: the largest move of a graph under a 1-ulp perturbation of its initial mask over the full horizon, measured on the CPU alone by
     #  make_golden_branches.py before any implementation ran - a calm graph that leaves at a pool tie must stay inside it)
     _full_horizon_verdict("config4", Dn, W.ids, np.maximum(err, ferr), gates, pool, _horizon_conditioning("config4", z["cond_mask"], z["cond_feat"]),
-                          helpers.CONFIG4_WINDOW_JUMP)
+                          helpers.CONFIG4_WINDOW_JUMP, list_name="config4")
 
 
 # ------------------------------------------------------------------ BASELINE config 5: BA-House x100k against the reference's own state ------------------------------------------------------------------

@@ -83,16 +83,13 @@ def test_resumed_segments_equal_straight_run_graph_mode(be, analyze):
 
 
 # ------------------------------------------------------------------ windows vs the reference's own state ------------------------------------------------------------------
-MIN_STRICT = 0.995         # share of the windows the CPU probes call well conditioned that must lie within 1e-5 (the rest: listed, and bounded)
-
-
-def _verdict(what, rows, bound=SUB_FLAG_BOUND):
+def _verdict(what, rows, bound=SUB_FLAG_BOUND, list_name=None):
     """rows: (key, window, sub or -1, err, conditioning) of every tested (target, window[, sub-window]).
-    Windows the CPU probes call well conditioned (conditioning <= 2e-6: helpers.Windows) must lie within 1e-5 of the reference's state -
-    all but at most 0.5 % of them, which are listed with their measured conditioning and must stay within SUB_FLAG_BOUND (the probes
-    sample the sensitivity of a window with four perturbed runs; the GPU's round-off is a fifth sample, and Adam turns 1e-6 into 1e-5
-    within 50 epochs on a few Tree-Grid windows whose measured sensitivity sits just below the flag).  Sub-windows the probes flag are
-    reported and bounded.  -> summary string (asserts on failure)."""
+    Windows the CPU probes call well conditioned (conditioning <= 2e-6: helpers.Windows) must lie within 1e-5 of the reference's state; one that does
+    not passes only if the DECISION suite has explained that very window (tests/golden/<list_name>_ties.json, part "windows": the engine's first
+    differing decision there is a tie of the reference, or every decision is identical and the drift is within 4 x the window's conditioning - round 6:
+    the 99.5 % share of rounds 3-5 is gone) and it stays within SUB_FLAG_BOUND.  Sub-windows the probes flag are reported and bounded.
+    -> summary string (asserts on failure)."""
     rows = np.asarray(rows, np.float64).reshape(-1, 5)
     agreed = rows[:, 4] <= helpers.WIN_FLAG
     n_ok = int((agreed & (rows[:, 3] <= TOL)).sum())
@@ -110,13 +107,19 @@ def _verdict(what, rows, bound=SUB_FLAG_BOUND):
     if dump:       # measurement aid: every (id, window, sub-window, error, conditioning) row of this config
         os.makedirs(dump, exist_ok=True)
         np.save(os.path.join(dump, what.split(" ")[0] + "_windows_rows.npy"), rows)
-    assert n_ok >= MIN_STRICT * int(agreed.sum()), msg
+    if len(bad):
+        ties = helpers.load_ties(list_name) if list_name else None
+        assert list_name is None or ties is not None or os.environ.get("GNNX_WRITE_TIES") == "1", f"{helpers.ties_path(list_name)} missing"
+        listed = set() if ties is None else {(i, w) for (i, w, _) in ties["windows"]}
+        unexplained = [(int(r[0]), int(r[1]), int(r[2]), float(r[3])) for r in bad if (int(r[0]), int(r[1])) not in listed]
+        # (a partial run - the emulator's handful of targets - has no list: every well-conditioned window must then be inside)
+        assert not unexplained or os.environ.get("GNNX_WRITE_TIES") == "1", msg + f"; well-conditioned windows beyond 1e-5 that the decision suite's list does not explain: {unexplained[:10]}"
     assert not len(bad) or bad[:, 3].max() <= bound, msg
     assert not len(loose) or loose[:, 3].max() <= bound, msg
     return msg
 
 
-def _windows_of_job(W, make_job, ks_all, what, coarse_windows=None, bound=SUB_FLAG_BOUND):
+def _windows_of_job(W, make_job, ks_all, what, coarse_windows=None, bound=SUB_FLAG_BOUND, list_name=None):
     """All 50-epoch windows of the targets ks_all (fixture indices) + the 10-epoch sub-windows of their flagged windows.
     make_job(ks) -> a MaskOptimJob over those targets with the seeded initial masks in M."""
     rows = []
@@ -138,7 +141,7 @@ def _windows_of_job(W, make_job, ks_all, what, coarse_windows=None, bound=SUB_FL
             mask_rc, feat = helpers.run_window(sub_job, W.sub_state(w, s, ks), W.sub)
             em, ef = helpers.window_errors(sub_eoff, mask_rc, feat, W.sub_state(w, s + 1, ks))
             rows += [(W.ids[k], w, s, max(em[i], ef[i]), c10[i, s]) for i, k in enumerate(ks)]
-    return _verdict(what, rows, bound)
+    return _verdict(what, rows, bound, list_name)
 
 
 def _node_subgraph_job(be, name, W, full):
@@ -212,7 +215,7 @@ def test_windows_every_target_every_window_gpu(name):
         job.set_masks_raw(engine.init_edge_masks_raw([len(nb) for nb in nbs], seeds=1000 + targets))
         assert np.array_equal(np.diff(job.fetch_edges().eoff), np.diff(W.eoff)[ks])
         return job
-    _windows_of_job(W, make, np.arange(W.T), name)
+    _windows_of_job(W, make, np.arange(W.T), name, list_name=name)
 
 
 @pytest.mark.gpu
@@ -229,7 +232,7 @@ def test_windows_config4_512_graphs_gpu():
         job.set_masks([s.mask0 for s in subs])
         return job
     # graph mode: a max-pool tie that flips moves the mask by up to 6e-2 (helpers.CONFIG4_WINDOW_JUMP, measured on the CPU in round 2)
-    _windows_of_job(W, make, np.arange(W.T), "config4", bound=helpers.CONFIG4_WINDOW_JUMP)
+    _windows_of_job(W, make, np.arange(W.T), "config4", bound=helpers.CONFIG4_WINDOW_JUMP, list_name="config4")
 
 
 # ------------------------------------------------------------------ k_sparse_large window by window against the dense streaming kernels ------------------------------------------------------------------
@@ -288,4 +291,4 @@ def test_windows_sparse_large_against_the_streaming_kernels_gpu(which):
     worst = rows[int(np.argmax(err[:, 0]))]
     print(f"k_sparse_large vs streaming, sizes {sorted(int(n) for n in dn.sizes)}: {int(ok.sum())} / {len(rows)} windows within 1e-5 "
           f"(masked_adj worst {err[:, 0].max():.2e} at target {worst[0]} window {worst[1]}, mask parameter worst {err[:, 1].max():.2e}, feat {err[:, 2].max():.2e})")
-    assert ok.mean() >= 0.97 and err[:, 0].max() <= SUB_FLAG_BOUND, [r for r, o in zip(rows, ok) if not o]
+    assert ok.all() and err[:, 0].max() <= SUB_FLAG_BOUND, [r for r, o in zip(rows, ok) if not o]      # (measured: every window, since round 4)
