@@ -30,12 +30,15 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ..engine import (FEAT_STRIDE, Hyper, MaskOptimJob, Subgraph, device_graph, init_edge_mask, init_edge_masks_raw,
+from ..engine import (FEAT_STRIDE, Hyper, MaskOptimJob, Subgraph, XLJob, device_graph, init_edge_mask, init_edge_masks_raw,
                       khop_device)
 from ..utils import io_utils
 from ..utils.graph_utils import KHopIndex
 
 COEFFS = {"size": 0.005, "feat_size": 1.0, "ent": 1.0, "feat_ent": 0.1, "grad": 0, "lap": 1.0}  # explain.py:624-631
+# sub-graphs of more nodes than this take the XL route in Explainer.explain_batch (engine.XLJob; GNNX_XL_MIN_N overrides).  The default keeps every
+# reference-sized dataset on the LDS-resident classes and sends what they cannot hold to the CSR-native kernel instead of dense n x n blocks.
+XL_MIN_N = int(os.environ.get("GNNX_XL_MIN_N", "512"))
 
 
 def _check_supported(args):
@@ -329,19 +332,91 @@ class Explainer:
         for v, n in zip(targets, dn.sizes):
             if n == 0:
                 raise IndexError("node %d has an empty %d-hop neighbourhood" % (v, self.n_hops))
-        raw = init_edge_masks_raw(dn.sizes)                              # global generator, target order
         labels = _np(self.label)[graph_idx][targets]                    # explain.py:751
-        raw_off = np.zeros(len(targets) + 1, np.int64)
-        np.cumsum(dn.sizes.astype(np.int64) ** 2, out=raw_off[1:])
         hy = _hyper(self.args, record_loss=record_loss, use_graph=use_graph and len(targets) > 1)
+        # Round 6: targets of more than XL_MIN_N sub-graph nodes take the XL route (engine.XLJob: sub-graph CSRs from the resident graph, masks and
+        # results as edge lists - no dense n x n block on the device; beyond 16 383 nodes the dense routes would stream 28 n^2 bytes per iteration).
+        # Plain configurations only; everything else stays on the dense-packed job.
+        xl_sel = np.zeros(len(targets), bool)
+        if (graph.binary and not (relu or bn or record_loss or unconstrained) and getattr(self.args, "method", "base") == "base" and
+                int(np.asarray(_np(self.pred)).shape[-1]) <= 8):
+            xl_sel = dn.sizes > XL_MIN_N
+        # The initial masks: ONE normal_ draw of n x n values per target from the caller's global generator, in target order, like
+        # construct_edge_mask (explain.py:645-652).  The dense-packed targets' draws land in one buffer; an XL target's draw is a temporary of which only
+        # the values on its edges are kept (its n^2 values still pass through the generator: the stream every later target sees is the reference's).
+        xl_pos = np.nonzero(xl_sel)[0]
+        xl_all = XLJob(graph, dn.subset(xl_pos), None, labels[xl_pos], sd, lib=lib) if len(xl_pos) else None
+        xl_vals = None
+        if xl_all is not None:
+            xl_eoff, xl_rc = xl_all.edge_ids()
+            xl_rc = xl_rc.cpu().numpy()
+            xl_vals = np.zeros((int(xl_eoff[-1]), 2), np.float32)
+        dense_sizes = np.where(xl_sel, 0, dn.sizes).astype(np.int64)
+        raw_off = np.zeros(len(targets) + 1, np.int64)
+        np.cumsum(dense_sizes ** 2, out=raw_off[1:])
+        raw = torch.empty(int(raw_off[-1]), dtype=torch.float32)
+        import math
+        xk = 0
+        for k, n_k in enumerate(dn.sizes):
+            std = math.sqrt(2.0) * math.sqrt(2.0 / (int(n_k) + int(n_k)))
+            if xl_sel[k]:
+                m0 = torch.empty(int(n_k), int(n_k)).normal_(1.0, std).numpy()
+                e = xl_rc[int(xl_eoff[xk]):int(xl_eoff[xk + 1])]
+                xl_vals[int(xl_eoff[xk]):int(xl_eoff[xk + 1]), 0] = m0[e[:, 0], e[:, 1]]
+                xl_vals[int(xl_eoff[xk]):int(xl_eoff[xk + 1]), 1] = m0[e[:, 1], e[:, 0]]
+                del m0
+                xk += 1
+            else:
+                raw[raw_off[k]:raw_off[k + 1]].normal_(1.0, std)
         last = {}
+
+        def compute_xl(idxs):
+            """The XL targets among idxs (positions in `targets`) -> {position: float64 masked adjacency}"""
+            pos = [i for i in idxs if xl_sel[i]]
+            if not pos:
+                return {}
+            where = {int(p_): j for j, p_ in enumerate(xl_pos)}
+            if len(pos) == len(xl_pos):
+                xj, sel = xl_all, np.arange(len(xl_pos))
+            else:
+                sel = np.asarray([where[int(i)] for i in pos], np.int64)
+                xj = XLJob(graph, dn.subset(np.asarray(pos, np.int64)), None, labels[pos], sd, lib=lib)
+            vals = np.concatenate([xl_vals[int(xl_eoff[j]):int(xl_eoff[j + 1])] for j in sel]) if len(sel) else np.zeros((0, 2), np.float32)
+            xj.set_masks_on_edges(torch.from_numpy(np.ascontiguousarray(vals)))
+            xj.launch(hy)
+            em = xj.fetch_edges()
+            last.setdefault("xl_feat", {}).update({int(p_): em.feat_mask[j] for j, p_ in enumerate(pos)})
+            return {int(p_): em.dense(j) for j, p_ in enumerate(pos)}
 
         def compute(idxs):
             """This rank's shard (all targets on one GPU): -> one float64 masked adjacency per target."""
+            xl_out = compute_xl(idxs)
+            all_idxs = list(idxs)
+            idxs = [i for i in all_idxs if not xl_sel[i]]
+            if not idxs:
+                last.update(feat_mask=np.stack([last["xl_feat"][int(i)] for i in all_idxs]), loss=None, edges=None, rows=dn.rows[all_idxs])
+                return [xl_out[int(i)] for i in all_idxs]
+            if xl_out:
+                dense_out = compute_dense(idxs)
+                merged, it = [], iter(dense_out)
+                fm_dense = iter(last["feat_mask"])
+                fms = []
+                for i in all_idxs:
+                    if xl_sel[i]:
+                        merged.append(xl_out[int(i)])
+                        fms.append(last["xl_feat"][int(i)])
+                    else:
+                        merged.append(next(it))
+                        fms.append(next(fm_dense))
+                last.update(feat_mask=np.stack(fms), edges=None, rows=dn.rows[all_idxs], denoised=None, auc=None)
+                return merged
+            return compute_dense(idxs)
+
+        def compute_dense(idxs):
             if len(idxs) == len(targets):
                 sub_dn, sub_raw = dn, raw
             else:
-                sub_dn = khop_device(graph, targets[idxs], self.n_hops, lib=lib)
+                sub_dn = dn.subset(np.asarray(idxs, np.int64))
                 sub_raw = torch.cat([raw[raw_off[i]:raw_off[i + 1]] for i in idxs])
             job = MaskOptimJob.from_csr(graph, sub_dn, None, labels[idxs], sd, lib=lib, mask_relu=relu, bn=bn, analyze=not unconstrained)
             true_adj = None

@@ -344,3 +344,42 @@ def test_print_training_prints_the_references_fields_on_the_emulator(tmp_path, e
 def test_print_training_prints_the_references_fields_on_gpu(tmp_path, capsys):
     _, _, ex = _explainer(tmp_path, 40)
     _check_print_training(ex, capsys, (302, 309, 300))
+
+
+def _xl_through_the_api(tmp_path, monkeypatch, epochs, check_golden):
+    """Explainer.explain / explain_nodes with the larger targets on the XL route (engine.XLJob: CSR-native, edge-list state; explain.XL_MIN_N lowered so
+    that syn1's sub-graphs take it): the SAME generator stream as the all-dense path (an XL target's n x n draw passes through the caller's global
+    generator like the reference's construct_edge_mask), results within round-off of the dense-packed routes, and of the reference's golden output."""
+    gx = helpers.load_explain("syn1")
+    ck, args, ex = _explainer(tmp_path, epochs)
+    nodes = [309, 302, 330]                       # n = 64 (stays dense-packed at XL_MIN_N = 100), 168 and 129 (XL)
+    monkeypatch.setattr(explain, "XL_MIN_N", 1 << 30)
+    torch.manual_seed(11)
+    dense = ex.explain_nodes(nodes, args)
+    after_dense = torch.rand(1).item()
+    monkeypatch.setattr(explain, "XL_MIN_N", 100)
+    torch.manual_seed(11)
+    mixed = ex.explain_nodes(nodes, args)
+    assert torch.rand(1).item() == after_dense                      # the generator has advanced exactly as on the dense path
+    for v, a, b in zip(nodes, dense, mixed):
+        assert a.shape == b.shape and b.dtype == np.float64 and np.array_equal(b, b.T)
+        assert np.array_equal(a != 0, b != 0)
+        assert np.abs(a - b).max() < 2e-5, (v, np.abs(a - b).max())
+    assert np.array_equal(mixed[0], dense[0])                       # the dense-packed target of the mixed batch: the same kernel, the same draw
+    if check_golden:
+        for t in (302,):
+            torch.manual_seed(1000 + t)
+            ma = ex.explain(t)
+            rc = gx[f"{t}:edge_rc"]
+            assert np.abs(ma[rc[:, 0], rc[:, 1]] - gx[f"{t}:masked_adj_edges"]).max() <= TOL
+            fm = 1 / (1 + np.exp(-ex.last_result.feat_mask[0]))
+            assert np.abs(fm - gx[f"{t}:feat_mask_sigmoid"]).max() <= TOL
+
+
+def test_xl_route_through_the_api_emulated(tmp_path, emu_engine, monkeypatch):
+    _xl_through_the_api(tmp_path, monkeypatch, 5, False)
+
+
+@pytest.mark.gpu
+def test_xl_route_through_the_api_on_gpu(tmp_path, monkeypatch):
+    _xl_through_the_api(tmp_path, monkeypatch, 300, True)
