@@ -2039,6 +2039,7 @@ struct gnnx_xl_s {
     int adam_first = -1;
     uint32_t* trace_gates = nullptr;
     long long* clk = nullptr;         // gnnx_xl_set_clocks: [T][4] device ticks of every target's workgroup (measurement hook)
+    void* mt_block = nullptr;         // gnnx_xl_mt_edge_words: segment tables + segment start states (pooled)
     // carve-out of the caller's two workspaces (bytes)
     size_t r_X, r_yhat, r_deg, r_updeg, r_rowptr, r_uprow, r_totals, rows_bytes = 0;
     size_t e_col, e_row, e_w, e_scr, entries_bytes = 0;
@@ -2139,6 +2140,7 @@ extern "C" int gnnx_xl_destroy(gnnx_xl_handle h) {
     if (!h) return 0;
     if (h->block1) (void)pool_free(h->block1);
     if (h->block2) (void)pool_free(h->block2);
+    if (h->mt_block) (void)pool_free(h->mt_block);
     if (h->d_adam && !h->adam_shared) (void)pool_free(h->d_adam);
     delete h;
     return 0;
@@ -2354,13 +2356,83 @@ extern "C" int gnnx_xl_run(gnnx_xl_handle h, const gnnx_hyper* hy, const gnnx_xl
     return 0;
 }
 
+// the jump polynomial of the segmented engine walk (utils/mt_jump.py): process-wide, one device copy per device; jump = 0: serial walks
+namespace {
+struct MtJump { std::vector<uint32_t> poly; long long jump = 0; uint32_t* d_poly[MAX_DEVICES] = {}; };
+MtJump g_mtj;
+std::mutex g_mtj_mu;
+}  // namespace
+extern "C" int gnnx_set_mt_jump_poly(const uint32_t* poly, int64_t jump_draws) {
+    std::lock_guard<std::mutex> lk(g_mtj_mu);
+    if (!poly || jump_draws <= 0) {
+        g_mtj.jump = 0;
+        return 0;
+    }
+    if (jump_draws % MT_N) return fail("gnnx_set_mt_jump_poly: the stride must be a whole number of 624-draw blocks");
+    g_mtj.poly.assign(poly, poly + MT_N);
+    g_mtj.jump = jump_draws;
+    for (auto& d : g_mtj.d_poly) d = nullptr;      // (device copies of an older polynomial are dropped: a few KB, once per process)
+    return 0;
+}
+
 extern "C" int gnnx_xl_mt_edge_words(gnnx_xl_handle h, const int64_t* seeds, void* ws_rows, void* ws_entries, uint32_t* words, void* stream) {
     if (!h || !seeds || !ws_rows || !ws_entries || !words) return fail("null argument");
     if (!h->built) return fail("gnnx_xl_mt_edge_words: call gnnx_xl_count and gnnx_xl_build first");
+    hipStream_t s = static_cast<hipStream_t>(stream);
     char* w = static_cast<char*>(ws_rows);
     char* e = static_cast<char*>(ws_entries);
-    hipLaunchKernelGGL(k_mt_edge_words_xl, dim3(h->prob.num_targets), dim3(MTX_THREADS), 0, static_cast<hipStream_t>(stream), h->d_meta, seeds, h->d_csr_off,
-                       reinterpret_cast<const int32_t*>(w + h->r_rowptr), reinterpret_cast<const int32_t*>(w + h->r_uprow),
+    const int T = h->prob.num_targets;
+    long long jump = 0;
+    const uint32_t* d_poly = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mtj_mu);
+        jump = g_mtj.jump;
+        if (jump > 0) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (dev < 0 || dev >= MAX_DEVICES) dev = 0;
+            if (!g_mtj.d_poly[dev]) {
+                uint32_t* d = nullptr;
+                HIPCK(hipMalloc(&d, sizeof(uint32_t) * MT_N));
+                HIPCK(upload_sync(d, g_mtj.poly.data(), sizeof(uint32_t) * MT_N));
+                g_mtj.d_poly[dev] = d;
+            }
+            d_poly = g_mtj.d_poly[dev];
+        }
+    }
+    // segments of every target (host: from the sizes alone), their start states in a pooled scratch block
+    std::vector<long long> seg_off((size_t)T + 1, 0);
+    std::vector<MtSeg> segs;
+    for (int t = 0; t < T; ++t) {
+        const int K = mt_segments(h->meta[t].n, jump);
+        seg_off[t + 1] = seg_off[t] + K;
+    }
+    segs.reserve((size_t)seg_off[T]);
+    // longest segments first are all alike (`jump` draws); the LAST segment of a target is the long one (up to 2 jump): launch those first
+    for (int t = 0; t < T; ++t)
+        if (seg_off[t + 1] > seg_off[t]) segs.push_back({t, (int32_t)(seg_off[t + 1] - seg_off[t] - 1)});
+    for (int t = 0; t < T; ++t)
+        for (int k = 0; k + 1 < seg_off[t + 1] - seg_off[t]; ++k) segs.push_back({t, k});
+    if (segs.empty()) return 0;
+    if (h->mt_block) {
+        HIPCK(hipStreamSynchronize(s));      // an earlier walk of this plan may still read the block
+        (void)pool_free(h->mt_block);
+        h->mt_block = nullptr;
+    }
+    const size_t o_off = 0, o_seg = align_up(sizeof(long long) * seg_off.size(), 256), o_state = align_up(o_seg + sizeof(MtSeg) * segs.size(), 256);
+    const size_t bytes = o_state + sizeof(uint32_t) * MT_N * (size_t)seg_off[T];
+    HIPCK(pool_malloc(&h->mt_block, bytes));
+    std::vector<char> host(o_state);
+    std::memcpy(host.data() + o_off, seg_off.data(), sizeof(long long) * seg_off.size());
+    std::memcpy(host.data() + o_seg, segs.data(), sizeof(MtSeg) * segs.size());
+    HIPCK(upload_sync(h->mt_block, host.data(), host.size()));
+    char* mb = static_cast<char*>(h->mt_block);
+    const long long* d_seg_off = reinterpret_cast<const long long*>(mb + o_off);
+    const MtSeg* d_segs = reinterpret_cast<const MtSeg*>(mb + o_seg);
+    uint32_t* d_state = reinterpret_cast<uint32_t*>(mb + o_state);
+    hipLaunchKernelGGL(k_mt_segment_starts, dim3(T), dim3(MTX_THREADS), 0, s, h->d_meta, seeds, d_seg_off, d_poly, jump, d_state);
+    hipLaunchKernelGGL(k_mt_edge_words_seg, dim3((unsigned)segs.size()), dim3(MTX_THREADS), 0, s, h->d_meta, d_segs, d_seg_off, jump, (const uint32_t*)d_state,
+                       h->d_csr_off, reinterpret_cast<const int32_t*>(w + h->r_rowptr), reinterpret_cast<const int32_t*>(w + h->r_uprow),
                        reinterpret_cast<const int32_t*>(e + h->e_col), reinterpret_cast<const int32_t*>(e + h->e_row), h->d_eoff, words);
     HIPCK(hipGetLastError());
     return 0;

@@ -142,45 +142,158 @@ __global__ __launch_bounds__(XL_ROWS_PER_BLOCK) void k_xl_emit(const TargetMeta*
 namespace gnnx {
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------
-// The seeded initial masks of XL targets with the engine walked on the DEVICE and NO n^2 scratch (round 6).  gnnx_mt_edge_words (gnnx_graph.hpp)
-// writes the raw mt19937 state words of all n^2 draws of a target into its dense block and gathers the pairs afterwards - 9.6 GB of words for
-// a 49 028-node target.  The directed entries of a sub-graph CSR are ASCENDING in their stream position p = r n + c (row-major rows, ascending
-// columns), so one pass suffices: the workgroup walks the engine block by block (624 words per update, three data-parallel sweeps) and hands
-// every entry whose Box-Muller pair lies in the current block its two raw words on the spot.  Entries are staged 256 at a time in LDS (block
-// index, word offset, destination 4 q + 2 dir in the edge-list layout of gnnx_host_transform_edge_words); a block without entries - nine out
-// of ten on BA-House x100k - costs one LDS compare beside its update.  The last 16 values of a ragged stream are redrawn from the 16 draws that
-// follow the fill (ATen's normal_fill): those words are kept as they pass and handed out at the end.
+// The seeded initial masks of XL targets with the engine walked on the DEVICE, NO n^2 scratch, and the walk of ONE target spread over many
+// workgroups (round 6).  gnnx_mt_edge_words (gnnx_graph.hpp) writes the raw mt19937 state words of all n^2 draws of a target into its dense block
+// and gathers the pairs afterwards - 9.6 GB of words for a 49 028-node target - and walks every target's engine in one serial chain of n^2 / 624
+// block updates: 3.7 million (1.7 s of one workgroup) for the 47 913-node sub-graph of BA-House x100k.
+//   * The directed entries of a sub-graph CSR are ASCENDING in their stream position p = r n + c (row-major rows, ascending columns), so one pass
+//     suffices: a workgroup walks its part of the engine block by block (624 words per update, three data-parallel sweeps) and hands every entry
+//     whose Box-Muller pair lies in the current block its two raw words on the spot.  Entries are staged 256 at a time in LDS (block index, word
+//     offset, destination 4 q + 2 dir in the edge-list layout of gnnx_host_transform_edge_words); a block without entries - nine out of ten on
+//     BA-House x100k - costs one LDS compare beside its update.  The last 16 values of a ragged stream are redrawn from the 16 draws that follow
+//     the fill (ATen's normal_fill): those words are kept as they pass and handed out at the end.
+//   * mt19937 is linear over GF(2): x_{m + J} = XOR of x_{m + i} over the set coefficients of g(x) = x^J mod phi(x) (utils/mt_jump.py: phi by
+//     Berlekamp-Massey, g by square-and-multiply; the published jump-ahead of Haramoto et al. 2008).  k_mt_segment_starts: one workgroup per target
+//     seeds the engine, produces the first block, and then jumps from segment start to segment start - 33 blocks of the plain sequence in LDS,
+//     10 047 XORs of sliding 624-word windows: ~0.1 ms per jump instead of 13 440 block updates (6.3 ms).  k_mt_edge_words_seg: one workgroup
+//     per (target, segment of `jump` draws) walks its segment from its start state.  The 47 913-node target: 274 segments, ~30 ms of jumps + 6 ms
+//     of walking instead of 1.7 s; a 17 000-node target: 34 segments.  Bit-identical to the serial walk (tests/test_xl_route.py, tests/test_mt_jump.py).
 // words [E][4] (uint32): for every upper-triangle edge (r, c): {w(j), w(j + 8)} of entry (r, c), then of entry (c, r).
 // ---------------------------------------------------------------------------------------------------------------------------------------------
 constexpr int MTX_THREADS = 256, MTX_CHUNK = 256;
+constexpr int MT_DEG = 19937;
+constexpr int MTJ_WORDS = MT_DEG + MT_N + 3;      // the plain sequence a jump sums over (x_m .. x_{m + 19936 + 623}), padded
 
-__global__ __launch_bounds__(MTX_THREADS) void k_mt_edge_words_xl(const TargetMeta* meta, const int64_t* seeds, const long long* csr_off,
-                                                                  const int32_t* rowptr, const int32_t* uprow, const int32_t* col, const int32_t* row,
-                                                                  const long long* eoff, uint32_t* words) {
+struct MtSeg { int32_t t, s; };      // work item of k_mt_edge_words_seg: segment s of target t
+
+// draws of target t: n^2 (+ 16 redrawn when ragged); segments of `jump` draws, the last one takes the remainder (so it always holds the tail)
+__host__ __device__ inline long long mt_total_draws(long long n) { const long long nn = n * n; return nn + ((nn & 15) ? 16 : 0); }
+__host__ __device__ inline int mt_segments(long long n, long long jump) {
+    const long long total = mt_total_draws(n);
+    if (n * n < 16 || jump <= 0) return (n * n < 16) ? 0 : 1;
+    const long long k = total / jump;
+    return (int)(k < 1 ? 1 : k);
+}
+
+// one block update in place of the three sweeps: y[i + 624] = y[i + 397] ^ twist(y[i], y[i + 1]) for i in [i0, i0 + 227) - the recurrence in a
+// contiguous buffer (dependency distance 227 words)
+__device__ __forceinline__ void mt_extend(uint32_t* y, int i0, int count, int tid) {
+    if (tid < count) {
+        const int i = i0 + tid;
+        y[i + MT_N] = y[i + MT_M] ^ mt_twist(y[i], y[i + 1]);
+    }
+}
+
+// seg_state [seg_off[t] + s][624]: the block of draws [s jump, s jump + 624) of target t - the state its segment starts from
+__global__ __launch_bounds__(MTX_THREADS) void k_mt_segment_starts(const TargetMeta* meta, const int64_t* seeds, const long long* seg_off,
+                                                                   const uint32_t* poly, long long jump, uint32_t* seg_state) {
+    __shared__ uint32_t y[MTJ_WORDS + MT_N];
+    const int t = blockIdx.x;
+    const int tid = threadIdx.x;
+    const long long n = meta[t].n;
+    const int K = mt_segments(n, jump);
+    if (K == 0) return;
+    if (tid == 0) {   // at::mt19937::init_with_uint32
+        uint32_t x = (uint32_t)((unsigned long long)seeds[t] & 0xffffffffull);
+        y[0] = x;
+        for (int j = 1; j < MT_N; ++j) {
+            x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)j;
+            y[j] = x;
+        }
+    }
+    __syncthreads();
+    // the first block: draws [0, 624) = x_624 .. x_1247
+    for (int i0 = 0; i0 < MT_N; i0 += MT_N - MT_M) {
+        mt_extend(y, i0, (MT_N - i0 < MT_N - MT_M) ? MT_N - i0 : MT_N - MT_M, tid);
+        __syncthreads();
+    }
+    uint32_t* out = seg_state + (size_t)seg_off[t] * MT_N;
+    for (int k = tid; k < MT_N; k += MTX_THREADS) {
+        const uint32_t v = y[MT_N + k];
+        out[k] = v;
+        y[k] = v;
+    }
+    __syncthreads();
+    for (int s = 1; s < K; ++s) {
+        // the plain sequence from the current window: x_m .. x_{m + 19936 + 623}
+        for (int i0 = 0; i0 < MT_DEG; i0 += MT_N - MT_M) {
+            const int left = MT_DEG - i0;
+            mt_extend(y, i0, left < MT_N - MT_M ? left : MT_N - MT_M, tid);
+            __syncthreads();
+        }
+        // window J draws ahead: word j = XOR over the set coefficients g_i of y[i + j]
+        uint32_t acc[3] = {0u, 0u, 0u};
+        for (int w = 0; w <= MT_DEG / 32; ++w) {
+            const uint32_t gw = (uint32_t)__builtin_amdgcn_readfirstlane((int)poly[w]);      // uniform: the branches below are scalar
+#pragma unroll 4
+            for (int b = 0; b < 32; ++b) {
+                if (gw >> b & 1u) {           // uniform branch
+                    const int i = 32 * w + b;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int j = tid + q * MTX_THREADS;
+                        if (j < MT_N) acc[q] ^= y[i + j];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        out += MT_N;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int j = tid + q * MTX_THREADS;
+            if (j < MT_N) {
+                out[j] = acc[q];
+                y[j] = acc[q];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(MTX_THREADS) void k_mt_edge_words_seg(const TargetMeta* meta, const MtSeg* segs, const long long* seg_off, long long jump,
+                                                                   const uint32_t* seg_state, const long long* csr_off, const int32_t* rowptr,
+                                                                   const int32_t* uprow, const int32_t* col, const int32_t* row, const long long* eoff,
+                                                                   uint32_t* words) {
     __shared__ uint32_t st[2][MT_N];
     __shared__ int s_blk[MTX_CHUNK], s_off[MTX_CHUNK];
     __shared__ long long s_out[MTX_CHUNK];
     __shared__ uint32_t tailw[16];
-    const int t = blockIdx.x;
+    const MtSeg sg = segs[blockIdx.x];
+    const int t = sg.t;
     const TargetMeta tm = meta[t];
     const int tid = threadIdx.x;
     const long long n = tm.n, nn = n * n;
     if (nn < 16) return;                       // the host draws such a target whole (ATen's scalar path)
     const long long reg_end = (nn & 15) ? nn - 16 : nn;
+    const long long total = nn + ((nn & 15) ? 16 : 0);
+    const int K = mt_segments(n, jump);
+    const long long d_begin = (long long)sg.s * jump, d_end = (sg.s == K - 1) ? total : d_begin + jump;
+    const bool last_seg = sg.s == K - 1;
     const int32_t* rp = rowptr + csr_off[2 * t];
     const int32_t* ur = uprow + csr_off[2 * t];
     const int32_t* cl = col + csr_off[2 * t + 1];
     const int32_t* rw = row + csr_off[2 * t + 1];
     const int nnz = rp[tm.ld];
     uint32_t* wout = words + 4 * eoff[t];
-    if (tid == 0) {   // at::mt19937::init_with_uint32
-        uint32_t x = (uint32_t)((unsigned long long)seeds[t] & 0xffffffffull);
-        st[0][0] = x;
-        for (int j = 1; j < MT_N; ++j) {
-            x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)j;
-            st[0][j] = x;
+    // the position key of directed entry e: the first draw of its 16-value group, or nn for the entries of the redrawn tail (ascending in e)
+    auto key = [&](int e) -> long long {
+        const long long p = (long long)rw[e] * n + cl[e];
+        return p < reg_end ? (p & ~15ll) : nn;
+    };
+    auto first_at = [&](long long d) {        // first entry whose key is >= d
+        int lo = 0, hi = nnz;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (key(mid) < d) lo = mid + 1; else hi = mid;
         }
-    }
+        return lo;
+    };
+    // this segment's entries: keys in [d_begin, d_end) - the last segment also takes the tail entries (key nn < total)
+    const int e_lo = first_at(d_begin);
+    const int e_hi = last_seg ? nnz : first_at(d_end);
+    const uint32_t* v0 = seg_state + ((size_t)seg_off[t] + sg.s) * MT_N;
+    for (int k = tid; k < MT_N; k += MTX_THREADS) st[0][k] = v0[k];
     // destination of directed entry e = (i, j): word pair 2 dir of edge q (the edge's index among the target's upper-triangle edges)
     auto dest = [&](int e, int i, int j) -> long long {
         if (j > i) {
@@ -195,13 +308,13 @@ __global__ __launch_bounds__(MTX_THREADS) void k_mt_edge_words_xl(const TargetMe
         const int firstup = rp[j + 1] - (ur[j + 1] - ur[j]);
         return 4ll * (ur[j] + (lo - firstup)) + 2;
     };
-    int ec = 0, ci = 0, cn = 0;      // next entry to stage, cursor / fill of the staged chunk (uniform)
-    auto stage = [&]() {             // the next MTX_CHUNK entries -> LDS (block-uniform call)
+    int ec = e_lo, ci = 0, cn = 0;      // next entry to stage, cursor / fill of the staged chunk (uniform)
+    auto stage = [&]() {                // the next MTX_CHUNK entries -> LDS (block-uniform call)
         __syncthreads();
         const int e = ec + tid;
         int blk = 0x7fffffff, off = 0;
         long long out = 0;
-        if (e < nnz) {
+        if (e < e_hi) {
             const int i = rw[e], j = cl[e];
             const long long p = (long long)i * n + j;
             if (p < reg_end) {
@@ -217,33 +330,37 @@ __global__ __launch_bounds__(MTX_THREADS) void k_mt_edge_words_xl(const TargetMe
         s_blk[tid] = blk;
         s_off[tid] = off;
         s_out[tid] = out;
-        cn = (nnz - ec < MTX_CHUNK) ? nnz - ec : MTX_CHUNK;
+        cn = (e_hi - ec < MTX_CHUNK) ? e_hi - ec : MTX_CHUNK;
         ec += cn;
         ci = 0;
         __syncthreads();
     };
     stage();
-    const long long total = nn + ((nn & 15) ? 16 : 0);
     int cur = 0;
-    int b = 0;
-    for (long long d0 = 0; d0 < total; d0 += MT_N, ++b) {
-        const uint32_t* o = st[cur];
-        uint32_t* nw = st[cur ^ 1];
-        if (tid < MT_N - MT_M) nw[tid] = o[tid + MT_M] ^ mt_twist(o[tid], o[tid + 1]);
-        __syncthreads();
-        if (tid < MT_N - MT_M) {
-            const int k = tid + (MT_N - MT_M);
-            nw[k] = nw[k - (MT_N - MT_M)] ^ mt_twist(o[k], o[k + 1]);
+    int b = (int)(d_begin / MT_N);
+    bool have = true;                  // the segment's start state IS its first block (draws [d_begin, d_begin + 624))
+    for (long long d0 = d_begin; d0 < d_end; d0 += MT_N, ++b) {
+        if (!have) {
+            const uint32_t* o = st[cur];
+            uint32_t* nw = st[cur ^ 1];
+            if (tid < MT_N - MT_M) nw[tid] = o[tid + MT_M] ^ mt_twist(o[tid], o[tid + 1]);
+            __syncthreads();
+            if (tid < MT_N - MT_M) {
+                const int k = tid + (MT_N - MT_M);
+                nw[k] = nw[k - (MT_N - MT_M)] ^ mt_twist(o[k], o[k + 1]);
+            }
+            __syncthreads();
+            if (tid < MT_N - 2 * (MT_N - MT_M)) {
+                const int k = tid + 2 * (MT_N - MT_M);      // 454 .. 623
+                nw[k] = nw[k - (MT_N - MT_M)] ^ mt_twist(o[k], k + 1 < MT_N ? o[k + 1] : nw[0]);
+            }
+            __syncthreads();
+            cur ^= 1;
         }
-        __syncthreads();
-        if (tid < MT_N - 2 * (MT_N - MT_M)) {
-            const int k = tid + 2 * (MT_N - MT_M);      // 454 .. 623
-            nw[k] = nw[k - (MT_N - MT_M)] ^ mt_twist(o[k], k + 1 < MT_N ? o[k + 1] : nw[0]);
-        }
-        __syncthreads();
-        cur ^= 1;
+        have = false;
+        const uint32_t* nw = st[cur];
         // the redrawn tail's 16 words (draws nn .. nn + 15) as they pass
-        if ((nn & 15) && tid < 16) {
+        if (last_seg && (nn & 15) && tid < 16) {
             const long long d = nn + tid - d0;
             if (d >= 0 && d < MT_N) tailw[tid] = nw[d];
         }
@@ -259,10 +376,11 @@ __global__ __launch_bounds__(MTX_THREADS) void k_mt_edge_words_xl(const TargetMe
             int nx = ci + 1;
             while (nx < cn && s_blk[nx] == b) ++nx;
             ci = nx;
-            if (ci == cn && ec < nnz) stage();      // the block's entries may continue in the next chunk
+            if (ci == cn && ec < e_hi) stage();      // the block's entries may continue in the next chunk
         }
     }
     __syncthreads();
+    if (!last_seg) return;
     // the entries of the last 16 stream positions: their words come from the redrawn tail
     for (;;) {
         const int k = ci + tid;
@@ -270,7 +388,7 @@ __global__ __launch_bounds__(MTX_THREADS) void k_mt_edge_words_xl(const TargetMe
             wout[s_out[k]] = tailw[s_off[k]];
             wout[s_out[k] + 1] = tailw[s_off[k] + 8];
         }
-        if (ec >= nnz) break;
+        if (ec >= e_hi) break;
         stage();
     }
 }

@@ -192,6 +192,7 @@ _API = {
     "gnnx_xl_set_trace": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "gnnx_xl_mt_edge_words": (ctypes.c_int, [ctypes.c_void_p] * 6),
     "gnnx_xl_set_clocks": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "gnnx_set_mt_jump_poly": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
     "gnnx_xl_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper), ctypes.POINTER(_XlState)] + [ctypes.c_void_p] * 5),
     "gnnx_last_error": (ctypes.c_char_p, []),
     "gnnx_version": (ctypes.c_char_p, []),
@@ -1068,6 +1069,7 @@ class XLJob:
     def draw_edge_words_device(self, seeds):
         """First half of the seeded masks with the engine walked on the DEVICE (gnnx_xl_mt_edge_words: no n^2 scratch): -> device int32 [E, 4] raw
         engine words; finish with engine.transform_edge_words(self.n, seeds, eoff, rc, words_host) + set_masks_on_edges."""
+        enable_mt_jump(self.lib)
         sd = _h2d(np.ascontiguousarray(np.asarray(seeds).astype(np.int64)), self.device)
         words = torch.empty(max(self.E, 1), 4, dtype=torch.int32, device=self.device)
         self._enter()
@@ -1180,6 +1182,28 @@ class XLJob:
             self.close()
         except Exception:
             pass
+
+
+_MT_JUMP_SET = set()
+
+
+def enable_mt_jump(lib=None, poly=None, jump=None):
+    """Hand the library the jump polynomial of the segmented engine walk (gnnx_set_mt_jump_poly; utils/mt_jump.py) - once per process and library.
+    poly / jump: another stride (tests); jump=0 switches back to serial walks."""
+    lib = lib if lib is not None else get_library()
+    key = id(lib)
+    if poly is None and jump is None:
+        if key in _MT_JUMP_SET or os.environ.get("GNNX_MT_JUMP", "1") == "0":
+            return
+        from .utils import mt_jump
+        poly, jump = mt_jump.load_jump_poly(), mt_jump.JUMP
+    _MT_JUMP_SET.add(key)
+    if not jump:
+        _check(lib, lib.gnnx_set_mt_jump_poly(None, 0))
+        return
+    poly = np.ascontiguousarray(poly, np.uint32)
+    assert poly.shape == (624,)
+    _check(lib, lib.gnnx_set_mt_jump_poly(poly.ctypes.data, int(jump)))
 
 
 @dataclass

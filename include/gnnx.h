@@ -389,6 +389,12 @@ int gnnx_xl_build(gnnx_xl_handle h, const int64_t* indptr, const int32_t* indice
  * their stream positions pass (k_mt_edge_words_xl).  The host finishes with the transform of include/gnnx_host.h - gnnx_host_transform_edge_words -: bit-identical to
  * torch.manual_seed(seed); torch.FloatTensor(n, n).normal_(1.0, std) on the edges (construct_edge_mask, explain.py:645-652). */
 int gnnx_xl_mt_edge_words(gnnx_xl_handle h, const int64_t* seeds, void* ws_rows, void* ws_entries, uint32_t* words, void* stream);
+/* The walk of ONE target's engine spread over many workgroups: mt19937 is linear over GF(2), so the state `jump_draws` draws ahead is the XOR of
+ * sliding windows of the plain sequence selected by g(x) = x^jump mod phi(x) (utils/mt_jump.py computes phi and g; poly = HOST, 624 uint32, bit i of the
+ * polynomial = bit i & 31 of word i >> 5; jump_draws a multiple of 624).  Once set (process-wide), gnnx_xl_mt_edge_words jumps from segment start to
+ * segment start (k_mt_segment_starts) and walks the segments in parallel (k_mt_edge_words_seg): the 2.3e9 draws of a 47 913-node sub-graph in ~35 ms
+ * instead of 1.7 s.  NULL / 0: serial walks. */
+int gnnx_set_mt_jump_poly(const uint32_t* poly, int64_t jump_draws);
 int gnnx_xl_set_trace(gnnx_xl_handle h, uint32_t* gates);
 /* Measurement hook: ticks [T][4] (DEVICE int64) receives, from every later gnnx_xl_run, the wall_clock64 value (100 MHz) at the start of target t's
  * workgroup, after its setup, after its iteration loop and at its end; NULL = off.  parallel.py calibrates the sharded job's cost model on them. */
