@@ -435,7 +435,7 @@ def bench_ba100k_all(args, dev, log, dist, world, rank):
             em = list(pipe1.run([pick]))[0]
             alone_ms = (time.perf_counter() - t0) * 1e3
             st = dict(pipe1.stats[-1])
-            reps = 3
+            reps = 6
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in pipe1.run([pick] * reps):
