@@ -417,6 +417,8 @@ def bench_ba100k_all(args, dev, log, dist, world, rank):
     sum_n2_all = float((sizes.astype(np.float64) ** 2).sum())
     strata = all_node_sample(sizes, scale=args.sample_scale)
     sample = np.sort(np.concatenate([s[3] for s in strata]))
+    if os.environ.get("GNNX_WRITE_SAMPLE") and rank == 0:      # tests/golden/ba100k_all_sample.npy: (node id, sub-graph size) of the sample - the CPU suite
+        np.save(os.environ["GNNX_WRITE_SAMPLE"], np.stack([sample, sizes[sample]]).astype(np.int64))      # checks the shards cut from it (tests/test_distributed.py)
     log(f"sizes of all {N} nodes: {sizes_ms:.0f} ms; sum n^2 = {sum_n2_all:.3g}; sample {len(sample)} targets in {len(strata)} strata: " +
         ", ".join(f"({lo},{hi}]: {len(pick)}/{pop}" for lo, hi, pop, pick in strata))
 

@@ -15,14 +15,22 @@ import numpy as np
 
 
 # Size classes of the cost model = the kernel classes of the plan (gnnx_plan_analyze; csrc/gnnx_sparse.hpp): one-wave targets
-# (n <= 32), the 256-thread class (n <= 128), the 512- / 1024-thread classes (n <= 512), k_sparse_large (n <= 16383), dense streaming.
-CLASS_EDGES = (32, 128, 512, 16383)
-# GPU microseconds one target adds to a SATURATED batch of its class on one MI355X, 300 iterations.  For k_sparse_large and the
-# streaming class the cost grows with the target: a + b n (large) resp. the HBM time of 28 n^2 bytes per iteration at ~4 TB/s.
-# These defaults were measured on the BA-House x100k target set (tools/probe_classes.py); `calibrate_cost_table` re-measures them
-# on the workload and machine at hand (bench.py --gpus N does, on rank 0, and broadcasts the table), so the shards do not
-# depend on one dataset's fit.
-DEFAULT_COST_TABLE = np.asarray([2.5, 11.0, 17.0, 45.0], np.float64)
+# (n <= 32), the 256-thread class (n <= 128), the 512- / 1024-thread classes (n <= 512), and the large-target kernel beyond
+# (k_sparse_large / its XL form: any size since round 6 - no target streams dense blocks any more).
+CLASS_EDGES = (32, 128, 512)
+# GPU microseconds one target adds to a SATURATED batch of its class on one MI355X, 300 iterations.  Beyond 512 nodes the cost grows with
+# the target: one workgroup (= one compute unit) per target for LARGE_MS(n) milliseconds - measured with the kernel's per-target device
+# clocks on BA-House x100k (profiles/r06_probe_xl_ba100k_first.json): 6.8 ms at n = 700, 14 at 4 400, 27 at 11 500, 52 at 18 800, then faster than
+# linearly (the sub-graphs of the hub's neighbourhood: 120 ms at 30 000, 480 at 48 000).  The table's fourth entry is the cost at n = 900.
+# The defaults were measured on the BA-House x100k target set; `calibrate_cost_table` re-measures them on the workload and machine at
+# hand, so the shards do not depend on one dataset's fit.
+DEFAULT_COST_TABLE = np.asarray([2.5, 11.0, 17.0, 29.0], np.float64)
+
+
+def large_ms(n):
+    """compute-unit milliseconds of the large-target kernel for a sub-graph of n nodes (300 iterations; the shape of the fit above)"""
+    n = np.asarray(n, np.float64)
+    return (5.5 + 2.2e-3 * np.minimum(n, 2.0e4)) * np.maximum(1.0, n / 2.0e4) ** 2.5
 
 
 def size_class(sizes) -> np.ndarray:
@@ -32,13 +40,12 @@ def size_class(sizes) -> np.ndarray:
 def target_cost(sizes, table=None) -> np.ndarray:
     """GPU time (microseconds) one target of n nodes adds to a batch that fills an MI355X, 300 iterations: the quantity the shards
     must balance.  The edge-sparse kernels cost per workgroup slot, not per n^2 (every iteration is the same latency chain whatever
-    n), so the model is one constant per kernel class (`table`, default DEFAULT_COST_TABLE; within the two larger classes scaled
-    linearly with n around the class mean the table was measured at), and HBM time beyond k_sparse_large's range."""
+    n), so the model is one constant per kernel class (`table`, default DEFAULT_COST_TABLE; the 512-thread class scaled linearly with
+    n around the class mean it was measured at, the large-target kernel by its measured shape large_ms)."""
     n = np.asarray(sizes, np.float64)
     t = DEFAULT_COST_TABLE if table is None else np.asarray(table, np.float64)
     c = size_class(n)
-    cost = np.choose(np.minimum(c, 3), [t[0], t[1], t[2] * (0.6 + 0.4 * n / 320.0), t[3] * (0.55 + 0.45 * n / 900.0)])
-    return np.where(c >= 4, 300 * 28.0 * n * n / 4e6, cost)
+    return np.choose(np.minimum(c, 3), [t[0], t[1], t[2] * (0.6 + 0.4 * n / 320.0), t[3] * large_ms(n) / large_ms(900.0)])
 
 
 def calibrate_cost_table(sizes, run_batch, per_class=1024, min_members=64) -> np.ndarray:

@@ -18,6 +18,7 @@ for step in "$@"; do
     smoke)        timeout 600 python __graft_entry__.py smoke 2>&1 | tail -4 ;;
     pytest)       timeout 3000 python -m pytest ${arg:-tests} -m gpu -x -q 2>&1 | tail -15 | tee "$O/pytest_$(echo "$arg" | tr '/ :' '___').txt" ;;
     pytest_all)   timeout 5000 python -m pytest tests -m gpu -q 2>&1 | tail -25 | tee "$O/pytest_all.txt" ;;
+    sample)       GNNX_WRITE_SAMPLE="$O/ba100k_all_sample.npy" timeout 1500 python bench.py --workload ba100k-all --steps 1 --warmup 1 --no-cpu-baseline > "$O/bench_sample.json" 2> "$O/bench_sample.err"; ls -la "$O" ;;
     ties)         GNNX_WRITE_TIES=1 timeout 3000 python -m pytest tests/test_decision_parity.py -m gpu -q 2>&1 | tail -8 | tee "$O/ties_pytest.txt"; cp tests/golden/*_ties.json "$O/" ;;
     probe_xl)     timeout 1500 python tools/probe_xl.py $arg --out "$O/probe_xl.json" 2>&1 | tail -12 ;;
     bench)        tag=$(echo "$arg" | tr -c 'a-zA-Z0-9' '_'); timeout 1500 python bench.py $arg > "$O/bench_$tag.json" 2> "$O/bench_$tag.err"; tail -c 1500 "$O/bench_$tag.json"; tail -3 "$O/bench_$tag.err" ;;
