@@ -2179,7 +2179,7 @@ extern "C" int gnnx_xl_count(gnnx_xl_handle h, const int64_t* indptr, const int3
     hipLaunchKernelGGL(k_xl_rowdeg, dim3((unsigned)h->blocks.size()), dim3(XL_ROWS_PER_BLOCK), 0, s, h->d_meta, h->d_blocks, indptr, indices, weights, nb,
                        nb_off, feat, (int)feat_stride, (int)h->prob.D, pred_label, reinterpret_cast<float*>(w + h->r_X),
                        reinterpret_cast<float*>(w + h->r_yhat), deg, updeg);
-    hipLaunchKernelGGL(k_xl_rowptr, dim3(T), dim3(1024), 0, s, h->d_meta, deg, updeg, h->d_rp_off, reinterpret_cast<int32_t*>(w + h->r_rowptr),
+    hipLaunchKernelGGL(k_xl_rowptr, dim3(T), dim3(XL_ROWPTR_THREADS), 0, s, h->d_meta, deg, updeg, h->d_rp_off, reinterpret_cast<int32_t*>(w + h->r_rowptr),
                        reinterpret_cast<int32_t*>(w + h->r_uprow), totals);
     HIPCK(hipGetLastError());
     std::vector<int32_t> tot(2 * (size_t)T);

@@ -62,9 +62,12 @@ __global__ __launch_bounds__(XL_ROWS_PER_BLOCK) void k_xl_rowdeg(const TargetMet
 }
 
 // exclusive scans of deg / updeg over the ld rows of one target -> rowptr [ld + 1] (at rp_off[t]), uprow [ld + 1]; totals[2 t], [2 t + 1]
-__global__ __launch_bounds__(1024) void k_xl_rowptr(const TargetMeta* meta, const int32_t* deg, const int32_t* updeg, const long long* rp_off,
-                                                    int32_t* rowptr, int32_t* uprow, int32_t* totals) {
-    constexpr int NT = 1024, NW = NT / 64;
+// (256 threads: four waves find a place beside a workgroup of the XL loop - 230 registers per lane, two waves per SIMD - where sixteen would wait
+// for a whole compute unit: 171 ms behind a batch of the largest sub-graphs, profiles/r06_kernel_stats_ba100k_all.csv)
+constexpr int XL_ROWPTR_THREADS = 256;
+__global__ __launch_bounds__(XL_ROWPTR_THREADS) void k_xl_rowptr(const TargetMeta* meta, const int32_t* deg, const int32_t* updeg, const long long* rp_off,
+                                                                 int32_t* rowptr, int32_t* uprow, int32_t* totals) {
+    constexpr int NT = XL_ROWPTR_THREADS, NW = NT / 64;
     __shared__ int part[2][NW];
     const int t = blockIdx.x;
     const TargetMeta tm = meta[t];
@@ -162,7 +165,6 @@ namespace gnnx {
 // ---------------------------------------------------------------------------------------------------------------------------------------------
 constexpr int MTX_THREADS = 256, MTX_CHUNK = 256;
 constexpr int MT_DEG = 19937;
-constexpr int MTJ_WORDS = MT_DEG + MT_N + 3;      // the plain sequence a jump sums over (x_m .. x_{m + 19936 + 623}), padded
 
 struct MtSeg { int32_t t, s; };      // work item of k_mt_edge_words_seg: segment s of target t
 
@@ -175,24 +177,37 @@ __host__ __device__ inline int mt_segments(long long n, long long jump) {
     return (int)(k < 1 ? 1 : k);
 }
 
-// one block update in place of the three sweeps: y[i + 624] = y[i + 397] ^ twist(y[i], y[i + 1]) for i in [i0, i0 + 227) - the recurrence in a
-// contiguous buffer (dependency distance 227 words)
-__device__ __forceinline__ void mt_extend(uint32_t* y, int i0, int count, int tid) {
-    if (tid < count) {
-        const int i = i0 + tid;
-        y[i + MT_N] = y[i + MT_M] ^ mt_twist(y[i], y[i + 1]);
-    }
-}
-
-// seg_state [seg_off[t] + s][624]: the block of draws [s jump, s jump + 624) of target t - the state its segment starts from
+// seg_state [seg_off[t] + s][624]: the block of draws [s jump, s jump + 624) of target t - the state its segment starts from.
+// The jump needs the plain sequence x_m .. x_{m + 19936 + 623} only as a SLIDING window: term i touches y[i .. i + 623], so three 624-word blocks in a
+// ring (the block that holds i, the next one, and the one being generated) are enough - 7.5 KB of LDS instead of 85, which lets the kernel run
+// beside the 96 KB workgroups of the XL loop instead of waiting for a compute unit to drain (profiles/r06_kernel_stats_ba100k_all.csv: 471 ms
+// behind a batch of the largest sub-graphs with the 85 KB form).
+constexpr int MTJ_RING = 3 * MT_N;
 __global__ __launch_bounds__(MTX_THREADS) void k_mt_segment_starts(const TargetMeta* meta, const int64_t* seeds, const long long* seg_off,
                                                                    const uint32_t* poly, long long jump, uint32_t* seg_state) {
-    __shared__ uint32_t y[MTJ_WORDS + MT_N];
+    __shared__ uint32_t y[MTJ_RING];
     const int t = blockIdx.x;
     const int tid = threadIdx.x;
     const long long n = meta[t].n;
     const int K = mt_segments(n, jump);
     if (K == 0) return;
+    // block `nb` of the ring <- the block after block `ob` (three sweeps: the recurrence's dependency distance is 227 words)
+    auto next_block = [&](int ob, int nb) {
+        const uint32_t* o = y + ob * MT_N;
+        uint32_t* nw = y + nb * MT_N;
+        if (tid < MT_N - MT_M) nw[tid] = o[tid + MT_M] ^ mt_twist(o[tid], o[tid + 1]);
+        __syncthreads();
+        if (tid < MT_N - MT_M) {
+            const int k = tid + (MT_N - MT_M);
+            nw[k] = nw[k - (MT_N - MT_M)] ^ mt_twist(o[k], o[k + 1]);
+        }
+        __syncthreads();
+        if (tid < MT_N - 2 * (MT_N - MT_M)) {
+            const int k = tid + 2 * (MT_N - MT_M);
+            nw[k] = nw[k - (MT_N - MT_M)] ^ mt_twist(o[k], k + 1 < MT_N ? o[k + 1] : nw[0]);
+        }
+        __syncthreads();
+    };
     if (tid == 0) {   // at::mt19937::init_with_uint32
         uint32_t x = (uint32_t)((unsigned long long)seeds[t] & 0xffffffffull);
         y[0] = x;
@@ -202,50 +217,60 @@ __global__ __launch_bounds__(MTX_THREADS) void k_mt_segment_starts(const TargetM
         }
     }
     __syncthreads();
-    // the first block: draws [0, 624) = x_624 .. x_1247
-    for (int i0 = 0; i0 < MT_N; i0 += MT_N - MT_M) {
-        mt_extend(y, i0, (MT_N - i0 < MT_N - MT_M) ? MT_N - i0 : MT_N - MT_M, tid);
-        __syncthreads();
-    }
+    next_block(0, 1);      // the first block: draws [0, 624) = x_624 .. x_1247
     uint32_t* out = seg_state + (size_t)seg_off[t] * MT_N;
-    for (int k = tid; k < MT_N; k += MTX_THREADS) {
-        const uint32_t v = y[MT_N + k];
-        out[k] = v;
-        y[k] = v;
+    uint32_t win[3];       // the current window (segment start), three words per thread
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int j = tid + q * MTX_THREADS;
+        win[q] = (j < MT_N) ? y[MT_N + j] : 0u;
+        if (j < MT_N) out[j] = win[q];
     }
     __syncthreads();
     for (int s = 1; s < K; ++s) {
-        // the plain sequence from the current window: x_m .. x_{m + 19936 + 623}
-        for (int i0 = 0; i0 < MT_DEG; i0 += MT_N - MT_M) {
-            const int left = MT_DEG - i0;
-            mt_extend(y, i0, left < MT_N - MT_M ? left : MT_N - MT_M, tid);
-            __syncthreads();
+        // ring block 0 <- the window, block 1 <- its successor
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int j = tid + q * MTX_THREADS;
+            if (j < MT_N) y[j] = win[q];
         }
-        // window J draws ahead: word j = XOR over the set coefficients g_i of y[i + j]
+        __syncthreads();
+        next_block(0, 1);
         uint32_t acc[3] = {0u, 0u, 0u};
-        for (int w = 0; w <= MT_DEG / 32; ++w) {
-            const uint32_t gw = (uint32_t)__builtin_amdgcn_readfirstlane((int)poly[w]);      // uniform: the branches below are scalar
-#pragma unroll 4
-            for (int b = 0; b < 32; ++b) {
-                if (gw >> b & 1u) {           // uniform branch
-                    const int i = 32 * w + b;
+        int b0 = 0;        // ring position of the block that holds the terms i of this round
+        for (int blk = 0; blk * MT_N < MT_DEG; ++blk) {
+            const int b1 = (b0 + 1) % 3, b2 = (b0 + 2) % 3;
+            // terms i in [624 blk, 624 (blk + 1)): word j of the window at i is ring[(b0 624 + (i - 624 blk) + j) mod 1872] (blocks b0, b1)
+            const int ilo = blk * MT_N, ihi = (ilo + MT_N < MT_DEG) ? ilo + MT_N : MT_DEG;
+            for (int w = ilo >> 5; 32 * w < ihi; ++w) {
+                uint32_t gw = (uint32_t)__builtin_amdgcn_readfirstlane((int)poly[w]);      // uniform: the branches below are scalar
+                // (a polynomial word may straddle two rounds: 624 is not a multiple of 32 - mask the bits of the other round)
+                const int lo = (32 * w < ilo) ? ilo - 32 * w : 0, hi = (32 * w + 32 > ihi) ? ihi - 32 * w : 32;
+                if (lo > 0) gw &= ~0u << lo;
+                if (hi < 32) gw &= (1u << hi) - 1u;
+                while (gw) {                                                           // uniform loop over the set bits
+                    const int bpos = __ffs((int)gw) - 1;
+                    gw &= gw - 1u;
+                    const int base = b0 * MT_N + (32 * w + bpos - ilo);
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         const int j = tid + q * MTX_THREADS;
-                        if (j < MT_N) acc[q] ^= y[i + j];
+                        int idx = base + j;
+                        idx -= (idx >= MTJ_RING) ? MTJ_RING : 0;
+                        if (j < MT_N) acc[q] ^= y[idx];
                     }
                 }
             }
+            __syncthreads();                     // every read of block b0 is done: it becomes the block after b1's successor
+            if ((blk + 1) * MT_N < MT_DEG) next_block(b1, b2), b0 = b1;
+            // (the ring now holds blocks blk + 1 (b0) and blk + 2; block blk + 2 was generated from blk + 1 - into the slot block blk left)
         }
-        __syncthreads();
         out += MT_N;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int j = tid + q * MTX_THREADS;
-            if (j < MT_N) {
-                out[j] = acc[q];
-                y[j] = acc[q];
-            }
+            win[q] = acc[q];
+            if (j < MT_N) out[j] = acc[q];
         }
         __syncthreads();
     }

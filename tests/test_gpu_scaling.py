@@ -38,20 +38,39 @@ def test_lpt_shards_by_calibrated_cost_take_equal_gpu_time():
     hy = Hyper(num_iters=100)
 
     def run_batch(idx):
+        """the optimisation of the targets idx as the pipeline routes them: dense-packed classes up to 512 sub-graph nodes, the XL route beyond,
+        the two launches side by side"""
         t_sub = targets[np.asarray(idx, np.int64)]
         dn = engine.khop_device(graph, t_sub, 3)
-        job = MaskOptimJob.from_csr(graph, dn, None, label[t_sub], ck["sd"])
-        job.set_masks_raw(engine.init_edge_masks_raw(dn.sizes, seeds=1000 + t_sub, threads=8))
-        job.launch(hy)
+        big = dn.sizes > 512
+        jobs = []
+        if (~big).any():
+            sel = np.nonzero(~big)[0]
+            job = MaskOptimJob.from_csr(graph, dn.subset(sel), None, label[t_sub[sel]], ck["sd"])
+            job.set_masks_raw(engine.init_edge_masks_raw(dn.sizes[sel], seeds=1000 + t_sub[sel], threads=8))
+            job.use_stream(torch.cuda.Stream())
+            jobs.append(job)
+        if big.any():
+            sel = np.nonzero(big)[0]
+            job = engine.XLJob(graph, dn.subset(sel), None, label[t_sub[sel]], ck["sd"])
+            job.set_masks_seeded(1000 + t_sub[sel], threads=8)
+            job.use_stream(torch.cuda.Stream())
+            jobs.append(job)
+        for job in jobs:
+            job.launch(hy)
         torch.cuda.synchronize()
         ms = []
         for _ in range(3):          # the best of three: a wall-clock comparison at the 15 % level (one run in the round-3 session lost 1.3 ms to the host)
+            for job in jobs:
+                job.reset_masks()
+            torch.cuda.synchronize()
             t0 = time.perf_counter()
-            job.set_masks_raw_resident()
-            job.launch(hy)
+            for job in jobs:
+                job.launch(hy)
             torch.cuda.synchronize()
             ms.append((time.perf_counter() - t0) * 1e3)
-        job.close()
+        for job in jobs:
+            job.close()
         return min(ms)
 
     table = parallel.calibrate_cost_table(sizes, run_batch)
