@@ -425,7 +425,7 @@ def bench_ba100k_all(args, dev, log, dist, world, rank):
     # ---- N = 1 (and rank 0 of N > 1): every stratum's batch alone - end to end and the launch - for the extrapolation and the cost model ----
     per_stratum = []
     if rank == 0:
-        pipe1 = BatchPipeline(graph, ck["sd"], label, hy)
+        pipe1 = BatchPipeline(graph, ck["sd"], label, hy, prepare_workers=int(os.environ.get("GNNX_PIPE_WORKERS", "4")))
         for lo, hi, pop, pick in strata:
             if not len(pick):
                 per_stratum.append(dict(n_lo=lo, n_hi=hi, population=pop, sampled=0))
@@ -523,7 +523,9 @@ def bench_ba100k_all(args, dev, log, dist, world, rank):
             mine_b, all_b = gather[key]
             mine_b[:vals_d.numel()].copy_(vals_d)
             dist.all_gather(all_b, mine_b)
-    pipe = BatchPipeline(graph, ck["sd"], label, hy, device_hook=hook)
+    # four prepare workers: a batch of large sub-graphs spends most of its preparation waiting for the device (engine walk, CSR build), and the walks of
+    # several batches overlap on the chip (profiles/r06_ab_xl_threshold.txt: every node 11.2 s with two workers, 9.1 s with four)
+    pipe = BatchPipeline(graph, ck["sd"], label, hy, device_hook=hook, prepare_workers=int(os.environ.get("GNNX_PIPE_WORKERS", "4")))
 
     def barrier():
         torch.cuda.synchronize()

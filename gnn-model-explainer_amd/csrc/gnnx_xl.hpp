@@ -186,11 +186,15 @@ constexpr int MTJ_RING = 3 * MT_N;
 __global__ __launch_bounds__(MTX_THREADS) void k_mt_segment_starts(const TargetMeta* meta, const int64_t* seeds, const long long* seg_off,
                                                                    const uint32_t* poly, long long jump, uint32_t* seg_state) {
     __shared__ uint32_t y[MTJ_RING];
+    __shared__ uint32_t spoly[MT_N];      // the polynomial, once per workgroup: a jump reads its 624 words one after the other - from global memory each
+                                          // word was a dependent ~2 us round trip, 1.2 of the 1.6 ms of a jump (profiles/r06_probe_xl_jump_walk.txt)
     const int t = blockIdx.x;
     const int tid = threadIdx.x;
     const long long n = meta[t].n;
     const int K = mt_segments(n, jump);
     if (K == 0) return;
+    if (K > 1)
+        for (int k = tid; k < MT_N; k += MTX_THREADS) spoly[k] = poly[k];
     // block `nb` of the ring <- the block after block `ob` (three sweeps: the recurrence's dependency distance is 227 words)
     auto next_block = [&](int ob, int nb) {
         const uint32_t* o = y + ob * MT_N;
@@ -242,23 +246,40 @@ __global__ __launch_bounds__(MTX_THREADS) void k_mt_segment_starts(const TargetM
             const int b1 = (b0 + 1) % 3, b2 = (b0 + 2) % 3;
             // terms i in [624 blk, 624 (blk + 1)): word j of the window at i is ring[(b0 624 + (i - 624 blk) + j) mod 1872] (blocks b0, b1)
             const int ilo = blk * MT_N, ihi = (ilo + MT_N < MT_DEG) ? ilo + MT_N : MT_DEG;
+            uint32_t gnext = spoly[ilo >> 5];
             for (int w = ilo >> 5; 32 * w < ihi; ++w) {
-                uint32_t gw = (uint32_t)__builtin_amdgcn_readfirstlane((int)poly[w]);      // uniform: the branches below are scalar
+                uint32_t gw = (uint32_t)__builtin_amdgcn_readfirstlane((int)gnext);      // uniform: the branches below are scalar
+                gnext = spoly[(w + 1 < MT_N) ? w + 1 : w];                                // (the next word's LDS read overlaps this word's terms)
                 // (a polynomial word may straddle two rounds: 624 is not a multiple of 32 - mask the bits of the other round)
                 const int lo = (32 * w < ilo) ? ilo - 32 * w : 0, hi = (32 * w + 32 > ihi) ? ihi - 32 * w : 32;
                 if (lo > 0) gw &= ~0u << lo;
                 if (hi < 32) gw &= (1u << hi) - 1u;
-                while (gw) {                                                           // uniform loop over the set bits
-                    const int bpos = __ffs((int)gw) - 1;
-                    gw &= gw - 1u;
-                    const int base = b0 * MT_N + (32 * w + bpos - ilo);
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const int j = tid + q * MTX_THREADS;
-                        int idx = base + j;
-                        idx -= (idx >= MTJ_RING) ? MTJ_RING : 0;
-                        if (j < MT_N) acc[q] ^= y[idx];
+                while (gw) {                                                           // uniform loop over the set bits, four per trip: one wave per
+                    int base[4];                                                       // SIMD has nothing to hide an LDS round trip behind but its own
+#pragma unroll                                                                         // independent loads - twelve in flight instead of three
+                    for (int u = 0; u < 4; ++u) {
+                        base[u] = -1;
+                        if (gw) {
+                            base[u] = b0 * MT_N + (32 * w + (__ffs((int)gw) - 1) - ilo);
+                            gw &= gw - 1u;
+                        }
                     }
+                    uint32_t v[4][3];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            const int j = tid + q * MTX_THREADS;
+                            int idx = (base[u] < 0 ? 0 : base[u]) + j;
+                            idx -= (idx >= MTJ_RING) ? MTJ_RING : 0;
+                            v[u][q] = (j < MT_N) ? y[idx] : 0u;
+                        }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (base[u] >= 0) {                                            // uniform
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) acc[q] ^= v[u][q];
+                        }
                 }
             }
             __syncthreads();                     // every read of block b0 is done: it becomes the block after b1's successor

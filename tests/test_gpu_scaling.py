@@ -86,5 +86,7 @@ def test_lpt_shards_by_calibrated_cost_take_equal_gpu_time():
     # 4.14 with the set's largest target, n = 4430, taking 4.9 ms alone.)
     poles = [run_batch([int(s[int(np.argmax(sizes[np.asarray(s, np.int64)]))])]) for s in shards]
     print(f"largest target of every shard alone: {np.round(poles, 2).tolist()} ms (n = {[int(sizes[np.asarray(s, np.int64)].max()) for s in shards]}); shards {np.round(times, 2).tolist()} ms")
+    # (round 6: the targets beyond 512 nodes run on the XL route, one workgroup per compute unit, beside the resident launch of the small ones - the two
+    #  launches of a shard share the chip and the cost of a shard is no longer the plain sum of its targets': 20 % instead of 12 %)
     for k in range(4):
-        assert times[k] <= 1.12 * max(poles[k], min(times)), (times, poles)
+        assert times[k] <= 1.20 * max(poles[k], min(times)), (times, poles)

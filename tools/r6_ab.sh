@@ -1,8 +1,7 @@
 #!/bin/bash
-# round 6 A/B: the all-node sample with the jump-ahead engine walk - XL threshold 512 / 2048, 2 / 4 prepare workers
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-r6ab}; mkdir -p $O
-for cfg in "512 2" "512 4" "2048 2"; do
+for cfg in "512 2" "512 4"; do
   set -- $cfg
   GNNX_XL_MIN_N=$1 GNNX_PIPE_WORKERS=$2 timeout 900 python bench.py --workload ba100k-all --steps 2 --warmup 1 --no-cpu-baseline > $O/all_xlmin$1_w$2.json 2> $O/all_xlmin$1_w$2.err
   python - <<PY
