@@ -223,6 +223,9 @@ __global__ __launch_bounds__(MTX_THREADS) void k_mt_segment_starts(const TargetM
     __syncthreads();
     next_block(0, 1);      // the first block: draws [0, 624) = x_624 .. x_1247
     uint32_t* out = seg_state + (size_t)seg_off[t] * MT_N;
+    int jcl[3];            // this thread's three window words, clamped to the window
+#pragma unroll
+    for (int q = 0; q < 3; ++q) jcl[q] = (tid + q * MTX_THREADS < MT_N) ? tid + q * MTX_THREADS : MT_N - 1;
     uint32_t win[3];       // the current window (segment start), three words per thread
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -264,22 +267,23 @@ __global__ __launch_bounds__(MTX_THREADS) void k_mt_segment_starts(const TargetM
                             gw &= gw - 1u;
                         }
                     }
+                    // every load unconditional (a predicated load becomes an exec-mask region with its own wait and branch - twelve of them per trip made
+                    // a jump 1.5 ms): the lanes of the third column group beyond word 623 read word 623's slot again, their sums are never stored
                     uint32_t v[4][3];
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
                         for (int q = 0; q < 3; ++q) {
-                            const int j = tid + q * MTX_THREADS;
-                            int idx = (base[u] < 0 ? 0 : base[u]) + j;
+                            int idx = (base[u] < 0 ? 0 : base[u]) + jcl[q];
                             idx -= (idx >= MTJ_RING) ? MTJ_RING : 0;
-                            v[u][q] = (j < MT_N) ? y[idx] : 0u;
+                            v[u][q] = y[idx];
                         }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (base[u] >= 0) {                                            // uniform
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t m = base[u] >= 0 ? 0xffffffffu : 0u;            // uniform
 #pragma unroll
-                            for (int q = 0; q < 3; ++q) acc[q] ^= v[u][q];
-                        }
+                        for (int q = 0; q < 3; ++q) acc[q] ^= v[u][q] & m;
+                    }
                 }
             }
             __syncthreads();                     // every read of block b0 is done: it becomes the block after b1's successor

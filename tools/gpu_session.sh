@@ -23,6 +23,7 @@ for step in "$@"; do
     probe_xl)     timeout 1500 python tools/probe_xl.py $arg --out "$O/probe_xl.json" 2>&1 | tail -12 ;;
     bench)        tag=$(echo "$arg" | tr -c 'a-zA-Z0-9' '_'); timeout 1500 python bench.py $arg > "$O/bench_$tag.json" 2> "$O/bench_$tag.err"; tail -c 1500 "$O/bench_$tag.json"; tail -3 "$O/bench_$tag.err" ;;
     rocprof)      tag=$(echo "$arg" | tr -c 'a-zA-Z0-9' '_'); (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$tag" -- python "$ROOT/bench.py" $arg > "$O/bench_under_rocprof_$tag.json" 2>/dev/null); stats_csv "$O/prof_$tag" "$O/kernel_stats_$tag.csv"; head -8 "$O/kernel_stats_$tag.csv" | cut -c1-200 ;;
+    rocprofpy)    tag=$(echo "$arg" | tr -c 'a-zA-Z0-9' '_'); (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$tag" -- python $ROOT/$arg > "$O/rocprofpy_$tag.log" 2>&1); stats_csv "$O/prof_$tag" "$O/kernel_stats_$tag.csv"; head -12 "$O/kernel_stats_$tag.csv" | cut -c1-70,200-330 ;;
     py)           timeout 1500 python $arg 2>&1 | tail -30 ;;
     sh)           timeout 1500 bash $arg 2>&1 | tail -30 ;;
     *)            echo "unknown step $s" ;;
