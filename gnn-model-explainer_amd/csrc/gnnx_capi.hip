@@ -287,9 +287,14 @@ struct gnnx_plan_s {
     float* d_watt = nullptr;         // method="att": attention weights of the three layers (gnnx_set_att_weights); every run takes k_att
     // the resident kernels run beside the streaming launches, each group on its own stream:
     // [0..RES_NBMAX) dense resident kernels by row blocks, [RES_NBMAX + k] sparse resident kernel of size class k
-    hipEvent_t ev_in = nullptr, ev_out[N_SIDE] = {};
-    hipEvent_t ev_t0[N_SIDE] = {};   // start of the resident launch on its side stream (timed, for gnnx_resident_times)
-    bool launched[N_SIDE] = {};
+    hipEvent_t ev_in = nullptr, ev_out[N_SIDE + 1] = {};   // (slot N_SIDE: the packed single-wave launch, k_sparse_resident_tiny*)
+    hipEvent_t ev_t0[N_SIDE + 1] = {};   // start of the resident launch on its side stream (timed, for gnnx_resident_times)
+    bool launched[N_SIDE + 1] = {};
+    // Packed single-wave targets (k_sparse_resident_tiny16 / 12, gnnx_sparse.hpp): tiny_pack[t] = 1 for the targets of the 64-thread class whose
+    // slim LDS form fits a slice; they come FIRST in d_sp[2] (n_tiny_pack of them) and take their own launch, the others run where they ran.
+    std::vector<char> tiny_pack;
+    int n_tiny_pack = 0;
+    int tiny_per_cu = 0;             // 16 / 12: single-wave targets per compute unit of the packed launch; 0: no packed launch (GNNX_TINY_PACK)
     std::vector<int> order;          // targets, largest first
     std::vector<int> cat;            // per target: 0 streaming, 1..RES_NBMAX dense resident kernel of that many row blocks, CAT_SPARSE
     int xconst = 0;                  // every target of the sparse resident classes has constant feature rows (gnnx_plan_analyze_features):
@@ -512,12 +517,13 @@ static int build_split(gnnx_handle h, bool upload) {
     h->n_unit_big = h->n_join_big = 0;
     std::vector<ConvTile> conv_big;
     long long n_mask_big = 0;
-    std::vector<int32_t> res_ids, sp_ids[N_SPC], big_ids;
+    std::vector<int32_t> res_ids, sp_ids[N_SPC], big_ids, packed_ids;
     for (int k = 0; k <= RES_NBMAX; ++k) h->res_count[k] = h->res_first[k] = 0;
     for (int t : h->order) {  // sorted by ld: the dense resident groups are contiguous
         const int nb = h->meta[t].ld / TILE, c = h->cat[t];
         if (c >= CAT_SPARSE) {
             sp_ids[c - CAT_SPARSE].push_back(t);
+            if (c == CAT_SPARSE + 2 && !h->tiny_pack.empty() && h->tiny_pack[t]) packed_ids.push_back(t);
         } else if (c >= 1) {
             if (h->res_count[nb]++ == 0) h->res_first[nb] = (int)res_ids.size();
             res_ids.push_back(t);
@@ -526,6 +532,14 @@ static int build_split(gnnx_handle h, bool upload) {
             for (int rb = 0; rb < nb; ++rb) conv_big.push_back({t, rb, h->meta[t]});
             n_mask_big += (long long)nb * (nb + 1) / 2;   // the tile pairs themselves: on first use (ensure_mask_big)
         }
+    }
+    h->n_tiny_pack = (int)packed_ids.size();
+    if (h->n_tiny_pack) {   // the packed targets lead the 64-thread class's list (both parts keep the plan's order)
+        std::vector<int32_t> rest;
+        for (int t : sp_ids[2])
+            if (!h->tiny_pack[t]) rest.push_back(t);
+        sp_ids[2] = packed_ids;
+        sp_ids[2].insert(sp_ids[2].end(), rest.begin(), rest.end());
     }
     h->big_ids = big_ids;
     h->n_res = (int)res_ids.size();
@@ -557,8 +571,8 @@ static int build_split(gnnx_handle h, bool upload) {
     if (any_resident && !h->ev_in) SPLITCK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     // (Disjoint compute-unit masks for the sparse and the single-tile dense launch - hipExtStreamCreateWithCUMask - were
     // measured on syn1 and made the sparse launch slower, 9.7 vs 6.4 ms in situ: not used.)
-    for (int k = 0; k < N_SIDE; ++k) {
-        const bool need = k < RES_NBMAX ? h->res_count[k + 1] > 0 : h->n_sp[k - RES_NBMAX] > 0;
+    for (int k = 0; k <= N_SIDE; ++k) {
+        const bool need = k == N_SIDE ? h->n_tiny_pack > 0 : k < RES_NBMAX ? h->res_count[k + 1] > 0 : h->n_sp[k - RES_NBMAX] > 0;
         if (need && !h->ev_out[k]) {
             SPLITCK(hipEventCreate(&h->ev_out[k]));
             SPLITCK(hipEventCreate(&h->ev_t0[k]));
@@ -734,7 +748,7 @@ extern "C" int gnnx_destroy(gnnx_handle h) {
                     // its tables to the next plan under them
     for (auto& b : h->busy) (void)hipEventDestroy(b.second);
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
-    for (int k = 0; k < N_SIDE; ++k) {
+    for (int k = 0; k <= N_SIDE; ++k) {
         if (h->ev_out[k]) (void)hipEventDestroy(h->ev_out[k]);
         if (h->ev_t0[k]) (void)hipEventDestroy(h->ev_t0[k]);
     }
@@ -1273,7 +1287,7 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
             }
         }
         HIPCK(hipEventRecord(h->ev_in, s));
-        for (int k = 0; k < N_SIDE; ++k) h->launched[k] = false;      // (which groups launch can change between runs: a class may ride in the mixed launch)
+        for (int k = 0; k <= N_SIDE; ++k) h->launched[k] = false;      // (which groups launch can change between runs: a class may ride in the mixed launch)
         // Launch order: sparse resident kernel (gnnx_plan_analyze), largest size class FIRST - its workgroups need a whole
         // CU (1024 threads x 128 VGPRs), so they must be placed before the small workgroups of the other launches spread
         // over every CU (measured on syn1: 21.5 -> 13.4 ms) - then the dense resident kernels.  Every group has its own
@@ -1287,13 +1301,21 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
         // node-mode batches of 512-thread and single-tile (64-thread class) targets: ONE launch (k_sparse_resident_mixed)
         // (with pair workgroups the 256-thread class rides in the same launch, two targets to a workgroup: h->pair256)
         const bool pairs = !h->prob.graph_mode && h->pair256 && h->n_sp[1] > 0;
+        // the packed single-wave targets lead d_sp[2] and take their own launch (below); the logging forms keep the classes' own bodies
+        const int n_pack = (h->tiny_per_cu && !log_resident && h->xconst == 2 && exact_shape(h, 10)) ? h->n_tiny_pack : 0;
+        const int32_t* tiny_ids = h->d_sp[2] ? h->d_sp[2] + n_pack : nullptr;
+        const int n_tiny = h->n_sp[2] - n_pack;
         const bool mixed = !h->prob.graph_mode && ((h->n_sp[SPC_512] > 0 && h->n_sp[2] > 0) || pairs);
         const int mixed_at = !mixed ? -1 : h->n_sp[SPC_512] > 0 ? SPC_512 : pairs ? 1 : 2;     // the class whose turn in the launch order starts the mixed launch
-        auto own_launch = [&](int k) { return h->n_sp[k] > 0 && (!mixed || k == mixed_at || !(k == 2 || k == SPC_512 || (pairs && k == 1))); };
+        auto own_launch = [&](int k) {
+            if (k == 2 && n_tiny == 0 && (!mixed || mixed_at != 2)) return false;      // the whole class went to the packed launch
+            if (mixed && k == mixed_at && h->n_sp[SPC_512] == 0 && !pairs && n_tiny == 0) return false;   // (a mixed launch of single-wave targets only, all packed)
+            return h->n_sp[k] > 0 && (!mixed || k == mixed_at || !(k == 2 || k == SPC_512 || (pairs && k == 1)));
+        };
         // A run whose targets all sit in ONE launch group (syn1 / syn4 / syn5: the mixed launch; config 4: the 256-thread class) needs no
         // side lane at all - nothing has to overlap inside the run: it goes to the caller's stream.  Fewer busy streams = fewer
         // hardware queues (HIP has eight at most) for the streams of a pipelined job to collide with.
-        int n_groups = 0;
+        int n_groups = n_pack > 0;
         for (int k = 0; k < N_SPC; ++k) n_groups += own_launch(k);
         for (int nb = 1; nb <= RES_NBMAX; ++nb) n_groups += h->res_count[nb] > 0;
         const bool single_group = n_groups == 1 && !streaming;
@@ -1305,6 +1327,20 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
             return st ? st : s;
         };
         const int launch_order[N_SPC] = {SPC_LARGE, 0, SPC_512, 1, 2};   // the longest workgroups first, then the other whole-CU ones
+        bool packed_done = n_pack == 0;
+        auto launch_packed = [&]() -> void {
+            if (packed_done) return;
+            packed_done = true;
+            hipStream_t ss = group_stream(N_SIDE);
+            if (ss != s) (void)hipStreamWaitEvent(ss, h->ev_in, 0);
+            (void)hipEventRecord(h->ev_t0[N_SIDE], ss);
+            h->launched[N_SIDE] = true;
+            if (h->tiny_per_cu == 16)
+                hipLaunchKernelGGL((k_sparse_resident_tiny16<5, 10, 2>), dim3((n_pack + 7) / 8), dim3(512), 0, ss, p, h->d_sp[2], n_pack, h->d_adam);
+            else
+                hipLaunchKernelGGL((k_sparse_resident_tiny12<5, 10, 2>), dim3((n_pack + 3) / 4), dim3(256), 0, ss, p, h->d_sp[2], n_pack, h->d_adam);
+            (void)hipEventRecord(h->ev_out[N_SIDE], ss);
+        };
         for (int ko = 0; ko < N_SPC; ++ko) {
             const int k = launch_order[ko];
             if (!own_launch(k)) continue;
@@ -1317,36 +1353,40 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
                 const int per_wg = sp_mix_tiny(h->prob.D, h->prob.H, h->prob.C);   // single-tile targets per workgroup
                 const int n_pair = pairs ? h->n_sp[1] : 0;
                 const int32_t* pair_ids = pairs ? h->d_sp[1] : nullptr;
-                const dim3 grid(h->n_sp[SPC_512] + (n_pair + 1) / 2 + (h->n_sp[2] + per_wg - 1) / per_wg), block(512);
+                const dim3 grid(h->n_sp[SPC_512] + (n_pair + 1) / 2 + (n_tiny + per_wg - 1) / per_wg), block(512);
                 if (log_resident && h->xconst == 2)
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, 2, true>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
-                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
+                                       tiny_ids, n_tiny, h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
                 else if (log_resident)
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, 0, true>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
-                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
+                                       tiny_ids, n_tiny, h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
                 else if (exact_shape(h, 10) && h->xconst == 2)
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, 2>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
-                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
+                                       tiny_ids, n_tiny, h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
                 else if (exact_shape(h, 10) && h->xconst == 1)
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, 1>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
-                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
+                                       tiny_ids, n_tiny, h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
                 else if (exact_shape(h, 10))
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
-                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
+                                       tiny_ids, n_tiny, h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
                 else if (small_shape(h, 10))
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, 0, false, false>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
-                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
+                                       tiny_ids, n_tiny, h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
                 else if (wide_shape(h, 10))
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 16, 0, false, false>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
-                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
+                                       tiny_ids, n_tiny, h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
                 else
                     hipLaunchKernelGGL((k_sparse_resident_mixed<16, 16>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
-                                       h->d_sp[2], h->n_sp[2], h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
+                                       tiny_ids, n_tiny, h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
+            } else if (k == 2) {
+                launch_sparse_nt<64>(h, p, tiny_ids, n_tiny, h->d_adam, ss, log_resident);
             } else {
                 launch_sparse(h, p, k, h->d_adam, ss, log_resident);
             }
             HIPCK(hipEventRecord(h->ev_out[g], ss));
+            if (k == SPC_512 || (mixed && k == mixed_at)) launch_packed();   // behind the whole-CU workgroups, ahead of nothing that needs a whole CU
         }
+        launch_packed();
         for (int nb = RES_NBMAX; nb >= 1; --nb) {  // largest targets first
             if (!h->res_count[nb]) continue;
             hipStream_t ss = group_stream(nb - 1);
@@ -1397,12 +1437,24 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
             if (h->res_count[k + 1]) HIPCK(hipStreamWaitEvent(s, h->ev_out[k], 0));
         for (int k = 0; k < N_SPC; ++k)
             if (h->n_sp[k] && h->launched[RES_NBMAX + k]) HIPCK(hipStreamWaitEvent(s, h->ev_out[RES_NBMAX + k], 0));
+        if (h->launched[N_SIDE]) HIPCK(hipStreamWaitEvent(s, h->ev_out[N_SIDE], 0));
     }
     if (feat_mask)
         HIPCK(hipMemcpyAsync(feat_mask, p.f[hy->num_iters & 1], sizeof(float) * h->prob.num_targets * FS,
                              hipMemcpyDeviceToDevice, s));
     HIPCK(hipGetLastError());
     mark_busy(h, s);
+    return 0;
+}
+
+extern "C" int gnnx_tiny_pack_info(gnnx_handle h, int32_t* per_cu, int32_t* n_packed, int32_t* flags) {
+    if (!h) return fail("null argument");
+    const bool on = h->tiny_per_cu && h->n_tiny_pack > 0;
+    if (per_cu) *per_cu = on ? h->tiny_per_cu : 0;
+    if (n_packed) *n_packed = on ? h->n_tiny_pack : 0;
+    if (flags)
+        for (int t = 0; t < h->prob.num_targets; ++t)
+            flags[t] = on && t < (int)h->tiny_pack.size() && h->tiny_pack[t] && h->cat[t] == CAT_SPARSE + 2;
     return 0;
 }
 
@@ -1413,6 +1465,12 @@ extern "C" int gnnx_resident_times(gnnx_handle h, float* ms) {
         if (!h->launched[k]) continue;
         HIPCK(hipEventSynchronize(h->ev_out[k]));
         HIPCK(hipEventElapsedTime(&ms[k], h->ev_t0[k], h->ev_out[k]));
+    }
+    if (h->launched[N_SIDE]) {   // the packed single-wave launch: reported in the 64-thread class's slot (it runs beside that class's other launch, if any)
+        float t = 0.0f;
+        HIPCK(hipEventSynchronize(h->ev_out[N_SIDE]));
+        HIPCK(hipEventElapsedTime(&t, h->ev_t0[N_SIDE], h->ev_out[N_SIDE]));
+        ms[RES_NBMAX + 2] = std::max(ms[RES_NBMAX + 2], t);
     }
     return 0;
 }
@@ -1608,6 +1666,25 @@ static int analyze_impl(gnnx_handle h, const float* A, const float* X, hipStream
         int xc_form = 2;   // GNNX_XCONST = 0 / 1 / 2: general form / bit-identical constant-feature form / algebraic form (default)
         if (const char* env = std::getenv("GNNX_XCONST")) xc_form = std::max(0, std::min(2, std::atoi(env)));
         h->xconst = (any && all && exact_shape(h, 10)) ? xc_form : 0;
+    }
+    // Packed single-wave launch (k_sparse_resident_tiny16 / 12): the targets of the 64-thread class whose slim LDS form fits a slice, when the
+    // plan runs the algebraic constant-feature form at the reference's widths.  GNNX_TINY_PACK = 16 (default) / 12 / 0 (off).
+    {
+        int per_cu = 16;
+        if (const char* env = std::getenv("GNNX_TINY_PACK")) per_cu = std::atoi(env);
+        if (per_cu != 16 && per_cu != 12) per_cu = 0;
+        const bool form_ok = per_cu && !graph && h->xconst == 2 && exact_shape(h, 10) && h->prob.C <= 4;
+        std::vector<char> flags(T, 0);
+        if (form_ok)
+            for (int t = 0; t < T; ++t) {
+                const TargetMeta& m = h->meta[t];
+                flags[t] = h->cat[t] == CAT_SPARSE + 2 &&
+                           sparse_fits(64, m.n, m.ld, h->nnz[2 * t], h->nnz[2 * t + 1], h->prob.D, h->prob.H, h->prob.C, 0, h->prob.O,
+                                       per_cu == 16 ? tiny_pool_floats(16) : tiny_pool_floats(12));
+            }
+        changed |= flags != h->tiny_pack;
+        h->tiny_pack.swap(flags);
+        h->tiny_per_cu = form_ok ? per_cu : 0;
     }
     if (changed || h->split_dirty) {
         if (int rc = build_split(h)) return rc;

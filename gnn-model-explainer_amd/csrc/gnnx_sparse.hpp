@@ -72,19 +72,23 @@ struct SparseLayout {
 // graph = 0: node mode (GcnEncoderNode: only row t of layer 3 is needed; dZ2 overwrites U2);
 // graph = 1: graph mode (GcnEncoderGraph: all three layers in full, U3 [ld][max(H, O)] overwritten by dZ3, dZ2 separate)
 // n rows of the big row arrays (rows >= n are never touched), ld = round_up(n, 32) entries of the per-row scalars
-__host__ __device__ inline SparseLayout sparse_layout(int n, int ld, int nnz, int D, int H, int C, int graph = 0, int O = 0) {
+// slim = 1 (k_sparse_resident_tiny: single-wave targets of the algebraic constant-feature form, model block shared by the workgroup): X is
+// one row (every row equals it), the dZ1 array one float per row (the per-row scalar ci = dY1 . wt is all that form keeps of dZ1), no
+// private model block; the arrays the setup's temporaries alias are padded to the temporaries' size.
+__host__ __device__ inline SparseLayout sparse_layout(int n, int ld, int nnz, int D, int H, int C, int graph = 0, int O = 0, int slim = 0) {
     SparseLayout L;
     L.sD = D | 1;
     L.sH = H | 1;
     L.sO = (O > H ? O : H) | 1;
     int o = 0;
-    L.oX = o;      o += n * L.sD;
+    L.oX = o;      o += (slim ? 1 : n) * L.sD;
     L.oU1 = o;     o += n * L.sH;
     L.oU2 = o;     o += n * L.sH;   // U2; node mode: overwritten row by row with dZ2 once the row's U2 has been consumed
     L.oU3 = o;     o += graph ? n * L.sO : 0;
     L.odZ2 = graph ? o : L.oU2;
     o += graph ? n * L.sH : 0;
-    L.odZ1 = o;    o += n * L.sD;
+    L.odZ1 = o;    o += slim ? ld : n * L.sD;
+    if (slim && o < 7 * ld + 2 * 16 + 8) o = 7 * ld + 2 * 16 + 8;   // the setup's temporaries (7 ld + 2 SP_CHUNK + 8 ints) live in front of Abar
     L.oAb = o;     o += nnz;
     L.oGe = o;     o += graph ? 0 : nnz;  // node mode: dL/dAbar per directed entry (row-side product), written by the layer-1 backward
     L.oCol = o;    o += (nnz + 1) / 2;  // uint16 columns
@@ -95,18 +99,19 @@ __host__ __device__ inline SparseLayout sparse_layout(int n, int ld, int nnz, in
     L.oRn3 = o;    o += graph ? ld : 0;
     L.oYhat = o;   o += ld;
     L.oG3 = o;     o += ld;
-    L.oW = o;      o += (D + 2 * H) * 33;  // rows k < D of W1, k < H of W2, k < H of W3, 33-float rows
-    L.oWp = o;     o += C * 96;
+    L.oW = o;      o += slim ? 0 : (D + 2 * H) * 33;  // rows k < D of W1, k < H of W2, k < H of W3, 33-float rows
+    L.oWp = o;     o += slim ? 0 : C * 96;
     L.total = o;
     return L;
 }
 // does a target fit the class of nt threads?  (slots: row slots it needs with EVERY row placed, from k_count_edges)
 __host__ __device__ inline bool sparse_fits(int nt, int n, int ld, int nnz, int slots, int D, int H, int C, int graph = 0,
-                                            int O = 0) {
+                                            int O = 0, int slim_pool = 0) {
     // the setup's temporaries (7 ld + 2 SP_CHUNK + 8 ints) live in the X / U1 / U2 / dZ1 arrays, which are contiguous
+    // slim_pool > 0: the slim layout in a pool of that many floats (k_sparse_resident_tiny)
     return ld <= sp_ld_max(nt) && nnz / 2 <= sp_qmax(nt) * nt && nnz < 65536 && slots >= 0 && slots <= nt / 2 &&
-           C <= RES_CMAX && H >= 2 && 2 * n * ((H | 1) + (D | 1)) >= 7 * ld + 2 * SP_CHUNK + 8 &&
-           sparse_layout(n, ld, nnz, D, H, C, graph, O).total <= sp_pool_floats(nt);
+           C <= RES_CMAX && H >= 2 && (slim_pool || 2 * n * ((H | 1) + (D | 1)) >= 7 * ld + 2 * SP_CHUNK + 8) &&
+           sparse_layout(n, ld, nnz, D, H, C, graph, O, slim_pool ? 1 : 0).total <= (slim_pool ? slim_pool : sp_pool_floats(nt));
 }
 
 // a lane's row slot in one row set: the row (valid when first), its chunk of entries, the split bookkeeping
@@ -119,20 +124,30 @@ struct RowSlot {
     unsigned bmask_hi;  // entries 32..63 (k_sparse_large: 64-entry slots)
 };
 
-struct SparseFixed {
+// SLIM (round 6, k_sparse_resident_tiny): the block of a single-wave target of the algebraic node-mode form - the members only the LDS
+// form of the head, graph mode, the logging form or the larger classes touch shrink to one element (those code paths are never
+// taken there: the register head is unconditional for one wave, see `reg_head`), dfw to the two rows one wave writes: 521 floats
+// instead of 1340, so that sixteen targets fit one compute unit's LDS.
+template <bool SLIM>
+struct SparseFixedT {
+    static constexpr bool slim = SLIM;
+    static constexpr int NWF = SLIM ? 2 : SP_THREADS / 64;
+    static constexpr int LX = SLIM ? 1 : 32, LX96 = SLIM ? 1 : 96;
     float sbp[CMAX];
     float phi[32], fcur[32], mf[32], vf[32], bias[3][32];
-    float z3[32], y3[32], dz3[32], e[96], g[CMAX], dEs[96], dfp[32], dfw[SP_THREADS / 64][32];
+    float z3[LX], y3[LX], dz3[32], e[LX96], g[CMAX], dEs[96], dfp[32], dfw[NWF][32];
     float sr3;
     int nnz, eup, bad;
     int xconst;  // node mode: every feature row of the sub-graph equals row 0 bit for bit (constant / featureless inputs)
     int set_rows[2], set_slots[2];
     int set_chunk[2];  // entries per row slot of the set: the smallest of {4, 8, 16} (8, 16 for set A) whose slots fit the class
     int chunk_b;       // node mode, set A: slot width of the rows of t and its neighbours (<= set_chunk[0]; see "slot width per row")
-    int erow[96];  // graph mode: arg-max row of every pooled column
-    float wt[32], vsum[32];  // algebraic constant-feature form: (x (.) phi) W1; vsum (sum over the rows of s_r dY1[r]) lives in wave 0's registers since round 4 - the slot keeps the struct's size, which the LDS budget of the mixed launch is built on
-    float lsum[SP_THREADS / 64][6];  // LOG form: per-wave partial sums over the owned edges: the logged size / entropy / Laplacian terms, [3] the masked adjacency AFTER the step and [4] the adjacency (mask density, explain.py:680-683)
+    int erow[LX96];  // graph mode: arg-max row of every pooled column
+    float wt[32], vsum[LX];  // algebraic constant-feature form: (x (.) phi) W1; vsum (sum over the rows of s_r dY1[r]) lives in wave 0's registers since round 4 - the slot keeps the struct's size, which the LDS budget of the mixed launch is built on
+    float lsum[SLIM ? 1 : SP_THREADS / 64][6];  // LOG form: per-wave partial sums over the owned edges: the logged size / entropy / Laplacian terms, [3] the masked adjacency AFTER the step and [4] the adjacency (mask density, explain.py:680-683)
 };
+using SparseFixed = SparseFixedT<false>;
+using SparseFixedSlim = SparseFixedT<true>;
 
 // every lane of a wave has finished its LDS accesses before any lane continues (LDS operations of one wave
 // execute in order; the fences keep the compiler from moving accesses across)
@@ -420,9 +435,13 @@ __device__ __forceinline__ void sparse_combine(float (&acc)[NQ], int rem, int ws
 // EX = false: the trip counts DQ / HQ bound the widths (D <= 2 DQ, H, O <= 2 HQ) but the widths themselves are run-time values - encoders whose
 // widths are not the reference's take the SMALLEST such instantiation that holds them instead of the 32-wide one (round 5: <16, 16> carries
 // 700-1000 B of scratch per lane and ran a --hidden-dim 16 encoder 4x slower than the reference's widths; profiles/r05_generic_widths_syn1.txt).
-template <int DQ, int HQ, bool GRAPH, int NT, int XC = 0, bool LOG = false, bool EX = true>
-__device__ __forceinline__ void sparse_resident_body(const Params p, int t, const float* adam_tab, float* pool, SparseFixed& sh,
-                                                     int tid, float* shared_w = nullptr, int* pair_flag = nullptr) {
+// SH = SparseFixedSlim + slim_pool > 0 (floats of `pool`): the slim LDS form of a single-wave target (sparse_layout: slim) - same arithmetic,
+// same order, so bit-identical to the full form; k_sparse_resident_tiny packs sixteen such targets on a compute unit.
+template <int DQ, int HQ, bool GRAPH, int NT, int XC = 0, bool LOG = false, bool EX = true, class SH = SparseFixed>
+__device__ __forceinline__ void sparse_resident_body(const Params p, int t, const float* adam_tab, float* pool, SH& sh,
+                                                     int tid, float* shared_w = nullptr, int* pair_flag = nullptr, int slim_pool = 0) {
+    constexpr bool SLIM = SH::slim;
+    static_assert(!SLIM || (NT == 64 && XC == 2 && !LOG && !GRAPH && EX), "the slim form: single-wave targets of the algebraic node-mode form, exact widths");
     constexpr int SCAN = (sp_ld_max(NT) + 63) / 64;  // rows per lane in the setup prefix scans
     constexpr int SP_QMAX = sp_qmax(NT);
     auto SYNC = []() {
@@ -480,7 +499,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     }
     SYNC();
     const int nnz = ld_ok ? sh.nnz : 0;
-    const bool fits = ld_ok && sparse_fits(NT, n, ld, nnz, 0, D, H, C, GRAPH, O);  // the slot count is checked once the slots are placed
+    const bool fits = ld_ok && sparse_fits(NT, n, ld, nnz, 0, D, H, C, GRAPH, O, SLIM ? slim_pool : 0) && (!SLIM || (slim_pool > 0 && shared_w));  // the slot count is checked once the slots are placed
     if (!fits) {
         // the plan promised a target that fits (gnnx_plan_analyze); anything else must fail loudly, not silently
         const float qnan = __builtin_nanf("");
@@ -488,7 +507,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = qnan;
         return;
     }
-    const SparseLayout L = sparse_layout(n, ld, nnz, D, H, C, GRAPH, O);
+    const SparseLayout L = sparse_layout(n, ld, nnz, D, H, C, GRAPH, O, SLIM ? 1 : 0);
     // rowptr currently sits at the start of the pool = inside the future sX region: move it through registers
     const int rp_keep = (tid < ld) ? tmp_deg[tid] : nnz;
     SYNC();
@@ -823,11 +842,11 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         sU1[e] = 0.0f;
         sU2[e] = 0.0f;
     }
-    for (int e = tid; e < n * sD; e += NT) sdZ1[e] = 0.0f;
+    for (int e = tid; e < (SLIM ? ld : n * sD); e += NT) sdZ1[e] = 0.0f;   // (slim form: one float per row, see sparse_layout)
     if (!GRAPH)  // entries of rows beyond two hops are never written: their row-side products are exactly zero
         for (int e = tid; e < nnz; e += NT) sGe[e] = 0.0f;
     // ---------------- load features, model, labels ----------------
-    for (int e = tid; e < n * 32; e += NT) {
+    for (int e = tid; e < (SLIM ? 1 : n) * 32; e += NT) {   // (slim form: row 0 stands for every row; verified against the others below)
         const int r = e >> 5, c = e & 31;
         // (the padding column of an even D is written too: the run-time-width forms multiply it by an exact zero, and 0 x stale LDS garbage
         // is NaN when the garbage is - found by the D = 8 case of test_mixed_launch_with_other_encoder_widths on the GPU, round 5)
@@ -865,7 +884,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         bool same = true;
         for (int e = tid; e < n * D; e += NT) {
             const int r = e / D, c = e - r * D;
-            same &= __float_as_uint(sX[r * sD + c]) == __float_as_uint(sX[c]);
+            if constexpr (SLIM) same &= __float_as_uint(p.X[(tm.offR + r) * FS + c]) == __float_as_uint(sX[c]);   // (the other rows stay in global memory)
+            else same &= __float_as_uint(sX[r * sD + c]) == __float_as_uint(sX[c]);
         }
         if (!same) sh.xconst = 0;
     }
@@ -1927,6 +1947,42 @@ __global__ __launch_bounds__(512) GNNX_MIXED_ATTR void k_sparse_resident_mixed(P
     SparseFixed* shp = reinterpret_cast<SparseFixed*>(pool + wsz + per_wg * slice) + wave;
     sparse_resident_body<DQ, HQ, false, 64, XC, LOG, EX>(p, tiny_ids[idx], adam_tab, pool + wsz + wave * slice, *shp, lane, pool);
 }
+
+// Packed single-wave targets (round 6: VERDICT r5 item 2, "sixteen one-wave chains per CU").  A single-wave target's iteration is a latency
+// chain that issues a fifth of one SIMD's cycles; what bounds a saturated batch is how many chains a compute unit holds.  In the mixed launch
+// (and in the 64-thread class's own launch) that was 8 (6): 188-218 registers per lane and 20 KB of LDS + a 5.4 KB SparseFixed each.  Here:
+//   * the slim LDS form (sparse_layout: slim, SparseFixedSlim): <= TINY_SLICE floats per target, the model block shared by the workgroup;
+//   * NWG targets per workgroup, one per wave, the workgroup's registers capped so that `PER_CU` waves share a compute unit:
+//       PER_CU = 16: 8 waves x 2 workgroups, 128 registers per lane, 80 KB of LDS per workgroup;
+//       PER_CU = 12: 4 waves x 3 workgroups, 168 registers, 52.5 KB;
+//   * exact widths of the reference's node encoder (D = 10, H = O = 20), C <= 4, the algebraic constant-feature form (XC = 2), no logging:
+//     everything else keeps the classes above.  Same body, same arithmetic, same order: bit-identical to them (tests/test_tiny_pack.py).
+// Which targets qualify is decided by the plan (gnnx_capi.hip: tiny_pack_fits); the rest of the 64-thread class runs where it ran.
+constexpr int TINY_W = (10 + 2 * 20) * 33 + 4 * 96;     // the shared model block: W1 | W2 | W3 (33-float rows) | four head rows
+__host__ __device__ constexpr int tiny_nwg(int per_cu) { return per_cu == 16 ? 8 : 4; }
+// floats per target (pool slice + SparseFixedSlim): LDS is allocated in 1280-byte granules, 128 of them per compute unit
+__host__ __device__ constexpr int tiny_slice(int per_cu) {
+    return ((128 / (per_cu / tiny_nwg(per_cu))) * 320 - TINY_W) / tiny_nwg(per_cu);
+}
+__host__ __device__ constexpr int tiny_fixed_floats() { return (int)((sizeof(SparseFixedSlim) + 3) / 4); }
+__host__ __device__ constexpr int tiny_pool_floats(int per_cu) { return tiny_slice(per_cu) - tiny_fixed_floats(); }
+#define GNNX_TINY_KERNEL(NAME, PER_CU, NUM_VGPR)                                                                                              \
+    template <int DQ, int HQ, int XC>                                                                                                         \
+    __global__ __launch_bounds__(64 * tiny_nwg(PER_CU)) GNNX_NUM_VGPR_ATTR(NUM_VGPR) void NAME(Params p, const int32_t* ids, int n_ids,     \
+                                                                                               const float* adam_tab) {                       \
+        constexpr int NWG = tiny_nwg(PER_CU), SLICE = tiny_slice(PER_CU), POOL = tiny_pool_floats(PER_CU);                                    \
+        __shared__ float lds[TINY_W + NWG * SLICE];                                                                                           \
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                                                                           \
+        const int idx = (int)blockIdx.x * NWG + wave;                                                                                         \
+        if (idx >= n_ids) return;   /* whole waves leave: the single-wave body has no workgroup barrier */                                   \
+        float* mine = lds + TINY_W + wave * SLICE;                                                                                            \
+        SparseFixedSlim* shp = reinterpret_cast<SparseFixedSlim*>(mine + POOL);                                                               \
+        sparse_resident_body<DQ, HQ, false, 64, XC, false, true, SparseFixedSlim>(p, ids[idx], adam_tab, mine, *shp, lane, lds, nullptr, POOL); \
+    }
+GNNX_TINY_KERNEL(k_sparse_resident_tiny16, 16, 64)
+GNNX_TINY_KERNEL(k_sparse_resident_tiny12, 12, 84)
+#undef GNNX_TINY_KERNEL
+static_assert(2 * (TINY_W + 8 * tiny_slice(16)) * 4 <= 160 * 1024 && 3 * (TINY_W + 4 * tiny_slice(12)) * 4 <= 160 * 1024, "LDS of a compute unit");
 
 // per target: directed off-diagonal non-zeros of its block of the packed adjacency and the row slots the sparse
 // resident kernel would need (-1: more than SP_LD_MAX rows) -> out[2 t], out[2 t + 1]   (gnnx_plan_analyze)

@@ -175,6 +175,7 @@ _API = {
     "gnnx_gather_edges": (ctypes.c_int, [ctypes.c_void_p] * 9 + [ctypes.c_size_t, ctypes.c_void_p]),
     "gnnx_pool_trim": (ctypes.c_int, []),
     "gnnx_sparse_tiny_per_workgroup": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "gnnx_tiny_pack_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "gnnx_set_service_stream": (ctypes.c_int, [ctypes.c_void_p]),
     "gnnx_lane_stream": (ctypes.c_void_p, [ctypes.c_int32]),
     "gnnx_stream_create_cu_mask": (ctypes.c_void_p, [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int32]),
@@ -940,6 +941,18 @@ class MaskOptimJob:
         ms = (ctypes.c_float * 8)()
         _check(self.lib, self.lib.gnnx_resident_times(self.handle, ms))
         return [float(x) for x in ms]
+
+    def tiny_pack(self):
+        """(targets per compute unit, targets) of the packed single-wave launch of this plan - (0, 0) when it has none (include/gnnx.h)."""
+        per_cu, cnt = ctypes.c_int32(), ctypes.c_int32()
+        _check(self.lib, self.lib.gnnx_tiny_pack_info(self.handle, ctypes.byref(per_cu), ctypes.byref(cnt), None))
+        return int(per_cu.value), int(cnt.value)
+
+    def tiny_packed(self):
+        """bool [T]: the targets the packed single-wave launch takes."""
+        f = np.zeros(self.T, np.int32)
+        _check(self.lib, self.lib.gnnx_tiny_pack_info(self.handle, None, None, f.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
+        return f.astype(bool)
 
     def route(self):
         """Kernel of every target: 0 dense streaming, 1..3 dense resident (row blocks), 4 / 5 / 6 sparse resident

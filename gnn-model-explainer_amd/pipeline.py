@@ -200,19 +200,24 @@ class BatchPipeline:
         return buf[:numel]
 
     @staticmethod
-    def _launch_cus(route, num_cus=256):
+    def _launch_cus(route, num_cus=256, tiny_pack=(0, 0)):
         """Compute units one optimisation launch of this batch keeps busy (an estimate from the routing: gnnx_sparse.hpp's classes - a 512-thread
         target, a PAIR of 256-thread targets or eight single-wave targets per workgroup of the mixed launch, one workgroup per CU; alone, the
-        single-wave class packs six workgroups per CU and the 256-thread class two)."""
+        single-wave class packs six workgroups per CU and the 256-thread class two; the packed single-wave launch, `tiny_pack` = (targets per
+        CU, targets), sixteen or twelve targets per CU)."""
         route = np.asarray(route)
         n8, n5, n6 = int((route == 8).sum()), int((route == 5).sum()), int((route == 6).sum())
+        packed_cus = 0
+        if tiny_pack[0] and tiny_pack[1]:
+            n6 -= int(tiny_pack[1])
+            packed_cus = -(-int(tiny_pack[1]) // int(tiny_pack[0]))
         n47 = int(np.isin(route, (4, 7)).sum())
         other = int((~np.isin(route, (4, 5, 6, 7, 8))).sum())
         if n8 or (n5 and n6):
             cus = n8 + (n5 + 1) // 2 + (n6 + 7) // 8
         else:
             cus = (n5 + 1) // 2 + (n6 + 5) // 6
-        return min(cus + n47, num_cus) if not other else -1      # (-1: streaming targets in the batch)
+        return min(cus + n47 + packed_cus, num_cus) if not other else -1      # (-1: streaming targets in the batch)
 
     # -- stage 1 -----------------------------------------------------------------------------------------------------------
     def _prepare(self, targets, k, s_prep):
@@ -320,7 +325,7 @@ class BatchPipeline:
         rc_host[:E].copy_(job._rc[:E], non_blocking=True)
         p.times["edge_layout_ms"] = (time.perf_counter() - t1b) * 1e3
         p.times["plan_pack_route_layout_ms"] = (time.perf_counter() - t1) * 1e3
-        lc = self._launch_cus(job.route())
+        lc = self._launch_cus(job.route(), tiny_pack=job.tiny_pack())
         p.launch_cus = -1 if (lc < 0 or p.launch_cus < 0) else p.launch_cus + lc
         if edges_only and not np.isin(job.route(), (4, 5, 6, 7, 8)).all():
             edges_only = False        # a target streams dense blocks: it needs every entry of its mask

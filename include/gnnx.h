@@ -338,6 +338,13 @@ int gnnx_pool_trim(void);
  * block fit the pool, else as many as fit (>= 5).  bench.py maps targets to workgroups with it for the executed-work roofline. */
 int gnnx_sparse_tiny_per_workgroup(int32_t D, int32_t H, int32_t C);
 
+/* Packed single-wave launch (gnnx_sparse.hpp: k_sparse_resident_tiny16 / 12; round 6): targets of the 64-thread class (n <= 32) whose slim LDS
+ * form fits a slice run sixteen (GNNX_TINY_PACK=12: twelve) to a compute unit in a launch of their own, when the plan runs the algebraic
+ * constant-feature form at the reference's widths (gnnx_plan_analyze_features; D = 10, H = O = 20, C <= 4); bit-identical to the class's
+ * other launches (the same body).  *per_cu = 16 / 12, or 0 when the plan has no such launch; *n_packed = its targets; flags[t] = 1 for the
+ * targets it takes (num_targets ints).  Each may be NULL.  The loop the packed targets run is explain.py:137-146, as for every resident class. */
+int gnnx_tiny_pack_info(gnnx_handle h, int32_t* per_cu, int32_t* n_packed, int32_t* flags);
+
 /* ---- the XL route: node-mode targets of ANY size, CSR-native (csrc/gnnx_xl.hpp, k_sparse_large<.., XL> in csrc/gnnx_sparse_large.hpp) ----------------
  *
  * What the reference does per target in Explainer.explain (explain.py:80-117: `sub_adj = adj[nb][:, nb]`, `sub_feat`, ExplainModule with its dense
