@@ -1020,15 +1020,21 @@ def main():
         res_ms = {1: rt[0], 4: rt[3], 5: rt[4], 6: rt[5], 7: rt[6], 8: rt[7]}
         # ONE launch (k_sparse_resident_mixed) for the 512-thread targets, the single-tile targets (eight per workgroup) and - "pair" workgroups,
         # round 5 - the 256-thread targets two to a workgroup: it is timed in the slot of the class that starts it (512 threads, else 256)
-        pairs = bool((route == 5).any() and ((rt[7] and not rt[4]) or (rt[4] and not rt[5] and (route == 6).any() and not (route == 8).any())))
-        mixed = bool(((route == 6).any() and (route == 8).any() and not rt[5] and rt[7]) or pairs)
+        # packed single-wave launch (k_sparse_resident_tiny16 / 12, round 6): its targets and its time (reported in the 64-thread class's slot)
+        pack_per_cu, n_packed = job.tiny_pack()
+        packed = job.tiny_packed() if n_packed else np.zeros(len(route), bool)
+        rt5_own = 0.0 if n_packed else rt[5]      # the 64-thread class's OWN launch (with a packed launch the slot holds the larger of the two; the rest of the class is small)
+        pairs = bool((route == 5).any() and ((rt[7] and not rt[4]) or (rt[4] and not rt5_own and (route == 6).any() and not (route == 8).any())))
+        mixed = bool((((route == 6) & ~packed).any() and (route == 8).any() and not rt5_own and rt[7]) or pairs)
         mixed_rv = 8 if rt[7] else 5
+        if n_packed:
+            res_names[6] = f"k_sparse_resident_tiny{pack_per_cu} ({pack_per_cu} single-wave targets per workgroup = per compute unit, slim LDS form)"
         tiny_per_wg = int(engine.get_library().gnnx_sparse_tiny_per_workgroup(int(job.D), int(job.H), int(job.C)))   # sp_mix_tiny() of gnnx_sparse.hpp
         if mixed:
             res_names[mixed_rv] = (f"k_sparse_resident_mixed (512-thread targets" + (", 256-thread targets two per workgroup" if pairs else "") +
                                    f" + {tiny_per_wg} single-tile targets per workgroup)")
-        in_mixed = (route == 8) | (route == 6) | ((route == 5) if pairs else np.zeros(len(route), bool))
-        sel_of = {rv: in_mixed if (mixed and rv == mixed_rv) else (route == rv) for rv in res_ms}
+        in_mixed = (route == 8) | ((route == 6) & ~packed) | ((route == 5) if pairs else np.zeros(len(route), bool))
+        sel_of = {rv: in_mixed if (mixed and rv == mixed_rv) else (packed if (n_packed and rv == 6) else (route == rv)) for rv in res_ms}
         for rv, ms_v in res_ms.items():
             if ms_v:
                 launches[res_names[rv]] = {"targets": int(sel_of[rv].sum()), "ms_total": ms_v}
@@ -1075,9 +1081,11 @@ def main():
                     np_ = int((r_sel == 5).sum())
                     wg[r_sel == 5] = nb + np.arange(np_) // 2
                     wg[r_sel == 6] = nb + (np_ + 1) // 2 + np.arange(int((r_sel == 6).sum())) // tiny_per_wg
+                elif n_packed and rv == 6:
+                    wg = np.arange(len(idx)) // pack_per_cu
                 else:
                     wg = np.arange(len(idx))
-                b = wm.launch_bounds(fl, by, ch, args.iters, wg, wgs_per_cu.get(rv, 1))
+                b = wm.launch_bounds(fl, by, ch, args.iters, wg, 1 if (n_packed and rv == 6) else wgs_per_cu.get(rv, 1))
                 ms_meas = res_ms[rv]
                 t = {"flops": b["flops_s"], "lds": b["lds_s"], "chain": b["chain_s"]}
                 cnt = pmc_counts.get(res_names[rv].split(" ")[0].split("<")[0], {})

@@ -1336,9 +1336,9 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
             (void)hipEventRecord(h->ev_t0[N_SIDE], ss);
             h->launched[N_SIDE] = true;
             if (h->tiny_per_cu == 16)
-                hipLaunchKernelGGL((k_sparse_resident_tiny16<5, 10, 2>), dim3((n_pack + 7) / 8), dim3(512), 0, ss, p, h->d_sp[2], n_pack, h->d_adam);
+                hipLaunchKernelGGL((k_sparse_resident_tiny16<5, 10, 2>), dim3((n_pack + 15) / 16), dim3(1024), 0, ss, p, h->d_sp[2], n_pack, h->d_adam);
             else
-                hipLaunchKernelGGL((k_sparse_resident_tiny12<5, 10, 2>), dim3((n_pack + 3) / 4), dim3(256), 0, ss, p, h->d_sp[2], n_pack, h->d_adam);
+                hipLaunchKernelGGL((k_sparse_resident_tiny12<5, 10, 2>), dim3((n_pack + 11) / 12), dim3(768), 0, ss, p, h->d_sp[2], n_pack, h->d_adam);
             (void)hipEventRecord(h->ev_out[N_SIDE], ss);
         };
         for (int ko = 0; ko < N_SPC; ++ko) {
@@ -1682,9 +1682,17 @@ static int analyze_impl(gnnx_handle h, const float* A, const float* X, hipStream
                            sparse_fits(64, m.n, m.ld, h->nnz[2 * t], h->nnz[2 * t + 1], h->prob.D, h->prob.H, h->prob.C, 0, h->prob.O,
                                        per_cu == 16 ? tiny_pool_floats(16) : tiny_pool_floats(12));
             }
+        // Only where it pays: packing trades a chain's speed for chains per compute unit (measured, syn4: one wave alone on its SIMD 2.09 ms per
+        // 300 iterations, two 2.6, three 3.1, four 4.0 with the spills of the 128-register build) - below about eight single-wave targets per
+        // compute unit of the chip a batch runs faster SPREAD (the class's own launch / the mixed launch's slices).  GNNX_TINY_PACK_MIN overrides.
+        long long min_targets = 8 * 256;
+        if (const char* env = std::getenv("GNNX_TINY_PACK_MIN")) min_targets = std::atoll(env);
+        long long n_flag = 0;
+        for (char f : flags) n_flag += f;
+        if (n_flag < min_targets) std::fill(flags.begin(), flags.end(), (char)0);
         changed |= flags != h->tiny_pack;
         h->tiny_pack.swap(flags);
-        h->tiny_per_cu = form_ok ? per_cu : 0;
+        h->tiny_per_cu = (form_ok && n_flag >= min_targets) ? per_cu : 0;
     }
     if (changed || h->split_dirty) {
         if (int rc = build_split(h)) return rc;

@@ -1952,25 +1952,28 @@ __global__ __launch_bounds__(512) GNNX_MIXED_ATTR void k_sparse_resident_mixed(P
 // chain that issues a fifth of one SIMD's cycles; what bounds a saturated batch is how many chains a compute unit holds.  In the mixed launch
 // (and in the 64-thread class's own launch) that was 8 (6): 188-218 registers per lane and 20 KB of LDS + a 5.4 KB SparseFixed each.  Here:
 //   * the slim LDS form (sparse_layout: slim, SparseFixedSlim): <= TINY_SLICE floats per target, the model block shared by the workgroup;
-//   * NWG targets per workgroup, one per wave, the workgroup's registers capped so that `PER_CU` waves share a compute unit:
-//       PER_CU = 16: 8 waves x 2 workgroups, 128 registers per lane, 80 KB of LDS per workgroup;
-//       PER_CU = 12: 4 waves x 3 workgroups, 168 registers, 52.5 KB;
+//   * ONE workgroup per compute unit, one target per wave: 16 waves (1024 threads, 128 registers per lane) or 12 (768 threads, 168 registers).
+//     A whole-CU workgroup on purpose: measured with 8-wave workgroups two to a CU (80 KB each) - alone 1.27x the class's own launch (syn4),
+//     but BESIDE the mixed launch's whole-CU workgroups the dispatcher spreads them one per CU, where each blocks a 158 KB workgroup of the
+//     other launch: syn1 301.7 k -> 151-183 k nodes/s (profiles/r06_tiny_pack_ab.txt).  With whole-CU workgroups in both launches a free
+//     compute unit takes either;
 //   * exact widths of the reference's node encoder (D = 10, H = O = 20), C <= 4, the algebraic constant-feature form (XC = 2), no logging:
 //     everything else keeps the classes above.  Same body, same arithmetic, same order: bit-identical to them (tests/test_tiny_pack.py).
 // Which targets qualify is decided by the plan (gnnx_capi.hip: tiny_pack_fits); the rest of the 64-thread class runs where it ran.
 constexpr int TINY_W = (10 + 2 * 20) * 33 + 4 * 96;     // the shared model block: W1 | W2 | W3 (33-float rows) | four head rows
-__host__ __device__ constexpr int tiny_nwg(int per_cu) { return per_cu == 16 ? 8 : 4; }
-// floats per target (pool slice + SparseFixedSlim): LDS is allocated in 1280-byte granules, 128 of them per compute unit
+__host__ __device__ constexpr int tiny_nwg(int per_cu) { return per_cu; }      // targets (= waves) per workgroup
+// floats per target (pool slice + SparseFixedSlim): the workgroup takes what the mixed launch's workgroups take (158.4 KB: the prepare
+// stage's service kernels keep their 5 KB of LDS beside it)
 __host__ __device__ constexpr int tiny_slice(int per_cu) {
-    return ((128 / (per_cu / tiny_nwg(per_cu))) * 320 - TINY_W) / tiny_nwg(per_cu);
+    return (GNNX_POOL512_FLOATS + (int)((sizeof(SparseFixed) + 3) / 4) - TINY_W) / per_cu;
 }
 __host__ __device__ constexpr int tiny_fixed_floats() { return (int)((sizeof(SparseFixedSlim) + 3) / 4); }
 __host__ __device__ constexpr int tiny_pool_floats(int per_cu) { return tiny_slice(per_cu) - tiny_fixed_floats(); }
 #define GNNX_TINY_KERNEL(NAME, PER_CU, NUM_VGPR)                                                                                              \
     template <int DQ, int HQ, int XC>                                                                                                         \
-    __global__ __launch_bounds__(64 * tiny_nwg(PER_CU)) GNNX_NUM_VGPR_ATTR(NUM_VGPR) void NAME(Params p, const int32_t* ids, int n_ids,     \
-                                                                                               const float* adam_tab) {                       \
-        constexpr int NWG = tiny_nwg(PER_CU), SLICE = tiny_slice(PER_CU), POOL = tiny_pool_floats(PER_CU);                                    \
+    __global__ __launch_bounds__(64 * PER_CU) GNNX_NUM_VGPR_ATTR(NUM_VGPR) void NAME(Params p, const int32_t* ids, int n_ids,               \
+                                                                                     const float* adam_tab) {                                 \
+        constexpr int NWG = PER_CU, SLICE = tiny_slice(PER_CU), POOL = tiny_pool_floats(PER_CU);                                              \
         __shared__ float lds[TINY_W + NWG * SLICE];                                                                                           \
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                                                                           \
         const int idx = (int)blockIdx.x * NWG + wave;                                                                                         \
@@ -1982,7 +1985,7 @@ __host__ __device__ constexpr int tiny_pool_floats(int per_cu) { return tiny_sli
 GNNX_TINY_KERNEL(k_sparse_resident_tiny16, 16, 64)
 GNNX_TINY_KERNEL(k_sparse_resident_tiny12, 12, 84)
 #undef GNNX_TINY_KERNEL
-static_assert(2 * (TINY_W + 8 * tiny_slice(16)) * 4 <= 160 * 1024 && 3 * (TINY_W + 4 * tiny_slice(12)) * 4 <= 160 * 1024, "LDS of a compute unit");
+static_assert((TINY_W + 16 * tiny_slice(16)) * 4 <= 160 * 1024 - 5 * 1024 && (TINY_W + 12 * tiny_slice(12)) * 4 <= 160 * 1024 - 5 * 1024, "LDS of a compute unit, less the service kernels' share");
 
 // per target: directed off-diagonal non-zeros of its block of the packed adjacency and the row slots the sparse
 // resident kernel would need (-1: more than SP_LD_MAX rows) -> out[2 t], out[2 t + 1]   (gnnx_plan_analyze)

@@ -31,6 +31,12 @@ def _subs(rng, sizes, density=0.2):
     return out
 
 
+@pytest.fixture(autouse=True)
+def _pack_small_batches(monkeypatch):
+    """the plan packs only batches that saturate the chip (>= 2048 single-wave targets); the tests' batches are small"""
+    monkeypatch.setenv("GNNX_TINY_PACK_MIN", "1")
+
+
 def _run(be, subs, sd, iters):
     job = be.job(subs, sd)
     res = job.run([s.mask0 for s in subs], Hyper(num_iters=iters))
@@ -96,3 +102,12 @@ def test_other_forms_keep_their_classes(be, monkeypatch):
                 s.feat[:] = rng.standard_normal(s.feat.shape).astype(np.float32)
         job = be.job(subs, sd)
         assert job.tiny_pack() == (0, 0), (D, H, C, const)
+
+
+def test_small_batches_are_not_packed(be, monkeypatch):
+    """Below eight single-wave targets per compute unit of the chip a batch runs faster spread (gnnx_capi.hip: tiny pack rule)."""
+    monkeypatch.delenv("GNNX_TINY_PACK_MIN")
+    rng = np.random.default_rng(34)
+    sd = helpers.random_model(rng, 10, 20, 20, 4)
+    job = be.job(_subs(rng, [(int(rng.integers(6, 20)), 2) for _ in range(6)]), sd)
+    assert job.tiny_pack() == (0, 0) and not job.tiny_packed().any()
