@@ -1150,6 +1150,46 @@ def main():
                 roof["traffic_source"] = os.path.relpath(pmc, ROOT)
             except Exception:
                 pass
+        # ---- what the hardware saw: utilisation of the launch's compute units from the PMC summary of the same command's loop ----
+        cand_u = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_summary_{name}" + (f"_{args.targets}targets" if name == "ba100k" else "") + "_loop_only.json")))
+        if cand_u and "model" in roof:
+            try:
+                ps = json.load(open(cand_u[-1]))
+                kname = roof["kernel"].split(" ")[0].split("<")[0]
+                cs = ps.get("counters_mean_per_launch", {}).get(kname, {})
+                # the summary's own launch duration (rocprofv3 kernel trace of the same passes) if it carries one, else this run's isolated launch
+                prof_ms = ps.get("avg_launch_ms", {}).get(kname) or roof["avg_launch_us"] / 1e3
+                busy = roof["model"]["busy_cus"]
+                cyc = prof_ms * 1e-3 * wm.CLOCK_HZ                       # shader cycles of one launch
+                hu = {"source": os.path.relpath(cand_u[-1], ROOT), "kernel": kname, "launch_ms_of_the_counter_passes": prof_ms, "busy_cus": busy,
+                      "note": "fractions of what the BUSY compute units could issue / move during the launch (a launch of W workgroups occupies W of 256 CUs); "
+                              "VALU: wave64 instruction = 2 cycles of a SIMD-32; MFMA: SQ_VALU_MFMA_BUSY_CYCLES per SIMD; LDS: SQ_LDS_IDX_ACTIVE cycles of the CU's "
+                              "LDS pipe; HBM: (2 FETCH_SIZE + WRITE_SIZE) KiB (gfx950 correction, MI355X_MICROARCH.md) against 8 TB/s; waves: SQ_WAIT_ANY, "
+                              "SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES (quad-cycles both)"}
+                if cs.get("SQ_INSTS_VALU"):
+                    hu["valu_issue_frac"] = cs["SQ_INSTS_VALU"] * 2.0 / (busy * 4.0 * cyc)
+                if cs.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+                    hu["mfma_busy_frac"] = cs["SQ_VALU_MFMA_BUSY_CYCLES"] / (busy * 4.0 * cyc)
+                if cs.get("SQ_LDS_IDX_ACTIVE"):
+                    hu["lds_pipe_frac"] = cs["SQ_LDS_IDX_ACTIVE"] / (busy * cyc)
+                    hu["lds_bank_conflict_frac_of_lds_cycles"] = cs.get("SQ_LDS_BANK_CONFLICT", 0.0) / cs["SQ_LDS_IDX_ACTIVE"]
+                hb = ps.get("hbm_bytes_per_launch", {}).get(kname)
+                if hb:
+                    hu["hbm_frac_of_8TBps"] = hb / (prof_ms * 1e-3) / HBM_PEAK
+                if cs.get("SQ_WAVE_CYCLES"):
+                    hu["waves_waiting_frac"] = cs.get("SQ_WAIT_ANY", 0.0) / cs["SQ_WAVE_CYCLES"]
+                    hu["waves_issuing_frac"] = cs.get("SQ_ACTIVE_INST_ANY", 0.0) / cs["SQ_WAVE_CYCLES"]
+                roof["hw_utilisation"] = hu
+            except Exception as e:      # a summary of another layout: say so instead of failing the line
+                roof["hw_utilisation"] = {"error": repr(e)}
+        # ---- the same kernel INSIDE the pipeline (three launches share the chip): mean launch time of the timed batches and the model's frac at it ----
+        if e2e_stats is not None and e2e_stats.get("launch_in_pipeline_ms") and "model" in roof:
+            lp = float(e2e_stats["launch_in_pipeline_ms"])
+            m_ = roof["model"]
+            roof["in_pipeline"] = {"mean_launch_ms": lp, "isolated_launch_ms": roof["avg_launch_us"] / 1e3,
+                                   "frac": m_["lower_bounds_ms"][m_["bound"]] / lp,
+                                   "note": "device time of the dominant launch while the batches ahead and behind share the chip (HIP events on the launch stream of every "
+                                           "timed batch, pipeline.py); `frac` above is for the isolated launch"}
         roof["launches"] = launches
         roof["whole_job"] = {"sum_n2": sum_n2, "directed_edge_entries": float(nnz.sum()),
                              "dense_alg_flops_per_step": 6.0 * sum_n2 * kagg * args.iters, "dense_alg_bytes_per_step": 28.0 * sum_n2 * args.iters,

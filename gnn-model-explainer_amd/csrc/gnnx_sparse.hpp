@@ -28,6 +28,12 @@
 #ifndef GNNX_OPAQUE_ALL
 #define GNNX_OPAQUE_ALL 1
 #endif
+#ifndef GNNX_OPAQUE_LANE
+#define GNNX_OPAQUE_LANE 2
+#endif
+#ifndef GNNX_OPAQUE_LANE_SLIM
+#define GNNX_OPAQUE_LANE_SLIM 2
+#endif
 #include <type_traits>
 #include "gnnx_kernels.hpp"
 #include "gnnx_resident.hpp"
@@ -449,7 +455,8 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     };
     const TargetMeta tm = p.meta[t];
     const int n = tm.n, ld = tm.ld, tr = tm.t;
-    const int wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int wave = tid >> 6;
+    int lane = tid & 63, li = lane & 31, h = lane >> 5;   // (not const: GNNX_OPAQUE_LANE below)
     constexpr int NW = NT / 64;
     // The <5, 10> / <7, 10> instantiations serve exactly the reference's encoders (node: D = 10, graph: D = 14; H = O = 20): the
     // widths are compile-time constants there (every column predicate, row stride and trip count folds); other shapes take <16, 16>.
@@ -976,6 +983,16 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
                 GNNX_OPAQUE(epk[q]);
                 GNNX_OPAQUE(npk[q]);
             }
+        }
+        // Round 6: the lane's own indices.  Every LDS address a lane derives from them (its column of a weight row, its bias entries, its row of
+        // the head block, ...) is loop invariant too, and with run-time array bases each (array, index pattern) pair is a register of its own
+        // held across the whole iteration: declared modified here they are formed where they are used.  Levels: 1 = li, 2 = + lane, 3 = + h
+        // (spilled registers of k_sparse_resident_mixed<5, 10, 2> under the 224-register cap: 30 / 9 / 2 / 0; scratch 92 / 40 / 12 / 0 B per lane).
+        constexpr int OL = SLIM ? GNNX_OPAQUE_LANE_SLIM : GNNX_OPAQUE_LANE;
+        if constexpr (OL > 0 && !GRAPH) {
+            GNNX_OPAQUE(li);
+            if constexpr (OL > 1) GNNX_OPAQUE(lane);
+            if constexpr (OL > 2) GNNX_OPAQUE(h);
         }
         if constexpr (LOG) Lrow = p.loss ? p.loss + ((size_t)t * p.num_iters + iter) * NLOSS : nullptr;
 

@@ -468,6 +468,12 @@ class BatchPipeline:
                 em = engine.EdgeMasks(*self._merge(len(p.targets), p.parts, got, p.parts[0].job.D))
             em.neighbors = p.dn
             em.routes = [("xl" if part.xl else "dense", len(part.idx)) for part in p.parts]
+            # device time of this batch's optimisation launch IN the pipeline (HIP events on its launch stream; the launch shares the chip with
+            # the batches ahead and behind - the isolated launch time is what bench.py measures afterwards): the longest resident launch
+            try:
+                p.times["launch_in_pipeline_ms"] = max(max(part.job.resident_times()) for part in p.parts if not part.xl)
+            except (ValueError, RuntimeError):
+                pass      # (XL parts only / a plan without resident launches)
             self.stats.append(p.times)
             for part in p.parts:
                 if part.xl:

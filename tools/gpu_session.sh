@@ -24,6 +24,13 @@ for step in "$@"; do
     bench)        tag=$(echo "$arg" | tr -c 'a-zA-Z0-9' '_'); timeout 1500 python bench.py $arg > "$O/bench_$tag.json" 2> "$O/bench_$tag.err"; tail -c 1500 "$O/bench_$tag.json"; tail -3 "$O/bench_$tag.err" ;;
     rocprof)      tag=$(echo "$arg" | tr -c 'a-zA-Z0-9' '_'); (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$tag" -- python "$ROOT/bench.py" $arg > "$O/bench_under_rocprof_$tag.json" 2>/dev/null); stats_csv "$O/prof_$tag" "$O/kernel_stats_$tag.csv"; head -8 "$O/kernel_stats_$tag.csv" | cut -c1-200 ;;
     rocprofpy)    tag=$(echo "$arg" | tr -c 'a-zA-Z0-9' '_'); (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$tag" -- python $ROOT/$arg > "$O/rocprofpy_$tag.log" 2>&1); stats_csv "$O/prof_$tag" "$O/kernel_stats_$tag.csv"; head -12 "$O/kernel_stats_$tag.csv" | cut -c1-70,200-330 ;;
+    pmc)          # three counter passes of the loop of a workload (arg = bench.py flags), summarised per kernel: profiles/rNN_pmc_summary_<workload>_loop_only.json
+                  tag=$(echo "$arg" | tr -c 'a-zA-Z0-9' '_'); B="python $ROOT/bench.py $arg --steps 3 --warmup 1 --no-cpu-baseline --no-parity-gate --loop-only"
+                  (cd /tmp && timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d "$O/pmc_a_$tag" -- $B > /dev/null 2> "$O/pmc_a_$tag.err"
+                   timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$O/pmc_b_$tag" -- $B > /dev/null 2> "$O/pmc_b_$tag.err"
+                   timeout 400 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_c_$tag" -- $B > /dev/null 2> "$O/pmc_c_$tag.err")
+                  python tools/pmc_summary.py "$O/pmc_summary_$tag.json" "$O/pmc_per_kernel_$tag.csv" "$O/pmc_a_$tag" "$O/pmc_b_$tag" "$O/pmc_c_$tag" | cut -c1-400
+                  tail -2 "$O/pmc_a_$tag.err"; rm -rf "$O/pmc_a_$tag" "$O/pmc_b_$tag" "$O/pmc_c_$tag" ;;
     py)           timeout 1500 python $arg 2>&1 | tail -30 ;;
     sh)           timeout 1500 bash $arg 2>&1 | tail -30 ;;
     *)            echo "unknown step $s" ;;
