@@ -93,6 +93,7 @@ class BatchPipeline:
         # others and lengthens the fill and drain of a short job.  Measured (profiles/r05_pipeline_workers_depth_room.txt): syn1 (116 workgroups
         # per launch) 20-batch regions 234-241 k nodes/s at four in flight, 249-250 k at three; Tree-Cycles (360 single-wave workgroups, six per
         # CU) 365-373 k at three, 449-455 k at four or more; steady state (300 batches) indifferent.  A number fixes it.
+        self.record_launch_ms = os.environ.get("GNNX_PIPE_LAUNCH_MS", "1") != "0"   # per-batch device time of the optimisation launch (eight event queries per batch)
         env_depth = os.environ.get("GNNX_PIPE_DEPTH")                               # (measurement knobs)
         if env_depth:
             depth = int(env_depth)
@@ -470,10 +471,11 @@ class BatchPipeline:
             em.routes = [("xl" if part.xl else "dense", len(part.idx)) for part in p.parts]
             # device time of this batch's optimisation launch IN the pipeline (HIP events on its launch stream; the launch shares the chip with
             # the batches ahead and behind - the isolated launch time is what bench.py measures afterwards): the longest resident launch
-            try:
-                p.times["launch_in_pipeline_ms"] = max(max(part.job.resident_times()) for part in p.parts if not part.xl)
-            except (ValueError, RuntimeError):
-                pass      # (XL parts only / a plan without resident launches)
+            if self.record_launch_ms:
+                try:
+                    p.times["launch_in_pipeline_ms"] = max(max(part.job.resident_times()) for part in p.parts if not part.xl)
+                except (ValueError, RuntimeError):
+                    pass      # (XL parts only / a plan without resident launches)
             self.stats.append(p.times)
             for part in p.parts:
                 if part.xl:

@@ -28,9 +28,10 @@ for step in "$@"; do
                   tag=$(echo "$arg" | tr -c 'a-zA-Z0-9' '_'); B="python $ROOT/bench.py $arg --steps 3 --warmup 1 --no-cpu-baseline --no-parity-gate --loop-only"
                   (cd /tmp && timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d "$O/pmc_a_$tag" -- $B > /dev/null 2> "$O/pmc_a_$tag.err"
                    timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$O/pmc_b_$tag" -- $B > /dev/null 2> "$O/pmc_b_$tag.err"
-                   timeout 400 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_c_$tag" -- $B > /dev/null 2> "$O/pmc_c_$tag.err")
-                  python tools/pmc_summary.py "$O/pmc_summary_$tag.json" "$O/pmc_per_kernel_$tag.csv" "$O/pmc_a_$tag" "$O/pmc_b_$tag" "$O/pmc_c_$tag" | cut -c1-400
-                  tail -2 "$O/pmc_a_$tag.err"; rm -rf "$O/pmc_a_$tag" "$O/pmc_b_$tag" "$O/pmc_c_$tag" ;;
+                   timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_c_$tag" -- $B > /dev/null 2> "$O/pmc_c_$tag.err"
+                   timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_d_$tag" -- $B > /dev/null 2> "$O/pmc_d_$tag.err")
+                  python tools/pmc_summary.py "$O/pmc_summary_$tag.json" "$O/pmc_per_kernel_$tag.csv" "$O/pmc_a_$tag" "$O/pmc_b_$tag" "$O/pmc_c_$tag" "$O/pmc_d_$tag" | cut -c1-400
+                  rm -rf "$O/pmc_a_$tag" "$O/pmc_b_$tag" "$O/pmc_c_$tag" "$O/pmc_d_$tag" "$O"/pmc_?_$tag.err ;;
     py)           timeout 1500 python $arg 2>&1 | tail -30 ;;
     sh)           timeout 1500 bash $arg 2>&1 | tail -30 ;;
     *)            echo "unknown step $s" ;;
