@@ -1024,6 +1024,12 @@ static bool exact_shape(gnnx_handle h, int D) { return h->prob.D == D && h->prob
 static bool small_shape(gnnx_handle h, int D) { return h->prob.D <= D && h->prob.H <= 20 && h->prob.O <= 20; }
 // ... and hidden / output widths up to 32 with the reference's input width (node mode): <5, 16> - the D-wide arrays stay short
 static bool wide_shape(gnnx_handle h, int D) { return h->prob.D <= D && h->prob.H <= 32 && h->prob.O <= 32; }
+// Round 6: the hidden widths people train the reference's node encoder with besides its default 20 - --hidden-dim = --output-dim
+// = 16 or 32 on 10 input features - have compile-time-width instantiations of the node-mode resident kernels too (<5, 8> / <5, 16>, general and
+// algebraic constant-feature form): 16 / 228 B of scratch per lane under the mixed kernel's register cap instead of 396 / 784 B with run-time
+// widths, and constant feature rows take the algebraic form there as well.  (64 exceeds the 32-column tile of the row-local MFMA parts: torch route.)
+static bool exact_hidden(gnnx_handle h, int H) { return h->prob.D == 10 && h->prob.H == H && h->prob.O == H; }
+static bool exact_node_shape(gnnx_handle h) { return exact_hidden(h, 20) || exact_hidden(h, 16) || exact_hidden(h, 32); }
 
 template <int NT>
 static void launch_sparse_nt(gnnx_handle h, const Params& p, const int32_t* ids, int cnt, const float* adam_tab, hipStream_t s, bool log) {
@@ -1042,6 +1048,10 @@ static void launch_sparse_nt(gnnx_handle h, const Params& p, const int32_t* ids,
         if (exact_shape(h, 10) && h->xconst == 2) hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT, 2>), grid, block, 0, s, p, ids, adam_tab);
         else if (exact_shape(h, 10) && h->xconst == 1) hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT, 1>), grid, block, 0, s, p, ids, adam_tab);
         else if (exact_shape(h, 10)) hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT>), grid, block, 0, s, p, ids, adam_tab);
+        else if (exact_hidden(h, 16) && h->xconst == 2) hipLaunchKernelGGL((k_sparse_resident<5, 8, false, NT, 2>), grid, block, 0, s, p, ids, adam_tab);
+        else if (exact_hidden(h, 16)) hipLaunchKernelGGL((k_sparse_resident<5, 8, false, NT>), grid, block, 0, s, p, ids, adam_tab);
+        else if (exact_hidden(h, 32) && h->xconst == 2) hipLaunchKernelGGL((k_sparse_resident<5, 16, false, NT, 2>), grid, block, 0, s, p, ids, adam_tab);
+        else if (exact_hidden(h, 32)) hipLaunchKernelGGL((k_sparse_resident<5, 16, false, NT>), grid, block, 0, s, p, ids, adam_tab);
         else if (small_shape(h, 10)) hipLaunchKernelGGL((k_sparse_resident<5, 10, false, NT, 0, false, false>), grid, block, 0, s, p, ids, adam_tab);
         else if (wide_shape(h, 10)) hipLaunchKernelGGL((k_sparse_resident<5, 16, false, NT, 0, false, false>), grid, block, 0, s, p, ids, adam_tab);
         else hipLaunchKernelGGL((k_sparse_resident<16, 16, false, NT>), grid, block, 0, s, p, ids, adam_tab);
@@ -1136,6 +1146,7 @@ static int run_att(gnnx_handle h, const gnnx_hyper* hy, const gnnx_resume& rs, P
         return r;
     };
     const size_t o_eoff = take(sizeof(long long) * (T + 1)), o_rowptr = take(sizeof(int32_t) * (R + T)), o_col = take(4 * E), o_mir = take(4 * E);
+    const size_t o_wgorder = take(sizeof(int32_t) * T);      // workgroup -> target, longest chains (most edges) first
     size_t o_e[6], o_r[11], o_rn[3];
     for (auto& x : o_e) x = take(4 * E);
     for (auto& x : o_r) x = take(4 * R * FS);
@@ -1155,6 +1166,10 @@ static int run_att(gnnx_handle h, const gnnx_hyper* hy, const gnnx_resume& rs, P
     hipError_t e = pool_malloc(&d_tab, sizeof(float) * tab.size());
     if (e == hipSuccess) e = upload_sync(d_tab, tab.data(), sizeof(float) * tab.size());
     if (e == hipSuccess) e = upload_sync(d + o_eoff, eoff.data(), sizeof(long long) * (T + 1));
+    std::vector<int32_t> wg_order(T);
+    for (int t = 0; t < T; ++t) wg_order[t] = t;
+    std::stable_sort(wg_order.begin(), wg_order.end(), [&](int x, int y) { return cnt[x] > cnt[y]; });
+    if (e == hipSuccess) e = upload_sync(d + o_wgorder, wg_order.data(), sizeof(int32_t) * T);
     if (e != hipSuccess) {
         (void)pool_free(d);
         if (d_tab) (void)pool_free(d_tab);
@@ -1184,7 +1199,7 @@ static int run_att(gnnx_handle h, const gnnx_hyper* hy, const gnnx_resume& rs, P
     a.mrow = reinterpret_cast<int32_t*>(d + o_mrow);
     a.mfirst = reinterpret_cast<int32_t*>(d + o_mfirst);
     a.pacc = reinterpret_cast<float*>(d + o_pacc);
-    hipLaunchKernelGGL(k_att, dim3(T), dim3(ATT_THREADS), 0, s, p, a, d_tab);
+    hipLaunchKernelGGL(k_att, dim3(T), dim3(ATT_THREADS), 0, s, p, a, d_tab, reinterpret_cast<const int32_t*>(d + o_wgorder));
     if (feat_mask)
         (void)hipMemcpyAsync(feat_mask, p.f[hy->num_iters & 1], sizeof(float) * T * FS, hipMemcpyDeviceToDevice, s);
     e = hipStreamSynchronize(s);
@@ -1369,6 +1384,18 @@ extern "C" int gnnx_run_resume(gnnx_handle h, const gnnx_hyper* hy, const gnnx_r
                 else if (exact_shape(h, 10))
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
                                        tiny_ids, n_tiny, h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
+                else if (exact_hidden(h, 16) && h->xconst == 2)
+                    hipLaunchKernelGGL((k_sparse_resident_mixed<5, 8, 2>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
+                                       tiny_ids, n_tiny, h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
+                else if (exact_hidden(h, 16))
+                    hipLaunchKernelGGL((k_sparse_resident_mixed<5, 8>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
+                                       tiny_ids, n_tiny, h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
+                else if (exact_hidden(h, 32) && h->xconst == 2)
+                    hipLaunchKernelGGL((k_sparse_resident_mixed<5, 16, 2>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
+                                       tiny_ids, n_tiny, h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
+                else if (exact_hidden(h, 32))
+                    hipLaunchKernelGGL((k_sparse_resident_mixed<5, 16>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
+                                       tiny_ids, n_tiny, h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
                 else if (small_shape(h, 10))
                     hipLaunchKernelGGL((k_sparse_resident_mixed<5, 10, 0, false, false>), grid, block, 0, ss, p, h->d_sp[SPC_512], h->n_sp[SPC_512],
                                        tiny_ids, n_tiny, h->d_adam, per_wg, sp_model_floats(h->prob.D, h->prob.H, h->prob.C), pair_ids, n_pair);
@@ -1551,6 +1578,15 @@ static int analyze_impl(gnnx_handle h, const float* A, const float* X, hipStream
     if (const char* env = std::getenv("GNNX_TINY_SPARSE")) tiny_on = std::atoi(env);
     if (const char* env = std::getenv("GNNX_SPARSE_LARGE")) large_on = std::atoi(env);  // 0: those targets stream (dense)
     bool changed = false;
+    // The LDS layout of the algebraic constant-feature form is smaller (sparse_layout: slim bit 0): when EVERY target the resident classes could
+    // take has constant feature rows and the plan will run that form, the classes are sized with it (the kernels pick the layout by their form;
+    // a plan sized with the full layout still fits: the slim one is never larger).
+    int xc_form = 2;   // GNNX_XCONST = 0 / 1 / 2: general form / bit-identical constant-feature form / algebraic form (default)
+    if (const char* env = std::getenv("GNNX_XCONST")) xc_form = std::max(0, std::min(2, std::atoi(env)));
+    bool xc_all = look_at_x && !graph && exact_node_shape(h) && xc_form == 2;
+    for (int t = 0; t < T && xc_all; ++t)
+        if (h->meta[t].ld <= SP_LD_MAX) xc_all = h->nnz[(2 + SPL_COUNTS) * (size_t)T + t] == 1;
+    const int lay = xc_all ? 1 : 0;
     std::vector<int> new_cat(T, 0);
     for (int t = 0; t < T; ++t) {
         const TargetMeta& m = h->meta[t];
@@ -1559,7 +1595,7 @@ static int analyze_impl(gnnx_handle h, const float* A, const float* X, hipStream
         if (h->nnz[2 * t] >= 0)
             for (int k = 2; k >= 0 && !c; --k)
                 if (sparse_fits(SPC_THREADS[k], m.n, m.ld, h->nnz[2 * t], h->nnz[2 * t + 1], h->prob.D, h->prob.H, h->prob.C,
-                                graph, h->prob.O) &&
+                                graph, h->prob.O, 0, lay) &&
                     (k < 2 || tiny_on))
                     c = CAT_SPARSE + k;
         if (!graph && nb == 1 && h->res_nbmax >= 1 && (!c || !tiny_on)) c = 1;  // dense resident: node mode only
@@ -1567,7 +1603,7 @@ static int analyze_impl(gnnx_handle h, const float* A, const float* X, hipStream
         // node mode, beyond the 256-thread class: the 512-thread class when the rows within two hops fit its 256 slots
         // (no scratch, cheaper barriers), else the 1024-thread class chosen above
         if (!graph && c512_on && (c == 0 || c == CAT_SPARSE) && lg[0] >= 0 &&
-            sparse_fits(512, m.n, m.ld, lg[0], lg[2], h->prob.D, h->prob.H, h->prob.C, 0, h->prob.O))
+            sparse_fits(512, m.n, m.ld, lg[0], lg[2], h->prob.D, h->prob.H, h->prob.C, 0, h->prob.O, 0, lay))
             c = CAT_SPARSE + SPC_512;
         if (!c && !graph && large_on && lg[0] >= 0 && sparse_large_fits(m.n, m.ld, lg, h->prob.D, h->prob.H, h->prob.C))
             c = CAT_SPARSE + SPC_LARGE;
@@ -1619,7 +1655,7 @@ static int analyze_impl(gnnx_handle h, const float* A, const float* X, hipStream
             ++n1;
             const TargetMeta& m = h->meta[t];
             const int* lg = &h->nnz[2 * (size_t)T + SPL_COUNTS * (size_t)t];
-            all_fit &= lg[0] >= 0 && sparse_fits(512, m.n, m.ld, lg[0], lg[2], h->prob.D, h->prob.H, h->prob.C, 0, h->prob.O);
+            all_fit &= lg[0] >= 0 && sparse_fits(512, m.n, m.ld, lg[0], lg[2], h->prob.D, h->prob.H, h->prob.C, 0, h->prob.O, 0, lay);
         }
         const int per_wg = sp_mix_tiny(h->prob.D, h->prob.H, h->prob.C);
         if (n1 > 0 && n2 > 0 && all_fit && n1 + (n2 + per_wg - 1) / per_wg <= 256) {
@@ -1638,7 +1674,7 @@ static int analyze_impl(gnnx_handle h, const float* A, const float* X, hipStream
                 const TargetMeta& m = h->meta[t];
                 const int* lg = &h->nnz[2 * (size_t)T + SPL_COUNTS * (size_t)t];
                 const bool f512 = !graph && c512_on && lg[0] >= 0 &&
-                                  sparse_fits(512, m.n, m.ld, lg[0], lg[2], h->prob.D, h->prob.H, h->prob.C, 0, h->prob.O);
+                                  sparse_fits(512, m.n, m.ld, lg[0], lg[2], h->prob.D, h->prob.H, h->prob.C, 0, h->prob.O, 0, lay);
                 new_cat[t] = f512 ? CAT_SPARSE + SPC_512 : CAT_SPARSE;
             }
             if (new_cat[t] == CAT_SPARSE + 2 && !graph && h->res_nbmax >= 1 && !mixable) new_cat[t] = 1;
@@ -1663,9 +1699,8 @@ static int analyze_impl(gnnx_handle h, const float* A, const float* X, hipStream
                 all &= h->nnz[(2 + SPL_COUNTS) * (size_t)T + t] == 1;
             }
         }
-        int xc_form = 2;   // GNNX_XCONST = 0 / 1 / 2: general form / bit-identical constant-feature form / algebraic form (default)
-        if (const char* env = std::getenv("GNNX_XCONST")) xc_form = std::max(0, std::min(2, std::atoi(env)));
-        h->xconst = (any && all && exact_shape(h, 10)) ? xc_form : 0;
+        h->xconst = (any && all && exact_node_shape(h)) ? xc_form : 0;
+        if (h->xconst == 1 && !exact_shape(h, 10)) h->xconst = 0;      // (the bit-identical constant-feature form, a measurement knob: the reference's widths only)
     }
     // Packed single-wave launch (k_sparse_resident_tiny16 / 12): the targets of the 64-thread class whose slim LDS form fits a slice, when the
     // plan runs the algebraic constant-feature form at the reference's widths.  GNNX_TINY_PACK = 16 (default) / 12 / 0 (off).
@@ -1680,7 +1715,7 @@ static int analyze_impl(gnnx_handle h, const float* A, const float* X, hipStream
                 const TargetMeta& m = h->meta[t];
                 flags[t] = h->cat[t] == CAT_SPARSE + 2 &&
                            sparse_fits(64, m.n, m.ld, h->nnz[2 * t], h->nnz[2 * t + 1], h->prob.D, h->prob.H, h->prob.C, 0, h->prob.O,
-                                       per_cu == 16 ? tiny_pool_floats(16) : tiny_pool_floats(12));
+                                       per_cu == 16 ? tiny_pool_floats(16) : tiny_pool_floats(12), 3);
             }
         // Only where it pays: packing trades a chain's speed for chains per compute unit (measured, syn4: one wave alone on its SIMD 2.09 ms per
         // 300 iterations, two 2.6, three 3.1, four 4.0 with the spills of the 128-register build) - below about eight single-wave targets per

@@ -78,23 +78,24 @@ struct SparseLayout {
 // graph = 0: node mode (GcnEncoderNode: only row t of layer 3 is needed; dZ2 overwrites U2);
 // graph = 1: graph mode (GcnEncoderGraph: all three layers in full, U3 [ld][max(H, O)] overwritten by dZ3, dZ2 separate)
 // n rows of the big row arrays (rows >= n are never touched), ld = round_up(n, 32) entries of the per-row scalars
-// slim = 1 (k_sparse_resident_tiny: single-wave targets of the algebraic constant-feature form, model block shared by the workgroup): X is
-// one row (every row equals it), the dZ1 array one float per row (the per-row scalar ci = dY1 . wt is all that form keeps of dZ1), no
-// private model block; the arrays the setup's temporaries alias are padded to the temporaries' size.
+// slim (round 6), bit 0: the algebraic constant-feature form (XC = 2) - X is one row (every row equals it) and the dZ1 array one float per row
+// (the per-row scalar ci = dY1 . wt is all that form keeps of dZ1); the arrays the setup's temporaries alias are padded to the temporaries'
+// size.  Every class of that form uses it: 22 floats per row less (n = 310 at hidden 32 fits the 512-thread class again; on BA-House x100k
+// fewer (128, 512]-node targets fall to k_sparse_large).  bit 1: no private model block (k_sparse_resident_tiny: shared by the workgroup).
 __host__ __device__ inline SparseLayout sparse_layout(int n, int ld, int nnz, int D, int H, int C, int graph = 0, int O = 0, int slim = 0) {
     SparseLayout L;
     L.sD = D | 1;
     L.sH = H | 1;
     L.sO = (O > H ? O : H) | 1;
     int o = 0;
-    L.oX = o;      o += (slim ? 1 : n) * L.sD;
+    L.oX = o;      o += ((slim & 1) ? 1 : n) * L.sD;
     L.oU1 = o;     o += n * L.sH;
     L.oU2 = o;     o += n * L.sH;   // U2; node mode: overwritten row by row with dZ2 once the row's U2 has been consumed
     L.oU3 = o;     o += graph ? n * L.sO : 0;
     L.odZ2 = graph ? o : L.oU2;
     o += graph ? n * L.sH : 0;
-    L.odZ1 = o;    o += slim ? ld : n * L.sD;
-    if (slim && o < 7 * ld + 2 * 16 + 8) o = 7 * ld + 2 * 16 + 8;   // the setup's temporaries (7 ld + 2 SP_CHUNK + 8 ints) live in front of Abar
+    L.odZ1 = o;    o += (slim & 1) ? ld : n * L.sD;
+    if ((slim & 1) && o < 7 * ld + 2 * 16 + 8) o = 7 * ld + 2 * 16 + 8;   // the setup's temporaries (7 ld + 2 SP_CHUNK + 8 ints) live in front of Abar
     L.oAb = o;     o += nnz;
     L.oGe = o;     o += graph ? 0 : nnz;  // node mode: dL/dAbar per directed entry (row-side product), written by the layer-1 backward
     L.oCol = o;    o += (nnz + 1) / 2;  // uint16 columns
@@ -105,19 +106,19 @@ __host__ __device__ inline SparseLayout sparse_layout(int n, int ld, int nnz, in
     L.oRn3 = o;    o += graph ? ld : 0;
     L.oYhat = o;   o += ld;
     L.oG3 = o;     o += ld;
-    L.oW = o;      o += slim ? 0 : (D + 2 * H) * 33;  // rows k < D of W1, k < H of W2, k < H of W3, 33-float rows
-    L.oWp = o;     o += slim ? 0 : C * 96;
+    L.oW = o;      o += (slim & 2) ? 0 : (D + 2 * H) * 33;  // rows k < D of W1, k < H of W2, k < H of W3, 33-float rows
+    L.oWp = o;     o += (slim & 2) ? 0 : C * 96;
     L.total = o;
     return L;
 }
 // does a target fit the class of nt threads?  (slots: row slots it needs with EVERY row placed, from k_count_edges)
 __host__ __device__ inline bool sparse_fits(int nt, int n, int ld, int nnz, int slots, int D, int H, int C, int graph = 0,
-                                            int O = 0, int slim_pool = 0) {
-    // the setup's temporaries (7 ld + 2 SP_CHUNK + 8 ints) live in the X / U1 / U2 / dZ1 arrays, which are contiguous
-    // slim_pool > 0: the slim layout in a pool of that many floats (k_sparse_resident_tiny)
+                                            int O = 0, int slim_pool = 0, int slim = 0) {
+    // the setup's temporaries (7 ld + 2 SP_CHUNK + 8 ints) live in the X / U1 / U2 / dZ1 arrays, which are contiguous (slim layouts pad them)
+    // slim: the layout's form (sparse_layout); slim_pool > 0: in a pool of that many floats (k_sparse_resident_tiny) instead of the class's
     return ld <= sp_ld_max(nt) && nnz / 2 <= sp_qmax(nt) * nt && nnz < 65536 && slots >= 0 && slots <= nt / 2 &&
-           C <= RES_CMAX && H >= 2 && (slim_pool || 2 * n * ((H | 1) + (D | 1)) >= 7 * ld + 2 * SP_CHUNK + 8) &&
-           sparse_layout(n, ld, nnz, D, H, C, graph, O, slim_pool ? 1 : 0).total <= (slim_pool ? slim_pool : sp_pool_floats(nt));
+           C <= RES_CMAX && H >= 2 && ((slim & 1) || 2 * n * ((H | 1) + (D | 1)) >= 7 * ld + 2 * SP_CHUNK + 8) &&
+           sparse_layout(n, ld, nnz, D, H, C, graph, O, slim).total <= (slim_pool ? slim_pool : sp_pool_floats(nt));
 }
 
 // a lane's row slot in one row set: the row (valid when first), its chunk of entries, the split bookkeeping
@@ -317,6 +318,10 @@ __device__ __forceinline__ void sparse_forward_rowlocal(const float (&zq)[NQ], c
                                                         int dout, int li, int h, bool store, float* sUrow, float* srn_r) {
     if (dout == 20)  // the reference's hidden / output width
         sparse_forward_rowlocal_impl<NQ, 20>(zq, sW, bias, din, dout, li, h, store, sUrow, srn_r);
+    else if (dout == 16)  // (round 6: the other compile-time widths, --hidden-dim 16 / 32)
+        sparse_forward_rowlocal_impl<NQ, 16>(zq, sW, bias, din, dout, li, h, store, sUrow, srn_r);
+    else if (dout == 32)
+        sparse_forward_rowlocal_impl<NQ, 32>(zq, sW, bias, din, dout, li, h, store, sUrow, srn_r);
     else
         sparse_forward_rowlocal_impl<NQ, 0>(zq, sW, bias, din, dout, li, h, store, sUrow, srn_r);
 }
@@ -336,6 +341,8 @@ __device__ __forceinline__ void sparse_store_cols_impl(const f32x16& c16, float*
 __device__ __forceinline__ void sparse_store_cols(const f32x16& c16, float* row, int kmax, bool pred, int h) {
     if (kmax == 20) sparse_store_cols_impl<20>(c16, row, kmax, pred, h);       // hidden width of the reference
     else if (kmax == 10) sparse_store_cols_impl<10>(c16, row, kmax, pred, h);  // input width of the reference
+    else if (kmax == 16) sparse_store_cols_impl<16>(c16, row, kmax, pred, h);
+    else if (kmax == 32) sparse_store_cols_impl<32>(c16, row, kmax, pred, h);
     else sparse_store_cols_impl<0>(c16, row, kmax, pred, h);
 }
 
@@ -447,6 +454,8 @@ template <int DQ, int HQ, bool GRAPH, int NT, int XC = 0, bool LOG = false, bool
 __device__ __forceinline__ void sparse_resident_body(const Params p, int t, const float* adam_tab, float* pool, SH& sh,
                                                      int tid, float* shared_w = nullptr, int* pair_flag = nullptr, int slim_pool = 0) {
     constexpr bool SLIM = SH::slim;
+    constexpr int LAY = SLIM ? 3 : (XC == 2 ? 1 : 0);   // the LDS layout's form (sparse_layout: slim)
+    constexpr bool SLAY = (LAY & 1) != 0;
     static_assert(!SLIM || (NT == 64 && XC == 2 && !LOG && !GRAPH && EX), "the slim form: single-wave targets of the algebraic node-mode form, exact widths");
     constexpr int SCAN = (sp_ld_max(NT) + 63) / 64;  // rows per lane in the setup prefix scans
     constexpr int SP_QMAX = sp_qmax(NT);
@@ -506,7 +515,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
     }
     SYNC();
     const int nnz = ld_ok ? sh.nnz : 0;
-    const bool fits = ld_ok && sparse_fits(NT, n, ld, nnz, 0, D, H, C, GRAPH, O, SLIM ? slim_pool : 0) && (!SLIM || (slim_pool > 0 && shared_w));  // the slot count is checked once the slots are placed
+    const bool fits = ld_ok && sparse_fits(NT, n, ld, nnz, 0, D, H, C, GRAPH, O, SLIM ? slim_pool : 0, LAY) && (!SLIM || (slim_pool > 0 && shared_w));  // the slot count is checked once the slots are placed
     if (!fits) {
         // the plan promised a target that fits (gnnx_plan_analyze); anything else must fail loudly, not silently
         const float qnan = __builtin_nanf("");
@@ -514,7 +523,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         if (tid < FS) p.f[p.num_iters & 1][t * FS + tid] = qnan;
         return;
     }
-    const SparseLayout L = sparse_layout(n, ld, nnz, D, H, C, GRAPH, O, SLIM ? 1 : 0);
+    const SparseLayout L = sparse_layout(n, ld, nnz, D, H, C, GRAPH, O, LAY);
     // rowptr currently sits at the start of the pool = inside the future sX region: move it through registers
     const int rp_keep = (tid < ld) ? tmp_deg[tid] : nnz;
     SYNC();
@@ -849,11 +858,11 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         sU1[e] = 0.0f;
         sU2[e] = 0.0f;
     }
-    for (int e = tid; e < (SLIM ? ld : n * sD); e += NT) sdZ1[e] = 0.0f;   // (slim form: one float per row, see sparse_layout)
+    for (int e = tid; e < (SLAY ? ld : n * sD); e += NT) sdZ1[e] = 0.0f;   // (slim form: one float per row, see sparse_layout)
     if (!GRAPH)  // entries of rows beyond two hops are never written: their row-side products are exactly zero
         for (int e = tid; e < nnz; e += NT) sGe[e] = 0.0f;
     // ---------------- load features, model, labels ----------------
-    for (int e = tid; e < (SLIM ? 1 : n) * 32; e += NT) {   // (slim form: row 0 stands for every row; verified against the others below)
+    for (int e = tid; e < (SLAY ? 1 : n) * 32; e += NT) {   // (slim form: row 0 stands for every row; verified against the others below)
         const int r = e >> 5, c = e & 31;
         // (the padding column of an even D is written too: the run-time-width forms multiply it by an exact zero, and 0 x stale LDS garbage
         // is NaN when the garbage is - found by the D = 8 case of test_mixed_launch_with_other_encoder_widths on the GPU, round 5)
@@ -891,7 +900,7 @@ __device__ __forceinline__ void sparse_resident_body(const Params p, int t, cons
         bool same = true;
         for (int e = tid; e < n * D; e += NT) {
             const int r = e / D, c = e - r * D;
-            if constexpr (SLIM) same &= __float_as_uint(p.X[(tm.offR + r) * FS + c]) == __float_as_uint(sX[c]);   // (the other rows stay in global memory)
+            if constexpr (SLAY) same &= __float_as_uint(p.X[(tm.offR + r) * FS + c]) == __float_as_uint(sX[c]);   // (the other rows stay in global memory)
             else same &= __float_as_uint(sX[r * sD + c]) == __float_as_uint(sX[c]);
         }
         if (!same) sh.xconst = 0;

@@ -48,6 +48,10 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 
 WIN, SUB, EPOCHS = 50, 10, 300
+# (target, window) pairs that get the 10-epoch snapshots although the CPU probes did not flag them (round 6, VERDICT r5 missing #6): windows in
+# which the GPU kernels take the other side of a gate the reference decides by 1e-6 ... 2e-5 - with the snapshots the decision suite leaves only
+# the 10 epochs around that tie ungated instead of the whole 50-epoch window (tests/golden/syn5_ties.json: sub = -1 before).
+FORCE_FINE = {"syn5": {(532, 2), (557, 5), (620, 3)}}
 FLAG = 2e-6
 MOTIF_START = {"syn1": 300, "syn4": 511, "syn5": 511}
 
@@ -170,7 +174,7 @@ def _oracle_out(o, rc, state, k0, steps):
     return (np.stack([o.M[r, c], o.M[c, r]], 1), None, None, o.f.copy())
 
 
-def classify_windows(sub_adj, sub_feat, sd, gt, pred_label, new_idx, mask0, rec, graph_mode, seed):
+def classify_windows(sub_adj, sub_feat, sd, gt, pred_label, new_idx, mask0, rec, graph_mode, seed, force=()):
     """(cond50, sens50) [2][6] and, for the flagged windows, (cond10, sens10) [2][5] each (see the module docstring)."""
     from oracle import closed_form
     o = closed_form.ClosedFormOracle(sub_adj.astype(np.float32), sub_feat.astype(np.float32), sd, gt, pred_label, new_idx, mask0,
@@ -193,7 +197,7 @@ def classify_windows(sub_adj, sub_feat, sd, gt, pred_label, new_idx, mask0, rec,
     cond50, cond10 = np.zeros((3, EPOCHS // WIN), np.float32), {}     # [0]: CPU vs CPU, [1]: 1-ulp sensitivity, [2]: smallest gate margin
     for w in range(EPOCHS // WIN):
         cond50[:, w] = _oracle_dev(o, rc, state(WIN * w), rec[WIN * (w + 1)], WIN * w, WIN, seed=(seed, w))
-        if cond50[:2, w].max() > FLAG or cond50[2, w] < GATE:
+        if cond50[:2, w].max() > FLAG or cond50[2, w] < GATE or w in force:
             cond10[w] = np.asarray([_oracle_dev(o, rc, state(WIN * w + SUB * s), rec[WIN * w + SUB * (s + 1)], WIN * w + SUB * s, SUB,
                                                 seed=(seed, w, s)) for s in range(WIN // SUB)], np.float32).T      # [3][5]
     return cond50, cond10
@@ -245,7 +249,8 @@ def _node_worker(job):
         # (not stored), so check the next best thing: every stored M is finite and the edge structure is the fixture's
         assert not np.isnan(ma).any() and all(np.isfinite(x[0]).all() for x in rec.values())
         pl = np.argmax(cg["pred"][0][nb], axis=1)
-        cond50, cond10 = classify_windows(sub_adj, sub_feat, sd, int(sub_label[new_idx]), pl, int(new_idx), mod.mask0.numpy(), rec, False, int(t))
+        force = {w for (tt, w) in FORCE_FINE.get(dataset, ()) if tt == int(t)}
+        cond50, cond10 = classify_windows(sub_adj, sub_feat, sd, int(sub_label[new_idx]), pl, int(new_idx), mod.mask0.numpy(), rec, False, int(t), force)
         out.append(_pack_target(int(t), rec, cond50, cond10, dict(nedges=len(r))))
         for f in os.listdir(args.logdir):
             os.remove(os.path.join(args.logdir, f))
@@ -415,6 +420,8 @@ def main():
             mg.mint_checkpoint(ds, a.work)
     for ds in ("syn1", "syn4", "syn5"):
         if ds in what:
+            if not os.path.exists(os.path.join(a.work, "ckpt", f"{ds}_base_h20_o20.pth.tar")):
+                _setup().mint_checkpoint(ds, a.work)
             node_windows(ds, a.work, a.procs, a.limit)
     if "config4" in what:
         config4_windows(a.work, a.procs, limit=a.limit)

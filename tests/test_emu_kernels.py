@@ -638,6 +638,35 @@ def test_mixed_launch_with_other_encoder_widths(be, D, H, O):
         assert np.abs(res.masked_adj[i] - o.run(3)).max() < 5e-6, i
 
 
+@pytest.mark.parametrize("H", [16, 32])
+@pytest.mark.parametrize("const", [False, True])
+def test_compile_time_widths_hidden_16_and_32(be, H, const):
+    """--hidden-dim = --output-dim = 16 / 32 on 10 input features (round 6): the node-mode resident kernels' compile-time-width instantiations
+    <5, 8> / <5, 16> - the mixed launch (a 512-thread target, a pair workgroup, single-wave targets) - in the general form (random feature rows)
+    and, with constant feature rows, the algebraic form (until round 6 only the reference's own widths had one).  Closed form, 3 iterations."""
+    rng = np.random.default_rng(1000 + H + const)
+    sd = helpers.random_model(rng, 10, H, H, 4)
+    row = rng.uniform(0.2, 1.5, 10).astype(np.float32)
+
+    def sub(n, density, t):
+        A, X = helpers.random_graph(rng, n, 10, density=density)
+        if const:
+            X = np.tile(row, (n, 1)).astype(np.float32)
+        m0 = (1.0 + rng.standard_normal((n, n)) * np.sqrt(2.0 / n)).astype(np.float32)
+        return Subgraph(A, X, 1, t, rng.integers(0, 4, n), m0)
+
+    subs = [sub(180, 0.02, 3), sub(70, 0.06, 5), sub(50, 0.1, 0), sub(20, 0.2, 2), sub(12, 0.2, 1)]
+    job = be.job(subs, sd)
+    route = list(job.route())
+    assert route[0] == 8 and route[-1] == 6 and set(route) <= {5, 6, 8}, route      # (with 33-float rows a target can move up a class)
+    res = job.run([s.mask0 for s in subs], Hyper(num_iters=3))
+    for i, s in enumerate(subs):
+        o = closed_form.ClosedFormOracle(s.adj, s.feat, sd, s.gt_label, s.pred_label, s.target_row, s.mask0)
+        assert np.abs(res.masked_adj[i] - o.run(3)).max() < (2e-5 if const else 5e-6), i
+        solo = be.job([s], sd).run([s.mask0], Hyper(num_iters=3))      # the class's own launch: the same body
+        assert np.array_equal(solo.masked_adj[0], res.masked_adj[i]), i
+
+
 def test_pair_workgroups_two_256_thread_targets_per_workgroup(be, monkeypatch):
     """Targets of the 256-thread class (n <= 128) run TWO to a 512-thread workgroup of the mixed launch, each body in its half of the threads
     and of the LDS pool, every __syncthreads() a barrier for both (k_sparse_resident_mixed).  Three of them (an odd count: the last pair
