@@ -131,13 +131,15 @@ def ties_path(name):
 
 
 def load_ties(name):
-    """-> {"windows": {(id, w, sub): row}, "full": {id: row}, "early": {id: row}} or None when the list has not been generated"""
+    """-> {"windows": {(id, w, sub): row}, "resolved": {(id, w): row}, "full": {id: row}, "early": {id: row}} or None when the list has not been generated
+    ("resolved": 50-epoch windows that miss at 50 epochs while their five 10-epoch sub-windows are all gated - tests/test_decision_parity.py::_verdict)"""
     import json
     p = ties_path(name)
     if not os.path.exists(p):
         return None
     z = json.load(open(p))
     return {"windows": {(int(r["id"]), int(r["w"]), int(r["sub"])): r for r in z.get("windows", [])},
+            "resolved": {(int(r["id"]), int(r["w"])): r for r in z.get("resolved", [])},
             "full": {int(r["id"]): r for r in z.get("full", [])},
             "early": {int(r["id"]) for r in z.get("windows", []) if int(r["w"]) == 0}}
 

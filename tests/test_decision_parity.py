@@ -84,8 +84,8 @@ def _decision_windows(W, Dn, make_job, ks_all, coarse_windows=None):
                          max(W.z["cond50"][k, w], W.z["sens50"][k, w], Nz["noise50"][k, w], Nz["ssens50"][k, w]))
             if (not row["agree"] or row["expansive"]) and (int(k), int(w)) in W.fine_row:
                 redo.append(int(k))
-            else:
-                rows.append(row)
+                row["redo"] = True      # judged through its five 10-epoch sub-windows (below); kept for the list's "resolved" part (see _verdict)
+            rows.append(row)
         if not redo:
             continue
         ks = np.asarray(redo, np.int64)
@@ -142,6 +142,16 @@ def _verdict(what, rows, Dn, jump, list_name=None):
     """rows of _decision_windows -> summary string; asserts the rules of the module docstring.  list_name: the fixture name whose committed list
     (tests/golden/<name>_ties.json, part "windows") every row not gated at plain 1e-5 must be on (GPU runs over ALL targets; None: a partial run)."""
     bound = lambda r: max(TOL, ROUNDOFF_BUDGET * r["smooth"])
+    # 50-epoch windows that were re-run as 10-epoch sub-windows are judged by those; the ones that end beyond 1e-5 (or with a differing decision)
+    # at 50 epochs while ALL their sub-windows - teacher-forced from the reference's own 10-epoch states - are gated at plain 1e-5 with identical
+    # decisions go on the list's "resolved" part: the outcome tests over whole windows (tests/test_windowed_parity.py) look them up there.
+    redone = [r for r in rows if r.get("redo")]
+    rows = [r for r in rows if not r.get("redo")]
+    subs_of = {}
+    for r in rows:
+        if r["sub"] >= 0:
+            subs_of.setdefault((r["id"], r["w"]), []).append(r)
+    resolved = [r for r in redone if (not r["agree"] or r["err"] > TOL) and all(x["agree"] and x["err"] <= TOL for x in subs_of.get((r["id"], r["w"]), []))]
     agreed = [r for r in rows if r["agree"]]
     ties = [r for r in rows if not r["agree"]]
     total = sum(r["iters"] for r in rows)
@@ -177,6 +187,10 @@ def _verdict(what, rows, Dn, jump, list_name=None):
     assert not unjust, msg + f"; first: {unjust[0]}"
     assert all(r["err"] <= jump for r in ties), msg
     _check_listed(list_name, "windows", [((r["id"], r["w"], r["sub"]), _tie_row(r, w=int(r["w"]), sub=int(r["sub"]))) for r in over + ties], lambda k: k)
+    _check_listed(list_name, "resolved", [((r["id"], r["w"]), _tie_row(r, w=int(r["w"]), sub=-1)) for r in resolved], lambda k: k)
+    if resolved:
+        print(f"{what}: {len(resolved)} 50-epoch windows beyond 1e-5 / with a differing decision whose five 10-epoch sub-windows are all gated at 1e-5: "
+              f"{[(r['id'], r['w'], float('%.2e' % r['err'])) for r in resolved[:20]]}")
     return msg
 
 

@@ -110,7 +110,7 @@ def _verdict(what, rows, bound=SUB_FLAG_BOUND, list_name=None):
     if len(bad):
         ties = helpers.load_ties(list_name) if list_name else None
         assert list_name is None or ties is not None or os.environ.get("GNNX_WRITE_TIES") == "1", f"{helpers.ties_path(list_name)} missing"
-        listed = set() if ties is None else {(i, w) for (i, w, _) in ties["windows"]}
+        listed = set() if ties is None else ({(i, w) for (i, w, _) in ties["windows"]} | set(ties["resolved"]))
         unexplained = [(int(r[0]), int(r[1]), int(r[2]), float(r[3])) for r in bad if (int(r[0]), int(r[1])) not in listed]
         # (a partial run - the emulator's handful of targets - has no list: every well-conditioned window must then be inside)
         assert not unexplained or os.environ.get("GNNX_WRITE_TIES") == "1", msg + f"; well-conditioned windows beyond 1e-5 that the decision suite's list does not explain: {unexplained[:10]}"
