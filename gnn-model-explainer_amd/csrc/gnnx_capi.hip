@@ -2478,22 +2478,26 @@ extern "C" int gnnx_xl_run(gnnx_xl_handle h, const gnnx_hyper* hy, const gnnx_xl
 
 // the jump polynomial of the segmented engine walk (utils/mt_jump.py): process-wide, one device copy per device; jump = 0: serial walks
 namespace {
-struct MtJump { std::vector<uint32_t> poly; long long jump = 0; uint32_t* d_poly[MAX_DEVICES] = {}; };
+struct MtJump { std::vector<uint32_t> poly; long long jump = 0; int levels = 1; uint32_t* d_poly[MAX_DEVICES] = {}; };
 MtJump g_mtj;
 std::mutex g_mtj_mu;
 }  // namespace
-extern "C" int gnnx_set_mt_jump_poly(const uint32_t* poly, int64_t jump_draws) {
+// polys [levels][624]: the polynomials of the strides 4^l segments (l = 0 .. levels - 1; levels <= 3): x^(4^l J) mod phi
+extern "C" int gnnx_set_mt_jump_polys(const uint32_t* polys, int64_t jump_draws, int32_t levels) {
     std::lock_guard<std::mutex> lk(g_mtj_mu);
-    if (!poly || jump_draws <= 0) {
+    if (!polys || jump_draws <= 0) {
         g_mtj.jump = 0;
         return 0;
     }
-    if (jump_draws % MT_N) return fail("gnnx_set_mt_jump_poly: the stride must be a whole number of 624-draw blocks");
-    g_mtj.poly.assign(poly, poly + MT_N);
+    if (jump_draws % MT_N) return fail("gnnx_set_mt_jump_polys: the stride must be a whole number of 624-draw blocks");
+    if (levels < 1 || levels > MTJ_MAX_LEVELS) return fail("gnnx_set_mt_jump_polys: one to three levels");
+    g_mtj.poly.assign(polys, polys + (size_t)levels * MT_N);
     g_mtj.jump = jump_draws;
+    g_mtj.levels = levels;
     for (auto& d : g_mtj.d_poly) d = nullptr;      // (device copies of an older polynomial are dropped: a few KB, once per process)
     return 0;
 }
+extern "C" int gnnx_set_mt_jump_poly(const uint32_t* poly, int64_t jump_draws) { return gnnx_set_mt_jump_polys(poly, jump_draws, 1); }
 
 extern "C" int gnnx_xl_mt_edge_words(gnnx_xl_handle h, const int64_t* seeds, void* ws_rows, void* ws_entries, uint32_t* words, void* stream) {
     if (!h || !seeds || !ws_rows || !ws_entries || !words) return fail("null argument");
@@ -2503,18 +2507,20 @@ extern "C" int gnnx_xl_mt_edge_words(gnnx_xl_handle h, const int64_t* seeds, voi
     char* e = static_cast<char*>(ws_entries);
     const int T = h->prob.num_targets;
     long long jump = 0;
+    int levels = 1;
     const uint32_t* d_poly = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_mtj_mu);
         jump = g_mtj.jump;
+        levels = g_mtj.levels;
         if (jump > 0) {
             int dev = 0;
             (void)hipGetDevice(&dev);
             if (dev < 0 || dev >= MAX_DEVICES) dev = 0;
             if (!g_mtj.d_poly[dev]) {
                 uint32_t* d = nullptr;
-                HIPCK(hipMalloc(&d, sizeof(uint32_t) * MT_N));
-                HIPCK(upload_sync(d, g_mtj.poly.data(), sizeof(uint32_t) * MT_N));
+                HIPCK(hipMalloc(&d, sizeof(uint32_t) * g_mtj.poly.size()));
+                HIPCK(upload_sync(d, g_mtj.poly.data(), sizeof(uint32_t) * g_mtj.poly.size()));
                 g_mtj.d_poly[dev] = d;
             }
             d_poly = g_mtj.d_poly[dev];
@@ -2539,18 +2545,50 @@ extern "C" int gnnx_xl_mt_edge_words(gnnx_xl_handle h, const int64_t* seeds, voi
         (void)pool_free(h->mt_block);
         h->mt_block = nullptr;
     }
-    const size_t o_off = 0, o_seg = align_up(sizeof(long long) * seg_off.size(), 256), o_state = align_up(o_seg + sizeof(MtSeg) * segs.size(), 256);
+    // the chains of the segment starts, level by level (k_mt_segment_starts): level l jumps 4^l segments at a time; the top level's chain of a
+    // target seeds it and runs from segment 0, every lower level starts one chain of up to three jumps at every multiple of 4^(l + 1)
+    std::vector<MtJumpItem> items;
+    size_t lvl_first[MTJ_MAX_LEVELS + 1] = {};
+    if (jump <= 0) levels = 1;
+    for (int l = levels - 1; l >= 0; --l) {
+        lvl_first[levels - 1 - l] = items.size();
+        int step = 1;
+        for (int k = 0; k < l; ++k) step *= MTJ_RADIX;
+        const bool top = l == levels - 1;
+        for (int t = 0; t < T; ++t) {
+            const int K = (int)(seg_off[t + 1] - seg_off[t]);
+            if (K == 0) continue;
+            if (top) {
+                items.push_back({t, 0, step, (K - 1) / step, 1, 0});
+            } else {
+                for (int s0 = 0; s0 < K; s0 += step * MTJ_RADIX) {
+                    const int cnt = std::min(MTJ_RADIX - 1, (K - 1 - s0) / step);
+                    if (cnt > 0) items.push_back({t, s0, step, cnt, 0, 0});
+                }
+            }
+        }
+    }
+    lvl_first[levels] = items.size();
+    const size_t o_off = 0, o_seg = align_up(sizeof(long long) * seg_off.size(), 256), o_items = align_up(o_seg + sizeof(MtSeg) * segs.size(), 256),
+                 o_state = align_up(o_items + sizeof(MtJumpItem) * items.size(), 256);
     const size_t bytes = o_state + sizeof(uint32_t) * MT_N * (size_t)seg_off[T];
     HIPCK(pool_malloc(&h->mt_block, bytes));
     std::vector<char> host(o_state);
     std::memcpy(host.data() + o_off, seg_off.data(), sizeof(long long) * seg_off.size());
     std::memcpy(host.data() + o_seg, segs.data(), sizeof(MtSeg) * segs.size());
+    std::memcpy(host.data() + o_items, items.data(), sizeof(MtJumpItem) * items.size());
     HIPCK(upload_sync(h->mt_block, host.data(), host.size()));
     char* mb = static_cast<char*>(h->mt_block);
     const long long* d_seg_off = reinterpret_cast<const long long*>(mb + o_off);
     const MtSeg* d_segs = reinterpret_cast<const MtSeg*>(mb + o_seg);
     uint32_t* d_state = reinterpret_cast<uint32_t*>(mb + o_state);
-    hipLaunchKernelGGL(k_mt_segment_starts, dim3(T), dim3(MTX_THREADS), 0, s, h->d_meta, seeds, d_seg_off, d_poly, jump, d_state);
+    const MtJumpItem* d_items = reinterpret_cast<const MtJumpItem*>(mb + o_items);
+    for (int k = 0; k < levels; ++k) {      // top level first; a level reads the states the one above it wrote (same stream)
+        const size_t cnt = lvl_first[k + 1] - lvl_first[k];
+        if (cnt)
+            hipLaunchKernelGGL(k_mt_segment_starts, dim3((unsigned)cnt), dim3(MTX_THREADS), 0, s, h->d_meta, seeds, d_seg_off,
+                               d_poly ? d_poly + (size_t)(levels - 1 - k) * MT_N : nullptr, jump, d_state, d_items + lvl_first[k]);
+    }
     hipLaunchKernelGGL(k_mt_edge_words_seg, dim3((unsigned)segs.size()), dim3(MTX_THREADS), 0, s, h->d_meta, d_segs, d_seg_off, jump, (const uint32_t*)d_state,
                        h->d_csr_off, reinterpret_cast<const int32_t*>(w + h->r_rowptr), reinterpret_cast<const int32_t*>(w + h->r_uprow),
                        reinterpret_cast<const int32_t*>(e + h->e_col), reinterpret_cast<const int32_t*>(e + h->e_row), h->d_eoff, words);

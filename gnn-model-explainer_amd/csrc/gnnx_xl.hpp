@@ -182,18 +182,26 @@ __host__ __device__ inline int mt_segments(long long n, long long jump) {
 // ring (the block that holds i, the next one, and the one being generated) are enough - 7.5 KB of LDS instead of 85, which lets the kernel run
 // beside the 96 KB workgroups of the XL loop instead of waiting for a compute unit to drain (profiles/r06_kernel_stats_ba100k_all.csv: 471 ms
 // behind a batch of the largest sub-graphs with the 85 KB form).
+// Hierarchical strides (round 6, second half): a target's segment starts were ONE serial chain of K - 1 jumps (0.9 ms each in the ring form): 250 ms
+// for the 47 913-node sub-graph's 274 segments - the pole of the batch that holds it and of the rank that owns it.  With the polynomials of the
+// strides J, 4 J and 16 J (g^4, g^16 mod phi: utils/mt_jump.py) the starts form a radix-4 tree: one chain of (K - 1) / 16 jumps of 16 segments, then - in
+// parallel, one workgroup per base - chains of at most three jumps of 4 segments and of 1 segment: the same K - 1 jumps, (K - 1) / 16 + 6 deep.
+// An item = one chain: from the state of segment s0 (seeded and produced here when `init`), `count` jumps of `step` segments with the level's polynomial.
 constexpr int MTJ_RING = 3 * MT_N;
+constexpr int MTJ_RADIX = 4, MTJ_MAX_LEVELS = 3;
+struct MtJumpItem { int32_t t, s0, step, count, init, pad; };
 __global__ __launch_bounds__(MTX_THREADS) void k_mt_segment_starts(const TargetMeta* meta, const int64_t* seeds, const long long* seg_off,
-                                                                   const uint32_t* poly, long long jump, uint32_t* seg_state) {
+                                                                   const uint32_t* poly, long long jump, uint32_t* seg_state, const MtJumpItem* items) {
     __shared__ uint32_t y[MTJ_RING];
     __shared__ uint32_t spoly[MT_N];      // the polynomial, once per workgroup: a jump reads its 624 words one after the other - from global memory each
                                           // word was a dependent ~2 us round trip, 1.2 of the 1.6 ms of a jump (profiles/r06_probe_xl_jump_walk.txt)
-    const int t = blockIdx.x;
+    const MtJumpItem it = items[blockIdx.x];
+    const int t = it.t;
     const int tid = threadIdx.x;
     const long long n = meta[t].n;
     const int K = mt_segments(n, jump);
     if (K == 0) return;
-    if (K > 1)
+    if (it.count > 0)
         for (int k = tid; k < MT_N; k += MTX_THREADS) spoly[k] = poly[k];
     // block `nb` of the ring <- the block after block `ob` (three sweeps: the recurrence's dependency distance is 227 words)
     auto next_block = [&](int ob, int nb) {
@@ -212,29 +220,37 @@ __global__ __launch_bounds__(MTX_THREADS) void k_mt_segment_starts(const TargetM
         }
         __syncthreads();
     };
-    if (tid == 0) {   // at::mt19937::init_with_uint32
-        uint32_t x = (uint32_t)((unsigned long long)seeds[t] & 0xffffffffull);
-        y[0] = x;
-        for (int j = 1; j < MT_N; ++j) {
-            x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)j;
-            y[j] = x;
-        }
-    }
-    __syncthreads();
-    next_block(0, 1);      // the first block: draws [0, 624) = x_624 .. x_1247
-    uint32_t* out = seg_state + (size_t)seg_off[t] * MT_N;
+    uint32_t* out = seg_state + ((size_t)seg_off[t] + it.s0) * MT_N;
     int jcl[3];            // this thread's three window words, clamped to the window
 #pragma unroll
     for (int q = 0; q < 3; ++q) jcl[q] = (tid + q * MTX_THREADS < MT_N) ? tid + q * MTX_THREADS : MT_N - 1;
     uint32_t win[3];       // the current window (segment start), three words per thread
+    if (it.init) {
+        if (tid == 0) {   // at::mt19937::init_with_uint32
+            uint32_t x = (uint32_t)((unsigned long long)seeds[t] & 0xffffffffull);
+            y[0] = x;
+            for (int j = 1; j < MT_N; ++j) {
+                x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)j;
+                y[j] = x;
+            }
+        }
+        __syncthreads();
+        next_block(0, 1);      // the first block: draws [0, 624) = x_624 .. x_1247
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const int j = tid + q * MTX_THREADS;
-        win[q] = (j < MT_N) ? y[MT_N + j] : 0u;
-        if (j < MT_N) out[j] = win[q];
+        for (int q = 0; q < 3; ++q) {
+            const int j = tid + q * MTX_THREADS;
+            win[q] = (j < MT_N) ? y[MT_N + j] : 0u;
+            if (j < MT_N) out[j] = win[q];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {      // the chain's first state: written by the level above (an earlier launch on this stream)
+            const int j = tid + q * MTX_THREADS;
+            win[q] = (j < MT_N) ? out[j] : 0u;
+        }
     }
     __syncthreads();
-    for (int s = 1; s < K; ++s) {
+    for (int s = 1; s <= it.count; ++s) {
         // ring block 0 <- the window, block 1 <- its successor
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -290,7 +306,7 @@ __global__ __launch_bounds__(MTX_THREADS) void k_mt_segment_starts(const TargetM
             if ((blk + 1) * MT_N < MT_DEG) next_block(b1, b2), b0 = b1;
             // (the ring now holds blocks blk + 1 (b0) and blk + 2; block blk + 2 was generated from blk + 1 - into the slot block blk left)
         }
-        out += MT_N;
+        out += (size_t)it.step * MT_N;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int j = tid + q * MTX_THREADS;

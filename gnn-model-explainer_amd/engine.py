@@ -194,6 +194,7 @@ _API = {
     "gnnx_xl_mt_edge_words": (ctypes.c_int, [ctypes.c_void_p] * 6),
     "gnnx_xl_set_clocks": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "gnnx_set_mt_jump_poly": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
+    "gnnx_set_mt_jump_polys": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]),
     "gnnx_xl_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(_Hyper), ctypes.POINTER(_XlState)] + [ctypes.c_void_p] * 5),
     "gnnx_last_error": (ctypes.c_char_p, []),
     "gnnx_version": (ctypes.c_char_p, []),
@@ -1216,7 +1217,10 @@ def enable_mt_jump(lib=None, poly=None, jump=None):
         return
     poly = np.ascontiguousarray(poly, np.uint32)
     assert poly.shape == (624,)
-    _check(lib, lib.gnnx_set_mt_jump_poly(poly.ctypes.data, int(jump)))
+    from .utils import mt_jump
+    levels = int(os.environ.get("GNNX_MT_JUMP_LEVELS", mt_jump.LEVELS))      # (1: one chain of K - 1 jumps per target, the first form)
+    polys = np.ascontiguousarray(mt_jump.jump_polys(poly, levels), np.uint32)      # strides J, 4 J, 16 J: ~0.2 s, once per process
+    _check(lib, lib.gnnx_set_mt_jump_polys(polys.ctypes.data, int(jump), levels))
 
 
 @dataclass

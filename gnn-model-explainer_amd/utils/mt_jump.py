@@ -88,6 +88,21 @@ def poly_words(g):
     return np.frombuffer(g.to_bytes(MT_N * 4, "little"), np.uint32).copy()
 
 
+LEVELS, RADIX = 3, 4      # the segment starts of a target form a radix-4 tree of jumps with the strides J, 4 J, 16 J (csrc/gnnx_xl.hpp: k_mt_segment_starts)
+
+
+def jump_polys(poly_words_J, levels=LEVELS, phi=None):
+    """uint32 [levels][624]: x^(RADIX^l J) mod phi for l = 0 .. levels - 1, from the words of g = x^J mod phi (g^4, g^16: two squarings each)"""
+    phi = charpoly() if (phi is None and levels > 1) else phi
+    g = int.from_bytes(np.ascontiguousarray(poly_words_J, np.uint32).tobytes(), "little")
+    out = [poly_words(g)]
+    for _ in range(1, levels):
+        for _ in range(RADIX.bit_length() - 1):
+            g = _mod(_square(g), phi)
+        out.append(poly_words(g))
+    return np.stack(out)
+
+
 def load_jump_poly():
     """The committed polynomial of stride JUMP (recomputed and compared by tests/test_mt_jump.py)."""
     return np.load(POLY_FILE)

@@ -402,6 +402,10 @@ int gnnx_xl_mt_edge_words(gnnx_xl_handle h, const int64_t* seeds, void* ws_rows,
  * segment start (k_mt_segment_starts) and walks the segments in parallel (k_mt_edge_words_seg): the 2.3e9 draws of a 47 913-node sub-graph in ~35 ms
  * instead of 1.7 s.  NULL / 0: serial walks. */
 int gnnx_set_mt_jump_poly(const uint32_t* poly, int64_t jump_draws);
+/* ... with the polynomials of the strides jump, 4 jump, 16 jump (polys [levels][624], levels <= 3: x^(4^l jump) mod phi - utils/mt_jump.jump_polys)
+ * the segment starts of a target form a radix-4 tree instead of one chain of K - 1 jumps: (K - 1) / 16 + 6 jumps deep (the 274 segments of the
+ * 47 913-node sub-graph: 23 instead of 273 dependent jumps). */
+int gnnx_set_mt_jump_polys(const uint32_t* polys, int64_t jump_draws, int32_t levels);
 int gnnx_xl_set_trace(gnnx_xl_handle h, uint32_t* gates);
 /* Measurement hook: ticks [T][4] (DEVICE int64) receives, from every later gnnx_xl_run, the wall_clock64 value (100 MHz) at the start of target t's
  * workgroup, after its setup, after its iteration loop and at its end; NULL = off.  parallel.py calibrates the sharded job's cost model on them. */
