@@ -588,7 +588,10 @@ def bench_ba100k_all(args, dev, log, dist, world, rank):
             "dense_equivalent": {"achieved_GBps": alg_bytes / (dom["loop_ms"] * 1e-3) / 1e9, "frac_of_8TBps": alg_bytes / (dom["loop_ms"] * 1e-3) / HBM_PEAK,
                                  "note": "SURVEY 8(d)'s 28 n^2 bytes per target and iteration over the launch time: the speed-up over a dense implementation at peak, not a utilisation"},
             "note": "edge formulation: the state of a target is O(edges) and L2-resident; one workgroup per target walks ~8 dependent phases per iteration - "
-                    "latency-bound on ONE compute unit per target, the chip is filled by the targets of a batch"}
+                    "latency-bound on ONE compute unit per target, the chip is filled by the targets of a batch.  `achieved` prices EVERY edge of the stratum's "
+                    "sub-graphs at 108 bytes per iteration (3 passes x 16 B per directed entry + 60 B of per-edge planes): an UPPER bound on what the kernel moves "
+                    "(it iterates the entries within two hops of the target; the far edges run a closed recursion once), and those bytes come from L2 / LDS, not "
+                    "from HBM - `frac` is that bound over 8 TB/s, not an HBM utilisation; `traffic` (PMC) is not collected for this workload"}
     out = {"metric": "explained nodes/sec (300 mask-opt iters, k-hop subgraph) on a stratified sample of ALL nodes of BA-House x100k",
            "value": value, "unit": "explained nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

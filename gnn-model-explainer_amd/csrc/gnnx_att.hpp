@@ -53,31 +53,6 @@ __device__ __forceinline__ float att_sum32(float v) {
     return xor16_sum(v);      // (gfx950: a lane swap, not a ds_bpermute - gnnx_kernels.hpp)
 }
 
-// Round 6: the per-entry dot products with lane = ENTRY.  Until round 5 a half-wave took its chunk's entries one after the
-// other, lane = feature column, every product a 32-lane butterfly (4 DPP rotations + a lane swap + 5 adds, and a select to park the result in
-// the entry's lane): ~15 wave-instructions per entry, the instruction-throughput bound of the edge phases (DESIGN_HISTORY Part I, 4.6).  Here every
-// lane takes ONE entry of the chunk: it reads its column's row `row` (128-byte rows of the workspace: float4 loads) and runs the din-term
-// product itself, the row vector `vi` of the chunk's own row (lane = column in the half-wave) arriving by broadcast - din + din / 4 instructions
-// for all 32 entries of the chunk.  Terms in column order, one FMA chain (fixed order; columns beyond din are exact zeros on both sides).
-__device__ __forceinline__ float att_dot_lane_entry(const float* row, float vi, int hbase, int din) {
-    const f32x4* r4 = reinterpret_cast<const f32x4*>(row);
-    float sacc = 0.0f;
-    for (int q0 = 0; q0 < din; q0 += 16) {      // sixteen columns per trip: four loads in flight, sixteen broadcasts + FMAs (din <= 32: two trips)
-        f32x4 r[4];
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) r[qd] = r4[(q0 >> 2) + qd];      // (rows are FS = 32 floats: always in range)
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd)
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const int c = q0 + 4 * qd + cc;
-                const float vb = __shfl(vi, hbase | c);
-                sacc = fmaf((c < din) ? vb : 0.0f, r[qd][cc], sacc);
-            }
-    }
-    return sacc;
-}
-
 constexpr int ATT_THREADS = 1024;
 constexpr int ATT_UN = 8;    // edges whose row loads are in flight together in the gathers of k_att
 
@@ -92,8 +67,11 @@ constexpr int ATT_UN = 8;    // edges whose row loads are in flight together in 
 //  * CHUNKED ROWS.  The unit of work of an edge phase is a CHUNK of at most 32 entries of one row; the 8 chunks of a hub row go to 8
 //    half-waves.  A row of one chunk finishes as before; the partial sums of the others go through `pacc` and a second, short pass adds them in
 //    chunk order (fixed order: deterministic, batch-invariant) and runs the row-local part.
-// `order` (round 6): workgroup -> target, the targets by decreasing edge count - a batch of more targets than compute units (one 1024-thread
-// workgroup each) starts its longest chains first and fills the tail with the short ones (measured: 400 syn1 targets 56 -> see profiles/r06).
+// `order_wg` (round 6): workgroup -> target, the targets by decreasing edge count, so that a batch of more targets than compute units (one
+// 1024-thread workgroup each) starts its longest chains first.  Round 6 also measured three reformulations of this kernel and dropped them - none
+// moved the 58 ms of the 400-target syn1 batch: the per-entry dot products with lane = entry (din + din / 4 instead of ~15
+// wave-instructions per entry), the two gathered row arrays of every phase staged in LDS (n <= 448), and 512- / 256-thread workgroups (86 / 146 ms:
+// the batch's time is the n = 310 target's own chain, 193 us per iteration, and it scales with the half-waves that share its chunks).
 __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, const float* __restrict__ adam, const int32_t* __restrict__ order_wg = nullptr) {
     constexpr int NWV = ATT_THREADS / 64;
     __shared__ float sW[3][32 * 33], sWa[3][32 * 33], sb[3][32];
@@ -318,23 +296,26 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
                 const bool eon = ln < k.mine;
                 const int ck = eon ? (col[k.e0 + k.j0 + ln] & 0xffff) : 0;
                 const float cw = eon ? w[k.e0 + k.j0 + ln] : 0.0f;
-                // lane = entry: the attention value of this lane's entry, s_e = u_i . u_k (idle lanes read row 0 and carry weight 0)
-                const float cs = att_dot_lane_entry(ul + (size_t)ck * FS, ui, hbase, din);
-                const float coef = cw * cs;
-                float acc = 0.0f;
-                // lane = column: Z_i = sum_e (w_e s_e) Xin_k - ATT_UN entries per trip, their row loads (L2: the row arrays live in the workspace)
-                // issued before the first use; the products are taken in entry order
+                float cs = 0.0f, acc = 0.0f;
+                // ATT_UN edges per trip: the row loads of all of them (L2: the row arrays live in the workspace) are issued before the first
+                // butterfly, so an entry costs a fraction of one L2 round trip; the products are taken in entry order
                 for (int jj = 0; jj < k.cnt; jj += ATT_UN) {
                     int kk[ATT_UN];
-                    float xk[ATT_UN];
+                    float uk[ATT_UN], xk[ATT_UN];
 #pragma unroll
                     for (int u = 0; u < ATT_UN; ++u) kk[u] = __shfl(ck, hbase | ((jj + u < k.cnt) ? jj + u : jj));
 #pragma unroll
-                    for (int u = 0; u < ATT_UN; ++u) xk[u] = xin[(size_t)kk[u] * FS + ln];
+                    for (int u = 0; u < ATT_UN; ++u) {
+                        uk[u] = ul[(size_t)kk[u] * FS + ln];
+                        xk[u] = xin[(size_t)kk[u] * FS + ln];
+                    }
 #pragma unroll
                     for (int u = 0; u < ATT_UN; ++u)
-                        if (jj + u < k.cnt)      // uniform over the wave (cnt is)
-                            acc = fmaf(__shfl(coef, hbase | (jj + u)), xk[u], acc);
+                        if (jj + u < k.cnt) {     // uniform over the wave (cnt is)
+                            const float se = att_sum32(ui * uk[u]);
+                            acc = fmaf(__shfl(cw, hbase | (jj + u)) * se, xk[u], acc);
+                            cs = (jj + u == ln) ? se : cs;
+                        }
                 }
                 if (eon) sl[k.e0 + k.j0 + ln] = cs;
                 if (k.on && k.multi) pacc[(size_t)k.c * 32 + ln] = acc;
@@ -419,20 +400,24 @@ __global__ __launch_bounds__(ATT_THREADS) void k_att(Params p, AttScratch a, con
                 const float cw = eon ? w[e] : 0.0f;
                 const float cs = !eon ? 0.0f : inz ? sl[e] : kin ? sl[mir[e]] : 0.0f;
                 const float cc = kin ? cw * cs : 0.0f;
-                // lane = entry: g_e = dZ_i . Xin_k (a row without dZ skips the products: its g is zero) - uniform test per wave
-                float cg = 0.0f;
-                if (__ballot(inz) != 0ull) cg = att_dot_lane_entry(xin + (size_t)ck * FS, dzi, hbase, din);
-                float acc = 0.0f;
+                float cg = 0.0f, acc = 0.0f;
                 for (int jj = 0; jj < k.cnt; jj += ATT_UN) {
                     int kk[ATT_UN];
-                    float zk[ATT_UN];
+                    float xk[ATT_UN], zk[ATT_UN];
 #pragma unroll
                     for (int u = 0; u < ATT_UN; ++u) kk[u] = __shfl(ck, hbase | ((jj + u < k.cnt) ? jj + u : jj));
 #pragma unroll
-                    for (int u = 0; u < ATT_UN; ++u) zk[u] = dZ[(size_t)kk[u] * FS + ln];
+                    for (int u = 0; u < ATT_UN; ++u) {
+                        xk[u] = xin[(size_t)kk[u] * FS + ln];
+                        zk[u] = dZ[(size_t)kk[u] * FS + ln];
+                    }
 #pragma unroll
                     for (int u = 0; u < ATT_UN; ++u)
-                        if (jj + u < k.cnt) acc = fmaf(__shfl(cc, hbase | (jj + u)), zk[u], acc);
+                        if (jj + u < k.cnt) {
+                            const float g = att_sum32(dzi * xk[u]);
+                            acc = fmaf(__shfl(cc, hbase | (jj + u)), zk[u], acc);
+                            cg = (jj + u == ln) ? g : cg;
+                        }
                 }
                 if (eon) {
                     if (inz) dA[e] += cg * cs;
