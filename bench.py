@@ -438,11 +438,14 @@ def bench_ba100k_all(args, dev, log, dist, world, rank):
             alone_ms = (time.perf_counter() - t0) * 1e3
             st = dict(pipe1.stats[-1])
             reps = 6
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in pipe1.run([pick] * reps):
-                pass
-            piped_ms = (time.perf_counter() - t0) * 1e3 / reps
+            piped_all = []
+            for _rep in range(3):      # median of three 6-batch regions (single regions scatter by 2-4 x on a loaded host: profiles/r06_bench_ba100k_all_*.json)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in pipe1.run([pick] * reps):
+                    pass
+                piped_all.append((time.perf_counter() - t0) * 1e3 / reps)
+            piped_ms = float(np.median(piped_all))
             # the optimisation launch(es) of the batch alone, on resident inputs
             dn = engine.khop_device(graph, pick, 3)
             big = dn.sizes > pipe1.xl_min_n
@@ -463,20 +466,23 @@ def bench_ba100k_all(args, dev, log, dist, world, rank):
                         routes[str(int(k))] = int((r == k).sum())
                 job.launch(hy)
                 torch.cuda.synchronize()
-                job.reset_masks()
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                with torch.cuda.stream(job.stream):
-                    e0.record(job.stream)
-                    job.launch(hy)
-                    e1.record(job.stream)
-                torch.cuda.synchronize()
-                loop_ms += e0.elapsed_time(e1)
+                lm = []
+                for _rep in range(3):      # median of three launches on resident inputs
+                    job.reset_masks()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    with torch.cuda.stream(job.stream):
+                        e0.record(job.stream)
+                        job.launch(hy)
+                        e1.record(job.stream)
+                    torch.cuda.synchronize()
+                    lm.append(e0.elapsed_time(e1))
+                loop_ms += float(np.median(lm))
                 job.close()
                 del job
             per_stratum.append(dict(n_lo=lo, n_hi=hi, population=pop, sampled=int(len(pick)), n_mean=float(sizes[pick].mean()), n_max=int(sizes[pick].max()),
                                     sum_n2_population=float((sizes[(sizes > lo) & (sizes <= hi)].astype(np.float64) ** 2).sum()), routes=routes,
-                                    one_batch_alone_ms=alone_ms, pipelined_ms_per_batch=piped_ms, loop_ms=loop_ms,
+                                    one_batch_alone_ms=alone_ms, pipelined_ms_per_batch=piped_ms, pipelined_ms_per_batch_repetitions=[round(x, 2) for x in piped_all], loop_ms=loop_ms,
                                     stage_ms={k: round(float(v), 3) for k, v in st.items() if k.endswith("_ms")}, edges=int(em.eoff[-1])))
             log(f"stratum ({lo},{hi}]: {len(pick)} of {pop}: alone {alone_ms:.1f} ms, pipelined {piped_ms:.1f} ms per batch, loop {loop_ms:.1f} ms, routes {routes}")
         del pipe1

@@ -197,6 +197,34 @@ __device__ __forceinline__ void sparse_gather_dict(const float* sAb, const CT* s
     }
 }
 
+// ... and when the dictionary holds ONE row (every feature row of the sub-graph equals it bit for bit: the reference's synthetic datasets use constant
+// features, gengraph.py:60-61): neither the column of an entry nor its dictionary index nor the row are read - the lane keeps the row's columns in
+// registers.  The same products in the same order as sparse_gather_dict with every index 0, so the results are bit-identical (round 6).
+template <int NQ, int UN>
+__device__ __forceinline__ void sparse_gather_onerow(const float* sAb, const float (&x0)[2 * NQ], int W, int e0, int e1, int half, float (&acc)[NQ]) {
+    float full[2 * NQ];
+#pragma unroll
+    for (int c = 0; c < 2 * NQ; ++c) full[c] = 0.0f;
+#pragma unroll 1
+    for (int e = e0 + half; e < e1; e += 2 * UN) {
+        float a[UN];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) a[j] = sAb[(e + 2 * j < e1) ? e + 2 * j : e1 - 1];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const float aj = (e + 2 * j < e1) ? a[j] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 2 * NQ; ++c) full[c] = fmaf(aj, (W == 2 * NQ || c < W) ? x0[c] : 0.0f, full[c]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const float mine = half ? full[2 * q + 1] : full[2 * q];
+        const float owed = half ? full[2 * q] : full[2 * q + 1];
+        acc[q] += mine + __shfl_xor(owed, 32);
+    }
+}
+
 // first position in [lo, hi) of a sorted id array whose value is >= key
 template <class CT>
 __device__ __forceinline__ int lower_bound_ids(const CT* a, int lo, int hi, int key) {
@@ -808,8 +836,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
     __syncthreads();
     // ---------------- feature dictionary: the distinct rows of X, if there are at most SPL_XD_MAX (bit-exact comparison) ----------------
     bool xdict = have_xi;      // (uniform; XL without room for a byte per node: the feature rows come from L2)
+    int nd = 0;                // rows of the dictionary (uniform: every thread walks the same loop)
     if (have_xi) {
-        int nd = 0;
         for (;;) {
             if (tid == 0) s_misc[0] = 0x7fffffff;
             __syncthreads();
@@ -843,6 +871,8 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         }
     }
 
+    // one dictionary row = constant feature rows: layer 1's gather and the X part of dL/dAbar read no column, no index and no row (below)
+    const bool xone = xdict && nd == 1;
     if constexpr (XL)
         if (xl.clk && tid == 0) xl.clk[4 * t + 1] = wall_clock64();
     for (int iter = 0; iter < p.num_iters; ++iter) {
@@ -869,7 +899,12 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             float acc[DQ];
 #pragma unroll
             for (int q = 0; q < DQ; ++q) acc[q] = 0.0f;
-            if (xdict) sparse_gather_dict<DQ, (DQ <= 5 ? 8 : 2)>(sAb, scol, sXi, sXd, sS, D, SA.e0, SA.e1, h, acc);
+            if (xone) {
+                float x0[2 * DQ];
+#pragma unroll
+                for (int c = 0; c < 2 * DQ; ++c) x0[c] = sXd[c];      // (the dictionary's rows are padded to sS >= 2 DQ floats)
+                sparse_gather_onerow<DQ, (DQ <= 5 ? 8 : 2)>(sAb, x0, D, SA.e0, SA.e1, h, acc);
+            } else if (xdict) sparse_gather_dict<DQ, (DQ <= 5 ? 8 : 2)>(sAb, scol, sXi, sXd, sS, D, SA.e0, SA.e1, h, acc);
             else sparse_gather_rows<false, DQ, spl_gather_unroll(DQ)>(sAb, scol, gX, D, SA.e0, SA.e1, h, acc);
             sparse_combine<DQ>(acc, SA.rem, SA.wsplit);
 #pragma unroll
@@ -1089,6 +1124,21 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                     for (int c = 0; c < 2 * HQ; ++c) d2[c] = (inB && c < H) ? gdZ2[ri * FS + c] : 0.0f;
                     // PK entries per trip and lane: their X / U1 rows (L2) are all requested before the first product
                     constexpr int PK = EXACT ? 4 : 1;
+                    // One dictionary row: dZ1[i] . (X[j] * phi) is the SAME number for every entry of the row - formed once, with the two chains of
+                    // the general path (bit-identical); the entries of a row beyond t's neighbours (no dZ2 part: nearly all rows within two hops)
+                    // are a stream of stores that reads neither columns nor rows, the others continue the two sums with their dZ2 . relu(U1[j]) terms.
+                    float c0 = 0.0f, c1 = 0.0f;
+                    if (xone) {
+#pragma unroll
+                        for (int c = 0; c < 2 * DQ; c += 2) {
+                            c0 = fmaf(dz[c], (EXACT || c < D) ? sXd[c] : 0.0f, c0);
+                            c1 = fmaf(dz[c + 1], (EXACT || c + 1 < D) ? sXd[c + 1] : 0.0f, c1);
+                        }
+                    }
+                    if (xone && !inB) {
+                        const float g = c0 + c1;
+                        for (int e = SA.e0 + h; e < SA.e1; e += 2) gGe[e] = g;
+                    } else
                     for (int e = SA.e0 + h; e < SA.e1; e += 2 * PK) {
                         int jj[PK];
                         float s0[PK], s1[PK];
@@ -1098,7 +1148,13 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                             s0[k] = 0.0f;
                             s1[k] = 0.0f;
                         }
-                        if (xdict) {   // uniform: the feature rows come from the LDS dictionary
+                        if (xone) {    // uniform: the X part is the row's constant
+#pragma unroll
+                            for (int k = 0; k < PK; ++k) {
+                                s0[k] = c0;
+                                s1[k] = c1;
+                            }
+                        } else if (xdict) {   // uniform: the feature rows come from the LDS dictionary
 #pragma unroll
                             for (int k = 0; k < PK; ++k) {
                                 const float* x = sXd + (int)sXi[jj[k]] * sS;
