@@ -32,6 +32,10 @@ for step in "$@"; do
                    timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_d_$tag" -- $B > /dev/null 2> "$O/pmc_d_$tag.err")
                   python tools/pmc_summary.py "$O/pmc_summary_$tag.json" "$O/pmc_per_kernel_$tag.csv" "$O/pmc_a_$tag" "$O/pmc_b_$tag" "$O/pmc_c_$tag" "$O/pmc_d_$tag" | cut -c1-400
                   rm -rf "$O/pmc_a_$tag" "$O/pmc_b_$tag" "$O/pmc_c_$tag" "$O/pmc_d_$tag" "$O"/pmc_?_$tag.err ;;
+    dist)         # the sharded bench with N ranks SHARING this box's one GPU (gloo instead of RCCL for the gather): a functional run of the --gpus N path, not a scaling number.  arg = N[,bench flags]
+                  n=${arg%% *}; rest=""; [[ "$arg" == *" "* ]] && rest=${arg#* }
+                  GNNX_DIST_BACKEND=gloo timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus $n $rest > "$O/bench_sharded_${n}ranks_one_gpu_gloo.json" 2> "$O/bench_sharded_${n}ranks.err"
+                  tail -c 1800 "$O/bench_sharded_${n}ranks_one_gpu_gloo.json"; grep -v "amdgpu.ids" "$O/bench_sharded_${n}ranks.err" | tail -6 ;;
     py)           timeout 1500 python $arg 2>&1 | tail -30 ;;
     sh)           timeout 1500 bash $arg 2>&1 | tail -30 ;;
     *)            echo "unknown step $s" ;;
