@@ -665,14 +665,26 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             }
         }
     }
-    auto slot_of = [&](int set, int round) -> RowSlot {  // this lane's slot in the given round (256 slots per round)
+    // the slot record of a round as it lies in memory (slot_raw) and its decoding (slot_dec): the two long row loops of an iteration load the
+    // NEXT round's record while they work on the current one (round 6: the record is the head of every round's chain of dependent loads)
+    using SlotRaw = std::conditional_t<XL, SlotRecXL, SlotRec>;
+    auto slot_raw = [&](int set, int round) -> SlotRaw {
         const int sl = round * (NT / 2) + wave * TILE + li;
+        const int npad = set ? padB : padA;
+        SlotRaw rec;
+        if constexpr (XL) {
+            rec.row = rec.e0 = rec.info = rec.m0 = rec.m1 = 0u;
+            if (sl < npad) rec = srecx[(set ? padA : 0) + sl];
+        } else {
+            rec.x = rec.y = rec.m0 = rec.m1 = 0u;
+            if (sl < npad) rec = srec[(set ? padA : 0) + sl];
+        }
+        return rec;
+    };
+    auto slot_dec = [&](const SlotRaw& rec, int set, int round) -> RowSlot {  // this lane's slot in the given round (256 slots per round)
         const int npad = set ? padB : padA;
         RowSlot z;
         if constexpr (XL) {
-            SlotRecXL rec;
-            rec.row = rec.e0 = rec.info = rec.m0 = rec.m1 = 0u;
-            if (sl < npad) rec = srecx[(set ? padA : 0) + sl];
             z.row = (int)rec.row;
             z.nsplit = (rec.info >> 8) & 31u;
             z.wsplit = (rec.info >> 13) & 31u;
@@ -685,9 +697,6 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             z.e0 = (int)rec.e0;
             z.e1 = z.e0 + (int)(rec.info & 255u);
         } else {
-            SlotRec rec;
-            rec.x = rec.y = rec.m0 = rec.m1 = 0u;
-            if (sl < npad) rec = srec[(set ? padA : 0) + sl];
             z.row = rec.x & 32767u;
             z.nsplit = (rec.x >> 15) & 31u;
             z.wsplit = (rec.x >> 20) & 31u;
@@ -705,6 +714,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         if (z.wsplit == 0) z.wsplit = 1;
         return z;
     };
+    auto slot_of = [&](int set, int round) -> RowSlot { return slot_dec(slot_raw(set, round), set, round); };
     const int roundsA = (padA + NT / 2 - 1) / (NT / 2), roundsB = (padB + NT / 2 - 1) / (NT / 2);
     const float inv_n2 = 1.0f / ((float)n * (float)n);
     // ---------------- setup 4: the undirected edges, near ones (an endpoint within two hops) first; per-edge planes ----------------
@@ -891,8 +901,11 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         };
 
         // ======== layer 1 on the rows within two hops: Zraw = Abar . X (kept for the feature-mask gradient), U1 ========
+        SlotRaw nxA = slot_raw(0, 0);
         for (int round = 0; round < roundsA; ++round) {
-            const RowSlot SA = slot_of(0, round);
+            const SlotRaw curA = nxA;
+            if (round + 1 < roundsA) nxA = slot_raw(0, round + 1);      // (in flight during this round)
+            const RowSlot SA = slot_dec(curA, 0, round);
             if (!SA.wave_active) continue;  // uniform per wave
             const bool first = SA.first;
             const int r = first ? SA.row : 0;
@@ -1058,11 +1071,21 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             float dfq[DQ];
 #pragma unroll
             for (int q = 0; q < DQ; ++q) dfq[q] = 0.0f;
+            SlotRaw nxB = slot_raw(0, 0);
             for (int round = 0; round < roundsA; ++round) {
-                const RowSlot SA = slot_of(0, round);
+                const SlotRaw curB = nxB;
+                if (round + 1 < roundsA) nxB = slot_raw(0, round + 1);      // (in flight during this round)
+                const RowSlot SA = slot_dec(curB, 0, round);
                 if (!SA.wave_active) continue;
                 const bool first = SA.first;
                 const int r = first ? SA.row : 0;
+                // the row's own U1 and Zraw values (L2): requested at the top of the round, consumed behind the gather / the row-local part (round 6:
+                // they used to be two more dependent round trips in the middle of the round; wave-level fences keep the compiler from moving loads)
+                float u1r[HQ], zr[DQ];
+#pragma unroll
+                for (int q = 0; q < HQ; ++q) u1r[q] = (first && 2 * q + h < H) ? gU1[r * FS + 2 * q + h] : 0.0f;
+#pragma unroll
+                for (int q = 0; q < DQ; ++q) zr[q] = (first && 2 * q + h < D) ? gZraw[r * FS + 2 * q + h] : 0.0f;
                 float acc[HQ], uu[HQ];
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;
@@ -1100,7 +1123,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) {
                     const int c = 2 * q + h;
-                    const float u = (first && c < H) ? gU1[r * FS + c] : 0.0f;
+                    const float u = u1r[q];
                     float dx = acc[q];
                     if (first && r == tr && c < H) dx += sh.dEs[c];
                     acc[q] = (u > 0.0f) ? dx : 0.0f;
@@ -1111,7 +1134,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 wave_sync();
 #pragma unroll
                 for (int q = 0; q < DQ; ++q)
-                    if (first && 2 * q + h < D) dfq[q] = fmaf(stage[li * sS + 2 * q + h], gZraw[r * FS + 2 * q + h], dfq[q]);
+                    if (first && 2 * q + h < D) dfq[q] = fmaf(stage[li * sS + 2 * q + h], zr[q], dfq[q]);
                 if (SA.e0 < SA.e1) {
                     // dL/dAbar on this slot's entries, row side (see k_sparse_resident): G[i][j] = dZ1[i] . (X[j] * phi) +
                     // dZ2[i] . relu(U1[j]); the row's dZ1 sits in the staging tile at its FIRST slot's lane (same 16-lane group)
@@ -1214,9 +1237,11 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
         // ======== per near edge: G_ij + G_ji, regulariser gradients, Adam in place on both directed entries, next Abar ========
         const bool republish = iter + 1 < p.num_iters;  // the returned mask is the one of the LAST forward (explain.py:209-211)
         float ls_size = 0.0f, ls_ent = 0.0f, ls_lap = 0.0f, ls_den = 0.0f, ls_adj = 0.0f;   // LOG form: this thread's part of the logged sums (its near edges, both directions)
-        // two edges per trip: the planes come from L2, and the loads of the second edge are in flight while the first is updated
-        for (int k0 = tid; k0 < eupN; k0 += 2 * NT) {
-            constexpr int EU = 2;
+        // EU edges per trip: the planes come from L2, and the loads of the later edges are in flight while the first is updated.  Round 6: four instead of
+        // two - the phase is a quarter of an XL target's iteration (26 of 111 us at n = 17 k, tools/probe_xl_timeline.py) and is bound by those round
+        // trips; a thread visits its edges in the same order, every edge's arithmetic is its own: bit-identical.
+        constexpr int EU = 4;
+        for (int k0 = tid; k0 < eupN; k0 += EU * NT) {
             int kk[EU], cij[EU], cji[EU];
             bool on[EU];
             float w[EU], lap[EU], Mij[EU], Mji[EU], mij[EU], mji[EU], vij[EU], vji[EU], G[EU];
