@@ -42,7 +42,23 @@ src = src.replace(end_anchor, "        PROBE(%d);\n" % k + end_anchor, 1)
 capi = capi.replace('#include "../../include/gnnx.h"', '#include "../../../include/gnnx.h"')
 capi += '\nextern "C" int gnnx_probe_read(unsigned long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gnnx::g_probe), sizeof(unsigned long long) * n); }\n'
 # `--build`: cross-compile here (no GPU needed) into tools/_build_large/ - the .so travels with the gpurun snapshot
-tmp = os.path.join(ROOT, "tools", "_build", "xl_timeline")
+KO = os.environ.get("GNNX_PROBE_KO", "")      # timing-only knock-outs (WRONG results): "fwdstores", "gestores", "mfma" - which part of a round is the bound?
+if "fwdstores" in KO:
+    a = "sparse_forward_rowlocal<DQ>(acc, sW1, sh.bias[0], D, H, li, h, first, gU1 + r * FS,"
+    assert a in src
+    src = src.replace(a, "sparse_forward_rowlocal<DQ>(acc, sW1, sh.bias[0], D, H, li, h, first && p.num_iters < 0, gU1 + r * FS,")
+    a = "if (first && 2 * q + h < D) gZraw[r * FS + 2 * q + h] = acc[q];"
+    assert a in src
+    src = src.replace(a, "if (first && 2 * q + h < D && p.num_iters < 0) gZraw[r * FS + 2 * q + h] = acc[q];")
+if "gestores" in KO:
+    a = "for (int e = SA.e0 + h; e < SA.e1; e += 2) gGe[e] = g;"
+    assert a in src
+    src = src.replace(a, "if (p.num_iters < 0) for (int e = SA.e0 + h; e < SA.e1; e += 2) gGe[e] = g;")
+if "bwdloads" in KO:
+    a = "u1r[q] = (first && 2 * q + h < H) ? gU1[r * FS + 2 * q + h] : 0.0f;"
+    assert a in src
+    src = src.replace(a, "u1r[q] = (first && 2 * q + h < H && p.num_iters < 0) ? gU1[r * FS + 2 * q + h] : 0.25f;")
+tmp = os.path.join(ROOT, "tools", "_build", "xl_timeline" + ("_" + KO if KO else ""))
 os.makedirs(tmp, exist_ok=True)
 so = os.path.join(tmp, "libprobe.so")
 srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".hip"))]
