@@ -276,9 +276,13 @@ __device__ __forceinline__ void sparse_gather_const(const float* sAb, const floa
 // forward row-local part for the lane's row: Y^T[c][r] = sum_k W[k][c] Z[r][k] on MFMA (the lane's registers zq[u] =
 // Z[r][2u + half] are the B operand of step u), + bias, L2 normalisation; U -> sU[r][c], norm -> srn[r].
 // DOUT_C = dout when it is known at compile time (the column predicates of the epilogue fold away), else 0.
-template <int NQ, int DOUT_C>
+// VEC4 (round 6, k_sparse_large: the row array lives in global memory, rows of FS = 32 floats, 128-byte aligned): the accumulator registers 4j .. 4j + 3 of
+// a lane are the four CONSECUTIVE columns 8j + 4h .. + 3, so the row is stored as 16-byte vectors - three / two stores per lane for 20 columns instead of ten
+// (the scattered dword stores of U1 and Zraw were 47 % of the large-target kernel's layer-1 loop: tools/probe_xl_timeline.py, knock-outs).  Same values.
+template <int NQ, int DOUT_C, bool VEC4 = false>
 __device__ __forceinline__ void sparse_forward_rowlocal_impl(const float (&zq)[NQ], const float* sW, const float* bias, int din,
                                                              int dout_rt, int li, int h, bool store, float* sUrow, float* srn_r) {
+    static_assert(!VEC4 || (DOUT_C > 0 && DOUT_C % 4 == 0), "vector stores: a compile-time width, a multiple of four");
     const int dout = DOUT_C ? DOUT_C : dout_rt;
     float bv[16];  // bias of this lane's 16 columns: loaded before the MFMA chain, consumed after it
 #pragma unroll
@@ -304,13 +308,37 @@ __device__ __forceinline__ void sparse_forward_rowlocal_impl(const float (&zq)[N
     ss = xor32_sum(ss);
     const float rnorm = fmaxf(sqrt_(ss), 1e-12f);
     const float rinv = rcp_(rnorm);
+    if constexpr (VEC4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (8 * j >= DOUT_C) continue;              // no lane holds a real column in this group
+            const int base = 8 * j + 4 * h;
+            f32x4 v = {c16[4 * j] * rinv, c16[4 * j + 1] * rinv, c16[4 * j + 2] * rinv, c16[4 * j + 3] * rinv};
+            if (store && base < DOUT_C) *reinterpret_cast<f32x4*>(sUrow + base) = v;
+        }
+    } else {
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
         const int c = acc_row(g, h);
         if (DOUT_C && (g & 3) + 8 * (g >> 2) >= DOUT_C) continue;  // no lane of this register holds a real column
         if (store && c < dout) sUrow[c] = c16[g] * rinv;
     }
+    }
     if (store && h == 0) *srn_r = rnorm;
+}
+
+// the same for a row in global memory (16-byte aligned, FS floats): vector stores at the reference's width
+template <int NQ>
+__device__ __forceinline__ void sparse_forward_rowlocal_global(const float (&zq)[NQ], const float* sW, const float* bias, int din,
+                                                               int dout, int li, int h, bool store, float* gUrow, float* srn_r) {
+    if (dout == 20)
+        sparse_forward_rowlocal_impl<NQ, 20, true>(zq, sW, bias, din, dout, li, h, store, gUrow, srn_r);
+    else if (dout == 16)
+        sparse_forward_rowlocal_impl<NQ, 16, true>(zq, sW, bias, din, dout, li, h, store, gUrow, srn_r);
+    else if (dout == 32)
+        sparse_forward_rowlocal_impl<NQ, 32, true>(zq, sW, bias, din, dout, li, h, store, gUrow, srn_r);
+    else
+        sparse_forward_rowlocal_impl<NQ, 0>(zq, sW, bias, din, dout, li, h, store, gUrow, srn_r);
 }
 
 template <int NQ>

@@ -920,12 +920,21 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             } else if (xdict) sparse_gather_dict<DQ, (DQ <= 5 ? 8 : 2)>(sAb, scol, sXi, sXd, sS, D, SA.e0, SA.e1, h, acc);
             else sparse_gather_rows<false, DQ, spl_gather_unroll(DQ)>(sAb, scol, gX, D, SA.e0, SA.e1, h, acc);
             sparse_combine<DQ>(acc, SA.rem, SA.wsplit);
+            // Zraw for the feature-mask gradient: read back by the SAME lane in the backward, so every lane keeps its DQ values side by side (columns
+            // 16 h + q of the row: a 16-byte vector per four values instead of DQ scattered dwords - round 6)
+            static_assert(DQ <= 16, "Zraw: two lanes' values per 32-float row");
+            if (first) {
 #pragma unroll
-            for (int q = 0; q < DQ; ++q) {
-                if (first && 2 * q + h < D) gZraw[r * FS + 2 * q + h] = acc[q];  // for the feature-mask gradient
-                acc[q] = (first && 2 * q + h < D) ? acc[q] * sh.phi[2 * q + h] : 0.0f;
+                for (int q4 = 0; q4 + 3 < DQ; q4 += 4) {
+                    f32x4 v = {acc[q4], acc[q4 + 1], acc[q4 + 2], acc[q4 + 3]};
+                    *reinterpret_cast<f32x4*>(gZraw + r * FS + 16 * h + q4) = v;
+                }
+#pragma unroll
+                for (int q = DQ & ~3; q < DQ; ++q) gZraw[r * FS + 16 * h + q] = acc[q];
             }
-            sparse_forward_rowlocal<DQ>(acc, sW1, sh.bias[0], D, H, li, h, first, gU1 + r * FS,
+#pragma unroll
+            for (int q = 0; q < DQ; ++q) acc[q] = (first && 2 * q + h < D) ? acc[q] * sh.phi[2 * q + h] : 0.0f;
+            sparse_forward_rowlocal_global<DQ>(acc, sW1, sh.bias[0], D, H, li, h, first, gU1 + r * FS,
                                         sRn1 + round * (NT / 2) + wave * TILE + li);
         }
         __syncthreads();
@@ -948,7 +957,7 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
             sparse_combine<HQ>(acc, SB.rem, SB.wsplit);
 #pragma unroll
             for (int q = 0; q < HQ; ++q) acc[q] = first ? acc[q] : 0.0f;
-            sparse_forward_rowlocal<HQ>(acc, sW2, sh.bias[1], H, H, li, h, first, gU2 + r * FS,
+            sparse_forward_rowlocal_global<HQ>(acc, sW2, sh.bias[1], H, H, li, h, first, gU2 + r * FS,
                                         sRn2 + round * (NT / 2) + wave * TILE + li);
         }
         __syncthreads();
@@ -1082,10 +1091,22 @@ __global__ __launch_bounds__(SPL_THREADS) void k_sparse_large(Params p, const in
                 // the row's own U1 and Zraw values (L2): requested at the top of the round, consumed behind the gather / the row-local part (round 6:
                 // they used to be two more dependent round trips in the middle of the round; wave-level fences keep the compiler from moving loads)
                 float u1r[HQ], zr[DQ];
+                {   // the whole row as 16-byte vectors (both lanes of the slot), this lane's columns 2q + h picked from them: half the load instructions
+                    constexpr int NV = (2 * HQ + 3) / 4;
+                    f32x4 v[NV];
 #pragma unroll
-                for (int q = 0; q < HQ; ++q) u1r[q] = (first && 2 * q + h < H) ? gU1[r * FS + 2 * q + h] : 0.0f;
+                    for (int k = 0; k < NV; ++k) v[k] = *reinterpret_cast<const f32x4*>(gU1 + r * FS + 4 * k);
 #pragma unroll
-                for (int q = 0; q < DQ; ++q) zr[q] = (first && 2 * q + h < D) ? gZraw[r * FS + 2 * q + h] : 0.0f;
+                    for (int q = 0; q < HQ; ++q) {
+                        const float ve = v[(2 * q) >> 2][(2 * q) & 3], vo = v[(2 * q + 1) >> 2][(2 * q + 1) & 3];
+                        u1r[q] = (first && 2 * q + h < H) ? (h ? vo : ve) : 0.0f;
+                    }
+                    f32x4 zv[(DQ + 3) / 4];      // Zraw: this lane's own values (layout: see layer 1)
+#pragma unroll
+                    for (int k = 0; k < (DQ + 3) / 4; ++k) zv[k] = *reinterpret_cast<const f32x4*>(gZraw + r * FS + 16 * h + 4 * k);
+#pragma unroll
+                    for (int q = 0; q < DQ; ++q) zr[q] = (first && 2 * q + h < D) ? zv[q >> 2][q & 3] : 0.0f;
+                }
                 float acc[HQ], uu[HQ];
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) acc[q] = 0.0f;

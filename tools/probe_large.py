@@ -29,8 +29,8 @@ for k, a in enumerate(anchors):
 k = len(anchors)
 # finer stamps inside layer 1 (wave 0's view): after the slot record, the gather, the combine, the row-local part
 fine = [("            const bool first = SA.first;\n            const int r = first ? SA.row : 0;\n            float acc[DQ];", 27),
-        ("            sparse_combine<DQ>(acc, SA.rem, SA.wsplit);\n#pragma unroll\n            for (int q = 0; q < DQ; ++q) {\n                if (first && 2 * q + h < D) gZraw", 28),
-        ("            sparse_forward_rowlocal<DQ>(acc, sW1, sh.bias[0]", 29)]
+        ("            sparse_combine<DQ>(acc, SA.rem, SA.wsplit);\n            // Zraw for the feature-mask gradient", 28),
+        ("            sparse_forward_rowlocal_global<DQ>(acc, sW1, sh.bias[0]", 29)]
 for mark, idx in fine:
     assert mark in src, mark
     src = src.replace(mark, "            PROBE(%d);\n" % idx + mark, 1)

@@ -31,8 +31,8 @@ for k, a in enumerate(anchors):
 k = len(anchors)
 # finer stamps inside layer 1 (wave 0's view): after the slot record, the gather, the combine, the row-local part
 fine = [("            const bool first = SA.first;\n            const int r = first ? SA.row : 0;\n            float acc[DQ];", 27),
-        ("            sparse_combine<DQ>(acc, SA.rem, SA.wsplit);\n#pragma unroll\n            for (int q = 0; q < DQ; ++q) {\n                if (first && 2 * q + h < D) gZraw", 28),
-        ("            sparse_forward_rowlocal<DQ>(acc, sW1, sh.bias[0]", 29)]
+        ("            sparse_combine<DQ>(acc, SA.rem, SA.wsplit);\n            // Zraw for the feature-mask gradient", 28),
+        ("            sparse_forward_rowlocal_global<DQ>(acc, sW1, sh.bias[0]", 29)]
 for mark, idx in fine:
     assert mark in src, mark
     src = src.replace(mark, "            PROBE(%d);\n" % idx + mark, 1)
@@ -44,20 +44,20 @@ capi += '\nextern "C" int gnnx_probe_read(unsigned long long* out, int n) { retu
 # `--build`: cross-compile here (no GPU needed) into tools/_build_large/ - the .so travels with the gpurun snapshot
 KO = os.environ.get("GNNX_PROBE_KO", "")      # timing-only knock-outs (WRONG results): "fwdstores", "gestores", "mfma" - which part of a round is the bound?
 if "fwdstores" in KO:
-    a = "sparse_forward_rowlocal<DQ>(acc, sW1, sh.bias[0], D, H, li, h, first, gU1 + r * FS,"
+    a = "sparse_forward_rowlocal_global<DQ>(acc, sW1, sh.bias[0], D, H, li, h, first, gU1 + r * FS,"
     assert a in src
-    src = src.replace(a, "sparse_forward_rowlocal<DQ>(acc, sW1, sh.bias[0], D, H, li, h, first && p.num_iters < 0, gU1 + r * FS,")
-    a = "if (first && 2 * q + h < D) gZraw[r * FS + 2 * q + h] = acc[q];"
+    src = src.replace(a, "sparse_forward_rowlocal_global<DQ>(acc, sW1, sh.bias[0], D, H, li, h, first && p.num_iters < 0, gU1 + r * FS,")
+    a = "            if (first) {\n#pragma unroll\n                for (int q4 = 0; q4 + 3 < DQ; q4 += 4) {"
     assert a in src
-    src = src.replace(a, "if (first && 2 * q + h < D && p.num_iters < 0) gZraw[r * FS + 2 * q + h] = acc[q];")
+    src = src.replace(a, a.replace("if (first) {", "if (first && p.num_iters < 0) {"))
 if "gestores" in KO:
     a = "for (int e = SA.e0 + h; e < SA.e1; e += 2) gGe[e] = g;"
     assert a in src
     src = src.replace(a, "if (p.num_iters < 0) for (int e = SA.e0 + h; e < SA.e1; e += 2) gGe[e] = g;")
 if "bwdloads" in KO:
-    a = "u1r[q] = (first && 2 * q + h < H) ? gU1[r * FS + 2 * q + h] : 0.0f;"
+    a = "for (int k = 0; k < NV; ++k) v[k] = *reinterpret_cast<const f32x4*>(gU1 + r * FS + 4 * k);"
     assert a in src
-    src = src.replace(a, "u1r[q] = (first && 2 * q + h < H && p.num_iters < 0) ? gU1[r * FS + 2 * q + h] : 0.25f;")
+    src = src.replace(a, "for (int k = 0; k < NV; ++k) v[k] = (p.num_iters < 0) ? *reinterpret_cast<const f32x4*>(gU1 + r * FS + 4 * k) : f32x4{0.25f, 0.25f, 0.25f, 0.25f};")
 tmp = os.path.join(ROOT, "tools", "_build", "xl_timeline" + ("_" + KO if KO else ""))
 os.makedirs(tmp, exist_ok=True)
 so = os.path.join(tmp, "libprobe.so")
