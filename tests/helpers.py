@@ -46,8 +46,11 @@ def dense_from_edges(n, rc, vals):
 # Targets whose optimisation crosses a loss plateau: fp32 round-off of any re-ordering is amplified (shown on the
 # CPU alone by tests/test_oracle_golden.py::test_ill_conditioned_targets_amplify_roundoff_even_on_cpu).
 ILL_CONDITIONED = {"syn5": (511, 1000, 1230)}
-ILL_TOL_MASK = 5e-4     # measured CPU-vs-CPU: up to 7.3e-5
-ILL_TOL_FEAT = 5e-2     # measured CPU-vs-CPU: up to 5.5e-3, GPU-vs-reference: up to 2.0e-2 (one entry of target 1230)
+# (round 6: these two bound the CPU-vs-CPU amplification test of tests/test_oracle_golden.py only.  The GPU outcome tests no longer hold the three targets to
+#  any number at the 300-epoch horizon - two CPU implementations differ by 5.5e-3 there, so no outcome bound says anything about a kernel; they are REPORTED, and gated
+#  like every target where a bound means something: every 50- / 10-epoch window of them against the reference's own state, tests/test_decision_parity.py.)
+ILL_TOL_MASK = 5e-4     # measured CPU-vs-CPU: up to 7.3e-5 (the GPU outcome tests keep this one on the masked adjacency)
+ILL_TOL_FEAT = 1e-2     # measured CPU-vs-CPU: up to 5.5e-3
 
 
 def random_model(rng, D, H, O, C):
