@@ -37,7 +37,7 @@ class _Prepared:
 
 class BatchPipeline:
     def __init__(self, graph, state_dict, labels, hyper, n_hops=3, seed_base=1000, rng_threads=None, depth=None, prepare_workers=2, reserve_cus=0, lib=None,
-                 device_hook=None, rng_threads_big=None, edge_draw=None, edge_draw_min_values=2e7, device_walk=None, xl_min_n=None, xl_device_walk=None):
+                 device_hook=None, rng_threads_big=None, edge_draw=None, edge_draw_min_values=0.0, device_walk=None, xl_min_n=None, xl_device_walk=None):
         """graph: engine.DeviceGraph (resident); labels [N]: the label the prediction loss uses (explain.py:750-753); the initial
         mask of target v is drawn from a generator seeded with seed_base + v (the seed protocol of the golden runs)."""
         self.graph, self.sd, self.labels, self.hyper = graph, state_dict, np.asarray(labels), hyper
@@ -62,7 +62,10 @@ class BatchPipeline:
         # container (profiles/r04_host_rng_edges_blocks.txt), bit-identical - ON by default; edge_draw=False / GNNX_PIPE_EDGE_DRAW=0 restores the
         # full stream.
         self.edge_draw = bool(int(os.environ.get("GNNX_PIPE_EDGE_DRAW", "1"))) if edge_draw is None else bool(edge_draw)
-        self.edge_draw_min_values = float(edge_draw_min_values)      # batches of fewer normals keep the full draw (it overlaps the plan; syn1: 0.5 ms)
+        self.edge_draw_min_values = float(os.environ.get("GNNX_PIPE_EDGE_MIN", edge_draw_min_values))      # batches of fewer normals keep the full draw.  Round 6: 0 (was 2e7) - the edge draw
+        # for small batches too: a syn1 batch's full draw is 2 M normals = 8 core-ms and 8 MB across PCIe for 45 KB of edge entries; A/B of the driver's command, three
+        # alternating pairs: 267.1 / 237.9 / 267.4 k with the full draw, 275.2 / 266.2 / 271.1 k with the edge draw, host core-seconds per batch 0.0083 -> 0.0069
+        # (tools/r6_edge_min_ab.sh).  Bit-identical masks (tests/test_pipeline.py).
         self.rng_threads_edges = int(os.environ.get("GNNX_PIPE_EDGE_THREADS", self.rng_threads_big))   # (the ranks of a node share its cores: the sharded bench passes its share)
         # Round 5: the engine of the edge draw walks on the DEVICE (gnnx_mt_edge_words: every target's mt19937 stream as raw state words, the two
         # words of each entry's Box-Muller pair gathered, 16 bytes per directed entry to the host) and the host only lets ATen transform those
